@@ -1,0 +1,200 @@
+"""Molecular-hypergraph batch container, collate rule and synthetic generator.
+
+The hot path consumes a PyG ``Batch`` of ``HData`` objects
+(reference: equihgnn/data/utils.py:150-178).  PyG is not part of this image, so
+this module carries the few fields the path reads, with the reference's batching
+rule (``HData.__inc__``: ``edge_index0`` is offset by the number of nodes and
+``edge_index1`` by ``n_e``, data/utils.py:172-178).  A real PyG ``Batch`` exposes
+the same attribute names, so the model classes accept either.
+
+Field layout (all row-major, on one device):
+    x           [N, 9]  int64   ogb atom features
+    pos         [N, 3]  float32 coordinates
+    edge_index0 [nnz]   int64   node id of every incidence
+    edge_index1 [nnz]   int64   hyperedge id of every incidence
+    edge_attr   [M, 1]  int64   bond type 0-4, 5 = conjugated group
+    n_e         [B]     int64   hyperedges per molecule
+    e_order     [M]     int64   nodes per hyperedge
+    batch       [N]     int64   molecule id per node (sorted)
+    y           [B]     float32 regression target
+
+The synthetic generator follows SURVEY.md §8(d): random spanning-tree molecules
+with a few ring-closing bonds, at most one conjugated hyperedge, incidences in
+the reference's order (data/utils.py:123-145: two incidences per bond, bond
+hyperedges first, conjugated-group incidences after, in atom order).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+# ogb 1.3.6 full_atom_feature_dims (ogb/utils/features.py), used by AtomEncoder.
+ATOM_FEATURE_DIMS = (119, 5, 12, 12, 10, 6, 6, 2, 2)
+NUM_BOND_TYPES = 6  # 0-4 bond types + 5 = conjugated hyperedge (data/utils.py:129-145)
+
+# (mean atoms, std, max atoms, P(conjugated hyperedge)) per dataset flavour, SURVEY §8(d)
+FLAVOURS = {
+    "qm9": (18.0, 3.0, 29, 0.3),
+    "pcqm": (30.0, 7.0, 60, 0.8),
+}
+
+
+@dataclass
+class HBatch:
+    x: torch.Tensor
+    pos: torch.Tensor
+    edge_index0: torch.Tensor
+    edge_index1: torch.Tensor
+    edge_attr: torch.Tensor
+    n_e: torch.Tensor
+    e_order: torch.Tensor
+    batch: torch.Tensor
+    y: torch.Tensor
+    # host-side sizes, kept so the GPU path never needs a device sync to learn them
+    num_nodes: int = 0
+    num_hyperedges: int = 0
+    num_graphs: int = 0
+
+    def to(self, device, non_blocking: bool = False) -> "HBatch":
+        kw = {}
+        for f in fields(self):
+            v = getattr(self, f.name)
+            kw[f.name] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
+        return HBatch(**kw)
+
+    def pin_memory(self) -> "HBatch":
+        kw = {}
+        for f in fields(self):
+            v = getattr(self, f.name)
+            kw[f.name] = v.pin_memory() if torch.is_tensor(v) else v
+        return HBatch(**kw)
+
+    @property
+    def nnz(self) -> int:
+        return int(self.edge_index0.shape[0])
+
+
+@dataclass
+class HMol:
+    """One molecule before batching (the HData fields the path reads)."""
+
+    x: np.ndarray            # [n, 9] int64
+    pos: np.ndarray          # [n, 3] float32
+    edge_index0: np.ndarray  # [nnz] int64, local node ids
+    edge_index1: np.ndarray  # [nnz] int64, local hyperedge ids
+    edge_attr: np.ndarray    # [m, 1] int64
+    e_order: np.ndarray      # [m] int64
+    y: float
+
+
+def collate(mols: Sequence[HMol]) -> HBatch:
+    """PyG ``Batch.from_data_list`` restricted to HData's fields.
+
+    Offsets follow ``HData.__inc__`` (data/utils.py:172-178): node ids shift by the
+    running node count, hyperedge ids by the running ``n_e``.
+    """
+    xs, ps, v, e, ea, eo, bt, ys, ne = [], [], [], [], [], [], [], [], []
+    n_off = 0
+    m_off = 0
+    for b, mol in enumerate(mols):
+        n = mol.x.shape[0]
+        m = mol.edge_attr.shape[0]
+        xs.append(mol.x)
+        ps.append(mol.pos)
+        v.append(mol.edge_index0 + n_off)
+        e.append(mol.edge_index1 + m_off)
+        ea.append(mol.edge_attr)
+        eo.append(mol.e_order)
+        bt.append(np.full((n,), b, dtype=np.int64))
+        ys.append(mol.y)
+        ne.append(m)
+        n_off += n
+        m_off += m
+    return HBatch(
+        x=torch.from_numpy(np.concatenate(xs, 0).astype(np.int64)),
+        pos=torch.from_numpy(np.concatenate(ps, 0).astype(np.float32)),
+        edge_index0=torch.from_numpy(np.concatenate(v, 0).astype(np.int64)),
+        edge_index1=torch.from_numpy(np.concatenate(e, 0).astype(np.int64)),
+        edge_attr=torch.from_numpy(np.concatenate(ea, 0).astype(np.int64)),
+        n_e=torch.tensor(ne, dtype=torch.int64),
+        e_order=torch.from_numpy(np.concatenate(eo, 0).astype(np.int64)),
+        batch=torch.from_numpy(np.concatenate(bt, 0)),
+        y=torch.tensor(ys, dtype=torch.float32),
+        num_nodes=n_off,
+        num_hyperedges=m_off,
+        num_graphs=len(mols),
+    )
+
+
+def synth_molecule(rng: np.random.Generator, flavour: str = "qm9",
+                   n_atoms: Optional[int] = None, force_conj: Optional[bool] = None) -> HMol:
+    mu, sigma, n_max, p_conj = FLAVOURS[flavour]
+    if n_atoms is None:
+        n = int(np.clip(np.rint(rng.normal(mu, sigma)), 3, n_max))
+    else:
+        n = int(n_atoms)
+    x = np.stack([rng.integers(0, d, size=n) for d in ATOM_FEATURE_DIMS], axis=1).astype(np.int64)
+
+    # bonds: random spanning tree + a few ring-closing bonds
+    bonds = []
+    parent = np.zeros(n, dtype=np.int64)
+    for a in range(1, n):
+        p = int(rng.integers(0, a))
+        parent[a] = p
+        bonds.append((p, a))
+    have = set(bonds)
+    for _ in range(int(np.rint(0.08 * n))):
+        a, b = sorted(int(t) for t in rng.choice(n, size=2, replace=False))
+        if (a, b) not in have:
+            have.add((a, b))
+            bonds.append((a, b))
+    nb = len(bonds)
+    v = np.empty(2 * nb, dtype=np.int64)
+    e = np.empty(2 * nb, dtype=np.int64)
+    for i, (a, b) in enumerate(bonds):
+        v[2 * i], v[2 * i + 1] = a, b
+        e[2 * i] = e[2 * i + 1] = i
+    edge_attr = rng.integers(0, 4, size=(nb, 1)).astype(np.int64)
+    e_order = np.full((nb,), 2, dtype=np.int64)
+
+    conj = (rng.random() < p_conj) if force_conj is None else force_conj
+    if conj and n >= 3:
+        k = int(rng.integers(3, min(8, n) + 1))
+        v = np.concatenate([v, np.arange(k, dtype=np.int64)])
+        e = np.concatenate([e, np.full((k,), nb, dtype=np.int64)])
+        edge_attr = np.concatenate([edge_attr, np.full((1, 1), 5, dtype=np.int64)], 0)
+        e_order = np.concatenate([e_order, np.array([k], dtype=np.int64)])
+
+    # coordinates: chain growth along the spanning tree, then centred
+    pos = np.zeros((n, 3), dtype=np.float64)
+    for a in range(1, n):
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        pos[a] = pos[parent[a]] + 1.4 * u
+    pos -= pos.mean(0, keepdims=True)
+    return HMol(x=x, pos=pos.astype(np.float32), edge_index0=v, edge_index1=e,
+                edge_attr=edge_attr, e_order=e_order, y=float(rng.normal()))
+
+
+def synth_batch(batch_size: int, seed: int, flavour: str = "qm9") -> HBatch:
+    """Seeded synthetic batch.  Pure host code, deterministic per seed."""
+    rng = np.random.default_rng(seed)
+    return collate([synth_molecule(rng, flavour) for _ in range(batch_size)])
+
+
+def shard_indices(n_items: int, rank: int, world_size: int, seed: int, epoch: int = 0,
+                  shuffle: bool = True) -> List[int]:
+    """DistributedSampler semantics (the Lightning default the reference relies on,
+    main.py:271-283): a shared shuffled permutation, padded to a multiple of the world
+    size, strided by rank."""
+    if shuffle:
+        g = np.random.default_rng(seed + epoch)
+        perm = g.permutation(n_items).tolist()
+    else:
+        perm = list(range(n_items))
+    total = -(-n_items // world_size) * world_size
+    perm += perm[: total - n_items]
+    return perm[rank:total:world_size]

@@ -1,0 +1,93 @@
+"""The oracle (oracle/ref_models.py) against the golden vectors captured from the reference
+itself (tests/golden/make_golden.py).  CPU only.  Tolerance: 1e-5 absolute on O(1) outputs
+(BASELINE.json north_star), gradients 1e-5 relative to the largest gradient entry."""
+import numpy as np
+import pytest
+import torch
+
+from common import batch_from_case, fill_state_dict, golden_args, load_case
+
+from oracle import ref_models
+
+TOL = 1e-5
+
+CASES = ["mhnnm_c64_train", "mhnnm_c64_eval", "mhnnm_c256_train",
+         "egnn_equihnns_c64", "egnn_equihnns_c64_b", "egnn_equihnns_c256"]
+
+
+def build(case, models=ref_models.MODELS):
+    method = str(case["meta_method"])
+    model = models[method](1, golden_args(method, int(case["meta_hidden"])))
+    fill_state_dict(model, int(case["meta_seed"]))
+    model.train(bool(int(case["meta_train"])))
+    return model
+
+
+def check_against_case(model, case, data, tol=TOL, taps=True):
+    tp = {} if taps else None
+    out = model(data, taps=tp) if taps else model(data)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), case["out"], atol=tol, rtol=0)
+    if taps:
+        for k, v in tp.items():
+            key = "tap_" + k
+            if key in case:
+                ref = case[key]
+                got = v.detach().cpu().numpy().reshape(ref.shape)
+                scale = max(1.0, float(np.abs(ref).max()))
+                np.testing.assert_allclose(got, ref, atol=tol * scale, rtol=0, err_msg=k)
+    loss = torch.nn.functional.mse_loss(out, data.y)
+    np.testing.assert_allclose(float(loss.detach()), float(case["loss"]), atol=tol * max(1.0, float(case["loss"])))
+    loss.backward()
+    names = [str(n) for n in case["grad_names"]]
+    present = case["grad_present"]
+    stats = case["grad_stats"]
+    params = dict(model.named_parameters())
+    assert sorted(params) == sorted(names)
+    # gradients that are analytically zero (e.g. a bias in front of a train-mode BatchNorm) are
+    # rounding noise on both sides: floor every tolerance at 1e-3 of the largest gradient norm
+    floor = 1e-3 * float(np.max(stats[:, 2]))
+    for n, has, st in zip(names, present, stats):
+        g = params[n].grad
+        if not has:
+            assert g is None or float(g.abs().max()) == 0.0, f"{n}: reference leaves grad None"
+            continue
+        assert g is not None, f"{n}: reference has a gradient"
+        g = g.detach().cpu()
+        if "grad_" + n in case:
+            ref = case["grad_" + n]
+            scale = max(floor, float(np.abs(ref).max()))
+            np.testing.assert_allclose(g.numpy(), ref, atol=10 * tol * scale, rtol=0, err_msg=n)
+        else:
+            ref = case["gradhead_" + n]
+            scale = max(floor, float(st[2]))
+            np.testing.assert_allclose(g.reshape(-1)[: ref.size].numpy(), ref, atol=10 * tol * scale,
+                                       rtol=0, err_msg=n)
+            np.testing.assert_allclose(float(g.norm()), st[2], rtol=1e-4, atol=10 * tol * floor, err_msg=n)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference(name):
+    case = load_case(name)
+    model = build(case)
+    data = batch_from_case(case)
+    check_against_case(model, case, data)
+    if "knn_idx" in case:
+        d2, idx = ref_models.knn_self_included(data.pos, 16)
+        assert np.array_equal(np.sort(idx.numpy(), -1), np.sort(case["knn_idx"], -1))
+
+
+def test_state_dict_names_match_reference():
+    """grad_names in the fixture are the reference's named_parameters()."""
+    for name in ("mhnnm_c64_train", "egnn_equihnns_c64"):
+        case = load_case(name)
+        model = build(case)
+        assert [n for n, _ in model.named_parameters()] == [str(n) for n in case["grad_names"]]
+
+
+def test_bn_running_stats_update():
+    case = load_case("mhnnm_c64_train")
+    model = build(case)
+    model(batch_from_case(case))
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            np.testing.assert_allclose(v.numpy(), case["buf_" + k], atol=1e-5, rtol=1e-5)
