@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py — training molecules/s of the egnn_equihnns hot path on synthetic QM9-like batches.
+
+    python bench.py --gpus N --steps K --warmup W           (N=1 default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + MSE + backward + gradient all-reduce (RCCL) + Adam on ONE batch per rank
+(BASELINE.json configs[1]: QM9-like, --method egnn_equihnns, batch 256 per rank, hidden 256 —
+scripts/run_qm9_3d.sh hyper-parameters).  Batches are pre-collated and resident in HBM before
+the timed region; the per-batch index build (CSR sort, kNN) is INSIDE the step.  Prints ONE
+JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--method", default="egnn_equihnns")
+    p.add_argument("--batch", type=int, default=256, help="molecules per rank per step")
+    p.add_argument("--flavour", default="qm9")
+    p.add_argument("--pool", type=int, default=8, help="distinct pre-collated batches per rank")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def seg_reduce_bytes(nnz, n_out, C, has_idx, has_ptr, has_w, n_src):
+    """Algorithmic bytes of one hg_segment_reduce_f32 launch:
+    4C*nnz gathered rows + 4*nnz index + 4*(R+1) rowptr + 4C*R output (+ the mean-weight
+    rowptr reads of the backward form)."""
+    b = 4 * C * nnz + 4 * C * n_out
+    if has_idx:
+        b += 4 * nnz
+    if has_ptr:
+        b += 4 * (n_out + 1)
+    if has_w:
+        b += 8 * nnz
+    return b
+
+
+def measure_scatter_roofline(model, batch, dev):
+    """Record every hg_segment_reduce_f32 launch of one training step, then replay each launch
+    behind a busy prefix (so the queue is GPU-bound) bracketed by HIP events on the launching
+    stream.  Returns the roofline dict for that kernel."""
+    from equihgnn_amd import hip, ops
+
+    calls = []
+    real = ops._segment_reduce
+
+    def spy(src, idx, rowptr, wptr, n_out, mean):
+        out = real(src, idx, rowptr, wptr, n_out, mean)
+        nnz = int(idx.numel()) if idx is not None else (int(n_out) if rowptr is None else int(src.shape[0]))
+        calls.append((src.detach(), idx, rowptr, wptr, int(n_out), bool(mean), nnz))
+        return out
+
+    ops._segment_reduce = spy
+    try:
+        batch._hyper_index = None
+        out = model(batch)
+        torch.nn.functional.mse_loss(out, batch.y).backward()
+    finally:
+        ops._segment_reduce = real
+    torch.cuda.synchronize(dev)
+
+    L = hip.lib()
+    stream = torch.cuda.current_stream(dev)
+    busy = torch.randn(4096, 4096, device=dev)
+    reps = 20
+    tot_bytes = tot_ms = 0.0
+    for (src, idx, rowptr, wptr, n_out, mean, nnz) in calls:
+        src = src.contiguous()
+        C = src.shape[-1]
+        o = torch.empty((n_out, C), dtype=torch.float32, device=dev)
+        args = (ops._ptr(src), ops._ptr(idx), ops._ptr(rowptr), ops._ptr(wptr), ops._ptr(o), n_out, C,
+                1 if mean else 0, ops._stream(dev))
+        L.hg_segment_reduce_f32(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(busy, busy)  # ~1 ms of queued work: the launches below are enqueued behind it
+        e0.record(stream)
+        for _ in range(reps):
+            L.hg_segment_reduce_f32(*args)
+        e1.record(stream)
+        e1.synchronize()
+        tot_ms += e0.elapsed_time(e1) / reps
+        tot_bytes += seg_reduce_bytes(nnz, n_out, C, idx is not None, rowptr is not None,
+                                      wptr is not None, src.shape[0])
+    n = max(len(calls), 1)
+    avg_ms = tot_ms / n
+    achieved = (tot_bytes / n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_segment_reduce (hg_segment_reduce_f32)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches_per_step": len(calls), "avg_launch_us": round(avg_ms * 1e3, 2),
+            "alg_bytes_per_launch": int(tot_bytes / n)}
+
+
+def cpu_baseline(method, args_ns, batch_cpu, seconds):
+    """The oracle (kind "port": this repo's CPU restatement, pinned to the reference by the
+    golden vectors) timed on the host cores: same batch shape, same full training step."""
+    from oracle import ref_models as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = O.MODELS[method](1, args_ns)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.mse_loss(model(batch_cpu), batch_cpu.y)
+        loss.backward()
+        opt.step()
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 2) or n >= 50:
+            break
+    mol_s = n * batch_cpu.y.shape[0] / el
+    return {"value": round(mol_s, 2), "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full training steps (fwd+MSE+bwd+Adam) of the CPU oracle on one "
+                      f"B={batch_cpu.y.shape[0]} batch of the same workload, after 1 warm-up; "
+                      f"{el:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import TrainStep
+
+    args_ns = default_args(method=a.method, batch_size=a.batch)
+    torch.manual_seed(0)
+    model = MODELS[a.method](1, args_ns).to(dev)
+    cfg_id = 2
+    host_batches = [synth_batch(a.batch, cfg_id * 1000 + rank * 100 + i, a.flavour) for i in range(a.pool)]
+    batches = [b.to(dev) for b in host_batches]
+    trainer = TrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
+
+    def fresh(b):  # every step sees a "new" batch: the index (CSR sort, kNN) is rebuilt
+        b._hyper_index = None
+
+    trainer.on_batch = fresh
+    for i in range(a.warmup):
+        trainer.step(batches[i % a.pool])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = trainer.step(batches[i % a.pool])
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    result = None
+    if rank == 0:
+        n_nodes = sum(b.num_nodes for b in host_batches) / a.pool
+        nnz = sum(b.nnz for b in host_batches) / a.pool
+        result = {
+            "metric": "training molecules/sec on QM9 egnn_equihnns" if a.method == "egnn_equihnns"
+            else f"training molecules/sec ({a.method})",
+            "value": round(world * a.batch * a.steps / el, 1),
+            "unit": "molecules/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(el / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.flavour}-like synthetic molecules, --method {a.method}, "
+                                   f"batch {a.batch}/rank, hidden 256, 3 layers (scripts/run_qm9_3d.sh); "
+                                   "full training step fwd+MSE+bwd+all-reduce+Adam",
+                       "batch_per_rank": a.batch, "global_batch": a.batch * world,
+                       "avg_nodes": round(n_nodes, 1), "avg_incidences": round(nnz, 1),
+                       "parallelism": f"dp{world}"},
+            "final_loss": round(float(loss), 6),
+        }
+        if not a.no_roofline:
+            result["roofline"] = measure_scatter_roofline(model, batches[0], dev)
+        if world == 1 and not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(a.method, args_ns, host_batches[0], a.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,30 @@
+// Shared helpers for the gfx950 kernels of libequihgnn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "equihgnn_hip.h"
+
+#define EQH_WAVE 64
+
+#define EQH_CHECK_LAUNCH()                                  \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return EQH_ERR_LAUNCH; \
+    } while (0)
+
+static inline bool eqh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+static inline int eqh_grid_for(int64_t work_items, int per_block, int cap) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return static_cast<int>(g);
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_fma(float4& a, const float4& v, float w) {
+    a.x = fmaf(v.x, w, a.x); a.y = fmaf(v.y, w, a.y); a.z = fmaf(v.z, w, a.z); a.w = fmaf(v.w, w, a.w);
+}
+__device__ __forceinline__ void f4_add(float4& a, const float4& v) {
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+}

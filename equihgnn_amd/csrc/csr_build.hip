@@ -1,0 +1,253 @@
+// Incidence COO -> CSR (counting sort on the device, stable inside a row).
+//
+// Replaces the "unsorted int64 index + atomicAdd" contract of torch_scatter.scatter
+// (reference call sites conv.py:91-93,97,173,177): done once per batch, after which every
+// node<->hyperedge aggregation is an atomic-free segmented reduction over rowptr/col.
+//
+// Pipeline (all on `stream`, no host sync):
+//   memset cnt -> k_hist (int atomics) -> 3-kernel exclusive scan -> k_fill (int atomics into a
+//   scratch permutation) -> k_sort_short (rows <= 16 entries: per-thread rank sort) and
+//   k_sort_long (one workgroup per longer row: bitonic sort in LDS).  Sorting each row by entry
+//   id makes the summation order, and therefore every result, bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 counters per block
+constexpr int SHORT_ROW = 16;
+constexpr int LONG_THREADS = 256;
+constexpr int LONG_LDS_CAP = 16384;  // ints (64 KiB)
+
+__global__ void k_hist(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
+                       int* __restrict__ cnt) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+        int64_t k = key[p];
+        if (k >= 0 && k < n_rows) atomicAdd(&cnt[k], 1);
+    }
+}
+
+// block-wide exclusive scan of per-thread totals; returns the exclusive prefix of this thread
+// and (in *block_total) the sum over the block.
+__device__ int block_exclusive_scan(int v, int* block_total) {
+    __shared__ int wave_sum[SCAN_THREADS / EQH_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / EQH_WAVE; ++w) {
+        int s = wave_sum[w];
+        if (w < wave) base += s;
+        total += s;
+    }
+    __syncthreads();
+    *block_total = total;
+    return base + inc - v;
+}
+
+__global__ void k_scan_block_sums(const int* __restrict__ cnt, int64_t n_items,
+                                  int* __restrict__ block_sums) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < n_items) s += cnt[base + i];
+    int total;
+    block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// one block, any number of block sums: sequential chunks with a running carry
+__global__ void k_scan_carry(int* __restrict__ block_sums, int n_blocks) {
+    int carry = 0;
+    for (int c0 = 0; c0 < n_blocks; c0 += SCAN_THREADS) {
+        int i = c0 + threadIdx.x;
+        int v = i < n_blocks ? block_sums[i] : 0;
+        int total;
+        int ex = block_exclusive_scan(v, &total);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// rowptr[i] = exclusive prefix; cnt[i] is overwritten with the same value (fill cursor)
+__global__ void k_scan_apply(int* __restrict__ cnt, int64_t n_items,
+                             const int* __restrict__ block_sums, int* __restrict__ rowptr) {
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n_items) ? cnt[base + i] : 0;
+        s += v[i];
+    }
+    int total;
+    int run = block_exclusive_scan(s, &total) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n_items) {
+            rowptr[base + i] = run;
+            cnt[base + i] = run;
+        }
+        run += v[i];
+    }
+}
+
+__global__ void k_fill(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
+                       int* __restrict__ cursor, int* __restrict__ tmp_perm) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
+        int64_t k = key[p];
+        if (k >= 0 && k < n_rows) {
+            int pos = atomicAdd(&cursor[k], 1);
+            tmp_perm[pos] = (int)p;
+        }
+    }
+}
+
+__device__ __forceinline__ void emit(int pos, int entry, const int64_t* other, int col_div,
+                                     int* perm, int* col) {
+    perm[pos] = entry;
+    if (col) col[pos] = other ? (int)other[entry] : entry / col_div;
+}
+
+__global__ void k_sort_short(const int* __restrict__ rowptr, int64_t n_rows,
+                             const int* __restrict__ tmp_perm, const int64_t* __restrict__ other,
+                             int col_div, int* __restrict__ perm, int* __restrict__ col,
+                             int* __restrict__ long_count, int* __restrict__ long_rows) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+        const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
+        if (deg > SHORT_ROW) {
+            long_rows[atomicAdd(long_count, 1)] = (int)r;
+            continue;
+        }
+        for (int a = 0; a < deg; ++a) {
+            const int x = tmp_perm[beg + a];
+            int rank = 0;
+            for (int b = 0; b < deg; ++b) rank += (tmp_perm[beg + b] < x) ? 1 : 0;
+            emit(beg + rank, x, other, col_div, perm, col);
+        }
+    }
+}
+
+// one workgroup per long row; "normalised" bitonic network (always ascending compares), which
+// tolerates virtual +inf padding above the row length.
+__global__ void __launch_bounds__(LONG_THREADS)
+k_sort_long(const int* __restrict__ rowptr, const int* __restrict__ tmp_perm,
+            const int64_t* __restrict__ other, int col_div, int* __restrict__ perm,
+            int* __restrict__ col, const int* __restrict__ long_count,
+            const int* __restrict__ long_rows) {
+    extern __shared__ int s_row[];
+    const int n_long = *long_count;
+    for (int li = blockIdx.x; li < n_long; li += gridDim.x) {
+        const int r = long_rows[li];
+        const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
+        if (deg > LONG_LDS_CAP) {  // keeps fill order: reproducible to fp32 rounding only
+            for (int a = threadIdx.x; a < deg; a += LONG_THREADS)
+                emit(beg + a, tmp_perm[beg + a], other, col_div, perm, col);
+            continue;
+        }
+        for (int a = threadIdx.x; a < deg; a += LONG_THREADS) s_row[a] = tmp_perm[beg + a];
+        __syncthreads();
+        int p2 = 1;
+        while (p2 < deg) p2 <<= 1;
+        for (int k = 2; k <= p2; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < p2; i += LONG_THREADS) {
+                    const int l = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+                    if (l > i && l < deg) {
+                        const int a = s_row[i], b = s_row[l];
+                        if (a > b) { s_row[i] = b; s_row[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (int a = threadIdx.x; a < deg; a += LONG_THREADS)
+            emit(beg + a, s_row[a], other, col_div, perm, col);
+        __syncthreads();
+    }
+}
+
+struct Workspace {
+    int* tmp_perm;
+    int* cnt;
+    int* block_sums;
+    int* long_count;
+    int* long_rows;
+    size_t bytes;
+};
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+Workspace carve(void* base, int64_t nnz, int64_t n_rows) {
+    Workspace w;
+    const int64_t n_items = n_rows + 1;
+    const int64_t n_blocks = (n_items + SCAN_TILE - 1) / SCAN_TILE;
+    size_t off = 0;
+    char* b = static_cast<char*>(base);
+    w.tmp_perm = reinterpret_cast<int*>(b + off); off += align_up((size_t)(nnz > 0 ? nnz : 1) * 4);
+    w.cnt = reinterpret_cast<int*>(b + off); off += align_up((size_t)n_items * 4);
+    w.block_sums = reinterpret_cast<int*>(b + off); off += align_up((size_t)n_blocks * 4);
+    w.long_count = reinterpret_cast<int*>(b + off); off += 256;
+    w.long_rows = reinterpret_cast<int*>(b + off); off += align_up((size_t)(nnz / (SHORT_ROW + 1) + 1) * 4);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows) {
+    if (nnz < 0 || n_rows < 0) return 0;
+    return carve(nullptr, nnz, n_rows).bytes;
+}
+
+extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+                            int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    if (nnz < 0 || n_rows < 0 || !rowptr || !workspace) return EQH_ERR_ARG;
+    if (nnz > 0 && (!key || !perm)) return EQH_ERR_ARG;
+    if (!other && col && col_div < 1) return EQH_ERR_ARG;
+    if (nnz >= (int64_t)1 << 31 || n_rows >= ((int64_t)1 << 31) - 1) return EQH_ERR_RANGE;
+    Workspace w = carve(workspace, nnz, n_rows);
+    if (workspace_bytes < w.bytes) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+
+    const int64_t n_items = n_rows + 1;
+    const int n_blocks = (int)((n_items + SCAN_TILE - 1) / SCAN_TILE);
+    if (hipMemsetAsync(w.cnt, 0, (size_t)n_items * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+    if (hipMemsetAsync(w.long_count, 0, 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+    const int g_nnz = eqh_grid_for(nnz, 256, 2048);
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_hist, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
+        EQH_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt,
+                       n_items, w.block_sums);
+    hipLaunchKernelGGL(k_scan_carry, dim3(1), dim3(SCAN_THREADS), 0, stream, w.block_sums, n_blocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt, n_items,
+                       w.block_sums, rowptr);
+    EQH_CHECK_LAUNCH();
+    if (nnz > 0) {
+        hipLaunchKernelGGL(k_fill, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt,
+                           w.tmp_perm);
+        hipLaunchKernelGGL(k_sort_short, dim3(eqh_grid_for(n_rows, 256, 2048)), dim3(256), 0, stream,
+                           rowptr, n_rows, w.tmp_perm, other, col_div, perm, col, w.long_count,
+                           w.long_rows);
+        hipLaunchKernelGGL(k_sort_long, dim3(1024), dim3(LONG_THREADS), LONG_LDS_CAP * sizeof(int),
+                           stream, rowptr, w.tmp_perm, other, col_div, perm, col, w.long_count,
+                           w.long_rows);
+        EQH_CHECK_LAUNCH();
+    }
+    return EQH_OK;
+}

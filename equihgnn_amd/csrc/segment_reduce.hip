@@ -1,0 +1,106 @@
+// Segmented row reduction / row gather over a CSR — the node<->hyperedge aggregation kernel.
+//
+// Replaces torch_scatter.scatter(src, index, dim=-2, reduce="sum"|"mean") (conv.py:91-93,97,
+// 173,177), the advanced-index gathers X[..., idx, :] (conv.py:90,96,172,175,176), their
+// backward passes, and global_add_pool (equihnn_egnn.py:167, mhnn.py:216).
+//
+// HBM-bound.  Layout: a row of C fp32 channels is read as float4 per lane — at C=256 one
+// 64-lane wavefront covers exactly one 1 KiB row per load instruction (fully coalesced); for
+// narrower rows a wavefront is split into 64/LPR sub-groups that each own one output row.
+// The per-row sum lives in registers; nothing is atomic; the output row is written once.
+// Up to 4 source rows are in flight per sub-group to cover HBM/L2 latency; occupancy
+// (<= 40 VGPRs) supplies the rest.  Algorithmic bytes per call:
+//   4*C*nnz (gathered rows) + 4*nnz (col idx) + 4*(R+1) (rowptr) + 4*C*R (output).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+
+__device__ __forceinline__ float src_weight(const int* __restrict__ wptr, int j) {
+    if (!wptr) return 1.0f;
+    int d = wptr[j + 1] - wptr[j];
+    return 1.0f / (float)(d > 1 ? d : 1);
+}
+
+// LPR = lanes per row (power of two, <= 64).  Column blocks of LPR*4 floats.
+template <int LPR, bool WEIGHTED>
+__global__ void __launch_bounds__(THREADS)
+k_segment_reduce(const float* __restrict__ src, const int* __restrict__ idx,
+                 const int* __restrict__ rowptr, const int* __restrict__ wptr,
+                 float* __restrict__ out, int64_t n_rows, int C, int mean) {
+    constexpr int ROWS_PER_BLOCK = THREADS / LPR;
+    const int sub = threadIdx.x / LPR;
+    const int sl = threadIdx.x % LPR;
+    const int64_t row_stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
+    for (int64_t r = (int64_t)blockIdx.x * ROWS_PER_BLOCK + sub; r < n_rows; r += row_stride) {
+        int beg, end;
+        if (rowptr) { beg = rowptr[r]; end = rowptr[r + 1]; }
+        else { beg = (int)r; end = (int)r + 1; }
+        const int deg = end - beg;
+        const float denom = (mean && deg > 1) ? (float)deg : 1.0f;  // sum / clamp(count, 1)
+        for (int c = sl * 4; c < C; c += LPR * 4) {
+            float4 acc = f4_zero();
+            int q = beg;
+            for (; q + 4 <= end; q += 4) {
+                int j0, j1, j2, j3;
+                if (idx) { j0 = idx[q]; j1 = idx[q + 1]; j2 = idx[q + 2]; j3 = idx[q + 3]; }
+                else { j0 = q; j1 = q + 1; j2 = q + 2; j3 = q + 3; }
+                const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)j0 * C + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)j1 * C + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)j2 * C + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)j3 * C + c);
+                if (WEIGHTED) {
+                    f4_fma(acc, v0, src_weight(wptr, j0)); f4_fma(acc, v1, src_weight(wptr, j1));
+                    f4_fma(acc, v2, src_weight(wptr, j2)); f4_fma(acc, v3, src_weight(wptr, j3));
+                } else {
+                    f4_add(acc, v0); f4_add(acc, v1); f4_add(acc, v2); f4_add(acc, v3);
+                }
+            }
+            for (; q < end; ++q) {
+                const int j = idx ? idx[q] : q;
+                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * C + c);
+                if (WEIGHTED) f4_fma(acc, v, src_weight(wptr, j));
+                else f4_add(acc, v);
+            }
+            acc.x /= denom; acc.y /= denom; acc.z /= denom; acc.w /= denom;
+            *reinterpret_cast<float4*>(out + r * C + c) = acc;
+        }
+    }
+}
+
+template <int LPR>
+int launch(const float* src, const int* idx, const int* rowptr, const int* wptr, float* out,
+           int64_t n_rows, int C, int mean, hipStream_t stream) {
+    constexpr int ROWS_PER_BLOCK = THREADS / LPR;
+    // enough workgroups to fill 256 CUs x 8 blocks, grid-stride beyond that
+    const int grid = eqh_grid_for(n_rows, ROWS_PER_BLOCK, 256 * 16);
+    if (wptr)
+        hipLaunchKernelGGL((k_segment_reduce<LPR, true>), dim3(grid), dim3(THREADS), 0, stream, src,
+                           idx, rowptr, wptr, out, n_rows, C, mean);
+    else
+        hipLaunchKernelGGL((k_segment_reduce<LPR, false>), dim3(grid), dim3(THREADS), 0, stream, src,
+                           idx, rowptr, wptr, out, n_rows, C, mean);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+}  // namespace
+
+extern "C" int hg_segment_reduce_f32(const float* src, const int32_t* idx, const int32_t* rowptr,
+                                     const int32_t* src_wptr, float* out, int64_t n_out_rows,
+                                     int32_t C, int32_t mean, void* stream_) {
+    if (n_out_rows < 0 || C <= 0) return EQH_ERR_ARG;
+    if (n_out_rows == 0) return EQH_OK;
+    if (!src || !out) return EQH_ERR_ARG;
+    if (!rowptr && !idx) return EQH_ERR_ARG;  // a gather needs an index
+    if ((C & 3) || !eqh_aligned16(src) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    if (n_out_rows >= ((int64_t)1 << 31) - 1) return EQH_ERR_RANGE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int lanes = C / 4;
+    if (lanes > 32) return launch<64>(src, idx, rowptr, src_wptr, out, n_out_rows, C, mean, stream);
+    if (lanes > 16) return launch<32>(src, idx, rowptr, src_wptr, out, n_out_rows, C, mean, stream);
+    if (lanes > 8) return launch<16>(src, idx, rowptr, src_wptr, out, n_out_rows, C, mean, stream);
+    if (lanes > 4) return launch<8>(src, idx, rowptr, src_wptr, out, n_out_rows, C, mean, stream);
+    return launch<4>(src, idx, rowptr, src_wptr, out, n_out_rows, C, mean, stream);
+}

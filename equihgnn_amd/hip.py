@@ -1,0 +1,66 @@
+"""ctypes binding of libequihgnn_hip.so — the C ABI declared in include/equihgnn_hip.h.
+
+There is NO fallback: if the shared library is missing or a call returns an error code this
+module raises.  The product path never routes through a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_void_p
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libequihgnn_hip.so")
+
+# name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
+SIGNATURES = {
+    "eqh_version": (c_int32, []),
+    "eqh_error_string": (c_char_p, [c_int32]),
+    "hg_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "hg_csr_build": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hg_segment_reduce_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                        c_int32, c_int32, c_void_p]),
+    "hg_embed_sum_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
+                                   c_void_p, c_void_p]),
+    "hg_embed_sum_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int64]),
+    "hg_embed_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "geo_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the shared library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -m equihgnn_amd.build` "
+            "(hipcc --offload-arch=gfx950).  equihgnn_amd has no CPU fallback.")
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().eqh_error_string(rc)
+        raise HipLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,71 @@
+"""Per-batch index structures, built once on the device and shared by every layer and by the
+backward pass: the two incidence CSRs (by hyperedge / by node), the pooling CSR and the
+k-nearest-neighbour lists.
+
+The reference re-derives all of this implicitly inside every torch_scatter / index call from the
+unsorted int64 COO lists (conv.py:90-98,172-177); sorting once per batch is what lets the
+aggregations run as atomic-free segmented reductions.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+
+
+class HyperIndex:
+    """CSR views of one batch's incidence structure.
+
+    by_e : rows = hyperedges, col = node of each incidence     (node -> hyperedge aggregation)
+    by_v : rows = nodes,      col = hyperedge of each incidence (hyperedge -> node aggregation)
+    pool : rows = molecules, entries = nodes (``batch`` is sorted)
+    """
+
+    def __init__(self, vertex: torch.Tensor, edges: torch.Tensor, num_nodes: int, num_hyperedges: int,
+                 batch: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None):
+        self.N, self.M = int(num_nodes), int(num_hyperedges)
+        self.nnz = int(vertex.numel())
+        self.v32 = vertex.to(torch.int32)
+        self.e32 = edges.to(torch.int32)
+        self.by_e = ops.csr_build(edges, vertex, self.M)
+        self.by_v = ops.csr_build(vertex, edges, self.N)
+        deg_v = self.by_v.rowptr[1:] - self.by_v.rowptr[:-1]
+        deg_e = self.by_e.rowptr[1:] - self.by_e.rowptr[:-1]
+        self.has_v = (deg_v > 0).to(torch.float32).unsqueeze(-1)  # rows a mean leaves at zero
+        self.has_e = (deg_e > 0).to(torch.float32).unsqueeze(-1)
+        self.pool = None
+        if batch is not None:
+            self.B = int(num_graphs)
+            self.batch32 = batch.to(torch.int32)
+            self.pool = ops.csr_build(batch, None, self.B)
+        self._knn = {}
+
+    @classmethod
+    def from_batch(cls, data) -> "HyperIndex":
+        cached = getattr(data, "_hyper_index", None)
+        if cached is not None:
+            return cached
+        n = getattr(data, "num_nodes", None) or data.x.shape[0]
+        m = getattr(data, "num_hyperedges", None)
+        if not m:
+            ea = getattr(data, "edge_attr", None)
+            m = ea.shape[0] if ea is not None else int(data.edge_index1.max()) + 1
+        b = getattr(data, "num_graphs", None) or data.y.shape[0]
+        idx = cls(data.edge_index0, data.edge_index1, n, m, data.batch, b)
+        try:
+            data._hyper_index = idx
+        except Exception:  # a frozen container: just rebuild next time
+            pass
+        return idx
+
+    def knn(self, pos: torch.Tensor, k: int, mode: int):
+        """(nbr int32 [N,k], key fp32 [N,k], CSR of the transposed neighbour graph)."""
+        hit = self._knn.get((k, mode))
+        if hit is None:
+            nbr, key = ops.knn(pos, k, mode)
+            csr_t = ops.csr_build(nbr.reshape(-1).to(torch.int64), None, self.N)
+            hit = (nbr, key, csr_t)
+            self._knn[(k, mode)] = hit
+        return hit

@@ -1,0 +1,249 @@
+"""Layers of the hot path, MI355X-native, with the reference's parameter names and shapes.
+
+The arithmetic is re-derived for the device rather than transcribed:
+
+* A Linear applied to ``cat(a[v], b[e])`` per incidence is split by columns,
+  ``W·cat(a,b) = W_a·a + W_b·b``, and evaluated at node / hyperedge level (N + M rows through
+  MFMA instead of 2·nnz rows); the per-incidence work becomes a row gather-add.
+* The last Linear of a per-incidence MLP commutes with the (linear) mean aggregation, so it runs
+  on the aggregated rows: ``mean_r(W·h_p + b) = W·mean_r(h_p) + b·[deg(r) > 0]``.
+* All gathers / scatters go through the CSR kernels of libequihgnn_hip.so (ops.py).
+
+Dense Linears are plain library GEMMs (fp32 MFMA through hipBLASLt via torch); they are the
+"dense per-type linear mixes" of the north star, not the hand-written part.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .batch import ATOM_FEATURE_DIMS
+from .index import HyperIndex
+
+
+def _make_norm(kind: str, width: int) -> nn.Module:
+    if kind == "ln":
+        return nn.LayerNorm(width)
+    if kind == "bn":
+        return nn.BatchNorm1d(width)
+    if kind == "None":
+        return nn.Identity()
+    raise AssertionError(f"Normalization must be bn/ln/None, got {kind}")  # mlp.py:27
+
+
+class AtomEncoder(nn.Module):
+    """ogb AtomEncoder (call sites equihnn_egnn.py:121,157): ``atom_embedding_list.{0..8}``."""
+
+    def __init__(self, emb_dim: int):
+        super().__init__()
+        self.atom_embedding_list = nn.ModuleList()
+        offs, run = [], 0
+        for d in ATOM_FEATURE_DIMS:
+            emb = nn.Embedding(d, emb_dim)
+            nn.init.xavier_uniform_(emb.weight.data)
+            self.atom_embedding_list.append(emb)
+            offs.append(run)
+            run += d
+        self.offsets = tuple(offs)
+
+    def forward(self, x):
+        table = torch.cat([e.weight for e in self.atom_embedding_list], 0)
+        return ops.embed_sum(x, table, self.offsets)
+
+
+class BondEncoder(nn.Embedding):
+    """nn.Embedding(6, C) on ``edge_attr`` (mhnn.py:165,202), through the same kernel."""
+
+    def forward(self, idx):
+        return ops.embed_sum(idx.reshape(-1, 1), self.weight, (0,))
+
+
+class MLP(nn.Module):
+    """mlp.py:9-99 — same ``lins`` / ``normalizations`` lists; forward mlp.py:91-99:
+    norm0 -> [Linear -> ReLU -> norm -> dropout]* -> Linear (the norm comes after ReLU)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers,
+                 dropout=0.5, Normalization="bn", InputNorm=False):
+        super().__init__()
+        self.lins = nn.ModuleList()
+        self.normalizations = nn.ModuleList()
+        self.InputNorm = InputNorm
+        self.normalizations.append(_make_norm(Normalization, in_channels) if InputNorm else nn.Identity())
+        widths = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        for i in range(num_layers):
+            self.lins.append(nn.Linear(widths[i], widths[i + 1]))
+            if i < num_layers - 1:
+                self.normalizations.append(_make_norm(Normalization, widths[i + 1]))
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        for n in self.normalizations:
+            if not isinstance(n, nn.Identity):
+                n.reset_parameters()
+
+    def hidden(self, h, start: int):
+        """ReLU -> norm -> dropout after Linear ``start``, then the hidden Linears up to (not
+        including) the last one."""
+        last = len(self.lins) - 1
+        for i in range(start, last):
+            if i > start:
+                h = self.lins[i](h)
+            h = F.relu(h)
+            h = self.normalizations[i + 1](h)
+            h = F.dropout(h, p=self.dropout, training=self.training)
+        return h
+
+    def forward(self, x):
+        x = self.normalizations[0](x)
+        if len(self.lins) == 1:
+            return self.lins[0](x)
+        h = self.hidden(self.lins[0](x), 0)
+        return self.lins[-1](h)
+
+
+def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr):
+    """reduce_r( mlp(cat(a[idx_a], b[idx_b])) ) over the rows of ``out_csr`` — the
+    per-incidence MLP + scatter of conv.py:90-93,96-97,175-177, restructured (module docstring).
+
+    a is indexed by idx_a32 (CSR keyed by that index: csr_a), b by idx_b32 (csr_b)."""
+    if mlp.InputNorm:
+        raise NotImplementedError("InputNorm=True is never set by the reference wrappers "
+                                  "(equihnn_egnn.py:139-149) and is not supported")
+    lin0 = mlp.lins[0]
+    ca = a.shape[-1]
+    wa, wb = lin0.weight[:, :ca], lin0.weight[:, ca:]
+    pa = F.linear(a, wa)                # rows of a
+    qb = F.linear(b, wb, lin0.bias)     # rows of b
+    h = ops.gather_rows(pa, idx_a32, csr_a) + ops.gather_rows(qb, idx_b32, csr_b)  # [nnz, C]
+    if len(mlp.lins) == 1:              # a single Linear: everything is linear in h
+        return ops.reduce_entries(h, out_csr, out_key32, aggr)
+    h = mlp.hidden(h, 0)
+    s = ops.reduce_entries(h, out_csr, out_key32, aggr)
+    last = mlp.lins[-1]
+    if aggr == "mean":
+        return F.linear(s, last.weight) + last.bias * has_row
+    deg = (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype).unsqueeze(-1)
+    return F.linear(s, last.weight) + last.bias * deg
+
+
+class MHNNConv(nn.Module):
+    """conv.py:8-101 (node and hyperedge features, W1..W4)."""
+
+    def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, mlp4_layers=1,
+                 aggr="mean", dropout=0.0, normalization="None", input_norm=False):
+        super().__init__()
+        if min(mlp1_layers, mlp2_layers, mlp3_layers, mlp4_layers) < 1:
+            raise NotImplementedError("mlpK_layers=0 (conv.py:33-34) is not reachable from the "
+                                      "reference's scripts and is not supported")
+        mk = lambda n: MLP(hid_dim * 2, hid_dim, hid_dim, n, dropout=dropout,
+                           Normalization=normalization, InputNorm=input_norm)
+        self.W1, self.W2, self.W3, self.W4 = mk(mlp1_layers), mk(mlp2_layers), mk(mlp3_layers), mk(mlp4_layers)
+        self.aggr = aggr
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        for w in (self.W1, self.W2, self.W3, self.W4):
+            w.reset_parameters()
+
+    def forward(self, X, E, index: HyperIndex):
+        ix = index
+        m_e = _pair_message(self.W1, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_e, ix.e32,
+                            ix.has_e, self.aggr)                     # conv.py:90-93
+        E = self.W2(torch.cat((E, m_e), -1))                          # conv.py:94
+        m_v = _pair_message(self.W3, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
+                            ix.has_v, self.aggr)                     # conv.py:96-97
+        X = self.W4(torch.cat((X, m_v), -1))                          # conv.py:98
+        return X, E
+
+
+class MHNNSConv(nn.Module):
+    """conv.py:104-182 (node features only, W1..W3, alpha residual to X0)."""
+
+    def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, aggr="mean",
+                 alpha=0.5, dropout=0.0, normalization="None", input_norm=False):
+        super().__init__()
+        if min(mlp1_layers, mlp2_layers, mlp3_layers) < 1:
+            raise NotImplementedError("mlpK_layers=0 (conv.py:129-130,155-156) is not supported")
+        self.W1 = MLP(hid_dim, hid_dim, hid_dim, mlp1_layers, dropout=dropout,
+                      Normalization=normalization, InputNorm=input_norm)
+        self.W2 = MLP(hid_dim * 2, hid_dim, hid_dim, mlp2_layers, dropout=dropout,
+                      Normalization=normalization, InputNorm=input_norm)
+        self.W3 = MLP(hid_dim, hid_dim, hid_dim, mlp3_layers, dropout=dropout,
+                      Normalization=normalization, InputNorm=input_norm)
+        self.aggr = aggr
+        self.alpha = alpha
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        for w in (self.W1, self.W2, self.W3):
+            w.reset_parameters()
+
+    def forward(self, X, index: HyperIndex, X0):
+        ix = index
+        x_e = ops.reduce_gathered(self.W1(X), ix.by_e, ix.by_v, self.aggr)       # conv.py:172-173
+        x_v = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
+                            ix.has_v, self.aggr)                                 # conv.py:175-177
+        return self.W3((1 - self.alpha) * x_v + self.alpha * X0)                 # conv.py:179-180
+
+
+class CoorsNorm(nn.Module):
+    """egnn_layer.py:71-81 — parameter kept for state_dict compatibility; the coordinate branch
+    is dead in this model (equihnn_egnn.py:158 discards the coordinate output)."""
+
+    def __init__(self, scale_init=1.0):
+        super().__init__()
+        self.scale = nn.Parameter(torch.full((1,), float(scale_init)))
+
+
+class EGNN(nn.Module):
+    """egnn_layer.py:145-366 as configured at equihnn_egnn.py:123-129 and called at :158
+    (mask=None, edges=None, k=16 incl. self, m_pool="sum").  ``coors_mlp`` / ``coors_norm`` are
+    kept as parameters and never receive a gradient, as in the reference."""
+
+    def __init__(self, dim, m_dim=16, num_nearest_neighbors=16, init_eps=1e-3,
+                 norm_coors_scale_init=1e-2):
+        super().__init__()
+        e_in = 2 * dim + 1
+        self.dim, self.m_dim, self.k = dim, m_dim, num_nearest_neighbors
+        self.edge_mlp = nn.Sequential(nn.Linear(e_in, 2 * e_in), nn.Identity(), nn.SiLU(),
+                                      nn.Linear(2 * e_in, m_dim), nn.SiLU())
+        self.node_norm = nn.LayerNorm(dim)
+        self.coors_norm = CoorsNorm(norm_coors_scale_init)
+        self.node_mlp = nn.Sequential(nn.Linear(dim + m_dim, 2 * dim), nn.Identity(), nn.SiLU(),
+                                      nn.Linear(2 * dim, dim))
+        self.coors_mlp = nn.Sequential(nn.Linear(m_dim, 4 * m_dim), nn.Identity(), nn.SiLU(),
+                                       nn.Linear(4 * m_dim, 1))
+        for mod in self.modules():  # egnn_layer.py:227-230
+            if type(mod) is nn.Linear:
+                nn.init.normal_(mod.weight, std=init_eps)
+
+    def forward(self, feats, coors, index: HyperIndex):
+        c = self.dim
+        nbr, d2, csr_t = index.knn(coors, self.k, 0)
+        lin1, lin2 = self.edge_mlp[0], self.edge_mlp[3]
+        # hidden width H = 2(2C+1) is padded with zero rows to a multiple of 16 so that rows stay
+        # 16-byte aligned for the gather kernel; silu(0) = 0, so the padding contributes nothing
+        hdim = lin1.weight.shape[0]
+        pad = (-hdim) % 16
+        w1 = F.pad(lin1.weight, (0, 0, 0, pad))
+        b1 = F.pad(lin1.bias, (0, pad))
+        w2 = F.pad(lin2.weight, (0, pad))
+        w_i, w_j, w_d = w1[:, :c], w1[:, c:2 * c], w1[:, 2 * c]
+        a = F.linear(feats, w_i, b1)                           # [N, Hp]  receiver part (+bias)
+        b = F.linear(feats, w_j)                               # [N, Hp]  sender part
+        n = feats.shape[0]
+        b_j = ops.gather_rows(b, nbr.reshape(-1), csr_t).view(n, self.k, -1)
+        h = a.unsqueeze(1) + b_j + d2.unsqueeze(-1) * w_d      # egnn_layer.py:305-310, split form
+        m_ij = F.silu(F.linear(F.silu(h), w2, lin2.bias))
+        m_i = m_ij.sum(-2)                                     # egnn_layer.py:357-358
+        node_in = torch.cat((self.node_norm(feats), m_i), -1)
+        return self.node_mlp(node_in) + feats                  # egnn_layer.py:360-362
+
+
+def pool_sum(x, index: HyperIndex):
+    """global_add_pool (equihnn_egnn.py:167, mhnn.py:216): per-molecule sum over sorted rows."""
+    return ops.reduce_entries(x, index.pool, index.batch32, "sum")

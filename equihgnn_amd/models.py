@@ -1,0 +1,114 @@
+"""Model classes registered under the reference's ``--method`` names.
+
+Constructor and call contract of main.py:28-34,46-47: ``cls(num_target, args)``;
+``model(data) -> float32 Tensor[B]`` on ``data.x.device``.  Parameter / buffer names and shapes are
+identical to the reference's, so its checkpoints load with ``strict=True``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .index import HyperIndex
+from .layers import EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, pool_sum
+from .registry import registry
+
+_ACT = {"Id": nn.Identity, "relu": nn.ReLU, "prelu": nn.PReLU}
+
+
+@registry.register_model("egnn_equihnns")
+class EGNNEquiHNNS(nn.Module):
+    """equihnn_egnn.py:98-169: AtomEncoder -> EGNN (once) -> shared MHNNSConv x L -> pool -> head."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.egnn_layer = EGNN(dim=args.MLP_hidden, num_nearest_neighbors=16)
+        self.conv = MHNNSConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers,
+                              mlp2_layers=self.mlp2_layers, mlp3_layers=self.mlp3_layers,
+                              aggr=args.aggregate, dropout=args.dropout,
+                              normalization=args.normalization)
+        self.mlp_out = MLP(in_channels=args.MLP_hidden, hidden_channels=args.output_hidden,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def reset_parameters(self):  # equihnn_egnn.py:151-153
+        self.conv.reset_parameters()
+        self.mlp_out.reset_parameters()
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        if taps is not None:
+            taps["atom_encoder"] = x
+        x = self.egnn_layer(x, data.pos, index)
+        if taps is not None:
+            taps["front_end"] = x
+        x0 = x
+        for i in range(self.nlayer):
+            x = self.conv(self.dropout(x), index, x0)
+            if taps is not None:
+                taps[f"conv{i}"] = x
+            x = self.act(x)
+        x = pool_sum(self.dropout(x), index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+@registry.register_model("mhnnm")
+class MHNNM(nn.Module):
+    """mhnn.py:144-218: L unshared MHNNConv layers + BatchNorm1d on node rows.  The host-side
+    per-molecule ``.item()`` loop of mhnn.py:196-199 builds a tensor the model never uses; it is
+    not reproduced (it costs B device syncs per step)."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.mlp4_layers = args.MLP4_num_layers
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.bond_encoder = BondEncoder(6, args.MLP_hidden)
+        self.layers = nn.ModuleList()
+        self.batch_norms = nn.ModuleList()
+        for _ in range(self.nlayer):
+            self.layers.append(MHNNConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers,
+                                        mlp2_layers=self.mlp2_layers, mlp3_layers=self.mlp3_layers,
+                                        mlp4_layers=self.mlp4_layers, aggr=args.aggregate,
+                                        dropout=args.dropout, normalization=args.normalization))
+            self.batch_norms.append(nn.BatchNorm1d(args.MLP_hidden))
+        self.mlp_out = MLP(in_channels=args.MLP_hidden, hidden_channels=args.output_hidden,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        e = self.bond_encoder(data.edge_attr)
+        if taps is not None:
+            taps["atom_encoder"] = x
+        for i, layer in enumerate(self.layers):
+            x, e = layer(x, e, index)
+            x = self.batch_norms[i](x)
+            if taps is not None:
+                taps[f"bn{i}"] = x
+            if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
+                x, e = self.act(x), self.act(e)
+            x, e = self.dropout(x), self.dropout(e)
+        x = pool_sum(x, index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM}

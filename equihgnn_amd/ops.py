@@ -1,0 +1,240 @@
+"""Host-side operators over libequihgnn_hip.so: torch.autograd.Functions whose forward and
+backward are C-ABI kernel launches on the current HIP stream.
+
+PyTorch supplies device memory, streams and the autograd tape; all gather / scatter /
+neighbour-search / embedding arithmetic runs in the hand-written gfx950 kernels.  Nothing here
+has a CPU fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip
+
+_c_void_p = ctypes.c_void_p
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else _c_void_p(t.data_ptr())
+
+
+def _stream(device) -> _c_void_p:
+    return _c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise hip.HipLibraryError(
+            f"{what}: tensor on {t.device}; equihgnn_amd runs on MI355X (HIP) devices only — "
+            "there is no CPU fallback")
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# CSR
+# --------------------------------------------------------------------------------------------
+@dataclass
+class CSR:
+    """rowptr[n_rows+1], perm[nnz] (entry ids grouped by row, ascending inside a row) and
+    col[nnz] (the other coordinate of each entry), all int32 on the device."""
+
+    rowptr: torch.Tensor
+    perm: torch.Tensor
+    col: torch.Tensor
+    n_rows: int
+    nnz: int
+
+
+def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1) -> CSR:
+    """hg_csr_build: COO (int64 keys) -> CSR.  ``other`` int64 or None (then col = perm//col_div)."""
+    _require_gpu(key, "csr_build")
+    assert key.dtype == torch.int64 and key.dim() == 1
+    key = key.contiguous()
+    if other is not None:
+        assert other.dtype == torch.int64 and other.shape == key.shape
+        other = other.contiguous()
+    nnz = key.numel()
+    dev = key.device
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+    L = hip.lib()
+    ws_bytes = L.hg_csr_build_workspace_bytes(nnz, n_rows)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    hip.check(L.hg_csr_build(_ptr(key), _ptr(other), nnz, n_rows, col_div, _ptr(rowptr), _ptr(perm),
+                             _ptr(col), _ptr(ws), ws_bytes, _stream(dev)), "hg_csr_build")
+    return CSR(rowptr, perm[:nnz], col[:nnz], n_rows, nnz)
+
+
+def _segment_reduce(src, idx, rowptr, wptr, n_out, mean: bool) -> torch.Tensor:
+    """Raw launch of hg_segment_reduce_f32 on 2-D ``src`` [rows, C]."""
+    _require_gpu(src, "segment_reduce")
+    src = _f32c(src)
+    C = src.shape[-1]
+    out = torch.empty((n_out, C), dtype=torch.float32, device=src.device)
+    hip.check(hip.lib().hg_segment_reduce_f32(_ptr(src), _ptr(idx), _ptr(rowptr), _ptr(wptr), _ptr(out),
+                                              n_out, C, 1 if mean else 0, _stream(src.device)),
+              "hg_segment_reduce_f32")
+    return out
+
+
+def _as2d(t: torch.Tensor):
+    """The Equiformer wrapper carries a leading 1-dim (equihnn_equiformer.py:82-85); every op
+    here reduces along dim -2, so flatten the leading dims of size 1."""
+    lead = t.shape[:-2]
+    for s in lead:
+        if s != 1:
+            raise ValueError(f"leading dims must be 1, got {tuple(t.shape)}")
+    return t.reshape(t.shape[-2], t.shape[-1]), lead
+
+
+# --------------------------------------------------------------------------------------------
+# autograd functions
+# --------------------------------------------------------------------------------------------
+class _ReduceGathered(torch.autograd.Function):
+    """out[r] = reduce_{q in row r of csr} src[csr.col[q]] — gather + scatter fused
+    (conv.py:172-173: ``scatter(W1(X)[..., vertex, :], edges)``).  Backward is the same kernel on
+    the transposed CSR with the mean weights of the forward rows."""
+
+    @staticmethod
+    def forward(ctx, src, csr: CSR, csr_t: CSR, mean: bool):
+        ctx.csr, ctx.csr_t, ctx.mean = csr, csr_t, mean
+        return _segment_reduce(src, csr.col, csr.rowptr, None, csr.n_rows, mean)
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr, csr_t = ctx.csr, ctx.csr_t
+        dsrc = _segment_reduce(dout, csr_t.col, csr_t.rowptr, csr.rowptr if ctx.mean else None,
+                               csr_t.n_rows, False)
+        return dsrc, None, None, None
+
+
+class _ReduceEntries(torch.autograd.Function):
+    """out[r] = reduce_{q in row r} src[csr.perm[q]] with ``src`` holding one row per entry
+    (torch_scatter.scatter of a per-incidence matrix, conv.py:91-93,97,177).  Backward is a row
+    gather: dsrc[p] = dout[key[p]] / max(deg(key[p]), 1)."""
+
+    @staticmethod
+    def forward(ctx, src, csr: CSR, key32, mean: bool):
+        ctx.csr, ctx.key32, ctx.mean = csr, key32, mean
+        return _segment_reduce(src, csr.perm, csr.rowptr, None, csr.n_rows, mean)
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr = ctx.csr
+        dsrc = _segment_reduce(dout, ctx.key32, None, csr.rowptr if ctx.mean else None, csr.nnz, False)
+        return dsrc, None, None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """out[p] = src[key32[p]] (X[..., vertex, :], conv.py:90,96,172,175,176).  Backward is the
+    segmented sum over the CSR keyed by the same index (what ATen does with index_put_
+    accumulate, 14 % of the reference's mhnnm CPU step)."""
+
+    @staticmethod
+    def forward(ctx, src, key32, csr: CSR):
+        ctx.csr = csr
+        return _segment_reduce(src, key32, None, None, key32.numel(), False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr = ctx.csr
+        return _segment_reduce(dout, csr.perm, csr.rowptr, None, csr.n_rows, False), None, None
+
+
+class _EmbedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table, offsets):
+        _require_gpu(table, "embed_sum")
+        x = x.contiguous()
+        table = _f32c(table)
+        N, F = x.shape
+        C = table.shape[1]
+        off = (ctypes.c_int32 * F)(*offsets)
+        out = torch.empty((N, C), dtype=torch.float32, device=table.device)
+        hip.check(hip.lib().hg_embed_sum_fwd(_ptr(x), _ptr(table), off, F, N, C, table.shape[0],
+                                             _ptr(out), _stream(table.device)), "hg_embed_sum_fwd")
+        ctx.save_for_backward(x)
+        ctx.offsets, ctx.rows = offsets, table.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        dout = _f32c(dout)
+        N, F = x.shape
+        C = dout.shape[1]
+        L = hip.lib()
+        off = (ctypes.c_int32 * F)(*ctx.offsets)
+        dtable = torch.empty((ctx.rows, C), dtype=torch.float32, device=dout.device)
+        ws_bytes = L.hg_embed_sum_bwd_workspace_bytes(N, C, ctx.rows)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dout.device)
+        hip.check(L.hg_embed_sum_bwd(_ptr(x), _ptr(dout), off, F, N, C, ctx.rows, _ptr(dtable), _ptr(ws),
+                                     ws_bytes, _stream(dout.device)), "hg_embed_sum_bwd")
+        return None, dtable, None
+
+
+# --------------------------------------------------------------------------------------------
+# public functional API
+# --------------------------------------------------------------------------------------------
+def reduce_gathered(src, csr: CSR, csr_t: CSR, reduce: str = "mean"):
+    s2, lead = _as2d(src)
+    out = _ReduceGathered.apply(s2, csr, csr_t, reduce == "mean")
+    return out.reshape(*lead, *out.shape)
+
+
+def reduce_entries(src, csr: CSR, key32, reduce: str = "mean"):
+    s2, lead = _as2d(src)
+    out = _ReduceEntries.apply(s2, csr, key32, reduce == "mean")
+    return out.reshape(*lead, *out.shape)
+
+
+def gather_rows(src, key32, csr: CSR):
+    s2, lead = _as2d(src)
+    out = _GatherRows.apply(s2, key32, csr)
+    return out.reshape(*lead, *out.shape)
+
+
+def embed_sum(x, table, offsets):
+    """out[n] = sum_f table[offsets[f] + x[n, f]] (ogb AtomEncoder order)."""
+    if x.dim() == 1:
+        x = x[:, None]
+    return _EmbedSum.apply(x, table, tuple(int(o) for o in offsets))
+
+
+def knn(pos, k: int, mode: int):
+    """geo_knn: (nbr int32 [N,k], key fp32 [N,k]); mode 0 = EGNN, 1 = Equiformer.  No gradient
+    (the reference feeds ``pos`` as data; its distances carry no grad to parameters)."""
+    _require_gpu(pos, "knn")
+    pos = _f32c(pos.detach())
+    N = pos.shape[0]
+    nbr = torch.empty((N, k), dtype=torch.int32, device=pos.device)
+    dist = torch.empty((N, k), dtype=torch.float32, device=pos.device)
+    hip.check(hip.lib().geo_knn(_ptr(pos), N, k, mode, _ptr(nbr), _ptr(dist), _stream(pos.device)),
+              "geo_knn")
+    return nbr, dist
+
+
+def scatter(src, index, dim: int = -1, out=None, dim_size=None, reduce: str = "sum"):
+    """Drop-in for ``torch_scatter.scatter`` at the reference's call sites (conv.py:3,91-93,97,
+    173,177): 1-D int64 ``index`` along ``dim=-2``.  Builds the CSR on the fly; the model classes
+    instead build it once per batch (HyperIndex) and call reduce_entries / reduce_gathered."""
+    if out is not None:
+        raise NotImplementedError("out= is not used by the reference")
+    if dim not in (-2, src.dim() - 2) or index.dim() != 1:
+        raise NotImplementedError("only the reference's pattern (1-D index, dim=-2) is supported")
+    if reduce not in ("sum", "add", "mean"):
+        raise ValueError(reduce)
+    if dim_size is None:
+        dim_size = int(index.max()) + 1  # device sync, as in torch_scatter
+    csr = csr_build(index, None, dim_size)
+    return reduce_entries(src, csr, index.to(torch.int32), "mean" if reduce == "mean" else "sum")

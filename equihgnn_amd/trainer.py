@@ -1,0 +1,95 @@
+"""Training-step harness equal to the reference's LitModel step (main.py:49-63,137-151):
+forward -> nn.MSELoss -> backward -> gradient average across ranks -> Adam(lr, wd).
+
+Data parallelism: one process per GPU, each rank steps its own molecule batch;
+the only exchange is ONE all-reduce of a flat gradient buffer per step (RCCL over xGMI when the
+backend is "nccl", gloo on CPU for the tests).  Parameter gradients are views into that flat
+buffer, so there is no pack/unpack copy, and parameters whose gradient the model never
+produces (the reference's dead branches, which is why main.py:281 needs
+``find_unused_parameters``) are simply left out: their ``.grad`` stays ``None`` on every rank.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _world() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class FlatGradients:
+    """One contiguous fp32 buffer holding every live parameter's gradient."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        n = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self):
+        w = _world()
+        if w > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / w)
+
+
+class TrainStep:
+    """``loss = step(data)``; ``data.y`` is the target.  Model-agnostic (the gloo tests drive it
+    with the CPU oracle, the GPU path with the HIP models)."""
+
+    def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
+                 broadcast_from_rank0: bool = True, on_batch: Optional[Callable] = None):
+        self.model = model
+        self.lr, self.wd = lr, weight_decay
+        self.on_batch = on_batch
+        self.flat: Optional[FlatGradients] = None
+        self.opt: Optional[torch.optim.Optimizer] = None
+        if broadcast_from_rank0 and _world() > 1:  # DDP broadcasts rank 0's parameters at wrap time
+            for t in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t.data, src=0)
+
+    def _first_step(self, data):
+        """Discover which parameters receive a gradient, then lay out the flat buffer."""
+        for p in self.model.parameters():
+            p.grad = None
+        loss = F.mse_loss(self.model(data), data.y)
+        loss.backward()
+        live = [p for p in self.model.parameters() if p.grad is not None]
+        first = [p.grad.clone() for p in live]
+        self.flat = FlatGradients(live)
+        for p, g in zip(live, first):
+            p.grad.copy_(g)
+        fused = live[0].is_cuda
+        self.opt = torch.optim.Adam(live, lr=self.lr, weight_decay=self.wd, fused=fused)
+        return loss
+
+    def step(self, data) -> torch.Tensor:
+        if self.on_batch is not None:
+            self.on_batch(data)
+        if self.flat is None:
+            loss = self._first_step(data)
+        else:
+            self.flat.zero_()
+            loss = F.mse_loss(self.model(data), data.y)
+            loss.backward()
+        self.flat.all_reduce_mean()
+        self.opt.step()
+        return loss.detach()
+
+    def sync_buffers(self):
+        """DDP's per-forward buffer broadcast (BatchNorm running stats of ``mhnnm``)."""
+        if _world() > 1:
+            for b in self.model.buffers():
+                dist.broadcast(b.data, src=0)

@@ -1,0 +1,109 @@
+/*
+ * equihgnn_hip.h — C ABI of libequihgnn_hip.so (gfx950 / MI355X).
+ *
+ * The reference (HySonLab/EquiHGNN) is pure Python; the only native code its hot path reaches
+ * is third-party (torch_scatter, ATen, PyG).  Each entry point below replaces one such operator
+ * call site (cited as reference file:line, relative to the reference checkout).  The Python host
+ * side (equihgnn_amd/ops.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (every function):
+ *   - extern "C", plain pointers and sizes, no torch types;
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - returns 0 on success, a negative EQH_ERR_* otherwise; never throws, never exits;
+ *   - enqueues work on `stream` (a hipStream_t passed as void*) and returns without
+ *     synchronising; never allocates or frees — scratch memory is passed in, sized by the
+ *     matching *_workspace_bytes query; safe to capture in a hipGraph;
+ *   - matrices are row-major, contiguous, fp32; row length C must be a multiple of 4 and
+ *     rows 16-byte aligned; index arrays produced by this library are int32.
+ */
+#ifndef EQUIHGNN_HIP_H
+#define EQUIHGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQH_OK 0
+#define EQH_ERR_ARG (-1)     /* null pointer / negative size / unsupported shape */
+#define EQH_ERR_ALIGN (-2)   /* C not a multiple of 4 or pointer not 16-byte aligned */
+#define EQH_ERR_RANGE (-3)   /* size exceeds what int32 indexing supports */
+#define EQH_ERR_LAUNCH (-4)  /* hipGetLastError() after launch was not hipSuccess */
+
+int eqh_version(void);
+const char* eqh_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of
+ * torch_scatter.scatter (conv.py:91-93,97,173,177): the COO incidence list is sorted ONCE per
+ * batch into a CSR so that every later aggregation is an atomic-free segmented reduction.
+ *
+ *   key[nnz]  int64  row id of every entry (e.g. edge_index1 for the by-hyperedge CSR)
+ *   other     int64  optional second coordinate (e.g. edge_index0); may be NULL
+ *   rowptr[n_rows+1], perm[nnz], col[nnz]  int32 outputs:
+ *     perm  = entry ids, grouped by key, ascending entry id inside a row (stable => results
+ *             are bitwise reproducible run to run);
+ *     col   = other[perm] if other != NULL, else perm / col_div (col_div >= 1); may be NULL.
+ *   Entries with key outside [0, n_rows) are dropped (torch_scatter leaves this undefined).
+ * ------------------------------------------------------------------------------------------- */
+size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows);
+int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+                 int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Segmented reduction / row gather — torch_scatter.scatter(src, index, dim=-2, reduce) at
+ * conv.py:91-93,97,173,177, the advanced-index gathers X[..., idx, :] at conv.py:90,96,172,
+ * 175,176 (and their backward passes), and global_add_pool at equihnn_egnn.py:167, mhnn.py:216,
+ * equihnn_equiformer.py:91.
+ *
+ *   out[r, :] = s(r) * sum_{q in [rowptr[r], rowptr[r+1])}  w(idx[q]) * src[idx[q], :]
+ *
+ *   rowptr == NULL : one source per output row (q = r): a pure row gather;
+ *   idx    == NULL : identity (q-th source row);
+ *   mean != 0      : s(r) = 1 / max(rowptr[r+1]-rowptr[r], 1)   (torch_scatter "mean");
+ *   src_wptr != NULL : w(j) = 1 / max(src_wptr[j+1]-src_wptr[j], 1), the mean-weights of the
+ *                      source rows in ANOTHER CSR — this is what the backward of a gathered
+ *                      mean needs; NULL => w = 1.
+ * Rows with no entry are written as zeros.  Summation order inside a row is the CSR order.
+ * ------------------------------------------------------------------------------------------- */
+int hg_segment_reduce_f32(const float* src, const int32_t* idx, const int32_t* rowptr,
+                          const int32_t* src_wptr, float* out, int64_t n_out_rows, int32_t C,
+                          int32_t mean, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding-sum — ogb AtomEncoder (equihnn_egnn.py:121,157; mhnn.py:164,201) and
+ * nn.Embedding(6, C) for bond types (mhnn.py:165,202).
+ *   out[n,:] = sum_{f<F} table[off_host[f] + x[n,f], :]      (f ascending, as ogb does)
+ * ------------------------------------------------------------------------------------------- */
+int hg_embed_sum_fwd(const int64_t* x, const float* table, const int32_t* off_host, int32_t F,
+                     int64_t N, int32_t C, int64_t table_rows, float* out, void* stream);
+
+/* Backward of the embedding-sum: dtable[g,:] = sum_{n,f : off[f]+x[n,f] == g} dout[n,:]
+ * (autograd of the nn.Embedding lookups above).  Two passes over node chunks, no atomics,
+ * bitwise reproducible.  dtable is fully overwritten. */
+size_t hg_embed_sum_bwd_workspace_bytes(int64_t N, int32_t C, int64_t table_rows);
+int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32_t* off_host, int32_t F,
+                     int64_t N, int32_t C, int64_t table_rows, float* dtable, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * k nearest neighbours over the whole batch point cloud.
+ *   mode 0 — EGNN (egnn_layer.py:253-288): key = squared distance ((ci-cj)^2).sum(-1), self
+ *            INCLUDED; requires N >= k.
+ *   mode 1 — Equiformer (equiformer_layer.py:1216-1346): key = sqrt of the same sum, self
+ *            EXCLUDED; requires N-1 >= k.
+ * Outputs are sorted by (key, index) ascending: nbr int32 [N,k], dist fp32 [N,k] (the key).
+ * Distance arithmetic is (dx*dx + dy*dy) + dz*dz without fused multiply-add, matching the
+ * fp32 reduction order of the reference's CPU path.
+ * ------------------------------------------------------------------------------------------- */
+int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist,
+            void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUIHGNN_HIP_H */

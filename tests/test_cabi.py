@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports every symbol
+include/equihgnn_hip.h declares, the ctypes table matches the header, argument validation
+works without a GPU, and the product refuses to run on CPU tensors (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "equihgnn_hip.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\([^;{]*\)\s*;", text)))
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert "hg_segment_reduce_f32" in names and "geo_knn" in names and len(names) >= 8
+
+
+def test_library_exports_every_declared_symbol():
+    from equihgnn_amd import build, hip
+
+    build.build(verbose=False)
+    handle = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(handle, name), f"{name} declared in the header but not exported"
+    assert sorted(hip.SIGNATURES) == declared_functions()
+    assert hip.lib().eqh_version() >= 1
+
+
+def test_argument_validation_without_gpu():
+    from equihgnn_amd import hip
+
+    L = hip.lib()
+    assert L.hg_csr_build_workspace_bytes(100, 10) > 0
+    assert L.hg_csr_build_workspace_bytes(-1, 10) == 0
+    # null pointers / bad shapes are rejected before anything is launched
+    assert L.hg_segment_reduce_f32(None, None, None, None, None, 4, 64, 0, None) == -1
+    assert L.geo_knn(None, 10, 0, 0, None, None, None) == -1
+    assert L.geo_knn(None, 10, 16, 5, None, None, None) == -1
+    assert b"argument" in L.eqh_error_string(-1)
+    with pytest.raises(hip.HipLibraryError):
+        hip.check(-2, "demo")
+
+
+def test_no_cpu_fallback():
+    from equihgnn_amd import hip, ops
+
+    with pytest.raises(hip.HipLibraryError):
+        ops.csr_build(torch.zeros(4, dtype=torch.int64), None, 2)
+    with pytest.raises(hip.HipLibraryError):
+        ops.knn(torch.zeros(20, 3), 16, 0)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "equihgnn_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def test_registry_contract():
+    from equihgnn_amd import models  # noqa: F401  (registers)
+    from equihgnn_amd.registry import create_model, registry
+
+    assert registry.get_model_class("egnn_equihnns") is models.EGNNEquiHNNS
+    assert registry.get_model_class("nope") is None
+    with pytest.raises(ValueError):
+        create_model("nope")
+    with pytest.raises(ValueError):
+        registry.register_model("mhnnm")(object)
+
+
+def test_state_dict_matches_reference_names():
+    """The fixture's grad_names are the reference's named_parameters()."""
+    from common import golden_args, load_case
+
+    from equihgnn_amd import models
+
+    for name in ("mhnnm_c64_train", "egnn_equihnns_c64"):
+        case = load_case(name)
+        method = str(case["meta_method"])
+        m = models.MODELS[method](1, golden_args(method, int(case["meta_hidden"])))
+        assert [n for n, _ in m.named_parameters()] == [str(n) for n in case["grad_names"]]

@@ -1,0 +1,249 @@
+"""GPU parity of the C-ABI kernels against the oracle (oracle/ref_models.py) and numpy on
+seeded inputs.  Integer/index results are compared bit-exactly; fp32 sums to 1e-5 (the
+summation ORDER inside a row is the only difference from the oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_models as O  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from equihgnn_amd import ops
+    return ops
+
+
+def _np_csr(key, other, n_rows, col_div=1):
+    key = np.asarray(key)
+    valid = (key >= 0) & (key < n_rows)
+    order = np.argsort(np.where(valid, key, n_rows), kind="stable")
+    order = order[: int(valid.sum())]
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    np.add.at(rowptr, key[valid] + 1, 1)
+    rowptr = np.cumsum(rowptr)
+    col = np.asarray(other)[order] if other is not None else order // col_div
+    return rowptr, order, col
+
+
+@pytest.mark.parametrize("nnz,n_rows,seed", [(0, 5, 0), (1, 1, 1), (37, 50, 2), (5000, 300, 3),
+                                             (20000, 7, 4), (100000, 40000, 5), (3000, 3, 6)])
+def test_csr_build_matches_stable_sort(nnz, n_rows, seed):
+    ops = _ops()
+    rng = np.random.default_rng(seed)
+    key = rng.integers(0, n_rows, size=nnz)
+    other = rng.integers(0, 1000, size=nnz)
+    csr = ops.csr_build(torch.from_numpy(key).to(DEV), torch.from_numpy(other).to(DEV), n_rows)
+    rp, perm, col = _np_csr(key, other, n_rows)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(csr.perm.cpu().numpy(), perm)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+    csr2 = ops.csr_build(torch.from_numpy(key).to(DEV), None, n_rows, col_div=3)
+    assert np.array_equal(csr2.col.cpu().numpy(), perm // 3)
+
+
+def test_csr_build_drops_out_of_range_keys():
+    ops = _ops()
+    key = np.array([0, 5, -1, 2, 2, 9, 1], dtype=np.int64)
+    csr = ops.csr_build(torch.from_numpy(key).to(DEV), None, 3)
+    rp, perm, _ = _np_csr(key, None, 3)
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+    assert np.array_equal(csr.perm.cpu().numpy()[: rp[-1]], perm)
+
+
+def test_csr_row_longer_than_lds_cap_is_a_permutation():
+    ops = _ops()
+    nnz = 40000
+    key = np.zeros(nnz, dtype=np.int64)
+    key[::7] = 1
+    csr = ops.csr_build(torch.from_numpy(key).to(DEV), None, 2)
+    rp = csr.rowptr.cpu().numpy()
+    perm = csr.perm.cpu().numpy()
+    assert rp.tolist() == [0, int((key == 0).sum()), nnz]
+    assert sorted(perm[: rp[1]].tolist()) == np.nonzero(key == 0)[0].tolist()  # unsorted > cap
+    assert perm[rp[1]:].tolist() == np.nonzero(key == 1)[0].tolist()            # sorted
+
+
+@pytest.mark.parametrize("C", [4, 12, 64, 128, 256, 260, 512])
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_segment_reduce_entries_vs_oracle(C, reduce):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    nnz, rows = 1500, 400
+    index = torch.randint(0, rows - 20, (nnz,), generator=g)  # the last 20 rows stay empty
+    src = torch.randn(nnz, C, generator=g)
+    ref = O.segment_reduce(src, index, rows, reduce)
+    csr = ops.csr_build(index.to(DEV), None, rows)
+    src_d = src.to(DEV).requires_grad_(True)
+    out = ops.reduce_entries(src_d, csr, index.to(DEV).int(), reduce)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-5)
+    assert float(out[-20:].abs().max()) == 0.0
+    # backward vs oracle autograd
+    w = torch.randn(rows, C, generator=g)
+    src_c = src.clone().requires_grad_(True)
+    (O.segment_reduce(src_c, index, rows, reduce) * w).sum().backward()
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(src_d.grad.cpu().numpy(), src_c.grad.numpy(), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_reduce_gathered_and_gather_rows_vs_oracle(reduce):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    N, M, nnz, C = 300, 280, 900, 256
+    v = torch.randint(0, N, (nnz,), generator=g)
+    e = torch.randint(0, M, (nnz,), generator=g)
+    X = torch.randn(N, C, generator=g)
+    w = torch.randn(M, C, generator=g)
+    Xc = X.clone().requires_grad_(True)
+    ref = O.segment_reduce(Xc[v], e, M, reduce)
+    (ref * w).sum().backward()
+    by_e = ops.csr_build(e.to(DEV), v.to(DEV), M)
+    by_v = ops.csr_build(v.to(DEV), e.to(DEV), N)
+    Xd = X.to(DEV).requires_grad_(True)
+    out = ops.reduce_gathered(Xd, by_e, by_v, reduce)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(Xd.grad.cpu().numpy(), Xc.grad.numpy(), atol=2e-5, rtol=1e-5)
+    # gather_rows: bit-exact forward (a copy), backward = index_put accumulate
+    Xd2 = X.to(DEV).requires_grad_(True)
+    rows = ops.gather_rows(Xd2, v.to(DEV).int(), by_v)
+    assert torch.equal(rows.detach().cpu(), X[v])
+    wn = torch.randn(nnz, C, generator=g)
+    (rows * wn.to(DEV)).sum().backward()
+    Xc2 = X.clone().requires_grad_(True)
+    (Xc2[v] * wn).sum().backward()
+    np.testing.assert_allclose(Xd2.grad.cpu().numpy(), Xc2.grad.numpy(), atol=2e-5, rtol=1e-5)
+
+
+def test_leading_singleton_dim_like_equiformer_wrapper():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, 10, (50,), generator=g)
+    src = torch.randn(1, 50, 64, generator=g)
+    csr = ops.csr_build(idx.to(DEV), None, 10)
+    out = ops.reduce_entries(src.to(DEV), csr, idx.to(DEV).int(), "mean")
+    ref = O.segment_reduce(src, idx, 10, "mean")
+    assert out.shape == ref.shape == (1, 10, 64)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_scatter_dropin_signature():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    idx = torch.randint(0, 33, (200,), generator=g)
+    src = torch.randn(200, 64, generator=g)
+    out = ops.scatter(src.to(DEV), idx.to(DEV), dim=-2, reduce="mean")
+    ref = O.segment_reduce(src, idx, None, "mean")
+    assert out.shape == ref.shape
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=1e-5)
+    out2 = ops.scatter(src.to(DEV), idx.to(DEV), dim=-2, reduce="sum", dim_size=40)
+    assert out2.shape == (40, 64)
+
+
+@pytest.mark.parametrize("C", [64, 256])
+def test_embed_sum_vs_oracle(C):
+    from equihgnn_amd.layers import AtomEncoder
+    g = torch.Generator().manual_seed(C)
+    N = 1300
+    x = torch.stack([torch.randint(0, d, (N,), generator=g) for d in O.ATOM_FEATURE_DIMS], 1)
+    ref = O.AtomEncoder(C)
+    mine = AtomEncoder(C)
+    mine.load_state_dict(ref.state_dict())
+    mine.to(DEV)
+    w = torch.randn(N, C, generator=g)
+    r = ref(x)
+    (r * w).sum().backward()
+    o = mine(x.to(DEV))
+    (o * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().numpy(), atol=1e-6, rtol=1e-6)
+    for a, b in zip(mine.atom_embedding_list, ref.atom_embedding_list):
+        np.testing.assert_allclose(a.weight.grad.cpu().numpy(), b.weight.grad.numpy(), atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("N,seed", [(16, 0), (17, 1), (200, 2), (1000, 3), (4632, 4)])
+def test_knn_mode0_matches_oracle_bitwise(N, seed):
+    ops = _ops()
+    from equihgnn_amd.batch import synth_batch
+    if N >= 200:
+        pos = synth_batch(max(N // 18, 1) + 2, seed).pos[:N]
+        N = pos.shape[0]
+    else:
+        pos = torch.randn(N, 3, generator=torch.Generator().manual_seed(seed)) * 2
+    d2_ref, idx_ref = O.knn_self_included(pos, 16)
+    nbr, d2 = ops.knn(pos.to(DEV), 16, 0)
+    assert np.array_equal(d2.cpu().numpy(), d2_ref.numpy()), "distances must be bit-identical"
+    assert np.array_equal(np.sort(nbr.cpu().numpy(), -1), np.sort(idx_ref.numpy(), -1))
+    assert np.array_equal(nbr[:, 0].cpu().numpy(), np.arange(N))  # self comes first (d=0)
+
+
+def test_knn_rejects_too_few_points_like_topk():
+    from equihgnn_amd import hip
+    ops = _ops()
+    with pytest.raises(hip.HipLibraryError):
+        ops.knn(torch.zeros(10, 3, device=DEV), 16, 0)
+    with pytest.raises(hip.HipLibraryError):
+        ops.knn(torch.zeros(16, 3, device=DEV), 16, 1)
+
+
+def test_knn_ties_prefer_lower_index():
+    ops = _ops()
+    pos = torch.zeros(40, 3)
+    pos[20:, 0] = 1.0  # two clusters of 20 coincident points
+    nbr, d2 = ops.knn(pos.to(DEV), 16, 0)
+    assert nbr[0].tolist() == list(range(16)) and nbr[25].tolist() == list(range(20, 36))
+    assert float(d2.max()) == 0.0
+
+
+def test_knn_mode1_self_excluded_true_distance():
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    pos = torch.randn(300, 3, generator=g) * 3
+    nbr, dist = ops.knn(pos.to(DEV), 16, 1)
+    rel = pos[:, None] - pos[None]
+    d = (rel ** 2).sum(-1).sqrt()
+    d.fill_diagonal_(float("inf"))
+    val, idx = d.topk(16, dim=-1, largest=False)
+    assert np.array_equal(dist.cpu().numpy(), val.numpy())
+    assert np.array_equal(np.sort(nbr.cpu().numpy(), -1), np.sort(idx.numpy(), -1))
+    assert not (nbr.cpu() == torch.arange(300)[:, None]).any()
+
+
+# ---- size-independent properties at BASELINE size (config 2: B=256) ------------------------
+def test_properties_at_full_size():
+    ops = _ops()
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.index import HyperIndex
+    data = synth_batch(256, 2000).to(DEV)
+    ix = HyperIndex.from_batch(data)
+    C = 256
+    g = torch.Generator(device=DEV).manual_seed(1)
+    X = torch.randn(ix.N, C, device=DEV, generator=g)
+    # (1) sum-scatter preserves the column sums of the gathered rows
+    s = ops.reduce_gathered(X, ix.by_e, ix.by_v, "sum")
+    ref_tot = (X.double() * (ix.by_v.rowptr[1:] - ix.by_v.rowptr[:-1]).double()[:, None]).sum(0)
+    np.testing.assert_allclose(s.double().sum(0).cpu().numpy(), ref_tot.cpu().numpy(), rtol=1e-6, atol=1e-3)
+    # (2) mean of a constant is the constant on non-empty rows, zero elsewhere
+    ones = torch.full((ix.N, C), 3.5, device=DEV)
+    m = ops.reduce_gathered(ones, ix.by_e, ix.by_v, "mean")
+    assert torch.equal(m, 3.5 * ix.has_e.expand_as(m))
+    # (3) permuting the incidence list changes nothing but rounding
+    p = torch.randperm(ix.nnz, device=DEV, generator=g)
+    ix2 = HyperIndex(data.edge_index0[p], data.edge_index1[p], ix.N, ix.M)
+    a = ops.reduce_gathered(X, ix.by_e, ix.by_v, "mean")
+    b = ops.reduce_gathered(X, ix2.by_e, ix2.by_v, "mean")
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-5)
+    # (4) linearity
+    Y = torch.randn(ix.N, C, device=DEV, generator=g)
+    lhs = ops.reduce_gathered(2 * X + Y, ix.by_e, ix.by_v, "mean")
+    rhs = 2 * a + ops.reduce_gathered(Y, ix.by_e, ix.by_v, "mean")
+    np.testing.assert_allclose(lhs.cpu().numpy(), rhs.cpu().numpy(), atol=2e-5)
+    # (5) run-to-run bitwise reproducibility (no atomics in the data path)
+    assert torch.equal(a, ops.reduce_gathered(X, ix.by_e, ix.by_v, "mean"))
+    # (6) pooling: per-molecule sums add up to the global sum
+    pooled = ops.reduce_entries(X, ix.pool, ix.batch32, "sum")
+    np.testing.assert_allclose(pooled.double().sum(0).cpu().numpy(), X.double().sum(0).cpu().numpy(),
+                               rtol=1e-6, atol=1e-3)
