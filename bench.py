@@ -112,12 +112,27 @@ def measure_scatter_roofline(model, batch, dev):
             "alg_bytes_per_launch": int(tot_bytes / n)}
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the
+    GPU box exposes 256 logical CPUs but grants a 16-core share per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    if os.environ.get("EQH_CPU_CORES"):
+        n = int(os.environ["EQH_CPU_CORES"])
+    return max(1, min(n, 16 if n > 64 else n))
+
+
 def cpu_baseline(method, args_ns, batch_cpu, seconds):
     """The oracle (kind "port": this repo's CPU restatement, pinned to the reference by the
     golden vectors) timed on the host cores: same batch shape, same full training step."""
     from oracle import ref_models as O
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     model = O.MODELS[method](1, args_ns)
@@ -129,14 +144,16 @@ def cpu_baseline(method, args_ns, batch_cpu, seconds):
         loss.backward()
         opt.step()
 
+    tw = time.perf_counter()
     step()  # warm-up
+    tw = time.perf_counter() - tw
     t0 = time.perf_counter()
     n = 0
     while True:
         step()
         n += 1
         el = time.perf_counter() - t0
-        if (el >= seconds and n >= 2) or n >= 50:
+        if el >= seconds or n >= 50 or (tw > seconds and n >= 1):
             break
     mol_s = n * batch_cpu.y.shape[0] / el
     return {"value": round(mol_s, 2), "unit": "molecules/s", "cores": cores, "kind": "port",

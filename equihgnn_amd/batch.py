@@ -173,7 +173,10 @@ def synth_molecule(rng: np.random.Generator, flavour: str = "qm9",
     for a in range(1, n):
         u = rng.normal(size=3)
         u /= np.linalg.norm(u)
-        pos[a] = pos[parent[a]] + 1.4 * u
+        # bond length 1.4 A +- 0.1: a constant length would make the squared distances of all
+        # bonded pairs EXACTLY equal in fp32, and torch.topk's choice among exact ties at the
+        # k-th neighbour is implementation-defined (see tests: test_knn_ties_prefer_lower_index)
+        pos[a] = pos[parent[a]] + (1.4 + 0.1 * rng.uniform(-1.0, 1.0)) * u
     pos -= pos.mean(0, keepdims=True)
     return HMol(x=x, pos=pos.astype(np.float32), edge_index0=v, edge_index1=e,
                 edge_attr=edge_attr, e_order=e_order, y=float(rng.normal()))

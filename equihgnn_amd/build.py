@@ -48,6 +48,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(bdir, exist_ok=True)
     hipcc = _hipcc()
     common = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", INCLUDE, "-I", CSRC,
+              "-ffp-contract=off",  # a*b+c stays two roundings unless written fmaf(): the kNN
+                                    # distances must match the reference's fp32 CPU arithmetic
               "-Wall", "-Wno-unused-function"]
     procs = []
     for src in sources():

@@ -207,7 +207,8 @@ def test_knn_mode1_self_excluded_true_distance():
     d = (rel ** 2).sum(-1).sqrt()
     d.fill_diagonal_(float("inf"))
     val, idx = d.topk(16, dim=-1, largest=False)
-    assert np.array_equal(dist.cpu().numpy(), val.numpy())
+    # sqrt may differ by one ulp between the host libm and the device; the neighbour SETS agree
+    np.testing.assert_allclose(dist.cpu().numpy(), val.numpy(), rtol=2e-7, atol=0)
     assert np.array_equal(np.sort(nbr.cpu().numpy(), -1), np.sort(idx.numpy(), -1))
     assert not (nbr.cpu() == torch.arange(300)[:, None]).any()
 

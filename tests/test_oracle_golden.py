@@ -23,10 +23,12 @@ def build(case, models=ref_models.MODELS):
     return model
 
 
-def check_against_case(model, case, data, tol=TOL, taps=True):
+def check_against_case(model, case, data, tol=TOL, taps=True, grad_rtol=1e-4):
     tp = {} if taps else None
     out = model(data, taps=tp) if taps else model(data)
-    np.testing.assert_allclose(out.detach().cpu().numpy(), case["out"], atol=tol, rtol=0)
+    # 1e-5 on O(1) outputs (north_star); outputs larger than 1 get the same RELATIVE budget
+    oscale = max(1.0, float(np.abs(case["out"]).max()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), case["out"], atol=tol * oscale, rtol=0)
     if taps:
         for k, v in tp.items():
             key = "tap_" + k
@@ -56,13 +58,14 @@ def check_against_case(model, case, data, tol=TOL, taps=True):
         if "grad_" + n in case:
             ref = case["grad_" + n]
             scale = max(floor, float(np.abs(ref).max()))
-            np.testing.assert_allclose(g.numpy(), ref, atol=10 * tol * scale, rtol=0, err_msg=n)
+            np.testing.assert_allclose(g.numpy(), ref, atol=grad_rtol * scale, rtol=0, err_msg=n)
         else:
             ref = case["gradhead_" + n]
             scale = max(floor, float(st[2]))
-            np.testing.assert_allclose(g.reshape(-1)[: ref.size].numpy(), ref, atol=10 * tol * scale,
+            np.testing.assert_allclose(g.reshape(-1)[: ref.size].numpy(), ref, atol=grad_rtol * scale,
                                        rtol=0, err_msg=n)
-            np.testing.assert_allclose(float(g.norm()), st[2], rtol=1e-4, atol=10 * tol * floor, err_msg=n)
+            np.testing.assert_allclose(float(g.norm()), st[2], rtol=10 * grad_rtol, atol=grad_rtol * floor,
+                                       err_msg=n)
 
 
 @pytest.mark.parametrize("name", CASES)
