@@ -1,0 +1,361 @@
+// Fused EGNN edge update (forward + backward) for k = 16 neighbours and m_dim = 16.
+//
+// Replaces, for the configuration equihnn_egnn.py:123-129 uses, the reference's
+//   feats_j = batched_index_select(feats, nbhd)            egnn_layer.py:298 (+ :18-32)
+//   edge_input = cat(feats_i, feats_j, rel_dist)           egnn_layer.py:302-305
+//   m_ij = edge_mlp(edge_input)                            egnn_layer.py:180-186,310
+//   m_i = m_ij.sum(dim=-2)                                 egnn_layer.py:357-358
+// and the autograd of all four (whose gather-backward allocates zeros[1,N,N,C] in the reference).
+//
+// Formulation.  The first edge Linear is split by input block,
+//   h_ij = W1·cat(f_i, f_j, d2_ij) + b1 = A[i] + B[j] + wd·d2_ij,   A = f·W1iᵀ + b1,  B = f·W1jᵀ
+// with A and B produced at NODE level by one library GEMM (`ab` = [A | B], row stride 2·Hp).  This
+// kernel then does, per node i, for its 16 neighbours j and the Hp hidden units (H = 2(2C+1)
+// zero-padded to a multiple of 16; silu(0) = 0 so the padding is inert):
+//   s_ij = silu(h_ij);  pre2_ij = W2·s_ij + b2  (a 16 x Hp x 16 product per node -> fp32 MFMA
+//   16x16x4, edges on the M axis, outputs on the N axis);  m_i = Σ_j silu(pre2_ij).
+// h and s (N·16·Hp floats, 0.3 GB at the BASELINE batch) never touch memory: the backward
+// recomputes them from `ab`.
+//
+// One 64-lane wavefront per node.  MFMA lane map (guide §3): lane l -> r = l & 15, q = l >> 4;
+// A operand A[row r][k q], B operand B[k q][col r], accumulator reg g <-> (row 4q+g, col r).
+// The K index of every product below is permuted so that each lane consumes 4 CONSECUTIVE hidden
+// units (one float4 load) per four MFMAs.
+//
+// Backward: pass 1 (by receiver i) gives dA, dW2, dwd and stores dpre2; pass 2 (by sender j, over
+// the transposed neighbour CSR) gives dB.  No atomics; per-block partial slabs are reduced by a
+// third kernel in block order, so every result is bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KNB = 16;    // neighbours per node
+constexpr int MDIM = 16;   // m_dim
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+constexpr int BWD_CHUNK = 16;  // nodes per workgroup in backward pass 1
+constexpr int PLD = 20;        // LDS row stride (floats) of the 16x16 dpre2 tiles: 16 + 4 pad
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// sigmoid via v_exp_f32 / v_rcp_f32 (each ~1 ulp); silu(x) = x * sigmoid(x)
+__device__ __forceinline__ float sigmoid_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+__device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
+// returns silu(x) and writes d silu / dx = sig + silu*(1 - sig)
+__device__ __forceinline__ float silu_grad(float x, float* ds) {
+    const float sig = sigmoid_fast(x);
+    const float s = x * sig;
+    *ds = fmaf(s, 1.0f - sig, sig);
+    return s;
+}
+
+__host__ __device__ inline int lds_row_stride(int Hp) {  // (stride mod 64) == 24: conflict-free b128
+    return Hp + ((24 - (Hp & 63)) + 64) % 64;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_edge_fwd(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
+           const float* __restrict__ b2, const int* __restrict__ nbr, const float* __restrict__ d2,
+           float* __restrict__ m, float* __restrict__ pre2, int N, int Hp) {
+    extern __shared__ float s_w2[];  // [16][ldw]
+    const int ldw = lds_row_stride(Hp);
+    for (int idx = threadIdx.x * 4; idx < MDIM * Hp; idx += THREADS * 4) {
+        const int o = idx / Hp, k = idx - o * Hp;
+        *reinterpret_cast<float4*>(s_w2 + o * ldw + k) = *reinterpret_cast<const float4*>(w2 + idx);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int steps = Hp >> 4;
+    const float bo = b2[r];
+    for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
+        const int j = nbr[node * KNB + r];
+        const float dd = d2[node * KNB + r];
+        const float* __restrict__ arow = ab + (int64_t)node * 2 * Hp + 4 * q;
+        const float* __restrict__ brow = ab + (int64_t)j * 2 * Hp + Hp + 4 * q;
+        const float* __restrict__ wrow = s_w2 + r * ldw + 4 * q;
+        const float* __restrict__ wdp = wd + 4 * q;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+
+        for (int t = 0; t < steps; ++t) {
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * t);
+            const float4 b4 = *reinterpret_cast<const float4*>(brow + 16 * t);
+            const float4 c4 = *reinterpret_cast<const float4*>(wdp + 16 * t);
+            const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * t);
+            acc = mfma16(silu_fast(fmaf(c4.x, dd, a4.x + b4.x)), w4.x, acc);
+            acc = mfma16(silu_fast(fmaf(c4.y, dd, a4.y + b4.y)), w4.y, acc);
+            acc = mfma16(silu_fast(fmaf(c4.z, dd, a4.z + b4.z)), w4.z, acc);
+            acc = mfma16(silu_fast(fmaf(c4.w, dd, a4.w + b4.w)), w4.w, acc);
+        }
+        // acc[g] = pre2[j = 4q+g][o = r] (before bias)
+        float msum = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float p = acc[g] + bo;
+            pre2[(int64_t)node * (KNB * MDIM) + (4 * q + g) * MDIM + r] = p;
+            msum += silu_fast(p);
+        }
+        msum += __shfl_xor(msum, 16, 64);
+        msum += __shfl_xor(msum, 32, 64);
+        if (q == 0) m[(int64_t)node * MDIM + r] = msum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 1: by receiver node.  One workgroup owns BWD_CHUNK consecutive nodes; wave w owns
+// the hidden tiles t = w, w+4, ... (16 hidden units each) for ALL nodes of the chunk, so its dW2 /
+// dwd tile accumulators stay in registers across the chunk and need no cross-wave reduction.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd,
+                const float* __restrict__ w2, const int* __restrict__ nbr,
+                const float* __restrict__ d2, const float* __restrict__ pre2,
+                const float* __restrict__ dm, float* __restrict__ dpre2_out,
+                float* __restrict__ dab, float* __restrict__ slab_w2, float* __restrict__ slab_wd,
+                int N, int Hp) {
+    __shared__ __attribute__((aligned(16))) float s_p[BWD_CHUNK][KNB * PLD];   // dpre2[n][j][o]
+    __shared__ __attribute__((aligned(16))) float s_pt[BWD_CHUNK][MDIM * PLD];  // dpre2[n][o][j]
+    __shared__ int s_nbr[BWD_CHUNK][KNB];
+    __shared__ float s_d2[BWD_CHUNK][KNB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int base = blockIdx.x * BWD_CHUNK;
+    const int cnt = (N - base < BWD_CHUNK) ? (N - base) : BWD_CHUNK;
+
+    // phase A: dpre2 = dm * silu'(pre2), one float4 (4 consecutive o of one j) per lane
+    for (int n = wave; n < cnt; n += WAVES) {
+        const int node = base + n;
+        const int jj = lane >> 2, o0 = (lane & 3) * 4;
+        const float4 p4 = *reinterpret_cast<const float4*>(pre2 + (int64_t)node * 256 + lane * 4);
+        const float4 g4 = *reinterpret_cast<const float4*>(dm + (int64_t)node * MDIM + o0);
+        float ds;
+        float4 d4;
+        silu_grad(p4.x, &ds); d4.x = g4.x * ds;
+        silu_grad(p4.y, &ds); d4.y = g4.y * ds;
+        silu_grad(p4.z, &ds); d4.z = g4.z * ds;
+        silu_grad(p4.w, &ds); d4.w = g4.w * ds;
+        *reinterpret_cast<float4*>(&s_p[n][jj * PLD + o0]) = d4;
+        s_pt[n][(o0 + 0) * PLD + jj] = d4.x;
+        s_pt[n][(o0 + 1) * PLD + jj] = d4.y;
+        s_pt[n][(o0 + 2) * PLD + jj] = d4.z;
+        s_pt[n][(o0 + 3) * PLD + jj] = d4.w;
+        *reinterpret_cast<float4*>(dpre2_out + (int64_t)node * 256 + lane * 4) = d4;
+        if (lane < KNB) {
+            s_nbr[n][lane] = nbr[node * KNB + lane];
+            s_d2[n][lane] = d2[node * KNB + lane];
+        }
+    }
+    __syncthreads();
+
+    // phase B
+    const int tiles = Hp >> 4;
+    for (int t = wave; t < tiles; t += WAVES) {
+        const int k = 16 * t + r;  // this lane's hidden unit
+        float wv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wv[s] = w2[(4 * q + s) * Hp + k];
+        const float wdk = wd[k];
+        f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};  // dW2[o = 4q+g][k]
+        float acc_wd = 0.f;
+        for (int n = 0; n < cnt; ++n) {
+            const int node = base + n;
+            // g[j = 4q+g][k] = sum_o dpre2[j][o] * W2[o][k]
+            const float4 pa = *reinterpret_cast<const float4*>(&s_p[n][r * PLD + 4 * q]);
+            f32x4 gk = {0.f, 0.f, 0.f, 0.f};
+            gk = mfma16(pa.x, wv[0], gk);
+            gk = mfma16(pa.y, wv[1], gk);
+            gk = mfma16(pa.z, wv[2], gk);
+            gk = mfma16(pa.w, wv[3], gk);
+            const float ai = ab[(int64_t)node * 2 * Hp + k];
+            float sv[4];
+            float da = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jn = s_nbr[n][4 * q + g];
+                const float dd = s_d2[n][4 * q + g];
+                const float h = fmaf(wdk, dd, ai + ab[(int64_t)jn * 2 * Hp + Hp + k]);
+                float ds;
+                sv[g] = silu_grad(h, &ds);
+                const float dh = gk[g] * ds;
+                da += dh;
+                acc_wd = fmaf(dh, dd, acc_wd);
+            }
+            da += __shfl_xor(da, 16, 64);
+            da += __shfl_xor(da, 32, 64);
+            if (q == 0) dab[(int64_t)node * 2 * Hp + k] = da;
+            // dW2[o][k] += sum_j dpre2[j][o] * s[j][k]
+            const float4 pt = *reinterpret_cast<const float4*>(&s_pt[n][r * PLD + 4 * q]);
+            acc_w = mfma16(pt.x, sv[0], acc_w);
+            acc_w = mfma16(pt.y, sv[1], acc_w);
+            acc_w = mfma16(pt.z, sv[2], acc_w);
+            acc_w = mfma16(pt.w, sv[3], acc_w);
+        }
+        float* __restrict__ sw = slab_w2 + (int64_t)blockIdx.x * MDIM * Hp;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sw[(4 * q + g) * Hp + k] = acc_w[g];
+        acc_wd += __shfl_xor(acc_wd, 16, 64);
+        acc_wd += __shfl_xor(acc_wd, 32, 64);
+        if (q == 0) slab_wd[(int64_t)blockIdx.x * Hp + k] = acc_wd;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward pass 2: by sender node j, over the transposed neighbour CSR (entries e = i*16 + slot).
+// dB[j][k] = sum over in-edges of g_e[k] * silu'(h_e[k]).  One wavefront per sender; in-edges are
+// consumed 16 at a time (one MFMA tile); groups after the first accumulate into the row this wave
+// owns exclusively.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(THREADS)
+k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
+                const float* __restrict__ w2, const float* __restrict__ d2,
+                const float* __restrict__ dpre2, const int* __restrict__ t_rowptr,
+                const int* __restrict__ t_perm, float* __restrict__ dab, int N, int Hp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int tiles = Hp >> 4;
+    for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
+        const int beg = t_rowptr[node], end = t_rowptr[node + 1];
+        float* __restrict__ drow = dab + (int64_t)node * 2 * Hp + Hp;
+        const float* __restrict__ brow = ab + (int64_t)node * 2 * Hp + Hp;
+        if (beg == end) {
+            for (int k = lane; k < Hp; k += 64) drow[k] = 0.f;
+            continue;
+        }
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            const bool first = (g0 == beg);
+            // entry owned by lane r (as MFMA row), replicated over q
+            const int e_r = (g0 + r < end) ? t_perm[g0 + r] : -1;
+            // the four entries whose results land in this lane: rows 4q+g
+            int e_g[4];
+            float dd_g[4];
+            int64_t arow_g[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                e_g[g] = __shfl(e_r, 4 * q + g, 64);
+                dd_g[g] = e_g[g] >= 0 ? d2[e_g[g]] : 0.f;
+                arow_g[g] = (int64_t)(e_g[g] >= 0 ? (e_g[g] >> 4) : 0) * 2 * Hp;
+            }
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e_r >= 0) pa = *reinterpret_cast<const float4*>(dpre2 + (int64_t)e_r * MDIM + 4 * q);
+            for (int t = 0; t < tiles; ++t) {
+                const int k = 16 * t + r;
+                f32x4 gk = {0.f, 0.f, 0.f, 0.f};
+                gk = mfma16(pa.x, w2[(4 * q + 0) * Hp + k], gk);
+                gk = mfma16(pa.y, w2[(4 * q + 1) * Hp + k], gk);
+                gk = mfma16(pa.z, w2[(4 * q + 2) * Hp + k], gk);
+                gk = mfma16(pa.w, w2[(4 * q + 3) * Hp + k], gk);
+                const float bj = brow[k];
+                const float wdk = wd[k];
+                float db = 0.f;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float h = fmaf(wdk, dd_g[g], ab[arow_g[g] + k] + bj);
+                    float ds;
+                    silu_grad(h, &ds);
+                    db = fmaf(gk[g], ds, db);  // gk is exactly 0 for padded entries
+                }
+                db += __shfl_xor(db, 16, 64);
+                db += __shfl_xor(db, 32, 64);
+                if (q == 0) drow[k] = first ? db : drow[k] + db;
+            }
+        }
+    }
+}
+
+// out[e] = sum_b slab[b][e], in block order
+__global__ void k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems,
+                               float* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += stride) {
+        float acc = 0.f;
+        for (int b = 0; b < n_slabs; ++b) acc += slab[(int64_t)b * elems + e];
+        out[e] = acc;
+    }
+}
+
+int check_common(int64_t N, int Hp) {
+    if (N < 0 || Hp <= 0) return EQH_ERR_ARG;
+    if (Hp & 15) return EQH_ERR_ALIGN;
+    if (N * 2 * (int64_t)Hp >= ((int64_t)1 << 31) * 4) return EQH_ERR_RANGE;
+    if (N * KNB >= ((int64_t)1 << 31)) return EQH_ERR_RANGE;
+    return EQH_OK;
+}
+
+}  // namespace
+
+extern "C" int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, const float* b2,
+                             const int32_t* nbr, const float* d2, int64_t N, int32_t Hp, float* m,
+                             float* pre2, void* stream_) {
+    int rc = check_common(N, Hp);
+    if (rc) return rc;
+    if (N == 0) return EQH_OK;
+    if (!ab || !wd || !w2 || !b2 || !nbr || !d2 || !m || !pre2) return EQH_ERR_ARG;
+    if (!eqh_aligned16(ab) || !eqh_aligned16(wd) || !eqh_aligned16(w2)) return EQH_ERR_ALIGN;
+    const size_t lds = (size_t)MDIM * lds_row_stride(Hp) * sizeof(float);
+    if (lds > 160 * 1024) return EQH_ERR_RANGE;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return EQH_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int grid = eqh_grid_for(N, WAVES, 512);  // 2 workgroups per CU hold W2 in LDS
+    hipLaunchKernelGGL(k_edge_fwd, dim3(grid), dim3(THREADS), lds, stream, ab, wd, w2, b2, nbr, d2, m,
+                       pre2, (int)N, (int)Hp);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp) {
+    if (N < 0 || Hp <= 0) return 0;
+    const int64_t blocks = (N + BWD_CHUNK - 1) / BWD_CHUNK;
+    return (size_t)(blocks > 0 ? blocks : 1) * (size_t)(MDIM + 1) * (size_t)Hp * sizeof(float);
+}
+
+extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
+                             const float* d2, const float* pre2, const float* dm,
+                             const int32_t* t_rowptr, const int32_t* t_perm, int64_t N, int32_t Hp,
+                             float* dab, float* dwd, float* dw2, float* dpre2, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+    int rc = check_common(N, Hp);
+    if (rc) return rc;
+    if (!dwd || !dw2) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N == 0) {
+        if (hipMemsetAsync(dwd, 0, (size_t)Hp * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+        if (hipMemsetAsync(dw2, 0, (size_t)MDIM * Hp * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+        return EQH_OK;
+    }
+    if (!ab || !wd || !w2 || !nbr || !d2 || !pre2 || !dm || !t_rowptr || !t_perm || !dab || !dpre2 ||
+        !workspace)
+        return EQH_ERR_ARG;
+    if (!eqh_aligned16(pre2) || !eqh_aligned16(dm) || !eqh_aligned16(dpre2) || !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < egnn_edge_bwd_workspace_bytes(N, Hp)) return EQH_ERR_ARG;
+    const int blocks = (int)((N + BWD_CHUNK - 1) / BWD_CHUNK);
+    float* slab_w2 = static_cast<float*>(workspace);
+    float* slab_wd = slab_w2 + (size_t)blocks * MDIM * Hp;
+    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(blocks), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, pre2,
+                       dm, dpre2, dab, slab_w2, slab_wd, (int)N, (int)Hp);
+    EQH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_edge_bwd_send, dim3(eqh_grid_for(N, WAVES, 2048)), dim3(THREADS), 0, stream, ab,
+                       wd, w2, d2, dpre2, t_rowptr, t_perm, dab, (int)N, (int)Hp);
+    EQH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(eqh_grid_for((int64_t)MDIM * Hp, 256, 256)), dim3(256), 0,
+                       stream, slab_w2, blocks, (int64_t)MDIM * Hp, dw2);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(eqh_grid_for(Hp, 256, 64)), dim3(256), 0, stream, slab_wd,
+                       blocks, (int64_t)Hp, dwd);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

@@ -27,6 +27,9 @@ SIGNATURES = {
     "hg_embed_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
     "geo_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "egnn_edge_fwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
+    "egnn_edge_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "egnn_edge_bwd": (c_int32, [c_void_p] * 9 + [c_int64, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
 }
 
 _lib = None

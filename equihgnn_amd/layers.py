@@ -232,14 +232,12 @@ class EGNN(nn.Module):
         w1 = F.pad(lin1.weight, (0, 0, 0, pad))
         b1 = F.pad(lin1.bias, (0, pad))
         w2 = F.pad(lin2.weight, (0, pad))
-        w_i, w_j, w_d = w1[:, :c], w1[:, c:2 * c], w1[:, 2 * c]
-        a = F.linear(feats, w_i, b1)                           # [N, Hp]  receiver part (+bias)
-        b = F.linear(feats, w_j)                               # [N, Hp]  sender part
-        n = feats.shape[0]
-        b_j = ops.gather_rows(b, nbr.reshape(-1), csr_t).view(n, self.k, -1)
-        h = a.unsqueeze(1) + b_j + d2.unsqueeze(-1) * w_d      # egnn_layer.py:305-310, split form
-        m_ij = F.silu(F.linear(F.silu(h), w2, lin2.bias))
-        m_i = m_ij.sum(-2)                                     # egnn_layer.py:357-358
+        # one node-level GEMM gives both halves: ab[:, :Hp] = W1_i f + b1 (receiver), ab[:, Hp:] = W1_j f
+        w_cat = torch.cat((w1[:, :c], w1[:, c:2 * c]), 0)
+        b_cat = F.pad(b1, (0, b1.shape[0]))
+        ab = F.linear(feats, w_cat, b_cat)
+        # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
+        m_i = ops.egnn_edge(ab, w1[:, 2 * c], w2, lin2.bias, nbr, d2, csr_t)
         node_in = torch.cat((self.node_norm(feats), m_i), -1)
         return self.node_mlp(node_in) + feats                  # egnn_layer.py:360-362
 

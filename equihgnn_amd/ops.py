@@ -183,9 +183,55 @@ class _EmbedSum(torch.autograd.Function):
         return None, dtable, None
 
 
+class _EgnnEdge(torch.autograd.Function):
+    """m_i = sum_j silu(W2 silu(A_i + B_j + wd d2_ij) + b2) — the fused EGNN edge update
+    (egnn_layer.py:298-310,357-358).  Saves only ``ab`` and the 16x16 second-layer
+    pre-activations; the per-edge hidden activations are recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR):
+        _require_gpu(ab, "egnn_edge")
+        ab, wd, w2, b2 = _f32c(ab), _f32c(wd), _f32c(w2), _f32c(b2)
+        N, Hp = ab.shape[0], ab.shape[1] // 2
+        if nbr.shape != (N, 16) or w2.shape != (16, Hp) or wd.shape != (Hp,) or b2.shape != (16,):
+            raise ValueError("egnn_edge: shapes must be ab[N,2Hp] wd[Hp] w2[16,Hp] b2[16] nbr[N,16]")
+        m = torch.empty((N, 16), dtype=torch.float32, device=ab.device)
+        pre2 = torch.empty((N, 16, 16), dtype=torch.float32, device=ab.device)
+        hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
+                                          _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd")
+        ctx.save_for_backward(ab, wd, w2, pre2)
+        ctx.nbr, ctx.d2, ctx.csr_t = nbr, d2, csr_t
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        ab, wd, w2, pre2 = ctx.saved_tensors
+        dm = _f32c(dm)
+        N, Hp = ab.shape[0], ab.shape[1] // 2
+        dev = ab.device
+        dab = torch.empty_like(ab)
+        dwd = torch.empty_like(wd)
+        dw2 = torch.empty_like(w2)
+        dpre2 = torch.empty_like(pre2)
+        L = hip.lib()
+        ws_bytes = L.egnn_edge_bwd_workspace_bytes(N, Hp)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
+                                  _ptr(dm), _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
+                                  _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(ws), ws_bytes, _stream(dev)),
+                  "egnn_edge_bwd")
+        db2 = dpre2.view(-1, 16).sum(0)
+        return dab, dwd, dw2, db2, None, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # public functional API
 # --------------------------------------------------------------------------------------------
+def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
+    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t)
+
+
+
 def reduce_gathered(src, csr: CSR, csr_t: CSR, reduce: str = "mean"):
     s2, lead = _as2d(src)
     out = _ReduceGathered.apply(s2, csr, csr_t, reduce == "mean")

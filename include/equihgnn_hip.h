@@ -103,6 +103,30 @@ int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32_t* off_hos
 int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist,
             void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused EGNN edge update for k = 16 neighbours, m_dim = 16 — egnn_layer.py:298-310,357-358
+ * (neighbour feature gather, cat(f_i, f_j, d2), edge_mlp = Linear -> SiLU -> Linear -> SiLU,
+ * sum over neighbours) and its autograd.
+ *   ab   [N, 2*Hp]  node-level pre-activations: ab[i, :Hp] = W1_i f_i + b1, ab[j, Hp:] = W1_j f_j
+ *                   (Hp = hidden width 2(2C+1) zero-padded to a multiple of 16)
+ *   wd   [Hp]       column of W1 that multiplies the squared distance
+ *   w2   [16, Hp], b2 [16]   second edge Linear
+ *   nbr  [N,16] int32, d2 [N,16]   geo_knn(mode 0) outputs
+ * fwd:  m[i,:] = sum_j silu(W2 silu(ab[i,:Hp] + ab[nbr_ij,Hp:] + wd*d2_ij) + b2);  pre2 [N,16,16]
+ *       (pre-activation of the second SiLU) is saved for the backward.
+ * bwd:  given dm [N,16]: dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16] (db2 is its sum over
+ *       the first two axes).  t_rowptr / t_perm: CSR of the transposed neighbour graph
+ *       (hg_csr_build with key = nbr flattened, n_rows = N; entries are i*16+slot).
+ * ------------------------------------------------------------------------------------------- */
+int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, const float* b2,
+                  const int32_t* nbr, const float* d2, int64_t N, int32_t Hp, float* m, float* pre2,
+                  void* stream);
+size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp);
+int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
+                  const float* d2, const float* pre2, const float* dm, const int32_t* t_rowptr,
+                  const int32_t* t_perm, int64_t N, int32_t Hp, float* dab, float* dwd, float* dw2,
+                  float* dpre2, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
