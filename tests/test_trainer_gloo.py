@@ -1,0 +1,94 @@
+"""World-size-2 data-parallel step on CPU (gloo): the flat-gradient all-reduce of
+equihgnn_amd.trainer reproduces what DDP does in the reference (main.py:281): every rank ends a
+step with identical parameters, equal to single-process Adam on the rank-averaged gradient, and
+parameters of dead branches keep grad=None on every rank.  The model driven here is the CPU oracle
+(the trainer is model-agnostic; the HIP models need a GPU)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from equihgnn_amd.batch import shard_indices, synth_batch
+from equihgnn_amd.registry import default_args
+from equihgnn_amd.trainer import TrainStep
+
+ARGS = dict(method="egnn_equihnns", MLP_hidden=32, output_hidden=16)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(seed):
+    from oracle import ref_models as O
+    torch.manual_seed(seed)
+    m = O.MODELS["egnn_equihnns"](1, default_args(**ARGS))
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Linear):
+            torch.nn.init.normal_(mod.weight, std=mod.in_features ** -0.5)
+    return m
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _make_model(seed=100 + rank)  # different init per rank: the broadcast must fix that
+    tr = TrainStep(model, lr=1e-2)
+    losses = []
+    for step in range(3):
+        data = synth_batch(6, 500 + 10 * step + rank)
+        losses.append(float(tr.step(data)))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    dead = [n for n, p in model.named_parameters() if p.grad is None]
+    torch.save({"sd": sd, "dead": dead, "losses": losses}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process_average(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"{k} differs across ranks"
+    assert r0["dead"] == r1["dead"] and any("coors_mlp" in n for n in r0["dead"])
+
+    # single-process emulation: same init as rank 0, Adam on the mean of the two ranks' gradients
+    model = _make_model(seed=100)
+    live = None
+    opt = None
+    for step in range(3):
+        grads = []
+        for rank in range(world):
+            for p in model.parameters():
+                p.grad = None
+            data = synth_batch(6, 500 + 10 * step + rank)
+            torch.nn.functional.mse_loss(model(data), data.y).backward()
+            grads.append([None if p.grad is None else p.grad.clone() for p in model.parameters()])
+        if live is None:
+            live = [p for p, g in zip(model.parameters(), grads[0]) if g is not None]
+            opt = torch.optim.Adam(live, lr=1e-2)
+        for p, g0, g1 in zip(model.parameters(), *grads):
+            p.grad = None if g0 is None else (g0 + g1) / 2
+        opt.step()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(r0["sd"][k].numpy(), v.numpy(), atol=2e-6, rtol=1e-5, err_msg=k)
+
+
+def test_shard_indices_partition_like_distributed_sampler():
+    n, world = 103, 4
+    parts = [shard_indices(n, r, world, seed=7, epoch=3) for r in range(world)]
+    assert len({len(p) for p in parts}) == 1 and len(parts[0]) == -(-n // world)
+    assert set().union(*map(set, parts)) == set(range(n))
+    assert parts != [shard_indices(n, r, world, seed=7, epoch=4) for r in range(world)]
+    assert shard_indices(10, 1, 2, seed=0, shuffle=False) == [1, 3, 5, 7, 9]
