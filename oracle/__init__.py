@@ -1,0 +1,5 @@
+"""ORACLE package — test infrastructure only (see ref_models.py).  Never imported by equihgnn_amd."""
+from . import ref_equiformer, ref_models
+
+ref_models.MODELS["equiformer_equihnns"] = ref_equiformer.EquiformerEquiHNNS
+MODELS = ref_models.MODELS

@@ -26,8 +26,11 @@ def golden_args(method: str, hidden: int, **kw) -> SimpleNamespace:
 
 
 def fill_state_dict(model: torch.nn.Module, seed: int) -> None:
-    """Overwrite every floating-point parameter/buffer with seeded values, in place."""
-    rng = np.random.default_rng(seed)
+    """Overwrite every floating-point parameter/buffer with seeded values, in place.  Each tensor
+    has its own generator keyed by (seed, crc32(name)), so the values do not depend on the order in
+    which an implementation registers its parameters."""
+    import zlib
+
     sd = model.state_dict()
     new = {}
     for name, t in sd.items():
@@ -36,6 +39,7 @@ def fill_state_dict(model: torch.nn.Module, seed: int) -> None:
             continue
         shape = tuple(t.shape)
         leaf = name.rsplit(".", 1)[-1]
+        rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         z = rng.standard_normal(shape if len(shape) else (1,)).astype(np.float32).reshape(shape)
         if name == "equiformer_layer.basis:(1,1)" or leaf == "beta":
             new[name] = t.clone()  # data / fixed-zero buffers stay as constructed
@@ -44,7 +48,7 @@ def fill_state_dict(model: torch.nn.Module, seed: int) -> None:
             new[name] = torch.from_numpy(v)
         elif leaf in ("running_mean", "bias"):
             new[name] = torch.from_numpy(0.1 * z)
-        elif leaf in ("gamma", "scale") or (leaf == "weight" and len(shape) == 1):
+        elif leaf in ("gamma", "scale") or ".transforms." in name or (leaf == "weight" and len(shape) == 1):
             new[name] = torch.from_numpy(1.0 + 0.1 * z)  # norm scales
         elif "embedding" in name or "bond_encoder" in name:
             new[name] = torch.from_numpy(0.5 * z)

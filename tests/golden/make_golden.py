@@ -255,7 +255,7 @@ def run_case(registry, method, hidden, seed, n_mols, train_mode=True, store_grad
         has_grad.append(p.grad is not None)
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         stats.append([float(g.sum()), float(g.abs().sum()), float(g.norm())])
-        if store_grads and p.grad is not None:
+        if store_grads and p.grad is not None and p.numel() <= 20000:
             case["grad_" + n] = g.numpy()
         elif p.grad is not None:
             flat = g.reshape(-1)

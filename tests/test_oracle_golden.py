@@ -7,12 +7,21 @@ import torch
 
 from common import batch_from_case, fill_state_dict, golden_args, load_case
 
+import oracle  # noqa: F401  (registers the Equiformer oracle in ref_models.MODELS)
 from oracle import ref_models
 
 TOL = 1e-5
 
 CASES = ["mhnnm_c64_train", "mhnnm_c64_eval", "mhnnm_c256_train",
-         "egnn_equihnns_c64", "egnn_equihnns_c64_b", "egnn_equihnns_c256"]
+         "egnn_equihnns_c64", "egnn_equihnns_c64_b", "egnn_equihnns_c256",
+         "equiformer_equihnns_c64", "equiformer_equihnns_c64_b", "equiformer_equihnns_c256"]
+
+
+def golden_neighbour_ids(case):
+    """The Equiformer's topk runs over the self-excluded candidate list (equiformer_layer.py:
+    1254-1257,1303): position p of row i is node p + (p >= i)."""
+    pos = case["knn_idx"]
+    return pos + (pos >= np.arange(pos.shape[0])[:, None])
 
 
 def build(case, models=ref_models.MODELS):
@@ -74,9 +83,14 @@ def test_oracle_matches_reference(name):
     model = build(case)
     data = batch_from_case(case)
     check_against_case(model, case, data)
-    if "knn_idx" in case:
+    if "knn_idx" in case and str(case["meta_method"]) == "egnn_equihnns":
         d2, idx = ref_models.knn_self_included(data.pos, 16)
         assert np.array_equal(np.sort(idx.numpy(), -1), np.sort(case["knn_idx"], -1))
+    if "knn_idx" in case and str(case["meta_method"]) == "equiformer_equihnns":
+        from oracle.ref_equiformer import neighbours_self_excluded
+        idx, dist, _, _ = neighbours_self_excluded(data.pos, 16, 5.0)
+        assert np.array_equal(np.sort(idx.numpy(), -1), np.sort(golden_neighbour_ids(case), -1))
+        np.testing.assert_allclose(dist.numpy(), case["knn_val"], rtol=1e-6)
 
 
 def test_state_dict_names_match_reference():
