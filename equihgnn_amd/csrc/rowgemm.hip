@@ -1,0 +1,193 @@
+// CSR-grouped small GEMMs: every entry (edge) e multiplies its feature row z[e, :Kd] with the
+// [Kd, L] matrix OWNED BY ITS CSR ROW (a node):   out[e, :] (+)= z[e, :] · w[row(e)].
+//
+// This is how the Equiformer's radial tensor product is evaluated without ever forming the
+// per-edge radial weights R[e, lo, li] (equiformer_layer.py:451-479 builds them with a
+// Linear(64 -> lo*li) per edge — 262 KB per edge at C=256 — and contracts them at :383):
+//   out[e, lo] = sum_li R[e, lo, li] x[e, li],  R[e] = reshape(W3 z_e + b3),  x[e] = xj[j] + xi[i]
+//             = sum_k z_e[k] (P[j, k, lo] + Q[i, k, lo]) + ...,   P[n] = sum_li W3[lo, li, k] xj[n, li]
+// P and Q are node-level library GEMMs; what is left per edge is z_e · P[sender] (+ z_e ·
+// Q[receiver]): a [deg x Kd] x [Kd x L] product per node, grouped by the sender (transposed
+// neighbour CSR) or by the receiver.  fp32 MFMA 16x16x4, 16 entries per tile on the M axis; the
+// node matrix is read once per 16 entries instead of once per edge.
+//
+// Backward: dz[e] = dout[e] · w[row]ᵀ and dw[row] = sum_e z[e]ᵀ ⊗ dout[e]; every dw[row] is written
+// by exactly one wavefront (no atomics, reproducible).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int entry_at(const int* __restrict__ perm, int pos, int end) {
+    if (pos >= end) return -1;
+    return perm ? perm[pos] : pos;
+}
+
+// grid.x strides rows (one wavefront per row), grid.y splits the L/16 column tiles
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_fwd(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
+              const int* __restrict__ perm, int R, int Kd, int L, float* __restrict__ out, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int ctiles = L >> 4, ksteps = Kd >> 4;
+    for (int row = blockIdx.x * WAVES + wave; row < R; row += gridDim.x * WAVES) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        const float* __restrict__ wr = w + (int64_t)row * Kd * L;
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            const int e_r = entry_at(perm, g0 + r_, end);
+            int e_g[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+            for (int ct = blockIdx.y; ct < ctiles; ct += gridDim.y) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int t = 0; t < ksteps; ++t) {
+                    float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e_r >= 0) z4 = *reinterpret_cast<const float4*>(z + (int64_t)e_r * Kd + 16 * t + 4 * q);
+                    const float* __restrict__ wb = wr + (int64_t)(16 * t + 4 * q) * L + ct * 16 + r_;
+                    acc = mfma16(z4.x, wb[0], acc);
+                    acc = mfma16(z4.y, wb[L], acc);
+                    acc = mfma16(z4.z, wb[2 * L], acc);
+                    acc = mfma16(z4.w, wb[3 * L], acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (e_g[g] >= 0) {
+                        float* o = out + (int64_t)e_g[g] * L + ct * 16 + r_;
+                        *o = accumulate ? (*o + acc[g]) : acc[g];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dz[e, k] (+)= sum_l dout[e, l] * w[row][k][l];   grid.y splits the Kd/16 k-tiles
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_bwd_z(const float* __restrict__ dout, const float* __restrict__ w,
+                const int* __restrict__ rowptr, const int* __restrict__ perm, int R, int Kd, int L,
+                float* __restrict__ dz, int accumulate) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int ktiles = Kd >> 4, lsteps = L >> 4;
+    for (int row = blockIdx.x * WAVES + wave; row < R; row += gridDim.x * WAVES) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        const float* __restrict__ wr = w + (int64_t)row * Kd * L;
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            const int e_r = entry_at(perm, g0 + r_, end);
+            int e_g[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+            for (int kt = blockIdx.y; kt < ktiles; kt += gridDim.y) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* __restrict__ wk = wr + (int64_t)(kt * 16 + r_) * L + 4 * q;
+                for (int t = 0; t < lsteps; ++t) {
+                    float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e_r >= 0) d4 = *reinterpret_cast<const float4*>(dout + (int64_t)e_r * L + 16 * t + 4 * q);
+                    const float4 w4 = *reinterpret_cast<const float4*>(wk + 16 * t);
+                    acc = mfma16(d4.x, w4.x, acc);
+                    acc = mfma16(d4.y, w4.y, acc);
+                    acc = mfma16(d4.z, w4.z, acc);
+                    acc = mfma16(d4.w, w4.w, acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (e_g[g] >= 0) {
+                        float* o = dz + (int64_t)e_g[g] * Kd + kt * 16 + r_;
+                        *o = accumulate ? (*o + acc[g]) : acc[g];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dw[row][k][l] = sum_{e in row} z[e, k] * dout[e, l];   grid.y splits the (Kd/16)*(L/16) tiles
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_bwd_w(const float* __restrict__ z, const float* __restrict__ dout,
+                const int* __restrict__ rowptr, const int* __restrict__ perm, int R, int Kd, int L,
+                float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int ktiles = Kd >> 4, ltiles = L >> 4;
+    for (int row = blockIdx.x * WAVES + wave; row < R; row += gridDim.x * WAVES) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        float* __restrict__ dwr = dw + (int64_t)row * Kd * L;
+        for (int tile = blockIdx.y; tile < ktiles * ltiles; tile += gridDim.y) {
+            const int kt = tile / ltiles, lt = tile - kt * ltiles;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int g0 = beg; g0 < end; g0 += 16) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int e = entry_at(perm, g0 + 4 * q + c, end);
+                    float a = 0.f, b = 0.f;
+                    if (e >= 0) {
+                        a = z[(int64_t)e * Kd + kt * 16 + r_];
+                        b = dout[(int64_t)e * L + lt * 16 + r_];
+                    }
+                    acc = mfma16(a, b, acc);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dwr[(int64_t)(kt * 16 + 4 * q + g) * L + lt * 16 + r_] = acc[g];
+        }
+    }
+}
+
+int check(int64_t R, int Kd, int L) {
+    if (R < 0 || Kd <= 0 || L <= 0) return EQH_ERR_ARG;
+    if ((Kd & 15) || (L & 15)) return EQH_ERR_ALIGN;
+    if (R >= ((int64_t)1 << 31) - 1) return EQH_ERR_RANGE;
+    return EQH_OK;
+}
+
+}  // namespace
+
+extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr,
+                              const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* out,
+                              int32_t accumulate, void* stream_) {
+    int rc = check(R, Kd, L);
+    if (rc) return rc;
+    if (R == 0) return EQH_OK;
+    if (!z || !w || !rowptr || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int gy = (L >> 4) < 4 ? (L >> 4) : 4;
+    dim3 grid(eqh_grid_for(R, WAVES, 4096), gy);
+    hipLaunchKernelGGL(k_rowgemm_fwd, grid, dim3(THREADS), 0, stream, z, w, rowptr, perm, (int)R, (int)Kd,
+                       (int)L, out, (int)accumulate);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
+                              const int32_t* rowptr, const int32_t* perm, int64_t R, int32_t Kd,
+                              int32_t L, float* dz, int32_t accumulate_dz, float* dw, void* stream_) {
+    int rc = check(R, Kd, L);
+    if (rc) return rc;
+    if (R == 0) return EQH_OK;
+    if (!z || !w || !dout || !rowptr) return EQH_ERR_ARG;
+    if (!eqh_aligned16(dout) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (dz) {
+        const int gy = (Kd >> 4) < 4 ? (Kd >> 4) : 4;
+        dim3 grid(eqh_grid_for(R, WAVES, 4096), gy);
+        hipLaunchKernelGGL(k_rowgemm_bwd_z, grid, dim3(THREADS), 0, stream, dout, w, rowptr, perm, (int)R,
+                           (int)Kd, (int)L, dz, (int)accumulate_dz);
+        EQH_CHECK_LAUNCH();
+    }
+    if (dw) {
+        const int tiles = (Kd >> 4) * (L >> 4);
+        dim3 grid(eqh_grid_for(R, WAVES, 2048), tiles < 8 ? tiles : 8);
+        hipLaunchKernelGGL(k_rowgemm_bwd_w, grid, dim3(THREADS), 0, stream, z, dout, rowptr, perm, (int)R,
+                           (int)Kd, (int)L, dw);
+        EQH_CHECK_LAUNCH();
+    }
+    return EQH_OK;
+}

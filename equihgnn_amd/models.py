@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .equiformer import Equiformer
 from .index import HyperIndex
 from .layers import EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, pool_sum
 from .registry import registry
@@ -111,4 +112,53 @@ class MHNNM(nn.Module):
         return self.mlp_out(x).view(-1)
 
 
-MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM}
+@registry.register_model("equiformer_equihnns")
+class EquiformerEquiHNNS(nn.Module):
+    """equihnn_equiformer.py:12-93: AtomEncoder -> Equiformer (once, type-0 output) -> shared
+    MHNNSConv x L -> pool -> head.  The reference keeps a leading batch dim of 1 through the conv /
+    pool / head (equihnn_equiformer.py:82-85) and flattens at the end; values are identical."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.equiformer_layer = Equiformer(dim=args.MLP_hidden, dim_head=48, num_neighbors=16,
+                                           valid_radius=5.0)
+        self.conv = MHNNSConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers,
+                              mlp2_layers=self.mlp2_layers, mlp3_layers=self.mlp3_layers,
+                              aggr=args.aggregate, dropout=args.dropout,
+                              normalization=args.normalization)
+        self.mlp_out = MLP(in_channels=args.MLP_hidden, hidden_channels=args.output_hidden,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def reset_parameters(self):
+        self.conv.reset_parameters()
+        self.mlp_out.reset_parameters()
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        if taps is not None:
+            taps["atom_encoder"] = x
+        x = self.equiformer_layer(x, data.pos, index)
+        if taps is not None:
+            taps["front_end"] = x
+        x0 = x
+        for i in range(self.nlayer):
+            x = self.conv(self.dropout(x), index, x0)
+            if taps is not None:
+                taps[f"conv{i}"] = x
+            x = self.act(x)
+        x = pool_sum(self.dropout(x), index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "equiformer_equihnns": EquiformerEquiHNNS}

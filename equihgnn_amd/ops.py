@@ -224,9 +224,45 @@ class _EgnnEdge(torch.autograd.Function):
         return dab, dwd, dw2, db2, None, None, None
 
 
+class _RowGemm(torch.autograd.Function):
+    """out[e] = z[e] @ w[row(e)] — hg_rowgemm_fwd/bwd (the radial tensor product of
+    equiformer_layer.py:376-383 re-associated; see csrc/rowgemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, w, rowptr, perm):
+        _require_gpu(z, "rowgemm")
+        z, w = _f32c(z), _f32c(w)
+        E, Kd = z.shape
+        R, Kd2, L = w.shape
+        if Kd2 != Kd or rowptr.numel() != R + 1:
+            raise ValueError("rowgemm: z[E,Kd], w[R,Kd,L], rowptr[R+1] expected")
+        out = torch.zeros((E, L), dtype=torch.float32, device=z.device)  # entries outside every row stay 0
+        hip.check(hip.lib().hg_rowgemm_fwd(_ptr(z), _ptr(w), _ptr(rowptr), _ptr(perm), R, Kd, L, _ptr(out), 0,
+                                           _stream(z.device)), "hg_rowgemm_fwd")
+        ctx.save_for_backward(z, w)
+        ctx.rowptr, ctx.perm = rowptr, perm
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, w = ctx.saved_tensors
+        dout = _f32c(dout)
+        R, Kd, L = w.shape
+        dz = torch.zeros_like(z) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        hip.check(hip.lib().hg_rowgemm_bwd(_ptr(z), _ptr(w), _ptr(dout), _ptr(ctx.rowptr), _ptr(ctx.perm), R, Kd,
+                                           L, _ptr(dz), 0, _ptr(dw), _stream(z.device)), "hg_rowgemm_bwd")
+        return dz, dw, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # public functional API
 # --------------------------------------------------------------------------------------------
+def rowgemm(z, w, rowptr, perm=None):
+    """out[e, :] = z[e, :] @ w[row(e)]; rows given by rowptr (+ perm: entry ids per row)."""
+    return _RowGemm.apply(z, w, rowptr, perm)
+
+
 def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
     return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t)
 

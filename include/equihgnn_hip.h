@@ -127,6 +127,21 @@ int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32
                   const int32_t* t_perm, int64_t N, int32_t Hp, float* dab, float* dwd, float* dw2,
                   float* dpre2, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * CSR-grouped small GEMMs — the Equiformer's radial tensor product (equiformer_layer.py:376-383:
+ * R = Radial(d) [lo, li] per edge, out = R x) re-associated so that the per-edge radial weights
+ * are never formed:  out[e, :] (+)= z[e, :Kd] . w[row(e)]  with one [Kd, L] matrix per CSR row
+ * (node), entries (edges) listed by rowptr / perm (perm NULL = identity: entry q belongs to the
+ * row whose range contains q).  Kd and L must be multiples of 16.
+ * bwd: dz[e, :] (+)= dout[e, :] . w[row(e)]^T (skipped if dz NULL);
+ *      dw[r] = sum_{e in row r} z[e]^T (x) dout[e]  (fully overwritten; skipped if dw NULL).
+ * ------------------------------------------------------------------------------------------- */
+int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm,
+                   int64_t R, int32_t Kd, int32_t L, float* out, int32_t accumulate, void* stream);
+int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int32_t* rowptr,
+                   const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz,
+                   int32_t accumulate_dz, float* dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
