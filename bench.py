@@ -39,6 +39,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-graph", action="store_true",
+                   help="eager launches instead of hipGraph replay of the step")
+    p.add_argument("--only-saturation", action="store_true",
+                   help="run just the cache-exceeding scatter probe (used for the rocprofv3 --pmc passes)")
     return p.parse_args()
 
 
@@ -112,6 +116,47 @@ def measure_scatter_roofline(model, batch, dev):
             "alg_bytes_per_launch": int(tot_bytes / n)}
 
 
+def saturation_probe(dev, log2_nodes=20, C=256, reps=10, seed=0):
+    """The scatter kernel alone at a size far beyond the 256 MiB Infinity Cache:
+    N = 2^20 nodes, nnz = 2.3 N incidences over M = 1.1 N hyperedges, C = 256 (1 GiB of node
+    features).  Forward node->hyperedge gathered mean and its backward (hyperedge->node, weighted),
+    each timed with HIP events over `reps` back-to-back launches."""
+    from equihgnn_amd import hip, ops
+
+    N = 1 << log2_nodes
+    M = int(1.1 * N)
+    nnz = int(2.3 * N)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    v = torch.randint(0, N, (nnz,), device=dev, generator=g)
+    e = torch.randint(0, M, (nnz,), device=dev, generator=g)
+    by_e = ops.csr_build(e, v, M)
+    by_v = ops.csr_build(v, e, N)
+    X = torch.randn(N, C, device=dev, generator=g)
+    dE = torch.randn(M, C, device=dev, generator=g)
+    L = hip.lib()
+    stream = torch.cuda.current_stream(dev)
+    res = {"nodes": N, "hyperedges": M, "incidences": nnz, "C": C}
+    for name, (src, idx, ptr, wptr, rows) in {
+            "fwd_v2e_mean": (X, by_e.col, by_e.rowptr, None, M),
+            "bwd_e2v_weighted": (dE, by_v.col, by_v.rowptr, by_e.rowptr, N)}.items():
+        out = torch.empty((rows, C), dtype=torch.float32, device=dev)
+        args = (ops._ptr(src), ops._ptr(idx), ops._ptr(ptr), ops._ptr(wptr), ops._ptr(out), rows, C,
+                1 if wptr is None else 0, ops._stream(dev))
+        for _ in range(2):
+            L.hg_segment_reduce_f32(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            L.hg_segment_reduce_f32(*args)
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        b = seg_reduce_bytes(nnz, rows, C, True, True, wptr is not None, src.shape[0])
+        res[name] = {"us": round(ms * 1e3, 1), "alg_bytes": b, "GBps": round(b / (ms * 1e-3) / 1e9, 1),
+                     "frac_of_8TBps": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    return res
+
+
 def usable_cores() -> int:
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (the
     GPU box exposes 256 logical CPUs but grants a 16-core share per GPU)."""
@@ -174,23 +219,39 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
-    from equihgnn_amd.batch import synth_batch
+    if a.only_saturation:
+        print(json.dumps({"saturation": saturation_probe(dev)}), flush=True)
+        return
+
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
     from equihgnn_amd.models import MODELS
     from equihgnn_amd.registry import default_args
-    from equihgnn_amd.trainer import TrainStep
+    from equihgnn_amd.trainer import GraphedTrainStep, TrainStep
 
     args_ns = default_args(method=a.method, batch_size=a.batch)
     torch.manual_seed(0)
     model = MODELS[a.method](1, args_ns).to(dev)
     cfg_id = 2
     host_batches = [synth_batch(a.batch, cfg_id * 1000 + rank * 100 + i, a.flavour) for i in range(a.pool)]
-    batches = [b.to(dev) for b in host_batches]
-    trainer = TrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
+    # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
+    # largest one (one dummy molecule owns the padding; exact for LayerNorm models).  mhnnm keeps
+    # eager launches (its BatchNorm statistics would see the padded rows).
+    use_graph = (not a.no_graph) and a.method != "mhnnm"
+    if use_graph:
+        ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]
+        tgt = tuple(max(e[i] for e in ext) for i in range(3))
+        batches = [pad_batch(b, *tgt).to(dev) for b in host_batches]
+        for b in batches:
+            b.num_real_graphs = a.batch
+        trainer = GraphedTrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
+    else:
+        batches = [b.to(dev) for b in host_batches]
+        trainer = TrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
 
-    def fresh(b):  # every step sees a "new" batch: the index (CSR sort, kNN) is rebuilt
-        b._hyper_index = None
+        def fresh(b):  # every step sees a "new" batch: the index (CSR sort, kNN) is rebuilt
+            b._hyper_index = None
 
-    trainer.on_batch = fresh
+        trainer.on_batch = fresh
     for i in range(a.warmup):
         trainer.step(batches[i % a.pool])
     torch.cuda.synchronize(dev)
@@ -228,11 +289,14 @@ def main():
                                    "full training step fwd+MSE+bwd+all-reduce+Adam",
                        "batch_per_rank": a.batch, "global_batch": a.batch * world,
                        "avg_nodes": round(n_nodes, 1), "avg_incidences": round(nnz, 1),
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay (padded static shapes)" if use_graph else "eager"},
             "final_loss": round(float(loss), 6),
         }
         if not a.no_roofline:
-            result["roofline"] = measure_scatter_roofline(model, batches[0], dev)
+            result["roofline"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
+            if world == 1:
+                result["roofline"]["saturation"] = saturation_probe(dev)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(a.method, args_ns, host_batches[0], a.cpu_seconds)
     if world > 1:

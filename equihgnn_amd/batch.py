@@ -129,6 +129,47 @@ def collate(mols: Sequence[HMol]) -> HBatch:
     )
 
 
+def bucket_sizes(n_nodes: int, n_hyperedges: int, n_inc: int, quantum: int = 256):
+    """Static shapes for hipGraph replay: round each extent up to a multiple of ``quantum`` with
+    at least one spare slot (the padding molecule needs a node and a hyperedge of its own)."""
+    up = lambda v: -(-(v + 1) // quantum) * quantum
+    return up(n_nodes), up(n_hyperedges), up(n_inc)
+
+
+def pad_batch(b: HBatch, n_nodes: int, n_hyperedges: int, n_inc: int) -> HBatch:
+    """Pad a batch to fixed extents with ONE extra dummy molecule (graph id B) that owns every
+    padded node, hyperedge and incidence.  Padded atoms sit 10 A apart on a line 10^4 A away, so no
+    real atom ever selects one as a neighbour (each real atom has >= 16 real candidates) and the
+    5 A radius mask drops them; padded rows never mix with real rows in any aggregation, and the
+    loss is taken over the first B outputs only — real-molecule outputs and all parameter gradients
+    are unchanged for models without batch statistics (LayerNorm models: egnn_equihnns,
+    equiformer_equihnns)."""
+    N, M, nnz, B = b.x.shape[0], b.edge_attr.shape[0], b.edge_index0.shape[0], b.y.shape[0]
+    if n_nodes <= N or n_hyperedges <= M or n_inc < nnz:
+        raise ValueError("pad_batch: target extents must exceed the batch (nodes and hyperedges strictly)")
+    dev = b.x.device
+    pn, pm, pz = n_nodes - N, n_hyperedges - M, n_inc - nnz
+    far = torch.zeros((pn, 3), dtype=b.pos.dtype, device=dev)
+    far[:, 0] = 1.0e4 + 10.0 * torch.arange(pn, device=dev, dtype=b.pos.dtype)
+    cat = torch.cat
+    zl = lambda n, like: torch.zeros((n, *like.shape[1:]), dtype=like.dtype, device=dev)
+    # padded incidences cycle over the padded nodes / hyperedges (bounded degrees)
+    iv = N + (torch.arange(pz, device=dev) % pn)
+    ie = M + (torch.arange(pz, device=dev) % pm)
+    out = HBatch(
+        x=cat((b.x, zl(pn, b.x))), pos=cat((b.pos, far)),
+        edge_index0=cat((b.edge_index0, iv.to(b.edge_index0.dtype))),
+        edge_index1=cat((b.edge_index1, ie.to(b.edge_index1.dtype))),
+        edge_attr=cat((b.edge_attr, zl(pm, b.edge_attr))),
+        n_e=cat((b.n_e, torch.tensor([pm], dtype=b.n_e.dtype, device=dev))),
+        e_order=cat((b.e_order, zl(pm, b.e_order))),
+        batch=cat((b.batch, torch.full((pn,), B, dtype=b.batch.dtype, device=dev))),
+        y=cat((b.y, zl(1, b.y))),
+        num_nodes=n_nodes, num_hyperedges=n_hyperedges, num_graphs=B + 1)
+    out.num_real_graphs = B
+    return out
+
+
 def synth_molecule(rng: np.random.Generator, flavour: str = "qm9",
                    n_atoms: Optional[int] = None, force_conj: Optional[bool] = None) -> HMol:
     mu, sigma, n_max, p_conj = FLAVOURS[flavour]

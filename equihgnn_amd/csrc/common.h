@@ -28,3 +28,15 @@ __device__ __forceinline__ void f4_fma(float4& a, const float4& v, float w) {
 __device__ __forceinline__ void f4_add(float4& a, const float4& v) {
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
 }
+
+// Zero-fill by kernel.  hipMemsetAsync is avoided everywhere in this library: memset nodes of a
+// stream-captured hipGraph were observed (ROCm 7.2, gfx950) not to clear again on replay.
+static __global__ void eqh_k_zero(float* __restrict__ p, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
+    if (n <= 0) return EQH_OK;
+    hipLaunchKernelGGL(eqh_k_zero, dim3(eqh_grid_for(n, 256, 1024)), dim3(256), 0, stream, p, n);
+    return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
+}

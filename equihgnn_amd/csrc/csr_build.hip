@@ -5,7 +5,7 @@
 // node<->hyperedge aggregation is an atomic-free segmented reduction over rowptr/col.
 //
 // Pipeline (all on `stream`, no host sync):
-//   memset cnt -> k_hist (int atomics) -> 3-kernel exclusive scan -> k_fill (int atomics into a
+//   k_clear -> k_hist (int atomics) -> 3-kernel exclusive scan -> k_fill (int atomics into a
 //   scratch permutation) -> k_sort_short (rows <= 16 entries: per-thread rank sort) and
 //   k_sort_long (one workgroup per longer row: bitonic sort in LDS).  Sorting each row by entry
 //   id makes the summation order, and therefore every result, bitwise reproducible.
@@ -19,6 +19,15 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 counters per block
 constexpr int SHORT_ROW = 16;
 constexpr int LONG_THREADS = 256;
 constexpr int LONG_LDS_CAP = 16384;  // ints (64 KiB)
+
+// counters are cleared by a kernel, not hipMemsetAsync: memset nodes of a captured hipGraph were
+// observed (ROCm 7.2) not to re-clear the 4-byte long-row counter on replay, which overflows
+// long_rows after a few replays.
+__global__ void k_clear(int* __restrict__ cnt, int64_t n_items, int* __restrict__ long_count) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += stride) cnt[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0;
+}
 
 __global__ void k_hist(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
                        int* __restrict__ cnt) {
@@ -225,8 +234,9 @@ extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nn
 
     const int64_t n_items = n_rows + 1;
     const int n_blocks = (int)((n_items + SCAN_TILE - 1) / SCAN_TILE);
-    if (hipMemsetAsync(w.cnt, 0, (size_t)n_items * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
-    if (hipMemsetAsync(w.long_count, 0, 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_clear, dim3(eqh_grid_for(n_items, 256, 1024)), dim3(256), 0, stream, w.cnt, n_items,
+                       w.long_count);
+    EQH_CHECK_LAUNCH();
     const int g_nnz = eqh_grid_for(nnz, 256, 2048);
     if (nnz > 0) {
         hipLaunchKernelGGL(k_hist, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);

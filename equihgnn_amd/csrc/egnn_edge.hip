@@ -333,8 +333,8 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     if (!dwd || !dw2) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (N == 0) {
-        if (hipMemsetAsync(dwd, 0, (size_t)Hp * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
-        if (hipMemsetAsync(dw2, 0, (size_t)MDIM * Hp * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
+        if (eqh_zero_async(dwd, Hp, stream) || eqh_zero_async(dw2, (int64_t)MDIM * Hp, stream))
+            return EQH_ERR_LAUNCH;
         return EQH_OK;
     }
     if (!ab || !wd || !w2 || !nbr || !d2 || !pre2 || !dm || !t_rowptr || !t_perm || !dab || !dpre2 ||

@@ -141,8 +141,7 @@ extern "C" int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t row_elems = table_rows * C;
     if (N == 0) {
-        if (hipMemsetAsync(dtable, 0, (size_t)row_elems * 4, stream) != hipSuccess) return EQH_ERR_LAUNCH;
-        return EQH_OK;
+        return eqh_zero_async(dtable, row_elems, stream);
     }
     if (!x || !dout || !workspace) return EQH_ERR_ARG;
     if (workspace_bytes < hg_embed_sum_bwd_workspace_bytes(N, C, table_rows)) return EQH_ERR_ARG;
