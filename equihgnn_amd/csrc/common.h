@@ -40,3 +40,27 @@ static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
     hipLaunchKernelGGL(eqh_k_zero, dim3(eqh_grid_for(n, 256, 1024)), dim3(256), 0, stream, p, n);
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
 }
+
+// out[e] = sum_b slab[b][e] for e < elems, summed in a FIXED order (bitwise reproducible): a block
+// covers 64 consecutive elements with 4 slab-groups (b = g, g+4, ...) that are combined through LDS.
+static __global__ void __launch_bounds__(256)
+eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out) {
+    __shared__ float s_part[256];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < elems; e0 += (int64_t)gridDim.x * 64) {
+        const int64_t e = e0 + col;
+        float acc = 0.f;
+        if (e < elems)
+            for (int b = grp; b < n_slabs; b += 4) acc += slab[(int64_t)b * elems + e];
+        s_part[threadIdx.x] = acc;
+        __syncthreads();
+        if (grp == 0 && e < elems) out[e] = ((s_part[col] + s_part[64 + col]) + s_part[128 + col]) + s_part[192 + col];
+        __syncthreads();
+    }
+}
+static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,
+                                         hipStream_t stream) {
+    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(256), 0, stream, slab,
+                       n_slabs, elems, out);
+    return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
+}

@@ -271,17 +271,6 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
     }
 }
 
-// out[e] = sum_b slab[b][e], in block order
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems,
-                               float* __restrict__ out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < elems; e += stride) {
-        float acc = 0.f;
-        for (int b = 0; b < n_slabs; ++b) acc += slab[(int64_t)b * elems + e];
-        out[e] = acc;
-    }
-}
-
 int check_common(int64_t N, int Hp) {
     if (N < 0 || Hp <= 0) return EQH_ERR_ARG;
     if (Hp & 15) return EQH_ERR_ALIGN;
@@ -352,10 +341,6 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     hipLaunchKernelGGL(k_edge_bwd_send, dim3(eqh_grid_for(N, WAVES, 2048)), dim3(THREADS), 0, stream, ab,
                        wd, w2, d2, dpre2, t_rowptr, t_perm, dab, (int)N, (int)Hp);
     EQH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(eqh_grid_for((int64_t)MDIM * Hp, 256, 256)), dim3(256), 0,
-                       stream, slab_w2, blocks, (int64_t)MDIM * Hp, dw2);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(eqh_grid_for(Hp, 256, 64)), dim3(256), 0, stream, slab_wd,
-                       blocks, (int64_t)Hp, dwd);
-    EQH_CHECK_LAUNCH();
-    return EQH_OK;
+    if (eqh_reduce_slabs_async(slab_w2, blocks, (int64_t)MDIM * Hp, dw2, stream)) return EQH_ERR_LAUNCH;
+    return eqh_reduce_slabs_async(slab_wd, blocks, (int64_t)Hp, dwd, stream);
 }

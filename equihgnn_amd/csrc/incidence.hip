@@ -1,0 +1,309 @@
+// Fused per-incidence message + aggregation:
+//   S[r] = reduce_{p in row r}  LayerNorm( ReLU( PA[ia[p]] + QB[ib[p]] ) )            (sum | mean)
+//
+// This is the hidden layer of the per-incidence MLPs of conv.py:90-93,96-97,175-177
+//   W(cat(X[v], E[e]))  ->  ReLU -> LayerNorm (mlp.py:93-97)  ->  scatter(reduce)
+// after the two algebraic moves of layers.py (first Linear split into node/hyperedge-level GEMMs
+// PA = X·Waᵀ, QB = E·Wbᵀ + b; last Linear applied after the aggregation).  It replaces two row
+// gathers, an add, a ReLU, a LayerNorm and a segmented reduction (six launches and four [nnz,C]
+// round trips through memory) by one launch that reads each gathered row once and writes one
+// row per output.  HBM-bound: algorithmic bytes 4C·(2·nnz + R) + 12·nnz + 4(R+1).
+//
+// One 64-lane wavefront per output row; a row of C <= 1024 channels is NV float4 per lane; the
+// LayerNorm statistics are wavefront butterfly reductions (no LDS, no atomics).  Nothing is saved
+// for the backward: it recomputes h, mean and rstd per incidence.  The backward runs twice — once
+// over the CSR keyed by `ia` (giving dPA) and once over the CSR keyed by `ib` (giving dQB) — so
+// that each gradient row is owned by one wavefront; d gamma is accumulated per workgroup into a
+// slab reduced in block order (bitwise reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ void wave_sum2(float& a, float& b) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        b += __shfl_xor(b, d, 64);
+    }
+}
+
+template <int NV>
+struct Row {
+    float4 v[NV];
+};
+
+// h = relu(pa[a] + qb[b]); returns xhat in `x`, rstd in *rstd, relu mask in `pos` (bit per comp)
+template <int NV>
+__device__ __forceinline__ void load_norm(const float* __restrict__ pa, const float* __restrict__ qb,
+                                          int a, int b, int C, int lane, float inv_c, float eps,
+                                          Row<NV>& x, unsigned& pos, float* rstd) {
+    float s = 0.f;
+    pos = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            const float4 u = *reinterpret_cast<const float4*>(pa + (int64_t)a * C + c);
+            const float4 w = *reinterpret_cast<const float4*>(qb + (int64_t)b * C + c);
+            h = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
+        }
+        pos |= ((h.x > 0.f) ? 1u : 0u) << (4 * i) | ((h.y > 0.f) ? 2u : 0u) << (4 * i) |
+               ((h.z > 0.f) ? 4u : 0u) << (4 * i) | ((h.w > 0.f) ? 8u : 0u) << (4 * i);
+        h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        x.v[i] = h;
+        s += (h.x + h.y) + (h.z + h.w);
+    }
+    const float mu = wave_sum(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        float4 d = x.v[i];
+        if (c < C) { d.x -= mu; d.y -= mu; d.z -= mu; d.w -= mu; }
+        x.v[i] = d;
+        ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float r = 1.0f / sqrtf(wave_sum(ss) * inv_c + eps);
+    *rstd = r;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { x.v[i].x *= r; x.v[i].y *= r; x.v[i].z *= r; x.v[i].w *= r; }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_inc_fwd(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ ia,
+          const int* __restrict__ ib, const int* __restrict__ rowptr, const int* __restrict__ perm,
+          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
+          int n_rows, int C, int mean, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        Row<NV> acc;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        for (int q0 = beg; q0 < end; q0 += 64) {
+            // the row's incidence ids and operand rows: one coalesced load each, then broadcast
+            const int cnt = (end - q0 < 64) ? (end - q0) : 64;
+            int my_a = 0, my_b = 0;
+            if (lane < cnt) {
+                const int p = perm[q0 + lane];
+                my_a = ia[p];
+                my_b = ib[p];
+            }
+            for (int j = 0; j < cnt; ++j) {
+                Row<NV> x;
+                unsigned pos;
+                float rstd;
+                load_norm<NV>(pa, qb, __shfl(my_a, j, 64), __shfl(my_b, j, 64), C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) f4_add(acc.v[i], x.v[i]);
+            }
+        }
+        const int deg = end - beg;
+        const float den = (mean && deg > 1) ? (float)deg : 1.0f;
+        const float bscale = mean ? (deg > 0 ? 1.0f : 0.0f) : (float)deg;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                float4 o;
+                o.x = fmaf(g.x, acc.v[i].x / den, b.x * bscale);
+                o.y = fmaf(g.y, acc.v[i].y / den, b.y * bscale);
+                o.z = fmaf(g.z, acc.v[i].z / den, b.z * bscale);
+                o.w = fmaf(g.w, acc.v[i].w / den, b.w * bscale);
+                *reinterpret_cast<float4*>(out + (int64_t)r * C + c) = o;
+            }
+        }
+    }
+}
+
+// One side of the backward.  Rows of (side_rowptr, side_perm) group the incidences by the index of
+// the operand whose gradient is produced; `okey[p]` is the OUTPUT row of incidence p and
+// `orowptr` the forward CSR's rowptr (for the mean weight).
+template <int NV, bool DGAMMA>
+__global__ void __launch_bounds__(THREADS)
+k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ ia,
+          const int* __restrict__ ib, const int* __restrict__ side_rowptr,
+          const int* __restrict__ side_perm, const int* __restrict__ okey,
+          const int* __restrict__ orowptr, const float* __restrict__ ds,
+          const float* __restrict__ gamma, float* __restrict__ dside, float* __restrict__ slab_dgamma,
+          int n_side_rows, int C, int mean, float eps) {
+    __shared__ float4 s_g[DGAMMA ? THREADS : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    Row<NV> gam, dgam;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
+        dgam.v[i] = f4_zero();
+    }
+    for (int s = blockIdx.x * WAVES + wave; s < n_side_rows; s += gridDim.x * WAVES) {
+        const int beg = side_rowptr[s], end = side_rowptr[s + 1];
+        Row<NV> acc;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        for (int q0 = beg; q0 < end; q0 += 64) {
+          const int cnt = (end - q0 < 64) ? (end - q0) : 64;
+          int my_a = 0, my_b = 0, my_r = 0;
+          float my_w = 1.0f;
+          if (lane < cnt) {
+              const int p = side_perm[q0 + lane];
+              my_a = ia[p];
+              my_b = ib[p];
+              my_r = okey[p];
+              const int deg = orowptr[my_r + 1] - orowptr[my_r];
+              my_w = (mean && deg > 1) ? 1.0f / (float)deg : 1.0f;
+          }
+          for (int j = 0; j < cnt; ++j) {
+            const int r = __shfl(my_r, j, 64);
+            const float w = __shfl(my_w, j, 64);
+            Row<NV> x;
+            unsigned pos;
+            float rstd;
+            load_norm<NV>(pa, qb, __shfl(my_a, j, 64), __shfl(my_b, j, 64), C, lane, inv_c, eps, x, pos, &rstd);
+            Row<NV> g;
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                float4 d = f4_zero();
+                if (c < C) d = *reinterpret_cast<const float4*>(ds + (int64_t)r * C + c);
+                d.x *= w; d.y *= w; d.z *= w; d.w *= w;
+                if (DGAMMA) {
+                    dgam.v[i].x = fmaf(d.x, x.v[i].x, dgam.v[i].x); dgam.v[i].y = fmaf(d.y, x.v[i].y, dgam.v[i].y);
+                    dgam.v[i].z = fmaf(d.z, x.v[i].z, dgam.v[i].z); dgam.v[i].w = fmaf(d.w, x.v[i].w, dgam.v[i].w);
+                }
+                d.x *= gam.v[i].x; d.y *= gam.v[i].y; d.z *= gam.v[i].z; d.w *= gam.v[i].w;
+                g.v[i] = d;
+                m1 += (d.x + d.y) + (d.z + d.w);
+                m2 += (d.x * x.v[i].x + d.y * x.v[i].y) + (d.z * x.v[i].z + d.w * x.v[i].w);
+            }
+            wave_sum2(m1, m2);
+            m1 *= inv_c;
+            m2 *= inv_c;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const unsigned b = pos >> (4 * i);
+                float4 dx;
+                dx.x = (b & 1u) ? rstd * (g.v[i].x - m1 - x.v[i].x * m2) : 0.f;
+                dx.y = (b & 2u) ? rstd * (g.v[i].y - m1 - x.v[i].y * m2) : 0.f;
+                dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
+                dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
+                f4_add(acc.v[i], dx);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) *reinterpret_cast<float4*>(dside + (int64_t)s * C + c) = acc.v[i];
+        }
+    }
+    if (DGAMMA) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s_g[threadIdx.x] = dgam.v[i];
+            __syncthreads();
+            if (wave == 0) {
+                float4 t = s_g[lane];
+                for (int w2 = 1; w2 < WAVES; ++w2) f4_add(t, s_g[w2 * 64 + lane]);
+                const int c = (lane + 64 * i) * 4;
+                if (c < C) *reinterpret_cast<float4*>(slab_dgamma + (int64_t)blockIdx.x * C + c) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+inline int bwd_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES, 512); }
+
+int check(int64_t rows, int C) {
+    if (rows < 0 || C <= 0) return EQH_ERR_ARG;
+    if ((C & 3) || C > 1024) return EQH_ERR_ALIGN;
+    if (rows >= ((int64_t)1 << 31) - 1) return EQH_ERR_RANGE;
+    return EQH_OK;
+}
+
+template <typename F>
+int dispatch_nv(int C, F&& f) {
+    if (C <= 256) return f(std::integral_constant<int, 1>{});
+    if (C <= 512) return f(std::integral_constant<int, 2>{});
+    return f(std::integral_constant<int, 4>{});
+}
+
+}  // namespace
+
+extern "C" int hg_incidence_ln_reduce_fwd(const float* pa, const float* qb, const int32_t* ia,
+                                          const int32_t* ib, const int32_t* rowptr, const int32_t* perm,
+                                          const float* gamma, const float* beta, int64_t n_rows,
+                                          int32_t C, int32_t mean, float eps, float* out, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!pa || !qb || !ia || !ib || !rowptr || !perm || !gamma || !beta || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(pa) || !eqh_aligned16(qb) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) ||
+        !eqh_aligned16(out))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_inc_fwd<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream,
+                           pa, qb, ia, ib, rowptr, perm, gamma, beta, out, (int)n_rows, (int)C, (int)mean, eps);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t hg_incidence_ln_reduce_bwd_workspace_bytes(int64_t n_a_rows, int32_t C) {
+    if (n_a_rows < 0 || C <= 0) return 0;
+    return (size_t)bwd_blocks(n_a_rows) * (size_t)C * sizeof(float);
+}
+
+extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, const int32_t* ia,
+                                          const int32_t* ib, const int32_t* a_rowptr,
+                                          const int32_t* a_perm, int64_t n_a_rows,
+                                          const int32_t* b_rowptr, const int32_t* b_perm,
+                                          int64_t n_b_rows, const int32_t* okey, const int32_t* orowptr,
+                                          const float* ds, const float* gamma, int32_t C, int32_t mean,
+                                          float eps, float* dpa, float* dqb, float* dgamma,
+                                          void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check(n_a_rows, C);
+    if (rc) return rc;
+    rc = check(n_b_rows, C);
+    if (rc) return rc;
+    if (!dgamma || !gamma) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_a_rows == 0 && n_b_rows == 0) return eqh_zero_async(dgamma, C, stream);
+    if (!pa || !qb || !ia || !ib || !a_rowptr || !a_perm || !b_rowptr || !b_perm || !okey || !orowptr || !ds ||
+        !dpa || !dqb || !workspace)
+        return EQH_ERR_ARG;
+    if (!eqh_aligned16(ds) || !eqh_aligned16(dpa) || !eqh_aligned16(dqb) || !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_incidence_ln_reduce_bwd_workspace_bytes(n_a_rows, C)) return EQH_ERR_ARG;
+    float* slab = static_cast<float*>(workspace);
+    const int blocks_a = bwd_blocks(n_a_rows);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_inc_bwd<NV, true>), dim3(blocks_a), dim3(THREADS), 0, stream, pa, qb, ia, ib,
+                           a_rowptr, a_perm, okey, orowptr, ds, gamma, dpa, slab, (int)n_a_rows, (int)C,
+                           (int)mean, eps);
+        hipLaunchKernelGGL((k_inc_bwd<NV, false>), dim3(bwd_blocks(n_b_rows)), dim3(THREADS), 0, stream, pa, qb,
+                           ia, ib, b_rowptr, b_perm, okey, orowptr, ds, gamma, dqb, (float*)nullptr,
+                           (int)n_b_rows, (int)C, (int)mean, eps);
+        EQH_CHECK_LAUNCH();
+        return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream);
+    });
+}

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libequihgnn_hip.so")
@@ -31,6 +31,10 @@ SIGNATURES = {
     "egnn_edge_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "egnn_edge_bwd": (c_int32, [c_void_p] * 9 + [c_int64, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "hg_rowgemm_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
+    "hg_incidence_ln_reduce_fwd": (c_int32, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]),
+    "hg_incidence_ln_reduce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hg_incidence_ln_reduce_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 4
+                                   + [c_int32, c_int32, c_float] + [c_void_p] * 4 + [c_size_t, c_void_p]),
     "hg_rowgemm_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                                 c_void_p]),
 }

@@ -118,12 +118,21 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
     wa, wb = lin0.weight[:, :ca], lin0.weight[:, ca:]
     pa = F.linear(a, wa)                # rows of a
     qb = F.linear(b, wb, lin0.bias)     # rows of b
+    norm = mlp.normalizations[1] if len(mlp.lins) > 1 else None
+    fused = (len(mlp.lins) == 2 and isinstance(norm, nn.LayerNorm) and pa.dim() == 2
+             and pa.shape[-1] % 4 == 0 and pa.shape[-1] <= 1024 and not (mlp.training and mlp.dropout > 0))
+    last = mlp.lins[-1]
+    if fused:
+        # gather + gather + add + ReLU + LayerNorm + segmented reduce in ONE kernel (incidence.hip)
+        s = ops.incidence_ln_reduce(pa, qb, norm.weight, norm.bias, idx_a32, idx_b32, csr_a, csr_b,
+                                    out_csr, out_key32, aggr, norm.eps)
+        return F.linear(s, last.weight) + last.bias * (has_row if aggr == "mean" else
+                                                       (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype)[:, None])
     h = ops.gather_rows(pa, idx_a32, csr_a) + ops.gather_rows(qb, idx_b32, csr_b)  # [nnz, C]
     if len(mlp.lins) == 1:              # a single Linear: everything is linear in h
         return ops.reduce_entries(h, out_csr, out_key32, aggr)
     h = mlp.hidden(h, 0)
     s = ops.reduce_entries(h, out_csr, out_key32, aggr)
-    last = mlp.lins[-1]
     if aggr == "mean":
         return F.linear(s, last.weight) + last.bias * has_row
     deg = (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype).unsqueeze(-1)

@@ -224,6 +224,46 @@ class _EgnnEdge(torch.autograd.Function):
         return dab, dwd, dw2, db2, None, None, None
 
 
+class _IncidenceLnReduce(torch.autograd.Function):
+    """S[r] = reduce_{p in row r} LayerNorm(relu(pa[ia[p]] + qb[ib[p]])) — one launch instead of
+    gather, gather, add, ReLU, LayerNorm, segmented reduce (csrc/incidence.hip)."""
+
+    @staticmethod
+    def forward(ctx, pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR, out_csr: CSR, okey32, mean, eps):
+        _require_gpu(pa, "incidence_ln_reduce")
+        pa, qb, gamma, beta = _f32c(pa), _f32c(qb), _f32c(gamma), _f32c(beta)
+        C = pa.shape[1]
+        out = torch.empty((out_csr.n_rows, C), dtype=torch.float32, device=pa.device)
+        hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
+            _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
+            _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
+            "hg_incidence_ln_reduce_fwd")
+        ctx.save_for_backward(pa, qb, gamma)
+        ctx.meta = (ia32, ib32, csr_a, csr_b, out_csr, okey32, mean, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, ds):
+        pa, qb, gamma = ctx.saved_tensors
+        ia32, ib32, csr_a, csr_b, out_csr, okey32, mean, eps = ctx.meta
+        ds = _f32c(ds)
+        C = pa.shape[1]
+        dev = pa.device
+        dpa, dqb, dgamma = torch.empty_like(pa), torch.empty_like(qb), torch.empty_like(gamma)
+        L = hip.lib()
+        ws_bytes = L.hg_incidence_ln_reduce_bwd_workspace_bytes(csr_a.n_rows, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        hip.check(L.hg_incidence_ln_reduce_bwd(
+            _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(csr_a.rowptr), _ptr(csr_a.perm), csr_a.n_rows,
+            _ptr(csr_b.rowptr), _ptr(csr_b.perm), csr_b.n_rows, _ptr(okey32), _ptr(out_csr.rowptr), _ptr(ds),
+            _ptr(gamma), C, 1 if mean else 0, float(eps), _ptr(dpa), _ptr(dqb), _ptr(dgamma), _ptr(ws), ws_bytes,
+            _stream(dev)), "hg_incidence_ln_reduce_bwd")
+        deg = out_csr.rowptr[1:] - out_csr.rowptr[:-1]
+        wrow = (deg > 0).to(ds.dtype) if mean else deg.to(ds.dtype)
+        dbeta = (ds * wrow[:, None]).sum(0)
+        return dpa, dqb, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
 class _RowGemm(torch.autograd.Function):
     """out[e] = z[e] @ w[row(e)] — hg_rowgemm_fwd/bwd (the radial tensor product of
     equiformer_layer.py:376-383 re-associated; see csrc/rowgemm.hip)."""
@@ -258,6 +298,14 @@ class _RowGemm(torch.autograd.Function):
 # --------------------------------------------------------------------------------------------
 # public functional API
 # --------------------------------------------------------------------------------------------
+def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR, out_csr: CSR, okey32,
+                        reduce: str = "mean", eps: float = 1e-5):
+    """reduce_{p in out row} LayerNorm(relu(pa[ia[p]] + qb[ib[p]])); csr_a / csr_b are the incidence
+    CSRs keyed by ia / ib (needed by the backward), out_csr the one keyed by okey32."""
+    return _IncidenceLnReduce.apply(pa, qb, gamma, beta, ia32, ib32, csr_a, csr_b, out_csr, okey32,
+                                    reduce == "mean", eps)
+
+
 def rowgemm(z, w, rowptr, perm=None):
     """out[e, :] = z[e, :] @ w[row(e)]; rows given by rowptr (+ perm: entry ids per row)."""
     return _RowGemm.apply(z, w, rowptr, perm)

@@ -142,6 +142,33 @@ int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int3
                    const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz,
                    int32_t accumulate_dz, float* dw, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused per-incidence hidden layer + aggregation — conv.py:90-93,96-97,175-177 with the MLP of
+ * mlp.py:91-99 (Linear -> ReLU -> LayerNorm -> Linear) after splitting the first Linear into
+ * node/hyperedge-level products (pa = X Wa^T, qb = E Wb^T + b) and moving the last Linear behind
+ * the (linear) aggregation:
+ *   out[r,:] = s(r) * sum_{q in row r} LN(relu(pa[ia[p]] + qb[ib[p]]))  with p = perm[q]
+ *            = gamma * (s(r) * sum xhat_p) + beta * (mean ? [deg>0] : deg)
+ * (rowptr, perm) is the CSR of the OUTPUT rows over incidences; ia/ib are the per-incidence row
+ * indices (int32) into pa/qb.  C <= 1024, multiple of 4.
+ * bwd: (a_rowptr,a_perm) / (b_rowptr,b_perm) are the CSRs of the incidences keyed by ia / ib;
+ * okey[p] is the output row of incidence p and orowptr the forward rowptr.  Produces dpa
+ * [n_a_rows,C], dqb [n_b_rows,C] and dgamma [C]; (d beta is a column sum of ds and is left to
+ * the caller).  Recomputes the LayerNorm statistics; nothing is saved by the forward.
+ * ------------------------------------------------------------------------------------------- */
+int hg_incidence_ln_reduce_fwd(const float* pa, const float* qb, const int32_t* ia, const int32_t* ib,
+                               const int32_t* rowptr, const int32_t* perm, const float* gamma,
+                               const float* beta, int64_t n_rows, int32_t C, int32_t mean, float eps,
+                               float* out, void* stream);
+size_t hg_incidence_ln_reduce_bwd_workspace_bytes(int64_t n_a_rows, int32_t C);
+int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, const int32_t* ia, const int32_t* ib,
+                               const int32_t* a_rowptr, const int32_t* a_perm, int64_t n_a_rows,
+                               const int32_t* b_rowptr, const int32_t* b_perm, int64_t n_b_rows,
+                               const int32_t* okey, const int32_t* orowptr, const float* ds,
+                               const float* gamma, int32_t C, int32_t mean, float eps, float* dpa,
+                               float* dqb, float* dgamma, void* workspace, size_t workspace_bytes,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

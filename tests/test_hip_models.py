@@ -72,12 +72,14 @@ def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed):
     # not a meaningful criterion here; require the same None-pattern and a small relative L2 error
     # per parameter.  The tight gradient check is test_hip_gradients_match_fp64_truth.
     gref = dict(ref.named_parameters())
+    # analytically-zero gradients (a bias in front of a train-mode BatchNorm) are pure rounding noise
+    floor = 1e-3 * max(float(q.grad.norm()) for q in gref.values() if q.grad is not None)
     for n, p in mine.named_parameters():
         r = gref[n].grad
         if r is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
-        rel = float((p.grad.cpu() - r).norm() / r.norm().clamp(min=1e-12))
+        rel = float((p.grad.cpu() - r).norm()) / max(float(r.norm()), floor)
         assert rel < 5e-2, (n, rel)
 
 
