@@ -213,11 +213,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  EQH_BACKEND=gloo exists only to rehearse the multi-rank code path
+        # on a one-GPU box (several ranks sharing one device cannot form an RCCL communicator).
+        backend = os.environ.get("EQH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if a.only_saturation:
         print(json.dumps({"saturation": saturation_probe(dev)}), flush=True)

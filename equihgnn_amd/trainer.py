@@ -155,13 +155,14 @@ class GraphedTrainStep:
                 self._loss(static).backward()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             self.flat.zero_()
             loss = self._loss(static)
             loss.backward()
         if self.opt_graph is None:
             self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph):
+            with torch.cuda.graph(self.opt_graph, capture_error_mode="thread_local"):
                 self.opt.step()
         return {"static": static, "graph": graph, "loss": loss}
 
