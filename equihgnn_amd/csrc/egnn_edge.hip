@@ -156,55 +156,86 @@ k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd,
     }
     __syncthreads();
 
-    // phase B
-    const int tiles = Hp >> 4;
-    for (int t = wave; t < tiles; t += WAVES) {
-        const int k = 16 * t + r;  // this lane's hidden unit
-        float wv[4];
+    // phase B: 64 hidden units per step (four MFMA column tiles); lane (r, q) owns the FOUR
+    // consecutive units k4 .. k4+3 with k4 = 64 T + 4 r, so every operand is a float4 load/store
+    // (column n = r of tile c is hidden unit k4 + c).
+    const int stiles = Hp >> 6;
+    for (int T = wave; T < stiles; T += WAVES) {
+        const int k4 = 64 * T + 4 * r;
+        float4 wv[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wv[s] = w2[(4 * q + s) * Hp + k];
-        const float wdk = wd[k];
-        f32x4 acc_w = {0.f, 0.f, 0.f, 0.f};  // dW2[o = 4q+g][k]
-        float acc_wd = 0.f;
+        for (int s = 0; s < 4; ++s) wv[s] = *reinterpret_cast<const float4*>(w2 + (4 * q + s) * Hp + k4);
+        const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
+        f32x4 acc_w[4];  // acc_w[c][g] = dW2[o = 4q+g][k4 + c]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc_w[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float acc_wd[4] = {0.f, 0.f, 0.f, 0.f};
         for (int n = 0; n < cnt; ++n) {
             const int node = base + n;
-            // g[j = 4q+g][k] = sum_o dpre2[j][o] * W2[o][k]
             const float4 pa = *reinterpret_cast<const float4*>(&s_p[n][r * PLD + 4 * q]);
-            f32x4 gk = {0.f, 0.f, 0.f, 0.f};
-            gk = mfma16(pa.x, wv[0], gk);
-            gk = mfma16(pa.y, wv[1], gk);
-            gk = mfma16(pa.z, wv[2], gk);
-            gk = mfma16(pa.w, wv[3], gk);
-            const float ai = ab[(int64_t)node * 2 * Hp + k];
-            float sv[4];
-            float da = 0.f;
+            const float pav[4] = {pa.x, pa.y, pa.z, pa.w};
+            f32x4 gk[4];  // gk[c][g] = sum_o dpre2[j = 4q+g][o] * W2[o][k4 + c]
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                gk[0] = mfma16(pav[s], wv[s].x, gk[0]);
+                gk[1] = mfma16(pav[s], wv[s].y, gk[1]);
+                gk[2] = mfma16(pav[s], wv[s].z, gk[2]);
+                gk[3] = mfma16(pav[s], wv[s].w, gk[3]);
+            }
+            const float4 ai4 = *reinterpret_cast<const float4*>(ab + (int64_t)node * 2 * Hp + k4);
+            const float aiv[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
+            const float wdv[4] = {wd4.x, wd4.y, wd4.z, wd4.w};
+            float sv[4][4];  // sv[c][g] = silu(h[j = 4q+g][k4 + c])
+            float da[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int jn = s_nbr[n][4 * q + g];
                 const float dd = s_d2[n][4 * q + g];
-                const float h = fmaf(wdk, dd, ai + ab[(int64_t)jn * 2 * Hp + Hp + k]);
-                float ds;
-                sv[g] = silu_grad(h, &ds);
-                const float dh = gk[g] * ds;
-                da += dh;
-                acc_wd = fmaf(dh, dd, acc_wd);
+                const float4 b4 = *reinterpret_cast<const float4*>(ab + (int64_t)jn * 2 * Hp + Hp + k4);
+                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float h = fmaf(wdv[c], dd, aiv[c] + bv[c]);
+                    float ds;
+                    sv[c][g] = silu_grad(h, &ds);
+                    const float dh = gk[c][g] * ds;
+                    da[c] += dh;
+                    acc_wd[c] = fmaf(dh, dd, acc_wd[c]);
+                }
             }
-            da += __shfl_xor(da, 16, 64);
-            da += __shfl_xor(da, 32, 64);
-            if (q == 0) dab[(int64_t)node * 2 * Hp + k] = da;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                da[c] += __shfl_xor(da[c], 16, 64);
+                da[c] += __shfl_xor(da[c], 32, 64);
+            }
+            if (q == 0)
+                *reinterpret_cast<float4*>(dab + (int64_t)node * 2 * Hp + k4) = make_float4(da[0], da[1], da[2], da[3]);
             // dW2[o][k] += sum_j dpre2[j][o] * s[j][k]
             const float4 pt = *reinterpret_cast<const float4*>(&s_pt[n][r * PLD + 4 * q]);
-            acc_w = mfma16(pt.x, sv[0], acc_w);
-            acc_w = mfma16(pt.y, sv[1], acc_w);
-            acc_w = mfma16(pt.z, sv[2], acc_w);
-            acc_w = mfma16(pt.w, sv[3], acc_w);
+            const float ptv[4] = {pt.x, pt.y, pt.z, pt.w};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc_w[0] = mfma16(ptv[g], sv[0][g], acc_w[0]);
+                acc_w[1] = mfma16(ptv[g], sv[1][g], acc_w[1]);
+                acc_w[2] = mfma16(ptv[g], sv[2][g], acc_w[2]);
+                acc_w[3] = mfma16(ptv[g], sv[3][g], acc_w[3]);
+            }
         }
         float* __restrict__ sw = slab_w2 + (int64_t)blockIdx.x * MDIM * Hp;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) sw[(4 * q + g) * Hp + k] = acc_w[g];
-        acc_wd += __shfl_xor(acc_wd, 16, 64);
-        acc_wd += __shfl_xor(acc_wd, 32, 64);
-        if (q == 0) slab_wd[(int64_t)blockIdx.x * Hp + k] = acc_wd;
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(sw + (4 * q + g) * Hp + k4) =
+                make_float4(acc_w[0][g], acc_w[1][g], acc_w[2][g], acc_w[3][g]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            acc_wd[c] += __shfl_xor(acc_wd[c], 16, 64);
+            acc_wd[c] += __shfl_xor(acc_wd[c], 32, 64);
+        }
+        if (q == 0)
+            *reinterpret_cast<float4*>(slab_wd + (int64_t)blockIdx.x * Hp + k4) =
+                make_float4(acc_wd[0], acc_wd[1], acc_wd[2], acc_wd[3]);
     }
 }
 
@@ -221,7 +252,6 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
                 const int* __restrict__ t_perm, float* __restrict__ dab, int N, int Hp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int tiles = Hp >> 4;
     for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
         const int beg = t_rowptr[node], end = t_rowptr[node + 1];
         float* __restrict__ drow = dab + (int64_t)node * 2 * Hp + Hp;
@@ -246,26 +276,51 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
             }
             float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
             if (e_r >= 0) pa = *reinterpret_cast<const float4*>(dpre2 + (int64_t)e_r * MDIM + 4 * q);
-            for (int t = 0; t < tiles; ++t) {
-                const int k = 16 * t + r;
-                f32x4 gk = {0.f, 0.f, 0.f, 0.f};
-                gk = mfma16(pa.x, w2[(4 * q + 0) * Hp + k], gk);
-                gk = mfma16(pa.y, w2[(4 * q + 1) * Hp + k], gk);
-                gk = mfma16(pa.z, w2[(4 * q + 2) * Hp + k], gk);
-                gk = mfma16(pa.w, w2[(4 * q + 3) * Hp + k], gk);
-                const float bj = brow[k];
-                const float wdk = wd[k];
-                float db = 0.f;
+            const float pav[4] = {pa.x, pa.y, pa.z, pa.w};
+            const int stiles = Hp >> 6;
+            for (int T = 0; T < stiles; ++T) {
+                const int k4 = 64 * T + 4 * r;  // this lane's four consecutive hidden units
+                f32x4 gk[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(w2 + (4 * q + s) * Hp + k4);
+                    gk[0] = mfma16(pav[s], w4.x, gk[0]);
+                    gk[1] = mfma16(pav[s], w4.y, gk[1]);
+                    gk[2] = mfma16(pav[s], w4.z, gk[2]);
+                    gk[3] = mfma16(pav[s], w4.w, gk[3]);
+                }
+                const float4 bj4 = *reinterpret_cast<const float4*>(brow + k4);
+                const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
+                const float bjv[4] = {bj4.x, bj4.y, bj4.z, bj4.w};
+                const float wdv[4] = {wd4.x, wd4.y, wd4.z, wd4.w};
+                float db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float h = fmaf(wdk, dd_g[g], ab[arow_g[g] + k] + bj);
-                    float ds;
-                    silu_grad(h, &ds);
-                    db = fmaf(gk[g], ds, db);  // gk is exactly 0 for padded entries
+                    const float4 a4 = *reinterpret_cast<const float4*>(ab + arow_g[g] + k4);
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float h = fmaf(wdv[c], dd_g[g], av[c] + bjv[c]);
+                        float ds;
+                        silu_grad(h, &ds);
+                        db[c] = fmaf(gk[c][g], ds, db[c]);  // gk is exactly 0 for padded entries
+                    }
                 }
-                db += __shfl_xor(db, 16, 64);
-                db += __shfl_xor(db, 32, 64);
-                if (q == 0) drow[k] = first ? db : drow[k] + db;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    db[c] += __shfl_xor(db[c], 16, 64);
+                    db[c] += __shfl_xor(db[c], 32, 64);
+                }
+                if (q == 0) {
+                    float4 o = make_float4(db[0], db[1], db[2], db[3]);
+                    if (!first) {
+                        const float4 prev = *reinterpret_cast<const float4*>(drow + k4);
+                        o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
+                    }
+                    *reinterpret_cast<float4*>(drow + k4) = o;
+                }
             }
         }
     }
@@ -273,7 +328,7 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
 
 int check_common(int64_t N, int Hp) {
     if (N < 0 || Hp <= 0) return EQH_ERR_ARG;
-    if (Hp & 15) return EQH_ERR_ALIGN;
+    if (Hp & 63) return EQH_ERR_ALIGN;  // the backward walks 64 hidden units per step
     if (N * 2 * (int64_t)Hp >= ((int64_t)1 << 31) * 4) return EQH_ERR_RANGE;
     if (N * KNB >= ((int64_t)1 << 31)) return EQH_ERR_RANGE;
     return EQH_OK;

@@ -126,8 +126,8 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
         # gather + gather + add + ReLU + LayerNorm + segmented reduce in ONE kernel (incidence.hip)
         s = ops.incidence_ln_reduce(pa, qb, norm.weight, norm.bias, idx_a32, idx_b32, csr_a, csr_b,
                                     out_csr, out_key32, aggr, norm.eps)
-        return F.linear(s, last.weight) + last.bias * (has_row if aggr == "mean" else
-                                                       (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype)[:, None])
+        rows = has_row if aggr == "mean" else (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype)[:, None]
+        return torch.addcmul(F.linear(s, last.weight), rows, last.bias)
     h = ops.gather_rows(pa, idx_a32, csr_a) + ops.gather_rows(qb, idx_b32, csr_b)  # [nnz, C]
     if len(mlp.lins) == 1:              # a single Linear: everything is linear in h
         return ops.reduce_entries(h, out_csr, out_key32, aggr)
@@ -196,7 +196,7 @@ class MHNNSConv(nn.Module):
         x_e = ops.reduce_gathered(self.W1(X), ix.by_e, ix.by_v, self.aggr)       # conv.py:172-173
         x_v = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                             ix.has_v, self.aggr)                                 # conv.py:175-177
-        return self.W3((1 - self.alpha) * x_v + self.alpha * X0)                 # conv.py:179-180
+        return self.W3(torch.lerp(x_v, X0, self.alpha))      # (1-a)*x_v + a*X0, conv.py:179-180
 
 
 class CoorsNorm(nn.Module):
@@ -234,10 +234,10 @@ class EGNN(nn.Module):
         c = self.dim
         nbr, d2, csr_t = index.knn(coors, self.k, 0)
         lin1, lin2 = self.edge_mlp[0], self.edge_mlp[3]
-        # hidden width H = 2(2C+1) is padded with zero rows to a multiple of 16 so that rows stay
-        # 16-byte aligned for the gather kernel; silu(0) = 0, so the padding contributes nothing
+        # hidden width H = 2(2C+1) is padded with zero rows to a multiple of 64 (the edge kernels walk
+        # 64 hidden units per step); silu(0) = 0, so the padding contributes nothing
         hdim = lin1.weight.shape[0]
-        pad = (-hdim) % 16
+        pad = (-hdim) % 64
         w1 = F.pad(lin1.weight, (0, 0, 0, pad))
         b1 = F.pad(lin1.bias, (0, pad))
         w2 = F.pad(lin2.weight, (0, pad))
