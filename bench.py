@@ -27,6 +27,17 @@ if not os.environ.get("EQH_NO_TUNABLEOP"):
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "50")
     os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME",
                           os.path.join(os.environ.get("TMPDIR", "/tmp"), "eqh_tunableop_%d.csv"))
+    # seed every rank's results file with the selections committed for the BASELINE shapes, so only
+    # shapes that are new (another batch size / method) are tuned during warm-up
+    _seed = os.path.join(os.path.dirname(os.path.abspath(__file__)), "equihgnn_amd", "tuned",
+                         "tunableop_gfx950.csv")
+    _dst = os.environ["PYTORCH_TUNABLEOP_FILENAME"].replace("%d", os.environ.get("LOCAL_RANK", "0"))
+    if os.path.exists(_seed) and not os.path.exists(_dst):
+        try:
+            import shutil
+            shutil.copyfile(_seed, _dst)
+        except OSError:
+            pass
 
 import torch
 import torch.distributed as dist
