@@ -228,6 +228,109 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Row-wise hidden layer of mlp.py:91-99 on dense rows: y = LayerNorm(relu(h + b)).  Same arithmetic
+// as load_norm with a = row, b = the bias row; the backward also produces the column sums that are
+// the bias gradient of the preceding Linear, d gamma and d beta (per-workgroup slabs, fixed order).
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_rowln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
+            const float* __restrict__ beta, float* __restrict__ out, int n_rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
+        Row<NV> x;
+        unsigned pos;
+        float rstd;
+        load_norm<NV>(h, bias, r, 0, C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                float4 o;
+                o.x = fmaf(g.x, x.v[i].x, b.x); o.y = fmaf(g.y, x.v[i].y, b.y);
+                o.z = fmaf(g.z, x.v[i].z, b.z); o.w = fmaf(g.w, x.v[i].w, b.w);
+                *reinterpret_cast<float4*>(out + (int64_t)r * C + c) = o;
+            }
+        }
+    }
+}
+
+// slab layout per workgroup: [dbias | dgamma | dbeta], each C floats
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
+            const float* __restrict__ dy, float* __restrict__ dh, float* __restrict__ slab, int n_rows,
+            int C, float eps) {
+    __shared__ float4 s_red[THREADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    Row<NV> gam, a_db, a_dg, a_dbeta;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
+        a_db.v[i] = a_dg.v[i] = a_dbeta.v[i] = f4_zero();
+    }
+    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
+        Row<NV> x, g;
+        unsigned pos;
+        float rstd;
+        load_norm<NV>(h, bias, r, 0, C, lane, inv_c, eps, x, pos, &rstd);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            float4 d = f4_zero();
+            if (c < C) d = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
+            f4_add(a_dbeta.v[i], d);
+            a_dg.v[i].x = fmaf(d.x, x.v[i].x, a_dg.v[i].x); a_dg.v[i].y = fmaf(d.y, x.v[i].y, a_dg.v[i].y);
+            a_dg.v[i].z = fmaf(d.z, x.v[i].z, a_dg.v[i].z); a_dg.v[i].w = fmaf(d.w, x.v[i].w, a_dg.v[i].w);
+            d.x *= gam.v[i].x; d.y *= gam.v[i].y; d.z *= gam.v[i].z; d.w *= gam.v[i].w;
+            g.v[i] = d;
+            m1 += (d.x + d.y) + (d.z + d.w);
+            m2 += (d.x * x.v[i].x + d.y * x.v[i].y) + (d.z * x.v[i].z + d.w * x.v[i].w);
+        }
+        wave_sum2(m1, m2);
+        m1 *= inv_c;
+        m2 *= inv_c;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            const unsigned b = pos >> (4 * i);
+            float4 dx;
+            dx.x = (b & 1u) ? rstd * (g.v[i].x - m1 - x.v[i].x * m2) : 0.f;
+            dx.y = (b & 2u) ? rstd * (g.v[i].y - m1 - x.v[i].y * m2) : 0.f;
+            dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
+            dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
+            f4_add(a_db.v[i], dx);
+            if (c < C) *reinterpret_cast<float4*>(dh + (int64_t)r * C + c) = dx;
+        }
+    }
+    // combine the workgroup's four wavefronts in a fixed order, one slab row per quantity
+    float* __restrict__ sl = slab + (int64_t)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s_red[threadIdx.x] = which == 0 ? a_db.v[i] : (which == 1 ? a_dg.v[i] : a_dbeta.v[i]);
+            __syncthreads();
+            if (wave == 0) {
+                float4 t = s_red[lane];
+                for (int w2 = 1; w2 < WAVES; ++w2) f4_add(t, s_red[w2 * 64 + lane]);
+                const int c = (lane + 64 * i) * 4;
+                if (c < C) *reinterpret_cast<float4*>(sl + which * C + c) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+inline int rowln_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES * 4, 256); }
+
 inline int bwd_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES, 512); }
 
 int check(int64_t rows, int C) {
@@ -305,5 +408,54 @@ extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, cons
                            (int)n_b_rows, (int)C, (int)mean, eps);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream);
+    });
+}
+
+extern "C" int hg_bias_relu_ln_fwd(const float* h, const float* bias, const float* gamma,
+                                   const float* beta, int64_t n_rows, int32_t C, float eps, float* out,
+                                   void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!h || !bias || !gamma || !beta || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(h) || !eqh_aligned16(bias) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) ||
+        !eqh_aligned16(out))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_rowln_fwd<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, h,
+                           bias, gamma, beta, out, (int)n_rows, (int)C, eps);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C) {
+    if (n_rows < 0 || C <= 0) return 0;
+    return (size_t)rowln_blocks(n_rows) * 3 * (size_t)C * sizeof(float);
+}
+
+extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
+                                   int64_t n_rows, int32_t C, float eps, float* dh, float* dbias_dgamma_dbeta,
+                                   void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (!dbias_dgamma_dbeta) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_rows == 0) return eqh_zero_async(dbias_dgamma_dbeta, 3 * (int64_t)C, stream);
+    if (!h || !bias || !gamma || !dy || !dh || !workspace) return EQH_ERR_ARG;
+    if (!eqh_aligned16(h) || !eqh_aligned16(dy) || !eqh_aligned16(dh) || !eqh_aligned16(workspace) ||
+        !eqh_aligned16(bias) || !eqh_aligned16(gamma))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_bias_relu_ln_bwd_workspace_bytes(n_rows, C)) return EQH_ERR_ARG;
+    const int blocks = rowln_blocks(n_rows);
+    float* slab = static_cast<float*>(workspace);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_rowln_bwd<NV>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
+                           (int)n_rows, (int)C, eps);
+        EQH_CHECK_LAUNCH();
+        return eqh_reduce_slabs_async(slab, blocks, 3 * (int64_t)C, dbias_dgamma_dbeta, stream);
     });
 }

@@ -97,10 +97,22 @@ class MLP(nn.Module):
             h = F.dropout(h, p=self.dropout, training=self.training)
         return h
 
+    def _fusable(self, x):
+        return (x.is_cuda and x.dim() == 2 and not (self.training and self.dropout > 0)
+                and all(isinstance(n, nn.LayerNorm) for n in self.normalizations[1:])
+                and all(l.out_features % 4 == 0 and l.out_features <= 1024 for l in self.lins[:-1]))
+
     def forward(self, x):
         x = self.normalizations[0](x)
         if len(self.lins) == 1:
             return self.lins[0](x)
+        if self._fusable(x):
+            # bias-free GEMM, then bias + ReLU + LayerNorm in one launch (its backward also yields
+            # the bias gradient, so no separate column-sum kernel runs)
+            for i in range(len(self.lins) - 1):
+                lin, norm = self.lins[i], self.normalizations[i + 1]
+                x = ops.bias_relu_ln(F.linear(x, lin.weight), lin.bias, norm.weight, norm.bias, norm.eps)
+            return self.lins[-1](x)
         h = self.hidden(self.lins[0](x), 0)
         return self.lins[-1](h)
 

@@ -264,6 +264,37 @@ class _IncidenceLnReduce(torch.autograd.Function):
         return dpa, dqb, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+class _BiasReluLn(torch.autograd.Function):
+    """LayerNorm(relu(h + bias)) over dense rows in one launch; the backward returns dh and, from the
+    same pass, the bias / gamma / beta gradients (csrc/incidence.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, bias, gamma, beta, eps):
+        _require_gpu(h, "bias_relu_ln")
+        h, bias, gamma, beta = _f32c(h), _f32c(bias), _f32c(gamma), _f32c(beta)
+        R, C = h.shape
+        out = torch.empty_like(h)
+        hip.check(hip.lib().hg_bias_relu_ln_fwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(beta), R, C, float(eps),
+                                                _ptr(out), _stream(h.device)), "hg_bias_relu_ln_fwd")
+        ctx.save_for_backward(h, bias, gamma)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, bias, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = h.shape
+        dh = torch.empty_like(h)
+        small = torch.empty((3, C), dtype=torch.float32, device=h.device)
+        L = hip.lib()
+        ws_bytes = L.hg_bias_relu_ln_bwd_workspace_bytes(R, C)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device)
+        hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
+                                        _ptr(small), _ptr(ws), ws_bytes, _stream(h.device)), "hg_bias_relu_ln_bwd")
+        return dh, small[0], small[1], small[2], None
+
+
 class _RowGemm(torch.autograd.Function):
     """out[e] = z[e] @ w[row(e)] — hg_rowgemm_fwd/bwd (the radial tensor product of
     equiformer_layer.py:376-383 re-associated; see csrc/rowgemm.hip)."""
@@ -304,6 +335,11 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
     CSRs keyed by ia / ib (needed by the backward), out_csr the one keyed by okey32."""
     return _IncidenceLnReduce.apply(pa, qb, gamma, beta, ia32, ib32, csr_a, csr_b, out_csr, okey32,
                                     reduce == "mean", eps)
+
+
+def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
+    """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C]."""
+    return _BiasReluLn.apply(h, bias, gamma, beta, eps)
 
 
 def rowgemm(z, w, rowptr, perm=None):

@@ -103,14 +103,18 @@ class GraphedTrainStep:
     eagerly between the two graphs (RCCL on its own terms), and the fused Adam update is a second
     graph.  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
     without batch statistics); the loss is taken over the real molecules only.
+
+    Gradients are the tensors autograd allocates inside the captured backward (``grad=None`` before
+    the capture, so the first contribution is written, not added — pre-allocated gradients cost one
+    extra add kernel per parameter use).  With more than one rank they are packed into one flat
+    buffer at the end of the first graph, all-reduced, and unpacked at the start of the second.
     """
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
                  broadcast_from_rank0: bool = True):
         self.model, self.lr, self.wd = model, lr, weight_decay
-        self.flat: Optional[FlatGradients] = None
+        self.live = None
         self.opt = None
-        self.opt_graph = None
         self.slots = {}
         if broadcast_from_rank0 and _world() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
@@ -126,48 +130,65 @@ class GraphedTrainStep:
             data._hyper_index = None
         return F.mse_loss(self.model(data)[:nb], data.y[:nb])
 
-    def _bootstrap(self, data):
-        """Eager first step: discovers the live parameters, lays out the flat gradient buffer,
-        creates the capturable fused Adam (also performs every lazy one-time initialisation of the
-        HIP library before anything is captured)."""
+    def _fwd_bwd(self, data):
         for p in self.model.parameters():
             p.grad = None
         loss = self._loss(data)
         loss.backward()
-        live = [p for p in self.model.parameters() if p.grad is not None]
-        first = [p.grad.clone() for p in live]
-        self.flat = FlatGradients(live)
-        for p, g in zip(live, first):
-            p.grad.copy_(g)
-        self.opt = torch.optim.Adam(live, lr=self.lr, weight_decay=self.wd, fused=True, capturable=True)
-        self.flat.all_reduce_mean()
+        return loss
+
+    def _reduce_eager(self):
+        if _world() > 1:
+            grads = [p.grad for p in self.live]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / _world())
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+
+    def _bootstrap(self, data):
+        """Eager first step: discovers the live parameters and creates the capturable fused Adam
+        (also performs every lazy one-time initialisation of the HIP library and of the GEMM
+        libraries before anything is captured)."""
+        loss = self._fwd_bwd(data)
+        self.live = [p for p in self.model.parameters() if p.grad is not None]
+        self.opt = torch.optim.Adam(self.live, lr=self.lr, weight_decay=self.wd, fused=True, capturable=True)
+        self._reduce_eager()
         self.opt.step()
         return loss.detach()
 
-    def _capture(self, data):
-        import copy
-        static = copy.copy(data)  # same static tensors; the slot owns them from now on
+    def _capture(self, static):
+        world = _world()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
             for _ in range(2):
-                self.flat.zero_()
-                self._loss(static).backward()
+                self._fwd_bwd(static)
         torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
+        for p in self.model.parameters():
+            p.grad = None
+        g_bwd = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            self.flat.zero_()
+        with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
             loss = self._loss(static)
             loss.backward()
-        if self.opt_graph is None:
-            self.opt_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.opt_graph, capture_error_mode="thread_local"):
-                self.opt.step()
-        return {"static": static, "graph": graph, "loss": loss}
+            grads = [p.grad for p in self.live]
+            flat = torch.cat([g.reshape(-1) for g in grads]) if world > 1 else None
+        g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
+            if world > 1:
+                flat.mul_(1.0 / world)
+                off = 0
+                for g in grads:
+                    g.copy_(flat[off:off + g.numel()].view_as(g))
+                    off += g.numel()
+            self.opt.step()
+        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss, "flat": flat, "grads": grads}
 
     def step(self, data) -> torch.Tensor:
-        if self.flat is None:
+        if self.live is None:
             return self._bootstrap(data)
         key = self._key(data)
         slot = self.slots.get(key)
@@ -181,7 +202,8 @@ class GraphedTrainStep:
             v = getattr(data, f)
             if torch.is_tensor(v):
                 getattr(st, f).copy_(v, non_blocking=True)
-        slot["graph"].replay()
-        self.flat.all_reduce_mean()
-        self.opt_graph.replay()
+        slot["bwd"].replay()
+        if slot["flat"] is not None:
+            dist.all_reduce(slot["flat"], op=dist.ReduceOp.SUM)
+        slot["opt"].replay()
         return slot["loss"].detach()

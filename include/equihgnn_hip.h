@@ -169,6 +169,19 @@ int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, const int32_t* 
                                float* dqb, float* dgamma, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense-row hidden layer of mlp.py:91-99: out = LayerNorm(relu(h + bias)) with h = x W^T computed
+ * by a bias-free library GEMM.  bwd: dh = d relu . d LayerNorm (recomputed statistics) and, from
+ * the same pass, [dbias | dgamma | dbeta] (3*C floats; dbias = column sums of dh is the bias
+ * gradient of the preceding Linear).  C <= 1024, multiple of 4.
+ * ------------------------------------------------------------------------------------------- */
+int hg_bias_relu_ln_fwd(const float* h, const float* bias, const float* gamma, const float* beta,
+                        int64_t n_rows, int32_t C, float eps, float* out, void* stream);
+size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C);
+int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
+                        int64_t n_rows, int32_t C, float eps, float* dh, float* dbias_dgamma_dbeta,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -354,3 +354,22 @@ def test_incidence_ln_reduce_matches_float64_reference(C, reduce):
     for name, x, r in zip(("dpa", "dqb", "dgamma", "dbeta"), d, t):
         err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max())
         assert err < 2e-5, (name, err)
+
+
+@pytest.mark.parametrize("R,C", [(1, 64), (37, 128), (1000, 256), (300, 1024)])
+def test_bias_relu_ln_matches_float64_reference(R, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    h, b = torch.randn(R, C, generator=g), 0.3 * torch.randn(C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    w = torch.randn(R, C, generator=g)
+    t = [x.double().requires_grad_(True) for x in (h, b, gamma, beta)]
+    ref = torch.nn.functional.layer_norm(torch.relu(t[0] + t[1]), (C,), t[2], t[3], 1e-5)
+    (ref * w.double()).sum().backward()
+    d = [x.to(DEV).requires_grad_(True) for x in (h, b, gamma, beta)]
+    out = ops.bias_relu_ln(d[0], d[1], d[2], d[3])
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    for name, x, r in zip(("dh", "dbias", "dgamma", "dbeta"), d, t):
+        err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
+        assert err < 3e-5, (name, err)
