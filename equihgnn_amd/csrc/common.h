@@ -41,18 +41,29 @@ static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
 }
 
-// out[e] = sum_b slab[b][e] for e < elems, summed in a FIXED order (bitwise reproducible): a block
-// covers 64 consecutive elements with 4 slab-groups (b = g, g+4, ...) that are combined through LDS.
+// out[e] = sum_b slab[b][e] for e < elems, summed in a FIXED order (bitwise reproducible).  A block
+// covers 64 consecutive elements with 4 slab-groups (b = g, g+4, ...); each group keeps 4 independent
+// partial sums so that four loads are in flight per lane (the loop is latency-, not bandwidth-bound),
+// and the groups are combined through LDS.
 static __global__ void __launch_bounds__(256)
 eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out) {
     __shared__ float s_part[256];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < elems; e0 += (int64_t)gridDim.x * 64) {
         const int64_t e = e0 + col;
-        float acc = 0.f;
-        if (e < elems)
-            for (int b = grp; b < n_slabs; b += 4) acc += slab[(int64_t)b * elems + e];
-        s_part[threadIdx.x] = acc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (e < elems) {
+            int b = grp;
+            for (; b + 12 < n_slabs; b += 16) {
+                const float v0 = slab[(int64_t)b * elems + e];
+                const float v1 = slab[(int64_t)(b + 4) * elems + e];
+                const float v2 = slab[(int64_t)(b + 8) * elems + e];
+                const float v3 = slab[(int64_t)(b + 12) * elems + e];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; b < n_slabs; b += 4) a0 += slab[(int64_t)b * elems + e];
+        }
+        s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
         __syncthreads();
         if (grp == 0 && e < elems) out[e] = ((s_part[col] + s_part[64 + col]) + s_part[128 + col]) + s_part[192 + col];
         __syncthreads();

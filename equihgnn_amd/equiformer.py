@@ -120,7 +120,9 @@ class EdgeGeometry:
             safe = dist.clamp(min=1e-30)[..., None]
             rhat = rel / safe
             # coincident points: the reference's rotation-to-y construction yields D[:, m=0] = y
-            rhat = torch.where((dist == 0)[..., None], rhat.new_tensor([0.0, 1.0, 0.0]), rhat)
+            yhat = torch.zeros_like(rhat)  # built on the device: no host copy inside a hipGraph capture
+            yhat[..., 1] = 1.0
+            rhat = torch.where((dist == 0)[..., None], yhat, rhat)
         self.dist = dist.reshape(-1, 1)                                   # [E, 1] true distance
         self.rhat = rhat.reshape(-1, 3)                                   # [E, 3] = D[:, m=0]
         self.mask = (dist <= radius)                                      # [N, K]   :1307
