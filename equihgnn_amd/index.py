@@ -41,6 +41,16 @@ class HyperIndex:
             self.batch32 = batch.to(torch.int32)
             self.pool = ops.csr_build(batch, None, self.B)
         self._knn = {}
+        self._he_pool = None
+
+    def hyperedge_pool(self, n_e: torch.Tensor):
+        """CSR of hyperedges per molecule (from ``n_e``; hyperedges are stored molecule by molecule,
+        data/utils.py:172-178) for the high-order-hyperedge pooling of mhnn.py:72."""
+        if self._he_pool is None:
+            b = n_e.shape[0]
+            e_batch = torch.repeat_interleave(torch.arange(b, device=n_e.device), n_e, output_size=self.M)
+            self._he_pool = (ops.csr_build(e_batch, None, b), e_batch.to(torch.int32))
+        return self._he_pool
 
     @classmethod
     def from_batch(cls, data) -> "HyperIndex":

@@ -161,4 +161,135 @@ class EquiformerEquiHNNS(nn.Module):
         return self.mlp_out(x).view(-1)
 
 
-MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "equiformer_equihnns": EquiformerEquiHNNS}
+class _PairedBase(nn.Module):
+    """``mhnn`` (mhnn.py:11-81) and ``egnn_equihnn`` (equihnn_egnn.py:12-95): ONE shared MHNNConv
+    applied L times; nodes and hyperedges of order > 2 are pooled per molecule and concatenated.
+    The reference sizes the hyperedge pool by ``he_batch.max()+1`` and fails in ``torch.cat`` when the
+    last molecules of a batch have no such hyperedge; here they get a zero row."""
+
+    def __init__(self, num_target, args, with_egnn: bool):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.mlp4_layers = args.MLP4_num_layers
+        self.nlayer = args.All_num_layers
+        if with_egnn:
+            self.egnn_layer = EGNN(dim=args.MLP_hidden, num_nearest_neighbors=16)
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.bond_encoder = BondEncoder(6, args.MLP_hidden)
+        self.conv = MHNNConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers, mlp2_layers=self.mlp2_layers,
+                             mlp3_layers=self.mlp3_layers, mlp4_layers=self.mlp4_layers,
+                             aggr=args.aggregate, dropout=args.dropout, normalization=args.normalization)
+        self.mlp_out = MLP(in_channels=args.MLP_hidden * 2, hidden_channels=args.output_hidden * 2,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+        self.with_egnn = with_egnn
+
+    def forward(self, data, taps=None):
+        from . import ops
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        if self.with_egnn:
+            x = self.egnn_layer(x, data.pos, index)
+            if taps is not None:
+                taps["front_end"] = x
+        e = self.bond_encoder(data.edge_attr)
+        for i in range(self.nlayer):
+            x, e = self.conv(x, e, index)
+            if i != self.nlayer - 1:
+                x, e = self.act(x), self.act(e)
+            x, e = self.dropout(x), self.dropout(e)
+        xp = pool_sum(x, index)
+        he_csr, he_key = index.hyperedge_pool(data.n_e)
+        keep = (data.e_order > 2).to(e.dtype).unsqueeze(-1)            # mhnn.py:58,72
+        ep = ops.reduce_entries(e * keep, he_csr, he_key, "sum")
+        both = torch.cat((xp, ep), -1)
+        if taps is not None:
+            taps["pool"] = both
+        return self.mlp_out(both).view(-1)
+
+
+@registry.register_model("mhnn")
+class MHNN(_PairedBase):
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args, with_egnn=False)
+
+
+@registry.register_model("egnn_equihnn")
+class EGNNEquiHNN(_PairedBase):
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args, with_egnn=True)
+
+
+@registry.register_model("mhnns")
+class MHNNS(nn.Module):
+    """mhnn.py:84-141: shared MHNNSConv x L on atom embeddings (no geometric front-end)."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.conv = MHNNSConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers, mlp2_layers=self.mlp2_layers,
+                              mlp3_layers=self.mlp3_layers, aggr=args.aggregate, dropout=args.dropout,
+                              normalization=args.normalization)
+        self.mlp_out = MLP(in_channels=args.MLP_hidden, hidden_channels=args.output_hidden,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def reset_parameters(self):
+        self.conv.reset_parameters()
+        self.mlp_out.reset_parameters()
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        x0 = x
+        for i in range(self.nlayer):
+            x = self.conv(self.dropout(x), index, x0)
+            if taps is not None:
+                taps[f"conv{i}"] = x
+            x = self.act(x)
+        x = pool_sum(self.dropout(x), index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+@registry.register_model("egnn_equihnnm")
+class EGNNEquiHNNM(MHNNM):
+    """equihnn_egnn.py:172-261: mhnnm with the EGNN front-end applied once to the atom embeddings."""
+
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args)
+        self.egnn_layer = EGNN(dim=args.MLP_hidden, num_nearest_neighbors=16)
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.egnn_layer(self.atom_encoder(data.x), data.pos, index)
+        if taps is not None:
+            taps["front_end"] = x
+        e = self.bond_encoder(data.edge_attr)
+        for i, layer in enumerate(self.layers):
+            x, e = layer(x, e, index)
+            x = self.batch_norms[i](x)
+            if taps is not None:
+                taps[f"bn{i}"] = x
+            if i != self.nlayer - 1:
+                x, e = self.act(x), self.act(e)
+            x, e = self.dropout(x), self.dropout(e)
+        x = pool_sum(x, index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "equiformer_equihnns": EquiformerEquiHNNS,
+          "mhnn": MHNN, "mhnns": MHNNS, "egnn_equihnn": EGNNEquiHNN, "egnn_equihnnm": EGNNEquiHNNM}

@@ -303,4 +303,128 @@ class MHNNM(nn.Module):
         return self.mlp_out(x).view(-1)
 
 
-MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM}
+def hyperedge_batch(data):
+    """mhnn.py:54-58: molecule id of every hyperedge (from n_e) — built without the reference's
+    per-molecule ``.item()`` loop."""
+    b = data.n_e.shape[0]
+    return torch.repeat_interleave(torch.arange(b, device=data.x.device), data.n_e)
+
+
+def pool_high_order(e, data):
+    """mhnn.py:72: global_add_pool(e[e_order > 2], he_batch).  The reference sizes the result by
+    he_batch.max()+1 and then fails in torch.cat when the last molecules have no hyperedge of
+    order > 2; here such molecules simply get a zero row (identical whenever the reference runs)."""
+    keep = (data.e_order > 2).to(e.dtype).unsqueeze(-1)
+    return segment_reduce(e * keep, hyperedge_batch(data), data.n_e.shape[0], "sum")
+
+
+class _PairedBase(nn.Module):
+    """Common part of mhnn.py:11-81 (``mhnn``) and equihnn_egnn.py:12-95 (``egnn_equihnn``): ONE
+    shared MHNNConv applied L times, node AND high-order-hyperedge pooling, 2C-wide head."""
+
+    def __init__(self, num_target, args, with_egnn):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.nlayer = args.All_num_layers
+        if with_egnn:
+            self.egnn_layer = EGNN(args.MLP_hidden)
+        self.atom_encoder = AtomEncoder(args.MLP_hidden)
+        self.bond_encoder = nn.Embedding(6, args.MLP_hidden)
+        self.conv = MHNNConv(args.MLP_hidden, args.MLP1_num_layers, args.MLP2_num_layers,
+                             args.MLP3_num_layers, args.MLP4_num_layers, aggr=args.aggregate,
+                             dropout=args.dropout, normalization=args.normalization)
+        self.mlp_out = MLP(args.MLP_hidden * 2, args.output_hidden * 2, num_target,
+                           args.output_num_layers, dropout=args.dropout,
+                           Normalization=args.normalization, InputNorm=False)
+        self.with_egnn = with_egnn
+
+    def forward(self, data, taps=None):
+        V, E = data.edge_index0, data.edge_index1
+        x = self.atom_encoder(data.x)
+        if self.with_egnn:
+            x = self.egnn_layer(x, data.pos)
+            if taps is not None:
+                taps["front_end"] = x
+        e = self.bond_encoder(data.edge_attr.squeeze(-1))
+        for i in range(self.nlayer):
+            x, e = self.conv(x, e, V, E)
+            if i != self.nlayer - 1:
+                x, e = self.act(x), self.act(e)
+            x, e = self.dropout(x), self.dropout(e)
+        xp = pool_sum(x, data.batch)
+        ep = pool_high_order(e, data)
+        if taps is not None:
+            taps["pool"] = torch.cat((xp, ep), -1)
+        return self.mlp_out(torch.cat((xp, ep), -1)).view(-1)
+
+
+class MHNN(_PairedBase):
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args, with_egnn=False)
+
+
+class EGNNEquiHNN(_PairedBase):
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args, with_egnn=True)
+
+
+class MHNNS(nn.Module):
+    """mhnn.py:84-141 (``mhnns``): egnn_equihnns without the geometric front-end."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(args.MLP_hidden)
+        self.conv = MHNNSConv(args.MLP_hidden, args.MLP1_num_layers, args.MLP2_num_layers,
+                              args.MLP3_num_layers, aggr=args.aggregate, dropout=args.dropout,
+                              normalization=args.normalization)
+        self.mlp_out = MLP(args.MLP_hidden, args.output_hidden, num_target, args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def forward(self, data, taps=None):
+        V, E = data.edge_index0, data.edge_index1
+        x = self.atom_encoder(data.x)
+        x0 = x
+        for i in range(self.nlayer):
+            x = self.conv(self.dropout(x), V, E, x0)
+            if taps is not None:
+                taps[f"conv{i}"] = x
+            x = self.act(x)
+        x = pool_sum(self.dropout(x), data.batch)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+class EGNNEquiHNNM(MHNNM):
+    """equihnn_egnn.py:172-261 (``egnn_equihnnm``): mhnnm with the EGNN front-end."""
+
+    def __init__(self, num_target, args):
+        super().__init__(num_target, args)
+        self.egnn_layer = EGNN(args.MLP_hidden)
+
+    def forward(self, data, taps=None):
+        V, E = data.edge_index0, data.edge_index1
+        x = self.egnn_layer(self.atom_encoder(data.x), data.pos)
+        if taps is not None:
+            taps["front_end"] = x
+        e = self.bond_encoder(data.edge_attr.squeeze(-1))
+        for i, layer in enumerate(self.layers):
+            x, e = layer(x, e, V, E)
+            x = self.batch_norms[i](x)
+            if taps is not None:
+                taps[f"bn{i}"] = x
+            if i != self.nlayer - 1:
+                x, e = self.act(x), self.act(e)
+            x, e = self.dropout(x), self.dropout(e)
+        x = pool_sum(x, data.batch)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
+MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "mhnn": MHNN, "mhnns": MHNNS,
+          "egnn_equihnn": EGNNEquiHNN, "egnn_equihnnm": EGNNEquiHNNM}

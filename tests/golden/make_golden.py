@@ -170,6 +170,8 @@ def make_batch(seed, n_mols, flavour="qm9", with_isolated=True):
     rng = np.random.default_rng(seed)
     mols = [synth_molecule(rng, flavour) for _ in range(n_mols)]
     mols[0] = synth_molecule(rng, flavour, n_atoms=9, force_conj=True)  # conj hyperedge, order>=3
+    # the reference's mhnn / egnn_equihnn fail unless the LAST molecule has a hyperedge of order > 2
+    mols[-1] = synth_molecule(rng, flavour, force_conj=True)
     if with_isolated:
         lone = synth_molecule(rng, flavour, n_atoms=3, force_conj=False)
         # a one-atom, zero-hyperedge molecule: its node row has no incidence at all
@@ -211,7 +213,9 @@ def run_case(registry, method, hidden, seed, n_mols, train_mode=True, store_grad
             tap("front_end", lambda o: o.type0[0])))
     if hasattr(model, "conv"):
         # the wrapper applies act() after conv; tap the conv output itself
-        hooks.append(model.conv.register_forward_hook(tap("conv", lambda o: o.reshape(-1, o.shape[-1]))))
+        # MHNNSConv returns X; MHNNConv returns (X, E): tap the node features
+        hooks.append(model.conv.register_forward_hook(
+            tap("conv", lambda o: (o[0] if isinstance(o, tuple) else o).reshape(-1, (o[0] if isinstance(o, tuple) else o).shape[-1]))))
     if hasattr(model, "batch_norms"):
         for i, bn in enumerate(model.batch_norms):
             hooks.append(bn.register_forward_hook(tap(f"bn{i}")))
@@ -278,6 +282,10 @@ CASES = [
     ("egnn_equihnns_c64", "egnn_equihnns", 64, 21, 6, True, True),
     ("egnn_equihnns_c64_b", "egnn_equihnns", 64, 22, 10, True, True),
     ("egnn_equihnns_c256", "egnn_equihnns", 256, 23, 5, True, False),
+    ("mhnn_c64", "mhnn", 64, 41, 6, True, True),
+    ("mhnns_c64", "mhnns", 64, 42, 6, True, True),
+    ("egnn_equihnn_c64", "egnn_equihnn", 64, 43, 6, True, True),
+    ("egnn_equihnnm_c64", "egnn_equihnnm", 64, 44, 6, True, True),
     ("equiformer_equihnns_c64", "equiformer_equihnns", 64, 31, 6, True, True),
     ("equiformer_equihnns_c64_b", "equiformer_equihnns", 64, 32, 3, True, True),
     ("equiformer_equihnns_c256", "equiformer_equihnns", 256, 33, 2, True, False),
@@ -288,9 +296,9 @@ def main(only=None):
     torch.set_num_threads(8)
     methods = {c[1] for c in CASES if only is None or c[0] in only}
     mods = []
-    if "mhnnm" in methods:
+    if methods & {"mhnnm", "mhnn", "mhnns"}:
         mods.append("mhnn")
-    if "egnn_equihnns" in methods:
+    if methods & {"egnn_equihnns", "egnn_equihnn", "egnn_equihnnm"}:
         mods.append("equihnn_egnn")
     if "equiformer_equihnns" in methods:
         mods.append("equihnn_equiformer")

@@ -14,7 +14,8 @@ TOL = 1e-5
 
 CASES = ["mhnnm_c64_train", "mhnnm_c64_eval", "mhnnm_c256_train",
          "egnn_equihnns_c64", "egnn_equihnns_c64_b", "egnn_equihnns_c256",
-         "equiformer_equihnns_c64", "equiformer_equihnns_c64_b", "equiformer_equihnns_c256"]
+         "equiformer_equihnns_c64", "equiformer_equihnns_c64_b", "equiformer_equihnns_c256",
+         "mhnn_c64", "mhnns_c64", "egnn_equihnn_c64", "egnn_equihnnm_c64"]
 
 
 def golden_neighbour_ids(case):
@@ -83,7 +84,7 @@ def test_oracle_matches_reference(name):
     model = build(case)
     data = batch_from_case(case)
     check_against_case(model, case, data)
-    if "knn_idx" in case and str(case["meta_method"]) == "egnn_equihnns":
+    if "knn_idx" in case and str(case["meta_method"]).startswith("egnn_"):
         d2, idx = ref_models.knn_self_included(data.pos, 16)
         assert np.array_equal(np.sort(idx.numpy(), -1), np.sort(case["knn_idx"], -1))
     if "knn_idx" in case and str(case["meta_method"]) == "equiformer_equihnns":
