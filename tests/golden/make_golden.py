@@ -90,6 +90,22 @@ def _standin_get_at(pattern, tensor, indices):
     raise NotImplementedError(pattern)
 
 
+def _standin_to_dense_batch(x, batch=None, fill_value=0.0, max_num_nodes=None, batch_size=None):
+    """torch_geometric.utils.to_dense_batch: [N, ...] + sorted batch vector -> [B, Nmax, ...], mask."""
+    if batch is None:
+        batch = x.new_zeros(x.shape[0], dtype=torch.long)
+    b = int(batch.max()) + 1 if batch_size is None else batch_size
+    counts = torch.bincount(batch, minlength=b)
+    nmax = int(counts.max()) if max_num_nodes is None else max_num_nodes
+    start = torch.cumsum(counts, 0) - counts
+    pos = torch.arange(x.shape[0]) - start[batch]
+    out = x.new_full((b, nmax, *x.shape[1:]), fill_value)
+    mask = torch.zeros(b, nmax, dtype=torch.bool)
+    out[batch, pos] = x
+    mask[batch, pos] = True
+    return out, mask
+
+
 def _module(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
@@ -104,6 +120,7 @@ def install_standins():
     _module("ogb.graphproppred.mol_encoder", AtomEncoder=_StandinAtomEncoder)
     tg = _module("torch_geometric")
     tg.nn = _module("torch_geometric.nn", global_add_pool=_standin_global_add_pool)
+    tg.utils = _module("torch_geometric.utils", to_dense_batch=_standin_to_dense_batch)
     import typing
 
     _module("beartype", beartype=lambda f: f)
@@ -208,6 +225,8 @@ def run_case(registry, method, hidden, seed, n_mols, train_mode=True, store_grad
     hooks.append(model.atom_encoder.register_forward_hook(tap("atom_encoder")))
     if hasattr(model, "egnn_layer"):
         hooks.append(model.egnn_layer.register_forward_hook(tap("front_end", lambda o: o[0][0])))
+    if hasattr(model, "fa_former"):
+        hooks.append(model.fa_former.register_forward_hook(tap("front_end", lambda o: o[0][0])))
     if hasattr(model, "equiformer_layer"):
         hooks.append(model.equiformer_layer.register_forward_hook(
             tap("front_end", lambda o: o.type0[0])))
@@ -286,6 +305,9 @@ CASES = [
     ("mhnns_c64", "mhnns", 64, 42, 6, True, True),
     ("egnn_equihnn_c64", "egnn_equihnn", 64, 43, 6, True, True),
     ("egnn_equihnnm_c64", "egnn_equihnnm", 64, 44, 6, True, True),
+    ("faformer_equihnns_c64", "faformer_equihnns", 64, 51, 6, False, True),
+    ("faformer_equihnns_c64_b", "faformer_equihnns", 64, 52, 3, False, True),
+    ("faformer_equihnns_c256", "faformer_equihnns", 256, 53, 2, False, False),
     ("equiformer_equihnns_c64", "equiformer_equihnns", 64, 31, 6, True, True),
     ("equiformer_equihnns_c64_b", "equiformer_equihnns", 64, 32, 3, True, True),
     ("equiformer_equihnns_c256", "equiformer_equihnns", 256, 33, 2, True, False),
@@ -302,6 +324,8 @@ def main(only=None):
         mods.append("equihnn_egnn")
     if "equiformer_equihnns" in methods:
         mods.append("equihnn_equiformer")
+    if "faformer_equihnns" in methods:
+        mods.append("equihnn_fa_former")
     registry = import_reference(tuple(mods))
     for name, method, hidden, seed, n_mols, train_mode, store in CASES:
         if only is not None and name not in only:

@@ -15,7 +15,8 @@ TOL = 1e-5
 CASES = ["mhnnm_c64_train", "mhnnm_c64_eval", "mhnnm_c256_train",
          "egnn_equihnns_c64", "egnn_equihnns_c64_b", "egnn_equihnns_c256",
          "equiformer_equihnns_c64", "equiformer_equihnns_c64_b", "equiformer_equihnns_c256",
-         "mhnn_c64", "mhnns_c64", "egnn_equihnn_c64", "egnn_equihnnm_c64"]
+         "mhnn_c64", "mhnns_c64", "egnn_equihnn_c64", "egnn_equihnnm_c64",
+         "faformer_equihnns_c64", "faformer_equihnns_c64_b", "faformer_equihnns_c256"]
 
 
 def golden_neighbour_ids(case):
