@@ -264,7 +264,7 @@ def main():
     # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
     # largest one (one dummy molecule owns the padding; exact for LayerNorm models).  mhnnm keeps
     # eager launches (its BatchNorm statistics would see the padded rows).
-    use_graph = (not a.no_graph) and a.method != "mhnnm"
+    use_graph = (not a.no_graph) and a.method not in ("mhnnm", "egnn_equihnnm", "faformer_equihnns")
     if use_graph:
         ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]
         tgt = tuple(max(e[i] for e in ext) for i in range(3))

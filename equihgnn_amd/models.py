@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .equiformer import Equiformer
+from .faformer import FAFormer
 from .index import HyperIndex
 from .layers import EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, pool_sum
 from .registry import registry
@@ -291,5 +292,53 @@ class EGNNEquiHNNM(MHNNM):
         return self.mlp_out(x).view(-1)
 
 
+@registry.register_model("faformer_equihnns")
+class FAFormerEquiHNNS(nn.Module):
+    """equihnn_fa_former.py:105-184: AtomEncoder -> FAFormer (once) -> shared MHNNSConv x L -> pool
+    -> head.  Note the reference keeps proj_drop = attn_drop = 0.1 inside FAFormer in training mode
+    (fa_former_layer.py:20-21), whatever ``--dropout`` says."""
+
+    def __init__(self, num_target, args):
+        super().__init__()
+        self.act = _ACT[args.activation]()
+        self.dropout = nn.Dropout(args.dropout)
+        self.mlp1_layers = args.MLP1_num_layers
+        self.mlp2_layers = args.MLP2_num_layers
+        self.mlp3_layers = args.MLP3_num_layers
+        self.nlayer = args.All_num_layers
+        self.atom_encoder = AtomEncoder(emb_dim=args.MLP_hidden)
+        self.fa_former = FAFormer(args.MLP_hidden, n_layers=2, n_heads=2, n_neighbors=16, valid_radius=5.0)
+        self.conv = MHNNSConv(args.MLP_hidden, mlp1_layers=self.mlp1_layers, mlp2_layers=self.mlp2_layers,
+                              mlp3_layers=self.mlp3_layers, aggr=args.aggregate, dropout=args.dropout,
+                              normalization=args.normalization)
+        self.mlp_out = MLP(in_channels=args.MLP_hidden, hidden_channels=args.output_hidden,
+                           out_channels=num_target, num_layers=args.output_num_layers,
+                           dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
+
+    def reset_parameters(self):
+        self.conv.reset_parameters()
+        self.mlp_out.reset_parameters()
+
+    def forward(self, data, taps=None):
+        index = HyperIndex.from_batch(data)
+        x = self.atom_encoder(data.x)
+        if taps is not None:
+            taps["atom_encoder"] = x
+        x = self.fa_former(x, data.pos, index)
+        if taps is not None:
+            taps["front_end"] = x
+        x0 = x
+        for i in range(self.nlayer):
+            x = self.conv(self.dropout(x), index, x0)
+            if taps is not None:
+                taps[f"conv{i}"] = x
+            x = self.act(x)
+        x = pool_sum(self.dropout(x), index)
+        if taps is not None:
+            taps["pool"] = x
+        return self.mlp_out(x).view(-1)
+
+
 MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "equiformer_equihnns": EquiformerEquiHNNS,
+          "faformer_equihnns": FAFormerEquiHNNS,
           "mhnn": MHNN, "mhnns": MHNNS, "egnn_equihnn": EGNNEquiHNN, "egnn_equihnnm": EGNNEquiHNNM}

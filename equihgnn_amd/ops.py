@@ -342,6 +342,16 @@ def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
     return _BiasReluLn.apply(h, bias, gamma, beta, eps)
 
 
+def eigh3(cov):
+    """Eigenvectors (columns, ascending eigenvalues) of a batch of symmetric 3x3 matrices [B,3,3];
+    no gradient (the reference detaches the covariance, fa_former_layer.py:98-99)."""
+    _require_gpu(cov, "eigh3")
+    cov = _f32c(cov.detach())
+    vec = torch.empty_like(cov)
+    hip.check(hip.lib().geo_eigh3(_ptr(cov), cov.shape[0], None, _ptr(vec), _stream(cov.device)), "geo_eigh3")
+    return vec
+
+
 def rowgemm(z, w, rowptr, perm=None):
     """out[e, :] = z[e, :] @ w[row(e)]; rows given by rowptr (+ perm: entry ids per row)."""
     return _RowGemm.apply(z, w, rowptr, perm)

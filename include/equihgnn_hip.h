@@ -182,6 +182,13 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
                         int64_t n_rows, int32_t C, float eps, float* dh, float* dbias_dgamma_dbeta,
                         void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
+ * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending
+ * (may be NULL), v [B,3,3] eigenvectors in columns, largest component of each column positive.
+ * ------------------------------------------------------------------------------------------- */
+int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

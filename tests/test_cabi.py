@@ -85,7 +85,7 @@ def test_state_dict_matches_reference_names():
     from equihgnn_amd import models
 
     for name in ("mhnnm_c64_train", "egnn_equihnns_c64", "equiformer_equihnns_c64", "mhnn_c64", "mhnns_c64",
-                 "egnn_equihnn_c64", "egnn_equihnnm_c64"):
+                 "egnn_equihnn_c64", "egnn_equihnnm_c64", "faformer_equihnns_c64"):
         case = load_case(name)
         method = str(case["meta_method"])
         m = models.MODELS[method](1, golden_args(method, int(case["meta_hidden"])))

@@ -373,3 +373,22 @@ def test_bias_relu_ln_matches_float64_reference(R, C):
     for name, x, r in zip(("dh", "dbias", "dgamma", "dbeta"), d, t):
         err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
         assert err < 3e-5, (name, err)
+
+
+def test_eigh3_matches_lapack_up_to_sign():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2000, 12, 3, generator=g)
+    x[:100, 3:] = 0                      # rank-deficient covariances (few valid neighbours)
+    cov = torch.bmm(x.transpose(1, 2), x)
+    w_ref, v_ref = torch.linalg.eigh(cov.double(), UPLO="U")
+    v = ops.eigh3(cov.to(DEV)).cpu().double()
+    # columns agree up to sign wherever the eigenvalue gap is not tiny
+    gap_ok = ((w_ref[:, 1] - w_ref[:, 0]) > 1e-3 * w_ref[:, 2]) & ((w_ref[:, 2] - w_ref[:, 1]) > 1e-3 * w_ref[:, 2])
+    dots = (v * v_ref).sum(1).abs()
+    assert float((1 - dots[gap_ok]).max()) < 1e-5
+    # always: orthonormal, and C v = w v
+    eye = torch.bmm(v.transpose(1, 2), v)
+    assert float((eye - torch.eye(3, dtype=torch.double)).abs().max()) < 1e-5
+    resid = torch.bmm(cov.double(), v) - v * w_ref.unsqueeze(1)
+    assert float(resid.abs().max() / cov.abs().max()) < 1e-5
