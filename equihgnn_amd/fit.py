@@ -1,0 +1,193 @@
+"""Training harness equal to the reference's ``LitModel`` + ``pl.Trainer`` configuration
+(main.py:21-151,259-293), without Lightning / torchmetrics / PyG (none are in this image):
+
+* loss ``nn.MSELoss`` on the (normalised) target, Adam(lr, weight_decay)          main.py:36,49-63,137-140
+* ``ReduceLROnPlateau(mode="min", factor=0.1, patience=10, min_lr=lr*1e-5)``
+  stepped once per epoch on ``val_mae_mean``                                      main.py:141-151
+* validation / test metrics = bootstrapped (50 resamples) MAE and MSE of
+  ``out*std`` vs ``y*std``; ``*_mean`` and ``*_std`` are logged                   main.py:37-42,65-76,90-110
+* ``ModelCheckpoint(save_top_k=1, monitor="val_mae_mean", mode="min")`` and
+  ``EarlyStopping(monitor="val_mae_mean", patience=50)``                          main.py:259-267
+* ``trainer.test(ckpt_path="best")`` gathers the predictions of all ranks          main.py:90-135,285-293
+* data: 80/10/10 ``random_split`` and target normalisation                        utils/data_split.py:54-79
+* data parallelism: per-rank batches with DistributedSampler semantics, one flat gradient all-reduce
+  per step (``trainer.TrainStep``); metrics are reduced over ranks like ``sync_dist=True``.
+
+The model is anything with the plugin contract ``model(data) -> Tensor[B]``: the HIP models on a
+GPU, the CPU oracle in the tests.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .batch import HMol, collate, shard_indices
+from .trainer import TrainStep, _world
+
+
+# ------------------------------------------------------------------------------------------------
+# data split / normalisation
+# ------------------------------------------------------------------------------------------------
+def split_80_10_10(n: int, seed: int):
+    """utils/data_split.py:54-65: random_split into int(0.8 n), int(0.1 n), rest."""
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(seed)).tolist()
+    n_tr, n_va = int(0.8 * n), int(0.1 * n)
+    return perm[:n_tr], perm[n_tr:n_tr + n_va], perm[n_tr + n_va:]
+
+
+def normalize_targets_like_reference(y: torch.Tensor):
+    """utils/data_split.py:67-72.  The three subsets returned by random_split share ONE underlying
+    dataset, and the reference normalises ``subset.dataset.y`` for each of them: the whole target
+    column is standardised with the FULL-dataset mean/std, three times in a row.  Reproduced as is
+    (returns the transformed targets and the std that main.py passes to LitModel)."""
+    mean, std = y.mean(dim=0, keepdim=True), y.std(dim=0, keepdim=True)
+    out = y
+    for _ in range(3):
+        out = (out - mean) / std
+    return out, float(std.reshape(-1)[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# metrics (torchmetrics BootStrapper(MeanAbsoluteError / MeanSquaredError, num_bootstraps=50))
+# ------------------------------------------------------------------------------------------------
+class BootstrapMetrics:
+    """Poisson(1) resampling of every update, 50 copies of (sum |err|, sum err^2, count); ``compute``
+    returns mean and std over the copies — the quantities LitModel logs as ``{mae,mse}_{mean,std}``."""
+
+    def __init__(self, num_bootstraps: int = 50, seed: int = 0):
+        self.nb = num_bootstraps
+        self.gen = torch.Generator().manual_seed(seed)
+        self.reset()
+
+    def reset(self):
+        self.abs = torch.zeros(self.nb, dtype=torch.float64)
+        self.sq = torch.zeros(self.nb, dtype=torch.float64)
+        self.cnt = torch.zeros(self.nb, dtype=torch.float64)
+
+    def update(self, pred: torch.Tensor, target: torch.Tensor):
+        err = (pred.detach().double().cpu() - target.detach().double().cpu()).reshape(-1)
+        w = torch.poisson(torch.ones(self.nb, err.numel()), generator=self.gen).double()
+        self.abs += w @ err.abs()
+        self.sq += w @ (err * err)
+        self.cnt += w.sum(1)
+
+    def compute(self) -> Dict[str, float]:
+        a, s, c = self.abs.clone(), self.sq.clone(), self.cnt.clone()
+        if _world() > 1:  # sync_dist=True
+            pack = torch.stack((a, s, c))
+            dist.all_reduce(pack)
+            a, s, c = pack
+        mae, mse = a / c.clamp(min=1), s / c.clamp(min=1)
+        return {"mae_mean": float(mae.mean()), "mae_std": float(mae.std()),
+                "mse_mean": float(mse.mean()), "mse_std": float(mse.std())}
+
+
+# ------------------------------------------------------------------------------------------------
+# loaders
+# ------------------------------------------------------------------------------------------------
+class MolLoader:
+    """torch_geometric DataLoader(batch_size, shuffle) over a list of HMol restricted to this rank
+    (DistributedSampler semantics when more than one rank runs)."""
+
+    def __init__(self, mols: Sequence[HMol], batch_size: int, shuffle: bool, seed: int = 0,
+                 device=None, rank: int = 0, world: int = 1):
+        self.mols, self.bs, self.shuffle, self.seed = mols, batch_size, shuffle, seed
+        self.device, self.rank, self.world = device, rank, world
+        self.epoch = 0
+
+    def __iter__(self):
+        idx = shard_indices(len(self.mols), self.rank, self.world, self.seed, self.epoch, self.shuffle)
+        self.epoch += 1
+        for i in range(0, len(idx), self.bs):
+            b = collate([self.mols[j] for j in idx[i:i + self.bs]])
+            yield b.to(self.device) if self.device is not None else b
+
+
+# ------------------------------------------------------------------------------------------------
+# the fit / test loop
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class FitResult:
+    history: List[Dict[str, float]] = field(default_factory=list)
+    best_epoch: int = -1
+    best_val_mae: float = float("inf")
+    stopped_early: bool = False
+    best_state: Optional[dict] = None
+
+
+class Fitter:
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
+                 std: Optional[float] = None, patience_lr: int = 10, patience_stop: int = 50,
+                 step_factory: Callable = TrainStep, metric_seed: int = 0):
+        self.model, self.lr, self.std = model, lr, std
+        self.step = step_factory(model, lr=lr, weight_decay=weight_decay)
+        self.metrics = BootstrapMetrics(50, metric_seed)
+        self.patience_lr, self.patience_stop = patience_lr, patience_stop
+        self.sched = None
+
+    def _evaluate(self, loader) -> Dict[str, float]:
+        self.model.eval()
+        self.metrics.reset()
+        scale = self.std if self.std else 1.0          # main.py:67-70: `if self.std:`
+        with torch.no_grad():
+            for data in loader:
+                self.metrics.update(self.model(data) * scale, data.y * scale)
+        self.model.train()
+        return self.metrics.compute()
+
+    def fit(self, train_loader, valid_loader, epochs: int) -> FitResult:
+        res = FitResult()
+        bad = 0
+        for epoch in range(epochs):
+            tot, n = 0.0, 0
+            for data in train_loader:
+                tot += float(self.step.step(data))
+                n += 1
+            if self.sched is None and self.step.opt is not None:  # built lazily with the optimiser
+                self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(
+                    self.step.opt, mode="min", factor=0.1, patience=self.patience_lr, min_lr=self.lr * 1e-5)
+            val = self._evaluate(valid_loader)
+            lr_now = self.step.opt.param_groups[0]["lr"] if self.step.opt is not None else self.lr
+            res.history.append({"epoch": epoch, "train_loss": tot / max(n, 1), "lr": float(lr_now),
+                                **{"val_" + k: v for k, v in val.items()}})
+            if self.sched is not None:
+                self.sched.step(val["mae_mean"])
+            if val["mae_mean"] < res.best_val_mae:     # ModelCheckpoint(save_top_k=1) + EarlyStopping
+                res.best_val_mae, res.best_epoch, bad = val["mae_mean"], epoch, 0
+                res.best_state = copy.deepcopy(self.model.state_dict())
+            else:
+                bad += 1
+                if bad >= self.patience_stop:
+                    res.stopped_early = True
+                    break
+        return res
+
+    def test(self, test_loader, best_state: Optional[dict] = None):
+        """trainer.test(ckpt_path="best"): metrics plus the gathered (pred, truth) table that
+        main.py:122-132 logs as test_results.csv (unscaled, as there)."""
+        if best_state is not None:
+            self.model.load_state_dict(best_state)
+        self.model.eval()
+        self.metrics.reset()
+        scale = self.std if self.std else 1.0
+        preds, truth = [], []
+        with torch.no_grad():
+            for data in test_loader:
+                out = self.model(data)
+                self.metrics.update(out * scale, data.y * scale)
+                preds.append(out.detach().float().cpu())
+                truth.append(data.y.detach().float().cpu())
+        p, t = torch.cat(preds), torch.cat(truth)
+        if _world() > 1:  # self.all_gather(preds)
+            gp = [None] * _world()
+            gt = [None] * _world()
+            dist.all_gather_object(gp, p)
+            dist.all_gather_object(gt, t)
+            p, t = torch.cat(gp), torch.cat(gt)
+        self.model.train()
+        return {"test_" + k: v for k, v in self.metrics.compute().items()}, np.stack((p.numpy(), t.numpy()), 1)
