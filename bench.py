@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--wgrad-side-stream", action="store_true",
+                   help="issue weight-gradient GEMMs on a second stream (parallel graph branch)")
     p.add_argument("--no-graph", action="store_true",
                    help="eager launches instead of hipGraph replay of the step")
     p.add_argument("--only-saturation", action="store_true",
@@ -256,6 +258,9 @@ def main():
     from equihgnn_amd.registry import default_args
     from equihgnn_amd.trainer import GraphedTrainStep, TrainStep
 
+    if a.wgrad_side_stream:
+        from equihgnn_amd import ops as _ops
+        _ops.WGRAD_ON_SIDE_STREAM = True
     args_ns = default_args(method=a.method, batch_size=a.batch)
     torch.manual_seed(0)
     model = MODELS[a.method](1, args_ns).to(dev)

@@ -91,7 +91,7 @@ class MLP(nn.Module):
         last = len(self.lins) - 1
         for i in range(start, last):
             if i > start:
-                h = self.lins[i](h)
+                h = ops.linear(h, self.lins[i].weight, self.lins[i].bias) if h.is_cuda else self.lins[i](h)
             h = F.relu(h)
             h = self.normalizations[i + 1](h)
             h = F.dropout(h, p=self.dropout, training=self.training)
@@ -105,16 +105,16 @@ class MLP(nn.Module):
     def forward(self, x):
         x = self.normalizations[0](x)
         if len(self.lins) == 1:
-            return self.lins[0](x)
+            return ops.linear(x, self.lins[0].weight, self.lins[0].bias)
         if self._fusable(x):
             # bias-free GEMM, then bias + ReLU + LayerNorm in one launch (its backward also yields
             # the bias gradient, so no separate column-sum kernel runs)
             for i in range(len(self.lins) - 1):
                 lin, norm = self.lins[i], self.normalizations[i + 1]
-                x = ops.bias_relu_ln(F.linear(x, lin.weight), lin.bias, norm.weight, norm.bias, norm.eps)
-            return self.lins[-1](x)
-        h = self.hidden(self.lins[0](x), 0)
-        return self.lins[-1](h)
+                x = ops.bias_relu_ln(ops.linear(x, lin.weight), lin.bias, norm.weight, norm.bias, norm.eps)
+            return ops.linear(x, self.lins[-1].weight, self.lins[-1].bias)
+        h = self.hidden(ops.linear(x, self.lins[0].weight, self.lins[0].bias), 0)
+        return ops.linear(h, self.lins[-1].weight, self.lins[-1].bias)
 
 
 def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr):
@@ -127,9 +127,9 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
                                   "(equihnn_egnn.py:139-149) and is not supported")
     lin0 = mlp.lins[0]
     ca = a.shape[-1]
-    wa, wb = lin0.weight[:, :ca], lin0.weight[:, ca:]
-    pa = F.linear(a, wa)                # rows of a
-    qb = F.linear(b, wb, lin0.bias)     # rows of b
+    cin = lin0.weight.shape[1]
+    pa = ops.linear(a, lin0.weight, None, (0, ca))              # rows of a
+    qb = ops.linear(b, lin0.weight, lin0.bias, (ca, cin))       # rows of b
     norm = mlp.normalizations[1] if len(mlp.lins) > 1 else None
     fused = (len(mlp.lins) == 2 and isinstance(norm, nn.LayerNorm) and pa.dim() == 2
              and pa.shape[-1] % 4 == 0 and pa.shape[-1] <= 1024 and not (mlp.training and mlp.dropout > 0))
@@ -139,16 +139,16 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
         s = ops.incidence_ln_reduce(pa, qb, norm.weight, norm.bias, idx_a32, idx_b32, csr_a, csr_b,
                                     out_csr, out_key32, aggr, norm.eps)
         rows = has_row if aggr == "mean" else (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype)[:, None]
-        return torch.addcmul(F.linear(s, last.weight), rows, last.bias)
+        return torch.addcmul(ops.linear(s, last.weight), rows, last.bias)
     h = ops.gather_rows(pa, idx_a32, csr_a) + ops.gather_rows(qb, idx_b32, csr_b)  # [nnz, C]
     if len(mlp.lins) == 1:              # a single Linear: everything is linear in h
         return ops.reduce_entries(h, out_csr, out_key32, aggr)
     h = mlp.hidden(h, 0)
     s = ops.reduce_entries(h, out_csr, out_key32, aggr)
     if aggr == "mean":
-        return F.linear(s, last.weight) + last.bias * has_row
+        return ops.linear(s, last.weight) + last.bias * has_row
     deg = (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype).unsqueeze(-1)
-    return F.linear(s, last.weight) + last.bias * deg
+    return ops.linear(s, last.weight) + last.bias * deg
 
 
 class MHNNConv(nn.Module):
@@ -260,7 +260,9 @@ class EGNN(nn.Module):
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w1[:, 2 * c], w2, lin2.bias, nbr, d2, csr_t)
         node_in = torch.cat((self.node_norm(feats), m_i), -1)
-        return self.node_mlp(node_in) + feats                  # egnn_layer.py:360-362
+        n0, n3 = self.node_mlp[0], self.node_mlp[3]
+        hid = F.silu(ops.linear(node_in, n0.weight, n0.bias))
+        return ops.linear(hid, n3.weight, n3.bias) + feats     # egnn_layer.py:360-362
 
 
 def pool_sum(x, index: HyperIndex):

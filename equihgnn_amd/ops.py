@@ -12,6 +12,7 @@ from dataclasses import dataclass
 from typing import Optional
 
 import torch
+import torch.nn.functional as F
 
 from . import hip
 
@@ -295,6 +296,75 @@ class _BiasReluLn(torch.autograd.Function):
         return dh, small[0], small[1], small[2], None
 
 
+WGRAD_ON_SIDE_STREAM = False
+_WGRAD_STREAMS = {}
+
+
+def wgrad_stream(device):
+    key = torch.device(device).index
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
+
+
+def join_wgrad_stream(device):
+    if WGRAD_ON_SIDE_STREAM and _WGRAD_STREAMS:
+        torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
+
+
+# parameters seen by ops.linear since the last reset (the trainer decides which of them get a
+# persistent gradient accumulator, see trainer.GradBuffers)
+LINEAR_PARAMS = {}
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W[:, c0:c1].T (+ bias): a library GEMM whose WEIGHT gradient, when the parameter
+    carries a persistent accumulator (``param._eqh_gbuf``, same shape as the parameter), is
+    accumulated by the GEMM itself (addmm_ with beta = 1 into the accumulator's column block)
+    instead of being materialised and then added by autograd — shared weights (the conv layer is
+    applied L times) and column-split weights (W·cat(a,b) = Wa·a + Wb·b) cost no extra kernels."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, c0, c1):
+        w = weight if c0 is None else weight[:, c0:c1]
+        ctx.save_for_backward(x, weight)
+        ctx.cols = (c0, c1)
+        ctx.has_bias = bias is not None
+        return F.linear(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        c0, c1 = ctx.cols
+        w = weight if c0 is None else weight[:, c0:c1]
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = (dy @ w) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            gbuf = getattr(weight, "_eqh_gbuf", None)
+            if gbuf is not None:
+                tgt = gbuf if c0 is None else gbuf[:, c0:c1]
+                side = wgrad_stream(dy.device) if WGRAD_ON_SIDE_STREAM else None
+                if side is None:
+                    tgt.addmm_(dy2.t(), x2)
+                else:
+                    # weight gradients are off the critical path of the backward chain: issue them
+                    # on a second HIP stream (a parallel branch of the captured graph); the trainer
+                    # joins the stream before the optimiser
+                    side.wait_stream(torch.cuda.current_stream(dy.device))
+                    with torch.cuda.stream(side):
+                        tgt.addmm_(dy2.t(), x2)
+                    dy2.record_stream(side)
+                    x2.record_stream(side)
+            elif c0 is None:
+                dw = dy2.t() @ x2
+            else:
+                dw = torch.zeros_like(weight)
+                dw[:, c0:c1] = dy2.t() @ x2
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None, None
+
+
 class _RowGemm(torch.autograd.Function):
     """out[e] = z[e] @ w[row(e)] — hg_rowgemm_fwd/bwd (the radial tensor product of
     equiformer_layer.py:376-383 re-associated; see csrc/rowgemm.hip)."""
@@ -335,6 +405,15 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
     CSRs keyed by ia / ib (needed by the backward), out_csr the one keyed by okey32."""
     return _IncidenceLnReduce.apply(pa, qb, gamma, beta, ia32, ib32, csr_a, csr_b, out_csr, okey32,
                                     reduce == "mean", eps)
+
+
+def linear(x, weight, bias=None, cols=None):
+    """F.linear(x, weight[:, cols[0]:cols[1]], bias) through _Linear (``weight`` is the PARAMETER,
+    not a slice of it, so that its gradient accumulator can be found)."""
+    if torch.is_grad_enabled() and weight.requires_grad:
+        LINEAR_PARAMS[id(weight)] = weight
+    c0, c1 = cols if cols is not None else (None, None)
+    return _Linear.apply(x, weight, bias, c0, c1)
 
 
 def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):

@@ -116,6 +116,8 @@ class GraphedTrainStep:
         self.live = None
         self.opt = None
         self.slots = {}
+        self.wflat = None
+        self.gb_params = []
         if broadcast_from_rank0 and _world() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
@@ -133,9 +135,40 @@ class GraphedTrainStep:
     def _fwd_bwd(self, data):
         for p in self.model.parameters():
             p.grad = None
+        if self.wflat is not None:
+            self.wflat.zero_()
         loss = self._loss(data)
         loss.backward()
+        self._join()
+        for p in self.gb_params:       # weights whose gradient the GEMMs accumulated in place
+            p.grad = p._eqh_gbuf
         return loss
+
+    def _join(self):
+        from . import ops
+        if self.gb_params:
+            ops.join_wgrad_stream(self.gb_params[0].device)
+
+    def _setup_grad_buffers(self, data, live):
+        """Give every weight that is used ONLY through ops.linear a persistent gradient accumulator
+        (one flat buffer, zeroed by a single fill per step); a probe pass drops any parameter that
+        autograd still produces a gradient for (i.e. that is also used some other way)."""
+        from . import ops
+        cand = [p for p in live if id(p) in ops.LINEAR_PARAMS and p.dim() == 2]
+        if not cand:
+            return
+        self.wflat = torch.zeros(sum(p.numel() for p in cand), dtype=cand[0].dtype, device=cand[0].device)
+        off = 0
+        for p in cand:
+            p._eqh_gbuf = self.wflat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        for p in self.model.parameters():
+            p.grad = None
+        self._loss(data).backward()
+        for p in cand:
+            if p.grad is not None:
+                del p._eqh_gbuf
+        self.gb_params = [p for p in cand if hasattr(p, "_eqh_gbuf")]
 
     def _reduce_eager(self):
         if _world() > 1:
@@ -152,8 +185,12 @@ class GraphedTrainStep:
         """Eager first step: discovers the live parameters and creates the capturable fused Adam
         (also performs every lazy one-time initialisation of the HIP library and of the GEMM
         libraries before anything is captured)."""
+        from . import ops
+        ops.LINEAR_PARAMS.clear()
         loss = self._fwd_bwd(data)
         self.live = [p for p in self.model.parameters() if p.grad is not None]
+        self._setup_grad_buffers(data, self.live)
+        loss = self._fwd_bwd(data)
         self.opt = torch.optim.Adam(self.live, lr=self.lr, weight_decay=self.wd, fused=True, capturable=True)
         self._reduce_eager()
         self.opt.step()
@@ -172,8 +209,13 @@ class GraphedTrainStep:
         g_bwd = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
+            if self.wflat is not None:
+                self.wflat.zero_()
             loss = self._loss(static)
             loss.backward()
+            self._join()
+            for p in self.gb_params:
+                p.grad = p._eqh_gbuf
             grads = [p.grad for p in self.live]
             flat = torch.cat([g.reshape(-1) for g in grads]) if world > 1 else None
         g_opt = torch.cuda.CUDAGraph()
