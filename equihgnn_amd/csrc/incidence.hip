@@ -22,17 +22,28 @@ namespace {
 constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / 64;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+// Wavefront all-reduce on the DPP cross-lane network (no LDS round trips): quad butterflies, then
+// rotations inside each 16-lane row, then the four row totals are combined through scalar reads.
+// Every lane of the wavefront must be active.  Fixed summation order => reproducible.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x124>(v);  // row_ror:4
+    v += dpp_move<0x128>(v);  // row_ror:8
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    const int bits = __float_as_int(row16_sum(v));  // readlane moves 32-bit integers
+    return (__int_as_float(__builtin_amdgcn_readlane(bits, 0)) + __int_as_float(__builtin_amdgcn_readlane(bits, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(bits, 32)) + __int_as_float(__builtin_amdgcn_readlane(bits, 48)));
+}
 __device__ __forceinline__ void wave_sum2(float& a, float& b) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        a += __shfl_xor(a, d, 64);
-        b += __shfl_xor(b, d, 64);
-    }
+    a = wave_sum(a);
+    b = wave_sum(b);
 }
 
 template <int NV>
@@ -170,6 +181,13 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
           for (int j = 0; j < cnt; ++j) {
             const int r = __shfl(my_r, j, 64);
             const float w = __shfl(my_w, j, 64);
+            // issue the d(out) row load before the LayerNorm reductions so its latency overlaps them
+            Row<NV> draw;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                draw.v[i] = (c < C) ? *reinterpret_cast<const float4*>(ds + (int64_t)r * C + c) : f4_zero();
+            }
             Row<NV> x;
             unsigned pos;
             float rstd;
@@ -178,9 +196,7 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
             float m1 = 0.f, m2 = 0.f;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int c = (lane + 64 * i) * 4;
-                float4 d = f4_zero();
-                if (c < C) d = *reinterpret_cast<const float4*>(ds + (int64_t)r * C + c);
+                float4 d = draw.v[i];
                 d.x *= w; d.y *= w; d.z *= w; d.w *= w;
                 if (DGAMMA) {
                     dgam.v[i].x = fmaf(d.x, x.v[i].x, dgam.v[i].x); dgam.v[i].y = fmaf(d.y, x.v[i].y, dgam.v[i].y);
