@@ -6,8 +6,8 @@
 //
 // Pipeline (all on `stream`, no host sync):
 //   k_clear -> k_hist (int atomics) -> 3-kernel exclusive scan -> k_fill (int atomics into a
-//   scratch permutation) -> k_sort_short (rows <= 16 entries: per-thread rank sort) and
-//   k_sort_long (one workgroup per longer row: bitonic sort in LDS).  Sorting each row by entry
+//   scratch permutation) -> k_sort_rows (one wavefront per row: rank sort by shuffles) and
+//   k_sort_long (rows > 2048 entries: one workgroup per row, bitonic sort in LDS).  Sorting each row by entry
 //   id makes the summation order, and therefore every result, bitwise reproducible.
 #include "common.h"
 
@@ -16,7 +16,7 @@ namespace {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 counters per block
-constexpr int SHORT_ROW = 16;
+constexpr int SHORT_ROW = 16;  // sizing of the long-row list only
 constexpr int LONG_THREADS = 256;
 constexpr int LONG_LDS_CAP = 16384;  // ints (64 KiB)
 
@@ -111,6 +111,36 @@ __global__ void k_scan_apply(int* __restrict__ cnt, int64_t n_items,
     }
 }
 
+// whole scan in ONE launch for n_items <= 64 Ki: a single 1024-thread block walks the counters in
+// chunks with a running carry (saves two launches per CSR at training batch sizes)
+__global__ void __launch_bounds__(1024)
+k_scan_small(int* __restrict__ cnt, int n_items, int* __restrict__ rowptr) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_items; c0 += 1024) {
+        const int i = c0 + threadIdx.x;
+        const int v = i < n_items ? cnt[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wave; ++w) base += s_wave[w];
+        const int ex = base + inc - v;
+        if (i < n_items) { rowptr[i] = ex; cnt[i] = ex; }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = ex + v;
+        __syncthreads();
+    }
+}
+
 __global__ void k_fill(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
                        int* __restrict__ cursor, int* __restrict__ tmp_perm) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -129,22 +159,36 @@ __device__ __forceinline__ void emit(int pos, int entry, const int64_t* other, i
     if (col) col[pos] = other ? (int)other[entry] : entry / col_div;
 }
 
-__global__ void k_sort_short(const int* __restrict__ rowptr, int64_t n_rows,
-                             const int* __restrict__ tmp_perm, const int64_t* __restrict__ other,
-                             int col_div, int* __restrict__ perm, int* __restrict__ col,
-                             int* __restrict__ long_count, int* __restrict__ long_rows) {
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_rows; r += stride) {
+// One wavefront per row (grid-stride).  Every lane ranks the entries it holds against the whole
+// row: rows of up to 64 entries are ranked from registers with wavefront shuffles; longer rows read
+// the row from memory (L1) — O(deg^2/64) per row — and rows above LONG_ROW go to the LDS bitonic
+// kernel instead.
+constexpr int LONG_ROW = 2048;
+__global__ void __launch_bounds__(256)
+k_sort_rows(const int* __restrict__ rowptr, int64_t n_rows, const int* __restrict__ tmp_perm,
+            const int64_t* __restrict__ other, int col_div, int* __restrict__ perm,
+            int* __restrict__ col, int* __restrict__ long_count, int* __restrict__ long_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t r = wave0; r < n_rows; r += (int64_t)gridDim.x * 4) {
         const int beg = rowptr[r], deg = rowptr[r + 1] - beg;
-        if (deg > SHORT_ROW) {
-            long_rows[atomicAdd(long_count, 1)] = (int)r;
+        if (deg == 0) continue;
+        if (deg > LONG_ROW) {
+            if (lane == 0) long_rows[atomicAdd(long_count, 1)] = (int)r;
             continue;
         }
-        for (int a = 0; a < deg; ++a) {
-            const int x = tmp_perm[beg + a];
+        if (deg <= 64) {
+            const int x = lane < deg ? tmp_perm[beg + lane] : 0x7fffffff;
             int rank = 0;
-            for (int b = 0; b < deg; ++b) rank += (tmp_perm[beg + b] < x) ? 1 : 0;
-            emit(beg + rank, x, other, col_div, perm, col);
+            for (int j = 0; j < deg; ++j) rank += (__shfl(x, j, 64) < x) ? 1 : 0;
+            if (lane < deg) emit(beg + rank, x, other, col_div, perm, col);
+        } else {
+            for (int a = lane; a < deg; a += 64) {
+                const int x = tmp_perm[beg + a];
+                int rank = 0;
+                for (int b = 0; b < deg; ++b) rank += (tmp_perm[beg + b] < x) ? 1 : 0;
+                emit(beg + rank, x, other, col_div, perm, col);
+            }
         }
     }
 }
@@ -242,21 +286,26 @@ extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nn
         hipLaunchKernelGGL(k_hist, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
         EQH_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt,
-                       n_items, w.block_sums);
-    hipLaunchKernelGGL(k_scan_carry, dim3(1), dim3(SCAN_THREADS), 0, stream, w.block_sums, n_blocks);
-    hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt, n_items,
-                       w.block_sums, rowptr);
+    if (n_items <= 65536) {
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, stream, w.cnt, (int)n_items, rowptr);
+    } else {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt,
+                           n_items, w.block_sums);
+        hipLaunchKernelGGL(k_scan_carry, dim3(1), dim3(SCAN_THREADS), 0, stream, w.block_sums, n_blocks);
+        hipLaunchKernelGGL(k_scan_apply, dim3(n_blocks), dim3(SCAN_THREADS), 0, stream, w.cnt, n_items,
+                           w.block_sums, rowptr);
+    }
     EQH_CHECK_LAUNCH();
     if (nnz > 0) {
         hipLaunchKernelGGL(k_fill, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt,
                            w.tmp_perm);
-        hipLaunchKernelGGL(k_sort_short, dim3(eqh_grid_for(n_rows, 256, 2048)), dim3(256), 0, stream,
+        hipLaunchKernelGGL(k_sort_rows, dim3(eqh_grid_for(n_rows, 4, 4096)), dim3(256), 0, stream,
                            rowptr, n_rows, w.tmp_perm, other, col_div, perm, col, w.long_count,
                            w.long_rows);
-        hipLaunchKernelGGL(k_sort_long, dim3(1024), dim3(LONG_THREADS), LONG_LDS_CAP * sizeof(int),
-                           stream, rowptr, w.tmp_perm, other, col_div, perm, col, w.long_count,
-                           w.long_rows);
+        // rows longer than LONG_ROW (none in molecular batches): LDS bitonic, one workgroup per row
+        hipLaunchKernelGGL(k_sort_long, dim3(nnz > 4 * LONG_ROW ? 256 : 1), dim3(LONG_THREADS),
+                           LONG_LDS_CAP * sizeof(int), stream, rowptr, w.tmp_perm, other, col_div, perm, col,
+                           w.long_count, w.long_rows);
         EQH_CHECK_LAUNCH();
     }
     return EQH_OK;
