@@ -201,3 +201,50 @@ def test_graphed_train_step_matches_eager():
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-6)
     for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=2e-5, rtol=1e-4, err_msg=n)
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    import os
+    import torch.distributed as dist
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # two ranks share the one GPU: no RCCL
+    torch.cuda.set_device(0)
+    args = default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32)
+    m = _models()["egnn_equihnns"](1, args)
+    fill_state_dict(m, 3 + rank)              # different initial weights: rank 0's must win
+    m.to(DEV)
+    raw = [synth_batch(8, 700 + 10 * i + rank) for i in range(3)]
+    ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64) for b in
+           [synth_batch(8, 700 + 10 * i + r) for i in range(3) for r in range(world)]]
+    tgt = tuple(max(e[i] for e in ext) for i in range(3))
+    batches = [pad_batch(b, *tgt).to(DEV) for b in raw]
+    for b in batches:
+        b.num_real_graphs = 8
+    tr = GraphedTrainStep(m, lr=1e-3)
+    losses = [float(tr.step(batches[i % 3])) for i in range(5)]
+    torch.save({"sd": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_two_ranks_stay_in_sync(tmp_path):
+    """Two ranks (gloo, sharing the GPU) through GraphedTrainStep: rank 0's initial weights are
+    broadcast, the packed gradient all-reduce between the two hipGraphs keeps every parameter
+    identical on both ranks although they see different batches."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["losses"] != r1["losses"]          # different data per rank ...
+    for k in r0["sd"]:                            # ... identical parameters
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    assert all(np.isfinite(r0["losses"]))
