@@ -1,0 +1,135 @@
+// Small dense helpers around the library GEMMs.
+//
+// hg_colsum_f32: out[c] = sum_r x[r, c] — the bias gradient of every nn.Linear on the path
+//   (autograd's `grad_output.sum(0)`).  Two passes (row-chunk partial sums with float4 per lane,
+//   then the fixed-order slab reduction): no atomics, bitwise reproducible, ~3x faster than the
+//   generic strided reduction at [~5k x 256].
+//
+// egnn_pack_weights_fwd/bwd: the EGNN edge kernel wants the first edge Linear W1 [H, 2C+1]
+//   (egnn_layer.py:180-186) as w_cat [2*Hp, C] = [W1[:, :C] ; W1[:, C:2C]] (zero rows up to Hp),
+//   b_cat [2*Hp] = [b1 ; 0], wd [Hp] = W1[:, 2C], and W2 [16, H] zero-padded to [16, Hp].  One launch
+//   each way instead of ~20 slicing / padding / concatenation launches per step.
+#include "common.h"
+
+namespace {
+
+constexpr int CS_ROWS = 128;  // rows per partial sum
+
+__global__ void __launch_bounds__(256)
+k_colsum_partial(const float* __restrict__ x, int64_t R, int C, float* __restrict__ part) {
+    // block (bx, by): columns [bx*1024, ...) as float4 per thread, rows [by*CS_ROWS, ...)
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r1 = (r0 + CS_ROWS < R) ? r0 + CS_ROWS : R;
+    float4 a0 = f4_zero(), a1 = f4_zero();
+    int64_t r = r0;
+    for (; r + 2 <= r1; r += 2) {
+        f4_add(a0, *reinterpret_cast<const float4*>(x + r * C + c));
+        f4_add(a1, *reinterpret_cast<const float4*>(x + (r + 1) * C + c));
+    }
+    if (r < r1) f4_add(a0, *reinterpret_cast<const float4*>(x + r * C + c));
+    f4_add(a0, a1);
+    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = a0;
+}
+
+__global__ void k_pack_fwd(const float* __restrict__ w1, const float* __restrict__ b1,
+                           const float* __restrict__ w2, int H, int Hp, int C, float* __restrict__ w_cat,
+                           float* __restrict__ b_cat, float* __restrict__ wd, float* __restrict__ w2p) {
+    const int64_t n_wcat = (int64_t)2 * Hp * C, n_b = 2 * Hp, n_wd = Hp, n_w2 = (int64_t)16 * Hp;
+    const int64_t total = n_wcat + n_b + n_wd + n_w2;
+    const int in_ld = 2 * C + 1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_wcat) {
+            const int row = (int)(i / C), col = (int)(i - (int64_t)row * C);
+            const int half = row >= Hp, h = row - half * Hp;
+            w_cat[i] = h < H ? w1[(int64_t)h * in_ld + half * C + col] : 0.f;
+        } else if (i < n_wcat + n_b) {
+            const int j = (int)(i - n_wcat);
+            b_cat[j] = j < H ? b1[j] : 0.f;
+        } else if (i < n_wcat + n_b + n_wd) {
+            const int h = (int)(i - n_wcat - n_b);
+            wd[h] = h < H ? w1[(int64_t)h * in_ld + 2 * C] : 0.f;
+        } else {
+            const int64_t j = i - n_wcat - n_b - n_wd;
+            const int o = (int)(j / Hp), h = (int)(j - (int64_t)o * Hp);
+            w2p[j] = h < H ? w2[(int64_t)o * H + h] : 0.f;
+        }
+    }
+}
+
+__global__ void k_pack_bwd(const float* __restrict__ dw_cat, const float* __restrict__ db_cat,
+                           const float* __restrict__ dwd, const float* __restrict__ dw2p, int H, int Hp,
+                           int C, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2) {
+    const int in_ld = 2 * C + 1;
+    const int64_t n_w1 = (int64_t)H * in_ld, n_b = H, n_w2 = (int64_t)16 * H;
+    const int64_t total = n_w1 + n_b + n_w2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_w1) {
+            const int h = (int)(i / in_ld), col = (int)(i - (int64_t)h * in_ld);
+            float v;
+            if (col < C) v = dw_cat[(int64_t)h * C + col];
+            else if (col < 2 * C) v = dw_cat[(int64_t)(Hp + h) * C + (col - C)];
+            else v = dwd[h];
+            dw1[i] = v;
+        } else if (i < n_w1 + n_b) {
+            db1[i - n_w1] = db_cat[i - n_w1];
+        } else {
+            const int64_t j = i - n_w1 - n_b;
+            const int o = (int)(j / H), h = (int)(j - (int64_t)o * H);
+            dw2[j] = dw2p[(int64_t)o * Hp + h];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t hg_colsum_workspace_bytes(int64_t R, int32_t C) {
+    if (R < 0 || C <= 0) return 0;
+    const int64_t chunks = (R + CS_ROWS - 1) / CS_ROWS;
+    return (size_t)(chunks > 0 ? chunks : 1) * (size_t)C * sizeof(float);
+}
+
+extern "C" int hg_colsum_f32(const float* x, int64_t R, int32_t C, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream_) {
+    if (R < 0 || C <= 0 || !out) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (R == 0) return eqh_zero_async(out, C, stream);
+    if (!x || !workspace) return EQH_ERR_ARG;
+    if ((C & 3) || !eqh_aligned16(x) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_colsum_workspace_bytes(R, C)) return EQH_ERR_ARG;
+    const int chunks = (int)((R + CS_ROWS - 1) / CS_ROWS);
+    if (chunks > 65535) return EQH_ERR_RANGE;
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 255) / 256, chunks), dim3(256), 0, stream, x, R, (int)C,
+                       part);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs_async(part, chunks, C, out, stream);
+}
+
+extern "C" int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H,
+                                     int32_t Hp, int32_t C, float* w_cat, float* b_cat, float* wd,
+                                     float* w2p, void* stream_) {
+    if (H <= 0 || Hp < H || C <= 0 || !w1 || !b1 || !w2 || !w_cat || !b_cat || !wd || !w2p) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t total = (int64_t)2 * Hp * C + 3 * (int64_t)Hp + (int64_t)16 * Hp;
+    hipLaunchKernelGGL(k_pack_fwd, dim3(eqh_grid_for(total, 256, 2048)), dim3(256), 0, stream, w1, b1, w2, (int)H,
+                       (int)Hp, (int)C, w_cat, b_cat, wd, w2p);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd,
+                                     const float* dw2p, int32_t H, int32_t Hp, int32_t C, float* dw1,
+                                     float* db1, float* dw2, void* stream_) {
+    if (H <= 0 || Hp < H || C <= 0 || !dw_cat || !db_cat || !dwd || !dw2p || !dw1 || !db1 || !dw2)
+        return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t total = (int64_t)H * (2 * C + 1) + H + (int64_t)16 * H;
+    hipLaunchKernelGGL(k_pack_bwd, dim3(eqh_grid_for(total, 256, 2048)), dim3(256), 0, stream, dw_cat, db_cat, dwd,
+                       dw2p, (int)H, (int)Hp, (int)C, dw1, db1, dw2);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

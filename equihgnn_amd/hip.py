@@ -39,6 +39,10 @@ SIGNATURES = {
     "hg_bias_relu_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p,
                                                       c_size_t, c_void_p]),
+    "hg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hg_colsum_f32": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "egnn_pack_weights_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p] * 5),
+    "egnn_pack_weights_bwd": (c_int32, [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 4),
     "geo_eigh3": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "hg_rowgemm_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                                 c_void_p]),

@@ -249,16 +249,14 @@ class EGNN(nn.Module):
         # hidden width H = 2(2C+1) is padded with zero rows to a multiple of 64 (the edge kernels walk
         # 64 hidden units per step); silu(0) = 0, so the padding contributes nothing
         hdim = lin1.weight.shape[0]
-        pad = (-hdim) % 64
-        w1 = F.pad(lin1.weight, (0, 0, 0, pad))
-        b1 = F.pad(lin1.bias, (0, pad))
-        w2 = F.pad(lin2.weight, (0, pad))
+        hp = hdim + (-hdim) % 64
+        # one launch re-lays the edge-MLP weights out as the kernels want them: w_cat = [W1_i ; W1_j],
+        # b_cat = [b1 ; 0], wd = W1[:, 2C], W2 padded (ops.egnn_pack_weights, csrc/dense_aux.hip)
+        w_cat, b_cat, w_d, w2 = ops.egnn_pack_weights(lin1.weight, lin1.bias, lin2.weight, hp)
         # one node-level GEMM gives both halves: ab[:, :Hp] = W1_i f + b1 (receiver), ab[:, Hp:] = W1_j f
-        w_cat = torch.cat((w1[:, :c], w1[:, c:2 * c]), 0)
-        b_cat = F.pad(b1, (0, b1.shape[0]))
         ab = F.linear(feats, w_cat, b_cat)
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
-        m_i = ops.egnn_edge(ab, w1[:, 2 * c], w2, lin2.bias, nbr, d2, csr_t)
+        m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
         node_in = torch.cat((self.node_norm(feats), m_i), -1)
         n0, n3 = self.node_mlp[0], self.node_mlp[3]
         hid = F.silu(ops.linear(node_in, n0.weight, n0.bias))

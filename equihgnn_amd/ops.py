@@ -312,6 +312,57 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
+def colsum(x):
+    """x.sum(0) for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients)."""
+    if not x.is_cuda or x.shape[-1] % 4 or x.dtype != torch.float32:
+        return x.sum(0)
+    x = x.contiguous()
+    R, C = x.shape
+    out = torch.empty(C, dtype=torch.float32, device=x.device)
+    L = hip.lib()
+    ws_bytes = L.hg_colsum_workspace_bytes(R, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    hip.check(L.hg_colsum_f32(_ptr(x), R, C, _ptr(out), _ptr(ws), ws_bytes, _stream(x.device)), "hg_colsum_f32")
+    return out
+
+
+class _EgnnPackWeights(torch.autograd.Function):
+    """(lin1.weight [H,2C+1], lin1.bias [H], lin2.weight [16,H]) -> (w_cat, b_cat, wd, w2p): the
+    operand layout of the fused EGNN edge kernel, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, Hp):
+        _require_gpu(w1, "egnn_pack_weights")
+        w1, b1, w2 = _f32c(w1), _f32c(b1), _f32c(w2)
+        H, in_ld = w1.shape
+        C = (in_ld - 1) // 2
+        dev = w1.device
+        w_cat = torch.empty((2 * Hp, C), dtype=torch.float32, device=dev)
+        b_cat = torch.empty(2 * Hp, dtype=torch.float32, device=dev)
+        wd = torch.empty(Hp, dtype=torch.float32, device=dev)
+        w2p = torch.empty((16, Hp), dtype=torch.float32, device=dev)
+        hip.check(hip.lib().egnn_pack_weights_fwd(_ptr(w1), _ptr(b1), _ptr(w2), H, Hp, C, _ptr(w_cat), _ptr(b_cat),
+                                                  _ptr(wd), _ptr(w2p), _stream(dev)), "egnn_pack_weights_fwd")
+        ctx.dims = (H, Hp, C)
+        return w_cat, b_cat, wd, w2p
+
+    @staticmethod
+    def backward(ctx, dw_cat, db_cat, dwd, dw2p):
+        H, Hp, C = ctx.dims
+        dev = dw_cat.device
+        dw1 = torch.empty((H, 2 * C + 1), dtype=torch.float32, device=dev)
+        db1 = torch.empty(H, dtype=torch.float32, device=dev)
+        dw2 = torch.empty((16, H), dtype=torch.float32, device=dev)
+        hip.check(hip.lib().egnn_pack_weights_bwd(_ptr(_f32c(dw_cat)), _ptr(_f32c(db_cat)), _ptr(_f32c(dwd)),
+                                                  _ptr(_f32c(dw2p)), H, Hp, C, _ptr(dw1), _ptr(db1), _ptr(dw2),
+                                                  _stream(dev)), "egnn_pack_weights_bwd")
+        return dw1, db1, dw2, None
+
+
+def egnn_pack_weights(w1, b1, w2, Hp):
+    return _EgnnPackWeights.apply(w1, b1, w2, Hp)
+
+
 # parameters seen by ops.linear since the last reset (the trainer decides which of them get a
 # persistent gradient accumulator, see trainer.GradBuffers)
 LINEAR_PARAMS = {}
@@ -361,7 +412,7 @@ class _Linear(torch.autograd.Function):
             else:
                 dw = torch.zeros_like(weight)
                 dw[:, c0:c1] = dy2.t() @ x2
-        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db, None, None
 
 

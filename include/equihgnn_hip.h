@@ -189,6 +189,24 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
  * ------------------------------------------------------------------------------------------- */
 int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dense helpers around the library GEMMs.
+ * hg_colsum_f32: out[c] = sum_r x[r,c] — the bias gradient of an nn.Linear (autograd's
+ *   grad_output.sum(0)); two passes, fixed order.
+ * egnn_pack_weights_fwd/bwd: layout change of the EGNN edge-MLP weights (egnn_layer.py:180-186) into
+ *   what egnn_edge_fwd consumes: w1 [H, 2C+1], b1 [H], w2 [16, H]  ->  w_cat [2*Hp, C]
+ *   (= [w1[:, :C] ; w1[:, C:2C]], zero rows from H to Hp), b_cat [2*Hp] (= [b1 ; 0]),
+ *   wd [Hp] (= w1[:, 2C]), w2p [16, Hp]; bwd is the exact adjoint.
+ * ------------------------------------------------------------------------------------------- */
+size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
+int hg_colsum_f32(const float* x, int64_t R, int32_t C, float* out, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hp,
+                          int32_t C, float* w_cat, float* b_cat, float* wd, float* w2p, void* stream);
+int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd, const float* dw2p,
+                          int32_t H, int32_t Hp, int32_t C, float* dw1, float* db1, float* dw2,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
