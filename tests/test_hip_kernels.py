@@ -180,6 +180,23 @@ def test_knn_mode0_matches_oracle_bitwise(N, seed):
     assert np.array_equal(nbr[:, 0].cpu().numpy(), np.arange(N))  # self comes first (d=0)
 
 
+def test_knn_large_cloud_uses_shared_candidate_path():
+    """N > 8192 takes the four-queries-per-wavefront kernel; same (key, index) ordering rule."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    pos = torch.randn(9000, 3, generator=g) * 6
+    rows = torch.tensor([0, 1, 2, 3, 4321, 8996, 8997, 8998, 8999])
+    rel = pos[rows][:, None] - pos[None]
+    d2 = (rel ** 2).sum(-1)
+    val, idx = d2.topk(16, dim=-1, largest=False)
+    nbr, key = ops.knn(pos.to(DEV), 16, 0)
+    assert np.array_equal(key[rows.to(DEV)].cpu().numpy(), val.numpy())
+    assert np.array_equal(np.sort(nbr[rows.to(DEV)].cpu().numpy(), -1), np.sort(idx.numpy(), -1))
+    nbr1, key1 = ops.knn(pos.to(DEV), 16, 1)
+    assert not (nbr1.cpu() == torch.arange(9000)[:, None]).any()
+    np.testing.assert_allclose(key1[rows.to(DEV)].cpu().numpy() ** 2, d2.topk(17, dim=-1, largest=False).values[:, 1:].numpy(), rtol=1e-6)
+
+
 def test_knn_rejects_too_few_points_like_topk():
     from equihgnn_amd import hip
     ops = _ops()
