@@ -47,6 +47,13 @@ __device__ __forceinline__ float sigmoid_fast(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 __device__ __forceinline__ float silu_fast(float x) { return x * sigmoid_fast(x); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// the same silu on two values with the non-transcendental steps packed
+__device__ __forceinline__ f32x2 silu_fast2(f32x2 x) {
+    const f32x2 t = x * f32x2{-1.442695041f, -1.442695041f};
+    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + f32x2{1.0f, 1.0f};
+    return x * f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+}
 // returns silu(x) and writes d silu / dx = sig + silu*(1 - sig)
 __device__ __forceinline__ float silu_grad(float x, float* ds) {
     const float sig = sigmoid_fast(x);
@@ -62,51 +69,200 @@ __host__ __device__ inline int lds_row_stride(int Hp) {  // (stride mod 64) == 2
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(THREADS)
+// Measured facts that shape it (rocprofv3 PMC + in-kernel s_memtime stamps at the BASELINE batch,
+// N = 4608, Hp = 1088; profiles/r01_edge_fwd_notes.md):
+//  * the fp32 MFMA does not run beside the VALU: a SIMD's time per 16-unit step is the SUM of the
+//    SiLU's VALU cycles (v_exp / v_rcp at quarter rate) and the 4 x 32 MFMA cycles, ~420 cycles, whatever
+//    the memory system does -- the kernel is issue-bound once its loads are hidden;
+//  * loading the B rows directly in MFMA operand order (neighbour r = lane & 15 in the LOW lane bits)
+//    costs 38 L1 (TCP) accesses per load instruction and kept the TCP busy for the whole kernel (92 us).
+//    Here every wavefront loads its B rows row-contiguously (a quarter-wavefront reads 256 consecutive
+//    bytes: 15 accesses per instruction), parks them in a private LDS tile and re-reads them in MFMA
+//    order (conflict-free with a 4-float row pad); the receiver's A row takes the same route;
+//  * the kNN graph ignores molecule boundaries (egnn_layer.py:253-288 ranks all atoms of the batch), so
+//    the gather has no locality to exploit: 341 MB per launch through L2 at a 38% hit rate.
+// A 1024-thread workgroup (16 wavefronts, 4 per SIMD) owns a CU and a contiguous run of nodes; four
+// wavefronts share one node, each walking a quarter of the hidden units in stages of 64.  Per wavefront
+// the work is one software pipeline over (group, stage): loads of the next stage, the neighbour list of
+// the next group and the first stage of the next group are all in flight behind SiLU/MFMA work.  The
+// four partial 16x16 accumulators meet in LDS and are added in wavefront order: bitwise reproducible.
+// W2 lives in LDS when it fits beside the tiles (Hp <= 1280), else it is read through L1.
+constexpr int FWD_THREADS = 1024;
+constexpr int FWD_SPLIT = 4;                             // wavefronts per node
+constexpr int FWD_NODES = FWD_THREADS / 64 / FWD_SPLIT;  // nodes per workgroup iteration
+constexpr int FWD_UB = 4;                                // 16-unit steps per stage (64 hidden units)
+constexpr int FWD_LD = 16 * FWD_UB + 4;                  // floats per staged row: 64 + 4 pad
+constexpr int FWD_TILE = (KNB + 1) * FWD_LD;             // floats per wavefront tile: 16 B rows + the A row
+
+template <int NU>
+__device__ __forceinline__ f32x4 fwd_stage(const float* __restrict__ t_rd, const float* __restrict__ t_rda,
+                                           const float* __restrict__ wrow, const float* __restrict__ crow,
+                                           float dd, f32x4 acc) {
+    const f32x2 dd2 = {dd, dd};
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const float4 b4 = *reinterpret_cast<const float4*>(t_rd + 16 * u);
+        const float4 a4 = *reinterpret_cast<const float4*>(t_rda + 16 * u);
+        const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * u);
+        const float4 c4 = *reinterpret_cast<const float4*>(crow + 16 * u);
+        // two hidden units per packed instruction (v_pk_add/fma/mul_f32 run at twice the scalar-f32 rate);
+        // the fp32 MFMA shares the VALU's FMA lanes, so every VALU cycle saved here is wall time
+        const f32x2 h01 = f32x2{c4.x, c4.y} * dd2 + (f32x2{a4.x, a4.y} + f32x2{b4.x, b4.y});
+        const f32x2 h23 = f32x2{c4.z, c4.w} * dd2 + (f32x2{a4.z, a4.w} + f32x2{b4.z, b4.w});
+        const f32x2 s01 = silu_fast2(h01);
+        const f32x2 s23 = silu_fast2(h23);
+        acc = mfma16(s01.x, w4.x, acc);
+        acc = mfma16(s01.y, w4.y, acc);
+        acc = mfma16(s23.x, w4.z, acc);
+        acc = mfma16(s23.y, w4.w, acc);
+    }
+    return acc;
+}
+
+template <bool W2_LDS>
+__global__ void __launch_bounds__(FWD_THREADS)
 k_edge_fwd(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
            const float* __restrict__ b2, const int* __restrict__ nbr, const float* __restrict__ d2,
            float* __restrict__ m, float* __restrict__ pre2, int N, int Hp) {
-    extern __shared__ float s_w2[];  // [16][ldw]
-    const int ldw = lds_row_stride(Hp);
-    for (int idx = threadIdx.x * 4; idx < MDIM * Hp; idx += THREADS * 4) {
-        const int o = idx / Hp, k = idx - o * Hp;
-        *reinterpret_cast<float4*>(s_w2 + o * ldw + k) = *reinterpret_cast<const float4*>(w2 + idx);
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    const int ldw = W2_LDS ? lds_row_stride(Hp) : Hp;
+    float* s_w2 = s_mem;                               // [16][ldw] (absent if !W2_LDS)
+    float* s_wd = s_w2 + (W2_LDS ? MDIM * ldw : 0);    // [Hp]
+    float* s_tile = s_wd + Hp;                         // [16 wavefronts][FWD_TILE]
+    if (W2_LDS) {
+        for (int idx = threadIdx.x * 4; idx < MDIM * Hp; idx += FWD_THREADS * 4) {
+            const int o = idx / Hp, k = idx - o * Hp;
+            *reinterpret_cast<float4*>(s_w2 + o * ldw + k) = *reinterpret_cast<const float4*>(w2 + idx);
+        }
     }
+    for (int idx = threadIdx.x * 4; idx < Hp; idx += FWD_THREADS * 4)
+        *reinterpret_cast<float4*>(s_wd + idx) = *reinterpret_cast<const float4*>(wd + idx);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int steps = Hp >> 4;
+    const int slot = wave / FWD_SPLIT, part = wave % FWD_SPLIT;
+    const int per = (Hp >> 4) / FWD_SPLIT;  // Hp % 64 == 0: every wavefront gets the same step count
+    const int s_beg = part * per;
+    const int nfull = per / FWD_UB, tail = per % FWD_UB;
+    const int nstages = nfull + (tail ? 1 : 0);
     const float bo = b2[r];
-    for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
-        const int j = nbr[node * KNB + r];
-        const float dd = d2[node * KNB + r];
-        const float* __restrict__ arow = ab + (int64_t)node * 2 * Hp + 4 * q;
-        const float* __restrict__ brow = ab + (int64_t)j * 2 * Hp + Hp + 4 * q;
-        const float* __restrict__ wrow = s_w2 + r * ldw + 4 * q;
-        const float* __restrict__ wdp = wd + 4 * q;
+    const float* __restrict__ wrow = (W2_LDS ? s_w2 : w2) + r * ldw + 4 * q + 16 * s_beg;
+    const float* __restrict__ crow = s_wd + 4 * q + 16 * s_beg;
+    float* tile = s_tile + wave * FWD_TILE;
+    float* t_wr = tile + q * FWD_LD + 4 * r;        // row 4i + q (i-th load), 16-byte piece r
+    const float* t_rd = tile + r * FWD_LD + 4 * q;  // neighbour r, k-quarter q
+    const float* t_rda = tile + KNB * FWD_LD + 4 * q;  // the receiver's own A row (broadcast over r)
+    float* t_wra = tile + KNB * FWD_LD + 4 * r;        // written by lanes 0..15
+    const int groups = (N + FWD_NODES - 1) / FWD_NODES;
+    const int gpb = (groups + gridDim.x - 1) / gridDim.x;
+    const int g_beg = blockIdx.x * gpb;
+    const int g_end = (g_beg + gpb < groups) ? g_beg + gpb : groups;
+    // column (float) offsets of this lane's pieces, clamped into the row: the ragged last stage of the
+    // last quarter re-reads the row's final piece instead of running past it (loads stay unconditional:
+    // a predicated load would be merged into its destination and waited for on the spot)
+    const int b_col0 = 16 * s_beg + 4 * r;
+    if (g_beg >= g_end) return;  // whole workgroup
+    const int bc0 = (b_col0 < Hp - 4) ? b_col0 : Hp - 4;
+    // The per-wavefront work is ONE software pipeline over (group, stage): the loads of stage s+1 fly
+    // during the SiLU/MFMA work of stage s, the neighbour list of the next group is fetched during the
+    // first stage of the current one, and the first stage of the next group is requested before the last
+    // stage of the current one is computed, so nothing but the two barriers separates two groups.
+    // (Named scalars, not arrays: an array assigned on both sides of a branch lands in scratch.)
+    int node_raw = g_beg * FWD_NODES + slot;
+    int node = (node_raw < N) ? node_raw : N - 1;  // tail: recompute the last node, not stored
+    float dd = d2[node * KNB + r];
+    const float* __restrict__ arow = ab + (int64_t)node * 2 * Hp;
+    const float* __restrict__ brow0 = ab + (int64_t)nbr[node * KNB + q] * 2 * Hp + Hp;
+    const float* __restrict__ brow1 = ab + (int64_t)nbr[node * KNB + 4 + q] * 2 * Hp + Hp;
+    const float* __restrict__ brow2 = ab + (int64_t)nbr[node * KNB + 8 + q] * 2 * Hp + Hp;
+    const float* __restrict__ brow3 = ab + (int64_t)nbr[node * KNB + 12 + q] * 2 * Hp + Hp;
+    float4 nb0 = *reinterpret_cast<const float4*>(brow0 + bc0);
+    float4 nb1 = *reinterpret_cast<const float4*>(brow1 + bc0);
+    float4 nb2 = *reinterpret_cast<const float4*>(brow2 + bc0);
+    float4 nb3 = *reinterpret_cast<const float4*>(brow3 + bc0);
+    // the A row goes through LDS too, fetched by 16 lanes: sixteen lanes asking the TCP for the SAME
+    // not-yet-resident line (the MFMA-order load) stall its pipeline until the line arrives
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q == 0) na = *reinterpret_cast<const float4*>(arow + bc0);
+    for (int group = g_beg; group < g_end; ++group) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-
-        for (int t = 0; t < steps; ++t) {
-            const float4 a4 = *reinterpret_cast<const float4*>(arow + 16 * t);
-            const float4 b4 = *reinterpret_cast<const float4*>(brow + 16 * t);
-            const float4 c4 = *reinterpret_cast<const float4*>(wdp + 16 * t);
-            const float4 w4 = *reinterpret_cast<const float4*>(wrow + 16 * t);
-            acc = mfma16(silu_fast(fmaf(c4.x, dd, a4.x + b4.x)), w4.x, acc);
-            acc = mfma16(silu_fast(fmaf(c4.y, dd, a4.y + b4.y)), w4.y, acc);
-            acc = mfma16(silu_fast(fmaf(c4.z, dd, a4.z + b4.z)), w4.z, acc);
-            acc = mfma16(silu_fast(fmaf(c4.w, dd, a4.w + b4.w)), w4.w, acc);
+        int j0 = 0, j1 = 0, j2 = 0, j3 = 0, node_raw_n = 0, node_n = 0;
+        float dd_n = 0.f;
+        for (int st = 0; st < nstages; ++st) {
+            *reinterpret_cast<float4*>(t_wr) = nb0;
+            *reinterpret_cast<float4*>(t_wr + 4 * FWD_LD) = nb1;
+            *reinterpret_cast<float4*>(t_wr + 8 * FWD_LD) = nb2;
+            *reinterpret_cast<float4*>(t_wr + 12 * FWD_LD) = nb3;
+            if (q == 0) *reinterpret_cast<float4*>(t_wra) = na;
+            if (st == 0) {  // next group's neighbour list (the last group re-reads its own)
+                const int gn = (group + 1 < g_end) ? group + 1 : group;
+                node_raw_n = gn * FWD_NODES + slot;
+                node_n = (node_raw_n < N) ? node_raw_n : N - 1;
+                j0 = nbr[node_n * KNB + q];
+                j1 = nbr[node_n * KNB + 4 + q];
+                j2 = nbr[node_n * KNB + 8 + q];
+                j3 = nbr[node_n * KNB + 12 + q];
+                dd_n = d2[node_n * KNB + r];
+            }
+            const float* __restrict__ p0 = brow0;
+            const float* __restrict__ p1 = brow1;
+            const float* __restrict__ p2 = brow2;
+            const float* __restrict__ p3 = brow3;
+            const float* __restrict__ pa = arow;
+            int bc;
+            if (st + 1 < nstages) {  // next stage of this group
+                const int off = 16 * FWD_UB * (st + 1);
+                bc = (b_col0 + off < Hp - 4) ? b_col0 + off : Hp - 4;
+            } else {  // first stage of the next group
+                // opaque to the optimiser: otherwise the index arithmetic is hoisted above the branch and
+                // the neighbour list is waited for right after it was requested
+                asm volatile("" : "+v"(j0), "+v"(j1), "+v"(j2), "+v"(j3), "+v"(node_n));
+                p0 = ab + (int64_t)j0 * 2 * Hp + Hp;
+                p1 = ab + (int64_t)j1 * 2 * Hp + Hp;
+                p2 = ab + (int64_t)j2 * 2 * Hp + Hp;
+                p3 = ab + (int64_t)j3 * 2 * Hp + Hp;
+                pa = ab + (int64_t)node_n * 2 * Hp;
+                bc = bc0;
+            }
+            nb0 = *reinterpret_cast<const float4*>(p0 + bc);
+            nb1 = *reinterpret_cast<const float4*>(p1 + bc);
+            nb2 = *reinterpret_cast<const float4*>(p2 + bc);
+            nb3 = *reinterpret_cast<const float4*>(p3 + bc);
+            if (q == 0) na = *reinterpret_cast<const float4*>(pa + bc);
+            __builtin_amdgcn_sched_barrier(0);
+            const float* wr = wrow + 16 * FWD_UB * st;
+            const float* cr = crow + 16 * FWD_UB * st;
+            if (st < nfull) acc = fwd_stage<FWD_UB>(t_rd, t_rda, wr, cr, dd, acc);
+            else if (tail == 1) acc = fwd_stage<1>(t_rd, t_rda, wr, cr, dd, acc);
+            else if (tail == 2) acc = fwd_stage<2>(t_rd, t_rda, wr, cr, dd, acc);
+            else acc = fwd_stage<3>(t_rd, t_rda, wr, cr, dd, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st + 1 == nstages) { brow0 = p0; brow1 = p1; brow2 = p2; brow3 = p3; arow = pa; }
         }
-        // acc[g] = pre2[j = 4q+g][o = r] (before bias)
-        float msum = 0.f;
+        // partial accumulators: wavefronts 1..3 of the node park theirs in their own (now idle) tile
+        if (part > 0) *reinterpret_cast<f32x4*>(tile + lane * 4) = acc;
+        __syncthreads();
+        if (part == 0 && node_raw < N) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float p = acc[g] + bo;
-            pre2[(int64_t)node * (KNB * MDIM) + (4 * q + g) * MDIM + r] = p;
-            msum += silu_fast(p);
+            for (int pp = 1; pp < FWD_SPLIT; ++pp)
+                acc += *reinterpret_cast<const f32x4*>(tile + pp * FWD_TILE + lane * 4);
+            // acc[g] = pre2[j = 4q+g][o = r] (before bias)
+            float msum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float pv = acc[g] + bo;
+                pre2[(int64_t)node * (KNB * MDIM) + (4 * q + g) * MDIM + r] = pv;
+                msum += silu_fast(pv);
+            }
+            msum += __shfl_xor(msum, 16, 64);
+            msum += __shfl_xor(msum, 32, 64);
+            if (q == 0) m[(int64_t)node * MDIM + r] = msum;
         }
-        msum += __shfl_xor(msum, 16, 64);
-        msum += __shfl_xor(msum, 32, 64);
-        if (q == 0) m[(int64_t)node * MDIM + r] = msum;
+        __syncthreads();  // tiles are overwritten by the next group's first stage
+        node_raw = node_raw_n;
+        node = node_n;
+        dd = dd_n;
     }
 }
 
@@ -344,19 +500,28 @@ extern "C" int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, 
     if (N == 0) return EQH_OK;
     if (!ab || !wd || !w2 || !b2 || !nbr || !d2 || !m || !pre2) return EQH_ERR_ARG;
     if (!eqh_aligned16(ab) || !eqh_aligned16(wd) || !eqh_aligned16(w2)) return EQH_ERR_ALIGN;
-    const size_t lds = (size_t)MDIM * lds_row_stride(Hp) * sizeof(float);
+    const size_t lds_rest = ((size_t)Hp + (size_t)(FWD_THREADS / 64) * FWD_TILE) * sizeof(float);
+    const size_t lds_w2 = (size_t)MDIM * lds_row_stride(Hp) * sizeof(float);
+    const bool w2_lds = lds_rest + lds_w2 <= 160 * 1024;
+    const size_t lds = lds_rest + (w2_lds ? lds_w2 : 0);
     if (lds > 160 * 1024) return EQH_ERR_RANGE;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return EQH_ERR_LAUNCH;
         attr_set = true;
     }
-    const int grid = eqh_grid_for(N, WAVES, 512);  // 2 workgroups per CU hold W2 in LDS
-    hipLaunchKernelGGL(k_edge_fwd, dim3(grid), dim3(THREADS), lds, stream, ab, wd, w2, b2, nbr, d2, m,
-                       pre2, (int)N, (int)Hp);
+    const int grid = eqh_grid_for(N, FWD_NODES, 256);  // one 16-wavefront workgroup per CU
+    if (w2_lds)
+        hipLaunchKernelGGL(k_edge_fwd<true>, dim3(grid), dim3(FWD_THREADS), lds, stream, ab, wd, w2, b2, nbr, d2,
+                           m, pre2, (int)N, (int)Hp);
+    else
+        hipLaunchKernelGGL(k_edge_fwd<false>, dim3(grid), dim3(FWD_THREADS), lds, stream, ab, wd, w2, b2, nbr, d2,
+                           m, pre2, (int)N, (int)Hp);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

@@ -267,7 +267,8 @@ def test_properties_at_full_size():
                                rtol=1e-6, atol=1e-3)
 
 
-@pytest.mark.parametrize("N,Hp,seed", [(16, 64, 0), (40, 320, 1), (300, 1088, 2), (1000, 1088, 3)])
+@pytest.mark.parametrize("N,Hp,seed", [(16, 64, 0), (40, 320, 1), (300, 1088, 2), (1000, 1088, 3),
+                                        (7, 128, 4), (130, 192, 5), (1283, 576, 6), (50, 2112, 7)])
 def test_egnn_edge_fused_matches_float64_reference(N, Hp, seed):
     """egnn_edge_fwd/bwd against the explicit per-edge formulation evaluated in float64:
     m_i = sum_j silu(W2 silu(A_i + B_j + wd*d2_ij) + b2) and all five gradients."""
