@@ -13,24 +13,34 @@
 
 namespace {
 
-constexpr int CS_ROWS = 128;  // rows per partial sum
+constexpr int CS_ROWS = 32;  // rows per partial sum: 4 row lanes x 8 rows, all eight loads in flight
 
 __global__ void __launch_bounds__(256)
 k_colsum_partial(const float* __restrict__ x, int64_t R, int C, float* __restrict__ part) {
-    // block (bx, by): columns [bx*1024, ...) as float4 per thread, rows [by*CS_ROWS, ...)
-    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (c >= C) return;
+    // block (bx, by): columns [bx*256, +256) as one float4 per thread of a 64-thread row lane; the four row
+    // lanes take rows r0 + ty, r0 + ty + 4, ... and meet in LDS in lane order (fixed summation order)
+    __shared__ float4 s_acc[3][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    const bool live = c < C;
     const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
-    const int64_t r1 = (r0 + CS_ROWS < R) ? r0 + CS_ROWS : R;
-    float4 a0 = f4_zero(), a1 = f4_zero();
-    int64_t r = r0;
-    for (; r + 2 <= r1; r += 2) {
-        f4_add(a0, *reinterpret_cast<const float4*>(x + r * C + c));
-        f4_add(a1, *reinterpret_cast<const float4*>(x + (r + 1) * C + c));
+    float4 v[CS_ROWS / 4];
+#pragma unroll
+    for (int i = 0; i < CS_ROWS / 4; ++i) {
+        const int64_t r = r0 + ty + 4 * i;
+        v[i] = (live && r < R) ? *reinterpret_cast<const float4*>(x + r * C + c) : f4_zero();
     }
-    if (r < r1) f4_add(a0, *reinterpret_cast<const float4*>(x + r * C + c));
-    f4_add(a0, a1);
-    *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = a0;
+    float4 a = v[0];
+#pragma unroll
+    for (int i = 1; i < CS_ROWS / 4; ++i) f4_add(a, v[i]);
+    if (ty > 0) s_acc[ty - 1][tx] = a;
+    __syncthreads();
+    if (ty == 0 && live) {
+        f4_add(a, s_acc[0][tx]);
+        f4_add(a, s_acc[1][tx]);
+        f4_add(a, s_acc[2][tx]);
+        *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = a;
+    }
 }
 
 __global__ void k_pack_fwd(const float* __restrict__ w1, const float* __restrict__ b1,
@@ -103,7 +113,7 @@ extern "C" int hg_colsum_f32(const float* x, int64_t R, int32_t C, float* out, v
     const int chunks = (int)((R + CS_ROWS - 1) / CS_ROWS);
     if (chunks > 65535) return EQH_ERR_RANGE;
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 255) / 256, chunks), dim3(256), 0, stream, x, R, (int)C,
+    hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 63) / 64, chunks), dim3(256), 0, stream, x, R, (int)C,
                        part);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(part, chunks, C, out, stream);

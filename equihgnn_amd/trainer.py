@@ -104,10 +104,12 @@ class GraphedTrainStep:
     graph.  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
     without batch statistics); the loss is taken over the real molecules only.
 
-    Gradients are the tensors autograd allocates inside the captured backward (``grad=None`` before
-    the capture, so the first contribution is written, not added — pre-allocated gradients cost one
-    extra add kernel per parameter use).  With more than one rank they are packed into one flat
-    buffer at the end of the first graph, all-reduced, and unpacked at the start of the second.
+    Parameters live in ONE flat buffer (``pflat``; every ``nn.Parameter`` is a view into it) and so
+    do their gradients (``gflat``, same element order): the weight gradients of ``ops.linear`` are
+    accumulated straight into its head by the GEMMs, the gradients autograd allocates inside the
+    captured backward (``grad=None`` before the capture, so the first contribution is written, not
+    added) are packed behind them by one batched copy at the end of the first graph.  The all-reduce
+    and the fused Adam therefore each see a single tensor.
     """
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
@@ -117,7 +119,12 @@ class GraphedTrainStep:
         self.opt = None
         self.slots = {}
         self.wflat = None
+        self.gflat = None
+        self.pflat = None
         self.gb_params = []
+        self.others = []
+        self.other_slots = []
+        self.n_w = 0
         if broadcast_from_rank0 and _world() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
@@ -140,8 +147,7 @@ class GraphedTrainStep:
         loss = self._loss(data)
         loss.backward()
         self._join()
-        for p in self.gb_params:       # weights whose gradient the GEMMs accumulated in place
-            p.grad = p._eqh_gbuf
+        self._gather_grads()
         return loss
 
     def _join(self):
@@ -149,50 +155,79 @@ class GraphedTrainStep:
         if self.gb_params:
             ops.join_wgrad_stream(self.gb_params[0].device)
 
+    def _gather_grads(self):
+        """After a backward: the weights the GEMMs accumulated in place already sit in the head of
+        ``gflat``; the gradients autograd allocated (biases, norms, embeddings, ...) are packed behind
+        them by one batched copy (the padding between slots stays zero, which Adam maps to a zero update)."""
+        for p in self.gb_params:
+            p.grad = p._eqh_gbuf
+        if self.gflat is None:
+            return
+        if self.others:
+            torch._foreach_copy_(self.other_slots, [p.grad for p in self.others])
+
     def _setup_grad_buffers(self, data, live):
         """Give every weight that is used ONLY through ops.linear a persistent gradient accumulator
-        (one flat buffer, zeroed by a single fill per step); a probe pass drops any parameter that
-        autograd still produces a gradient for (i.e. that is also used some other way)."""
+        (the head of one flat buffer, zeroed by a single fill per step); a probe pass drops any
+        parameter that autograd still produces a gradient for (i.e. that is also used some other way)."""
         from . import ops
         cand = [p for p in live if id(p) in ops.LINEAR_PARAMS and p.dim() == 2]
-        if not cand:
-            return
-        self.wflat = torch.zeros(sum(p.numel() for p in cand), dtype=cand[0].dtype, device=cand[0].device)
-        off = 0
-        for p in cand:
-            p._eqh_gbuf = self.wflat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-        for p in self.model.parameters():
-            p.grad = None
-        self._loss(data).backward()
-        for p in cand:
-            if p.grad is not None:
-                del p._eqh_gbuf
-        self.gb_params = [p for p in cand if hasattr(p, "_eqh_gbuf")]
-
-    def _reduce_eager(self):
-        if _world() > 1:
-            grads = [p.grad for p in self.live]
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.mul_(1.0 / _world())
+        dev, dt = live[0].device, live[0].dtype
+        if cand:
+            probe = torch.zeros(sum(p.numel() for p in cand), dtype=dt, device=dev)
             off = 0
-            for g in grads:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+            for p in cand:
+                p._eqh_gbuf = probe[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            for p in self.model.parameters():
+                p.grad = None
+            self._loss(data).backward()
+            self._join()
+            for p in cand:
+                if p.grad is not None:
+                    del p._eqh_gbuf
+        self.gb_params = [p for p in cand if hasattr(p, "_eqh_gbuf")]
+        gb = {id(p) for p in self.gb_params}
+        self.others = [p for p in live if id(p) not in gb]
+        order = self.gb_params + self.others
+        pad = lambda k: (k + 63) // 64 * 64   # every view starts 256-byte aligned (the kernels want 16)
+        n = sum(pad(p.numel()) for p in order)
+        self.n_w = sum(pad(p.numel()) for p in self.gb_params)
+        # one flat buffer each for parameters and gradients, same element order: the optimiser, the
+        # all-reduce and the zero-fill all see ONE tensor instead of ~100
+        self.gflat = torch.zeros(n, dtype=dt, device=dev)
+        pflat = torch.zeros(n, dtype=dt, device=dev)
+        self.other_slots = []
+        off = 0
+        for p in order:
+            k = p.numel()
+            pflat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = pflat[off:off + k].view_as(p)
+            if id(p) in gb:
+                p._eqh_gbuf = self.gflat[off:off + k].view_as(p)
+            else:
+                self.other_slots.append(self.gflat[off:off + k].view_as(p))
+            off += pad(k)
+        self.wflat = self.gflat[:self.n_w] if self.n_w else None
+        self.pflat = torch.nn.Parameter(pflat)
+        self.pflat.grad = self.gflat
 
     def _bootstrap(self, data):
-        """Eager first step: discovers the live parameters and creates the capturable fused Adam
-        (also performs every lazy one-time initialisation of the HIP library and of the GEMM
-        libraries before anything is captured)."""
+        """Eager first step: discovers the live parameters, lays out the flat buffers and creates
+        the capturable fused Adam (also performs every lazy one-time initialisation of the HIP
+        library and of the GEMM libraries before anything is captured)."""
         from . import ops
         ops.LINEAR_PARAMS.clear()
+        self.gflat = None
         loss = self._fwd_bwd(data)
         self.live = [p for p in self.model.parameters() if p.grad is not None]
         self._setup_grad_buffers(data, self.live)
         loss = self._fwd_bwd(data)
-        self.opt = torch.optim.Adam(self.live, lr=self.lr, weight_decay=self.wd, fused=True, capturable=True)
-        self._reduce_eager()
+        # Adam is elementwise: one update over the flat tensor equals the per-parameter updates bit for bit
+        self.opt = torch.optim.Adam([self.pflat], lr=self.lr, weight_decay=self.wd, fused=True, capturable=True)
+        if _world() > 1:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
+            self.gflat.mul_(1.0 / _world())
         self.opt.step()
         return loss.detach()
 
@@ -214,20 +249,13 @@ class GraphedTrainStep:
             loss = self._loss(static)
             loss.backward()
             self._join()
-            for p in self.gb_params:
-                p.grad = p._eqh_gbuf
-            grads = [p.grad for p in self.live]
-            flat = torch.cat([g.reshape(-1) for g in grads]) if world > 1 else None
+            self._gather_grads()
         g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
             if world > 1:
-                flat.mul_(1.0 / world)
-                off = 0
-                for g in grads:
-                    g.copy_(flat[off:off + g.numel()].view_as(g))
-                    off += g.numel()
+                self.gflat.mul_(1.0 / world)
             self.opt.step()
-        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss, "flat": flat, "grads": grads}
+        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss}
 
     def step(self, data) -> torch.Tensor:
         if self.live is None:
@@ -245,7 +273,7 @@ class GraphedTrainStep:
             if torch.is_tensor(v):
                 getattr(st, f).copy_(v, non_blocking=True)
         slot["bwd"].replay()
-        if slot["flat"] is not None:
-            dist.all_reduce(slot["flat"], op=dist.ReduceOp.SUM)
+        if _world() > 1:
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
         slot["opt"].replay()
         return slot["loss"].detach()

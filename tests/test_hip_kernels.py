@@ -312,6 +312,17 @@ def test_egnn_edge_fused_matches_float64_reference(N, Hp, seed):
     assert torch.equal(m, m2) and all(torch.equal(a.grad, b.grad) for a, b in zip(dev, dev2))
 
 
+@pytest.mark.parametrize("R,C", [(1, 4), (33, 8), (4608, 256), (9733, 256), (1000, 1092), (5, 2176), (0, 16)])
+def test_colsum_matches_float64(R, C):
+    """hg_colsum_f32 (bias gradients): against the float64 column sum, and bitwise reproducible."""
+    ops = _ops()
+    x = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).to(DEV)
+    out = ops.colsum(x)
+    ref = x.double().sum(0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6 * max(R, 1) ** 0.5 * 4)
+    assert torch.equal(out, ops.colsum(x))
+
+
 @pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3)])
 def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     """hg_rowgemm_fwd/bwd: out[e] = z[e] @ w[row(e)] with rows from a CSR (empty rows, rows longer
