@@ -42,36 +42,59 @@ static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
 }
 
 // out[e] = sum_b slab[b][e] for e < elems, summed in a FIXED order (bitwise reproducible).  A block
-// covers 64 consecutive elements with 4 slab-groups (b = g, g+4, ...); each group keeps 4 independent
-// partial sums so that four loads are in flight per lane (the loop is latency-, not bandwidth-bound),
-// and the groups are combined through LDS.
-static __global__ void __launch_bounds__(256)
-eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out) {
-    __shared__ float s_part[256];
+// covers 64 consecutive elements with 16 slab-groups (b = g, g+16, ...); each group keeps 4 independent
+// partial sums and issues eight loads before the first add (the loop is latency-, not bandwidth-bound:
+// the typical call reduces 100-300 slabs of a few hundred floats), and the groups are combined through
+// LDS in group order.
+// Output: up to three segments of seg_len elements each (out0 | out1 | out2; out1 == nullptr means one
+// contiguous run of `elems`), overwritten or, with accumulate != 0, added to (gradient accumulators of
+// parameters that are used several times per step).
+static __global__ void __launch_bounds__(1024)
+eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out0,
+                   float* __restrict__ out1, float* __restrict__ out2, int64_t seg_len, int accumulate) {
+    __shared__ float s_part[1024];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < elems; e0 += (int64_t)gridDim.x * 64) {
         const int64_t e = e0 + col;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (e < elems) {
+            const float* __restrict__ p = slab + e;
             int b = grp;
-            for (; b + 12 < n_slabs; b += 16) {
-                const float v0 = slab[(int64_t)b * elems + e];
-                const float v1 = slab[(int64_t)(b + 4) * elems + e];
-                const float v2 = slab[(int64_t)(b + 8) * elems + e];
-                const float v3 = slab[(int64_t)(b + 12) * elems + e];
-                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            for (; b + 112 < n_slabs; b += 128) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = p[(int64_t)(b + 16 * i) * elems];
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
             }
-            for (; b < n_slabs; b += 4) a0 += slab[(int64_t)b * elems + e];
+            {   // ragged end: same accumulator assignment (i mod 4), loads still issued together
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = (b + 16 * i < n_slabs) ? p[(int64_t)(b + 16 * i) * elems] : 0.f;
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
+            }
         }
         s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
         __syncthreads();
-        if (grp == 0 && e < elems) out[e] = ((s_part[col] + s_part[64 + col]) + s_part[128 + col]) + s_part[192 + col];
+        if (grp == 0 && e < elems) {
+            float t = s_part[col];
+#pragma unroll
+            for (int g = 1; g < 16; ++g) t += s_part[64 * g + col];
+            float* dst = out0 + e;
+            if (out1 != nullptr && e >= seg_len) dst = (e < 2 * seg_len) ? out1 + (e - seg_len) : out2 + (e - 2 * seg_len);
+            *dst = accumulate ? *dst + t : t;
+        }
         __syncthreads();
     }
 }
-static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,
-                                         hipStream_t stream) {
-    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(256), 0, stream, slab,
-                       n_slabs, elems, out);
+static inline int eqh_reduce_slabs3_async(const float* slab, int n_slabs, int64_t elems, float* out0, float* out1,
+                                          float* out2, int64_t seg_len, int accumulate, hipStream_t stream) {
+    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(1024), 0, stream, slab,
+                       n_slabs, elems, out0, out1, out2, seg_len, accumulate);
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
+}
+static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,
+                                         hipStream_t stream, int accumulate = 0) {
+    return eqh_reduce_slabs3_async(slab, n_slabs, elems, out, nullptr, nullptr, elems, accumulate, stream);
 }

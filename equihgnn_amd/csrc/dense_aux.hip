@@ -16,7 +16,8 @@ namespace {
 constexpr int CS_ROWS = 32;  // rows per partial sum: 4 row lanes x 8 rows, all eight loads in flight
 
 __global__ void __launch_bounds__(256)
-k_colsum_partial(const float* __restrict__ x, int64_t R, int C, float* __restrict__ part) {
+k_colsum_partial(const float* __restrict__ x, const int* __restrict__ rowptr, int mode, int64_t R, int C,
+                 float* __restrict__ part) {
     // block (bx, by): columns [bx*256, +256) as one float4 per thread of a 64-thread row lane; the four row
     // lanes take rows r0 + ty, r0 + ty + 4, ... and meet in LDS in lane order (fixed summation order)
     __shared__ float4 s_acc[3][64];
@@ -29,6 +30,11 @@ k_colsum_partial(const float* __restrict__ x, int64_t R, int C, float* __restric
     for (int i = 0; i < CS_ROWS / 4; ++i) {
         const int64_t r = r0 + ty + 4 * i;
         v[i] = (live && r < R) ? *reinterpret_cast<const float4*>(x + r * C + c) : f4_zero();
+        if (mode != 0 && r < R) {  // row weight from the CSR row length: [len > 0] or len
+            const int len = rowptr[r + 1] - rowptr[r];
+            const float w = (mode == 1) ? (len > 0 ? 1.f : 0.f) : (float)len;
+            v[i].x *= w; v[i].y *= w; v[i].z *= w; v[i].w *= w;
+        }
     }
     float4 a = v[0];
 #pragma unroll
@@ -102,21 +108,23 @@ extern "C" size_t hg_colsum_workspace_bytes(int64_t R, int32_t C) {
     return (size_t)(chunks > 0 ? chunks : 1) * (size_t)C * sizeof(float);
 }
 
-extern "C" int hg_colsum_f32(const float* x, int64_t R, int32_t C, float* out, void* workspace,
-                             size_t workspace_bytes, void* stream_) {
-    if (R < 0 || C <= 0 || !out) return EQH_ERR_ARG;
+extern "C" int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
+                             int32_t accumulate, float* out, void* workspace, size_t workspace_bytes,
+                             void* stream_) {
+    if (R < 0 || C <= 0 || !out || weight_mode < 0 || weight_mode > 2) return EQH_ERR_ARG;
+    if (weight_mode != 0 && !rowptr) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (R == 0) return eqh_zero_async(out, C, stream);
+    if (R == 0) return accumulate ? EQH_OK : eqh_zero_async(out, C, stream);
     if (!x || !workspace) return EQH_ERR_ARG;
     if ((C & 3) || !eqh_aligned16(x) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
     if (workspace_bytes < hg_colsum_workspace_bytes(R, C)) return EQH_ERR_ARG;
     const int chunks = (int)((R + CS_ROWS - 1) / CS_ROWS);
     if (chunks > 65535) return EQH_ERR_RANGE;
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 63) / 64, chunks), dim3(256), 0, stream, x, R, (int)C,
-                       part);
+    hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 63) / 64, chunks), dim3(256), 0, stream, x, rowptr,
+                       (int)weight_mode, R, (int)C, part);
     EQH_CHECK_LAUNCH();
-    return eqh_reduce_slabs_async(part, chunks, C, out, stream);
+    return eqh_reduce_slabs_async(part, chunks, C, out, stream, accumulate);
 }
 
 extern "C" int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H,

@@ -398,14 +398,15 @@ extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, cons
                                           int64_t n_b_rows, const int32_t* okey, const int32_t* orowptr,
                                           const float* ds, const float* gamma, int32_t C, int32_t mean,
                                           float eps, float* dpa, float* dqb, float* dgamma,
-                                          void* workspace, size_t workspace_bytes, void* stream_) {
+                                          int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                          void* stream_) {
     int rc = check(n_a_rows, C);
     if (rc) return rc;
     rc = check(n_b_rows, C);
     if (rc) return rc;
     if (!dgamma || !gamma) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n_a_rows == 0 && n_b_rows == 0) return eqh_zero_async(dgamma, C, stream);
+    if (n_a_rows == 0 && n_b_rows == 0) return accumulate ? EQH_OK : eqh_zero_async(dgamma, C, stream);
     if (!pa || !qb || !ia || !ib || !a_rowptr || !a_perm || !b_rowptr || !b_perm || !okey || !orowptr || !ds ||
         !dpa || !dqb || !workspace)
         return EQH_ERR_ARG;
@@ -423,7 +424,7 @@ extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, cons
                            ia, ib, b_rowptr, b_perm, okey, orowptr, ds, gamma, dqb, (float*)nullptr,
                            (int)n_b_rows, (int)C, (int)mean, eps);
         EQH_CHECK_LAUNCH();
-        return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream);
+        return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream, accumulate);
     });
 }
 
@@ -453,13 +454,18 @@ extern "C" size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C)
 }
 
 extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
-                                   int64_t n_rows, int32_t C, float eps, float* dh, float* dbias_dgamma_dbeta,
-                                   void* workspace, size_t workspace_bytes, void* stream_) {
+                                   int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                                   float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
     int rc = check(n_rows, C);
     if (rc) return rc;
-    if (!dbias_dgamma_dbeta) return EQH_ERR_ARG;
+    if (!dbias || !dgamma || !dbeta) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (n_rows == 0) return eqh_zero_async(dbias_dgamma_dbeta, 3 * (int64_t)C, stream);
+    if (n_rows == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dbias, C, stream) || eqh_zero_async(dgamma, C, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(dbeta, C, stream);
+    }
     if (!h || !bias || !gamma || !dy || !dh || !workspace) return EQH_ERR_ARG;
     if (!eqh_aligned16(h) || !eqh_aligned16(dy) || !eqh_aligned16(dh) || !eqh_aligned16(workspace) ||
         !eqh_aligned16(bias) || !eqh_aligned16(gamma))
@@ -472,6 +478,6 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
         hipLaunchKernelGGL((k_rowln_bwd<NV>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
                            (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
-        return eqh_reduce_slabs_async(slab, blocks, 3 * (int64_t)C, dbias_dgamma_dbeta, stream);
+        return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, accumulate, stream);
     });
 }

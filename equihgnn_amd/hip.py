@@ -34,13 +34,15 @@ SIGNATURES = {
     "hg_incidence_ln_reduce_fwd": (c_int32, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "hg_incidence_ln_reduce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_incidence_ln_reduce_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 4
-                                   + [c_int32, c_int32, c_float] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+                                   + [c_int32, c_int32, c_float] + [c_void_p] * 3 + [c_int32, c_void_p, c_size_t,
+                                                                                    c_void_p]),
     "hg_bias_relu_ln_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "hg_bias_relu_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p,
-                                                      c_size_t, c_void_p]),
+    "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4
+                            + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hg_colsum_f32": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hg_colsum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                c_size_t, c_void_p]),
     "egnn_pack_weights_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p] * 5),
     "egnn_pack_weights_bwd": (c_int32, [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 4),
     "geo_eigh3": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -117,7 +117,16 @@ class MLP(nn.Module):
         return ops.linear(h, self.lins[-1].weight, self.lins[-1].bias)
 
 
-def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr):
+def _row_weight(out_csr, has_row, aggr, dtype):
+    """Per-row multiplier of the last Linear's bias after the reduction: 1 (mean over a non-empty row),
+    0 (empty row) or the row length (sum)."""
+    if aggr == "mean":
+        return has_row
+    return (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(dtype)[:, None]
+
+
+def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr,
+                  residual=None):
     """reduce_r( mlp(cat(a[idx_a], b[idx_b])) ) over the rows of ``out_csr`` — the
     per-incidence MLP + scatter of conv.py:90-93,96-97,175-177, restructured (module docstring).
 
@@ -138,17 +147,18 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
         # gather + gather + add + ReLU + LayerNorm + segmented reduce in ONE kernel (incidence.hip)
         s = ops.incidence_ln_reduce(pa, qb, norm.weight, norm.bias, idx_a32, idx_b32, csr_a, csr_b,
                                     out_csr, out_key32, aggr, norm.eps)
-        rows = has_row if aggr == "mean" else (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype)[:, None]
-        return torch.addcmul(ops.linear(s, last.weight), rows, last.bias)
+        if residual is not None:   # (scale, c): scale * last(s) + c, c already holds the scaled bias
+            return ops.linear_add(s, last.weight, residual[1], residual[0])
+        return torch.addcmul(ops.linear(s, last.weight), _row_weight(out_csr, has_row, aggr, s.dtype), last.bias)
     h = ops.gather_rows(pa, idx_a32, csr_a) + ops.gather_rows(qb, idx_b32, csr_b)  # [nnz, C]
     if len(mlp.lins) == 1:              # a single Linear: everything is linear in h
-        return ops.reduce_entries(h, out_csr, out_key32, aggr)
+        out = ops.reduce_entries(h, out_csr, out_key32, aggr)
+        return out if residual is None else residual[0] * out + residual[2]
     h = mlp.hidden(h, 0)
     s = ops.reduce_entries(h, out_csr, out_key32, aggr)
-    if aggr == "mean":
-        return ops.linear(s, last.weight) + last.bias * has_row
-    deg = (out_csr.rowptr[1:] - out_csr.rowptr[:-1]).to(s.dtype).unsqueeze(-1)
-    return ops.linear(s, last.weight) + last.bias * deg
+    if residual is not None:
+        return ops.linear_add(s, last.weight, residual[1], residual[0])
+    return ops.linear(s, last.weight) + last.bias * _row_weight(out_csr, has_row, aggr, s.dtype)
 
 
 class MHNNConv(nn.Module):
@@ -203,9 +213,34 @@ class MHNNSConv(nn.Module):
         for w in (self.W1, self.W2, self.W3):
             w.reset_parameters()
 
-    def forward(self, X, index: HyperIndex, X0):
+    def residual(self, X0, index: HyperIndex):
+        """The layer-independent part of conv.py:179-180's mix, built once per forward pass:
+        (1-a) * x_v + a * X0 with x_v = W2_last(s) + rows * b  ==  (1-a) * W2_last_nobias(s) + c,
+        c = a * X0 + (1-a) * rows * b.  ``c`` enters the last GEMM of W2 as its beta = 1 operand, so
+        neither the bias broadcast nor the lerp is a kernel of its own (nor are their backward passes:
+        the weights are shared, so c is the same tensor in all L applications of the layer).
+        Returns (scale, c, c without the bias) for _pair_message."""
+        a = self.alpha
+        x0a = X0 * a
+        if X0.dim() != 2:
+            return (1.0 - a, None, x0a)
+        rows = _row_weight(index.by_v, index.has_v, self.aggr, X0.dtype)
+        return (1.0 - a, torch.addcmul(x0a, rows, self.W2.lins[-1].bias, value=1.0 - a), x0a)
+
+    def prepare(self, X0, index: HyperIndex):
+        """``residual`` for forward() when the fused path applies (call once per model forward)."""
+        if X0.is_cuda and X0.dim() == 2 and len(self.W2.lins) > 1:
+            return self.residual(X0, index)
+        return None
+
+    def forward(self, X, index: HyperIndex, X0, residual=None):
         ix = index
         x_e = ops.reduce_gathered(self.W1(X), ix.by_e, ix.by_v, self.aggr)       # conv.py:172-173
+        if X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1:
+            res = residual if residual is not None else self.residual(X0, ix)
+            mixed = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
+                                  ix.has_v, self.aggr, residual=res)             # conv.py:175-180
+            return self.W3(mixed)
         x_v = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                             ix.has_v, self.aggr)                                 # conv.py:175-177
         return self.W3(torch.lerp(x_v, X0, self.alpha))      # (1-a)*x_v + a*X0, conv.py:179-180
@@ -254,7 +289,7 @@ class EGNN(nn.Module):
         # b_cat = [b1 ; 0], wd = W1[:, 2C], W2 padded (ops.egnn_pack_weights, csrc/dense_aux.hip)
         w_cat, b_cat, w_d, w2 = ops.egnn_pack_weights(lin1.weight, lin1.bias, lin2.weight, hp)
         # one node-level GEMM gives both halves: ab[:, :Hp] = W1_i f + b1 (receiver), ab[:, Hp:] = W1_j f
-        ab = F.linear(feats, w_cat, b_cat)
+        ab = ops.linear(feats, w_cat, b_cat)
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
         node_in = torch.cat((self.node_norm(feats), m_i), -1)

@@ -53,8 +53,9 @@ class EGNNEquiHNNS(nn.Module):
         if taps is not None:
             taps["front_end"] = x
         x0 = x
+        res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0)
+            x = self.conv(self.dropout(x), index, x0, res)
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
@@ -151,8 +152,9 @@ class EquiformerEquiHNNS(nn.Module):
         if taps is not None:
             taps["front_end"] = x
         x0 = x
+        res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0)
+            x = self.conv(self.dropout(x), index, x0, res)
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
@@ -253,8 +255,9 @@ class MHNNS(nn.Module):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         x0 = x
+        res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0)
+            x = self.conv(self.dropout(x), index, x0, res)
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
@@ -328,8 +331,9 @@ class FAFormerEquiHNNS(nn.Module):
         if taps is not None:
             taps["front_end"] = x
         x0 = x
+        res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0)
+            x = self.conv(self.dropout(x), index, x0, res)
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)

@@ -230,7 +230,8 @@ class _IncidenceLnReduce(torch.autograd.Function):
     gather, gather, add, ReLU, LayerNorm, segmented reduce (csrc/incidence.hip)."""
 
     @staticmethod
-    def forward(ctx, pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR, out_csr: CSR, okey32, mean, eps):
+    def forward(ctx, pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR, out_csr: CSR, okey32, mean, eps,
+                acc_params):
         _require_gpu(pa, "incidence_ln_reduce")
         pa, qb, gamma, beta = _f32c(pa), _f32c(qb), _f32c(gamma), _f32c(beta)
         C = pa.shape[1]
@@ -241,6 +242,7 @@ class _IncidenceLnReduce(torch.autograd.Function):
             "hg_incidence_ln_reduce_fwd")
         ctx.save_for_backward(pa, qb, gamma)
         ctx.meta = (ia32, ib32, csr_a, csr_b, out_csr, okey32, mean, eps)
+        ctx.acc = acc_params
         return out
 
     @staticmethod
@@ -250,19 +252,20 @@ class _IncidenceLnReduce(torch.autograd.Function):
         ds = _f32c(ds)
         C = pa.shape[1]
         dev = pa.device
-        dpa, dqb, dgamma = torch.empty_like(pa), torch.empty_like(qb), torch.empty_like(gamma)
+        dpa, dqb = torch.empty_like(pa), torch.empty_like(qb)
+        g_acc, b_acc = (_acc_target(p) for p in ctx.acc)
+        dgamma = g_acc if g_acc is not None else torch.empty_like(gamma)
         L = hip.lib()
         ws_bytes = L.hg_incidence_ln_reduce_bwd_workspace_bytes(csr_a.n_rows, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         hip.check(L.hg_incidence_ln_reduce_bwd(
             _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(csr_a.rowptr), _ptr(csr_a.perm), csr_a.n_rows,
             _ptr(csr_b.rowptr), _ptr(csr_b.perm), csr_b.n_rows, _ptr(okey32), _ptr(out_csr.rowptr), _ptr(ds),
-            _ptr(gamma), C, 1 if mean else 0, float(eps), _ptr(dpa), _ptr(dqb), _ptr(dgamma), _ptr(ws), ws_bytes,
-            _stream(dev)), "hg_incidence_ln_reduce_bwd")
-        deg = out_csr.rowptr[1:] - out_csr.rowptr[:-1]
-        wrow = (deg > 0).to(ds.dtype) if mean else deg.to(ds.dtype)
-        dbeta = (ds * wrow[:, None]).sum(0)
-        return dpa, dqb, dgamma, dbeta, None, None, None, None, None, None, None, None
+            _ptr(gamma), C, 1 if mean else 0, float(eps), _ptr(dpa), _ptr(dqb), _ptr(dgamma),
+            1 if g_acc is not None else 0, _ptr(ws), ws_bytes, _stream(dev)), "hg_incidence_ln_reduce_bwd")
+        # d beta = sum_r w_r ds[r], w_r = [row non-empty] (mean) or the row length (sum)
+        dbeta = colsum(ds, out_csr.rowptr, 1 if mean else 2, into=b_acc)
+        return (dpa, dqb, None if g_acc is not None else dgamma, dbeta) + (None,) * 9
 
 
 class _BiasReluLn(torch.autograd.Function):
@@ -270,7 +273,7 @@ class _BiasReluLn(torch.autograd.Function):
     same pass, the bias / gamma / beta gradients (csrc/incidence.hip)."""
 
     @staticmethod
-    def forward(ctx, h, bias, gamma, beta, eps):
+    def forward(ctx, h, bias, gamma, beta, eps, acc_params):
         _require_gpu(h, "bias_relu_ln")
         h, bias, gamma, beta = _f32c(h), _f32c(bias), _f32c(gamma), _f32c(beta)
         R, C = h.shape
@@ -279,6 +282,7 @@ class _BiasReluLn(torch.autograd.Function):
                                                 _ptr(out), _stream(h.device)), "hg_bias_relu_ln_fwd")
         ctx.save_for_backward(h, bias, gamma)
         ctx.eps = eps
+        ctx.acc = acc_params  # the Parameter objects (their accumulators are looked up at backward time)
         return out
 
     @staticmethod
@@ -287,13 +291,20 @@ class _BiasReluLn(torch.autograd.Function):
         dy = _f32c(dy)
         R, C = h.shape
         dh = torch.empty_like(h)
-        small = torch.empty((3, C), dtype=torch.float32, device=h.device)
         L = hip.lib()
         ws_bytes = L.hg_bias_relu_ln_bwd_workspace_bytes(R, C)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device)
+        tg = [_acc_target(p) for p in ctx.acc]
+        if all(t is not None for t in tg):   # all three accumulate in place: nothing for autograd to add
+            hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps),
+                                            _ptr(dh), _ptr(tg[0]), _ptr(tg[1]), _ptr(tg[2]), 1, _ptr(ws), ws_bytes,
+                                            _stream(h.device)), "hg_bias_relu_ln_bwd")
+            return dh, None, None, None, None, None
+        small = torch.empty((3, C), dtype=torch.float32, device=h.device)
         hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
-                                        _ptr(small), _ptr(ws), ws_bytes, _stream(h.device)), "hg_bias_relu_ln_bwd")
-        return dh, small[0], small[1], small[2], None
+                                        _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), 0, _ptr(ws), ws_bytes,
+                                        _stream(h.device)), "hg_bias_relu_ln_bwd")
+        return dh, small[0], small[1], small[2], None, None
 
 
 WGRAD_ON_SIDE_STREAM = False
@@ -312,18 +323,43 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-def colsum(x):
-    """x.sum(0) for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients)."""
+def _acc_target(param):
+    """The persistent gradient accumulator of a parameter (set by the graphed trainer), or None."""
+    return getattr(param, "_eqh_gbuf", None) if param is not None else None
+
+
+def _note_acc(*params):
+    """Remember 1-D parameters whose gradient the kernels can accumulate in place."""
+    if torch.is_grad_enabled():
+        for p in params:
+            if p is not None and p.requires_grad and p.is_leaf:
+                ACC_PARAMS[id(p)] = p
+
+
+def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
+    """sum_r w_r x[r, :] for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients).  ``rowptr`` +
+    ``weight_mode`` (1: [row non-empty], 2: row length) give the row weights; ``into`` is an accumulator
+    the result is ADDED to (returns None then)."""
     if not x.is_cuda or x.shape[-1] % 4 or x.dtype != torch.float32:
-        return x.sum(0)
-    x = x.contiguous()
+        # widths the float4 kernel does not take (the 1-wide output head): the device's generic reduction
+        if weight_mode:
+            deg = rowptr[1:] - rowptr[:-1]
+            x = x * ((deg > 0) if weight_mode == 1 else deg).to(x.dtype)[:, None]
+        r = x.sum(0)
+        if into is None:
+            return r
+        into.add_(r)
+        return None
+    x = _f32c(x)
     R, C = x.shape
-    out = torch.empty(C, dtype=torch.float32, device=x.device)
     L = hip.lib()
+    out = into if into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws_bytes = L.hg_colsum_workspace_bytes(R, C)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    hip.check(L.hg_colsum_f32(_ptr(x), R, C, _ptr(out), _ptr(ws), ws_bytes, _stream(x.device)), "hg_colsum_f32")
-    return out
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    hip.check(L.hg_colsum_f32(_ptr(x), _ptr(rowptr) if rowptr is not None else None, weight_mode, R, C,
+                              1 if into is not None else 0, _ptr(out), _ptr(ws), ws_bytes, _stream(x.device)),
+              "hg_colsum_f32")
+    return None if into is not None else out
 
 
 class _EgnnPackWeights(torch.autograd.Function):
@@ -366,6 +402,7 @@ def egnn_pack_weights(w1, b1, w2, Hp):
 # parameters seen by ops.linear since the last reset (the trainer decides which of them get a
 # persistent gradient accumulator, see trainer.GradBuffers)
 LINEAR_PARAMS = {}
+ACC_PARAMS = {}   # 1-D parameters (biases, LayerNorm gamma / beta) used through the fused kernels
 
 
 class _Linear(torch.autograd.Function):
@@ -381,6 +418,7 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.cols = (c0, c1)
         ctx.has_bias = bias is not None
+        ctx.bias_param = bias
         return F.linear(x, w, bias)
 
     @staticmethod
@@ -412,8 +450,36 @@ class _Linear(torch.autograd.Function):
             else:
                 dw = torch.zeros_like(weight)
                 dw[:, c0:c1] = dy2.t() @ x2
-        db = colsum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2, into=_acc_target(ctx.bias_param))   # None when accumulated in place
         return dx, dw, db, None, None
+
+
+class _LinearAddC(torch.autograd.Function):
+    """y = scale * (x @ W.T) + c in ONE GEMM launch (beta = 1 epilogue); ``c`` carries whatever is
+    added after the Linear (residual mix, row-masked bias).  Weight gradient as in _Linear; the two
+    backward GEMMs take ``scale`` as their alpha, so no scaling kernel runs either way."""
+
+    @staticmethod
+    def forward(ctx, x, weight, c, scale):
+        ctx.save_for_backward(x, weight)
+        ctx.scale = float(scale)
+        return torch.addmm(c, x, weight.t(), beta=1.0, alpha=ctx.scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        a = ctx.scale
+        dx = torch.addmm(x, dy, weight, beta=0.0, alpha=a) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            gbuf = getattr(weight, "_eqh_gbuf", None)
+            if gbuf is not None:
+                gbuf.addmm_(dy.t(), x, alpha=a)
+            else:
+                dw = torch.addmm(weight, dy.t(), x, beta=0.0, alpha=a)
+        return dx, dw, (dy if ctx.needs_input_grad[2] else None), None
 
 
 class _RowGemm(torch.autograd.Function):
@@ -454,22 +520,32 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
                         reduce: str = "mean", eps: float = 1e-5):
     """reduce_{p in out row} LayerNorm(relu(pa[ia[p]] + qb[ib[p]])); csr_a / csr_b are the incidence
     CSRs keyed by ia / ib (needed by the backward), out_csr the one keyed by okey32."""
+    _note_acc(gamma, beta)
     return _IncidenceLnReduce.apply(pa, qb, gamma, beta, ia32, ib32, csr_a, csr_b, out_csr, okey32,
-                                    reduce == "mean", eps)
+                                    reduce == "mean", eps, (gamma, beta))
 
 
 def linear(x, weight, bias=None, cols=None):
     """F.linear(x, weight[:, cols[0]:cols[1]], bias) through _Linear (``weight`` is the PARAMETER,
     not a slice of it, so that its gradient accumulator can be found)."""
-    if torch.is_grad_enabled() and weight.requires_grad:
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
         LINEAR_PARAMS[id(weight)] = weight
+    _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
     return _Linear.apply(x, weight, bias, c0, c1)
 
 
+def linear_add(x, weight, c, scale: float = 1.0):
+    """scale * F.linear(x, weight) + c with the addition done by the GEMM epilogue (2-D x, c)."""
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
+        LINEAR_PARAMS[id(weight)] = weight
+    return _LinearAddC.apply(x, weight, c, scale)
+
+
 def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
     """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C]."""
-    return _BiasReluLn.apply(h, bias, gamma, beta, eps)
+    _note_acc(bias, gamma, beta)
+    return _BiasReluLn.apply(h, bias, gamma, beta, eps, (bias, gamma, beta))
 
 
 def eigh3(cov):

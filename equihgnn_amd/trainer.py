@@ -167,11 +167,14 @@ class GraphedTrainStep:
             torch._foreach_copy_(self.other_slots, [p.grad for p in self.others])
 
     def _setup_grad_buffers(self, data, live):
-        """Give every weight that is used ONLY through ops.linear a persistent gradient accumulator
-        (the head of one flat buffer, zeroed by a single fill per step); a probe pass drops any
-        parameter that autograd still produces a gradient for (i.e. that is also used some other way)."""
+        """Give every weight that is used ONLY through ops.linear, and every bias / LayerNorm vector used
+        ONLY through the fused kernels, a persistent gradient accumulator (the head of one flat buffer,
+        zeroed by a single fill per step): the kernels add into it, so a layer applied L times costs no
+        autograd add kernels.  A probe pass drops any parameter that autograd still produces a gradient
+        for (i.e. that is also used some other way)."""
         from . import ops
-        cand = [p for p in live if id(p) in ops.LINEAR_PARAMS and p.dim() == 2]
+        cand = [p for p in live if (id(p) in ops.LINEAR_PARAMS and p.dim() == 2)
+                or (id(p) in ops.ACC_PARAMS and p.dim() == 1)]
         dev, dt = live[0].device, live[0].dtype
         if cand:
             probe = torch.zeros(sum(p.numel() for p in cand), dtype=dt, device=dev)
@@ -218,6 +221,7 @@ class GraphedTrainStep:
         library and of the GEMM libraries before anything is captured)."""
         from . import ops
         ops.LINEAR_PARAMS.clear()
+        ops.ACC_PARAMS.clear()
         self.gflat = None
         loss = self._fwd_bwd(data)
         self.live = [p for p in self.model.parameters() if p.grad is not None]

@@ -153,8 +153,9 @@ int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int3
  * indices (int32) into pa/qb.  C <= 1024, multiple of 4.
  * bwd: (a_rowptr,a_perm) / (b_rowptr,b_perm) are the CSRs of the incidences keyed by ia / ib;
  * okey[p] is the output row of incidence p and orowptr the forward rowptr.  Produces dpa
- * [n_a_rows,C], dqb [n_b_rows,C] and dgamma [C]; (d beta is a column sum of ds and is left to
- * the caller).  Recomputes the LayerNorm statistics; nothing is saved by the forward.
+ * [n_a_rows,C], dqb [n_b_rows,C] and dgamma [C] (added to dgamma if accumulate != 0: a layer applied
+ * L times per step sums its parameter gradients in place); d beta is a row-weighted column sum of ds
+ * (hg_colsum_f32 with orowptr).  Recomputes the LayerNorm statistics; nothing is saved by the forward.
  * ------------------------------------------------------------------------------------------- */
 int hg_incidence_ln_reduce_fwd(const float* pa, const float* qb, const int32_t* ia, const int32_t* ib,
                                const int32_t* rowptr, const int32_t* perm, const float* gamma,
@@ -166,21 +167,23 @@ int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, const int32_t* 
                                const int32_t* b_rowptr, const int32_t* b_perm, int64_t n_b_rows,
                                const int32_t* okey, const int32_t* orowptr, const float* ds,
                                const float* gamma, int32_t C, int32_t mean, float eps, float* dpa,
-                               float* dqb, float* dgamma, void* workspace, size_t workspace_bytes,
-                               void* stream);
+                               float* dqb, float* dgamma, int32_t accumulate, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense-row hidden layer of mlp.py:91-99: out = LayerNorm(relu(h + bias)) with h = x W^T computed
  * by a bias-free library GEMM.  bwd: dh = d relu . d LayerNorm (recomputed statistics) and, from
- * the same pass, [dbias | dgamma | dbeta] (3*C floats; dbias = column sums of dh is the bias
- * gradient of the preceding Linear).  C <= 1024, multiple of 4.
+ * the same pass, dbias, dgamma, dbeta (C floats each, three separate destinations; dbias = column
+ * sums of dh is the bias gradient of the preceding Linear), overwritten or, with accumulate != 0,
+ * added to.  C <= 1024, multiple of 4.
  * ------------------------------------------------------------------------------------------- */
 int hg_bias_relu_ln_fwd(const float* h, const float* bias, const float* gamma, const float* beta,
                         int64_t n_rows, int32_t C, float eps, float* out, void* stream);
 size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C);
 int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
-                        int64_t n_rows, int32_t C, float eps, float* dh, float* dbias_dgamma_dbeta,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                        float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
@@ -191,16 +194,18 @@ int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense helpers around the library GEMMs.
- * hg_colsum_f32: out[c] = sum_r x[r,c] — the bias gradient of an nn.Linear (autograd's
- *   grad_output.sum(0)); two passes, fixed order.
+ * hg_colsum_f32: out[c] (+)= sum_r w_r x[r,c] — the bias gradient of an nn.Linear (autograd's
+ *   grad_output.sum(0)); two passes, fixed order.  weight_mode 0: w_r = 1 (rowptr may be NULL);
+ *   1: w_r = [row r of the CSR rowptr is non-empty]; 2: w_r = length of row r (the bias of a Linear
+ *   applied before a mean / sum over incidences, conv.py:91-97,175-177).  accumulate != 0 adds to out.
  * egnn_pack_weights_fwd/bwd: layout change of the EGNN edge-MLP weights (egnn_layer.py:180-186) into
  *   what egnn_edge_fwd consumes: w1 [H, 2C+1], b1 [H], w2 [16, H]  ->  w_cat [2*Hp, C]
  *   (= [w1[:, :C] ; w1[:, C:2C]], zero rows from H to Hp), b_cat [2*Hp] (= [b1 ; 0]),
  *   wd [Hp] (= w1[:, 2C]), w2p [16, Hp]; bwd is the exact adjoint.
  * ------------------------------------------------------------------------------------------- */
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
-int hg_colsum_f32(const float* x, int64_t R, int32_t C, float* out, void* workspace,
-                  size_t workspace_bytes, void* stream);
+int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
+                  int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);
 int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hp,
                           int32_t C, float* w_cat, float* b_cat, float* wd, float* w2p, void* stream);
 int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd, const float* dw2p,

@@ -321,6 +321,46 @@ def test_colsum_matches_float64(R, C):
     ref = x.double().sum(0)
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6 * max(R, 1) ** 0.5 * 4)
     assert torch.equal(out, ops.colsum(x))
+    if R == 0:
+        return
+    # row weights from a CSR rowptr ([row non-empty] / row length) and in-place accumulation
+    lens = torch.randint(0, 4, (R,), generator=torch.Generator().manual_seed(1))
+    rowptr = torch.cat((torch.zeros(1, dtype=torch.int64), lens.cumsum(0))).int().to(DEV)
+    for mode, w in ((1, (lens > 0).double()), (2, lens.double())):
+        got = ops.colsum(x, rowptr, mode)
+        want = (x.double() * w.to(DEV)[:, None]).sum(0)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=0, atol=2e-5 * max(R, 1) ** 0.5)
+    acc = torch.full((C,), 3.0, device=DEV)
+    assert ops.colsum(x, into=acc) is None
+    np.testing.assert_allclose(acc.cpu().numpy(), (ref + 3.0).cpu().numpy(), rtol=0, atol=2e-6 * max(R, 1) ** 0.5 * 4)
+
+
+def test_fused_ops_accumulate_into_parameter_buffers():
+    """With a persistent accumulator on the parameters (what the graphed trainer installs), two uses of
+    the same bias / LayerNorm vectors add their gradients in place and hand autograd nothing."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    C, R = 64, 300
+    mk = lambda *sh: torch.randn(*sh, generator=g).to(DEV).requires_grad_(True)
+    bias, gamma, beta, lb = mk(C), mk(C), mk(C), mk(C)
+    w = mk(C, C)
+    h1, h2 = mk(R, C), mk(R, C)
+
+    def run():
+        y = ops.bias_relu_ln(h1, bias, gamma, beta) + ops.bias_relu_ln(h2, bias, gamma, beta)
+        z = ops.linear(y, w, lb) + ops.linear(h1, w, lb)
+        (z * z).sum().backward()
+
+    run()
+    want = [p.grad.clone() for p in (bias, gamma, beta, lb, w)]
+    for p in (bias, gamma, beta, lb, w, h1, h2):
+        p.grad = None
+    for p in (bias, gamma, beta, lb, w):
+        p._eqh_gbuf = torch.zeros_like(p)
+    run()
+    for p, ref in zip((bias, gamma, beta, lb, w), want):
+        assert p.grad is None
+        np.testing.assert_allclose(p._eqh_gbuf.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-4)
 
 
 @pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3)])

@@ -95,7 +95,7 @@ def main():
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     add("hg_incidence_ln_reduce_bwd (both sides)", timed(lambda: L.hg_incidence_ln_reduce_bwd(
         p(X), p(E), p(ix.v32), p(ix.e32), p(ix.by_v.rowptr), p(ix.by_v.perm), N, p(ix.by_e.rowptr), p(ix.by_e.perm), M,
-        p(ix.v32), p(ix.by_v.rowptr), p(S), p(gamma), C, 1, 1e-5, p(dpa), p(dqb), p(dg), p(ws), wsb, st)),
+        p(ix.v32), p(ix.by_v.rowptr), p(S), p(gamma), C, 1, 1e-5, p(dpa), p(dqb), p(dg), 0, p(ws), wsb, st)),
         nbytes=2 * (4 * C * 3 * nnz) + 4 * C * (N + M) + 32 * nnz)
     out = torch.empty_like(X)
     add("hg_bias_relu_ln_fwd", timed(lambda: L.hg_bias_relu_ln_fwd(p(X), p(beta), p(gamma), p(beta), N, C, 1e-5, p(out), st)),
@@ -104,10 +104,11 @@ def main():
     wsb2 = L.hg_bias_relu_ln_bwd_workspace_bytes(N, C)
     ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
     add("hg_bias_relu_ln_bwd", timed(lambda: L.hg_bias_relu_ln_bwd(p(X), p(beta), p(gamma), p(S), N, C, 1e-5, p(out), p(small),
-                                                                     p(ws2), wsb2, st)), nbytes=12 * C * N)
+                                                                     p(small[C:]), p(small[2 * C:]), 0, p(ws2), wsb2, st)),
+        nbytes=12 * C * N)
     wsb3 = L.hg_colsum_workspace_bytes(N, C)
     ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
-    add("hg_colsum_f32", timed(lambda: L.hg_colsum_f32(p(X), N, C, p(dg), p(ws3), wsb3, st)), nbytes=4 * C * N)
+    add("hg_colsum_f32", timed(lambda: L.hg_colsum_f32(p(X), None, 0, N, C, 0, p(dg), p(ws3), wsb3, st)), nbytes=4 * C * N)
     xi = torch.stack([torch.randint(0, d, (N,), device=dev, generator=g) for d in (119, 5, 12, 12, 10, 6, 6, 2, 2)], 1)
     table = torch.randn(174, C, device=dev, generator=g)
     offs = (0, 119, 124, 136, 148, 158, 164, 170, 172)
