@@ -46,12 +46,12 @@ static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
 // partial sums and issues eight loads before the first add (the loop is latency-, not bandwidth-bound:
 // the typical call reduces 100-300 slabs of a few hundred floats), and the groups are combined through
 // LDS in group order.
-// Output: up to three segments of seg_len elements each (out0 | out1 | out2; out1 == nullptr means one
-// contiguous run of `elems`), overwritten or, with accumulate != 0, added to (gradient accumulators of
+// Output: up to three segments (out0: elements [0, len0), out1: the next len1, out2: the rest; out1 ==
+// nullptr means one contiguous run of `elems`), overwritten or, with accumulate != 0, added to (gradient accumulators of
 // parameters that are used several times per step).
 static __global__ void __launch_bounds__(1024)
 eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out0,
-                   float* __restrict__ out1, float* __restrict__ out2, int64_t seg_len, int accumulate) {
+                   float* __restrict__ out1, float* __restrict__ out2, int64_t len0, int64_t len1, int accumulate) {
     __shared__ float s_part[1024];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < elems; e0 += (int64_t)gridDim.x * 64) {
@@ -82,19 +82,20 @@ eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, f
 #pragma unroll
             for (int g = 1; g < 16; ++g) t += s_part[64 * g + col];
             float* dst = out0 + e;
-            if (out1 != nullptr && e >= seg_len) dst = (e < 2 * seg_len) ? out1 + (e - seg_len) : out2 + (e - 2 * seg_len);
+            if (out1 != nullptr && e >= len0) dst = (e < len0 + len1) ? out1 + (e - len0) : out2 + (e - len0 - len1);
             *dst = accumulate ? *dst + t : t;
         }
         __syncthreads();
     }
 }
 static inline int eqh_reduce_slabs3_async(const float* slab, int n_slabs, int64_t elems, float* out0, float* out1,
-                                          float* out2, int64_t seg_len, int accumulate, hipStream_t stream) {
+                                          float* out2, int64_t len0, int64_t len1, int accumulate,
+                                          hipStream_t stream) {
     hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(1024), 0, stream, slab,
-                       n_slabs, elems, out0, out1, out2, seg_len, accumulate);
+                       n_slabs, elems, out0, out1, out2, len0, len1, accumulate);
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
 }
 static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,
                                          hipStream_t stream, int accumulate = 0) {
-    return eqh_reduce_slabs3_async(slab, n_slabs, elems, out, nullptr, nullptr, elems, accumulate, stream);
+    return eqh_reduce_slabs3_async(slab, n_slabs, elems, out, nullptr, nullptr, elems, 0, accumulate, stream);
 }

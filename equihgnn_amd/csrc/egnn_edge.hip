@@ -35,8 +35,6 @@ constexpr int KNB = 16;    // neighbours per node
 constexpr int MDIM = 16;   // m_dim
 constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / 64;
-constexpr int BWD_CHUNK = 16;  // nodes per workgroup in backward pass 1
-constexpr int PLD = 20;        // LDS row stride (floats) of the 16x16 dpre2 tiles: 16 + 4 pad
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -267,30 +265,43 @@ k_edge_fwd(const float* __restrict__ ab, const float* __restrict__ wd, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 1: by receiver node.  One workgroup owns BWD_CHUNK consecutive nodes; wave w owns
-// the hidden tiles t = w, w+4, ... (16 hidden units each) for ALL nodes of the chunk, so its dW2 /
-// dwd tile accumulators stay in registers across the chunk and need no cross-wave reduction.
+// backward.  Three kernels, no atomics:
+//   prep : dpre2 = dm * silu'(pre2), stored twice ([n][j][o] and [n][o][j]: the two MFMA operand orders)
+//   recv : by receiver i  -> dA (= dab[:, :Hp]), per-chunk partial slabs of dW2 and dwd
+//   send : by sender j, over the transposed neighbour CSR -> dB (= dab[:, Hp:])
+// Both main kernels recompute h = A_i + B_j + wd d2_ij and silu'(h) (the forward saves no per-edge
+// tensor) and use the same decomposition: grid = (64-unit hidden tile) x (chunk of nodes / senders),
+// 4 wavefronts per workgroup, every wavefront walking its share of the chunk for ONE hidden tile.  All
+// wavefronts of the launch have the same amount of work whatever Hp / 64 is (the earlier version gave a
+// wavefront all nodes of a 16-node chunk for hidden tiles w, w+4, ...: 17 tiles over 4 wavefronts and
+// 288 workgroups over 256 CUs lost ~45% to quantisation), and the chunk count is chosen so that the
+// whole grid is resident at once (4 workgroups per CU).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(THREADS)
-k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd,
-                const float* __restrict__ w2, const int* __restrict__ nbr,
-                const float* __restrict__ d2, const float* __restrict__ pre2,
-                const float* __restrict__ dm, float* __restrict__ dpre2_out,
-                float* __restrict__ dab, float* __restrict__ slab_w2, float* __restrict__ slab_wd,
-                int N, int Hp) {
-    __shared__ __attribute__((aligned(16))) float s_p[BWD_CHUNK][KNB * PLD];   // dpre2[n][j][o]
-    __shared__ __attribute__((aligned(16))) float s_pt[BWD_CHUNK][MDIM * PLD];  // dpre2[n][o][j]
-    __shared__ int s_nbr[BWD_CHUNK][KNB];
-    __shared__ float s_d2[BWD_CHUNK][KNB];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, q = lane >> 4;
-    const int base = blockIdx.x * BWD_CHUNK;
-    const int cnt = (N - base < BWD_CHUNK) ? (N - base) : BWD_CHUNK;
+constexpr int BW_RESIDENT = 768;  // 256 CUs x 3 workgroups of 4 wavefronts (129..168 VGPRs per lane)
 
-    // phase A: dpre2 = dm * silu'(pre2), one float4 (4 consecutive o of one j) per lane
-    for (int n = wave; n < cnt; n += WAVES) {
-        const int node = base + n;
-        const int jj = lane >> 2, o0 = (lane & 3) * 4;
+__host__ __device__ inline int bw_chunks(int64_t n_items, int tiles) {
+    int64_t c = BW_RESIDENT / tiles;
+    if (c < 1) c = 1;
+    const int64_t most = (n_items + WAVES - 1) / WAVES;  // at least one item per wavefront
+    if (c > most) c = most;
+    return (int)(c < 1 ? 1 : c);
+}
+
+__global__ void __launch_bounds__(THREADS)
+k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, float* __restrict__ dpre2,
+                float* __restrict__ dpre2_t, const int* __restrict__ t_perm, const int* __restrict__ nbr,
+                const float* __restrict__ d2, int4* __restrict__ rec, int N) {
+    // records for the sender pass: one 16-byte record per position p of the transposed CSR, (entry
+    // e = i*16 + slot, sender j = nbr[e], d2[e], -), so that its pipeline has no dependent load chain
+    // (t_perm -> nbr / d2) in front of the row gathers
+    const int64_t E = (int64_t)N * KNB;
+    for (int64_t p = (int64_t)blockIdx.x * THREADS + threadIdx.x; p < E; p += (int64_t)gridDim.x * THREADS) {
+        const int e = t_perm[p];
+        rec[p] = make_int4(e, nbr[e], __float_as_int(d2[e]), 0);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
+        const int jj = lane >> 2, o0 = (lane & 3) * 4;  // one float4 (4 consecutive o of one j) per lane
         const float4 p4 = *reinterpret_cast<const float4*>(pre2 + (int64_t)node * 256 + lane * 4);
         const float4 g4 = *reinterpret_cast<const float4*>(dm + (int64_t)node * MDIM + o0);
         float ds;
@@ -299,186 +310,292 @@ k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd,
         silu_grad(p4.y, &ds); d4.y = g4.y * ds;
         silu_grad(p4.z, &ds); d4.z = g4.z * ds;
         silu_grad(p4.w, &ds); d4.w = g4.w * ds;
-        *reinterpret_cast<float4*>(&s_p[n][jj * PLD + o0]) = d4;
-        s_pt[n][(o0 + 0) * PLD + jj] = d4.x;
-        s_pt[n][(o0 + 1) * PLD + jj] = d4.y;
-        s_pt[n][(o0 + 2) * PLD + jj] = d4.z;
-        s_pt[n][(o0 + 3) * PLD + jj] = d4.w;
-        *reinterpret_cast<float4*>(dpre2_out + (int64_t)node * 256 + lane * 4) = d4;
-        if (lane < KNB) {
-            s_nbr[n][lane] = nbr[node * KNB + lane];
-            s_d2[n][lane] = d2[node * KNB + lane];
+        *reinterpret_cast<float4*>(dpre2 + (int64_t)node * 256 + lane * 4) = d4;
+        float* __restrict__ t = dpre2_t + (int64_t)node * 256 + jj;
+        t[(o0 + 0) * KNB] = d4.x;
+        t[(o0 + 1) * KNB] = d4.y;
+        t[(o0 + 2) * KNB] = d4.z;
+        t[(o0 + 3) * KNB] = d4.w;
+    }
+}
+
+// Per-node operands of the receiver pass, as named scalars (see the forward: no arrays across branches).
+struct RecvOps {
+    float4 pa;   // dpre2[node][j = r][o = 4q .. 4q+3]
+    float4 pt;   // dpre2[node][j = 4q .. 4q+3][o = r]   (from the transposed copy)
+    float4 a;    // A_i[k4 .. k4+3]
+    float4 dd;   // d2[node][4q .. 4q+3]
+    float4 b0, b1, b2, b3;  // B_j[k4 .. k4+3] for the neighbours j = nbr[node][4q + g]
+};
+
+__device__ __forceinline__ void recv_load(RecvOps& o, const float* __restrict__ ab, const float* __restrict__ d2,
+                                          const float* __restrict__ dpre2, const float* __restrict__ dpre2_t,
+                                          int node, int4 nb, int Hp, int k4, int r, int q) {
+    o.pa = *reinterpret_cast<const float4*>(dpre2 + (int64_t)node * 256 + r * MDIM + 4 * q);
+    o.pt = *reinterpret_cast<const float4*>(dpre2_t + (int64_t)node * 256 + r * KNB + 4 * q);
+    o.a = *reinterpret_cast<const float4*>(ab + (int64_t)node * 2 * Hp + k4);
+    o.dd = *reinterpret_cast<const float4*>(d2 + (int64_t)node * KNB + 4 * q);
+    o.b0 = *reinterpret_cast<const float4*>(ab + (int64_t)nb.x * 2 * Hp + Hp + k4);
+    o.b1 = *reinterpret_cast<const float4*>(ab + (int64_t)nb.y * 2 * Hp + Hp + k4);
+    o.b2 = *reinterpret_cast<const float4*>(ab + (int64_t)nb.z * 2 * Hp + Hp + k4);
+    o.b3 = *reinterpret_cast<const float4*>(ab + (int64_t)nb.w * 2 * Hp + Hp + k4);
+}
+
+// One hidden unit column c (of the lane's four) of one node: the four edges g = 0..3 of this lane.
+// Returns sum_g dh, accumulates dwd, and feeds dW2[o][k4 + c] += sum_j dpre2[j][o] * silu(h[j][k4 + c]).
+__device__ __forceinline__ float recv_column(float a, float wdc, const float4& dd, float b0, float b1, float b2,
+                                             float b3, const f32x4& gk, const float4& pt, float& acc_wd,
+                                             f32x4& acc_w) {
+    float ds0, ds1, ds2, ds3;
+    const float s0 = silu_grad(fmaf(wdc, dd.x, a + b0), &ds0);
+    const float s1 = silu_grad(fmaf(wdc, dd.y, a + b1), &ds1);
+    const float s2 = silu_grad(fmaf(wdc, dd.z, a + b2), &ds2);
+    const float s3 = silu_grad(fmaf(wdc, dd.w, a + b3), &ds3);
+    const float dh0 = gk[0] * ds0, dh1 = gk[1] * ds1, dh2 = gk[2] * ds2, dh3 = gk[3] * ds3;
+    acc_wd = fmaf(dh0, dd.x, acc_wd);
+    acc_wd = fmaf(dh1, dd.y, acc_wd);
+    acc_wd = fmaf(dh2, dd.z, acc_wd);
+    acc_wd = fmaf(dh3, dd.w, acc_wd);
+    acc_w = mfma16(pt.x, s0, acc_w);
+    acc_w = mfma16(pt.y, s1, acc_w);
+    acc_w = mfma16(pt.z, s2, acc_w);
+    acc_w = mfma16(pt.w, s3, acc_w);
+    return (dh0 + dh1) + (dh2 + dh3);
+}
+
+__global__ void __launch_bounds__(THREADS)
+k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
+                const int* __restrict__ nbr, const float* __restrict__ d2, const float* __restrict__ dpre2,
+                const float* __restrict__ dpre2_t, float* __restrict__ dab, float* __restrict__ slab_w2,
+                float* __restrict__ slab_wd, int N, int Hp, int tiles, int chunk_nodes) {
+    __shared__ __attribute__((aligned(16))) float s_red[WAVES - 1][64 * 20];  // 16 dW2 + 4 dwd floats per lane
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int T = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const int base = chunk * chunk_nodes;
+    const int cnt = (N - base < chunk_nodes) ? (N - base) : chunk_nodes;
+    // lane (r, q) owns the FOUR consecutive hidden units k4 .. k4+3, k4 = 64 T + 4 r (column n = r of MFMA
+    // tile c is unit k4 + c), so every operand is one float4 and a quarter-wavefront reads 256 contiguous bytes
+    const int k4 = 64 * T + 4 * r;
+    const float4 w0 = *reinterpret_cast<const float4*>(w2 + (4 * q + 0) * Hp + k4);
+    const float4 w1 = *reinterpret_cast<const float4*>(w2 + (4 * q + 1) * Hp + k4);
+    const float4 w2v = *reinterpret_cast<const float4*>(w2 + (4 * q + 2) * Hp + k4);
+    const float4 w3 = *reinterpret_cast<const float4*>(w2 + (4 * q + 3) * Hp + k4);
+    const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
+    f32x4 aw0 = {0.f, 0.f, 0.f, 0.f}, aw1 = aw0, aw2 = aw0, aw3 = aw0;  // aw_c[g] = dW2[o = 4q+g][k4 + c]
+    float ad0 = 0.f, ad1 = 0.f, ad2 = 0.f, ad3 = 0.f;                   // dwd[k4 + c], this lane's edges
+    // software pipeline over this wavefront's nodes n = wave, wave + 4, ...: operands of node n+1 and the
+    // neighbour list of node n+2 are in flight while node n is computed
+    const int last = cnt - 1;
+    int n = wave;
+    if (n < cnt) {
+        const int4* __restrict__ nbr4 = reinterpret_cast<const int4*>(nbr);
+        auto clampn = [&](int x) { return base + (x < last ? x : last); };
+        int4 nb_next = nbr4[(int64_t)clampn(n) * 4 + q];
+        RecvOps nx;
+        recv_load(nx, ab, d2, dpre2, dpre2_t, clampn(n), nb_next, Hp, k4, r, q);
+        nb_next = nbr4[(int64_t)clampn(n + WAVES) * 4 + q];
+        for (; n < cnt; n += WAVES) {
+            const RecvOps cur = nx;
+            const int node = base + n;
+            recv_load(nx, ab, d2, dpre2, dpre2_t, clampn(n + WAVES), nb_next, Hp, k4, r, q);
+            nb_next = nbr4[(int64_t)clampn(n + 2 * WAVES) * 4 + q];
+            __builtin_amdgcn_sched_barrier(0);
+            // gk_c[g] = sum_o dpre2[j = 4q+g][o] * W2[o][k4 + c]
+            f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+            g0 = mfma16(cur.pa.x, w0.x, g0); g1 = mfma16(cur.pa.x, w0.y, g1);
+            g2 = mfma16(cur.pa.x, w0.z, g2); g3 = mfma16(cur.pa.x, w0.w, g3);
+            g0 = mfma16(cur.pa.y, w1.x, g0); g1 = mfma16(cur.pa.y, w1.y, g1);
+            g2 = mfma16(cur.pa.y, w1.z, g2); g3 = mfma16(cur.pa.y, w1.w, g3);
+            g0 = mfma16(cur.pa.z, w2v.x, g0); g1 = mfma16(cur.pa.z, w2v.y, g1);
+            g2 = mfma16(cur.pa.z, w2v.z, g2); g3 = mfma16(cur.pa.z, w2v.w, g3);
+            g0 = mfma16(cur.pa.w, w3.x, g0); g1 = mfma16(cur.pa.w, w3.y, g1);
+            g2 = mfma16(cur.pa.w, w3.z, g2); g3 = mfma16(cur.pa.w, w3.w, g3);
+            float da0 = recv_column(cur.a.x, wd4.x, cur.dd, cur.b0.x, cur.b1.x, cur.b2.x, cur.b3.x, g0, cur.pt, ad0, aw0);
+            float da1 = recv_column(cur.a.y, wd4.y, cur.dd, cur.b0.y, cur.b1.y, cur.b2.y, cur.b3.y, g1, cur.pt, ad1, aw1);
+            float da2 = recv_column(cur.a.z, wd4.z, cur.dd, cur.b0.z, cur.b1.z, cur.b2.z, cur.b3.z, g2, cur.pt, ad2, aw2);
+            float da3 = recv_column(cur.a.w, wd4.w, cur.dd, cur.b0.w, cur.b1.w, cur.b2.w, cur.b3.w, g3, cur.pt, ad3, aw3);
+            da0 += __shfl_xor(da0, 16, 64); da1 += __shfl_xor(da1, 16, 64);
+            da2 += __shfl_xor(da2, 16, 64); da3 += __shfl_xor(da3, 16, 64);
+            da0 += __shfl_xor(da0, 32, 64); da1 += __shfl_xor(da1, 32, 64);
+            da2 += __shfl_xor(da2, 32, 64); da3 += __shfl_xor(da3, 32, 64);
+            if (q == 0)
+                *reinterpret_cast<float4*>(dab + (int64_t)node * 2 * Hp + k4) = make_float4(da0, da1, da2, da3);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // the four wavefronts' partial dW2 / dwd tiles meet in LDS and are added in wavefront order
+    ad0 += __shfl_xor(ad0, 16, 64); ad1 += __shfl_xor(ad1, 16, 64);
+    ad2 += __shfl_xor(ad2, 16, 64); ad3 += __shfl_xor(ad3, 16, 64);
+    ad0 += __shfl_xor(ad0, 32, 64); ad1 += __shfl_xor(ad1, 32, 64);
+    ad2 += __shfl_xor(ad2, 32, 64); ad3 += __shfl_xor(ad3, 32, 64);
+    if (wave > 0) {
+        float* p = &s_red[wave - 1][lane * 20];
+        *reinterpret_cast<f32x4*>(p) = aw0;
+        *reinterpret_cast<f32x4*>(p + 4) = aw1;
+        *reinterpret_cast<f32x4*>(p + 8) = aw2;
+        *reinterpret_cast<f32x4*>(p + 12) = aw3;
+        *reinterpret_cast<float4*>(p + 16) = make_float4(ad0, ad1, ad2, ad3);
+    }
     __syncthreads();
-
-    // phase B: 64 hidden units per step (four MFMA column tiles); lane (r, q) owns the FOUR
-    // consecutive units k4 .. k4+3 with k4 = 64 T + 4 r, so every operand is a float4 load/store
-    // (column n = r of tile c is hidden unit k4 + c).
-    const int stiles = Hp >> 6;
-    for (int T = wave; T < stiles; T += WAVES) {
-        const int k4 = 64 * T + 4 * r;
-        float4 wv[4];
+    if (wave == 0) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) wv[s] = *reinterpret_cast<const float4*>(w2 + (4 * q + s) * Hp + k4);
-        const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
-        f32x4 acc_w[4];  // acc_w[c][g] = dW2[o = 4q+g][k4 + c]
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc_w[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float acc_wd[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < cnt; ++n) {
-            const int node = base + n;
-            const float4 pa = *reinterpret_cast<const float4*>(&s_p[n][r * PLD + 4 * q]);
-            const float pav[4] = {pa.x, pa.y, pa.z, pa.w};
-            f32x4 gk[4];  // gk[c][g] = sum_o dpre2[j = 4q+g][o] * W2[o][k4 + c]
-#pragma unroll
-            for (int c = 0; c < 4; ++c) gk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                gk[0] = mfma16(pav[s], wv[s].x, gk[0]);
-                gk[1] = mfma16(pav[s], wv[s].y, gk[1]);
-                gk[2] = mfma16(pav[s], wv[s].z, gk[2]);
-                gk[3] = mfma16(pav[s], wv[s].w, gk[3]);
-            }
-            const float4 ai4 = *reinterpret_cast<const float4*>(ab + (int64_t)node * 2 * Hp + k4);
-            const float aiv[4] = {ai4.x, ai4.y, ai4.z, ai4.w};
-            const float wdv[4] = {wd4.x, wd4.y, wd4.z, wd4.w};
-            float sv[4][4];  // sv[c][g] = silu(h[j = 4q+g][k4 + c])
-            float da[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int jn = s_nbr[n][4 * q + g];
-                const float dd = s_d2[n][4 * q + g];
-                const float4 b4 = *reinterpret_cast<const float4*>(ab + (int64_t)jn * 2 * Hp + Hp + k4);
-                const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float h = fmaf(wdv[c], dd, aiv[c] + bv[c]);
-                    float ds;
-                    sv[c][g] = silu_grad(h, &ds);
-                    const float dh = gk[c][g] * ds;
-                    da[c] += dh;
-                    acc_wd[c] = fmaf(dh, dd, acc_wd[c]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                da[c] += __shfl_xor(da[c], 16, 64);
-                da[c] += __shfl_xor(da[c], 32, 64);
-            }
-            if (q == 0)
-                *reinterpret_cast<float4*>(dab + (int64_t)node * 2 * Hp + k4) = make_float4(da[0], da[1], da[2], da[3]);
-            // dW2[o][k] += sum_j dpre2[j][o] * s[j][k]
-            const float4 pt = *reinterpret_cast<const float4*>(&s_pt[n][r * PLD + 4 * q]);
-            const float ptv[4] = {pt.x, pt.y, pt.z, pt.w};
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc_w[0] = mfma16(ptv[g], sv[0][g], acc_w[0]);
-                acc_w[1] = mfma16(ptv[g], sv[1][g], acc_w[1]);
-                acc_w[2] = mfma16(ptv[g], sv[2][g], acc_w[2]);
-                acc_w[3] = mfma16(ptv[g], sv[3][g], acc_w[3]);
-            }
+        for (int w = 0; w < WAVES - 1; ++w) {
+            const float* p = &s_red[w][lane * 20];
+            aw0 += *reinterpret_cast<const f32x4*>(p);
+            aw1 += *reinterpret_cast<const f32x4*>(p + 4);
+            aw2 += *reinterpret_cast<const f32x4*>(p + 8);
+            aw3 += *reinterpret_cast<const f32x4*>(p + 12);
+            const float4 d = *reinterpret_cast<const float4*>(p + 16);
+            ad0 += d.x; ad1 += d.y; ad2 += d.z; ad3 += d.w;
         }
-        float* __restrict__ sw = slab_w2 + (int64_t)blockIdx.x * MDIM * Hp;
+        float* __restrict__ sw = slab_w2 + (int64_t)chunk * (MDIM + 1) * Hp;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(sw + (4 * q + g) * Hp + k4) =
-                make_float4(acc_w[0][g], acc_w[1][g], acc_w[2][g], acc_w[3][g]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            acc_wd[c] += __shfl_xor(acc_wd[c], 16, 64);
-            acc_wd[c] += __shfl_xor(acc_wd[c], 32, 64);
-        }
+            *reinterpret_cast<float4*>(sw + (4 * q + g) * Hp + k4) = make_float4(aw0[g], aw1[g], aw2[g], aw3[g]);
         if (q == 0)
-            *reinterpret_cast<float4*>(slab_wd + (int64_t)blockIdx.x * Hp + k4) =
-                make_float4(acc_wd[0], acc_wd[1], acc_wd[2], acc_wd[3]);
+            *reinterpret_cast<float4*>(slab_wd + (int64_t)chunk * (MDIM + 1) * Hp + k4) = make_float4(ad0, ad1, ad2, ad3);
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward pass 2: by sender node j, over the transposed neighbour CSR (entries e = i*16 + slot).
-// dB[j][k] = sum over in-edges of g_e[k] * silu'(h_e[k]).  One wavefront per sender; in-edges are
-// consumed 16 at a time (one MFMA tile); groups after the first accumulate into the row this wave
-// owns exclusively.
+// sender pass.  dB[j][k] = sum over in-edges e = (i -> j) of g_e[k] * silu'(h_e[k]).  The entries of the
+// transposed neighbour CSR (sorted by sender) are consumed 16 at a time as ONE MFMA tile regardless of
+// sender boundaries -- the earlier one-sender-per-tile version padded every in-degree to a multiple of 16
+// (+45% work on a kNN graph) -- and the 16 x 64 tile of dh is summed per sender by a segmented walk:
+// the tile goes through LDS, lane u owns hidden unit u and adds rows while the (wavefront-uniform) sender
+// stays the same, storing a finished sender's 256-byte row piece exactly once.
 // ------------------------------------------------------------------------------------------------
+constexpr int SEND_LD = 68;  // floats per staged row: 64 + 4 pad
+
+struct SendOps {
+    float4 pa;                       // dpre2[e_r][4q .. 4q+3] (MFMA row r)
+    float4 a0, a1, a2, a3;           // A_i[k4 .. k4+3] of the receivers of MFMA rows 4q + g
+    float4 b0, b1, b2, b3;           // B_j[k4 .. k4+3] of their senders
+    float dd0, dd1, dd2, dd3;
+};
+
+__device__ __forceinline__ void send_load(SendOps& o, const float* __restrict__ ab,
+                                          const float* __restrict__ dpre2, int4 rc, int Hp, int k4, int q) {
+    o.pa = *reinterpret_cast<const float4*>(dpre2 + (int64_t)rc.x * MDIM + 4 * q);
+    const int e0 = __shfl(rc.x, 4 * q + 0, 64), e1 = __shfl(rc.x, 4 * q + 1, 64);
+    const int e2 = __shfl(rc.x, 4 * q + 2, 64), e3 = __shfl(rc.x, 4 * q + 3, 64);
+    const int j0 = __shfl(rc.y, 4 * q + 0, 64), j1 = __shfl(rc.y, 4 * q + 1, 64);
+    const int j2 = __shfl(rc.y, 4 * q + 2, 64), j3 = __shfl(rc.y, 4 * q + 3, 64);
+    o.dd0 = __int_as_float(__shfl(rc.z, 4 * q + 0, 64));
+    o.dd1 = __int_as_float(__shfl(rc.z, 4 * q + 1, 64));
+    o.dd2 = __int_as_float(__shfl(rc.z, 4 * q + 2, 64));
+    o.dd3 = __int_as_float(__shfl(rc.z, 4 * q + 3, 64));
+    o.a0 = *reinterpret_cast<const float4*>(ab + (int64_t)(e0 >> 4) * 2 * Hp + k4);
+    o.a1 = *reinterpret_cast<const float4*>(ab + (int64_t)(e1 >> 4) * 2 * Hp + k4);
+    o.a2 = *reinterpret_cast<const float4*>(ab + (int64_t)(e2 >> 4) * 2 * Hp + k4);
+    o.a3 = *reinterpret_cast<const float4*>(ab + (int64_t)(e3 >> 4) * 2 * Hp + k4);
+    o.b0 = *reinterpret_cast<const float4*>(ab + (int64_t)j0 * 2 * Hp + Hp + k4);
+    o.b1 = *reinterpret_cast<const float4*>(ab + (int64_t)j1 * 2 * Hp + Hp + k4);
+    o.b2 = *reinterpret_cast<const float4*>(ab + (int64_t)j2 * 2 * Hp + Hp + k4);
+    o.b3 = *reinterpret_cast<const float4*>(ab + (int64_t)j3 * 2 * Hp + Hp + k4);
+}
+
+__device__ __forceinline__ float4 send_row(const float4& wd4, float dd, const float4& a4, const float4& b4,
+                                           float gk0, float gk1, float gk2, float gk3) {
+    float ds;
+    float4 dh;
+    silu_grad(fmaf(wd4.x, dd, a4.x + b4.x), &ds); dh.x = gk0 * ds;
+    silu_grad(fmaf(wd4.y, dd, a4.y + b4.y), &ds); dh.y = gk1 * ds;
+    silu_grad(fmaf(wd4.z, dd, a4.z + b4.z), &ds); dh.z = gk2 * ds;
+    silu_grad(fmaf(wd4.w, dd, a4.w + b4.w), &ds); dh.w = gk3 * ds;
+    return dh;
+}
+
 __global__ void __launch_bounds__(THREADS)
-k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd,
-                const float* __restrict__ w2, const float* __restrict__ d2,
-                const float* __restrict__ dpre2, const int* __restrict__ t_rowptr,
-                const int* __restrict__ t_perm, float* __restrict__ dab, int N, int Hp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
+                const float* __restrict__ dpre2, const int* __restrict__ t_rowptr, const int4* __restrict__ rec,
+                float* __restrict__ dab, int N, int Hp, int tiles, int chunk_senders) {
+    __shared__ __attribute__((aligned(16))) float s_tile[WAVES][KNB * SEND_LD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
-        const int beg = t_rowptr[node], end = t_rowptr[node + 1];
-        float* __restrict__ drow = dab + (int64_t)node * 2 * Hp + Hp;
-        const float* __restrict__ brow = ab + (int64_t)node * 2 * Hp + Hp;
-        if (beg == end) {
-            for (int k = lane; k < Hp; k += 64) drow[k] = 0.f;
-            continue;
-        }
-        for (int g0 = beg; g0 < end; g0 += 16) {
-            const bool first = (g0 == beg);
-            // entry owned by lane r (as MFMA row), replicated over q
-            const int e_r = (g0 + r < end) ? t_perm[g0 + r] : -1;
-            // the four entries whose results land in this lane: rows 4q+g
-            int e_g[4];
-            float dd_g[4];
-            int64_t arow_g[4];
+    const int T = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const int k4 = 64 * T + 4 * r;
+    // this wavefront's senders [s_beg, s_end): an equal share of the chunk
+    const int c_beg = chunk * chunk_senders;
+    const int c_cnt = (N - c_beg < chunk_senders) ? (N - c_beg) : chunk_senders;
+    const int per = (c_cnt + WAVES - 1) / WAVES;
+    const int s_beg = c_beg + ((wave * per < c_cnt) ? wave * per : c_cnt);
+    const int s_end = c_beg + (((wave + 1) * per < c_cnt) ? (wave + 1) * per : c_cnt);
+    if (s_beg >= s_end) return;
+    const int p_beg = t_rowptr[s_beg], p_end = t_rowptr[s_end];
+    float* drow = dab + Hp + 64 * T + lane;  // + sender * 2 Hp: this lane's hidden unit of dB
+    if (p_beg == p_end) {  // no in-edge in the whole range
+        for (int sj = s_beg; sj < s_end; ++sj) drow[(int64_t)sj * 2 * Hp] = 0.f;
+        return;
+    }
+    const float4 w0 = *reinterpret_cast<const float4*>(w2 + (4 * q + 0) * Hp + k4);
+    const float4 w1 = *reinterpret_cast<const float4*>(w2 + (4 * q + 1) * Hp + k4);
+    const float4 w2v = *reinterpret_cast<const float4*>(w2 + (4 * q + 2) * Hp + k4);
+    const float4 w3 = *reinterpret_cast<const float4*>(w2 + (4 * q + 3) * Hp + k4);
+    const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
+    float* tile = s_tile[wave];
+    // end positions of up to 64 consecutive senders live in one VGPR (lane i: sender rp_base + i),
+    // read with v_readlane as the walk advances
+    int rp_base = s_beg;
+    int rp = t_rowptr[((rp_base + lane < N) ? rp_base + lane : N - 1) + 1];
+    int cur = s_beg;                           // sender whose sum is being built
+    int cur_end = __builtin_amdgcn_readlane(rp, 0);  // one past its last entry position
+    float run = 0.f;
+    // pipeline: records two tiles ahead, row gathers one tile ahead (positions clamped into the range; the
+    // rows of a ragged last tile are made inert by zeroing their dpre2 operand)
+    const int p_last = p_end - 1;
+    auto pos = [&](int p) { return (p + r < p_last) ? p + r : p_last; };
+    int4 rc_next = rec[pos(p_beg)];
+    SendOps nx;
+    send_load(nx, ab, dpre2, rc_next, Hp, k4, q);
+    rc_next = rec[pos(p_beg + KNB)];
+    for (int p0 = p_beg; p0 < p_end; p0 += KNB) {
+        const SendOps cur_ops = nx;
+        send_load(nx, ab, dpre2, rc_next, Hp, k4, q);
+        rc_next = rec[pos(p0 + 2 * KNB)];
+        __builtin_amdgcn_sched_barrier(0);
+        const bool live_r = p0 + r < p_end;
+        const float4 pa = live_r ? cur_ops.pa : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+        g0 = mfma16(pa.x, w0.x, g0); g1 = mfma16(pa.x, w0.y, g1); g2 = mfma16(pa.x, w0.z, g2); g3 = mfma16(pa.x, w0.w, g3);
+        g0 = mfma16(pa.y, w1.x, g0); g1 = mfma16(pa.y, w1.y, g1); g2 = mfma16(pa.y, w1.z, g2); g3 = mfma16(pa.y, w1.w, g3);
+        g0 = mfma16(pa.z, w2v.x, g0); g1 = mfma16(pa.z, w2v.y, g1); g2 = mfma16(pa.z, w2v.z, g2); g3 = mfma16(pa.z, w2v.w, g3);
+        g0 = mfma16(pa.w, w3.x, g0); g1 = mfma16(pa.w, w3.y, g1); g2 = mfma16(pa.w, w3.z, g2); g3 = mfma16(pa.w, w3.w, g3);
+        // dh of the four entries whose results land in this lane (MFMA rows 4q + g); gk = 0 on padding rows
+        float* trow = tile + 4 * q * SEND_LD + 4 * r;
+        *reinterpret_cast<float4*>(trow) = send_row(wd4, cur_ops.dd0, cur_ops.a0, cur_ops.b0, g0[0], g1[0], g2[0], g3[0]);
+        *reinterpret_cast<float4*>(trow + SEND_LD) = send_row(wd4, cur_ops.dd1, cur_ops.a1, cur_ops.b1, g0[1], g1[1], g2[1], g3[1]);
+        *reinterpret_cast<float4*>(trow + 2 * SEND_LD) = send_row(wd4, cur_ops.dd2, cur_ops.a2, cur_ops.b2, g0[2], g1[2], g2[2], g3[2]);
+        *reinterpret_cast<float4*>(trow + 3 * SEND_LD) = send_row(wd4, cur_ops.dd3, cur_ops.a3, cur_ops.b3, g0[3], g1[3], g2[3], g3[3]);
+        // segmented walk over the 16 rows (the same wavefront wrote the tile; LDS ops are in order)
+        float v[KNB];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                e_g[g] = __shfl(e_r, 4 * q + g, 64);
-                dd_g[g] = e_g[g] >= 0 ? d2[e_g[g]] : 0.f;
-                arow_g[g] = (int64_t)(e_g[g] >= 0 ? (e_g[g] >> 4) : 0) * 2 * Hp;
-            }
-            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e_r >= 0) pa = *reinterpret_cast<const float4*>(dpre2 + (int64_t)e_r * MDIM + 4 * q);
-            const float pav[4] = {pa.x, pa.y, pa.z, pa.w};
-            const int stiles = Hp >> 6;
-            for (int T = 0; T < stiles; ++T) {
-                const int k4 = 64 * T + 4 * r;  // this lane's four consecutive hidden units
-                f32x4 gk[4];
+        for (int row = 0; row < KNB; ++row) v[row] = tile[row * SEND_LD + lane];
+        const int rows = (p_end - p0 < KNB) ? (p_end - p0) : KNB;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) gk[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(w2 + (4 * q + s) * Hp + k4);
-                    gk[0] = mfma16(pav[s], w4.x, gk[0]);
-                    gk[1] = mfma16(pav[s], w4.y, gk[1]);
-                    gk[2] = mfma16(pav[s], w4.z, gk[2]);
-                    gk[3] = mfma16(pav[s], w4.w, gk[3]);
-                }
-                const float4 bj4 = *reinterpret_cast<const float4*>(brow + k4);
-                const float4 wd4 = *reinterpret_cast<const float4*>(wd + k4);
-                const float bjv[4] = {bj4.x, bj4.y, bj4.z, bj4.w};
-                const float wdv[4] = {wd4.x, wd4.y, wd4.z, wd4.w};
-                float db[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 a4 = *reinterpret_cast<const float4*>(ab + arow_g[g] + k4);
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float h = fmaf(wdv[c], dd_g[g], av[c] + bjv[c]);
-                        float ds;
-                        silu_grad(h, &ds);
-                        db[c] = fmaf(gk[c][g], ds, db[c]);  // gk is exactly 0 for padded entries
+        for (int row = 0; row < KNB; ++row) {
+            if (row < rows) {
+                while (p0 + row >= cur_end) {  // sender `cur` is complete (possibly without any entry)
+                    drow[(int64_t)cur * 2 * Hp] = run;
+                    run = 0.f;
+                    ++cur;
+                    if (cur - rp_base >= 64) {
+                        rp_base += 64;
+                        rp = t_rowptr[((rp_base + lane < N) ? rp_base + lane : N - 1) + 1];
                     }
+                    cur_end = __builtin_amdgcn_readlane(rp, cur - rp_base);
                 }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    db[c] += __shfl_xor(db[c], 16, 64);
-                    db[c] += __shfl_xor(db[c], 32, 64);
-                }
-                if (q == 0) {
-                    float4 o = make_float4(db[0], db[1], db[2], db[3]);
-                    if (!first) {
-                        const float4 prev = *reinterpret_cast<const float4*>(drow + k4);
-                        o.x += prev.x; o.y += prev.y; o.z += prev.z; o.w += prev.w;
-                    }
-                    *reinterpret_cast<float4*>(drow + k4) = o;
-                }
+                run += v[row];
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; cur < s_end; ++cur) {  // the last sender with entries, then trailing senders without any
+        drow[(int64_t)cur * 2 * Hp] = run;
+        run = 0.f;
     }
 }
 
@@ -528,8 +645,11 @@ extern "C" int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, 
 
 extern "C" size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp) {
     if (N < 0 || Hp <= 0) return 0;
-    const int64_t blocks = (N + BWD_CHUNK - 1) / BWD_CHUNK;
-    return (size_t)(blocks > 0 ? blocks : 1) * (size_t)(MDIM + 1) * (size_t)Hp * sizeof(float);
+    const int chunks = bw_chunks(N, Hp >> 6);
+    // [chunks][16 + 1][Hp] partial slabs of dW2 / dwd, the transposed copy of dpre2 [N][16][16] and the
+    // 16-byte records of the transposed CSR [16 N]
+    return ((size_t)chunks * (size_t)(MDIM + 1) * (size_t)Hp + (size_t)(N > 0 ? N : 1) * 256 +
+            (size_t)(N > 0 ? N : 1) * KNB * 4) * sizeof(float);
 }
 
 extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
@@ -549,18 +669,28 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     if (!ab || !wd || !w2 || !nbr || !d2 || !pre2 || !dm || !t_rowptr || !t_perm || !dab || !dpre2 ||
         !workspace)
         return EQH_ERR_ARG;
-    if (!eqh_aligned16(pre2) || !eqh_aligned16(dm) || !eqh_aligned16(dpre2) || !eqh_aligned16(workspace))
+    if (!eqh_aligned16(ab) || !eqh_aligned16(wd) || !eqh_aligned16(w2) || !eqh_aligned16(nbr) ||
+        !eqh_aligned16(d2) || !eqh_aligned16(pre2) || !eqh_aligned16(dm) || !eqh_aligned16(dpre2) ||
+        !eqh_aligned16(dab) || !eqh_aligned16(workspace))
         return EQH_ERR_ALIGN;
     if (workspace_bytes < egnn_edge_bwd_workspace_bytes(N, Hp)) return EQH_ERR_ARG;
-    const int blocks = (int)((N + BWD_CHUNK - 1) / BWD_CHUNK);
-    float* slab_w2 = static_cast<float*>(workspace);
-    float* slab_wd = slab_w2 + (size_t)blocks * MDIM * Hp;
-    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(blocks), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, pre2,
-                       dm, dpre2, dab, slab_w2, slab_wd, (int)N, (int)Hp);
+    const int tiles = Hp >> 6;
+    const int chunks = bw_chunks(N, tiles);
+    const int chunk_items = (int)((N + chunks - 1) / chunks);
+    const int used = (int)((N + chunk_items - 1) / chunk_items);  // chunks that own at least one item
+    float* slab_w2 = static_cast<float*>(workspace);  // per chunk: [16][Hp] of dW2, then [Hp] of dwd
+    float* slab_wd = slab_w2 + (size_t)MDIM * Hp;
+    float* dpre2_t = slab_w2 + (size_t)chunks * (MDIM + 1) * Hp;
+    int4* rec = reinterpret_cast<int4*>(dpre2_t + (size_t)N * 256);
+    hipLaunchKernelGGL(k_edge_bwd_prep, dim3(eqh_grid_for(N, WAVES, 2048)), dim3(THREADS), 0, stream, pre2, dm,
+                       dpre2, dpre2_t, t_perm, nbr, d2, rec, (int)N);
     EQH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_edge_bwd_send, dim3(eqh_grid_for(N, WAVES, 2048)), dim3(THREADS), 0, stream, ab,
-                       wd, w2, d2, dpre2, t_rowptr, t_perm, dab, (int)N, (int)Hp);
+    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, dpre2,
+                       dpre2_t, dab, slab_w2, slab_wd, (int)N, (int)Hp, tiles, chunk_items);
     EQH_CHECK_LAUNCH();
-    if (eqh_reduce_slabs_async(slab_w2, blocks, (int64_t)MDIM * Hp, dw2, stream)) return EQH_ERR_LAUNCH;
-    return eqh_reduce_slabs_async(slab_wd, blocks, (int64_t)Hp, dwd, stream);
+    hipLaunchKernelGGL(k_edge_bwd_send, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, dpre2, t_rowptr,
+                       rec, dab, (int)N, (int)Hp, tiles, chunk_items);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs3_async(slab_w2, used, (int64_t)(MDIM + 1) * Hp, dw2, dwd, dwd, (int64_t)MDIM * Hp, Hp, 0,
+                                   stream);
 }

@@ -478,6 +478,6 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
         hipLaunchKernelGGL((k_rowln_bwd<NV>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
                            (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
-        return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, accumulate, stream);
+        return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
     });
 }

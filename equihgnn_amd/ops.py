@@ -221,7 +221,7 @@ class _EgnnEdge(torch.autograd.Function):
                                   _ptr(dm), _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
                                   _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(ws), ws_bytes, _stream(dev)),
                   "egnn_edge_bwd")
-        db2 = dpre2.view(-1, 16).sum(0)
+        db2 = colsum(dpre2.view(N, 256)).view(16, 16).sum(0)   # over nodes (kernel), then over the 16 slots
         return dab, dwd, dw2, db2, None, None, None
 
 
