@@ -1,5 +1,123 @@
-// Library identity + error strings.
+// Library identity, error strings and the deferred-reduction registry.
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include "common.h"
+
+namespace {
+
+constexpr int MANY = 24;  // descriptors per batched launch (kernel-argument struct of 24 x 72 bytes)
+
+// Descriptors that add into the SAME destination form a group (kept in issue order): one block owns a
+// 64-element chunk of the destination and runs the group's reductions one after the other, so the
+// read-modify-writes of a shared accumulator never race and keep their order.
+struct ReduceBatch {
+    EqhReduceDesc d[MANY];
+    int g_start[MANY + 1];  // group g = descriptors [g_start[g], g_start[g+1])
+    int n_groups;
+};
+
+__global__ void __launch_bounds__(1024) eqh_k_reduce_many(ReduceBatch b) {
+    __shared__ float s_part[1024];
+    int g = 0;
+    while (g + 1 < b.n_groups && (int)blockIdx.x >= b.d[b.g_start[g + 1]].first_block) ++g;  // block-uniform
+    const int i0 = b.g_start[g], i1 = b.g_start[g + 1];
+    const int64_t e0 = (int64_t)((int)blockIdx.x - b.d[i0].first_block) * 64;
+    for (int i = i0; i < i1; ++i) eqh_reduce_chunk(b.d[i], e0, 1, s_part);
+}
+
+std::mutex g_mu;
+std::unordered_map<hipStream_t, std::vector<EqhReduceDesc>> g_deferred;  // key present = deferral active
+
+}  // namespace
+
+bool eqh_defer_try(hipStream_t stream, const EqhReduceDesc& d) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_deferred.find(stream);
+    if (it == g_deferred.end()) return false;
+    it->second.push_back(d);
+    return true;
+}
+
+extern "C" int eqh_defer_begin(void* stream_) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_deferred[static_cast<hipStream_t>(stream_)];  // creates the (empty) list
+    return EQH_OK;
+}
+
+extern "C" int eqh_defer_flush(void* stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    std::vector<EqhReduceDesc> todo;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto it = g_deferred.find(stream);
+        if (it == g_deferred.end()) return EQH_OK;
+        todo.swap(it->second);
+        g_deferred.erase(it);
+    }
+    // group by destination (stable: issue order inside a group); a reduction that shares a destination
+    // pointer with a group of a different shape starts a new, later launch
+    auto same = [](const EqhReduceDesc& x, const EqhReduceDesc& y) {
+        return x.out0 == y.out0 && x.out1 == y.out1 && x.out2 == y.out2 && x.elems == y.elems && x.len0 == y.len0 &&
+               x.len1 == y.len1;
+    };
+    auto touches = [](const EqhReduceDesc& x, const EqhReduceDesc& y) {
+        const float* px[3] = {x.out0, x.out1, x.out2};
+        const float* py[3] = {y.out0, y.out1, y.out2};
+        for (const float* a : px)
+            for (const float* c : py)
+                if (a != nullptr && a == c) return true;
+        return false;
+    };
+    std::vector<std::vector<EqhReduceDesc>> groups;
+    auto launch_groups = [&]() -> int {
+        size_t gi = 0;
+        while (gi < groups.size()) {
+            ReduceBatch b;
+            int n = 0, blocks = 0;
+            b.n_groups = 0;
+            while (gi < groups.size() && n + (int)groups[gi].size() <= MANY) {
+                b.g_start[b.n_groups++] = n;
+                const int chunks = (int)((groups[gi][0].elems + 63) / 64);
+                for (const EqhReduceDesc& d : groups[gi]) {
+                    b.d[n] = d;
+                    b.d[n].first_block = blocks;
+                    ++n;
+                }
+                blocks += chunks;
+                ++gi;
+            }
+            if (n == 0) {  // one group larger than a batch: consecutive launches, in order
+                std::vector<EqhReduceDesc>& g = groups[gi];
+                b.n_groups = 1;
+                b.g_start[0] = 0;
+                n = MANY;
+                for (int i = 0; i < MANY; ++i) { b.d[i] = g[i]; b.d[i].first_block = 0; }
+                blocks = (int)((g[0].elems + 63) / 64);
+                g.erase(g.begin(), g.begin() + MANY);
+            }
+            b.g_start[b.n_groups] = n;
+            if (blocks == 0) continue;
+            hipLaunchKernelGGL(eqh_k_reduce_many, dim3(blocks), dim3(1024), 0, stream, b);
+            if (hipGetLastError() != hipSuccess) return EQH_ERR_LAUNCH;
+        }
+        groups.clear();
+        return EQH_OK;
+    };
+    for (const EqhReduceDesc& d : todo) {
+        bool placed = false, conflict = false;
+        for (auto& g : groups) {
+            if (same(g[0], d)) { g.push_back(d); placed = true; break; }
+            if (touches(g[0], d)) conflict = true;
+        }
+        if (placed) continue;
+        if (conflict && launch_groups() != EQH_OK) return EQH_ERR_LAUNCH;
+        groups.push_back({d});
+    }
+    if (launch_groups() != EQH_OK) return EQH_ERR_LAUNCH;
+    return EQH_OK;
+}
 
 extern "C" int eqh_version(void) { return 1; }
 

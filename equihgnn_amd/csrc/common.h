@@ -47,52 +47,77 @@ static inline int eqh_zero_async(float* p, int64_t n, hipStream_t stream) {
 // the typical call reduces 100-300 slabs of a few hundred floats), and the groups are combined through
 // LDS in group order.
 // Output: up to three segments (out0: elements [0, len0), out1: the next len1, out2: the rest; out1 ==
-// nullptr means one contiguous run of `elems`), overwritten or, with accumulate != 0, added to (gradient accumulators of
-// parameters that are used several times per step).
-static __global__ void __launch_bounds__(1024)
-eqh_k_reduce_slabs(const float* __restrict__ slab, int n_slabs, int64_t elems, float* __restrict__ out0,
-                   float* __restrict__ out1, float* __restrict__ out2, int64_t len0, int64_t len1, int accumulate) {
-    __shared__ float s_part[1024];
+// nullptr means one contiguous run of `elems`), overwritten or, with accumulate != 0, added to (gradient
+// accumulators of parameters that are used several times per step).
+struct EqhReduceDesc {
+    const float* slab;
+    float* out0;
+    float* out1;
+    float* out2;
+    int64_t elems, len0, len1;
+    int n_slabs;
+    int first_block;  // eqh_k_reduce_many: first block of this descriptor in the batched grid
+};
+
+// one 64-element chunk (starting at e0) of one reduction, by a 1024-thread block
+static __device__ __forceinline__ void eqh_reduce_chunk(const EqhReduceDesc& d, int64_t e0, int accumulate,
+                                                        float* s_part) {
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < elems; e0 += (int64_t)gridDim.x * 64) {
-        const int64_t e = e0 + col;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (e < elems) {
-            const float* __restrict__ p = slab + e;
-            int b = grp;
-            for (; b + 112 < n_slabs; b += 128) {
-                float v[8];
+    const int64_t e = e0 + col;
+    const int64_t elems = d.elems;
+    const int n_slabs = d.n_slabs;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (e < elems) {
+        const float* __restrict__ p = d.slab + e;
+        int b = grp;
+        for (; b + 112 < n_slabs; b += 128) {
+            float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = p[(int64_t)(b + 16 * i) * elems];
-                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-                a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
-            }
-            {   // ragged end: same accumulator assignment (i mod 4), loads still issued together
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = (b + 16 * i < n_slabs) ? p[(int64_t)(b + 16 * i) * elems] : 0.f;
-                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-                a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
-            }
+            for (int i = 0; i < 8; ++i) v[i] = p[(int64_t)(b + 16 * i) * elems];
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
         }
-        s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
-        if (grp == 0 && e < elems) {
-            float t = s_part[col];
+        {   // ragged end: same accumulator assignment (i mod 4), loads still issued together
+            float v[8];
 #pragma unroll
-            for (int g = 1; g < 16; ++g) t += s_part[64 * g + col];
-            float* dst = out0 + e;
-            if (out1 != nullptr && e >= len0) dst = (e < len0 + len1) ? out1 + (e - len0) : out2 + (e - len0 - len1);
-            *dst = accumulate ? *dst + t : t;
+            for (int i = 0; i < 8; ++i) v[i] = (b + 16 * i < n_slabs) ? p[(int64_t)(b + 16 * i) * elems] : 0.f;
+            a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            a0 += v[4]; a1 += v[5]; a2 += v[6]; a3 += v[7];
         }
-        __syncthreads();
     }
+    s_part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (grp == 0 && e < elems) {
+        float t = s_part[col];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) t += s_part[64 * g + col];
+        float* dst = d.out0 + e;
+        if (d.out1 != nullptr && e >= d.len0)
+            dst = (e < d.len0 + d.len1) ? d.out1 + (e - d.len0) : d.out2 + (e - d.len0 - d.len1);
+        *dst = accumulate ? *dst + t : t;
+    }
+    __syncthreads();
 }
+
+static __global__ void __launch_bounds__(1024)
+eqh_k_reduce_slabs(EqhReduceDesc d, int accumulate) {
+    __shared__ float s_part[1024];
+    for (int64_t e0 = (int64_t)blockIdx.x * 64; e0 < d.elems; e0 += (int64_t)gridDim.x * 64)
+        eqh_reduce_chunk(d, e0, accumulate, s_part);
+}
+
+// Deferred reductions (api.hip).  Between eqh_defer_begin(stream) and eqh_defer_flush(stream) every
+// ACCUMULATING slab reduction issued on that stream is recorded instead of launched, and the flush
+// runs them all in one launch: the accumulators (parameter gradients) are only read by the optimiser,
+// so ~25 five-microsecond launches per training step become one.  Returns true if recorded.
+bool eqh_defer_try(hipStream_t stream, const EqhReduceDesc& d);
+
 static inline int eqh_reduce_slabs3_async(const float* slab, int n_slabs, int64_t elems, float* out0, float* out1,
                                           float* out2, int64_t len0, int64_t len1, int accumulate,
                                           hipStream_t stream) {
-    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(1024), 0, stream, slab,
-                       n_slabs, elems, out0, out1, out2, len0, len1, accumulate);
+    EqhReduceDesc d{slab, out0, out1, out2, elems, len0, len1, n_slabs, 0};
+    if (accumulate && eqh_defer_try(stream, d)) return EQH_OK;
+    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(1024), 0, stream, d, accumulate);
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
 }
 static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,

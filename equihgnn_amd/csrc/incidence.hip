@@ -51,22 +51,27 @@ struct Row {
     float4 v[NV];
 };
 
-// h = relu(pa[a] + qb[b]); returns xhat in `x`, rstd in *rstd, relu mask in `pos` (bit per comp)
+// the two gathered operand rows of one incidence (loads only: issued ahead of their use)
 template <int NV>
-__device__ __forceinline__ void load_norm(const float* __restrict__ pa, const float* __restrict__ qb,
-                                          int a, int b, int C, int lane, float inv_c, float eps,
-                                          Row<NV>& x, unsigned& pos, float* rstd) {
+__device__ __forceinline__ void gather_pair(const float* __restrict__ pa, const float* __restrict__ qb, int a, int b,
+                                            int C, int lane, Row<NV>& u, Row<NV>& w) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        u.v[i] = (c < C) ? *reinterpret_cast<const float4*>(pa + (int64_t)a * C + c) : f4_zero();
+        w.v[i] = (c < C) ? *reinterpret_cast<const float4*>(qb + (int64_t)b * C + c) : f4_zero();
+    }
+}
+
+// h = relu(u + w); returns xhat in `x`, rstd in *rstd, relu mask in `pos` (bit per comp)
+template <int NV>
+__device__ __forceinline__ void norm_pair(const Row<NV>& u, const Row<NV>& w, int C, int lane, float inv_c,
+                                          float eps, Row<NV>& x, unsigned& pos, float* rstd) {
     float s = 0.f;
     pos = 0u;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < C) {
-            const float4 u = *reinterpret_cast<const float4*>(pa + (int64_t)a * C + c);
-            const float4 w = *reinterpret_cast<const float4*>(qb + (int64_t)b * C + c);
-            h = make_float4(u.x + w.x, u.y + w.y, u.z + w.z, u.w + w.w);
-        }
+        float4 h = make_float4(u.v[i].x + w.v[i].x, u.v[i].y + w.v[i].y, u.v[i].z + w.v[i].z, u.v[i].w + w.v[i].w);
         pos |= ((h.x > 0.f) ? 1u : 0u) << (4 * i) | ((h.y > 0.f) ? 2u : 0u) << (4 * i) |
                ((h.z > 0.f) ? 4u : 0u) << (4 * i) | ((h.w > 0.f) ? 8u : 0u) << (4 * i);
         h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
@@ -87,6 +92,15 @@ __device__ __forceinline__ void load_norm(const float* __restrict__ pa, const fl
     *rstd = r;
 #pragma unroll
     for (int i = 0; i < NV; ++i) { x.v[i].x *= r; x.v[i].y *= r; x.v[i].z *= r; x.v[i].w *= r; }
+}
+
+template <int NV>
+__device__ __forceinline__ void load_norm(const float* __restrict__ pa, const float* __restrict__ qb,
+                                          int a, int b, int C, int lane, float inv_c, float eps,
+                                          Row<NV>& x, unsigned& pos, float* rstd) {
+    Row<NV> u, w;
+    gather_pair<NV>(pa, qb, a, b, C, lane, u, w);
+    norm_pair<NV>(u, w, C, lane, inv_c, eps, x, pos, rstd);
 }
 
 template <int NV>
@@ -141,16 +155,22 @@ k_inc_fwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
 }
 
 // One side of the backward.  Rows of (side_rowptr, side_perm) group the incidences by the index of
-// the operand whose gradient is produced; `okey[p]` is the OUTPUT row of incidence p and
-// `orowptr` the forward CSR's rowptr (for the mean weight).
-template <int NV, bool DGAMMA>
+// the operand whose gradient is produced (SIDE_A: ia, else ib -- so the row of an incidence is simply
+// that index); `okey[p]` is the OUTPUT row of incidence p and `orowptr` the forward CSR's rowptr (for
+// the mean weight).
+// Hypergraph rows are short (2-3 incidences), so one row per wavefront spends its time in the dependent
+// load chain rowptr -> perm -> (ia, ib, okey) -> orowptr -> rows.  A wavefront therefore owns a RANGE of
+// consecutive rows: one chain fetches the metadata of up to 64 incidences at once (a lane each), the
+// operand rows of incidence j+1 are gathered while incidence j is normalised, and the per-row sums are
+// flushed when the (wavefront-uniform) row index changes.
+template <int NV, bool DGAMMA, bool SIDE_A>
 __global__ void __launch_bounds__(THREADS)
 k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ ia,
           const int* __restrict__ ib, const int* __restrict__ side_rowptr,
           const int* __restrict__ side_perm, const int* __restrict__ okey,
           const int* __restrict__ orowptr, const float* __restrict__ ds,
           const float* __restrict__ gamma, float* __restrict__ dside, float* __restrict__ slab_dgamma,
-          int n_side_rows, int C, int mean, float eps) {
+          int n_side_rows, int C, int mean, float eps, int rows_per_wave) {
     __shared__ float4 s_g[DGAMMA ? THREADS : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
@@ -161,72 +181,99 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
         gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
         dgam.v[i] = f4_zero();
     }
-    for (int s = blockIdx.x * WAVES + wave; s < n_side_rows; s += gridDim.x * WAVES) {
-        const int beg = side_rowptr[s], end = side_rowptr[s + 1];
+    const int64_t s_beg64 = (int64_t)(blockIdx.x * WAVES + wave) * rows_per_wave;
+    const int s_beg = (s_beg64 < n_side_rows) ? (int)s_beg64 : n_side_rows;
+    const int s_end = (s_beg + rows_per_wave < n_side_rows) ? s_beg + rows_per_wave : n_side_rows;
+    if (s_beg < s_end) {
+        const int p_beg = side_rowptr[s_beg], p_end = side_rowptr[s_end];
+        int cur_row = s_beg;  // row whose sum `acc` is building
         Row<NV> acc;
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
-        for (int q0 = beg; q0 < end; q0 += 64) {
-          const int cnt = (end - q0 < 64) ? (end - q0) : 64;
-          int my_a = 0, my_b = 0, my_r = 0;
-          float my_w = 1.0f;
-          if (lane < cnt) {
-              const int p = side_perm[q0 + lane];
-              my_a = ia[p];
-              my_b = ib[p];
-              my_r = okey[p];
-              const int deg = orowptr[my_r + 1] - orowptr[my_r];
-              my_w = (mean && deg > 1) ? 1.0f / (float)deg : 1.0f;
-          }
-          for (int j = 0; j < cnt; ++j) {
-            const int r = __shfl(my_r, j, 64);
-            const float w = __shfl(my_w, j, 64);
-            // issue the d(out) row load before the LayerNorm reductions so its latency overlaps them
-            Row<NV> draw;
+        auto flush_until = [&](int row) {  // rows [cur_row, row) are complete (empty ones store zeros)
+            for (; cur_row < row; ++cur_row) {
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = (lane + 64 * i) * 4;
-                draw.v[i] = (c < C) ? *reinterpret_cast<const float4*>(ds + (int64_t)r * C + c) : f4_zero();
-            }
-            Row<NV> x;
-            unsigned pos;
-            float rstd;
-            load_norm<NV>(pa, qb, __shfl(my_a, j, 64), __shfl(my_b, j, 64), C, lane, inv_c, eps, x, pos, &rstd);
-            Row<NV> g;
-            float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                float4 d = draw.v[i];
-                d.x *= w; d.y *= w; d.z *= w; d.w *= w;
-                if (DGAMMA) {
-                    dgam.v[i].x = fmaf(d.x, x.v[i].x, dgam.v[i].x); dgam.v[i].y = fmaf(d.y, x.v[i].y, dgam.v[i].y);
-                    dgam.v[i].z = fmaf(d.z, x.v[i].z, dgam.v[i].z); dgam.v[i].w = fmaf(d.w, x.v[i].w, dgam.v[i].w);
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (lane + 64 * i) * 4;
+                    if (c < C) *reinterpret_cast<float4*>(dside + (int64_t)cur_row * C + c) = acc.v[i];
+                    acc.v[i] = f4_zero();
                 }
-                d.x *= gam.v[i].x; d.y *= gam.v[i].y; d.z *= gam.v[i].z; d.w *= gam.v[i].w;
-                g.v[i] = d;
-                m1 += (d.x + d.y) + (d.z + d.w);
-                m2 += (d.x * x.v[i].x + d.y * x.v[i].y) + (d.z * x.v[i].z + d.w * x.v[i].w);
             }
-            wave_sum2(m1, m2);
-            m1 *= inv_c;
-            m2 *= inv_c;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const unsigned b = pos >> (4 * i);
-                float4 dx;
-                dx.x = (b & 1u) ? rstd * (g.v[i].x - m1 - x.v[i].x * m2) : 0.f;
-                dx.y = (b & 2u) ? rstd * (g.v[i].y - m1 - x.v[i].y * m2) : 0.f;
-                dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
-                dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
-                f4_add(acc.v[i], dx);
+        };
+        for (int q0 = p_beg; q0 < p_end; q0 += 64) {
+            const int cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+            int my_a = 0, my_b = 0, my_r = 0;
+            float my_w = 1.0f;
+            if (lane < cnt) {
+                const int p = side_perm[q0 + lane];
+                my_a = ia[p];
+                my_b = ib[p];
+                my_r = okey[p];
+                const int deg = orowptr[my_r + 1] - orowptr[my_r];
+                my_w = (mean && deg > 1) ? 1.0f / (float)deg : 1.0f;
             }
-          }
-        }
+            Row<NV> nu, nw, nd;  // operands of the next incidence
+            {
+                const int a0 = __builtin_amdgcn_readlane(my_a, 0), b0 = __builtin_amdgcn_readlane(my_b, 0);
+                const int r0 = __builtin_amdgcn_readlane(my_r, 0);
+                gather_pair<NV>(pa, qb, a0, b0, C, lane, nu, nw);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + 64 * i) * 4;
-            if (c < C) *reinterpret_cast<float4*>(dside + (int64_t)s * C + c) = acc.v[i];
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (lane + 64 * i) * 4;
+                    nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(ds + (int64_t)r0 * C + c) : f4_zero();
+                }
+            }
+            for (int j = 0; j < cnt; ++j) {
+                const Row<NV> cu = nu, cw = nw, draw = nd;
+                const int a_j = __builtin_amdgcn_readlane(my_a, j), b_j = __builtin_amdgcn_readlane(my_b, j);
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+                {
+                    const int jn = (j + 1 < cnt) ? j + 1 : j;  // the last one re-reads itself
+                    const int a1 = __builtin_amdgcn_readlane(my_a, jn), b1 = __builtin_amdgcn_readlane(my_b, jn);
+                    const int r1 = __builtin_amdgcn_readlane(my_r, jn);
+                    gather_pair<NV>(pa, qb, a1, b1, C, lane, nu, nw);
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        const int c = (lane + 64 * i) * 4;
+                        nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(ds + (int64_t)r1 * C + c) : f4_zero();
+                    }
+                }
+                flush_until(SIDE_A ? a_j : b_j);
+                Row<NV> x;
+                unsigned pos;
+                float rstd;
+                norm_pair<NV>(cu, cw, C, lane, inv_c, eps, x, pos, &rstd);
+                Row<NV> g;
+                float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    float4 d = draw.v[i];
+                    d.x *= w; d.y *= w; d.z *= w; d.w *= w;
+                    if (DGAMMA) {
+                        dgam.v[i].x = fmaf(d.x, x.v[i].x, dgam.v[i].x); dgam.v[i].y = fmaf(d.y, x.v[i].y, dgam.v[i].y);
+                        dgam.v[i].z = fmaf(d.z, x.v[i].z, dgam.v[i].z); dgam.v[i].w = fmaf(d.w, x.v[i].w, dgam.v[i].w);
+                    }
+                    d.x *= gam.v[i].x; d.y *= gam.v[i].y; d.z *= gam.v[i].z; d.w *= gam.v[i].w;
+                    g.v[i] = d;
+                    m1 += (d.x + d.y) + (d.z + d.w);
+                    m2 += (d.x * x.v[i].x + d.y * x.v[i].y) + (d.z * x.v[i].z + d.w * x.v[i].w);
+                }
+                wave_sum2(m1, m2);
+                m1 *= inv_c;
+                m2 *= inv_c;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const unsigned b = pos >> (4 * i);
+                    float4 dx;
+                    dx.x = (b & 1u) ? rstd * (g.v[i].x - m1 - x.v[i].x * m2) : 0.f;
+                    dx.y = (b & 2u) ? rstd * (g.v[i].y - m1 - x.v[i].y * m2) : 0.f;
+                    dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
+                    dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
+                    f4_add(acc.v[i], dx);
+                }
+            }
         }
+        flush_until(s_end);
     }
     if (DGAMMA) {
 #pragma unroll
@@ -347,7 +394,16 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
 
 inline int rowln_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES * 4, 256); }
 
-inline int bwd_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES, 512); }
+// rows per wavefront of the backward: about 2048 wavefronts per launch (two per SIMD)
+inline int bwd_rpw(int64_t rows) {
+    const int64_t r = (rows + 2047) / 2048;
+    return (int)(r < 1 ? 1 : r);
+}
+inline int bwd_blocks(int64_t rows) {
+    const int64_t per_block = (int64_t)bwd_rpw(rows) * WAVES;
+    const int64_t b = (rows + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : b);
+}
 
 int check(int64_t rows, int C) {
     if (rows < 0 || C <= 0) return EQH_ERR_ARG;
@@ -417,12 +473,12 @@ extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, cons
     const int blocks_a = bwd_blocks(n_a_rows);
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        hipLaunchKernelGGL((k_inc_bwd<NV, true>), dim3(blocks_a), dim3(THREADS), 0, stream, pa, qb, ia, ib,
+        hipLaunchKernelGGL((k_inc_bwd<NV, true, true>), dim3(blocks_a), dim3(THREADS), 0, stream, pa, qb, ia, ib,
                            a_rowptr, a_perm, okey, orowptr, ds, gamma, dpa, slab, (int)n_a_rows, (int)C,
-                           (int)mean, eps);
-        hipLaunchKernelGGL((k_inc_bwd<NV, false>), dim3(bwd_blocks(n_b_rows)), dim3(THREADS), 0, stream, pa, qb,
-                           ia, ib, b_rowptr, b_perm, okey, orowptr, ds, gamma, dqb, (float*)nullptr,
-                           (int)n_b_rows, (int)C, (int)mean, eps);
+                           (int)mean, eps, bwd_rpw(n_a_rows));
+        hipLaunchKernelGGL((k_inc_bwd<NV, false, false>), dim3(bwd_blocks(n_b_rows)), dim3(THREADS), 0, stream, pa,
+                           qb, ia, ib, b_rowptr, b_perm, okey, orowptr, ds, gamma, dqb, (float*)nullptr,
+                           (int)n_b_rows, (int)C, (int)mean, eps, bwd_rpw(n_b_rows));
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream, accumulate);
     });

@@ -257,7 +257,7 @@ class _IncidenceLnReduce(torch.autograd.Function):
         dgamma = g_acc if g_acc is not None else torch.empty_like(gamma)
         L = hip.lib()
         ws_bytes = L.hg_incidence_ln_reduce_bwd_workspace_bytes(csr_a.n_rows, C)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(ws_bytes, dev)
         hip.check(L.hg_incidence_ln_reduce_bwd(
             _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(csr_a.rowptr), _ptr(csr_a.perm), csr_a.n_rows,
             _ptr(csr_b.rowptr), _ptr(csr_b.perm), csr_b.n_rows, _ptr(okey32), _ptr(out_csr.rowptr), _ptr(ds),
@@ -293,7 +293,7 @@ class _BiasReluLn(torch.autograd.Function):
         dh = torch.empty_like(h)
         L = hip.lib()
         ws_bytes = L.hg_bias_relu_ln_bwd_workspace_bytes(R, C)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=h.device)
+        ws = _workspace(ws_bytes, h.device)
         tg = [_acc_target(p) for p in ctx.acc]
         if all(t is not None for t in tg):   # all three accumulate in place: nothing for autograd to add
             hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps),
@@ -321,6 +321,31 @@ def wgrad_stream(device):
 def join_wgrad_stream(device):
     if WGRAD_ON_SIDE_STREAM and _WGRAD_STREAMS:
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
+
+
+_DEFER = {"active": False, "keep": []}
+
+
+def _workspace(nbytes, device):
+    """Scratch for one kernel call; while reductions are deferred it must outlive the call (the slabs
+    it holds are read by defer_flush), so it is parked until then."""
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if _DEFER["active"]:
+        _DEFER["keep"].append(ws)
+    return ws
+
+
+def defer_begin(device):
+    """Start recording the accumulating gradient reductions issued on the current stream of ``device``
+    (eqh_defer_begin); they all run in one launch at defer_flush()."""
+    hip.check(hip.lib().eqh_defer_begin(_stream(device)), "eqh_defer_begin")
+    _DEFER["active"] = True
+
+
+def defer_flush(device):
+    _DEFER["active"] = False
+    hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
+    _DEFER["keep"].clear()
 
 
 def _acc_target(param):
@@ -355,7 +380,7 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
     L = hip.lib()
     out = into if into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws_bytes = L.hg_colsum_workspace_bytes(R, C)
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    ws = _workspace(max(ws_bytes, 16), x.device)
     hip.check(L.hg_colsum_f32(_ptr(x), _ptr(rowptr) if rowptr is not None else None, weight_mode, R, C,
                               1 if into is not None else 0, _ptr(out), _ptr(ws), ws_bytes, _stream(x.device)),
               "hg_colsum_f32")

@@ -145,10 +145,24 @@ class GraphedTrainStep:
         if self.wflat is not None:
             self.wflat.zero_()
         loss = self._loss(data)
-        loss.backward()
+        self._backward(loss)
+        return loss
+
+    def _backward(self, loss):
+        """backward with the accumulating gradient reductions of the fused kernels deferred into one
+        launch (ops.defer_begin / defer_flush), then the packing of the remaining gradients."""
+        from . import ops
+        dev = loss.device
+        defer = self.gflat is not None and dev.type == "cuda"
+        if defer:
+            ops.defer_begin(dev)
+        try:
+            loss.backward()
+        finally:
+            if defer:
+                ops.defer_flush(dev)
         self._join()
         self._gather_grads()
-        return loss
 
     def _join(self):
         from . import ops
@@ -251,9 +265,7 @@ class GraphedTrainStep:
             if self.wflat is not None:
                 self.wflat.zero_()
             loss = self._loss(static)
-            loss.backward()
-            self._join()
-            self._gather_grads()
+            self._backward(loss)
         g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
             if world > 1:

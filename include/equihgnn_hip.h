@@ -36,6 +36,15 @@ extern "C" {
 int eqh_version(void);
 const char* eqh_error_string(int code);
 
+/* Deferred gradient reductions.  Several backward kernels end in a fixed-order reduction of per-workgroup
+ * partial slabs into a parameter gradient; with accumulate != 0 that gradient is only read by the
+ * optimiser.  Between eqh_defer_begin(stream) and eqh_defer_flush(stream) such accumulating reductions
+ * issued on `stream` are recorded instead of launched, and the flush performs all of them in ONE launch
+ * (a training step of egnn_equihnns has ~25 of them).  The workspaces passed to the deferred calls must
+ * stay allocated and untouched until the flush.  Without begin/flush every call reduces at once. */
+int eqh_defer_begin(void* stream);
+int eqh_defer_flush(void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of
  * torch_scatter.scatter (conv.py:91-93,97,173,177): the COO incidence list is sorted ONCE per

@@ -361,6 +361,17 @@ def test_fused_ops_accumulate_into_parameter_buffers():
     for p, ref in zip((bias, gamma, beta, lb, w), want):
         assert p.grad is None
         np.testing.assert_allclose(p._eqh_gbuf.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-4)
+    # deferred mode (eqh_defer_begin / eqh_defer_flush): the same reductions in ONE launch at the flush,
+    # bit-identical to reducing at once
+    immediate = [p._eqh_gbuf.clone() for p in (bias, gamma, beta, lb, w)]
+    for p in (bias, gamma, beta, lb, w):
+        p._eqh_gbuf.zero_()
+    ops.defer_begin(DEV)
+    run()
+    assert float(bias._eqh_gbuf.abs().max()) == 0.0     # nothing reduced yet
+    ops.defer_flush(DEV)
+    for p, ref in zip((bias, gamma, beta, lb, w), immediate):
+        assert torch.equal(p._eqh_gbuf, ref)
 
 
 @pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3)])
