@@ -273,7 +273,7 @@ def main():
     if use_graph:
         ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]
         tgt = tuple(max(e[i] for e in ext) for i in range(3))
-        batches = [pad_batch(b, *tgt).to(dev) for b in host_batches]
+        batches = [pad_batch(b, *tgt).packed().to(dev) for b in host_batches]   # one staging buffer per batch
         for b in batches:
             b.num_real_graphs = a.batch
         trainer = GraphedTrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)

@@ -59,11 +59,44 @@ class HBatch:
     num_graphs: int = 0
 
     def to(self, device, non_blocking: bool = False) -> "HBatch":
+        flat = getattr(self, "_flat", None)
+        if flat is not None:   # packed: ONE transfer, then the same views over the new buffer
+            return self._from_flat(flat.to(device, non_blocking=non_blocking), self._layout)
         kw = {}
         for f in fields(self):
             v = getattr(self, f.name)
             kw[f.name] = v.to(device, non_blocking=non_blocking) if torch.is_tensor(v) else v
-        return HBatch(**kw)
+        out = HBatch(**kw)
+        if hasattr(self, "num_real_graphs"):
+            out.num_real_graphs = self.num_real_graphs
+        return out
+
+    def packed(self) -> "HBatch":
+        """The same batch with every tensor field a view into ONE flat byte buffer (256-byte aligned
+        slots): host-to-device staging and the refresh of a captured graph's static inputs become a
+        single copy instead of one per field."""
+        names = [f.name for f in fields(self) if torch.is_tensor(getattr(self, f.name))]
+        layout, total = [], 0
+        for n in names:
+            t = getattr(self, n)
+            layout.append((n, total, tuple(t.shape), t.dtype))
+            total += (t.numel() * t.element_size() + 255) // 256 * 256
+        flat = torch.empty(max(total, 256), dtype=torch.uint8, device=self.x.device)
+        out = self._from_flat(flat, tuple(layout))
+        for n in names:
+            getattr(out, n).copy_(getattr(self, n))
+        return out
+
+    def _from_flat(self, flat, layout) -> "HBatch":
+        kw = {f.name: getattr(self, f.name) for f in fields(self) if not torch.is_tensor(getattr(self, f.name))}
+        for n, off, shape, dtype in layout:
+            nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            kw[n] = flat[off:off + nbytes].view(dtype).view(shape)
+        out = HBatch(**kw)
+        out._flat, out._layout = flat, layout
+        if hasattr(self, "num_real_graphs"):
+            out.num_real_graphs = self.num_real_graphs
+        return out
 
     def pin_memory(self) -> "HBatch":
         kw = {}

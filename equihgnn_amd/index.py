@@ -29,8 +29,11 @@ class HyperIndex:
         self.nnz = int(vertex.numel())
         self.v32 = vertex.to(torch.int32)
         self.e32 = edges.to(torch.int32)
-        self.by_e = ops.csr_build(edges, vertex, self.M)
-        self.by_v = ops.csr_build(vertex, edges, self.N)
+        problems = [(edges, vertex, self.M), (vertex, edges, self.N)]
+        if batch is not None:
+            problems.append((batch, None, int(num_graphs)))
+        built = ops.csr_build_batch(problems)   # all of them in three launches
+        self.by_e, self.by_v = built[0], built[1]
         deg_v = self.by_v.rowptr[1:] - self.by_v.rowptr[:-1]
         deg_e = self.by_e.rowptr[1:] - self.by_e.rowptr[:-1]
         self.has_v = (deg_v > 0).to(torch.float32).unsqueeze(-1)  # rows a mean leaves at zero
@@ -39,7 +42,7 @@ class HyperIndex:
         if batch is not None:
             self.B = int(num_graphs)
             self.batch32 = batch.to(torch.int32)
-            self.pool = ops.csr_build(batch, None, self.B)
+            self.pool = built[2]
         self._knn = {}
         self._he_pool = None
 

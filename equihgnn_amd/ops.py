@@ -76,6 +76,41 @@ def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col
     return CSR(rowptr, perm[:nnz], col[:nnz], n_rows, nnz)
 
 
+def csr_build_batch(problems):
+    """hg_csr_build_batch: several COO -> CSR builds in three launches.  ``problems`` is a list of
+    (key int64, other int64 or None, n_rows[, col_div]); returns the CSRs in the same order."""
+    n = len(problems)
+    dev = problems[0][0].device
+    _require_gpu(problems[0][0], "csr_build_batch")
+    keys, others, outs = [], [], []
+    for pr in problems:
+        key, other, n_rows = pr[0], pr[1], int(pr[2])
+        assert key.dtype == torch.int64 and key.dim() == 1
+        key = key.contiguous()
+        if other is not None:
+            assert other.dtype == torch.int64 and other.shape == key.shape
+            other = other.contiguous()
+        nnz = key.numel()
+        keys.append(key)
+        others.append(other)
+        outs.append((torch.empty(n_rows + 1, dtype=torch.int32, device=dev),
+                     torch.empty(max(nnz, 1), dtype=torch.int32, device=dev),
+                     torch.empty(max(nnz, 1), dtype=torch.int32, device=dev), n_rows, nnz))
+    i64, i32, vp = ctypes.c_int64 * n, ctypes.c_int32 * n, ctypes.c_void_p * n
+    nnz_a = i64(*[o[4] for o in outs])
+    rows_a = i64(*[o[3] for o in outs])
+    div_a = i32(*[(int(pr[3]) if len(pr) > 3 else 1) for pr in problems])
+    key_a = vp(*[k.data_ptr() for k in keys])
+    oth_a = vp(*[(o.data_ptr() if o is not None else None) for o in others])
+    rp_a, pm_a, cl_a = vp(*[o[0].data_ptr() for o in outs]), vp(*[o[1].data_ptr() for o in outs]), vp(*[o[2].data_ptr() for o in outs])
+    L = hip.lib()
+    ws_bytes = L.hg_csr_build_batch_workspace_bytes(n, nnz_a, rows_a)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    hip.check(L.hg_csr_build_batch(n, key_a, oth_a, nnz_a, rows_a, div_a, rp_a, pm_a, cl_a, _ptr(ws), ws_bytes,
+                                   _stream(dev)), "hg_csr_build_batch")
+    return [CSR(o[0], o[1][:o[4]], o[2][:o[4]], o[3], o[4]) for o in outs]
+
+
 def _segment_reduce(src, idx, rowptr, wptr, n_out, mean: bool) -> torch.Tensor:
     """Raw launch of hg_segment_reduce_f32 on 2-D ``src`` [rows, C]."""
     _require_gpu(src, "segment_reduce")

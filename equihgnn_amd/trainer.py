@@ -279,15 +279,22 @@ class GraphedTrainStep:
         key = self._key(data)
         slot = self.slots.get(key)
         if slot is None:
-            static = type(data)(**{f: (getattr(data, f).clone() if torch.is_tensor(getattr(data, f))
-                                       else getattr(data, f)) for f in data.__dataclass_fields__})
+            if hasattr(data, "packed"):
+                static = data.packed()       # one flat buffer: refreshed by ONE copy per step
+            else:
+                static = type(data)(**{f: (getattr(data, f).clone() if torch.is_tensor(getattr(data, f))
+                                           else getattr(data, f)) for f in data.__dataclass_fields__})
             static.num_real_graphs = getattr(data, "num_real_graphs", None)
             slot = self.slots[key] = self._capture(static)
         st = slot["static"]
-        for f in data.__dataclass_fields__:
-            v = getattr(data, f)
-            if torch.is_tensor(v):
-                getattr(st, f).copy_(v, non_blocking=True)
+        lay = getattr(data, "_layout", None)
+        if lay is not None and lay == getattr(st, "_layout", None):
+            st._flat.copy_(data._flat, non_blocking=True)
+        else:
+            for f in data.__dataclass_fields__:
+                v = getattr(data, f)
+                if torch.is_tensor(v):
+                    getattr(st, f).copy_(v, non_blocking=True)
         slot["bwd"].replay()
         if _world() > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)

@@ -62,6 +62,13 @@ size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows);
 int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
                  int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* n independent builds at once (arrays of n pointers / sizes, same meaning as above): the three CSRs a
+ * model step derives from the batch structure cost 3 launches instead of 18. */
+size_t hg_csr_build_batch_workspace_bytes(int32_t n, const int64_t* nnz, const int64_t* n_rows);
+int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* const* other, const int64_t* nnz,
+                       const int64_t* n_rows, const int32_t* col_div, int32_t* const* rowptr,
+                       int32_t* const* perm, int32_t* const* col, void* workspace, size_t workspace_bytes,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Segmented reduction / row gather — torch_scatter.scatter(src, index, dim=-2, reduce) at

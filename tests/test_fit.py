@@ -75,3 +75,20 @@ def test_early_stopping_and_plateau_schedule():
     res = fitter.fit(MolLoader(mols[:16], 8, False), MolLoader(mols[16:], 8, False), epochs=50)
     assert res.stopped_early and len(res.history) < 50
     assert len(res.history) - 1 - res.best_epoch == 4   # exactly `patience_stop` bad epochs after the best
+
+
+def test_packed_batch_is_a_view_of_one_buffer_and_survives_to():
+    """HBatch.packed(): same values, every tensor field inside one flat buffer; .to() keeps the packing
+    (one transfer) and the extra attributes."""
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    raw = synth_batch(6, 11, "qm9")
+    b = pad_batch(raw, *bucket_sizes(raw.num_nodes, raw.num_hyperedges, raw.nnz))
+    p = b.packed()
+    lo, hi = p._flat.data_ptr(), p._flat.data_ptr() + p._flat.numel()
+    for name in ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order", "batch", "y"):
+        t, u = getattr(b, name), getattr(p, name)
+        assert torch.equal(t, u) and t.dtype == u.dtype
+        assert lo <= u.data_ptr() < hi and (u.data_ptr() - lo) % 256 == 0
+    q = p.to("cpu")
+    assert q._layout == p._layout and torch.equal(q.pos, b.pos) and q.num_real_graphs == b.num_real_graphs
+    assert (q.num_nodes, q.num_hyperedges, q.num_graphs) == (b.num_nodes, b.num_hyperedges, b.num_graphs)

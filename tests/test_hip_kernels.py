@@ -45,6 +45,29 @@ def test_csr_build_matches_stable_sort(nnz, n_rows, seed):
     assert np.array_equal(csr2.col.cpu().numpy(), perm // 3)
 
 
+def test_csr_build_batch_matches_stable_sort():
+    """hg_csr_build_batch: problems of very different shapes in one call (empty, single row with a long
+    row > 2048 entries, more rows than the LDS counters hold -> per-problem fallback, out-of-range keys),
+    each identical to the stable sort."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    shapes = [(0, 5), (37, 50), (5000, 300), (20000, 7), (100000, 40000), (9728, 4864), (73728, 4608)]
+    probs, refs = [], []
+    for i, (nnz, n_rows) in enumerate(shapes):
+        key = rng.integers(0, n_rows, size=nnz)
+        if nnz > 10:
+            key[3] = -1
+            key[7] = n_rows + 4
+        other = rng.integers(0, 1000, size=nnz) if i % 2 == 0 else None
+        probs.append((torch.from_numpy(key).to(DEV), None if other is None else torch.from_numpy(other).to(DEV),
+                      n_rows, 1 if other is not None else 16))
+        refs.append(_np_csr(key, other, n_rows, 1 if other is not None else 16))
+    for csr, (rp, perm, col) in zip(ops.csr_build_batch(probs), refs):
+        assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+        assert np.array_equal(csr.perm.cpu().numpy()[: rp[-1]], perm)
+        assert np.array_equal(csr.col.cpu().numpy()[: rp[-1]], col)
+
+
 def test_csr_build_drops_out_of_range_keys():
     ops = _ops()
     key = np.array([0, 5, -1, 2, 2, 9, 1], dtype=np.int64)
