@@ -60,7 +60,7 @@ extern "C" int eqh_defer_flush(void* stream_) {
     // pointer with a group of a different shape starts a new, later launch
     auto same = [](const EqhReduceDesc& x, const EqhReduceDesc& y) {
         return x.out0 == y.out0 && x.out1 == y.out1 && x.out2 == y.out2 && x.elems == y.elems && x.len0 == y.len0 &&
-               x.len1 == y.len1;
+               x.len1 == y.len1 && x.out_ld == y.out_ld && x.row_len == y.row_len;
     };
     auto touches = [](const EqhReduceDesc& x, const EqhReduceDesc& y) {
         const float* px[3] = {x.out0, x.out1, x.out2};

@@ -55,6 +55,8 @@ struct EqhReduceDesc {
     float* out1;
     float* out2;
     int64_t elems, len0, len1;
+    int64_t out_ld;   // row_len > 0: element e goes to out0[(e / row_len) * out_ld + e % row_len] (2-D block)
+    int row_len;
     int n_slabs;
     int first_block;  // eqh_k_reduce_many: first block of this descriptor in the batched grid
 };
@@ -91,7 +93,7 @@ static __device__ __forceinline__ void eqh_reduce_chunk(const EqhReduceDesc& d, 
         float t = s_part[col];
 #pragma unroll
         for (int g = 1; g < 16; ++g) t += s_part[64 * g + col];
-        float* dst = d.out0 + e;
+        float* dst = d.out0 + (d.row_len > 0 ? (e / d.row_len) * d.out_ld + (e % d.row_len) : e);
         if (d.out1 != nullptr && e >= d.len0)
             dst = (e < d.len0 + d.len1) ? d.out1 + (e - d.len0) : d.out2 + (e - d.len0 - d.len1);
         *dst = accumulate ? *dst + t : t;
@@ -115,9 +117,17 @@ bool eqh_defer_try(hipStream_t stream, const EqhReduceDesc& d);
 static inline int eqh_reduce_slabs3_async(const float* slab, int n_slabs, int64_t elems, float* out0, float* out1,
                                           float* out2, int64_t len0, int64_t len1, int accumulate,
                                           hipStream_t stream) {
-    EqhReduceDesc d{slab, out0, out1, out2, elems, len0, len1, n_slabs, 0};
+    EqhReduceDesc d{slab, out0, out1, out2, elems, len0, len1, 0, 0, n_slabs, 0};
     if (accumulate && eqh_defer_try(stream, d)) return EQH_OK;
     hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(elems, 64, 2048)), dim3(1024), 0, stream, d, accumulate);
+    return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
+}
+// 2-D destination block: rows of row_len elements, out_ld apart
+static inline int eqh_reduce_slabs2d_async(const float* slab, int n_slabs, int64_t rows, int row_len, float* out,
+                                           int64_t out_ld, int accumulate, hipStream_t stream) {
+    EqhReduceDesc d{slab, out, nullptr, nullptr, rows * row_len, rows * row_len, 0, out_ld, row_len, n_slabs, 0};
+    if (accumulate && eqh_defer_try(stream, d)) return EQH_OK;
+    hipLaunchKernelGGL(eqh_k_reduce_slabs, dim3(eqh_grid_for(d.elems, 64, 2048)), dim3(1024), 0, stream, d, accumulate);
     return hipGetLastError() == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
 }
 static inline int eqh_reduce_slabs_async(const float* slab, int n_slabs, int64_t elems, float* out,

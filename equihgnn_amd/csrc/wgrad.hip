@@ -1,0 +1,216 @@
+// Weight gradient of a Linear:  dW[o][i] (+)= alpha * sum_k dy[k][o] * x[k][i]   (dy [K,O], x [K,I], K = rows).
+//
+// Replaces the library GEMM autograd runs for `grad_output.t() @ input` on every nn.Linear of the path
+// (mlp.py:91-99, conv.py:90-97,172-180).  At the BASELINE batch these are [256 x K] . [K x 256] products
+// with K = 4608 .. 9728: 256 output tiles and a long reduction, for which hipBLASLt's best kernel
+// (MT16x16x256, one wavefront per tile, no split of K) reaches 35 TFLOP/s -- 17.4 us each, 21 of them
+// per step, a third of all GEMM time.
+//
+// Here K is split: grid = (64 x 64 output tiles) x (S chunks of K), four wavefronts per workgroup each
+// walking a quarter of the chunk for the same output tile.  Both operands are K-major in memory, which is
+// exactly the MFMA operand order (k in the high lane bits, m / n in the low ones), so they go from global
+// memory straight into the operand registers: lane (r, q) reads ONE float4 of dy[k0+q][o0+4r ..] and one
+// of x[k0+q][i0+4r ..] per 4 rows of K, and component j of the float4 belongs to the j-th of four
+// interleaved 16-row MFMA tiles (rows o0 + 4r + j) -- two fully coalesced 1 KB loads feed sixteen
+// v_mfma_f32_16x16x4_f32.  Loads run three register stages (24 rows of K) ahead.  The four wavefronts' 64 x 64
+// accumulators meet in LDS (wavefront order), each workgroup writes one slab, and the slabs are reduced
+// in chunk order by the common slab reducer -- which can add into the destination (a weight shared by L
+// layer applications) and is deferred to the one batched launch of eqh_defer_flush when active.
+// No atomics: bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256;
+constexpr int WAVES = 4;
+constexpr int AHEAD = 2;  // k-steps (of 4 rows) per register stage
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct Stage {
+    float4 a[AHEAD], b[AHEAD];
+};
+
+// rows k = k0 + 4 t + q, t < AHEAD; rows at or past k_end contribute zeros (address clamped, value masked)
+__device__ __forceinline__ void load_stage(Stage& st, const float* __restrict__ pa, const float* __restrict__ pb,
+                                           int64_t k0, int64_t k_end, int64_t k_clamp, int O, int I, int q) {
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t) {
+        const int64_t k = k0 + 4 * t + q;
+        const int64_t kc = k < k_clamp ? k : k_clamp;
+        float4 a = *reinterpret_cast<const float4*>(pa + kc * O);
+        float4 b = *reinterpret_cast<const float4*>(pb + kc * I);
+        if (k >= k_end) { a = make_float4(0.f, 0.f, 0.f, 0.f); b = a; }
+        st.a[t] = a;
+        st.b[t] = b;
+    }
+}
+
+__global__ void __launch_bounds__(THREADS)
+k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, int O, int I, float* __restrict__ out,
+        int64_t out_ld, int tiles_i, int tiles, int64_t k_chunk, int direct, int accumulate, float alpha) {
+    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  All output tiles of one K-chunk read the same
+    // rows of dy and x, so a chunk's tiles go to ONE XCD: each input byte crosses the fabric once and is
+    // re-read from that XCD's L2 (with tiles spread over XCDs the same rows were fetched into every L2:
+    // 28 MB instead of 9 MB per launch at the BASELINE batch, and the kernel was bound by that).
+    int tile, chunk;
+    const int n_chunks = gridDim.x / tiles;
+    if ((n_chunks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % tiles;
+        chunk = xcd + 8 * (j / tiles);
+    } else {
+        tile = blockIdx.x % tiles;
+        chunk = blockIdx.x / tiles;
+    }
+    const int o0 = 64 * (tile / tiles_i), i0 = 64 * (tile % tiles_i);
+    // this wavefront's rows of K: a quarter of the chunk (multiples of 4)
+    const int64_t k_quarter = k_chunk / WAVES;
+    const int64_t k_beg = (int64_t)chunk * k_chunk + wave * k_quarter;
+    int64_t k_end = k_beg + k_quarter;
+    if (k_end > K) k_end = K;
+    const float* __restrict__ pa = dy + o0 + 4 * r;
+    const float* __restrict__ pb = x + i0 + 4 * r;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k_beg < k_end) {
+        // four register stages in a ring: the loads of stage s+3 are issued before stage s is consumed (a
+        // single stage of look-ahead left every stage waiting ~2000 cycles for its rows: 65 cycles per MFMA
+        // instead of 32)
+        const int64_t k_clamp = K - 1;
+        constexpr int64_t STEP = 4 * AHEAD;
+        Stage s0, s1, s2, s3;
+        load_stage(s0, pa, pb, k_beg, k_end, k_clamp, O, I, q);
+        load_stage(s1, pa, pb, k_beg + STEP, k_end, k_clamp, O, I, q);
+        load_stage(s2, pa, pb, k_beg + 2 * STEP, k_end, k_clamp, O, I, q);
+        auto consume = [&](const Stage& st) {
+#pragma unroll
+            for (int t = 0; t < AHEAD; ++t) {
+                const float av[4] = {st.a[t].x, st.a[t].y, st.a[t].z, st.a[t].w};
+                const float bv[4] = {st.b[t].x, st.b[t].y, st.b[t].z, st.b[t].w};
+#pragma unroll
+                for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+                    for (int jb = 0; jb < 4; ++jb) acc[ja][jb] = mfma16(av[ja], bv[jb], acc[ja][jb]);
+            }
+        };
+        for (int64_t k0 = k_beg; k0 < k_end; k0 += 4 * STEP) {
+            load_stage(s3, pa, pb, k0 + 3 * STEP, k_end, k_clamp, O, I, q);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(s0, pa, pb, k0 + 4 * STEP, k_end, k_clamp, O, I, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + STEP < k_end) consume(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(s1, pa, pb, k0 + 5 * STEP, k_end, k_clamp, O, I, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 2 * STEP < k_end) consume(s2);
+            __builtin_amdgcn_sched_barrier(0);
+            load_stage(s2, pa, pb, k0 + 6 * STEP, k_end, k_clamp, O, I, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (k0 + 3 * STEP < k_end) consume(s3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // acc[ja][jb][g] = C[o0 + 4 (4q + g) + ja][i0 + 4 r + jb].  Every wavefront parks its 64 x 64 partial in
+    // LDS ([row][col] image); then all 256 threads add the four images in wavefront order, a float4 each per
+    // pass (the first version let wavefront 0 do all of it: 4600 cycles of a 23000-cycle kernel).
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(s_acc[wave] + (16 * q + 4 * g + ja) * 64 + 4 * r) =
+                make_float4(acc[ja][0][g], acc[ja][1][g], acc[ja][2][g], acc[ja][3][g]);
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int e = (pass * THREADS + threadIdx.x) * 4;  // element index in the 64 x 64 tile
+        const int row = e >> 6, col = e & 63;
+        float4 v = *reinterpret_cast<const float4*>(s_acc[0] + e);
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) {
+            const float4 u = *reinterpret_cast<const float4*>(s_acc[w] + e);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+        float* dst;
+        if (direct) {  // a single chunk: straight to the destination block
+            dst = out + (int64_t)(o0 + row) * out_ld + i0 + col;
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(dst);
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+        } else {       // slab [chunk][O][I]
+            dst = out + ((int64_t)chunk * O + o0 + row) * I + i0 + col;
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+    }
+}
+
+// chunks of K: enough workgroups to fill the chip, rows per chunk a whole number of register stages
+inline void plan(int64_t K, int O, int I, int* chunks, int64_t* k_chunk) {
+    const int tiles = (O / 64) * (I / 64);
+    int64_t c = 256 / tiles;   // one workgroup per CU (two per CU measured slower: 13.4 vs 12.0 us)
+    if (c < 1) c = 1;
+    int64_t kc = (K + c - 1) / c;
+    kc = (kc + 16 * AHEAD - 1) / (16 * AHEAD) * (16 * AHEAD);   // whole register stages per wavefront
+    if (kc < 64) kc = 64;
+    c = (K + kc - 1) / kc;
+    *chunks = (int)(c < 1 ? 1 : c);
+    *k_chunk = kc;
+}
+
+}  // namespace
+
+extern "C" size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I) {
+    if (K <= 0 || O <= 0 || I <= 0 || (O & 63) || (I & 63)) return 0;
+    int chunks;
+    int64_t kc;
+    plan(K, O, I, &chunks, &kc);
+    return chunks > 1 ? (size_t)chunks * (size_t)O * (size_t)I * sizeof(float) : 16;
+}
+
+extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t I, float alpha,
+                            float* dw, int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                            void* stream_) {
+    if (K < 0 || O <= 0 || I <= 0 || !dw || ldw < I) return EQH_ERR_ARG;
+    if ((O & 63) || (I & 63) || (ldw & 3)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (K == 0) {
+        if (accumulate) return EQH_OK;
+        for (int o = 0; o < O; ++o)
+            if (eqh_zero_async(dw + (int64_t)o * ldw, I, stream)) return EQH_ERR_LAUNCH;
+        return EQH_OK;
+    }
+    if (!dy || !x) return EQH_ERR_ARG;
+    if (!eqh_aligned16(dy) || !eqh_aligned16(x) || !eqh_aligned16(dw)) return EQH_ERR_ALIGN;
+    int chunks;
+    int64_t kc;
+    plan(K, O, I, &chunks, &kc);
+    const int tiles_i = I / 64, tiles = (O / 64) * tiles_i;
+    if (chunks == 1) {
+        hipLaunchKernelGGL(k_wgrad, dim3(tiles), dim3(THREADS), 0, stream, dy, x, K, (int)O, (int)I, dw, ldw, tiles_i,
+                           tiles, kc, 1, (int)accumulate, alpha);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    }
+    if (!workspace || !eqh_aligned16(workspace)) return EQH_ERR_ARG;
+    if (workspace_bytes < hg_wgrad_workspace_bytes(K, O, I)) return EQH_ERR_ARG;
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_wgrad, dim3(tiles * chunks), dim3(THREADS), 0, stream, dy, x, K, (int)O, (int)I, slab,
+                       (int64_t)I, tiles_i, tiles, kc, 0, 0, alpha);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs2d_async(slab, chunks, O, I, dw, ldw, accumulate, stream);
+}

@@ -465,6 +465,39 @@ LINEAR_PARAMS = {}
 ACC_PARAMS = {}   # 1-D parameters (biases, LayerNorm gamma / beta) used through the fused kernels
 
 
+# hg_wgrad_f32 (split-K fp32 MFMA, csrc/wgrad.hip) against the TunableOp-selected library GEMM for the weight
+# gradients: 12.0 us + its share of the batched slab reduction against 17.4 us per [256 x 4608].[4608 x 256]
+# product in isolation, but the training step as a whole measured 2.375 ms with it and 2.354 ms without
+# (its 4.2 MB slabs per product make the end-of-backward reduction the longer kernel), so the library GEMM
+# stays the default.  The kernel remains callable (ops.wgrad, tests, tools/kernel_bench.py).
+USE_WGRAD_KERNEL = False
+
+
+def _wgrad_ok(dy2, x2):
+    return (USE_WGRAD_KERNEL and dy2.is_cuda and dy2.dtype == torch.float32 and x2.dtype == torch.float32
+            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 512)
+
+
+def wgrad(dy2, x2, alpha: float = 1.0, into=None):
+    """alpha * dy2.T @ x2 through hg_wgrad_f32 (split-K fp32 MFMA, fixed order).  ``into``: a [O, I] view
+    (possibly a column block of a wider matrix, unit inner stride) the product is ADDED to; returns None
+    then, else the new [O, I] tensor."""
+    dy2, x2 = _f32c(dy2), _f32c(x2)
+    K, O = dy2.shape
+    I = x2.shape[1]
+    if into is not None:
+        assert into.shape == (O, I) and into.stride(1) == 1
+        out, ld, acc = into, into.stride(0), 1
+    else:
+        out, ld, acc = torch.empty((O, I), dtype=torch.float32, device=dy2.device), I, 0
+    L = hip.lib()
+    ws_bytes = L.hg_wgrad_workspace_bytes(K, O, I)
+    ws = _workspace(max(ws_bytes, 16), dy2.device)
+    hip.check(L.hg_wgrad_f32(_ptr(dy2), _ptr(x2), K, O, I, float(alpha), _ptr(out), ld, acc, _ptr(ws), ws_bytes,
+                             _stream(dy2.device)), "hg_wgrad_f32")
+    return None if into is not None else out
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W[:, c0:c1].T (+ bias): a library GEMM whose WEIGHT gradient, when the parameter
     carries a persistent accumulator (``param._eqh_gbuf``, same shape as the parameter), is
@@ -494,7 +527,9 @@ class _Linear(torch.autograd.Function):
             if gbuf is not None:
                 tgt = gbuf if c0 is None else gbuf[:, c0:c1]
                 side = wgrad_stream(dy.device) if WGRAD_ON_SIDE_STREAM else None
-                if side is None:
+                if side is None and _wgrad_ok(dy2, x2):
+                    wgrad(dy2, x2, into=tgt)
+                elif side is None:
                     tgt.addmm_(dy2.t(), x2)
                 else:
                     # weight gradients are off the critical path of the backward chain: issue them
@@ -506,7 +541,7 @@ class _Linear(torch.autograd.Function):
                     dy2.record_stream(side)
                     x2.record_stream(side)
             elif c0 is None:
-                dw = dy2.t() @ x2
+                dw = wgrad(dy2, x2) if _wgrad_ok(dy2, x2) else dy2.t() @ x2
             else:
                 dw = torch.zeros_like(weight)
                 dw[:, c0:c1] = dy2.t() @ x2
@@ -535,8 +570,12 @@ class _LinearAddC(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             gbuf = getattr(weight, "_eqh_gbuf", None)
-            if gbuf is not None:
+            if gbuf is not None and _wgrad_ok(dy, x):
+                wgrad(dy, x, a, into=gbuf)
+            elif gbuf is not None:
                 gbuf.addmm_(dy.t(), x, alpha=a)
+            elif _wgrad_ok(dy, x):
+                dw = wgrad(dy, x, a)
             else:
                 dw = torch.addmm(weight, dy.t(), x, beta=0.0, alpha=a)
         return dx, dw, (dy if ctx.needs_input_grad[2] else None), None

@@ -219,6 +219,12 @@ int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
  *   (= [w1[:, :C] ; w1[:, C:2C]], zero rows from H to Hp), b_cat [2*Hp] (= [b1 ; 0]),
  *   wd [Hp] (= w1[:, 2C]), w2p [16, Hp]; bwd is the exact adjoint.
  * ------------------------------------------------------------------------------------------- */
+/* Weight gradient of a Linear, dw[o*ldw + i] (+)= alpha * sum_k dy[k*O + o] * x[k*I + i]  (autograd's
+ * grad_output.t() @ input, mlp.py:91-99 / conv.py:90-97,172-180): split-K fp32 MFMA, fixed summation
+ * order.  O and I multiples of 64; dw may be a column block of a wider matrix (ldw >= I, multiple of 4). */
+size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I);
+int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t I, float alpha, float* dw,
+                 int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
 int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
                   int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);

@@ -358,6 +358,25 @@ def test_colsum_matches_float64(R, C):
     np.testing.assert_allclose(acc.cpu().numpy(), (ref + 3.0).cpu().numpy(), rtol=0, atol=2e-6 * max(R, 1) ** 0.5 * 4)
 
 
+@pytest.mark.parametrize("K,O,I", [(1, 64, 64), (70, 64, 128), (513, 128, 64), (4608, 256, 256), (9733, 256, 256),
+                                    (4864, 512, 256), (3000, 2176, 256)])
+def test_wgrad_matches_float64(K, O, I):
+    """hg_wgrad_f32: alpha * dy.T @ x against float64, fresh and accumulated into a column block of a
+    wider matrix; bitwise reproducible."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + O + I)
+    dy, x = torch.randn(K, O, generator=g).to(DEV), torch.randn(K, I, generator=g).to(DEV)
+    ref = dy.double().t() @ x.double()
+    tol = 3e-6 * K ** 0.5 * 4
+    got = ops.wgrad(dy, x)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=tol)
+    assert torch.equal(got, ops.wgrad(dy, x))
+    wide = torch.full((O, 2 * I + 64), 2.0, device=DEV)
+    assert ops.wgrad(dy, x, 0.5, into=wide[:, 64:64 + I]) is None
+    np.testing.assert_allclose(wide[:, 64:64 + I].cpu().numpy(), (0.5 * ref + 2.0).cpu().numpy(), rtol=0, atol=tol)
+    assert float((wide[:, :64] - 2.0).abs().max()) == 0.0 and float((wide[:, 64 + I:] - 2.0).abs().max()) == 0.0
+
+
 def test_fused_ops_accumulate_into_parameter_buffers():
     """With a persistent accumulator on the parameters (what the graphed trainer installs), two uses of
     the same bias / LayerNorm vectors add their gradients in place and hand autograd nothing."""

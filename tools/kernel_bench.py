@@ -130,6 +130,11 @@ def main():
     add("egnn_edge_bwd (recv + send + slabs)", timed(lambda: L.egnn_edge_bwd(
         p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), p(csr_t.rowptr), p(csr_t.perm), N, Hp, p(dab), p(dwd), p(dw2),
         p(dpre2), p(ws4), wsb4, st)), flops=N * 16 * Hp * (3 * 2 * 16 + 40) * 1.0)
+    # weight gradient of a C x C Linear: split-K kernel against the library GEMM
+    dY = torch.randn(N, C, device=dev, generator=g)
+    gacc = torch.zeros(C, C, device=dev)
+    add("hg_wgrad_f32 [C x N].[N x C] (+ slab reduction)", timed(lambda: ops.wgrad(dY, X, into=gacc)), flops=2.0 * N * C * C)
+    add("  library: gacc.addmm_(dY.t(), X)", timed(lambda: gacc.addmm_(dY.t(), X)), flops=2.0 * N * C * C)
     print(f"shapes: N={N} M={M} nnz={nnz} B={ix.B} C={C} Hp={Hp}")
     for r in rows:
         bw = f"{r['GBps']:8.1f} GB/s ({100 * r['frac_hbm']:4.1f}% HBM)" if "GBps" in r else " " * 26
