@@ -171,12 +171,17 @@ def bucket_sizes(n_nodes: int, n_hyperedges: int, n_inc: int, quantum: int = 256
 
 def pad_batch(b: HBatch, n_nodes: int, n_hyperedges: int, n_inc: int) -> HBatch:
     """Pad a batch to fixed extents with ONE extra dummy molecule (graph id B) that owns every
-    padded node, hyperedge and incidence.  Padded atoms sit 10 A apart on a line 10^4 A away, so no
-    real atom ever selects one as a neighbour (each real atom has >= 16 real candidates) and the
-    5 A radius mask drops them; padded rows never mix with real rows in any aggregation, and the
-    loss is taken over the first B outputs only — real-molecule outputs and all parameter gradients
-    are unchanged for models without batch statistics (LayerNorm models: egnn_equihnns,
-    equiformer_equihnns)."""
+    padded node and hyperedge.  Padded atoms sit 10 A apart on a line 10^4 A away, so no real atom
+    ever selects one as a neighbour (each real atom has >= 16 real candidates) and the 5 A radius mask
+    drops them; padded rows never mix with real rows in any aggregation, and the loss is taken over the
+    first B outputs only — real-molecule outputs and all parameter gradients are unchanged for models
+    without batch statistics (LayerNorm models: egnn_equihnns, equiformer_equihnns).
+
+    Padded INCIDENCES are null: both coordinates are -1, which the CSR builders drop (out-of-range keys),
+    so no aggregation ever visits them and the padded nodes / hyperedges have no incidences at all.
+    (Spreading them over the few padded rows instead gave those rows 20-40 incidences each against 2-3
+    for real rows, and the wavefront that owned them ran 10x longer than the rest of the launch: 112 us
+    for a backward kernel that needs 10.)  `HyperIndex` clamps the int32 gather copies to row 0."""
     N, M, nnz, B = b.x.shape[0], b.edge_attr.shape[0], b.edge_index0.shape[0], b.y.shape[0]
     if n_nodes <= N or n_hyperedges <= M or n_inc < nnz:
         raise ValueError("pad_batch: target extents must exceed the batch (nodes and hyperedges strictly)")
@@ -186,9 +191,8 @@ def pad_batch(b: HBatch, n_nodes: int, n_hyperedges: int, n_inc: int) -> HBatch:
     far[:, 0] = 1.0e4 + 10.0 * torch.arange(pn, device=dev, dtype=b.pos.dtype)
     cat = torch.cat
     zl = lambda n, like: torch.zeros((n, *like.shape[1:]), dtype=like.dtype, device=dev)
-    # padded incidences cycle over the padded nodes / hyperedges (bounded degrees)
-    iv = N + (torch.arange(pz, device=dev) % pn)
-    ie = M + (torch.arange(pz, device=dev) % pm)
+    iv = torch.full((pz,), -1, device=dev)
+    ie = torch.full((pz,), -1, device=dev)
     out = HBatch(
         x=cat((b.x, zl(pn, b.x))), pos=cat((b.pos, far)),
         edge_index0=cat((b.edge_index0, iv.to(b.edge_index0.dtype))),

@@ -27,8 +27,10 @@ class HyperIndex:
                  batch: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None):
         self.N, self.M = int(num_nodes), int(num_hyperedges)
         self.nnz = int(vertex.numel())
-        self.v32 = vertex.to(torch.int32)
-        self.e32 = edges.to(torch.int32)
+        # gather indices per incidence; null incidences of a padded batch (-1, dropped by the CSR builds
+        # below) point at row 0 so that code walking ALL incidences stays in bounds
+        self.v32 = vertex.clamp(min=0).to(torch.int32)
+        self.e32 = edges.clamp(min=0).to(torch.int32)
         problems = [(edges, vertex, self.M), (vertex, edges, self.N)]
         if batch is not None:
             problems.append((batch, None, int(num_graphs)))
