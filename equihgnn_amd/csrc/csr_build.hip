@@ -380,6 +380,28 @@ __global__ void __launch_bounds__(LONG_THREADS) k_sort_long_batch(Batch b) {
     }
 }
 
+// per-batch index vectors every layer reads, in ONE launch (the torch expressions they replace were 13
+// elementwise launches per step): int32 copies of the incidence coordinates and of `batch` (null
+// incidences, -1, clamped to row 0) and the 0/1 "row has an incidence" masks of both CSRs
+__global__ void k_index_aux(const int64_t* __restrict__ vertex, const int64_t* __restrict__ edges, int64_t nnz,
+                            const int64_t* __restrict__ batch, int64_t n_nodes, int64_t n_edges,
+                            const int* __restrict__ rowptr_v, const int* __restrict__ rowptr_e,
+                            int* __restrict__ v32, int* __restrict__ e32, int* __restrict__ batch32,
+                            float* __restrict__ has_v, float* __restrict__ has_e) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t p = t0; p < nnz; p += stride) {
+        const int64_t v = vertex[p], e = edges[p];
+        v32[p] = v > 0 ? (int)v : 0;
+        e32[p] = e > 0 ? (int)e : 0;
+    }
+    for (int64_t i = t0; i < n_nodes; i += stride) {
+        if (batch32) batch32[i] = (int)batch[i];
+        has_v[i] = rowptr_v[i + 1] > rowptr_v[i] ? 1.f : 0.f;
+    }
+    for (int64_t i = t0; i < n_edges; i += stride) has_e[i] = rowptr_e[i + 1] > rowptr_e[i] ? 1.f : 0.f;
+}
+
 struct Workspace {
     int* tmp_perm;
     int* cnt;
@@ -525,5 +547,21 @@ extern "C" int hg_csr_build_batch(int32_t n, const int64_t* const* key, const in
             EQH_CHECK_LAUNCH();
         }
     }
+    return EQH_OK;
+}
+
+extern "C" int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
+                            int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
+                            int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e,
+                            void* stream_) {
+    if (nnz < 0 || n_nodes < 0 || n_edges < 0) return EQH_ERR_ARG;
+    if (nnz > 0 && (!vertex || !edges || !v32 || !e32)) return EQH_ERR_ARG;
+    if (n_nodes > 0 && (!rowptr_v || !has_v || (batch32 && !batch))) return EQH_ERR_ARG;
+    if (n_edges > 0 && (!rowptr_e || !has_e)) return EQH_ERR_ARG;
+    const int64_t most = nnz > n_nodes ? (nnz > n_edges ? nnz : n_edges) : (n_nodes > n_edges ? n_nodes : n_edges);
+    if (most == 0) return EQH_OK;
+    hipLaunchKernelGGL(k_index_aux, dim3(eqh_grid_for(most, 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       vertex, edges, nnz, batch, n_nodes, n_edges, rowptr_v, rowptr_e, v32, e32, batch32, has_v, has_e);
+    EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

@@ -27,24 +27,21 @@ class HyperIndex:
                  batch: Optional[torch.Tensor] = None, num_graphs: Optional[int] = None):
         self.N, self.M = int(num_nodes), int(num_hyperedges)
         self.nnz = int(vertex.numel())
-        # gather indices per incidence; null incidences of a padded batch (-1, dropped by the CSR builds
-        # below) point at row 0 so that code walking ALL incidences stays in bounds
-        self.v32 = vertex.clamp(min=0).to(torch.int32)
-        self.e32 = edges.clamp(min=0).to(torch.int32)
         problems = [(edges, vertex, self.M), (vertex, edges, self.N)]
         if batch is not None:
             problems.append((batch, None, int(num_graphs)))
         built = ops.csr_build_batch(problems)   # all of them in three launches
         self.by_e, self.by_v = built[0], built[1]
-        deg_v = self.by_v.rowptr[1:] - self.by_v.rowptr[:-1]
-        deg_e = self.by_e.rowptr[1:] - self.by_e.rowptr[:-1]
-        self.has_v = (deg_v > 0).to(torch.float32).unsqueeze(-1)  # rows a mean leaves at zero
-        self.has_e = (deg_e > 0).to(torch.float32).unsqueeze(-1)
         self.pool = None
         if batch is not None:
             self.B = int(num_graphs)
-            self.batch32 = batch.to(torch.int32)
             self.pool = built[2]
+        # gather indices per incidence (null incidences of a padded batch, -1, point at row 0 so that code
+        # walking ALL incidences stays in bounds), int32 `batch`, and the masks of rows a mean leaves at
+        # zero -- one launch (hg_index_aux)
+        self.v32, self.e32, self.batch32, has_v, has_e = ops.index_aux(vertex, edges, batch, self.N, self.M,
+                                                                       self.by_v.rowptr, self.by_e.rowptr)
+        self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
         self._he_pool = None
 

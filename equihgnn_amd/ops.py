@@ -111,6 +111,23 @@ def csr_build_batch(problems):
     return [CSR(o[0], o[1][:o[4]], o[2][:o[4]], o[3], o[4]) for o in outs]
 
 
+def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr_e):
+    """hg_index_aux: (v32, e32, batch32 or None, has_v [N] float, has_e [M] float)."""
+    _require_gpu(vertex, "index_aux")
+    dev = vertex.device
+    vertex, edges = vertex.contiguous(), edges.contiguous()
+    nnz = vertex.numel()
+    v32 = torch.empty(nnz, dtype=torch.int32, device=dev)
+    e32 = torch.empty(nnz, dtype=torch.int32, device=dev)
+    b32 = torch.empty(n_nodes, dtype=torch.int32, device=dev) if batch is not None else None
+    has_v = torch.empty(n_nodes, dtype=torch.float32, device=dev)
+    has_e = torch.empty(n_edges, dtype=torch.float32, device=dev)
+    hip.check(hip.lib().hg_index_aux(_ptr(vertex), _ptr(edges), nnz, _ptr(batch.contiguous()) if batch is not None else None,
+                                     n_nodes, n_edges, _ptr(rowptr_v), _ptr(rowptr_e), _ptr(v32), _ptr(e32), _ptr(b32),
+                                     _ptr(has_v), _ptr(has_e), _stream(dev)), "hg_index_aux")
+    return v32, e32, b32, has_v, has_e
+
+
 def _segment_reduce(src, idx, rowptr, wptr, n_out, mean: bool) -> torch.Tensor:
     """Raw launch of hg_segment_reduce_f32 on 2-D ``src`` [rows, C]."""
     _require_gpu(src, "segment_reduce")

@@ -64,6 +64,13 @@ int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t 
                  void* workspace, size_t workspace_bytes, void* stream);
 /* n independent builds at once (arrays of n pointers / sizes, same meaning as above): the three CSRs a
  * model step derives from the batch structure cost 3 launches instead of 18. */
+/* The per-batch index vectors the layers read besides the CSRs, in one launch: int32 copies of the
+ * incidence coordinates (null incidences, -1, clamped to 0) and of `batch` (batch32 may be NULL), and
+ * the float 0/1 masks "row has at least one incidence" of the two CSRs (conv.py's mean leaves such rows
+ * at zero, so the bias of the last Linear must not reach them). */
+int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
+                 int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
+                 int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e, void* stream);
 size_t hg_csr_build_batch_workspace_bytes(int32_t n, const int64_t* nnz, const int64_t* n_rows);
 int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* const* other, const int64_t* nnz,
                        const int64_t* n_rows, const int32_t* col_div, int32_t* const* rowptr,
