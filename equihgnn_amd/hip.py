@@ -43,6 +43,8 @@ SIGNATURES = {
     "hg_csr_build_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
     "hg_csr_build_batch": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 8),
+    "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_void_p]),
+    "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

@@ -400,6 +400,19 @@ def defer_flush(device):
     _DEFER["keep"].clear()
 
 
+def copy_many(dsts, srcs):
+    """dst[i].copy_(src[i]) for lists of contiguous fp32 device tensors, in one launch (eqh_copy_many)."""
+    n = len(dsts)
+    if n == 0:
+        return
+    srcs = [_f32c(t) for t in srcs]
+    vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+    for d, t in zip(dsts, srcs):
+        assert d.is_contiguous() and d.numel() == t.numel() and d.dtype == torch.float32
+    hip.check(hip.lib().eqh_copy_many(n, vp(*[t.data_ptr() for t in srcs]), vp(*[d.data_ptr() for d in dsts]),
+                                      i64(*[d.numel() for d in dsts]), _stream(dsts[0].device)), "eqh_copy_many")
+
+
 def _acc_target(param):
     """The persistent gradient accumulator of a parameter (set by the graphed trainer), or None."""
     return getattr(param, "_eqh_gbuf", None) if param is not None else None

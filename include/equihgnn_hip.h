@@ -36,6 +36,16 @@ extern "C" {
 int eqh_version(void);
 const char* eqh_error_string(int code);
 
+/* Optimiser-side helpers of a training step over flat parameter / gradient buffers (main.py:137-140:
+ * torch.optim.Adam).  eqh_adam_step: p, exp_avg, exp_avg_sq updated in place from grad * grad_scale
+ * (+ weight_decay * p); `lr` is a DEVICE float and `state` a 16-byte zero-initialised device block holding
+ * the step counter (advanced by the kernel), so a captured hipGraph follows a learning-rate schedule.
+ * eqh_copy_many: count device-to-device float copies (n[i] elements each) in one launch. */
+int eqh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  const float* lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                  void* state, void* stream);
+int eqh_copy_many(int32_t count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
+
 /* Deferred gradient reductions.  Several backward kernels end in a fixed-order reduction of per-workgroup
  * partial slabs into a parameter gradient; with accumulate != 0 that gradient is only read by the
  * optimiser.  Between eqh_defer_begin(stream) and eqh_defer_flush(stream) such accumulating reductions

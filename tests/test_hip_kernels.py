@@ -377,6 +377,45 @@ def test_wgrad_matches_float64(K, O, I):
     assert float((wide[:, :64] - 2.0).abs().max()) == 0.0 and float((wide[:, 64 + I:] - 2.0).abs().max()) == 0.0
 
 
+def test_flat_adam_matches_torch_adam():
+    """eqh_adam_step (trainer.FlatAdam) against torch.optim.Adam: several steps, L2 weight decay, a
+    learning-rate change through param_groups, a length that is not a multiple of 4."""
+    from equihgnn_amd.trainer import FlatAdam
+    g = torch.Generator().manual_seed(2)
+    n = 70003
+    w0 = torch.randn(n, generator=g)
+    p1 = torch.nn.Parameter(w0.clone().to(DEV))
+    p2 = torch.nn.Parameter(w0.clone().to(DEV))
+    o1 = FlatAdam(p1, lr=1e-2, weight_decay=0.1)
+    o2 = torch.optim.Adam([p2], lr=1e-2, weight_decay=0.1)
+    for t in range(7):
+        gr = torch.randn(n, generator=g).to(DEV) * (0.5 + t)
+        p1.grad, p2.grad = gr.clone(), gr.clone()
+        if t == 4:
+            for o in (o1, o2):
+                o.param_groups[0]["lr"] = 3e-3
+        o1.sync_lr()
+        o1.step()
+        o2.step()
+        np.testing.assert_allclose(p1.detach().cpu().numpy(), p2.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    assert int(o1.state[p1]["step_block"][0]) == 7 and int(o1.state[p1]["step_block"][1]) == 0
+
+
+def test_copy_many():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in (1, 7, 256, 44544, 100000, 3)]
+    flat = torch.zeros(sum(t.numel() for t in srcs) + 64, device=DEV)
+    dsts, off = [], 5
+    for t in srcs:
+        dsts.append(flat[off:off + t.numel()])
+        off += t.numel()
+    ops.copy_many(dsts, srcs)
+    for d, t in zip(dsts, srcs):
+        assert torch.equal(d, t)
+    assert float(flat[:5].abs().max()) == 0.0 and float(flat[off:].abs().max()) == 0.0
+
+
 def test_fused_ops_accumulate_into_parameter_buffers():
     """With a persistent accumulator on the parameters (what the graphed trainer installs), two uses of
     the same bias / LayerNorm vectors add their gradients in place and hand autograd nothing."""
