@@ -21,9 +21,17 @@ import time
 # Library-GEMM algorithm selection: let PyTorch's TunableOp pick, per GEMM shape, the fastest
 # rocBLAS / hipBLASLt solution during the (untimed) warm-up; +13 % step throughput on MI355X for the
 # fp32 [~4.8k x 256] x [256 x 256] shapes of this model (profiles/README.md).  Opt out: EQH_NO_TUNABLEOP=1.
+def _argv_value(flag, default):
+    return sys.argv[sys.argv.index(flag) + 1] if flag in sys.argv[:-1] else default
+
+
+# Methods that run eagerly on unpadded batches (BatchNorm / dropout models) see new GEMM shapes at every
+# step: tuning each of them would cost seconds per step, so they only use the committed selections.
+_EAGER_METHODS = ("mhnnm", "egnn_equihnnm", "faformer_equihnns")
+_static_shapes = _argv_value("--method", "egnn_equihnns") not in _EAGER_METHODS and "--no-graph" not in sys.argv
 if not os.environ.get("EQH_NO_TUNABLEOP"):
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "1" if _static_shapes else "0")
     os.environ.setdefault("PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS", "50")
     os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME",
                           os.path.join(os.environ.get("TMPDIR", "/tmp"), "eqh_tunableop_%d.csv"))
@@ -137,6 +145,60 @@ def measure_scatter_roofline(model, batch, dev):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches_per_step": len(calls), "avg_launch_us": round(avg_ms * 1e3, 2),
             "alg_bytes_per_launch": int(tot_bytes / n)}
+
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def measure_edge_kernels(batch, dev, hidden=256, reps=20):
+    """The other hand-written hot kernels of the step, the fused EGNN edge update (egnn_edge_fwd / _bwd),
+    timed live with HIP events on the batch's own neighbour graph.  FLOPs per launch:
+    forward N*16*Hp*(2*16 + 12), backward N*16*Hp*(3*2*16 + 40); they are bound by fp32 MFMA + VALU issue
+    (the fp32 MFMA shares the VALU pipe, profiles/r01_edge_fwd_notes.md), so the fraction of the MFMA peak
+    is an upper-bound style figure, not a bandwidth one."""
+    from equihgnn_amd import hip, ops
+    from equihgnn_amd.index import HyperIndex
+
+    batch._hyper_index = None
+    ix = HyperIndex.from_batch(batch)
+    nbr, d2, csr_t = ix.knn(batch.pos, 16, 0)
+    N = ix.N
+    H = 2 * (2 * hidden + 1)
+    Hp = H + (-H) % 64
+    g = torch.Generator(device=dev).manual_seed(0)
+    ab = torch.randn(N, 2 * Hp, device=dev, generator=g)
+    wd = torch.randn(Hp, device=dev, generator=g) * 0.1
+    w2 = torch.randn(16, Hp, device=dev, generator=g) / Hp ** 0.5
+    b2 = torch.zeros(16, device=dev)
+    m, pre2 = torch.empty(N, 16, device=dev), torch.empty(N, 16, 16, device=dev)
+    dm = torch.randn(N, 16, device=dev, generator=g)
+    dab, dwd, dw2, dpre2 = torch.empty_like(ab), torch.empty_like(wd), torch.empty_like(w2), torch.empty_like(pre2)
+    L, p, st = hip.lib(), ops._ptr, ops._stream(dev)
+    wsb = L.egnn_edge_bwd_workspace_bytes(N, Hp)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    fwd = lambda: L.egnn_edge_fwd(p(ab), p(wd), p(w2), p(b2), p(nbr), p(d2), N, Hp, p(m), p(pre2), st)
+    bwd = lambda: L.egnn_edge_bwd(p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), p(csr_t.rowptr), p(csr_t.perm),
+                                  N, Hp, p(dab), p(dwd), p(dw2), p(dpre2), p(ws), wsb, st)
+    busy = torch.randn(4096, 4096, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    out = {}
+    for name, fn, flops in (("egnn_edge_fwd", fwd, N * 16 * Hp * (2 * 16 + 12)),
+                            ("egnn_edge_bwd", bwd, N * 16 * Hp * (3 * 2 * 16 + 40))):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(busy, busy)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        tf = flops / us / 1e6
+        out[name] = {"us": round(us, 1), "flops": int(flops), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+    out["bound"] = "mfma"
+    out["nodes"], out["Hp"] = N, Hp
+    return out
 
 
 def saturation_probe(dev, log2_nodes=20, C=256, reps=10, seed=0):
@@ -269,7 +331,7 @@ def main():
     # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
     # largest one (one dummy molecule owns the padding; exact for LayerNorm models).  mhnnm keeps
     # eager launches (its BatchNorm statistics would see the padded rows).
-    use_graph = (not a.no_graph) and a.method not in ("mhnnm", "egnn_equihnnm", "faformer_equihnns")
+    use_graph = (not a.no_graph) and a.method not in _EAGER_METHODS
     if use_graph:
         ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]
         tgt = tuple(max(e[i] for e in ext) for i in range(3))
@@ -330,6 +392,8 @@ def main():
             result["roofline"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
             if world == 1:
                 result["roofline"]["saturation"] = saturation_probe(dev)
+                if a.method == "egnn_equihnns":
+                    result["roofline"]["edge_kernels"] = measure_edge_kernels(batches[0], dev)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(a.method, args_ns, host_batches[0], a.cpu_seconds)
     if world > 1:
