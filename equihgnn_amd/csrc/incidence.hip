@@ -338,17 +338,37 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
         gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
         a_db.v[i] = a_dg.v[i] = a_dbeta.v[i] = f4_zero();
     }
-    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
-        Row<NV> x, g;
-        unsigned pos;
-        float rstd;
-        load_norm<NV>(h, bias, r, 0, C, lane, inv_c, eps, x, pos, &rstd);
-        float m1 = 0.f, m2 = 0.f;
+    // rows r, r + stride, ...: the operands of the next row are in flight while this one is normalised (a
+    // wavefront walks ~5 rows; unpipelined, each waited a full memory latency for h and again for dy)
+    const int stride = gridDim.x * WAVES;
+    int r = blockIdx.x * WAVES + wave;
+    Row<NV> bias_row, nh, nd;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        bias_row.v[i] = (c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+    }
+    auto fetch = [&](int row) {
+        const int rr = row < n_rows ? row : n_rows - 1;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            float4 d = f4_zero();
-            if (c < C) d = *reinterpret_cast<const float4*>(dy + (int64_t)r * C + c);
+            nh.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)rr * C + c) : f4_zero();
+            nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dy + (int64_t)rr * C + c) : f4_zero();
+        }
+    };
+    if (r < n_rows) fetch(r);
+    for (; r < n_rows; r += stride) {
+        const Row<NV> ch = nh, cd = nd;
+        fetch(r + stride);
+        Row<NV> x, g;
+        unsigned pos;
+        float rstd;
+        norm_pair<NV>(ch, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float4 d = cd.v[i];
             f4_add(a_dbeta.v[i], d);
             a_dg.v[i].x = fmaf(d.x, x.v[i].x, a_dg.v[i].x); a_dg.v[i].y = fmaf(d.y, x.v[i].y, a_dg.v[i].y);
             a_dg.v[i].z = fmaf(d.z, x.v[i].z, a_dg.v[i].z); a_dg.v[i].w = fmaf(d.w, x.v[i].w, a_dg.v[i].w);
