@@ -83,7 +83,15 @@ __global__ void __launch_bounds__(256) k_copy_many(CopyBatch b) {
     const float* __restrict__ s = b.src[blockIdx.x];
     float* __restrict__ d = b.dst[blockIdx.x];
     const int n = b.n[blockIdx.x];
-    for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) d[i] = s[i];
+    if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {  // float4 body, scalar tail
+        const int n4 = n >> 2;
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n4; i += gridDim.y * 256)
+            reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        if (blockIdx.y == 0)
+            for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) d[i] = s[i];
+    } else {
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < n; i += gridDim.y * 256) d[i] = s[i];
+    }
 }
 
 }  // namespace
@@ -121,7 +129,7 @@ extern "C" int eqh_copy_many(int32_t count, const float* const* src, float* cons
             if (n[i0 + i] > most) most = n[i0 + i];
         }
         if (most == 0) continue;
-        const int by = (int)((most + 4095) / 4096 < 64 ? (most + 4095) / 4096 : 64);
+        const int by = (int)((most + 4095) / 4096 < 256 ? (most + 4095) / 4096 : 256);  // 16 floats per thread and pass
         hipLaunchKernelGGL(k_copy_many, dim3(m, by), dim3(256), 0, stream, b);
         EQH_CHECK_LAUNCH();
     }
