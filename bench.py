@@ -25,9 +25,10 @@ def _argv_value(flag, default):
     return sys.argv[sys.argv.index(flag) + 1] if flag in sys.argv[:-1] else default
 
 
-# Methods that run eagerly on unpadded batches (BatchNorm / dropout models) see new GEMM shapes at every
-# step: tuning each of them would cost seconds per step, so they only use the committed selections.
-_EAGER_METHODS = ("mhnnm", "egnn_equihnnm", "faformer_equihnns")
+# Methods that run eagerly on unpadded batches see new GEMM shapes at every step: tuning each of them would
+# cost seconds per step, so they only use the committed selections.  (FAFormer: training-mode dropout and a
+# first, unfused version; the BatchNorm models run padded + graphed: their statistics skip the padding.)
+_EAGER_METHODS = ("faformer_equihnns",)
 _static_shapes = _argv_value("--method", "egnn_equihnns") not in _EAGER_METHODS and "--no-graph" not in sys.argv
 if not os.environ.get("EQH_NO_TUNABLEOP"):
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
@@ -329,8 +330,8 @@ def main():
     cfg_id = 2
     host_batches = [synth_batch(a.batch, cfg_id * 1000 + rank * 100 + i, a.flavour) for i in range(a.pool)]
     # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
-    # largest one (one dummy molecule owns the padding; exact for LayerNorm models).  mhnnm keeps
-    # eager launches (its BatchNorm statistics would see the padded rows).
+    # largest one (one dummy molecule owns the padding; exact for the LayerNorm models, and for the
+    # BatchNorm ones because their statistics count the real atoms only).
     use_graph = (not a.no_graph) and a.method not in _EAGER_METHODS
     if use_graph:
         ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]

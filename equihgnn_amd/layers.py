@@ -191,6 +191,34 @@ class MHNNConv(nn.Module):
         return X, E
 
 
+def real_row_mask(data, like):
+    """[N, 1] float mask of the rows that belong to real molecules of a padded batch (batch.pad_batch gives
+    all padded atoms to one extra molecule, id = num_real_graphs), or None for an unpadded batch."""
+    nb = getattr(data, "num_real_graphs", None)
+    if nb is None or nb >= data.y.shape[0]:
+        return None
+    return (data.batch < nb).to(like.dtype).unsqueeze(-1)
+
+
+def batch_norm_rows(bn: nn.BatchNorm1d, x, mask):
+    """nn.BatchNorm1d over node rows (mhnn.py:182,206) whose TRAINING statistics count the real rows only:
+    with it a padded batch gives the real rows the same outputs, the parameters the same gradients and the
+    running buffers the same updates as the unpadded one, so the BatchNorm models can run under hipGraph
+    replay too.  Everything stays on the device (the row count is a device scalar: it changes per batch)."""
+    if mask is None or not bn.training or not bn.track_running_stats or bn.momentum is None:
+        return bn(x)
+    n = mask.sum()
+    mean = (x * mask).sum(0) / n
+    xc = x - mean
+    var = (xc * xc * mask).sum(0) / n                      # biased, as F.batch_norm normalises with
+    y = xc * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+    with torch.no_grad():
+        bn.running_mean.lerp_(mean, bn.momentum)
+        bn.running_var.lerp_(var * (n / (n - 1.0)), bn.momentum)   # unbiased, as nn.BatchNorm1d stores
+        bn.num_batches_tracked.add_(1)
+    return y
+
+
 class MHNNSConv(nn.Module):
     """conv.py:104-182 (node features only, W1..W3, alpha residual to X0)."""
 

@@ -12,7 +12,8 @@ import torch.nn as nn
 from .equiformer import Equiformer
 from .faformer import FAFormer
 from .index import HyperIndex
-from .layers import EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, pool_sum
+from .layers import (EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, batch_norm_rows, pool_sum,
+                     real_row_mask)
 from .registry import registry
 
 _ACT = {"Id": nn.Identity, "relu": nn.ReLU, "prelu": nn.PReLU}
@@ -100,9 +101,10 @@ class MHNNM(nn.Module):
         e = self.bond_encoder(data.edge_attr)
         if taps is not None:
             taps["atom_encoder"] = x
+        mask = real_row_mask(data, x)   # padded batch: BatchNorm statistics over the real atoms only
         for i, layer in enumerate(self.layers):
             x, e = layer(x, e, index)
-            x = self.batch_norms[i](x)
+            x = batch_norm_rows(self.batch_norms[i], x, mask)
             if taps is not None:
                 taps[f"bn{i}"] = x
             if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
@@ -281,9 +283,10 @@ class EGNNEquiHNNM(MHNNM):
         if taps is not None:
             taps["front_end"] = x
         e = self.bond_encoder(data.edge_attr)
+        mask = real_row_mask(data, x)   # padded batch: BatchNorm statistics over the real atoms only
         for i, layer in enumerate(self.layers):
             x, e = layer(x, e, index)
-            x = self.batch_norms[i](x)
+            x = batch_norm_rows(self.batch_norms[i], x, mask)
             if taps is not None:
                 taps[f"bn{i}"] = x
             if i != self.nlayer - 1:

@@ -135,10 +135,11 @@ def test_rigid_motion_invariance():
     np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-4)
 
 
-@pytest.mark.parametrize("method", ["egnn_equihnns", "equiformer_equihnns"])
-def test_padded_batch_is_exact_for_layernorm_models(method):
+@pytest.mark.parametrize("method", ["egnn_equihnns", "equiformer_equihnns", "mhnnm", "egnn_equihnnm"])
+def test_padded_batch_is_exact(method):
     """batch.pad_batch (static shapes for hipGraph replay): outputs of the real molecules and every
-    parameter gradient are unchanged by the padding molecule."""
+    parameter gradient are unchanged by the padding molecule -- also for the BatchNorm models, whose
+    training statistics (and running buffers) count the real atoms only."""
     from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
     from equihgnn_amd.registry import default_args
     args = default_args(method=method, MLP_hidden=64, output_hidden=32)
@@ -148,19 +149,32 @@ def test_padded_batch_is_exact_for_layernorm_models(method):
     b = synth_batch(12, 4242)
     p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64)).to(DEV)
     b = b.to(DEV)
+    p.num_real_graphs = 12
+    buf0 = {n: t.clone() for n, t in m.named_buffers()}
     out = m(b)
     torch.nn.functional.mse_loss(out, b.y).backward()
     g0 = {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}
+    buf1 = {n: t.clone() for n, t in m.named_buffers()}
     for q in m.parameters():
         q.grad = None
+    for n, t in m.named_buffers():
+        t.copy_(buf0[n])
     outp = m(p)
     assert outp.shape[0] == 13
+    for n, t in m.named_buffers():   # BatchNorm running statistics moved exactly as without padding
+        np.testing.assert_allclose(t.cpu().numpy(), buf1[n].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
     torch.nn.functional.mse_loss(outp[:12], p.y[:12]).backward()
-    np.testing.assert_allclose(outp[:12].detach().cpu().numpy(), out.detach().cpu().numpy(), atol=2e-6, rtol=1e-6)
+    # LayerNorm models: the same kernels see the same rows.  BatchNorm models: the masked statistics are a
+    # different (torch-op) evaluation of the same formula as the fused batch_norm kernel -> fp32 rounding,
+    # held to the 1e-5 forward tolerance of the north star
+    bn = method in ("mhnnm", "egnn_equihnnm")
+    np.testing.assert_allclose(outp[:12].detach().cpu().numpy(), out.detach().cpu().numpy(),
+                               atol=1e-5 if bn else 2e-6, rtol=1e-5 if bn else 1e-6)
+    gmax = max(float(g.abs().max()) for g in g0.values())
     for n, q in m.named_parameters():
-        if n in g0:
-            scale = float(g0[n].abs().max()) + 1e-12
-            assert float((q.grad - g0[n]).abs().max()) / scale < 1e-4, n
+        if n in g0:   # (a bias in front of a BatchNorm has an analytically zero gradient: floor the scale)
+            scale = max(float(g0[n].abs().max()), 1e-3 * gmax) + 1e-12
+            assert float((q.grad - g0[n]).abs().max()) / scale < (2e-3 if bn else 1e-4), n
 
 
 def test_graphed_train_step_matches_eager():
