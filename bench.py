@@ -26,9 +26,9 @@ def _argv_value(flag, default):
 
 
 # Methods that run eagerly on unpadded batches see new GEMM shapes at every step: tuning each of them would
-# cost seconds per step, so they only use the committed selections.  (FAFormer: training-mode dropout and a
-# first, unfused version; the BatchNorm models run padded + graphed: their statistics skip the padding.)
-_EAGER_METHODS = ("faformer_equihnns",)
+# cost seconds per step, so they would only use the committed selections.  None is left: the BatchNorm models
+# and FAFormer take their batch / cloud statistics over the real atoms of a padded batch.
+_EAGER_METHODS = ()
 _static_shapes = _argv_value("--method", "egnn_equihnns") not in _EAGER_METHODS and "--no-graph" not in sys.argv
 if not os.environ.get("EQH_NO_TUNABLEOP"):
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")

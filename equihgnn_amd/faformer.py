@@ -73,9 +73,14 @@ def _frame_axes(x, mask=None):
         xm = xc
     else:
         m = mask.unsqueeze(-1).to(x.dtype)
-        center = (x * m).sum(1) / m.sum(1)
-        xc = x - center.unsqueeze(1) * m                                   # masked rows keep raw x (:94)
-        xm = xc * m
+        keep = m > 0
+        zero = x.new_zeros(())
+        # a point set with NO valid member (the far-away atoms of a padded batch: every neighbour is beyond the
+        # radius) gets centre 0 instead of the reference's 0/0 = NaN, which would leak into the weight
+        # gradients through 0 * NaN
+        center = torch.where(keep, x, zero).sum(1) / m.sum(1).clamp(min=1.0)  # (where, not *: masked rows may
+        xc = x - center.unsqueeze(1) * m                                   #  hold anything; they keep raw x, :94)
+        xm = torch.where(keep, xc, zero)
     with torch.no_grad():
         vec = ops.eigh3(torch.bmm(xm.transpose(1, 2), xm))                 # geo_eigh3 (csrc/eigh3.hip)
     return torch.bmm(xc, vec), vec, center
@@ -143,7 +148,7 @@ class MLPAttnEdgeAggregation(nn.Module):
         nn.init.constant_(self.W_gate.weight, 0.0)
         nn.init.constant_(self.W_gate.bias, 1.0)
 
-    def forward(self, tok, geo, edge, g: EdgeGraph):
+    def forward(self, tok, geo, edge, g: EdgeGraph, row_mask=None):
         n, k, h = g.N, g.K, self.h
         q, kk, v = self.layernorm_qkv(tok).chunk(3, -1)
         kv = g.gather(torch.cat((kk, v), -1))                               # one gather for k and v
@@ -159,7 +164,10 @@ class MLPAttnEdgeAggregation(nn.Module):
         out = self.W_output(torch.cat((ctx, ectx), -1)) + tok
         # geometric context: with the reference's frame-0 gather (module docstring) the signed frame
         # average cancels and what is left is the centroid of the cloud, for every atom
-        centre = geo.mean(0, keepdim=True)
+        if row_mask is None:
+            centre = geo.mean(0, keepdim=True)
+        else:   # padded batch (hipGraph replay): the centroid of the real atoms
+            centre = torch.where(row_mask > 0, geo, geo.new_zeros(())).sum(0, keepdim=True) / row_mask.sum()
         # W_frame_agg multiplies the cancelled term: its gradient is rounding noise in the reference;
         # keep it in the autograd graph with an exactly-zero contribution so it gets a (zero) gradient
         # like there, instead of None
@@ -176,8 +184,8 @@ class FAFFN(nn.Module):
         self.ffn = SwiGLUMLP(2 * d, 4 * d, d, drop)
         self.ln = nn.LayerNorm(d)
 
-    def forward(self, tok, geo):
-        y, _, _ = _frame_axes(geo.unsqueeze(0))
+    def forward(self, tok, geo, row_mask=None):
+        y, _, _ = _frame_axes(geo.unsqueeze(0), None if row_mask is None else row_mask.view(1, -1))
         gfeat = self.W_frame.frame_mean(y[0])                               # [N,C]
         return self.ffn(torch.cat((self.ln(tok), gfeat), -1))
 
@@ -189,11 +197,11 @@ class FAFormerEncoderLayer(nn.Module):
         self.ffn = FAFFN(d, proj_drop)
         self.edge_module = EdgeModule(d, d_edge, proj_drop)
 
-    def forward(self, tok, geo, edge, g, last):
-        tok, geo = self.self_attn(tok, geo, edge, g)
+    def forward(self, tok, geo, edge, g, last, row_mask=None):
+        tok, geo = self.self_attn(tok, geo, edge, g, row_mask)
         if not last:
             edge = edge + self.edge_module(tok, geo, g)                     # :602-604
-        return tok + self.ffn(tok, geo), geo, edge                          # :606
+        return tok + self.ffn(tok, geo, row_mask), geo, edge                # :606
 
 
 class FAFormer(nn.Module):
@@ -206,11 +214,13 @@ class FAFormer(nn.Module):
                                      for _ in range(n_layers)])
         self.k, self.radius, self.p = n_neighbors, float(valid_radius), proj_drop
 
-    def forward(self, feats, coords, index: HyperIndex):
+    def forward(self, feats, coords, index: HyperIndex, row_mask=None):
+        """``row_mask`` [N,1] float: 1 for the atoms of real molecules of a padded batch (the two cloud-wide
+        statistics -- the centroid in the attention and the frame of the FFN -- then skip the padding)."""
         tok = F.dropout(self.input_transform(feats), self.p, self.training)
         g = EdgeGraph(coords, index, self.k, self.radius)
         edge = self.edge_module(tok, coords, g)
         geo = coords
         for i, layer in enumerate(self.layers):
-            tok, geo, edge = layer(tok, geo, edge, g, last=(i == len(self.layers) - 1))
+            tok, geo, edge = layer(tok, geo, edge, g, last=(i == len(self.layers) - 1), row_mask=row_mask)
         return tok

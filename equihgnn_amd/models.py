@@ -330,7 +330,7 @@ class FAFormerEquiHNNS(nn.Module):
         x = self.atom_encoder(data.x)
         if taps is not None:
             taps["atom_encoder"] = x
-        x = self.fa_former(x, data.pos, index)
+        x = self.fa_former(x, data.pos, index, real_row_mask(data, x))
         if taps is not None:
             taps["front_end"] = x
         x0 = x
