@@ -50,28 +50,14 @@ __device__ __forceinline__ void load_stage(Stage& st, const float* __restrict__ 
     }
 }
 
-__global__ void __launch_bounds__(THREADS)
-k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, int O, int I, float* __restrict__ out,
-        int64_t out_ld, int tiles_i, int tiles, int64_t k_chunk, int direct, int accumulate, float alpha) {
-    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+// one 64 x 64 output tile over the rows [chunk * k_chunk, (chunk + 1) * k_chunk) of K, by one workgroup
+__device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const float* __restrict__ x, int64_t K,
+                                           int O, int I, float* __restrict__ out, int64_t out_ld, int o0, int i0,
+                                           int chunk, int64_t k_chunk, int direct, int accumulate, float alpha,
+                                           float (*s_acc)[64 * 64]) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  All output tiles of one K-chunk read the same
-    // rows of dy and x, so a chunk's tiles go to ONE XCD: each input byte crosses the fabric once and is
-    // re-read from that XCD's L2 (with tiles spread over XCDs the same rows were fetched into every L2:
-    // 28 MB instead of 9 MB per launch at the BASELINE batch, and the kernel was bound by that).
-    int tile, chunk;
-    const int n_chunks = gridDim.x / tiles;
-    if ((n_chunks & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        tile = j % tiles;
-        chunk = xcd + 8 * (j / tiles);
-    } else {
-        tile = blockIdx.x % tiles;
-        chunk = blockIdx.x / tiles;
-    }
-    const int o0 = 64 * (tile / tiles_i), i0 = 64 * (tile % tiles_i);
     // this wavefront's rows of K: a quarter of the chunk (multiples of 4)
     const int64_t k_quarter = k_chunk / WAVES;
     const int64_t k_beg = (int64_t)chunk * k_chunk + wave * k_quarter;
@@ -159,6 +145,55 @@ k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, in
     }
 }
 
+__global__ void __launch_bounds__(THREADS)
+k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, int O, int I, float* __restrict__ out,
+        int64_t out_ld, int tiles_i, int tiles, int64_t k_chunk, int direct, int accumulate, float alpha) {
+    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch).  All output tiles of one K-chunk read the same
+    // rows of dy and x, so a chunk's tiles go to ONE XCD: each input byte crosses the fabric once and is
+    // re-read from that XCD's L2.
+    int tile, chunk;
+    const int n_chunks = gridDim.x / tiles;
+    if ((n_chunks & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = j % tiles;
+        chunk = xcd + 8 * (j / tiles);
+    } else {
+        tile = blockIdx.x % tiles;
+        chunk = blockIdx.x / tiles;
+    }
+    wgrad_tile(dy, x, K, O, I, out, out_ld, 64 * (tile / tiles_i), 64 * (tile % tiles_i), chunk, k_chunk, direct,
+               accumulate, alpha, s_acc);
+}
+
+// Many weight gradients of the same [O x I] shape in ONE launch (the backward of a model step defers them to
+// its end: 21 products of [256 x K].[K x 256] at the BASELINE batch).  One product alone has too few tiles to
+// fill the chip without a deep split of K, and every split costs a slab; together they fill it with a split
+// of two.  blockIdx.y = product, blockIdx.x = (tile, half of K).
+constexpr int WG_MAX_BATCH = 24;
+struct WgradEntry {
+    const float* dy;
+    const float* x;
+    float* slab;      // [splits][O][I]
+    int64_t K;
+    float alpha;
+    int pad;
+};
+struct WgradBatch {
+    WgradEntry e[WG_MAX_BATCH];
+};
+
+__global__ void __launch_bounds__(THREADS)
+k_wgrad_batch(WgradBatch b, int O, int I, int tiles_i, int tiles, int splits) {
+    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+    const WgradEntry& en = b.e[blockIdx.y];
+    const int tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    int64_t kc = (en.K + splits - 1) / splits;
+    kc = (kc + 16 * AHEAD - 1) / (16 * AHEAD) * (16 * AHEAD);
+    wgrad_tile(en.dy, en.x, en.K, O, I, en.slab, (int64_t)I, 64 * (tile / tiles_i), 64 * (tile % tiles_i), chunk, kc,
+               0, 0, en.alpha, s_acc);
+}
+
 // chunks of K: enough workgroups to fill the chip, rows per chunk a whole number of register stages
 inline void plan(int64_t K, int O, int I, int* chunks, int64_t* k_chunk) {
     const int tiles = (O / 64) * (I / 64);
@@ -213,4 +248,50 @@ extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t 
                        (int64_t)I, tiles_i, tiles, kc, 0, 0, alpha);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs2d_async(slab, chunks, O, I, dw, ldw, accumulate, stream);
+}
+
+/* count products of one shape in one launch: dw[i] (+)= alpha[i] * dy[i].T @ x[i].  Entries that share a
+ * destination must be adjacent (they are summed in array order by one reduction); the workspace holds
+ * count * 2 slabs of O x I floats. */
+extern "C" size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I) {
+    if (count <= 0 || O <= 0 || I <= 0) return 0;
+    return (size_t)count * 2 * (size_t)O * (size_t)I * sizeof(float);
+}
+
+extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K,
+                                  int32_t O, int32_t I, const float* alpha, float* const* dw, const int64_t* ldw,
+                                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (count < 0 || O <= 0 || I <= 0) return EQH_ERR_ARG;
+    if (count == 0) return EQH_OK;
+    if (!dy || !x || !K || !alpha || !dw || !ldw || !workspace) return EQH_ERR_ARG;
+    if ((O & 63) || (I & 63) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_wgrad_batch_workspace_bytes(count, O, I)) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    constexpr int SPLITS = 2;
+    const int tiles_i = I / 64, tiles = (O / 64) * tiles_i;
+    const size_t slab_elems = (size_t)O * I;
+    float* ws = static_cast<float*>(workspace);
+    for (int i0 = 0; i0 < count; i0 += WG_MAX_BATCH) {
+        WgradBatch b;
+        const int m = (count - i0 < WG_MAX_BATCH) ? count - i0 : WG_MAX_BATCH;
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            if (K[j] <= 0 || !dy[j] || !x[j] || !dw[j] || ldw[j] < I || (ldw[j] & 3)) return EQH_ERR_ARG;
+            if (!eqh_aligned16(dy[j]) || !eqh_aligned16(x[j]) || !eqh_aligned16(dw[j])) return EQH_ERR_ALIGN;
+            b.e[i] = WgradEntry{dy[j], x[j], ws + (size_t)j * SPLITS * slab_elems, K[j], alpha[j], 0};
+        }
+        hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
+                           tiles, SPLITS);
+        EQH_CHECK_LAUNCH();
+    }
+    // one reduction per destination: runs of equal (dw, ldw) are adjacent, their slabs contiguous
+    for (int j = 0; j < count;) {
+        int j1 = j + 1;
+        while (j1 < count && dw[j1] == dw[j] && ldw[j1] == ldw[j]) ++j1;
+        const int rc = eqh_reduce_slabs2d_async(ws + (size_t)j * SPLITS * slab_elems, (j1 - j) * SPLITS, O, I, dw[j],
+                                                ldw[j], accumulate, stream);
+        if (rc) return rc;
+        j = j1;
+    }
+    return EQH_OK;
 }

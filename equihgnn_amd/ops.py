@@ -375,7 +375,7 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-_DEFER = {"active": False, "keep": []}
+_DEFER = {"active": False, "keep": [], "wgrad": []}
 
 
 def _workspace(nbytes, device):
@@ -394,10 +394,45 @@ def defer_begin(device):
     _DEFER["active"] = True
 
 
+def wgrad_batch(entries):
+    """hg_wgrad_batch_f32: ``entries`` = [(dy [K,O], x [K,I], alpha, into [O,I] view)], all of one O x I;
+    every product is ADDED to its destination, products with the same destination in list order."""
+    if not entries:
+        return
+    O, I = entries[0][3].shape
+    order = {}
+    for en in entries:   # group by destination, keep first-seen order
+        order.setdefault((en[3].data_ptr(), en[3].stride(0)), []).append(en)
+    flat = [en for grp in order.values() for en in grp]
+    n = len(flat)
+    dys, xs = [_f32c(en[0]) for en in flat], [_f32c(en[1]) for en in flat]
+    vp, i64, f32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_float * n
+    dev = dys[0].device
+    L = hip.lib()
+    ws_bytes = L.hg_wgrad_batch_workspace_bytes(n, O, I)
+    ws = _workspace(ws_bytes, dev)
+    _DEFER["keep"].extend(dys + xs)
+    hip.check(L.hg_wgrad_batch_f32(n, vp(*[t.data_ptr() for t in dys]), vp(*[t.data_ptr() for t in xs]),
+                                   i64(*[t.shape[0] for t in dys]), O, I, f32(*[float(en[2]) for en in flat]),
+                                   vp(*[en[3].data_ptr() for en in flat]), i64(*[en[3].stride(0) for en in flat]), 1,
+                                   _ptr(ws), ws_bytes, _stream(dev)), "hg_wgrad_batch_f32")
+
+
 def defer_flush(device):
-    _DEFER["active"] = False
-    hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
-    _DEFER["keep"].clear()
+    """Run everything that was deferred: first the weight gradients (one batched launch per shape; their slab
+    reductions are themselves deferred), then all slab reductions in one launch."""
+    pending = _DEFER["wgrad"]
+    _DEFER["wgrad"] = []
+    try:
+        by_shape = {}
+        for en in pending:
+            by_shape.setdefault(tuple(en[3].shape), []).append(en)
+        for group in by_shape.values():
+            wgrad_batch(group)
+    finally:
+        _DEFER["active"] = False
+        hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
+        _DEFER["keep"].clear()
 
 
 def copy_many(dsts, srcs):
@@ -495,17 +530,30 @@ LINEAR_PARAMS = {}
 ACC_PARAMS = {}   # 1-D parameters (biases, LayerNorm gamma / beta) used through the fused kernels
 
 
-# hg_wgrad_f32 (split-K fp32 MFMA, csrc/wgrad.hip) against the TunableOp-selected library GEMM for the weight
-# gradients: 12.0 us + its share of the batched slab reduction against 17.4 us per [256 x 4608].[4608 x 256]
-# product in isolation, but the training step as a whole measured 2.375 ms with it and 2.354 ms without
-# (its 4.2 MB slabs per product make the end-of-backward reduction the longer kernel), so the library GEMM
-# stays the default.  The kernel remains callable (ops.wgrad, tests, tools/kernel_bench.py).
-USE_WGRAD_KERNEL = False
+# Weight gradients.  One [256 x K].[K x 256] product has too few output tiles to fill the chip (the library's
+# best kernel runs it at 35 TFLOP/s, 17.4 us; the split-K hg_wgrad_f32 at 12 us plus slabs -- no gain for the
+# step as a whole), but a backward pass has 21 of them and nothing reads them before the optimiser.  While
+# reductions are deferred (graphed trainer) they are therefore only RECORDED here and run together at
+# defer_flush (hg_wgrad_batch_f32): one launch per shape.  Outside deferral the library GEMM is used.
+USE_WGRAD_KERNEL = False      # the single-product kernel (ops.wgrad) for immediate weight gradients
+DEFER_WGRAD = True            # batched weight gradients at defer_flush
+
+
+def _wgrad_shape_ok(dy2, x2):
+    return (dy2.is_cuda and dy2.dtype == torch.float32 and x2.dtype == torch.float32
+            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 512)
 
 
 def _wgrad_ok(dy2, x2):
-    return (USE_WGRAD_KERNEL and dy2.is_cuda and dy2.dtype == torch.float32 and x2.dtype == torch.float32
-            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 512)
+    return USE_WGRAD_KERNEL and _wgrad_shape_ok(dy2, x2)
+
+
+def _wgrad_deferred(dy2, x2, alpha, into) -> bool:
+    """Record alpha * dy2.T @ x2 -> += into for the batched launch at defer_flush; False if not applicable."""
+    if not (DEFER_WGRAD and _DEFER["active"] and into is not None and into.stride(1) == 1 and _wgrad_shape_ok(dy2, x2)):
+        return False
+    _DEFER["wgrad"].append((dy2, x2, alpha, into))
+    return True
 
 
 def wgrad(dy2, x2, alpha: float = 1.0, into=None):
@@ -557,7 +605,9 @@ class _Linear(torch.autograd.Function):
             if gbuf is not None:
                 tgt = gbuf if c0 is None else gbuf[:, c0:c1]
                 side = wgrad_stream(dy.device) if WGRAD_ON_SIDE_STREAM else None
-                if side is None and _wgrad_ok(dy2, x2):
+                if side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
+                    pass
+                elif side is None and _wgrad_ok(dy2, x2):
                     wgrad(dy2, x2, into=tgt)
                 elif side is None:
                     tgt.addmm_(dy2.t(), x2)
@@ -600,7 +650,9 @@ class _LinearAddC(torch.autograd.Function):
         dw = None
         if ctx.needs_input_grad[1]:
             gbuf = getattr(weight, "_eqh_gbuf", None)
-            if gbuf is not None and _wgrad_ok(dy, x):
+            if gbuf is not None and _wgrad_deferred(dy, x, a, gbuf):
+                pass
+            elif gbuf is not None and _wgrad_ok(dy, x):
                 wgrad(dy, x, a, into=gbuf)
             elif gbuf is not None:
                 gbuf.addmm_(dy.t(), x, alpha=a)

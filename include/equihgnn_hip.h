@@ -242,6 +242,13 @@ int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
 size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I);
 int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t I, float alpha, float* dw,
                  int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* count such products of one [O x I] shape in one launch (a training step defers the weight gradients of its
+ * backward pass to the end: 21 products at the BASELINE batch, which fill the chip together where one alone
+ * cannot).  Entries with the same destination must be adjacent; they are added in array order. */
+size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I);
+int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K, int32_t O,
+                       int32_t I, const float* alpha, float* const* dw, const int64_t* ldw, int32_t accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
 int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
                   int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);

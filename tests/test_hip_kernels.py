@@ -377,6 +377,47 @@ def test_wgrad_matches_float64(K, O, I):
     assert float((wide[:, :64] - 2.0).abs().max()) == 0.0 and float((wide[:, 64 + I:] - 2.0).abs().max()) == 0.0
 
 
+def test_wgrad_batch_matches_float64():
+    """hg_wgrad_batch_f32: several products of one shape in one launch, products that share a destination
+    (a shared weight) and a column-block destination, all added in place; and the deferral path of
+    ops.linear (recorded during backward, executed at defer_flush) against immediate autograd."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    O = I = 128
+    wa = torch.full((O, I), 1.0, device=DEV)
+    wide = torch.full((O, 2 * I), -2.0, device=DEV)
+    Ks = [700, 4608, 5120, 513]
+    dys = [torch.randn(K, O, generator=g).to(DEV) for K in Ks]
+    xs = [torch.randn(K, I, generator=g).to(DEV) for K in Ks]
+    ops.defer_begin(DEV)
+    ops.wgrad_batch([(dys[0], xs[0], 1.0, wa), (dys[1], xs[1], 0.5, wide[:, I:]), (dys[2], xs[2], 1.0, wa),
+                     (dys[3], xs[3], 2.0, wide[:, I:])])
+    ops.defer_flush(DEV)
+    ref_a = 1.0 + dys[0].double().t() @ xs[0].double() + dys[2].double().t() @ xs[2].double()
+    ref_b = -2.0 + 0.5 * (dys[1].double().t() @ xs[1].double()) + 2.0 * (dys[3].double().t() @ xs[3].double())
+    np.testing.assert_allclose(wa.cpu().numpy(), ref_a.cpu().numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(wide[:, I:].cpu().numpy(), ref_b.cpu().numpy(), rtol=0, atol=2e-3)
+    assert float((wide[:, :I] + 2.0).abs().max()) == 0.0
+    # through ops.linear: weight with an accumulator, used twice, backward under deferral
+    w = torch.randn(O, I, generator=g).to(DEV).requires_grad_(True)
+    x1 = torch.randn(900, I, generator=g).to(DEV).requires_grad_(True)
+    x2 = torch.randn(1500, I, generator=g).to(DEV).requires_grad_(True)
+
+    def run():
+        return (ops.linear(x1, w).square().sum() + ops.linear(x2, w).sum())
+
+    run().backward()
+    want = w.grad.clone()
+    w.grad = None
+    w._eqh_gbuf = torch.zeros_like(w)
+    ops.defer_begin(DEV)
+    run().backward()
+    assert float(w._eqh_gbuf.abs().max()) == 0.0     # recorded, not yet computed
+    ops.defer_flush(DEV)
+    assert w.grad is None
+    np.testing.assert_allclose(w._eqh_gbuf.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=2e-3)
+
+
 def test_flat_adam_matches_torch_adam():
     """eqh_adam_step (trainer.FlatAdam) against torch.optim.Adam: several steps, L2 weight decay, a
     learning-rate change through param_groups, a length that is not a multiple of 4."""
