@@ -54,7 +54,7 @@ __device__ __forceinline__ void load_stage(Stage& st, const float* __restrict__ 
 __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const float* __restrict__ x, int64_t K,
                                            int O, int I, float* __restrict__ out, int64_t out_ld, int o0, int i0,
                                            int chunk, int64_t k_chunk, int direct, int accumulate, float alpha,
-                                           float (*s_acc)[64 * 64]) {
+                                           float (*s_acc)[64 * 64]) {   // s_acc[2][64 * 64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -110,24 +110,39 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const f
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // acc[ja][jb][g] = C[o0 + 4 (4q + g) + ja][i0 + 4 r + jb].  Every wavefront parks its 64 x 64 partial in
-    // LDS ([row][col] image); then all 256 threads add the four images in wavefront order, a float4 each per
-    // pass (the first version let wavefront 0 do all of it: 4600 cycles of a 23000-cycle kernel).
+    // acc[ja][jb][g] = C[o0 + 4 (4q + g) + ja][i0 + 4 r + jb].  Two LDS images ([row][col], 32 KB: three
+    // workgroups fit a CU; four images allowed only two): wavefronts 2, 3 park their partials, wavefronts 0, 1
+    // add them to their own and park the sums, then all 256 threads add the two images, a float4 each per pass.
+    // Order (w0 + w2) + (w1 + w3): fixed.
+    auto park = [&](float* img) {
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja)
+        for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(s_acc[wave] + (16 * q + 4 * g + ja) * 64 + 4 * r) =
-                make_float4(acc[ja][0][g], acc[ja][1][g], acc[ja][2][g], acc[ja][3][g]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(img + (16 * q + 4 * g + ja) * 64 + 4 * r) =
+                    make_float4(acc[ja][0][g], acc[ja][1][g], acc[ja][2][g], acc[ja][3][g]);
+    };
+    if (wave >= 2) park(s_acc[wave - 2]);
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 u = *reinterpret_cast<const float4*>(s_acc[wave] + (16 * q + 4 * g + ja) * 64 + 4 * r);
+                acc[ja][0][g] += u.x; acc[ja][1][g] += u.y; acc[ja][2][g] += u.z; acc[ja][3][g] += u.w;
+            }
+    }
+    __syncthreads();
+    if (wave < 2) park(s_acc[wave]);
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int e = (pass * THREADS + threadIdx.x) * 4;  // element index in the 64 x 64 tile
         const int row = e >> 6, col = e & 63;
         float4 v = *reinterpret_cast<const float4*>(s_acc[0] + e);
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) {
-            const float4 u = *reinterpret_cast<const float4*>(s_acc[w] + e);
+        {
+            const float4 u = *reinterpret_cast<const float4*>(s_acc[1] + e);
             v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
         }
         v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
@@ -148,7 +163,7 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const f
 __global__ void __launch_bounds__(THREADS)
 k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, int O, int I, float* __restrict__ out,
         int64_t out_ld, int tiles_i, int tiles, int64_t k_chunk, int direct, int accumulate, float alpha) {
-    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_acc[2][64 * 64];
     // Workgroup b runs on XCD b % 8 (round-robin dispatch).  All output tiles of one K-chunk read the same
     // rows of dy and x, so a chunk's tiles go to ONE XCD: each input byte crosses the fabric once and is
     // re-read from that XCD's L2.
@@ -170,6 +185,10 @@ k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, in
 // its end: 21 products of [256 x K].[K x 256] at the BASELINE batch).  One product alone has too few tiles to
 // fill the chip without a deep split of K, and every split costs a slab; together they fill it with a split
 // of two.  blockIdx.y = product, blockIdx.x = (tile, half of K).
+// (Measured and not kept: a 128 x 128 workgroup tile with eight wavefronts so that quadrant pairs share operand
+// rows through L1 -- same 141 us per 21-product batch; a main loop without clamps / masks / 64-bit multiplies --
+// 157 us.  The memory side alone takes 63 us of the 140, the MFMAs 86: they overlap poorly at two wavefronts
+// per SIMD, which is what the 64 KB LDS epilogue buffer allows.)
 constexpr int WG_MAX_BATCH = 24;
 struct WgradEntry {
     const float* dy;
@@ -185,7 +204,7 @@ struct WgradBatch {
 
 __global__ void __launch_bounds__(THREADS)
 k_wgrad_batch(WgradBatch b, int O, int I, int tiles_i, int tiles, int splits) {
-    __shared__ __attribute__((aligned(16))) float s_acc[WAVES][64 * 64];
+    __shared__ __attribute__((aligned(16))) float s_acc[2][64 * 64];
     const WgradEntry& en = b.e[blockIdx.y];
     const int tile = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
     int64_t kc = (en.K + splits - 1) / splits;
@@ -252,10 +271,10 @@ extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t 
 
 /* count products of one shape in one launch: dw[i] (+)= alpha[i] * dy[i].T @ x[i].  Entries that share a
  * destination must be adjacent (they are summed in array order by one reduction); the workspace holds
- * count * 2 slabs of O x I floats. */
+ * count * 3 slabs of O x I floats. */
 extern "C" size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I) {
     if (count <= 0 || O <= 0 || I <= 0) return 0;
-    return (size_t)count * 2 * (size_t)O * (size_t)I * sizeof(float);
+    return (size_t)count * 3 * (size_t)O * (size_t)I * sizeof(float);
 }
 
 extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K,
@@ -267,7 +286,7 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
     if ((O & 63) || (I & 63) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
     if (workspace_bytes < hg_wgrad_batch_workspace_bytes(count, O, I)) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    constexpr int SPLITS = 2;
+    constexpr int SPLITS = 3;  // measured flat between 2 and 6 (2.03-2.06 ms per step); 1 loses 5 %
     const int tiles_i = I / 64, tiles = (O / 64) * tiles_i;
     const size_t slab_elems = (size_t)O * I;
     float* ws = static_cast<float*>(workspace);

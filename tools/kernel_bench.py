@@ -135,6 +135,17 @@ def main():
     gacc = torch.zeros(C, C, device=dev)
     add("hg_wgrad_f32 [C x N].[N x C] (+ slab reduction)", timed(lambda: ops.wgrad(dY, X, into=gacc)), flops=2.0 * N * C * C)
     add("  library: gacc.addmm_(dY.t(), X)", timed(lambda: gacc.addmm_(dY.t(), X)), flops=2.0 * N * C * C)
+    # the 21 deferred weight gradients of one backward pass (7 weights x 3 layer applications) in one launch
+    dYs = [torch.randn(N, C, device=dev, generator=g) for _ in range(21)]
+    Xs = [torch.randn(N, C, device=dev, generator=g) for _ in range(21)]
+    dsts = [torch.zeros(C, C, device=dev) for _ in range(7)]
+
+    def batch21():
+        ops.defer_begin(dev)
+        ops.wgrad_batch([(dYs[i], Xs[i], 1.0, dsts[i % 7]) for i in range(21)])
+        ops.defer_flush(dev)
+
+    add("hg_wgrad_batch_f32, 21 x [C x N].[N x C] (+ reduction)", timed(batch21, reps=10), flops=21 * 2.0 * N * C * C)
     print(f"shapes: N={N} M={M} nnz={nnz} B={ix.B} C={C} Hp={Hp}")
     for r in rows:
         bw = f"{r['GBps']:8.1f} GB/s ({100 * r['frac_hbm']:4.1f}% HBM)" if "GBps" in r else " " * 26
