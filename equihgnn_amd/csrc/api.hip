@@ -27,6 +27,30 @@ __global__ void __launch_bounds__(1024) eqh_k_reduce_many(ReduceBatch b) {
     for (int i = i0; i < i1; ++i) eqh_reduce_chunk(b.d[i], e0, 1, s_part);
 }
 
+// "wide" reductions (weight-gradient slabs: a handful of slabs of 65 536 elements each): one float4 of the
+// destination per thread, the group's slabs added one after the other -- the 64-column x 16-slab-group blocks
+// of the kernel above left most of their threads idle on these (33 us for 16 MB; this takes a quarter).
+__global__ void __launch_bounds__(256) eqh_k_reduce_wide(ReduceBatch b) {
+    int g = 0;
+    while (g + 1 < b.n_groups && (int)blockIdx.x >= b.d[b.g_start[g + 1]].first_block) ++g;  // block-uniform
+    const int i0 = b.g_start[g], i1 = b.g_start[g + 1];
+    const EqhReduceDesc& d0 = b.d[i0];
+    const int64_t e = ((int64_t)((int)blockIdx.x - d0.first_block) * 256 + threadIdx.x) * 4;
+    if (e >= d0.elems) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = i0; i < i1; ++i) {
+        const float* __restrict__ p = b.d[i].slab + e;
+        const int n = b.d[i].n_slabs;
+        for (int s = 0; s < n; ++s) {
+            const float4 u = *reinterpret_cast<const float4*>(p + (int64_t)s * d0.elems);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+    }
+    float* dst = d0.out0 + (d0.row_len > 0 ? (e / d0.row_len) * d0.out_ld + (e % d0.row_len) : e);
+    const float4 old = *reinterpret_cast<const float4*>(dst);
+    *reinterpret_cast<float4*>(dst) = make_float4(old.x + v.x, old.y + v.y, old.z + v.z, old.w + v.w);
+}
+
 std::mutex g_mu;
 std::unordered_map<hipStream_t, std::vector<EqhReduceDesc>> g_deferred;  // key present = deferral active
 
@@ -71,15 +95,27 @@ extern "C" int eqh_defer_flush(void* stream_) {
         return false;
     };
     std::vector<std::vector<EqhReduceDesc>> groups;
-    auto launch_groups = [&]() -> int {
+    auto is_wide = [](const std::vector<EqhReduceDesc>& g) {
+        const EqhReduceDesc& d = g[0];
+        int slabs = 0;
+        for (const EqhReduceDesc& x : g) slabs += x.n_slabs;
+        return d.out1 == nullptr && d.elems >= 4096 && (d.elems & 3) == 0 && (d.row_len & 3) == 0 && (d.out_ld & 3) == 0 &&
+               slabs <= 64 && (((uintptr_t)d.out0 | (uintptr_t)d.slab) & 15) == 0;
+    };
+    auto launch_kind = [&](bool wide) -> int {
         size_t gi = 0;
         while (gi < groups.size()) {
             ReduceBatch b;
             int n = 0, blocks = 0;
             b.n_groups = 0;
-            while (gi < groups.size() && n + (int)groups[gi].size() <= MANY) {
+            bool oversize = false;
+            while (gi < groups.size()) {
+                if (is_wide(groups[gi]) != wide || groups[gi].empty()) { ++gi; continue; }
+                if ((int)groups[gi].size() > MANY) { oversize = true; break; }
+                if (n + (int)groups[gi].size() > MANY) break;
                 b.g_start[b.n_groups++] = n;
-                const int chunks = (int)((groups[gi][0].elems + 63) / 64);
+                const int per = wide ? 1024 : 64;
+                const int chunks = (int)((groups[gi][0].elems + per - 1) / per);
                 for (const EqhReduceDesc& d : groups[gi]) {
                     b.d[n] = d;
                     b.d[n].first_block = blocks;
@@ -88,20 +124,28 @@ extern "C" int eqh_defer_flush(void* stream_) {
                 blocks += chunks;
                 ++gi;
             }
-            if (n == 0) {  // one group larger than a batch: consecutive launches, in order
+            if (n == 0 && oversize) {  // one group larger than a batch: consecutive launches, in order
                 std::vector<EqhReduceDesc>& g = groups[gi];
                 b.n_groups = 1;
                 b.g_start[0] = 0;
                 n = MANY;
                 for (int i = 0; i < MANY; ++i) { b.d[i] = g[i]; b.d[i].first_block = 0; }
-                blocks = (int)((g[0].elems + 63) / 64);
+                const int per = wide ? 1024 : 64;
+                blocks = (int)((g[0].elems + per - 1) / per);
                 g.erase(g.begin(), g.begin() + MANY);
             }
             b.g_start[b.n_groups] = n;
-            if (blocks == 0) continue;
-            hipLaunchKernelGGL(eqh_k_reduce_many, dim3(blocks), dim3(1024), 0, stream, b);
+            if (n == 0 || blocks == 0) continue;
+            if (wide)
+                hipLaunchKernelGGL(eqh_k_reduce_wide, dim3(blocks), dim3(256), 0, stream, b);
+            else
+                hipLaunchKernelGGL(eqh_k_reduce_many, dim3(blocks), dim3(1024), 0, stream, b);
             if (hipGetLastError() != hipSuccess) return EQH_ERR_LAUNCH;
         }
+        return EQH_OK;
+    };
+    auto launch_groups = [&]() -> int {
+        if (launch_kind(false) != EQH_OK || launch_kind(true) != EQH_OK) return EQH_ERR_LAUNCH;
         groups.clear();
         return EQH_OK;
     };
