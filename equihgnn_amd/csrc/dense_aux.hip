@@ -49,6 +49,54 @@ k_colsum_partial(const float* __restrict__ x, const int* __restrict__ rowptr, in
     }
 }
 
+// many column sums in one launch (the bias gradients of a backward pass, deferred to its end):
+// blockIdx.z = entry, (blockIdx.x, blockIdx.y) = (column block, row chunk) of the LARGEST entry -- blocks
+// outside their own entry's extent leave at once
+constexpr int CS_MAX_BATCH = 24;
+struct ColsumEntry {
+    const float* x;
+    const int* rowptr;
+    float* part;
+    int64_t R;
+    int C;
+    int mode;
+};
+struct ColsumBatch {
+    ColsumEntry e[CS_MAX_BATCH];
+};
+
+__global__ void __launch_bounds__(256) k_colsum_partial_batch(ColsumBatch b) {
+    __shared__ float4 s_acc[3][64];
+    const ColsumEntry& en = b.e[blockIdx.z];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + tx) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    if (r0 >= en.R || blockIdx.x * 256 >= en.C) return;   // block-uniform
+    const bool live = c < en.C;
+    float4 v[CS_ROWS / 4];
+#pragma unroll
+    for (int i = 0; i < CS_ROWS / 4; ++i) {
+        const int64_t r = r0 + ty + 4 * i;
+        v[i] = (live && r < en.R) ? *reinterpret_cast<const float4*>(en.x + r * en.C + c) : f4_zero();
+        if (en.mode != 0 && r < en.R) {
+            const int len = en.rowptr[r + 1] - en.rowptr[r];
+            const float w = (en.mode == 1) ? (len > 0 ? 1.f : 0.f) : (float)len;
+            v[i].x *= w; v[i].y *= w; v[i].z *= w; v[i].w *= w;
+        }
+    }
+    float4 a = v[0];
+#pragma unroll
+    for (int i = 1; i < CS_ROWS / 4; ++i) f4_add(a, v[i]);
+    if (ty > 0) s_acc[ty - 1][tx] = a;
+    __syncthreads();
+    if (ty == 0 && live) {
+        f4_add(a, s_acc[0][tx]);
+        f4_add(a, s_acc[1][tx]);
+        f4_add(a, s_acc[2][tx]);
+        *reinterpret_cast<float4*>(en.part + (int64_t)blockIdx.y * en.C + c) = a;
+    }
+}
+
 __global__ void k_pack_fwd(const float* __restrict__ w1, const float* __restrict__ b1,
                            const float* __restrict__ w2, int H, int Hp, int C, float* __restrict__ w_cat,
                            float* __restrict__ b_cat, float* __restrict__ wd, float* __restrict__ w2p) {
@@ -125,6 +173,57 @@ extern "C" int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weig
                        (int)weight_mode, R, (int)C, part);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(part, chunks, C, out, stream, accumulate);
+}
+
+extern "C" size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* R, const int32_t* C) {
+    if (count < 0 || (count > 0 && (!R || !C))) return 0;
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) total += (hg_colsum_workspace_bytes(R[i], C[i]) + 255) & ~(size_t)255;
+    return total;
+}
+
+extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
+                                   const int32_t* weight_mode, const int64_t* R, const int32_t* C,
+                                   float* const* out, void* workspace, size_t workspace_bytes, void* stream_) {
+    if (count < 0) return EQH_ERR_ARG;
+    if (count == 0) return EQH_OK;
+    if (!x || !rowptr || !weight_mode || !R || !C || !out || !workspace) return EQH_ERR_ARG;
+    if (workspace_bytes < hg_colsum_batch_workspace_bytes(count, R, C)) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    char* ws = static_cast<char*>(workspace);
+    for (int i0 = 0; i0 < count; i0 += CS_MAX_BATCH) {
+        ColsumBatch b;
+        const int m = (count - i0 < CS_MAX_BATCH) ? count - i0 : CS_MAX_BATCH;
+        int max_chunks = 0, max_cb = 0, live = 0;
+        float* parts[CS_MAX_BATCH];
+        for (int i = 0; i < m; ++i) {
+            const int j = i0 + i;
+            if (R[j] < 0 || C[j] <= 0 || !out[j] || weight_mode[j] < 0 || weight_mode[j] > 2) return EQH_ERR_ARG;
+            if (weight_mode[j] != 0 && !rowptr[j]) return EQH_ERR_ARG;
+            if ((C[j] & 3) || (R[j] > 0 && (!x[j] || !eqh_aligned16(x[j])))) return EQH_ERR_ALIGN;
+            parts[i] = reinterpret_cast<float*>(ws);
+            ws += (hg_colsum_workspace_bytes(R[j], C[j]) + 255) & ~(size_t)255;
+            const int chunks = (int)((R[j] + CS_ROWS - 1) / CS_ROWS);
+            if (chunks > 65535) return EQH_ERR_RANGE;
+            b.e[i] = ColsumEntry{x[j], rowptr[j], parts[i], R[j], (int)C[j], (int)weight_mode[j]};
+            if (R[j] > 0) ++live;
+            if (chunks > max_chunks) max_chunks = chunks;
+            const int cb = (C[j] / 4 + 63) / 64;
+            if (cb > max_cb) max_cb = cb;
+        }
+        if (live) {
+            hipLaunchKernelGGL(k_colsum_partial_batch, dim3(max_cb, max_chunks, m), dim3(256), 0, stream, b);
+            EQH_CHECK_LAUNCH();
+        }
+        for (int i = 0; i < m; ++i) {   // accumulating reductions (deferred into the batched one when active)
+            const int j = i0 + i;
+            if (R[j] == 0) continue;
+            const int chunks = (int)((R[j] + CS_ROWS - 1) / CS_ROWS);
+            const int rc = eqh_reduce_slabs_async(parts[i], chunks, C[j], out[j], stream, 1);
+            if (rc) return rc;
+        }
+    }
+    return EQH_OK;
 }
 
 extern "C" int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "hg_wgrad_batch_f32": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                      c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hg_colsum_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
+    "hg_colsum_batch_f32": (c_int32, [c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]),
     "hg_colsum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     "egnn_pack_weights_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p] * 5),

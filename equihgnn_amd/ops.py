@@ -375,7 +375,7 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-_DEFER = {"active": False, "keep": [], "wgrad": []}
+_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": []}
 
 
 def _workspace(nbytes, device):
@@ -418,17 +418,40 @@ def wgrad_batch(entries):
                                    _ptr(ws), ws_bytes, _stream(dev)), "hg_wgrad_batch_f32")
 
 
+def colsum_batch(entries):
+    """hg_colsum_batch_f32: ``entries`` = [(x [R,C], rowptr or None, weight_mode, into [C])]; every sum is ADDED
+    to its destination, in one launch."""
+    n = len(entries)
+    if n == 0:
+        return
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int32 * n
+    dev = entries[0][0].device
+    R = i64(*[en[0].shape[0] for en in entries])
+    C = i32(*[en[0].shape[1] for en in entries])
+    L = hip.lib()
+    ws_bytes = L.hg_colsum_batch_workspace_bytes(n, R, C)
+    ws = _workspace(max(ws_bytes, 16), dev)
+    _DEFER["keep"].extend(en[0] for en in entries)
+    hip.check(L.hg_colsum_batch_f32(n, vp(*[en[0].data_ptr() for en in entries]),
+                                    vp(*[(en[1].data_ptr() if en[1] is not None else None) for en in entries]),
+                                    i32(*[int(en[2]) for en in entries]), R, C, vp(*[en[3].data_ptr() for en in entries]),
+                                    _ptr(ws), ws_bytes, _stream(dev)), "hg_colsum_batch_f32")
+
+
 def defer_flush(device):
-    """Run everything that was deferred: first the weight gradients (one batched launch per shape; their slab
-    reductions are themselves deferred), then all slab reductions in one launch."""
+    """Run everything that was deferred: first the weight and bias gradients (one batched launch per shape /
+    one for all column sums; their slab reductions are themselves deferred), then all slab reductions."""
     pending = _DEFER["wgrad"]
     _DEFER["wgrad"] = []
+    sums = _DEFER["colsum"]
+    _DEFER["colsum"] = []
     try:
         by_shape = {}
         for en in pending:
             by_shape.setdefault(tuple(en[3].shape), []).append(en)
         for group in by_shape.values():
             wgrad_batch(group)
+        colsum_batch(sums)
     finally:
         _DEFER["active"] = False
         hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
@@ -477,6 +500,9 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
         return None
     x = _f32c(x)
     R, C = x.shape
+    if into is not None and _DEFER["active"] and DEFER_WGRAD:
+        _DEFER["colsum"].append((x, rowptr, weight_mode, into))   # runs with all the others at defer_flush
+        return None
     L = hip.lib()
     out = into if into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws_bytes = L.hg_colsum_workspace_bytes(R, C)

@@ -252,6 +252,12 @@ int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
 int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
                   int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* count row-weighted column sums in one launch, each ADDED to its out[i] (the bias gradients of a backward
+ * pass, deferred to its end like the weight gradients). */
+size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* R, const int32_t* C);
+int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
+                        const int32_t* weight_mode, const int64_t* R, const int32_t* C, float* const* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hp,
                           int32_t C, float* w_cat, float* b_cat, float* wd, float* w2p, void* stream);
 int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd, const float* dw2p,

@@ -356,6 +356,17 @@ def test_colsum_matches_float64(R, C):
     acc = torch.full((C,), 3.0, device=DEV)
     assert ops.colsum(x, into=acc) is None
     np.testing.assert_allclose(acc.cpu().numpy(), (ref + 3.0).cpu().numpy(), rtol=0, atol=2e-6 * max(R, 1) ** 0.5 * 4)
+    # deferred: several accumulating sums (one with row weights) recorded, then ONE batched launch at the flush
+    acc2, acc3 = torch.full((C,), 3.0, device=DEV), torch.zeros(C, device=DEV)
+    ops.defer_begin(DEV)
+    ops.colsum(x, into=acc2)
+    ops.colsum(x, rowptr, 2, into=acc3)
+    ops.colsum(x, into=acc3)
+    assert float((acc2 - 3.0).abs().max()) == 0.0
+    ops.defer_flush(DEV)
+    assert torch.equal(acc2, acc)
+    want3 = (x.double() * lens.double().to(DEV)[:, None]).sum(0) + ref
+    np.testing.assert_allclose(acc3.cpu().numpy(), want3.cpu().numpy(), rtol=0, atol=4e-5 * max(R, 1) ** 0.5)
 
 
 @pytest.mark.parametrize("K,O,I", [(1, 64, 64), (70, 64, 128), (513, 128, 64), (4608, 256, 256), (9733, 256, 256),
