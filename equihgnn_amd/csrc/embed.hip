@@ -6,15 +6,19 @@
 // fwd: HBM/L2-bound row gather: F table rows (1 KiB each at C=256) summed per node in registers.
 // bwd: d table[g,:] = sum over nodes whose feature value selects row g of d out[n,:].  A table
 //      row can be selected by thousands of nodes (e.g. the 2-row "is aromatic" table), so the sum
-//      is split over node chunks: pass 1 writes per-(chunk,row) partial sums, pass 2 adds the
-//      partials in chunk order.  No atomics; bitwise reproducible.
+//      is split over chunks of 128 nodes: a workgroup (table row, chunk) first COMPACTS the ids of
+//      its matching nodes (ballot + prefix: node order), then its four wavefronts add those rows
+//      with four loads in flight each -- the first version tested node after node and loaded a row
+//      only after the comparison (one dependent memory latency per node: 60 us) -- and the
+//      per-chunk partial sums are added in chunk order by the common slab reducer (optionally
+//      into the destination: the tables are parameters).  No atomics; bitwise reproducible.
 #include "common.h"
 
 namespace {
 
 constexpr int THREADS = 256;
 constexpr int MAX_F = 16;
-constexpr int BWD_CHUNK = 512;  // nodes per partial sum
+constexpr int BWD_CHUNK = 128;  // nodes per partial sum (two wavefronts' worth of comparisons)
 
 struct Offsets { int off[MAX_F + 1]; };
 
@@ -47,36 +51,49 @@ k_embed_bwd_partial(const int64_t* __restrict__ x, const float* __restrict__ dou
                     int F, int64_t N, int C, int table_rows, float* __restrict__ part) {
     constexpr int SUBS = THREADS / LPR;
     __shared__ float4 s_acc[THREADS];
+    __shared__ int s_list[BWD_CHUNK];
+    __shared__ int s_cnt[2];
     const int g = blockIdx.x, chunk = blockIdx.y;
     int f = 0;
     for (int t = 1; t < F; ++t)
         if (g >= offs.off[t]) f = t;
     const int64_t value = g - offs.off[f];
-    const int sub = threadIdx.x / LPR, sl = threadIdx.x % LPR;
     const int64_t n0 = (int64_t)chunk * BWD_CHUNK;
-    const int64_t n1 = (n0 + BWD_CHUNK < N) ? n0 + BWD_CHUNK : N;
+    // compaction: threads 0..127 (wavefronts 0, 1) test one node each; matching ids in node order
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool hit = false;
+    if (threadIdx.x < BWD_CHUNK) {
+        const int64_t n = n0 + threadIdx.x;
+        hit = n < N && x[n * F + f] == value;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (wave < 2 && lane == 0) s_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (hit) s_list[(wave == 1 ? s_cnt[0] : 0) + __popcll(mask & ((1ull << lane) - 1ull))] = threadIdx.x;
+    __syncthreads();
+    const int m = s_cnt[0] + s_cnt[1];
+    const int sub = threadIdx.x / LPR, sl = threadIdx.x % LPR;
     for (int c = sl * 4; c < C; c += LPR * 4) {
-        float4 acc = f4_zero();
-        for (int64_t n = n0 + sub; n < n1; n += SUBS)
-            if (x[n * F + f] == value) f4_add(acc, *reinterpret_cast<const float4*>(dout + n * C + c));
-        s_acc[threadIdx.x] = acc;
+        float4 a0 = f4_zero(), a1 = f4_zero(), a2 = f4_zero(), a3 = f4_zero();
+        int i = sub;
+        for (; i + 3 * SUBS < m; i += 4 * SUBS) {   // four independent row loads in flight
+            const float4 v0 = *reinterpret_cast<const float4*>(dout + (n0 + s_list[i]) * C + c);
+            const float4 v1 = *reinterpret_cast<const float4*>(dout + (n0 + s_list[i + SUBS]) * C + c);
+            const float4 v2 = *reinterpret_cast<const float4*>(dout + (n0 + s_list[i + 2 * SUBS]) * C + c);
+            const float4 v3 = *reinterpret_cast<const float4*>(dout + (n0 + s_list[i + 3 * SUBS]) * C + c);
+            f4_add(a0, v0); f4_add(a1, v1); f4_add(a2, v2); f4_add(a3, v3);
+        }
+        for (; i < m; i += SUBS) f4_add(a0, *reinterpret_cast<const float4*>(dout + (n0 + s_list[i]) * C + c));
+        f4_add(a0, a1);
+        f4_add(a2, a3);
+        f4_add(a0, a2);
+        s_acc[threadIdx.x] = a0;
         __syncthreads();
         if (sub == 0) {
-            for (int s = 1; s < SUBS; ++s) f4_add(acc, s_acc[s * LPR + sl]);
-            *reinterpret_cast<float4*>(part + ((int64_t)chunk * table_rows + g) * C + c) = acc;
+            for (int s = 1; s < SUBS; ++s) f4_add(a0, s_acc[s * LPR + sl]);
+            *reinterpret_cast<float4*>(part + ((int64_t)chunk * table_rows + g) * C + c) = a0;
         }
         __syncthreads();
-    }
-}
-
-__global__ void k_embed_bwd_final(const float* __restrict__ part, int n_chunks, int64_t row_elems,
-                                  float* __restrict__ dtable) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < row_elems; i += stride) {
-        float4 acc = f4_zero();
-        for (int k = 0; k < n_chunks; ++k)
-            f4_add(acc, *reinterpret_cast<const float4*>(part + (int64_t)k * row_elems + i * 4));
-        *reinterpret_cast<float4*>(dtable + i * 4) = acc;
     }
 }
 
@@ -131,7 +148,7 @@ extern "C" size_t hg_embed_sum_bwd_workspace_bytes(int64_t N, int32_t C, int64_t
 
 extern "C" int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32_t* off_host,
                                 int32_t F, int64_t N, int32_t C, int64_t table_rows, float* dtable,
-                                void* workspace, size_t workspace_bytes, void* stream_) {
+                                int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
     if (N < 0 || C <= 0 || table_rows <= 0 || !dtable) return EQH_ERR_ARG;
     Offsets o;
     int rc = fill_offsets(o, off_host, F, table_rows);
@@ -140,9 +157,7 @@ extern "C" int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32
         return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t row_elems = table_rows * C;
-    if (N == 0) {
-        return eqh_zero_async(dtable, row_elems, stream);
-    }
+    if (N == 0) return accumulate ? EQH_OK : eqh_zero_async(dtable, row_elems, stream);
     if (!x || !dout || !workspace) return EQH_ERR_ARG;
     if (workspace_bytes < hg_embed_sum_bwd_workspace_bytes(N, C, table_rows)) return EQH_ERR_ARG;
     const int n_chunks = (int)((N + BWD_CHUNK - 1) / BWD_CHUNK);
@@ -156,8 +171,5 @@ extern "C" int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32
         return EQH_OK;
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(k_embed_bwd_final, dim3(eqh_grid_for(row_elems / 4, 256, 1024)), dim3(256), 0,
-                       stream, part, n_chunks, row_elems, dtable);
-    EQH_CHECK_LAUNCH();
-    return EQH_OK;
+    return eqh_reduce_slabs_async(part, n_chunks, row_elems, dtable, stream, accumulate);
 }

@@ -24,8 +24,8 @@ SIGNATURES = {
     "hg_embed_sum_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
                                    c_void_p, c_void_p]),
     "hg_embed_sum_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int64]),
-    "hg_embed_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
-                                   c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hg_embed_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_int32,
+                                   c_void_p, c_size_t, c_void_p]),
     "geo_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "egnn_edge_fwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "egnn_edge_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),

@@ -49,8 +49,9 @@ class AtomEncoder(nn.Module):
         self.offsets = tuple(offs)
 
     def forward(self, x):
-        table = torch.cat([e.weight for e in self.atom_embedding_list], 0)
-        return ops.embed_sum(x, table, self.offsets)
+        # the nine weights go in as they are: back to back in the trainer's flat parameter buffer their
+        # concatenation is a view, and the backward adds into their (equally contiguous) accumulators
+        return ops.embed_sum(x, [e.weight for e in self.atom_embedding_list], self.offsets)
 
 
 class BondEncoder(nn.Embedding):

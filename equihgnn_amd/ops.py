@@ -204,12 +204,32 @@ class _GatherRows(torch.autograd.Function):
         return _segment_reduce(dout, csr.perm, csr.rowptr, None, csr.n_rows, False), None, None
 
 
+def _contiguous_run(ts):
+    """True if the tensors sit back to back in one storage, in order (each contiguous)."""
+    for a, b in zip(ts[:-1], ts[1:]):
+        if not (a.is_contiguous() and b.is_contiguous() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+                and b.storage_offset() == a.storage_offset() + a.numel()):
+            return False
+    return ts[0].is_contiguous()
+
+
+def _stacked_view(ts):
+    """[sum rows, C] view over tensors for which _contiguous_run holds (no copy)."""
+    rows = sum(t.shape[0] for t in ts)
+    return torch.as_strided(ts[0].detach(), (rows, ts[0].shape[1]), (ts[0].shape[1], 1), ts[0].storage_offset())
+
+
 class _EmbedSum(torch.autograd.Function):
+    """out[n] = sum_f table_f[x[n, f]] over F embedding tables given as separate [rows_f, C] weights
+    (hg_embed_sum_fwd/bwd on their row-wise concatenation).  When the weights lie back to back in memory
+    (the graphed trainer lays all parameters out in one flat buffer) the concatenation is a view, and when
+    their gradient accumulators do too the backward adds straight into them: no cat, no split, no copy."""
+
     @staticmethod
-    def forward(ctx, x, table, offsets):
-        _require_gpu(table, "embed_sum")
+    def forward(ctx, x, offsets, *tables):
+        _require_gpu(tables[0], "embed_sum")
         x = x.contiguous()
-        table = _f32c(table)
+        table = _stacked_view(tables) if _contiguous_run(tables) else torch.cat([_f32c(t) for t in tables], 0)
         N, F = x.shape
         C = table.shape[1]
         off = (ctypes.c_int32 * F)(*offsets)
@@ -217,7 +237,7 @@ class _EmbedSum(torch.autograd.Function):
         hip.check(hip.lib().hg_embed_sum_fwd(_ptr(x), _ptr(table), off, F, N, C, table.shape[0],
                                              _ptr(out), _stream(table.device)), "hg_embed_sum_fwd")
         ctx.save_for_backward(x)
-        ctx.offsets, ctx.rows = offsets, table.shape[0]
+        ctx.offsets, ctx.rows, ctx.tables = offsets, table.shape[0], tables
         return out
 
     @staticmethod
@@ -228,12 +248,22 @@ class _EmbedSum(torch.autograd.Function):
         C = dout.shape[1]
         L = hip.lib()
         off = (ctypes.c_int32 * F)(*ctx.offsets)
-        dtable = torch.empty((ctx.rows, C), dtype=torch.float32, device=dout.device)
+        accs = [_acc_target(t) for t in ctx.tables]
+        have = all(a is not None for a in accs)
+        direct = have and _contiguous_run(accs)
+        dtable = _stacked_view(accs) if direct else torch.empty((ctx.rows, C), dtype=torch.float32, device=dout.device)
         ws_bytes = L.hg_embed_sum_bwd_workspace_bytes(N, C, ctx.rows)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dout.device)
-        hip.check(L.hg_embed_sum_bwd(_ptr(x), _ptr(dout), off, F, N, C, ctx.rows, _ptr(dtable), _ptr(ws),
-                                     ws_bytes, _stream(dout.device)), "hg_embed_sum_bwd")
-        return None, dtable, None
+        ws = _workspace(ws_bytes, dout.device)
+        hip.check(L.hg_embed_sum_bwd(_ptr(x), _ptr(dout), off, F, N, C, ctx.rows, _ptr(dtable), 1 if direct else 0,
+                                     _ptr(ws), ws_bytes, _stream(dout.device)), "hg_embed_sum_bwd")
+        if direct:
+            return (None, None) + (None,) * len(ctx.tables)
+        parts = torch.split(dtable, [t.shape[0] for t in ctx.tables], 0)
+        if have:   # accumulators present but scattered (the trainer's probe pass): add piece by piece
+            for a, g in zip(accs, parts):
+                a.add_(g)
+            return (None, None) + (None,) * len(ctx.tables)
+        return (None, None) + tuple(parts)
 
 
 class _EgnnEdge(torch.autograd.Function):
@@ -793,11 +823,24 @@ def gather_rows(src, key32, csr: CSR):
     return out.reshape(*lead, *out.shape)
 
 
-def embed_sum(x, table, offsets):
-    """out[n] = sum_f table[offsets[f] + x[n, f]] (ogb AtomEncoder order)."""
+def embed_sum(x, tables, offsets=None):
+    """out[n] = sum_f tables[f][x[n, f]] (ogb AtomEncoder order).  ``tables``: one [rows, C] weight or a
+    sequence of F of them (the PARAMETERS, so that their gradient accumulators can be found)."""
     if x.dim() == 1:
         x = x[:, None]
-    return _EmbedSum.apply(x, table, tuple(int(o) for o in offsets))
+    if torch.is_tensor(tables):
+        tables = (tables,)
+    tables = tuple(tables)
+    if offsets is None:
+        offsets, run = [], 0
+        for t in tables:
+            offsets.append(run)
+            run += t.shape[0]
+    if torch.is_grad_enabled():
+        for t in tables:
+            if t.requires_grad and t.is_leaf:
+                ACC_PARAMS[id(t)] = t
+    return _EmbedSum.apply(x, tuple(int(o) for o in offsets), *tables)
 
 
 def knn(pos, k: int, mode: int):

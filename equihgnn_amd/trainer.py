@@ -227,8 +227,7 @@ class GraphedTrainStep:
         autograd add kernels.  A probe pass drops any parameter that autograd still produces a gradient
         for (i.e. that is also used some other way)."""
         from . import ops
-        cand = [p for p in live if (id(p) in ops.LINEAR_PARAMS and p.dim() == 2)
-                or (id(p) in ops.ACC_PARAMS and p.dim() == 1)]
+        cand = [p for p in live if (id(p) in ops.LINEAR_PARAMS and p.dim() == 2) or id(p) in ops.ACC_PARAMS]
         dev, dt = live[0].device, live[0].dtype
         if cand:
             probe = torch.zeros(sum(p.numel() for p in cand), dtype=dt, device=dev)

@@ -120,8 +120,8 @@ int hg_embed_sum_fwd(const int64_t* x, const float* table, const int32_t* off_ho
  * bitwise reproducible.  dtable is fully overwritten. */
 size_t hg_embed_sum_bwd_workspace_bytes(int64_t N, int32_t C, int64_t table_rows);
 int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32_t* off_host, int32_t F,
-                     int64_t N, int32_t C, int64_t table_rows, float* dtable, void* workspace,
-                     size_t workspace_bytes, void* stream);
+                     int64_t N, int32_t C, int64_t table_rows, float* dtable, int32_t accumulate,
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * k nearest neighbours over the whole batch point cloud.

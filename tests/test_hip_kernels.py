@@ -185,6 +185,26 @@ def test_embed_sum_vs_oracle(C):
     np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().numpy(), atol=1e-6, rtol=1e-6)
     for a, b in zip(mine.atom_embedding_list, ref.atom_embedding_list):
         np.testing.assert_allclose(a.weight.grad.cpu().numpy(), b.weight.grad.numpy(), atol=2e-4, rtol=1e-5)
+    # the layout of the graphed trainer: the nine weights back to back in ONE buffer and their gradient
+    # accumulators too -> the table is a view, the backward adds in place, used twice = twice the gradient
+    ops = _ops()
+    ws = [e.weight for e in mine.atom_embedding_list]
+    flat_p = torch.cat([t.detach().reshape(-1) for t in ws])
+    flat_g = torch.zeros_like(flat_p)
+    off = 0
+    for t in ws:
+        t.grad = None
+        t.data = flat_p[off:off + t.numel()].view_as(t)
+        t._eqh_gbuf = flat_g[off:off + t.numel()].view_as(t)
+        off += t.numel()
+    assert ops._contiguous_run(ws)
+    o2 = mine(x.to(DEV))
+    assert torch.equal(o2, o)
+    ((o2 + mine(x.to(DEV))) * w.to(DEV)).sum().backward()
+    off = 0
+    for a, b in zip(mine.atom_embedding_list, ref.atom_embedding_list):
+        assert a.weight.grad is None
+        np.testing.assert_allclose(a.weight._eqh_gbuf.cpu().numpy(), 2 * b.weight.grad.numpy(), atol=4e-4, rtol=1e-5)
 
 
 @pytest.mark.parametrize("N,seed", [(16, 0), (17, 1), (200, 2), (1000, 3), (4632, 4)])

@@ -12,6 +12,7 @@ rate, the cache-exceeding figure is bench.py's `roofline.saturation`.
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -113,6 +114,12 @@ def main():
     table = torch.randn(174, C, device=dev, generator=g)
     offs = (0, 119, 124, 136, 148, 158, 164, 170, 172)
     add("hg_embed_sum_fwd", timed(lambda: ops.embed_sum(xi, table, offs)), nbytes=(9 * 4 * C + 72 + 4 * C) * N)
+    dtab = torch.empty_like(table)
+    off9 = (ctypes.c_int32 * 9)(*offs)
+    wsb5 = L.hg_embed_sum_bwd_workspace_bytes(N, C, 174)
+    ws5 = torch.empty(wsb5, dtype=torch.uint8, device=dev)
+    add("hg_embed_sum_bwd (+ slab reduction)", timed(lambda: L.hg_embed_sum_bwd(p(xi), p(X), off9, 9, N, C, 174, p(dtab), 0,
+                                                                               p(ws5), wsb5, st)), nbytes=9 * 4 * C * N)
     # fused EGNN edge kernels
     H = 2 * (2 * C + 1)
     Hp = H + (-H) % 64
