@@ -162,9 +162,11 @@ def collate(mols: Sequence[HMol]) -> HBatch:
     )
 
 
-def bucket_sizes(n_nodes: int, n_hyperedges: int, n_inc: int, quantum: int = 256):
+def bucket_sizes(n_nodes: int, n_hyperedges: int, n_inc: int, quantum: int = 128):
     """Static shapes for hipGraph replay: round each extent up to a multiple of ``quantum`` with
-    at least one spare slot (the padding molecule needs a node and a hyperedge of its own)."""
+    at least one spare slot (the padding molecule needs a node and a hyperedge of its own).  The quantum
+    trades padded rows (every kernel and GEMM of the step works on them: 128 is <= 2.8 % of a 256-molecule
+    QM9 batch) against the number of distinct shape buckets, each of which is captured once (~0.3 s)."""
     up = lambda v: -(-(v + 1) // quantum) * quantum
     return up(n_nodes), up(n_hyperedges), up(n_inc)
 

@@ -16,7 +16,7 @@ namespace {
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;  // 2048 counters per block
-constexpr int SHORT_ROW = 16;  // sizing of the long-row list only
+constexpr int SHORT_ROW = 64;  // sizing of the long-row list: rows longer than this go on it
 constexpr int LONG_THREADS = 256;
 constexpr int LONG_LDS_CAP = 16384;  // ints (64 KiB)
 
@@ -159,11 +159,11 @@ __device__ __forceinline__ void emit(int pos, int entry, const int64_t* other, i
     if (col) col[pos] = other ? (int)other[entry] : entry / col_div;
 }
 
-// One wavefront per row (grid-stride).  Every lane ranks the entries it holds against the whole
-// row: rows of up to 64 entries are ranked from registers with wavefront shuffles; longer rows read
-// the row from memory (L1) — O(deg^2/64) per row — and rows above LONG_ROW go to the LDS bitonic
-// kernel instead.
-constexpr int LONG_ROW = 2048;
+// One wavefront per row (grid-stride).  Every lane ranks the entry it holds against the whole row with
+// wavefront shuffles (rows of up to 64 entries); longer rows go to the LDS bitonic kernel (a 255-entry row
+// -- the padding molecule of a batch padded by 255 atoms -- ranked from memory in O(deg^2/64) kept one
+// wavefront busy for 50 us).
+constexpr int LONG_ROW = 64;   // longer rows: one workgroup, LDS bitonic (k_sort_long)
 __global__ void __launch_bounds__(256)
 k_sort_rows(const int* __restrict__ rowptr, int64_t n_rows, const int* __restrict__ tmp_perm,
             const int64_t* __restrict__ other, int col_div, int* __restrict__ perm,
@@ -177,19 +177,10 @@ k_sort_rows(const int* __restrict__ rowptr, int64_t n_rows, const int* __restric
             if (lane == 0) long_rows[atomicAdd(long_count, 1)] = (int)r;
             continue;
         }
-        if (deg <= 64) {
-            const int x = lane < deg ? tmp_perm[beg + lane] : 0x7fffffff;
-            int rank = 0;
-            for (int j = 0; j < deg; ++j) rank += (__shfl(x, j, 64) < x) ? 1 : 0;
-            if (lane < deg) emit(beg + rank, x, other, col_div, perm, col);
-        } else {
-            for (int a = lane; a < deg; a += 64) {
-                const int x = tmp_perm[beg + a];
-                int rank = 0;
-                for (int b = 0; b < deg; ++b) rank += (tmp_perm[beg + b] < x) ? 1 : 0;
-                emit(beg + rank, x, other, col_div, perm, col);
-            }
-        }
+        const int x = lane < deg ? tmp_perm[beg + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) rank += (__shfl(x, j, 64) < x) ? 1 : 0;
+        if (lane < deg) emit(beg + rank, x, other, col_div, perm, col);
     }
 }
 
@@ -325,19 +316,10 @@ __device__ __forceinline__ void sort_rows_of(const Problem& q, int64_t wave0, in
             if (lane == 0) q.long_rows[atomicAdd(q.long_count, 1)] = (int)r;
             continue;
         }
-        if (deg <= 64) {
-            const int x = lane < deg ? q.tmp_perm[beg + lane] : 0x7fffffff;
-            int rank = 0;
-            for (int j = 0; j < deg; ++j) rank += (__shfl(x, j, 64) < x) ? 1 : 0;
-            if (lane < deg) emit(beg + rank, x, q.other, q.col_div, q.perm, q.col);
-        } else {
-            for (int a = lane; a < deg; a += 64) {
-                const int x = q.tmp_perm[beg + a];
-                int rank = 0;
-                for (int c = 0; c < deg; ++c) rank += (q.tmp_perm[beg + c] < x) ? 1 : 0;
-                emit(beg + rank, x, q.other, q.col_div, q.perm, q.col);
-            }
-        }
+        const int x = lane < deg ? q.tmp_perm[beg + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int j = 0; j < deg; ++j) rank += (__shfl(x, j, 64) < x) ? 1 : 0;
+        if (lane < deg) emit(beg + rank, x, q.other, q.col_div, q.perm, q.col);
     }
 }
 
