@@ -164,14 +164,13 @@ k_inc_fwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
 // operand rows of incidence j+1 are gathered while incidence j is normalised, and the per-row sums are
 // flushed when the (wavefront-uniform) row index changes.
 template <int NV, bool DGAMMA, bool SIDE_A>
-__global__ void __launch_bounds__(THREADS)
-k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ ia,
-          const int* __restrict__ ib, const int* __restrict__ side_rowptr,
-          const int* __restrict__ side_perm, const int* __restrict__ okey,
-          const int* __restrict__ orowptr, const float* __restrict__ ds,
-          const float* __restrict__ gamma, float* __restrict__ dside, float* __restrict__ slab_dgamma,
-          int n_side_rows, int C, int mean, float eps, int rows_per_wave) {
-    __shared__ float4 s_g[DGAMMA ? THREADS : 1];
+__device__ __forceinline__ void
+inc_bwd_body(const int block, float4* s_g, const float* __restrict__ pa, const float* __restrict__ qb,
+             const int* __restrict__ ia, const int* __restrict__ ib, const int* __restrict__ side_rowptr,
+             const int* __restrict__ side_perm, const int* __restrict__ okey,
+             const int* __restrict__ orowptr, const float* __restrict__ ds,
+             const float* __restrict__ gamma, float* __restrict__ dside, float* __restrict__ slab_dgamma,
+             int n_side_rows, int C, int mean, float eps, int rows_per_wave) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
     Row<NV> gam, dgam;
@@ -181,7 +180,7 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
         gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
         dgam.v[i] = f4_zero();
     }
-    const int64_t s_beg64 = (int64_t)(blockIdx.x * WAVES + wave) * rows_per_wave;
+    const int64_t s_beg64 = (int64_t)(block * WAVES + wave) * rows_per_wave;
     const int s_beg = (s_beg64 < n_side_rows) ? (int)s_beg64 : n_side_rows;
     const int s_end = (s_beg + rows_per_wave < n_side_rows) ? s_beg + rows_per_wave : n_side_rows;
     if (s_beg < s_end) {
@@ -284,7 +283,7 @@ k_inc_bwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
                 float4 t = s_g[lane];
                 for (int w2 = 1; w2 < WAVES; ++w2) f4_add(t, s_g[w2 * 64 + lane]);
                 const int c = (lane + 64 * i) * 4;
-                if (c < C) *reinterpret_cast<float4*>(slab_dgamma + (int64_t)blockIdx.x * C + c) = t;
+                if (c < C) *reinterpret_cast<float4*>(slab_dgamma + (int64_t)block * C + c) = t;
             }
             __syncthreads();
         }
@@ -320,6 +319,26 @@ k_rowln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const f
             }
         }
     }
+}
+
+// both sides of the backward in ONE launch: workgroups [0, blocks_a) take the side keyed by ia (d pa and the
+// d gamma slabs), the rest the side keyed by ib (d qb).  The two sides are independent, so one launch saves a
+// kernel boundary and lets the shorter side's tail overlap the other.
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_inc_bwd_both(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ ia,
+               const int* __restrict__ ib, const int* __restrict__ a_rowptr, const int* __restrict__ a_perm,
+               const int* __restrict__ b_rowptr, const int* __restrict__ b_perm, const int* __restrict__ okey,
+               const int* __restrict__ orowptr, const float* __restrict__ ds, const float* __restrict__ gamma,
+               float* __restrict__ dpa, float* __restrict__ dqb, float* __restrict__ slab_dgamma, int n_a_rows,
+               int n_b_rows, int blocks_a, int C, int mean, float eps, int rpw_a, int rpw_b) {
+    __shared__ float4 s_g[THREADS];
+    if ((int)blockIdx.x < blocks_a)
+        inc_bwd_body<NV, true, true>((int)blockIdx.x, s_g, pa, qb, ia, ib, a_rowptr, a_perm, okey, orowptr, ds, gamma, dpa,
+                                     slab_dgamma, n_a_rows, C, mean, eps, rpw_a);
+    else
+        inc_bwd_body<NV, false, false>((int)blockIdx.x - blocks_a, s_g, pa, qb, ia, ib, b_rowptr, b_perm, okey, orowptr,
+                                       ds, gamma, dqb, nullptr, n_b_rows, C, mean, eps, rpw_b);
 }
 
 // slab layout per workgroup: [dbias | dgamma | dbeta], each C floats
@@ -493,12 +512,10 @@ extern "C" int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, cons
     const int blocks_a = bwd_blocks(n_a_rows);
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        hipLaunchKernelGGL((k_inc_bwd<NV, true, true>), dim3(blocks_a), dim3(THREADS), 0, stream, pa, qb, ia, ib,
-                           a_rowptr, a_perm, okey, orowptr, ds, gamma, dpa, slab, (int)n_a_rows, (int)C,
-                           (int)mean, eps, bwd_rpw(n_a_rows));
-        hipLaunchKernelGGL((k_inc_bwd<NV, false, false>), dim3(bwd_blocks(n_b_rows)), dim3(THREADS), 0, stream, pa,
-                           qb, ia, ib, b_rowptr, b_perm, okey, orowptr, ds, gamma, dqb, (float*)nullptr,
-                           (int)n_b_rows, (int)C, (int)mean, eps, bwd_rpw(n_b_rows));
+        hipLaunchKernelGGL((k_inc_bwd_both<NV>), dim3(blocks_a + bwd_blocks(n_b_rows)), dim3(THREADS), 0, stream, pa, qb,
+                           ia, ib, a_rowptr, a_perm, b_rowptr, b_perm, okey, orowptr, ds, gamma, dpa, dqb, slab,
+                           (int)n_a_rows, (int)n_b_rows, blocks_a, (int)C, (int)mean, eps, bwd_rpw(n_a_rows),
+                           bwd_rpw(n_b_rows));
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs_async(slab, blocks_a, C, dgamma, stream, accumulate);
     });

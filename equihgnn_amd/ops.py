@@ -480,7 +480,12 @@ def defer_flush(device):
         for en in pending:
             by_shape.setdefault(tuple(en[3].shape), []).append(en)
         for group in by_shape.values():
-            wgrad_batch(group)
+            if len(group) >= 3:
+                wgrad_batch(group)
+            else:   # too few products of this shape to fill the chip together: the library GEMM is faster
+                with torch.no_grad():
+                    for dy2, x2, alpha, into in group:
+                        into.addmm_(dy2.t(), x2, alpha=alpha)
         colsum_batch(sums)
     finally:
         _DEFER["active"] = False
