@@ -29,7 +29,8 @@ __global__ void k_clear(int* __restrict__ cnt, int64_t n_items, int* __restrict_
     if (blockIdx.x == 0 && threadIdx.x == 0) *long_count = 0;
 }
 
-__global__ void k_hist(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
+template <typename KeyT>
+__global__ void k_hist(const KeyT* __restrict__ key, int64_t nnz, int64_t n_rows,
                        int* __restrict__ cnt) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
@@ -141,7 +142,8 @@ k_scan_small(int* __restrict__ cnt, int n_items, int* __restrict__ rowptr) {
     }
 }
 
-__global__ void k_fill(const int64_t* __restrict__ key, int64_t nnz, int64_t n_rows,
+template <typename KeyT>
+__global__ void k_fill(const KeyT* __restrict__ key, int64_t nnz, int64_t n_rows,
                        int* __restrict__ cursor, int* __restrict__ tmp_perm) {
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) {
@@ -417,7 +419,8 @@ extern "C" size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows) {
     return carve(nullptr, nnz, n_rows).bytes;
 }
 
-extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+template <typename KeyT>
+static int csr_build_impl(const KeyT* key, const int64_t* other, int64_t nnz, int64_t n_rows,
                             int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
                             void* workspace, size_t workspace_bytes, void* stream_) {
     if (nnz < 0 || n_rows < 0 || !rowptr || !workspace) return EQH_ERR_ARG;
@@ -435,7 +438,7 @@ extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nn
     EQH_CHECK_LAUNCH();
     const int g_nnz = eqh_grid_for(nnz, 256, 2048);
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_hist, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
+        hipLaunchKernelGGL(k_hist<KeyT>, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
         EQH_CHECK_LAUNCH();
     }
     if (n_items <= 65536) {
@@ -449,7 +452,7 @@ extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nn
     }
     EQH_CHECK_LAUNCH();
     if (nnz > 0) {
-        hipLaunchKernelGGL(k_fill, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt,
+        hipLaunchKernelGGL(k_fill<KeyT>, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt,
                            w.tmp_perm);
         hipLaunchKernelGGL(k_sort_rows, dim3(eqh_grid_for(n_rows, 4, 4096)), dim3(256), 0, stream,
                            rowptr, n_rows, w.tmp_perm, other, col_div, perm, col, w.long_count,
@@ -461,6 +464,21 @@ extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nn
         EQH_CHECK_LAUNCH();
     }
     return EQH_OK;
+}
+
+extern "C" int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+                            int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    return csr_build_impl<int64_t>(key, other, nnz, n_rows, col_div, rowptr, perm, col, workspace, workspace_bytes,
+                                   stream_);
+}
+
+/* same with int32 keys (the neighbour lists geo_knn produces: no widening copy in front of the build) */
+extern "C" int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+                                int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
+                                void* workspace, size_t workspace_bytes, void* stream_) {
+    return csr_build_impl<int32_t>(key, other, nnz, n_rows, col_div, rowptr, perm, col, workspace, workspace_bytes,
+                                   stream_);
 }
 
 /* Several CSRs in three launches (see k_csr_front).  Problems whose row counters do not fit LDS, or with

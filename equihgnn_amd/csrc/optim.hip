@@ -94,7 +94,35 @@ __global__ void __launch_bounds__(256) k_copy_many(CopyBatch b) {
     }
 }
 
+__global__ void __launch_bounds__(1024)
+k_mse(const float* __restrict__ pred, const float* __restrict__ target, int n, float* __restrict__ loss,
+      float* __restrict__ grad) {
+    __shared__ float s_sum[1024];
+    const float inv_n = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {   // fixed assignment and tree: reproducible
+        const float d = pred[i] - target[i];
+        acc = fmaf(d, d, acc);
+        grad[i] = 2.0f * d * inv_n;
+    }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) s_sum[threadIdx.x] += s_sum[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = s_sum[0] * inv_n;
+}
+
 }  // namespace
+
+extern "C" int eqh_mse_fwd_bwd(const float* pred, const float* target, int32_t n, float* loss, float* grad,
+                               void* stream_) {
+    if (n <= 0 || n > 65536 || !pred || !target || !loss || !grad) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(k_mse, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream_), pred, target, (int)n, loss, grad);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
 
 extern "C" int eqh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              const float* lr, float beta1, float beta2, float eps, float weight_decay,

@@ -19,6 +19,8 @@ SIGNATURES = {
     "hg_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "hg_csr_build": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "hg_csr_build_i32": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
     "hg_segment_reduce_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                         c_int32, c_int32, c_void_p]),
     "hg_embed_sum_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
@@ -45,6 +47,7 @@ SIGNATURES = {
     "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 8),
     "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

@@ -77,7 +77,7 @@ class HyperIndex:
         hit = self._knn.get((k, mode))
         if hit is None:
             nbr, key = ops.knn(pos, k, mode)
-            csr_t = ops.csr_build(nbr.reshape(-1).to(torch.int64), None, self.N)
+            csr_t = ops.csr_build(nbr.reshape(-1), None, self.N)      # int32 keys: no widening copy
             hit = (nbr, key, csr_t)
             self._knn[(k, mode)] = hit
         return hit

@@ -56,9 +56,9 @@ class CSR:
 
 
 def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1) -> CSR:
-    """hg_csr_build: COO (int64 keys) -> CSR.  ``other`` int64 or None (then col = perm//col_div)."""
+    """hg_csr_build: COO (int64 or int32 keys) -> CSR.  ``other`` int64 or None (then col = perm//col_div)."""
     _require_gpu(key, "csr_build")
-    assert key.dtype == torch.int64 and key.dim() == 1
+    assert key.dtype in (torch.int64, torch.int32) and key.dim() == 1
     key = key.contiguous()
     if other is not None:
         assert other.dtype == torch.int64 and other.shape == key.shape
@@ -71,8 +71,9 @@ def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col
     L = hip.lib()
     ws_bytes = L.hg_csr_build_workspace_bytes(nnz, n_rows)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    hip.check(L.hg_csr_build(_ptr(key), _ptr(other), nnz, n_rows, col_div, _ptr(rowptr), _ptr(perm),
-                             _ptr(col), _ptr(ws), ws_bytes, _stream(dev)), "hg_csr_build")
+    build = L.hg_csr_build if key.dtype == torch.int64 else L.hg_csr_build_i32
+    hip.check(build(_ptr(key), _ptr(other), nnz, n_rows, col_div, _ptr(rowptr), _ptr(perm),
+                    _ptr(col), _ptr(ws), ws_bytes, _stream(dev)), "hg_csr_build")
     return CSR(rowptr, perm[:nnz], col[:nnz], n_rows, nnz)
 
 
@@ -491,6 +492,35 @@ def defer_flush(device):
         _DEFER["active"] = False
         hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
         _DEFER["keep"].clear()
+
+
+class _MseLoss(torch.autograd.Function):
+    """F.mse_loss(pred, target) (mean) with forward value and gradient from ONE launch (eqh_mse_fwd_bwd)
+    instead of six tiny elementwise / reduction launches."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _require_gpu(pred, "mse_loss")
+        pred, target = _f32c(pred), _f32c(target)
+        n = pred.numel()
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        grad = torch.empty_like(pred)
+        hip.check(hip.lib().eqh_mse_fwd_bwd(_ptr(pred), _ptr(target), n, _ptr(loss), _ptr(grad), _stream(pred.device)),
+                  "eqh_mse_fwd_bwd")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (grad,) = ctx.saved_tensors
+        return grad * dloss, None
+
+
+def mse_loss(pred, target):
+    """mean((pred - target)^2) for 1-D fp32 device tensors of up to 65 536 values (a batch of molecules)."""
+    if pred.is_cuda and pred.dtype == torch.float32 and 0 < pred.numel() <= 65536 and not target.requires_grad:
+        return _MseLoss.apply(pred.reshape(-1), target.reshape(-1))
+    return F.mse_loss(pred, target)
 
 
 def copy_many(dsts, srcs):

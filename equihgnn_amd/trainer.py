@@ -176,7 +176,9 @@ class GraphedTrainStep:
         nb = getattr(data, "num_real_graphs", None) or data.y.shape[0]
         if hasattr(data, "_hyper_index"):
             data._hyper_index = None
-        return F.mse_loss(self.model(data)[:nb], data.y[:nb])
+        from . import ops
+        out = self.model(data)[:nb]
+        return ops.mse_loss(out, data.y[:nb]) if out.is_cuda else F.mse_loss(out, data.y[:nb])
 
     def _fwd_bwd(self, data):
         for p in self.model.parameters():

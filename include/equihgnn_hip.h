@@ -45,6 +45,9 @@ int eqh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   const float* lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                   void* state, void* stream);
 int eqh_copy_many(int32_t count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
+/* Mean-squared-error loss of main.py:36,49-63 and its gradient in one launch: loss[0] = mean((pred - target)^2)
+ * over n values, grad[i] = 2 (pred[i] - target[i]) / n.  n <= 65536 (one workgroup; a batch of molecules). */
+int eqh_mse_fwd_bwd(const float* pred, const float* target, int32_t n, float* loss, float* grad, void* stream);
 
 /* Deferred gradient reductions.  Several backward kernels end in a fixed-order reduction of per-workgroup
  * partial slabs into a parameter gradient; with accumulate != 0 that gradient is only read by the
@@ -72,6 +75,10 @@ size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows);
 int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
                  int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* the same with int32 keys (neighbour lists as geo_knn writes them) */
+int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int64_t n_rows, int32_t col_div,
+                     int32_t* rowptr, int32_t* perm, int32_t* col, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* n independent builds at once (arrays of n pointers / sizes, same meaning as above): the three CSRs a
  * model step derives from the batch structure cost 3 launches instead of 18. */
 /* The per-batch index vectors the layers read besides the CSRs, in one launch: int32 copies of the

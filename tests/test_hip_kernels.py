@@ -473,6 +473,24 @@ def test_flat_adam_matches_torch_adam():
     assert int(o1.state[p1]["step_block"][0]) == 7 and int(o1.state[p1]["step_block"][1]) == 0
 
 
+def test_mse_loss_and_int32_csr_keys():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    for n in (1, 7, 256, 1025, 40000):
+        p = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+        t = torch.randn(n, generator=g).to(DEV)
+        loss = ops.mse_loss(p, t)
+        (loss * 3.0).backward()
+        ref = ((p.detach().double() - t.double()) ** 2).mean()
+        np.testing.assert_allclose(float(loss), float(ref), rtol=2e-6)
+        gref = 3.0 * 2.0 * (p.detach().double() - t.double()) / n
+        np.testing.assert_allclose(p.grad.cpu().numpy(), gref.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    key = torch.randint(0, 50, (3000,), generator=g)
+    a = ops.csr_build(key.to(DEV), None, 50, col_div=16)
+    b = ops.csr_build(key.int().to(DEV), None, 50, col_div=16)
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.perm, b.perm) and torch.equal(a.col, b.col)
+
+
 def test_copy_many():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
