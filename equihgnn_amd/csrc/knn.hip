@@ -13,6 +13,10 @@
 // k-th entry; insertion is O(1) wave operations (ballot -> popcount -> shuffle-up), and happens
 // ~k*ln(N/k) times per query, so the loop is dominated by the distance evaluations.
 // Distance arithmetic: (dx*dx + dy*dy) + dz*dz with separately rounded products (no FMA).
+// (Measured and not kept: holding all positions of a <= 12 k-atom cloud in LDS -- 64-84 us against 47 us at
+// 4.7 k atoms.  The molecules of a batch overlap in space, so the k-th distance shrinks slowly and a query
+// performs ~k ln(N/k) + 64 list insertions of ~25 wavefront instructions each: the kernel is bound by that
+// serial chain, not by the candidate loads.)
 #include <limits.h>
 #include <math.h>
 
