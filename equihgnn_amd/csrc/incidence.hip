@@ -63,8 +63,8 @@ __device__ __forceinline__ void gather_pair(const float* __restrict__ pa, const 
     }
 }
 
-// h = relu(u + w); returns xhat in `x`, rstd in *rstd, relu mask in `pos` (bit per comp)
-template <int NV>
+// h = relu(u + w) (RELU) or u + w; returns xhat in `x`, rstd in *rstd, relu mask in `pos` (bit per comp)
+template <int NV, bool RELU = true>
 __device__ __forceinline__ void norm_pair(const Row<NV>& u, const Row<NV>& w, int C, int lane, float inv_c,
                                           float eps, Row<NV>& x, unsigned& pos, float* rstd) {
     float s = 0.f;
@@ -72,9 +72,13 @@ __device__ __forceinline__ void norm_pair(const Row<NV>& u, const Row<NV>& w, in
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float4 h = make_float4(u.v[i].x + w.v[i].x, u.v[i].y + w.v[i].y, u.v[i].z + w.v[i].z, u.v[i].w + w.v[i].w);
-        pos |= ((h.x > 0.f) ? 1u : 0u) << (4 * i) | ((h.y > 0.f) ? 2u : 0u) << (4 * i) |
-               ((h.z > 0.f) ? 4u : 0u) << (4 * i) | ((h.w > 0.f) ? 8u : 0u) << (4 * i);
-        h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        if (RELU) {
+            pos |= ((h.x > 0.f) ? 1u : 0u) << (4 * i) | ((h.y > 0.f) ? 2u : 0u) << (4 * i) |
+                   ((h.z > 0.f) ? 4u : 0u) << (4 * i) | ((h.w > 0.f) ? 8u : 0u) << (4 * i);
+            h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        } else {
+            pos |= 15u << (4 * i);
+        }
         x.v[i] = h;
         s += (h.x + h.y) + (h.z + h.w);
     }
@@ -295,17 +299,29 @@ inc_bwd_body(const int block, float4* s_g, const float* __restrict__ pa, const f
 // as load_norm with a = row, b = the bias row; the backward also produces the column sums that are
 // the bias gradient of the preceding Linear, d gamma and d beta (per-workgroup slabs, fixed order).
 // ------------------------------------------------------------------------------------------------
-template <int NV>
+// RELU: LayerNorm(relu(h + bias)) (mlp.py:91-99); !RELU: plain LayerNorm(h) (bias unused; egnn_layer.py:192)
+template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
             const float* __restrict__ beta, float* __restrict__ out, int n_rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
+    Row<NV> bias_row;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        bias_row.v[i] = (RELU && c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+    }
     for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
-        Row<NV> x;
+        Row<NV> x, hr;
         unsigned pos;
         float rstd;
-        load_norm<NV>(h, bias, r, 0, C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            hr.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)r * C + c) : f4_zero();
+        }
+        norm_pair<NV, RELU>(hr, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
@@ -342,7 +358,7 @@ k_inc_bwd_both(const float* __restrict__ pa, const float* __restrict__ qb, const
 }
 
 // slab layout per workgroup: [dbias | dgamma | dbeta], each C floats
-template <int NV>
+template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
             const float* __restrict__ dy, float* __restrict__ dh, float* __restrict__ slab, int n_rows,
@@ -365,7 +381,7 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
-        bias_row.v[i] = (c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+        bias_row.v[i] = (RELU && c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
     }
     auto fetch = [&](int row) {
         const int rr = row < n_rows ? row : n_rows - 1;
@@ -383,7 +399,7 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
         Row<NV> x, g;
         unsigned pos;
         float rstd;
-        norm_pair<NV>(ch, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
+        norm_pair<NV, RELU>(ch, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
         float m1 = 0.f, m2 = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -534,7 +550,7 @@ extern "C" int hg_bias_relu_ln_fwd(const float* h, const float* bias, const floa
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        hipLaunchKernelGGL((k_rowln_fwd<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, h,
+        hipLaunchKernelGGL((k_rowln_fwd<NV, true>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, h,
                            bias, gamma, beta, out, (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
         return EQH_OK;
@@ -568,9 +584,62 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
     float* slab = static_cast<float*>(workspace);
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        hipLaunchKernelGGL((k_rowln_bwd<NV>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
+        hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
                            (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
+    });
+}
+
+/* plain LayerNorm over dense rows (the EGNN node_norm, egnn_layer.py:192) on the same row machinery */
+extern "C" int hg_layer_norm_fwd(const float* x, const float* gamma, const float* beta, int64_t n_rows, int32_t C,
+                                 float eps, float* out, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!x || !gamma || !beta || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_rowln_fwd<NV, false>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, x,
+                           (const float*)nullptr, gamma, beta, out, (int)n_rows, (int)C, eps);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t hg_layer_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C) {
+    if (n_rows < 0 || C <= 0) return 0;
+    return hg_bias_relu_ln_bwd_workspace_bytes(n_rows, C) + (size_t)C * sizeof(float);  // + a discarded "d bias" row
+}
+
+extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t n_rows, int32_t C,
+                                 float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+                                 void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (!dgamma || !dbeta) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_rows == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dgamma, C, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(dbeta, C, stream);
+    }
+    if (!x || !gamma || !dy || !dx || !workspace) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(dy) || !eqh_aligned16(dx) || !eqh_aligned16(workspace) || !eqh_aligned16(gamma))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_layer_norm_bwd_workspace_bytes(n_rows, C)) return EQH_ERR_ARG;
+    const int blocks = rowln_blocks(n_rows);
+    float* slab = static_cast<float*>(workspace);
+    float* discard = slab + (size_t)blocks * 3 * C;
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_rowln_bwd<NV, false>), dim3(blocks), dim3(THREADS), 0, stream, x, (const float*)nullptr, gamma,
+                           dy, dx, slab, (int)n_rows, (int)C, eps);
+        EQH_CHECK_LAUNCH();
+        // the slab's first segment (column sums of dx) has no consumer here; it goes to the discard row.  Never
+        // deferred-with-accumulate for that segment's sake: accumulate applies to all three alike, harmlessly.
+        return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, discard, dgamma, dbeta, C, C, accumulate, stream);
     });
 }

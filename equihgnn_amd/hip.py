@@ -38,6 +38,10 @@ SIGNATURES = {
     "hg_incidence_ln_reduce_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 4
                                    + [c_int32, c_int32, c_float] + [c_void_p] * 3 + [c_int32, c_void_p, c_size_t,
                                                                                     c_void_p]),
+    "hg_layer_norm_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
+    "hg_layer_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "hg_layer_norm_bwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_float] + [c_void_p] * 3
+                          + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_bias_relu_ln_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "hg_bias_relu_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4

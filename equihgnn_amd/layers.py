@@ -321,7 +321,10 @@ class EGNN(nn.Module):
         ab = ops.linear(feats, w_cat, b_cat)
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
-        node_in = torch.cat((self.node_norm(feats), m_i), -1)
+        nn_ = self.node_norm
+        normed = (ops.layer_norm_rows(feats, nn_.weight, nn_.bias, nn_.eps) if c % 4 == 0 and c <= 1024
+                  else nn_(feats))
+        node_in = torch.cat((normed, m_i), -1)
         n0, n3 = self.node_mlp[0], self.node_mlp[3]
         hid = F.silu(ops.linear(node_in, n0.weight, n0.bias))
         return ops.linear(hid, n3.weight, n3.bias) + feats     # egnn_layer.py:360-362

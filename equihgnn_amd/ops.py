@@ -390,6 +390,42 @@ class _BiasReluLn(torch.autograd.Function):
         return dh, small[0], small[1], small[2], None, None
 
 
+class _LayerNormRows(torch.autograd.Function):
+    """Plain LayerNorm over dense rows; one launch each way, dgamma/dbeta from the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, acc_params):
+        _require_gpu(x, "layer_norm_rows")
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        R, C = x.shape
+        out = torch.empty_like(x)
+        hip.check(hip.lib().hg_layer_norm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), R, C, float(eps), _ptr(out),
+                                              _stream(x.device)), "hg_layer_norm_fwd")
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        dx = torch.empty_like(x)
+        L = hip.lib()
+        ws_bytes = L.hg_layer_norm_bwd_workspace_bytes(R, C)
+        ws = _workspace(ws_bytes, x.device)
+        tg = [_acc_target(p) for p in ctx.acc]
+        if all(t is not None for t in tg):
+            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
+                                          _ptr(tg[1]), 1, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
+            return dx, None, None, None, None
+        small = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
+                                      _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
+        return dx, small[0], small[1], None, None
+
+
 WGRAD_ON_SIDE_STREAM = False
 _WGRAD_STREAMS = {}
 
@@ -818,6 +854,12 @@ def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
     """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C]."""
     _note_acc(bias, gamma, beta)
     return _BiasReluLn.apply(h, bias, gamma, beta, eps, (bias, gamma, beta))
+
+
+def layer_norm_rows(x, gamma, beta, eps: float = 1e-5):
+    """nn.LayerNorm over the last dim of 2-D ``x`` [rows, C] (C % 4 == 0, C <= 1024)."""
+    _note_acc(gamma, beta)
+    return _LayerNormRows.apply(x, gamma, beta, eps, (gamma, beta))
 
 
 def eigh3(cov):

@@ -626,6 +626,25 @@ def test_bias_relu_ln_matches_float64_reference(R, C):
         assert err < 3e-5, (name, err)
 
 
+@pytest.mark.parametrize("R,C", [(1, 64), (37, 128), (5000, 256), (300, 1024)])
+def test_layer_norm_rows_matches_float64_reference(R, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    h = torch.randn(R, C, generator=g) - 0.5          # negatives must survive (no ReLU on this path)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    w = torch.randn(R, C, generator=g)
+    t = [x.double().requires_grad_(True) for x in (h, gamma, beta)]
+    ref = torch.nn.functional.layer_norm(t[0], (C,), t[1], t[2], 1e-5)
+    (ref * w.double()).sum().backward()
+    d = [x.to(DEV).requires_grad_(True) for x in (h, gamma, beta)]
+    out = ops.layer_norm_rows(d[0], d[1], d[2])
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    for name, x, r in zip(("dx", "dgamma", "dbeta"), d, t):
+        err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
+        assert err < 3e-5, (name, err)
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
