@@ -16,8 +16,8 @@ namespace {
 constexpr int CS_ROWS = 32;  // rows per partial sum: 4 row lanes x 8 rows, all eight loads in flight
 
 __global__ void __launch_bounds__(256)
-k_colsum_partial(const float* __restrict__ x, const int* __restrict__ rowptr, int mode, int64_t R, int C,
-                 float* __restrict__ part) {
+k_colsum_partial(const float* __restrict__ x, const int* __restrict__ rowptr, int mode, float scale, int64_t R,
+                 int C, float* __restrict__ part) {
     // block (bx, by): columns [bx*256, +256) as one float4 per thread of a 64-thread row lane; the four row
     // lanes take rows r0 + ty, r0 + ty + 4, ... and meet in LDS in lane order (fixed summation order)
     __shared__ float4 s_acc[3][64];
@@ -45,6 +45,7 @@ k_colsum_partial(const float* __restrict__ x, const int* __restrict__ rowptr, in
         f4_add(a, s_acc[0][tx]);
         f4_add(a, s_acc[1][tx]);
         f4_add(a, s_acc[2][tx]);
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
         *reinterpret_cast<float4*>(part + (int64_t)blockIdx.y * C + c) = a;
     }
 }
@@ -60,6 +61,7 @@ struct ColsumEntry {
     int64_t R;
     int C;
     int mode;
+    float scale;
 };
 struct ColsumBatch {
     ColsumEntry e[CS_MAX_BATCH];
@@ -93,7 +95,29 @@ __global__ void __launch_bounds__(256) k_colsum_partial_batch(ColsumBatch b) {
         f4_add(a, s_acc[0][tx]);
         f4_add(a, s_acc[1][tx]);
         f4_add(a, s_acc[2][tx]);
+        a.x *= en.scale; a.y *= en.scale; a.z *= en.scale; a.w *= en.scale;
         *reinterpret_cast<float4*>(en.part + (int64_t)blockIdx.y * en.C + c) = a;
+    }
+}
+
+// out[r, :] = alpha * x0[r, :] + (1 - alpha) * w_r * bias[:]  (w_r as in the column sums above): the
+// layer-independent half of conv.py:179-180's residual mix with the last Linear's bias folded in
+__global__ void __launch_bounds__(256)
+k_residual_mix(const float* __restrict__ x0, const float* __restrict__ bias, const int* __restrict__ rowptr, int mode,
+               float alpha, int64_t R, int C, float* __restrict__ out) {
+    const int c4 = C >> 2;
+    const int64_t total = R * c4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        const int len = rowptr[r + 1] - rowptr[r];
+        const float w = (1.f - alpha) * ((mode == 1) ? (len > 0 ? 1.f : 0.f) : (float)len);
+        const float4 x = *reinterpret_cast<const float4*>(x0 + r * C + c);
+        const float4 b = *reinterpret_cast<const float4*>(bias + c);
+        float4 o;
+        o.x = fmaf(alpha, x.x, w * b.x); o.y = fmaf(alpha, x.y, w * b.y);
+        o.z = fmaf(alpha, x.z, w * b.z); o.w = fmaf(alpha, x.w, w * b.w);
+        *reinterpret_cast<float4*>(out + r * C + c) = o;
     }
 }
 
@@ -156,8 +180,8 @@ extern "C" size_t hg_colsum_workspace_bytes(int64_t R, int32_t C) {
     return (size_t)(chunks > 0 ? chunks : 1) * (size_t)C * sizeof(float);
 }
 
-extern "C" int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
-                             int32_t accumulate, float* out, void* workspace, size_t workspace_bytes,
+extern "C" int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, float scale, int64_t R,
+                             int32_t C, int32_t accumulate, float* out, void* workspace, size_t workspace_bytes,
                              void* stream_) {
     if (R < 0 || C <= 0 || !out || weight_mode < 0 || weight_mode > 2) return EQH_ERR_ARG;
     if (weight_mode != 0 && !rowptr) return EQH_ERR_ARG;
@@ -170,7 +194,7 @@ extern "C" int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weig
     if (chunks > 65535) return EQH_ERR_RANGE;
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_colsum_partial, dim3((C / 4 + 63) / 64, chunks), dim3(256), 0, stream, x, rowptr,
-                       (int)weight_mode, R, (int)C, part);
+                       (int)weight_mode, scale, R, (int)C, part);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(part, chunks, C, out, stream, accumulate);
 }
@@ -183,8 +207,8 @@ extern "C" size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* 
 }
 
 extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
-                                   const int32_t* weight_mode, const int64_t* R, const int32_t* C,
-                                   float* const* out, void* workspace, size_t workspace_bytes, void* stream_) {
+                                   const int32_t* weight_mode, const float* scale, const int64_t* R,
+                                   const int32_t* C, float* const* out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (count < 0) return EQH_ERR_ARG;
     if (count == 0) return EQH_OK;
     if (!x || !rowptr || !weight_mode || !R || !C || !out || !workspace) return EQH_ERR_ARG;
@@ -205,7 +229,7 @@ extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const i
             ws += (hg_colsum_workspace_bytes(R[j], C[j]) + 255) & ~(size_t)255;
             const int chunks = (int)((R[j] + CS_ROWS - 1) / CS_ROWS);
             if (chunks > 65535) return EQH_ERR_RANGE;
-            b.e[i] = ColsumEntry{x[j], rowptr[j], parts[i], R[j], (int)C[j], (int)weight_mode[j]};
+            b.e[i] = ColsumEntry{x[j], rowptr[j], parts[i], R[j], (int)C[j], (int)weight_mode[j], scale ? scale[j] : 1.f};
             if (R[j] > 0) ++live;
             if (chunks > max_chunks) max_chunks = chunks;
             const int cb = (C[j] / 4 + 63) / 64;
@@ -223,6 +247,19 @@ extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const i
             if (rc) return rc;
         }
     }
+    return EQH_OK;
+}
+
+extern "C" int hg_residual_mix_f32(const float* x0, const float* bias, const int32_t* rowptr, int32_t weight_mode,
+                                   float alpha, int64_t R, int32_t C, float* out, void* stream_) {
+    if (R < 0 || C <= 0 || weight_mode < 1 || weight_mode > 2) return EQH_ERR_ARG;
+    if (R == 0) return EQH_OK;
+    if (!x0 || !bias || !rowptr || !out) return EQH_ERR_ARG;
+    if ((C & 3) || !eqh_aligned16(x0) || !eqh_aligned16(bias) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_residual_mix, dim3(eqh_grid_for(R * (C / 4), 256, 4096)), dim3(256), 0, stream, x0, bias,
+                       rowptr, (int)weight_mode, alpha, R, (int)C, out);
+    EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
 

@@ -62,9 +62,11 @@ SIGNATURES = {
                                      c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_colsum_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
-    "hg_colsum_batch_f32": (c_int32, [c_int32] + [c_void_p] * 6 + [c_void_p, c_size_t, c_void_p]),
-    "hg_colsum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int32, c_void_p, c_void_p,
+    "hg_colsum_batch_f32": (c_int32, [c_int32] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "hg_colsum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
+    "hg_residual_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_int64, c_int32, c_void_p,
+                                      c_void_p]),
     "egnn_pack_weights_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p] * 5),
     "egnn_pack_weights_bwd": (c_int32, [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 4),
     "geo_eigh3": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -486,8 +486,8 @@ def wgrad_batch(entries):
 
 
 def colsum_batch(entries):
-    """hg_colsum_batch_f32: ``entries`` = [(x [R,C], rowptr or None, weight_mode, into [C])]; every sum is ADDED
-    to its destination, in one launch."""
+    """hg_colsum_batch_f32: ``entries`` = [(x [R,C], rowptr or None, weight_mode, into [C], scale)]; every sum
+    is ADDED to its destination, in one launch."""
     n = len(entries)
     if n == 0:
         return
@@ -501,7 +501,9 @@ def colsum_batch(entries):
     _DEFER["keep"].extend(en[0] for en in entries)
     hip.check(L.hg_colsum_batch_f32(n, vp(*[en[0].data_ptr() for en in entries]),
                                     vp(*[(en[1].data_ptr() if en[1] is not None else None) for en in entries]),
-                                    i32(*[int(en[2]) for en in entries]), R, C, vp(*[en[3].data_ptr() for en in entries]),
+                                    i32(*[int(en[2]) for en in entries]),
+                                    (ctypes.c_float * n)(*[float(en[4]) for en in entries]), R, C,
+                                    vp(*[en[3].data_ptr() for en in entries]),
                                     _ptr(ws), ws_bytes, _stream(dev)), "hg_colsum_batch_f32")
 
 
@@ -585,8 +587,8 @@ def _note_acc(*params):
                 ACC_PARAMS[id(p)] = p
 
 
-def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
-    """sum_r w_r x[r, :] for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients).  ``rowptr`` +
+def colsum(x, rowptr=None, weight_mode: int = 0, into=None, scale: float = 1.0):
+    """scale * sum_r w_r x[r, :] for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients).  ``rowptr`` +
     ``weight_mode`` (1: [row non-empty], 2: row length) give the row weights; ``into`` is an accumulator
     the result is ADDED to (returns None then)."""
     if not x.is_cuda or x.shape[-1] % 4 or x.dtype != torch.float32:
@@ -594,7 +596,7 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
         if weight_mode:
             deg = rowptr[1:] - rowptr[:-1]
             x = x * ((deg > 0) if weight_mode == 1 else deg).to(x.dtype)[:, None]
-        r = x.sum(0)
+        r = x.sum(0) if scale == 1.0 else x.sum(0) * scale
         if into is None:
             return r
         into.add_(r)
@@ -602,13 +604,13 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None):
     x = _f32c(x)
     R, C = x.shape
     if into is not None and _DEFER["active"] and DEFER_WGRAD:
-        _DEFER["colsum"].append((x, rowptr, weight_mode, into))   # runs with all the others at defer_flush
+        _DEFER["colsum"].append((x, rowptr, weight_mode, into, scale))   # runs with all the others at defer_flush
         return None
     L = hip.lib()
     out = into if into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws_bytes = L.hg_colsum_workspace_bytes(R, C)
     ws = _workspace(max(ws_bytes, 16), x.device)
-    hip.check(L.hg_colsum_f32(_ptr(x), _ptr(rowptr) if rowptr is not None else None, weight_mode, R, C,
+    hip.check(L.hg_colsum_f32(_ptr(x), _ptr(rowptr) if rowptr is not None else None, weight_mode, float(scale), R, C,
                               1 if into is not None else 0, _ptr(out), _ptr(ws), ws_bytes, _stream(x.device)),
               "hg_colsum_f32")
     return None if into is not None else out
@@ -854,6 +856,38 @@ def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
     """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C]."""
     _note_acc(bias, gamma, beta)
     return _BiasReluLn.apply(h, bias, gamma, beta, eps, (bias, gamma, beta))
+
+
+class _ResidualMix(torch.autograd.Function):
+    """c = a * X0 + (1 - a) * w_r * bias (hg_residual_mix_f32); backward: dX0 = a * dc and the bias gradient
+    as a scaled, row-weighted column sum (batched with the other bias gradients of the step)."""
+
+    @staticmethod
+    def forward(ctx, x0, bias, rowptr, weight_mode, alpha, bias_param):
+        _require_gpu(x0, "residual_mix")
+        x0, bias = _f32c(x0), _f32c(bias)
+        R, C = x0.shape
+        out = torch.empty_like(x0)
+        hip.check(hip.lib().hg_residual_mix_f32(_ptr(x0), _ptr(bias), _ptr(rowptr), weight_mode, float(alpha), R, C,
+                                                _ptr(out), _stream(x0.device)), "hg_residual_mix_f32")
+        ctx.rowptr, ctx.mode, ctx.alpha, ctx.bias_param = rowptr, weight_mode, float(alpha), bias_param
+        return out
+
+    @staticmethod
+    def backward(ctx, dc):
+        dc = _f32c(dc)
+        dx0 = dc * ctx.alpha if ctx.needs_input_grad[0] else None
+        db = None
+        if ctx.needs_input_grad[1]:
+            db = colsum(dc, ctx.rowptr, ctx.mode, into=_acc_target(ctx.bias_param), scale=1.0 - ctx.alpha)
+        return dx0, db, None, None, None, None
+
+
+def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
+    """alpha * x0 + (1 - alpha) * w_r * bias for 2-D x0 [rows, C] (C % 4 == 0); w_r from the int32 CSR ``rowptr``
+    (weight_mode 1: [row non-empty], 2: row length)."""
+    _note_acc(bias)
+    return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
 
 
 def layer_norm_rows(x, gamma, beta, eps: float = 1e-5):

@@ -249,7 +249,11 @@ int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
  * hg_colsum_f32: out[c] (+)= sum_r w_r x[r,c] — the bias gradient of an nn.Linear (autograd's
  *   grad_output.sum(0)); two passes, fixed order.  weight_mode 0: w_r = 1 (rowptr may be NULL);
  *   1: w_r = [row r of the CSR rowptr is non-empty]; 2: w_r = length of row r (the bias of a Linear
- *   applied before a mean / sum over incidences, conv.py:91-97,175-177).  accumulate != 0 adds to out.
+ *   applied before a mean / sum over incidences, conv.py:91-97,175-177).  The sums are multiplied by
+ *   ``scale``.  accumulate != 0 adds to out.
+ * hg_residual_mix_f32: out[r,:] = alpha * x0[r,:] + (1 - alpha) * w_r * bias[:] (w_r by weight_mode 1 / 2 as
+ *   above) — the layer-independent half of the residual mix (1-a) * x_v + a * X0 of conv.py:179-180 with the
+ *   bias of the Linear that produced x_v folded in; its bias gradient is hg_colsum_f32 with scale = 1 - alpha.
  * egnn_pack_weights_fwd/bwd: layout change of the EGNN edge-MLP weights (egnn_layer.py:180-186) into
  *   what egnn_edge_fwd consumes: w1 [H, 2C+1], b1 [H], w2 [16, H]  ->  w_cat [2*Hp, C]
  *   (= [w1[:, :C] ; w1[:, C:2C]], zero rows from H to Hp), b_cat [2*Hp] (= [b1 ; 0]),
@@ -269,14 +273,16 @@ int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const
                        int32_t I, const float* alpha, float* const* dw, const int64_t* ldw, int32_t accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
-int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, int64_t R, int32_t C,
+int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, float scale, int64_t R, int32_t C,
                   int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);
+int hg_residual_mix_f32(const float* x0, const float* bias, const int32_t* rowptr, int32_t weight_mode,
+                        float alpha, int64_t R, int32_t C, float* out, void* stream);
 /* count row-weighted column sums in one launch, each ADDED to its out[i] (the bias gradients of a backward
- * pass, deferred to its end like the weight gradients). */
+ * pass, deferred to its end like the weight gradients).  scale may be NULL (all 1). */
 size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* R, const int32_t* C);
 int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
-                        const int32_t* weight_mode, const int64_t* R, const int32_t* C, float* const* out,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        const int32_t* weight_mode, const float* scale, const int64_t* R, const int32_t* C,
+                        float* const* out, void* workspace, size_t workspace_bytes, void* stream);
 int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hp,
                           int32_t C, float* w_cat, float* b_cat, float* wd, float* w2p, void* stream);
 int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd, const float* dw2p,

@@ -389,6 +389,39 @@ def test_colsum_matches_float64(R, C):
     np.testing.assert_allclose(acc3.cpu().numpy(), want3.cpu().numpy(), rtol=0, atol=4e-5 * max(R, 1) ** 0.5)
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_residual_mix_matches_float64(mode):
+    """c = a X0 + (1-a) w_r b (conv.py:179-180 with the last bias folded in), its X0 gradient and its
+    scaled row-weighted bias gradient, eagerly and with the bias gradient deferred into an accumulator."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(mode)
+    R, C, a = 777, 256, 0.3
+    x0, b, w = torch.randn(R, C, generator=g), torch.randn(C, generator=g), torch.randn(R, C, generator=g)
+    lens = torch.randint(0, 4, (R,), generator=g)
+    rowptr = torch.cat((torch.zeros(1, dtype=torch.int64), lens.cumsum(0))).int().to(DEV)
+    rw = ((lens > 0) if mode == 1 else lens).double()[:, None]
+    t = [v.double().requires_grad_(True) for v in (x0, b)]
+    ref = a * t[0] + (1 - a) * rw * t[1]
+    (ref * w.double()).sum().backward()
+    d = [v.to(DEV).requires_grad_(True) for v in (x0, b)]
+    out = ops.residual_mix(d[0], d[1], rowptr, mode, a)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(d[0].grad.cpu().numpy(), t[0].grad.numpy(), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(d[1].grad.cpu().numpy(), t[1].grad.numpy(), atol=2e-4, rtol=1e-5)
+    # scale on the plain column sum, eager and deferred
+    x = w.to(DEV)
+    np.testing.assert_allclose(ops.colsum(x, rowptr, mode, scale=0.7).cpu().numpy(),
+                               (0.7 * (w.double() * rw).sum(0)).numpy(), atol=2e-4, rtol=1e-5)
+    acc = torch.zeros(C, device=DEV)
+    ops.defer_begin(DEV)
+    ops.colsum(x, rowptr, mode, into=acc, scale=0.7)
+    ops.colsum(x, into=acc)
+    ops.defer_flush(DEV)
+    np.testing.assert_allclose(acc.cpu().numpy(), (0.7 * (w.double() * rw).sum(0) + w.double().sum(0)).numpy(),
+                               atol=3e-4, rtol=1e-5)
+
+
 @pytest.mark.parametrize("K,O,I", [(1, 64, 64), (70, 64, 128), (513, 128, 64), (4608, 256, 256), (9733, 256, 256),
                                     (4864, 512, 256), (3000, 2176, 256)])
 def test_wgrad_matches_float64(K, O, I):

@@ -109,7 +109,7 @@ def main():
         nbytes=12 * C * N)
     wsb3 = L.hg_colsum_workspace_bytes(N, C)
     ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
-    add("hg_colsum_f32", timed(lambda: L.hg_colsum_f32(p(X), None, 0, N, C, 0, p(dg), p(ws3), wsb3, st)), nbytes=4 * C * N)
+    add("hg_colsum_f32", timed(lambda: L.hg_colsum_f32(p(X), None, 0, 1.0, N, C, 0, p(dg), p(ws3), wsb3, st)), nbytes=4 * C * N)
     xi = torch.stack([torch.randint(0, d, (N,), device=dev, generator=g) for d in (119, 5, 12, 12, 10, 6, 6, 2, 2)], 1)
     table = torch.randn(174, C, device=dev, generator=g)
     offs = (0, 119, 124, 136, 148, 158, 164, 170, 172)
