@@ -336,3 +336,29 @@ class EGNN(nn.Module):
 def pool_sum(x, index: HyperIndex):
     """global_add_pool (equihnn_egnn.py:167, mhnn.py:216): per-molecule sum over sorted rows."""
     return ops.reduce_entries(x, index.pool, index.batch32, "sum")
+
+
+def head_loss(out, head):
+    """``out`` itself, or with head = (target, n_real[, unit_grad]) the training loss of main.py:49-63:
+    F.mse_loss over the first n_real molecules (the rest of a padded batch is padding)."""
+    if head is None:
+        return out
+    nb = head[1] or out.shape[0]
+    return ops.mse_loss(out[:nb], head[0][:nb])
+
+
+def readout(mlp_out, x, index: HyperIndex, taps=None, head=None):
+    """The tail of every wrapper: global_add_pool -> output MLP -> .view(-1) (equihnn_egnn.py:167-169,
+    mhnn.py:216-218, equihnn_equiformer.py:91-93).  With ``head`` the training loss is returned instead, and
+    when the head has the scripts' shape (three Linears, LayerNorm) pool, MLP, loss and the whole backward
+    pass of the head are one launch (ops.readout_mse)."""
+    if head is not None and taps is None:
+        x2 = x.reshape(-1, x.shape[-1])
+        if ops.readout_mse_supported(x2, mlp_out) and head[0].is_cuda:
+            loss, _ = ops.readout_mse(x2, index.pool.rowptr, mlp_out, head[0], head[1],
+                                      unit_grad=bool(head[2]) if len(head) > 2 else False)
+            return loss
+    xp = pool_sum(x, index)
+    if taps is not None:
+        taps["pool"] = xp
+    return head_loss(mlp_out(xp).view(-1), head)

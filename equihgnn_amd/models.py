@@ -12,7 +12,7 @@ import torch.nn as nn
 from .equiformer import Equiformer
 from .faformer import FAFormer
 from .index import HyperIndex
-from .layers import (EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, batch_norm_rows, pool_sum,
+from .layers import (EGNN, MLP, AtomEncoder, BondEncoder, MHNNConv, MHNNSConv, batch_norm_rows, head_loss, pool_sum, readout,
                      real_row_mask)
 from .registry import registry
 
@@ -45,7 +45,7 @@ class EGNNEquiHNNS(nn.Module):
         self.conv.reset_parameters()
         self.mlp_out.reset_parameters()
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         if taps is not None:
@@ -60,10 +60,7 @@ class EGNNEquiHNNS(nn.Module):
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
-        x = pool_sum(self.dropout(x), index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
 @registry.register_model("mhnnm")
@@ -95,7 +92,7 @@ class MHNNM(nn.Module):
                            out_channels=num_target, num_layers=args.output_num_layers,
                            dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         e = self.bond_encoder(data.edge_attr)
@@ -110,10 +107,7 @@ class MHNNM(nn.Module):
             if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
                 x, e = self.act(x), self.act(e)
             x, e = self.dropout(x), self.dropout(e)
-        x = pool_sum(x, index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, x, index, taps, head)
 
 
 @registry.register_model("equiformer_equihnns")
@@ -145,7 +139,7 @@ class EquiformerEquiHNNS(nn.Module):
         self.conv.reset_parameters()
         self.mlp_out.reset_parameters()
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         if taps is not None:
@@ -160,10 +154,7 @@ class EquiformerEquiHNNS(nn.Module):
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
-        x = pool_sum(self.dropout(x), index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
 class _PairedBase(nn.Module):
@@ -193,7 +184,7 @@ class _PairedBase(nn.Module):
                            dropout=args.dropout, Normalization=args.normalization, InputNorm=False)
         self.with_egnn = with_egnn
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         from . import ops
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
@@ -214,7 +205,7 @@ class _PairedBase(nn.Module):
         both = torch.cat((xp, ep), -1)
         if taps is not None:
             taps["pool"] = both
-        return self.mlp_out(both).view(-1)
+        return head_loss(self.mlp_out(both).view(-1), head)
 
 
 @registry.register_model("mhnn")
@@ -253,7 +244,7 @@ class MHNNS(nn.Module):
         self.conv.reset_parameters()
         self.mlp_out.reset_parameters()
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         x0 = x
@@ -263,10 +254,7 @@ class MHNNS(nn.Module):
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
-        x = pool_sum(self.dropout(x), index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
 @registry.register_model("egnn_equihnnm")
@@ -277,7 +265,7 @@ class EGNNEquiHNNM(MHNNM):
         super().__init__(num_target, args)
         self.egnn_layer = EGNN(dim=args.MLP_hidden, num_nearest_neighbors=16)
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.egnn_layer(self.atom_encoder(data.x), data.pos, index)
         if taps is not None:
@@ -292,10 +280,7 @@ class EGNNEquiHNNM(MHNNM):
             if i != self.nlayer - 1:
                 x, e = self.act(x), self.act(e)
             x, e = self.dropout(x), self.dropout(e)
-        x = pool_sum(x, index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, x, index, taps, head)
 
 
 @registry.register_model("faformer_equihnns")
@@ -325,7 +310,7 @@ class FAFormerEquiHNNS(nn.Module):
         self.conv.reset_parameters()
         self.mlp_out.reset_parameters()
 
-    def forward(self, data, taps=None):
+    def forward(self, data, taps=None, head=None):
         index = HyperIndex.from_batch(data)
         x = self.atom_encoder(data.x)
         if taps is not None:
@@ -340,10 +325,7 @@ class FAFormerEquiHNNS(nn.Module):
             if taps is not None:
                 taps[f"conv{i}"] = x
             x = self.act(x)
-        x = pool_sum(self.dropout(x), index)
-        if taps is not None:
-            taps["pool"] = x
-        return self.mlp_out(x).view(-1)
+        return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
 MODELS = {"egnn_equihnns": EGNNEquiHNNS, "mhnnm": MHNNM, "equiformer_equihnns": EquiformerEquiHNNS,

@@ -561,6 +561,92 @@ def mse_loss(pred, target):
     return F.mse_loss(pred, target)
 
 
+_READOUT_STATE = {}
+
+
+def _readout_state(device):
+    key = torch.device(device).index
+    if key not in _READOUT_STATE:
+        _READOUT_STATE[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _READOUT_STATE[key]
+
+
+class _ReadoutMse(torch.autograd.Function):
+    """pool -> MLP(C -> H -> H -> 1, LN) -> MSE with loss, dx and all parameter gradients from ONE launch
+    (hg_readout_mse_f32).  The gradients are computed in forward(); backward() hands them out -- scaled by the
+    incoming gradient unless ``unit_grad`` says it is the implicit 1 of ``loss.backward()``, in which case the
+    parameter gradients may already have been added to their persistent accumulators."""
+
+    @staticmethod
+    def forward(ctx, x, rowptr, n_graphs, n_real, target, eps, unit_grad, params, *weights):
+        _require_gpu(x, "readout_mse")
+        dev = x.device
+        x, target = _f32c(x), _f32c(target)
+        ws_t = [_f32c(w.detach()) for w in weights]
+        H, C = ws_t[0].shape
+        L = hip.lib()
+        vp = ctypes.c_void_p * 10
+        y = torch.empty(n_graphs, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        ws_bytes = L.hg_readout_mse_workspace_bytes(n_graphs, C, H)
+        ws = _workspace(ws_bytes, dev)
+        tg = [_acc_target(w) for w in params] if unit_grad else [None]
+        in_place = all(t is not None for t in tg)
+        grads = tg if in_place else [torch.empty_like(w) for w in ws_t]
+        hip.check(L.hg_readout_mse_f32(_ptr(x), _ptr(rowptr), n_graphs, n_real, C, H, vp(*[w.data_ptr() for w in ws_t]),
+                                       float(eps), _ptr(target), _ptr(y), _ptr(loss), _ptr(dx),
+                                       vp(*[g.data_ptr() for g in grads]), 1 if in_place else 0, _ptr(ws), ws_bytes,
+                                       _ptr(_readout_state(dev)), _stream(dev)), "hg_readout_mse_f32")
+        ctx.unit_grad, ctx.in_place = unit_grad, in_place
+        ctx.held = (dx,) if in_place else (dx, *grads)
+        ctx.mark_non_differentiable(y)
+        return loss, y
+
+    @staticmethod
+    def backward(ctx, dloss, _dy):
+        held = ctx.held
+        if not ctx.unit_grad:
+            held = tuple(h * dloss for h in held)
+        dx = held[0]
+        dws = (None,) * 10 if ctx.in_place else tuple(g.view_as(g) for g in held[1:])
+        return (dx, None, None, None, None, None, None, None, *dws)
+
+
+def readout_mse_supported(x, mlp) -> bool:
+    """Whether ops.readout_mse takes this pooled-MLP head: 2-D fp32 device rows, MLP of three Linears with
+    LayerNorm hidden layers and one output, no active dropout, widths the kernel is built for."""
+    lins = getattr(mlp, "lins", None)
+    if lins is None or len(lins) != 3 or not x.is_cuda or x.dim() != 2 or x.dtype != torch.float32:
+        return False
+    norms = mlp.normalizations
+    if mlp.InputNorm or not all(isinstance(n, torch.nn.LayerNorm) for n in norms[1:]):
+        return False
+    if mlp.training and mlp.dropout > 0:
+        return False
+    H, C = lins[0].weight.shape
+    if lins[1].weight.shape != (H, H) or lins[2].weight.shape != (1, H) or x.shape[1] != C:
+        return False
+    if norms[1].eps != norms[2].eps:
+        return False
+    return bool(hip.lib().hg_readout_mse_supported(C, H))
+
+
+def readout_mse(x, pool_rowptr, mlp, target, n_real=None, unit_grad=False):
+    """(loss, predictions) of the readout head: x [N, C] node rows, pool_rowptr int32 [B+1] (sorted ``batch``),
+    ``mlp`` the output MLP, ``target`` [>= n_real]; loss = mean over the first n_real molecules."""
+    n_graphs = pool_rowptr.shape[0] - 1
+    n_real = n_graphs if n_real is None else int(n_real)
+    lins, norms = mlp.lins, mlp.normalizations
+    weights = (lins[0].weight, lins[0].bias, norms[1].weight, norms[1].bias, lins[1].weight, lins[1].bias,
+               norms[2].weight, norms[2].bias, lins[2].weight, lins[2].bias)
+    if torch.is_grad_enabled():
+        for w in weights:
+            if w.requires_grad and w.is_leaf:
+                (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
+    return _ReadoutMse.apply(x, pool_rowptr, n_graphs, n_real, target, norms[1].eps, unit_grad, weights, *weights)
+
+
 def copy_many(dsts, srcs):
     """dst[i].copy_(src[i]) for lists of contiguous fp32 device tensors, in one launch (eqh_copy_many)."""
     n = len(dsts)

@@ -10,6 +10,7 @@ produces (the reference's dead branches, which is why main.py:281 needs
 """
 from __future__ import annotations
 
+import inspect
 from typing import Callable, Optional
 
 import torch
@@ -164,6 +165,7 @@ class GraphedTrainStep:
         self.others = []
         self.other_slots = []
         self.n_w = 0
+        self.fused_head = "head" in inspect.signature(model.forward).parameters
         if broadcast_from_rank0 and _world() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
@@ -177,6 +179,10 @@ class GraphedTrainStep:
         if hasattr(data, "_hyper_index"):
             data._hyper_index = None
         from . import ops
+        if self.fused_head and data.y.is_cuda:
+            # pool + output MLP + MSE and their backward in one launch; the gradient that loss.backward()
+            # feeds in is the implicit 1, so the head's parameter gradients go straight to the accumulators
+            return self.model(data, head=(data.y, nb, True))
         out = self.model(data)[:nb]
         return ops.mse_loss(out, data.y[:nb]) if out.is_cuda else F.mse_loss(out, data.y[:nb])
 
@@ -185,25 +191,26 @@ class GraphedTrainStep:
             p.grad = None
         if self.wflat is not None:
             self.wflat.zero_()
-        loss = self._loss(data)
-        self._backward(loss)
-        return loss
+        return self._loss_backward(data)
 
-    def _backward(self, loss):
-        """backward with the accumulating gradient reductions of the fused kernels deferred into one
-        launch (ops.defer_begin / defer_flush), then the packing of the remaining gradients."""
+    def _loss_backward(self, data):
+        """forward + backward with the accumulating gradient reductions of the fused kernels deferred into
+        one launch (ops.defer_begin / defer_flush; the fused readout head produces its parameter gradients
+        during the forward pass, so the window opens before it), then the packing of the remaining gradients."""
         from . import ops
-        dev = loss.device
+        dev = data.y.device
         defer = self.gflat is not None and dev.type == "cuda"
         if defer:
             ops.defer_begin(dev)
         try:
+            loss = self._loss(data)
             loss.backward()
         finally:
             if defer:
                 ops.defer_flush(dev)
         self._join()
         self._gather_grads()
+        return loss
 
     def _join(self):
         from . import ops
@@ -305,8 +312,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
             if self.wflat is not None:
                 self.wflat.zero_()
-            loss = self._loss(static)
-            self._backward(loss)
+            loss = self._loss_backward(static)
             if world == 1:          # nothing happens between backward and update: one graph, one launch
                 self.opt.step()
         g_opt = None

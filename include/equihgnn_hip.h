@@ -238,6 +238,27 @@ int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Readout head, forward + loss + complete backward in one launch: global_add_pool over the sorted node
+ * rows of each molecule (equihnn_egnn.py:167, mhnn.py:216, equihnn_equiformer.py:91), the output MLP
+ * C -> H -> H -> 1 with LayerNorm after ReLU (mlp.py:91-99 as built at equihnn_egnn.py:139-149 with
+ * output_num_layers = 3, Normalization "ln"), y.view(-1), and F.mse_loss over the first n_real molecules
+ * (main.py:49-63; the rest of the n_graphs rows are padding).
+ *   x [n_nodes, C]; rowptr int32 [n_graphs + 1] (nodes of molecule b = rows rowptr[b] .. rowptr[b+1]-1);
+ *   weights[10] = {W1 [H,C], b1, gamma1, beta1, W2 [H,H], b2, gamma2, beta2, w3 [1,H], b3 [1]};
+ *   y [n_graphs] predictions (rows >= n_real are not meaningful).
+ * target == NULL: predictions only.  Otherwise also loss [1], dx [n_nodes, C] = d loss / d x (written for
+ * every node row), and the ten parameter gradients dweights[10] (same shapes; overwritten or, with
+ * accumulate != 0, added to).  state: one int32 in device memory, zero before the first launch (the kernel
+ * leaves it zero); calls sharing one state must be stream-ordered.  Supported: C in {64,128,256}, H in {64,128}.
+ * ------------------------------------------------------------------------------------------- */
+int hg_readout_mse_supported(int32_t C, int32_t H);
+size_t hg_readout_mse_workspace_bytes(int32_t n_graphs, int32_t C, int32_t H);
+int hg_readout_mse_f32(const float* x, const int32_t* rowptr, int32_t n_graphs, int32_t n_real, int32_t C,
+                       int32_t H, const float* const* weights, float eps, const float* target, float* y,
+                       float* loss, float* dx, float* const* dweights, int32_t accumulate, void* workspace,
+                       size_t workspace_bytes, int32_t* state, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending
  * (may be NULL), v [B,3,3] eigenvectors in columns, largest component of each column positive.

@@ -678,6 +678,77 @@ def test_layer_norm_rows_matches_float64_reference(R, C):
         assert err < 3e-5, (name, err)
 
 
+@pytest.mark.parametrize("C,H,B,n_real", [(256, 128, 37, 33), (64, 128, 16, 16), (128, 64, 5, 4), (256, 64, 257, 256)])
+def test_readout_mse_matches_float64_reference(C, H, B, n_real):
+    """pool -> MLP(C,H,H,1; LN after ReLU) -> MSE over the first n_real molecules, fused (one launch for loss, dx and
+    the ten parameter gradients) against the same head in float64 autograd; then the accumulate-in-place mode
+    the trainer uses, eagerly and with the reductions deferred."""
+    ops = _ops()
+    from equihgnn_amd.layers import MLP
+    g = torch.Generator().manual_seed(C + H + B)
+    sizes = torch.randint(1, 30, (B,), generator=g)
+    sizes[min(2, B - 1)] = 0                               # a molecule without atoms pools to zero
+    rowptr64 = torch.cat((torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)))
+    N = int(rowptr64[-1])
+    x = torch.randn(N, C, generator=g)
+    y = torch.randn(B, generator=g)
+    torch.manual_seed(B)
+    mlp = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False)
+    for p in mlp.parameters():
+        p.data.add_(0.1 * torch.randn(p.shape, generator=g))
+    ref = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False).double()
+    ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+    xd = x.double().requires_grad_(True)
+    batch = torch.repeat_interleave(torch.arange(B), sizes)
+    pooled = torch.zeros(B, C, dtype=torch.double).index_add_(0, batch, xd)
+    h = pooled
+    for i in range(2):
+        h = torch.nn.functional.layer_norm(torch.relu(ref.lins[i](h)), (H,), ref.normalizations[i + 1].weight,
+                                           ref.normalizations[i + 1].bias, 1e-5)
+    out = ref.lins[2](h).view(-1)
+    loss_ref = ((out[:n_real] - y[:n_real].double()) ** 2).mean()
+    loss_ref.backward()
+
+    mlp = mlp.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    rowptr = rowptr64.int().to(DEV)
+    assert ops.readout_mse_supported(xg, mlp)
+    loss, pred = ops.readout_mse(xg, rowptr, mlp, y.to(DEV), n_real)
+    (3.0 * loss).backward()                                # a non-unit incoming gradient scales everything
+    np.testing.assert_allclose(pred[:n_real].cpu().numpy(), out[:n_real].detach().numpy(), atol=2e-5, rtol=1e-5)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+
+    def rel(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max().clamp(min=1e-9))
+
+    assert rel(xg.grad / 3.0, xd.grad) < 3e-5
+    names = [n for n, _ in mlp.named_parameters()]
+    for (n, p), pr in zip(mlp.named_parameters(), ref.parameters()):
+        assert rel(p.grad / 3.0, pr.grad) < 5e-5, n
+    # rows of padding molecules get exactly zero
+    if n_real < B:
+        assert float(xg.grad[int(rowptr64[n_real]):].abs().max()) == 0.0
+    # trainer mode: unit incoming gradient, parameter gradients ADDED to persistent accumulators
+    for deferred in (False, True):
+        for p in mlp.parameters():
+            p.grad = None
+            p._eqh_gbuf = torch.full_like(p, 0.5)
+        xg2 = x.to(DEV).requires_grad_(True)
+        if deferred:
+            ops.defer_begin(DEV)
+        loss2, _ = ops.readout_mse(xg2, rowptr, mlp, y.to(DEV), n_real, unit_grad=True)
+        loss2.backward()
+        if deferred:
+            ops.defer_flush(DEV)
+        assert float(loss2) == float(loss)
+        assert torch.equal(xg2.grad, xg.grad / 3.0) or rel(xg2.grad, xd.grad) < 3e-5
+        for (n, p), pr in zip(mlp.named_parameters(), ref.parameters()):
+            assert p.grad is None, n
+            assert rel(p._eqh_gbuf - 0.5, pr.grad) < 5e-5, (n, deferred)
+        for p in mlp.parameters():
+            del p._eqh_gbuf
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
