@@ -47,51 +47,56 @@ __device__ __forceinline__ float half_sum(float v) {
     return v;
 }
 
-// out[m][n] = sum_k A[m][k] W[n][k]: A in LDS (16 rows, stride lda), W [N][K] row-major in global memory
-template <int K, int N>
-__device__ __forceinline__ void rows_times_wt(const float* sA, int lda, const float* __restrict__ W, float* sOut,
-                                              int ldo, int wave, int lane) {
+// out[m][n] = sum_k A[m][k] W[n][k]: A in LDS (16 rows, stride lda), W [N][K] row-major in global memory.
+// The two halves are separate so that a tile's weights can be requested a phase ahead of their use (the kernel
+// is a chain of short dependent phases on 17 workgroups: every exposed memory latency is step time).
+template <int K>
+__device__ __forceinline__ void wt_tile_load(const float* __restrict__ W, int t, int lane, float4 (&b)[K / 16]) {
+    const float* wrow = W + (int64_t)(16 * t + (lane & 15)) * K + 4 * (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < K / 16; ++s) b[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+}
+template <int K>
+__device__ __forceinline__ void wt_tile_mma(const float* sA, int lda, const float4 (&b)[K / 16], float* sOut, int ldo,
+                                            int t, int lane) {
     const int r = lane & 15, q = lane >> 4;
-    for (int t = wave; t < N / 16; t += RH_WAVES) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* wrow = W + (int64_t)(16 * t + r) * K + 4 * q;
-        float4 b[K / 16];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < K / 16; ++s) b[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
-#pragma unroll
-        for (int s = 0; s < K / 16; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(sA + r * lda + 16 * s + 4 * q);
-            acc = mfma16(a.x, b[s].x, acc);
-            acc = mfma16(a.y, b[s].y, acc);
-            acc = mfma16(a.z, b[s].z, acc);
-            acc = mfma16(a.w, b[s].w, acc);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sOut[(4 * q + g) * ldo + 16 * t + r] = acc[g];
+    for (int s = 0; s < K / 16; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(sA + r * lda + 16 * s + 4 * q);
+        acc = mfma16(a.x, b[s].x, acc);
+        acc = mfma16(a.y, b[s].y, acc);
+        acc = mfma16(a.z, b[s].z, acc);
+        acc = mfma16(a.w, b[s].w, acc);
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sOut[(4 * q + g) * ldo + 16 * t + r] = acc[g];
 }
 
 // out[m][i] = sum_o A[m][o] W[o][i]: A in LDS (stride lda), W [O][I] row-major in global memory
 template <int O, int I>
-__device__ __forceinline__ void rows_times_w(const float* sA, int lda, const float* __restrict__ W, float* sOut,
-                                             int ldo, int wave, int lane) {
-    const int r = lane & 15, q = lane >> 4;
-    for (int t = wave; t < I / 16; t += RH_WAVES) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* wcol = W + (int64_t)(4 * q) * I + 16 * t + r;
-#pragma unroll 4
-        for (int s = 0; s < O / 16; ++s) {
-            const float4 a = *reinterpret_cast<const float4*>(sA + r * lda + 16 * s + 4 * q);
-            const float* w = wcol + (int64_t)(16 * s) * I;
-            const float b0 = w[0], b1 = w[I], b2 = w[2 * I], b3 = w[3 * I];
-            acc = mfma16(a.x, b0, acc);
-            acc = mfma16(a.y, b1, acc);
-            acc = mfma16(a.z, b2, acc);
-            acc = mfma16(a.w, b3, acc);
-        }
+__device__ __forceinline__ void w_cols_load(const float* __restrict__ W, int t, int lane, float (&b)[O / 4]) {
+    const float* wcol = W + (int64_t)(4 * (lane >> 4)) * I + 16 * t + (lane & 15);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) sOut[(4 * q + g) * ldo + 16 * t + r] = acc[g];
+    for (int s = 0; s < O / 16; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[4 * s + j] = wcol[(int64_t)(16 * s + j) * I];
+}
+template <int O>
+__device__ __forceinline__ void w_cols_mma(const float* sA, int lda, const float (&b)[O / 4], float* sOut, int ldo,
+                                           int t, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < O / 16; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(sA + r * lda + 16 * s + 4 * q);
+        acc = mfma16(a.x, b[4 * s + 0], acc);
+        acc = mfma16(a.y, b[4 * s + 1], acc);
+        acc = mfma16(a.z, b[4 * s + 2], acc);
+        acc = mfma16(a.w, b[4 * s + 3], acc);
     }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sOut[(4 * q + g) * ldo + 16 * t + r] = acc[g];
 }
 
 // out[o][i] = sum_{m < 16} D[m][o] In[m][i] (both in LDS) -> this workgroup's slab [O][I] in global memory
@@ -198,7 +203,8 @@ struct RhLds {
     static constexpr int X = 0, DX = X + RH_ROWS * LX, A1 = DX + RH_ROWS * LX, XH1 = A1 + RH_ROWS * LH,
                          H1 = XH1 + RH_ROWS * LH, A2 = H1 + RH_ROWS * LH, XH2 = A2 + RH_ROWS * LH,
                          H2 = XH2 + RH_ROWS * LH, DZ2 = H2 + RH_ROWS * LH, DH1 = DZ2 + RH_ROWS * LH,
-                         DZ1 = DH1 + RH_ROWS * LH, STAT = DZ1 + RH_ROWS * LH, TOTAL = STAT + 4 * RH_ROWS;
+                         DZ1 = DH1 + RH_ROWS * LH, STAT = DZ1 + RH_ROWS * LH, VEC = STAT + 4 * RH_ROWS,
+                         TOTAL = VEC + 7 * H + 4;   // VEC: b1 g1 be1 b2 g2 be2 w3 b3
 };
 
 template <int C, int H>
@@ -230,56 +236,97 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
     const int b0 = blockIdx.x * RH_ROWS;
     const bool train = target != nullptr;
 
+    // ---- requests issued first: the small parameter vectors (to LDS) and this wavefront's tile of W1
+    float* sV = s_mem + L::VEC;
+    const float *vb1 = sV, *vg1 = sV + H, *vbe1 = sV + 2 * H, *vb2 = sV + 3 * H, *vg2 = sV + 4 * H,
+                *vbe2 = sV + 5 * H, *vw3 = sV + 6 * H, *vb3 = sV + 7 * H;
+    constexpr int VPT = (7 * H + RH_THREADS - 1) / RH_THREADS;
+    float vreg[VPT];
+    {
+        const float* src[7] = {w.b1, w.g1, w.be1, w.b2, w.g2, w.be2, w.w3};
+#pragma unroll
+        for (int k = 0; k < VPT; ++k) {
+            const int i = threadIdx.x + k * RH_THREADS;
+            vreg[k] = i < 7 * H ? src[i / H][i % H] : 0.f;
+        }
+    }
+    const float vb3_reg = w.b3[0];
+    static_assert(H / 16 <= RH_WAVES && C / 16 <= 2 * RH_WAVES, "one H tile, two C tiles per wavefront");
+    const bool has_h_tile = wave < H / 16;
+    float4 bw1[C / 16];
+    if (has_h_tile) wt_tile_load<C>(w.w1, wave, lane, bw1);
+
     // ---- global_add_pool: wavefront w owns molecules 2w, 2w+1 of the tile; a row of X is C/4 float4 lanes, so
-    // 64 / (C/4) atoms are read side by side, four deep
+    // 64 / (C/4) atoms are read side by side, eight deep for each of the two molecules at once
     constexpr int LPR = C / 4, AP = 64 / LPR;
     static_assert(LPR <= 64 && 64 % LPR == 0, "C in {16..256}, power-of-two float4 lanes");
     const int sub = lane / LPR, cl = lane - sub * LPR;
-    for (int mi = 2 * wave; mi < 2 * wave + 2; ++mi) {
-        const int b = b0 + mi;
-        float4 acc = f4_zero();
-        if (b < n_real) {
-            const int beg = rowptr[b], end = rowptr[b + 1];
-            for (int n = beg + sub; n < end; n += 4 * AP) {
-                float4 v[4];
+    {
+        const int m0 = b0 + 2 * wave, m1 = m0 + 1;
+        int beg0 = 0, end0 = 0, beg1 = 0, end1 = 0;
+        if (m0 < n_real) { beg0 = rowptr[m0]; end0 = rowptr[m0 + 1]; }
+        if (m1 < n_real) { beg1 = rowptr[m1]; end1 = rowptr[m1 + 1]; }
+        const int last0 = end0 > 0 ? end0 - 1 : 0, last1 = end1 > 0 ? end1 - 1 : 0;
+        float4 acc0 = f4_zero(), acc1 = f4_zero();
+        constexpr int DEEP = 8;   // rows in flight per molecule: a QM9 molecule (<= 29 atoms) takes <= 4 rounds
+        for (int n0 = beg0 + sub, n1 = beg1 + sub; n0 < end0 || n1 < end1; n0 += DEEP * AP, n1 += DEEP * AP) {
+            float4 v0[DEEP], v1[DEEP];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int nn = n + u * AP;
-                    const int nc = nn < end ? nn : end - 1;
-                    v[u] = *reinterpret_cast<const float4*>(X + (int64_t)nc * C + 4 * cl);
-                    if (nn >= end) v[u] = f4_zero();
-                }
+            for (int u = 0; u < DEEP; ++u) {
+                const int a0 = n0 + u * AP, a1 = n1 + u * AP;
+                v0[u] = *reinterpret_cast<const float4*>(X + (int64_t)(a0 < end0 ? a0 : last0) * C + 4 * cl);
+                v1[u] = *reinterpret_cast<const float4*>(X + (int64_t)(a1 < end1 ? a1 : last1) * C + 4 * cl);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) f4_add(acc, v[u]);
+            for (int u = 0; u < DEEP; ++u) {
+                if (n0 + u * AP < end0) f4_add(acc0, v0[u]);
+                if (n1 + u * AP < end1) f4_add(acc1, v1[u]);
             }
         }
 #pragma unroll
         for (int off = LPR; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            acc.w += __shfl_xor(acc.w, off);
+            acc0.x += __shfl_xor(acc0.x, off); acc0.y += __shfl_xor(acc0.y, off);
+            acc0.z += __shfl_xor(acc0.z, off); acc0.w += __shfl_xor(acc0.w, off);
+            acc1.x += __shfl_xor(acc1.x, off); acc1.y += __shfl_xor(acc1.y, off);
+            acc1.z += __shfl_xor(acc1.z, off); acc1.w += __shfl_xor(acc1.w, off);
         }
-        if (sub == 0) *reinterpret_cast<float4*>(sX + mi * LX + 4 * cl) = acc;
+        if (sub == 0) {
+            *reinterpret_cast<float4*>(sX + (2 * wave) * LX + 4 * cl) = acc0;
+            *reinterpret_cast<float4*>(sX + (2 * wave + 1) * LX + 4 * cl) = acc1;
+        }
     }
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int i = threadIdx.x + k * RH_THREADS;
+        if (i < 7 * H) sV[i] = vreg[k];
+    }
+    if (threadIdx.x == 0) sV[7 * H] = vb3_reg;
     __syncthreads();
 
     // ---- forward
-    rows_times_wt<C, H>(sX, LX, w.w1, sA1, LH, wave, lane);
+    float4 bw2[H / 16];
+    if (has_h_tile) {
+        wt_tile_mma<C>(sX, LX, bw1, sA1, LH, wave, lane);
+        wt_tile_load<H>(w.w2, wave, lane, bw2);          // in flight during LayerNorm 1
+    }
     __syncthreads();
-    relu_ln_rows<H>(sA1, w.b1, w.g1, w.be1, sXH1, sH1, sR1, LH, eps);
+    relu_ln_rows<H>(sA1, vb1, vg1, vbe1, sXH1, sH1, sR1, LH, eps);
     __syncthreads();
-    rows_times_wt<H, H>(sH1, LH, w.w2, sA2, LH, wave, lane);
+    float cw2[H / 4];
+    if (has_h_tile) {
+        wt_tile_mma<H>(sH1, LH, bw2, sA2, LH, wave, lane);
+        if (train) w_cols_load<H, H>(w.w2, wave, lane, cw2);   // for d h1, three phases ahead
+    }
     __syncthreads();
-    relu_ln_rows<H>(sA2, w.b2, w.g2, w.be2, sXH2, sH2, sR2, LH, eps);
+    relu_ln_rows<H>(sA2, vb2, vg2, vbe2, sXH2, sH2, sR2, LH, eps);
     __syncthreads();
     {
         constexpr int CPT = H / 32;
         const int row = threadIdx.x >> 5, l = threadIdx.x & 31;
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) s = fmaf(sH2[row * LH + l + 32 * j], w.w3[l + 32 * j], s);
-        s = half_sum(s) + w.b3[0];
+        for (int j = 0; j < CPT; ++j) s = fmaf(sH2[row * LH + l + 32 * j], vw3[l + 32 * j], s);
+        s = half_sum(s) + vb3[0];
         if (l == 0) {
             const int b = b0 + row;
             if (b < n_graphs) y[b] = s;
@@ -298,7 +345,7 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
 
     // ---- backward
     const int64_t wg = blockIdx.x;
-    relu_ln_bwd_rows<H>(nullptr, w.w3, sDy, sA2, sXH2, w.g2, sR2, sDZ2, LH);
+    relu_ln_bwd_rows<H>(nullptr, vw3, sDy, sA2, sXH2, vg2, sR2, sDZ2, LH);
     {   // dw3 | db3 | pad, and the squared-error partial (row order)
         float* v3 = slab.v3 + wg * (H + 4);
         const int t = threadIdx.x;
@@ -311,19 +358,24 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
             for (int m = 0; m < RH_ROWS; ++m) { s += sDy[m]; e += sSq[m]; }
             v3[H] = s;
             v3[H + 1] = 0.f; v3[H + 2] = 0.f; v3[H + 3] = 0.f;
-            loss_part[wg] = e;
+            // agent-scope atomic store: visible to the other XCDs without a cache write-back; it has long
+            // completed when this workgroup takes its ticket at the end of the kernel
+            __hip_atomic_store(loss_part + wg, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
-    ln_param_sums<H>(nullptr, w.w3, sDy, sXH2, sDZ2, LH, slab.v2 + wg * 3 * H);
+    float cw1a[H / 4], cw1b[H / 4];   // W1 columns of this wavefront's (up to) two C tiles, for dx
+    const bool has_c0 = wave < C / 16, has_c1 = wave + RH_WAVES < C / 16;
+    if (has_h_tile) w_cols_mma<H>(sDZ2, LH, cw2, sDH1, LH, wave, lane);
+    if (has_c0) w_cols_load<H, C>(w.w1, wave, lane, cw1a);
+    if (has_c1) w_cols_load<H, C>(w.w1, wave + RH_WAVES, lane, cw1b);
+    ln_param_sums<H>(nullptr, vw3, sDy, sXH2, sDZ2, LH, slab.v2 + wg * 3 * H);
     outer_rows<H, H>(sDZ2, LH, sH1, LH, slab.w2 + wg * H * H, wave, lane);
-    rows_times_w<H, H>(sDZ2, LH, w.w2, sDH1, LH, wave, lane);
     __syncthreads();
-    relu_ln_bwd_rows<H>(sDH1, nullptr, nullptr, sA1, sXH1, w.g1, sR1, sDZ1, LH);
+    relu_ln_bwd_rows<H>(sDH1, nullptr, nullptr, sA1, sXH1, vg1, sR1, sDZ1, LH);
     __syncthreads();
-    ln_param_sums<H>(sDH1, nullptr, nullptr, sXH1, sDZ1, LH, slab.v1 + wg * 3 * H);
-    outer_rows<H, C>(sDZ1, LH, sX, LX, slab.w1 + wg * (int64_t)H * C, wave, lane);
-    rows_times_w<H, C>(sDZ1, LH, w.w1, sDX, LX, wave, lane);
+    if (has_c0) w_cols_mma<H>(sDZ1, LH, cw1a, sDX, LX, wave, lane);
+    if (has_c1) w_cols_mma<H>(sDZ1, LH, cw1b, sDX, LX, wave + RH_WAVES, lane);
     __syncthreads();
 
     // ---- dX[n, :] = dx[molecule(n), :] (zero rows for the padding molecules b >= n_real: their dy is 0)
@@ -335,18 +387,22 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         for (int n = beg + sub; n < end; n += AP) *reinterpret_cast<float4*>(dX + (int64_t)n * C + 4 * cl) = g;
     }
 
+    // ---- the two large gradient slabs last: nothing in this kernel waits for them
+    ln_param_sums<H>(sDH1, nullptr, nullptr, sXH1, sDZ1, LH, slab.v1 + wg * 3 * H);
+    outer_rows<H, C>(sDZ1, LH, sX, LX, slab.w1 + wg * (int64_t)H * C, wave, lane);
+
     // ---- loss = sum of the workgroups' partials / n_real, by the last workgroup to arrive, in workgroup order
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(state, 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
-        __threadfence();
-        float e = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) e += __builtin_nontemporal_load(loss_part + i);
-        loss[0] = e / (float)n_real;
-        *state = 0;   // ready for the next launch (graph replay)
+    if (threadIdx.x == H) {   // the thread that stored this workgroup's partial: its store is ordered before its ticket
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        const int ticket = __hip_atomic_fetch_add(state, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (int)gridDim.x - 1) {
+            float e = 0.f;
+            for (unsigned i = 0; i < gridDim.x; ++i)
+                e += __hip_atomic_load(loss_part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss[0] = e / (float)n_real;
+            __hip_atomic_store(state, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
     }
 }
 
@@ -376,7 +432,7 @@ int rh_launch(const float* x, const int32_t* rowptr, int n_graphs, int n_real, c
               const float* target, float* y, float* loss, float* dx, const RhSlabs& slab, float* loss_part, int* state,
               int n_wg, hipStream_t stream) {
     constexpr size_t lds = (size_t)RhLds<C, H>::TOTAL * sizeof(float);
-    static_assert(lds + 64 <= 160 * 1024, "LDS budget (dynamic + the static ticket flag)");
+    static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_readout_mse<C, H>),
