@@ -89,6 +89,9 @@ class Radial(nn.Module):
                                 nn.Linear(mid, nc_in * nc_out))
 
     def trunk(self, dist_flat):  # [E, 1] -> [E, mid]
+        rp = self.rp
+        if ops.radial_trunk_supported(dist_flat, rp[0], rp[2], rp[3], rp[5]):
+            return ops.radial_trunk(dist_flat, rp[0], rp[2], rp[3], rp[5])   # one launch each way (csrc/radial.hip)
         h = dist_flat
         for i in range(6):
             h = self.rp[i](h)

@@ -976,6 +976,63 @@ def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
     return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
 
 
+class _RadialTrunk(torch.autograd.Function):
+    """Linear(1,64) -> SiLU -> LN -> Linear(64,64) -> SiLU -> LN per edge, one launch each way
+    (eqf_radial_trunk_fwd / _bwd, csrc/radial.hip); the backward recomputes the forward from ``dist``."""
+
+    @staticmethod
+    def forward(ctx, dist, eps, acc_params, w0, b0, g1, be1, w1, b1, g2, be2):
+        _require_gpu(dist, "radial_trunk")
+        dist = _f32c(dist).reshape(-1)
+        ps = [_f32c(t.detach()) for t in (w0, b0, g1, be1, w1, b1, g2, be2)]
+        E, M = dist.shape[0], ps[4].shape[0]
+        out = torch.empty((E, M), dtype=torch.float32, device=dist.device)
+        vp = ctypes.c_void_p * 8
+        hip.check(hip.lib().eqf_radial_trunk_fwd(_ptr(dist), vp(*[t.data_ptr() for t in ps]), E, M, float(eps), _ptr(out),
+                                                 _stream(dist.device)), "eqf_radial_trunk_fwd")
+        ctx.dist, ctx.ps, ctx.eps, ctx.acc = dist, ps, float(eps), acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        dist, ps = ctx.dist, ctx.ps
+        dh = _f32c(dh)
+        E, M = dist.shape[0], ps[4].shape[0]
+        dev = dist.device
+        L = hip.lib()
+        ws_bytes = L.eqf_radial_trunk_bwd_workspace_bytes(E)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(p) for p in ctx.acc]          # order: w0, b0, g1, w1, b1, g2
+        in_place = all(t is not None for t in tg)
+        grads = tg if in_place else [torch.empty_like(ps[i]) for i in (0, 1, 2, 4, 5, 6)]
+        vp8, vp6 = ctypes.c_void_p * 8, ctypes.c_void_p * 6
+        hip.check(L.eqf_radial_trunk_bwd(_ptr(dist), vp8(*[t.data_ptr() for t in ps]), _ptr(dh), E, M, ctx.eps,
+                                         vp6(*[g.data_ptr() for g in grads]), 1 if in_place else 0, _ptr(ws), ws_bytes,
+                                         _stream(dev)), "eqf_radial_trunk_bwd")
+        if in_place:
+            return (None,) * 11
+        dw0, db0, dg1, dw1, db1, dg2 = grads
+        return None, None, None, dw0, db0, dg1, None, dw1, db1, dg2, None
+
+
+def radial_trunk_supported(dist, lin0, ln1, lin1, ln2) -> bool:
+    return (dist.is_cuda and not dist.requires_grad and dist.dtype == torch.float32 and lin0.in_features == 1
+            and lin0.out_features == 64 and lin1.in_features == 64 and lin1.out_features == 64
+            and lin0.bias is not None and lin1.bias is not None)
+
+
+def radial_trunk(dist, lin0, ln1, lin1, ln2, eps: float = 1e-5):
+    """[E] or [E,1] distances -> [E,64]: ``lin0`` Linear(1,64), ``ln1``/``ln2`` modules with ``gamma`` (parameter)
+    and ``beta`` (buffer), ``lin1`` Linear(64,64); SiLU between Linear and LayerNorm (equiformer_layer.py:451-479)."""
+    params = (lin0.weight, lin0.bias, ln1.gamma, lin1.weight, lin1.bias, ln2.gamma)
+    if torch.is_grad_enabled():
+        for w in params:
+            if w.requires_grad and w.is_leaf:
+                (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
+    return _RadialTrunk.apply(dist, eps, params, lin0.weight, lin0.bias, ln1.gamma, ln1.beta, lin1.weight, lin1.bias,
+                              ln2.gamma, ln2.beta)
+
+
 def layer_norm_rows(x, gamma, beta, eps: float = 1e-5):
     """nn.LayerNorm over the last dim of 2-D ``x`` [rows, C] (C % 4 == 0, C <= 1024)."""
     _note_acc(gamma, beta)

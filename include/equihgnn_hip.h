@@ -238,6 +238,21 @@ int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Trunk of the Equiformer radial network, `Radial.rp[0..5]` of equiformer_layer.py:451-479, per edge:
+ * Linear(1,64) -> SiLU -> LayerNorm -> Linear(64,64) -> SiLU -> LayerNorm (the local LayerNorm of
+ * :158-165: learnable gamma, beta a zero buffer).  dist [E]; params[8] = {w0 [64] (= rp.0.weight[:,0]),
+ * b0, gamma1, beta1, W1 [64,64], b1, gamma2, beta2}; out [E,64].  bwd recomputes the forward from dist
+ * (nothing saved) and yields dparams[6] = {dw0, db0, dgamma1, dW1, db1, dgamma2} (overwritten, or added to
+ * with accumulate != 0); dist gets no gradient (positions are data, basis.py:194).  M must be 64.
+ * ------------------------------------------------------------------------------------------- */
+int eqf_radial_trunk_fwd(const float* dist, const float* const* params, int64_t E, int32_t M, float eps,
+                         float* out, void* stream);
+size_t eqf_radial_trunk_bwd_workspace_bytes(int64_t E);
+int eqf_radial_trunk_bwd(const float* dist, const float* const* params, const float* dh, int64_t E, int32_t M,
+                         float eps, float* const* dparams, int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Readout head, forward + loss + complete backward in one launch: global_add_pool over the sorted node
  * rows of each molecule (equihnn_egnn.py:167, mhnn.py:216, equihnn_equiformer.py:91), the output MLP
  * C -> H -> H -> 1 with LayerNorm after ReLU (mlp.py:91-99 as built at equihnn_egnn.py:139-149 with

@@ -749,6 +749,57 @@ def test_readout_mse_matches_float64_reference(C, H, B, n_real):
             del p._eqh_gbuf
 
 
+@pytest.mark.parametrize("E", [1, 77, 5000, 36864])
+def test_radial_trunk_matches_float64_reference(E):
+    """Linear(1,64) -> SiLU -> LN -> Linear(64,64) -> SiLU -> LN per edge (equiformer_layer.py:451-479): forward and
+    the six parameter gradients against the same modules in float64; then accumulation into persistent buffers."""
+    ops = _ops()
+    from equihgnn_amd.equiformer import Radial
+    torch.manual_seed(E)
+    rad = Radial(4, 4)
+    g = torch.Generator().manual_seed(E + 1)
+    for p in rad.parameters():
+        p.data.add_(0.3 * torch.randn(p.shape, generator=g))
+    rad.rp[2].beta.copy_(0.1 * torch.randn(64, generator=g))          # buffers: honoured, no gradient
+    dist = 0.8 + 4.0 * torch.rand(E, 1, generator=g)
+    w = torch.randn(E, 64, generator=g)
+    ref = Radial(4, 4).double()
+    ref.load_state_dict({k: v.double() for k, v in rad.state_dict().items()})
+    h = dist.double()
+    for i in range(6):
+        h = ref.rp[i](h)
+    (h * w.double()).sum().backward()
+    rad = rad.to(DEV)
+    rp = rad.rp
+    d = dist.to(DEV)
+    assert ops.radial_trunk_supported(d, rp[0], rp[2], rp[3], rp[5])
+    out = ops.radial_trunk(d, rp[0], rp[2], rp[3], rp[5])
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), h.detach().numpy(), atol=2e-5, rtol=2e-5)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max().clamp(min=1e-9))
+
+    pairs = [(rp[i].weight, ref.rp[i].weight) for i in (0, 3)] + [(rp[i].bias, ref.rp[i].bias) for i in (0, 3)] \
+        + [(rp[i].gamma, ref.rp[i].gamma) for i in (2, 5)]
+    for mine, theirs in pairs:
+        assert rel(mine.grad, theirs.grad) < 5e-5, tuple(mine.shape)
+    assert rp[6].weight.grad is None
+    # trainer mode: gradients ADDED to persistent accumulators, reductions deferred to one launch
+    for mine, _ in pairs:
+        mine.grad = None
+        mine._eqh_gbuf = torch.full_like(mine, 0.25)
+    ops.defer_begin(DEV)
+    out2 = ops.radial_trunk(d, rp[0], rp[2], rp[3], rp[5])
+    (out2 * w.to(DEV)).sum().backward()
+    ops.defer_flush(DEV)
+    assert torch.equal(out2, out)
+    for mine, theirs in pairs:
+        assert mine.grad is None
+        assert rel(mine._eqh_gbuf - 0.25, theirs.grad) < 5e-5, tuple(mine.shape)
+        del mine._eqh_gbuf
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
