@@ -133,12 +133,19 @@ class EdgeGeometry:
         self.has = (self.mask.sum(1, keepdim=True) > 0).to(pos.dtype)
         self.maskf = self.mask.to(pos.dtype)
         self.recv_rowptr = torch.arange(0, (n + 1) * self.K, self.K, dtype=torch.int32, device=pos.device)
+        # masked mean over the neighbour slots as a batched product: weights mask / count (0 for an empty set)
+        self.mean_w = (self.maskf * (self.has / self.cnt))[:, None, :]                        # [N, 1, K]
+        self.mean_w_rhat = (self.maskf * (self.has / self.cnt))[..., None] * rhat             # [N, K, 3]
 
     def masked_mean(self, t):
         """equiformer/utils.py:71-82 over the K neighbour slots; t is [E, ...]."""
         shape = t.shape[1:]
-        t = t.view(self.N, self.K, -1) * self.maskf[..., None]
-        return (t.sum(1) / self.cnt * self.has).view(self.N, *shape)
+        return torch.bmm(self.mean_w, t.view(self.N, self.K, -1)).view(self.N, *shape)
+
+    def masked_mean_times_rhat(self, t):
+        """masked_mean(t[:, :, None] * r_hat[:, None, :]) for t [E, C] -> [N, C, 3] without the [E, C, 3]
+        intermediate: one batched [C x K] . [K x 3] product per node."""
+        return torch.bmm(t.view(self.N, self.K, -1).transpose(1, 2), self.mean_w_rhat)
 
 
 def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
@@ -161,7 +168,8 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
         qb = xi.transpose(1, 2) @ b3.t()                                            # [N, 3, lo]
         g = ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]
         bias = (g.reshape(-1, 3, lo) * zscale[:, :, None]).sum(1)
-    out = ops.rowgemm(ze, p, geo.csr_t.rowptr, geo.csr_t.perm) + ops.rowgemm(ze, q, geo.recv_rowptr, None)
+    # sender rows (transposed neighbour CSR) and receiver rows both list every edge: one buffer, second pass adds
+    out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
     return out[:, :lo] + bias
 
 
@@ -182,7 +190,7 @@ class DTPIn(nn.Module):
         o0 = radial_contract(r00, r00.trunk(geo.dist), xj, xi, geo)                 # [E, C]
         o1 = radial_contract(r01, r01.trunk(geo.dist), xj, xi, geo)                 # [E, C]
         p0 = geo.masked_mean(o0)                                                    # [N, C]
-        p1 = geo.masked_mean(o1[:, :, None] * geo.rhat[:, None, :])                 # [N, C, 3]
+        p1 = geo.masked_mean_times_rhat(o1)                                         # [N, C, 3]
         out0 = p0 @ self.to_out.w(0) + x0 @ self.self_interact.w(0)
         out1 = torch.einsum("ndm,de->nem", p1, self.to_out.w(1))
         return out0, out1

@@ -909,6 +909,51 @@ class _RowGemm(torch.autograd.Function):
         return dz, dw, None, None
 
 
+class _RowGemm2(torch.autograd.Function):
+    """out[e] = z[e] @ wa[row_a(e)] + z[e] @ wb[row_b(e)] for two groupings of the same entries that each cover
+    EVERY entry (sender rows and receiver rows of the neighbour graph): the second pass accumulates into the
+    first one's output, and so do the two halves of dz, so neither a zero fill nor an add kernel runs."""
+
+    @staticmethod
+    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+        _require_gpu(z, "rowgemm2")
+        z, wa, wb = _f32c(z), _f32c(wa), _f32c(wb)
+        E, Kd = z.shape
+        Ra, _, L = wa.shape
+        Rb = wb.shape[0]
+        if wa.shape[1:] != wb.shape[1:] or wa.shape[1] != Kd or rowptr_a.numel() != Ra + 1 or rowptr_b.numel() != Rb + 1:
+            raise ValueError("rowgemm2: z[E,Kd], wa[Ra,Kd,L], wb[Rb,Kd,L], rowptr_a[Ra+1], rowptr_b[Rb+1] expected")
+        out = torch.empty((E, L), dtype=torch.float32, device=z.device)
+        L_ = hip.lib()
+        st = _stream(z.device)
+        hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0, st),
+                  "hg_rowgemm_fwd")
+        hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1, st),
+                  "hg_rowgemm_fwd")
+        ctx.save_for_backward(z, wa, wb)
+        ctx.idx = (rowptr_a, perm_a, rowptr_b, perm_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, wa, wb = ctx.saved_tensors
+        rowptr_a, perm_a, rowptr_b, perm_b = ctx.idx
+        dout = _f32c(dout)
+        Ra, Kd, L = wa.shape
+        Rb = wb.shape[0]
+        need_z = ctx.needs_input_grad[0]
+        dz = torch.empty_like(z) if need_z else None
+        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] else None
+        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] else None
+        L_ = hip.lib()
+        st = _stream(z.device)
+        hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz), 0,
+                                    _ptr(dwa), st), "hg_rowgemm_bwd")
+        hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
+                                    _ptr(dwb), st), "hg_rowgemm_bwd")
+        return dz, dwa, None, None, dwb, None, None
+
+
 # --------------------------------------------------------------------------------------------
 # public functional API
 # --------------------------------------------------------------------------------------------
@@ -1052,6 +1097,12 @@ def eigh3(cov):
 def rowgemm(z, w, rowptr, perm=None):
     """out[e, :] = z[e, :] @ w[row(e)]; rows given by rowptr (+ perm: entry ids per row)."""
     return _RowGemm.apply(z, w, rowptr, perm)
+
+
+def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+    """rowgemm(z, wa, rowptr_a, perm_a) + rowgemm(z, wb, rowptr_b, perm_b) when BOTH groupings cover every entry
+    of z (no entry outside all rows): one output buffer, the second pass accumulates."""
+    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
 
 
 def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
