@@ -46,6 +46,10 @@ SIGNATURES = {
     "eqf_radial_trunk_bwd_workspace_bytes": (c_size_t, [c_int64]),
     "eqf_radial_trunk_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_int32,
                                        c_void_p, c_size_t, c_void_p]),
+    "geo_knn_grid_max_points": (c_int64, []),
+    "geo_knn_grid_workspace_bytes": (c_size_t, [c_int64]),
+    "geo_knn_grid": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_void_p]),
     "hg_readout_mse_supported": (c_int32, [c_int32, c_int32]),
     "hg_readout_mse_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "hg_readout_mse_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_float,

@@ -44,6 +44,7 @@ class HyperIndex:
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
         self._he_pool = None
+        self.n_box = None   # int32 device [1]: number of real atoms of a padded batch (box of the kNN grid)
 
     def hyperedge_pool(self, n_e: torch.Tensor):
         """CSR of hyperedges per molecule (from ``n_e``; hyperedges are stored molecule by molecule,
@@ -66,6 +67,10 @@ class HyperIndex:
             m = ea.shape[0] if ea is not None else int(data.edge_index1.max()) + 1
         b = getattr(data, "num_graphs", None) or data.y.shape[0]
         idx = cls(data.edge_index0, data.edge_index1, n, m, data.batch, b)
+        real = getattr(data, "num_real_graphs", None)
+        if real and real < b and idx.pool is not None:
+            # padded batch: the atoms of the first `real` molecules come first; their count stays on the device
+            idx.n_box = idx.pool.rowptr[real:real + 1]
         try:
             data._hyper_index = idx
         except Exception:  # a frozen container: just rebuild next time
@@ -76,7 +81,7 @@ class HyperIndex:
         """(nbr int32 [N,k], key fp32 [N,k], CSR of the transposed neighbour graph)."""
         hit = self._knn.get((k, mode))
         if hit is None:
-            nbr, key = ops.knn(pos, k, mode)
+            nbr, key = ops.knn(pos, k, mode, self.n_box)
             csr_t = ops.csr_build(nbr.reshape(-1), None, self.N)      # int32 keys: no widening copy
             hit = (nbr, key, csr_t)
             self._knn[(k, mode)] = hit

@@ -238,6 +238,18 @@ int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * geo_knn through a uniform cell grid: identical outputs (neighbours ordered by (distance, index), same
+ * distance arithmetic, same modes and error behaviour as geo_knn above), O(N) distance evaluations.
+ * n_box: device int32 or NULL — the bounding box of the grid is taken over the first *n_box points only
+ * (a padded batch passes its number of real atoms: padding atoms are parked far away and are clamped
+ * into the boundary cells); NULL = all N.  N <= geo_knn_grid_max_points().
+ * ------------------------------------------------------------------------------------------- */
+int64_t geo_knn_grid_max_points(void);
+size_t geo_knn_grid_workspace_bytes(int64_t N);
+int geo_knn_grid(const float* pos, int64_t N, int32_t k, int32_t mode, const int32_t* n_box, int32_t* nbr,
+                 float* dist, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Trunk of the Equiformer radial network, `Radial.rp[0..5]` of equiformer_layer.py:451-479, per edge:
  * Linear(1,64) -> SiLU -> LayerNorm -> Linear(64,64) -> SiLU -> LayerNorm (the local LayerNorm of
  * :158-165: learnable gamma, beta a zero buffer).  dist [E]; params[8] = {w0 [64] (= rp.0.weight[:,0]),

@@ -800,6 +800,57 @@ def test_radial_trunk_matches_float64_reference(E):
         del mine._eqh_gbuf
 
 
+def _clouds(n_mol, per, seed, lattice=False):
+    g = torch.Generator().manual_seed(seed)
+    pts = []
+    for _ in range(n_mol):
+        n = int(torch.randint(max(3, per - 6), per + 7, (1,), generator=g))
+        p = torch.zeros(n, 3)
+        for i in range(1, n):                                   # chain growth, 1.4 A steps, then centred
+            u = torch.randn(3, generator=g)
+            p[i] = p[int(torch.randint(0, i, (1,), generator=g))] + 1.4 * u / u.norm()
+        pts.append(p - p.mean(0))
+    pos = torch.cat(pts)
+    if lattice:                                                 # exact ties: snap to a 0.5 A lattice (duplicates too)
+        pos = (pos * 2).round() / 2
+    return pos
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("case", ["molecules", "lattice", "padded", "uniform", "flat", "small"])
+def test_knn_grid_is_identical_to_brute_force(case, mode):
+    """geo_knn_grid against geo_knn: same indices in the same order and bitwise equal distances, on overlapping
+    molecule clouds, with exact distance ties, with far-away padding atoms behind an n_box limit, on a uniform
+    box, on a planar cloud and on a cloud smaller than one wavefront's candidates."""
+    ops = _ops()
+    n_box = None
+    if case == "molecules":
+        pos = _clouds(256, 18, 1)
+    elif case == "lattice":
+        pos = _clouds(200, 18, 2, lattice=True)
+    elif case == "padded":
+        real = _clouds(300, 30, 3)
+        far = torch.zeros(255, 3)
+        far[:, 0] = 1.0e4 + 10.0 * torch.arange(255)
+        pos = torch.cat((real, far))
+        n_box = torch.tensor([real.shape[0]], dtype=torch.int32, device=DEV)
+    elif case == "uniform":
+        pos = 40.0 * torch.rand(20000, 3, generator=torch.Generator().manual_seed(4))
+    elif case == "flat":
+        pos = _clouds(100, 18, 5)
+        pos[:, 2] = 0.25
+    else:
+        pos = _clouds(3, 12, 6)
+    pos = pos.to(DEV)
+    nb, db = ops.knn(pos, 16, mode, algorithm="brute")
+    ng, dg = ops.knn(pos, 16, mode, n_box, algorithm="grid")
+    assert torch.equal(db, dg), float((db - dg).abs().max())
+    assert torch.equal(nb, ng), int((nb != ng).sum())
+    if case == "padded":                                        # without the hint: still exact, only slower
+        ng2, dg2 = ops.knn(pos, 16, mode, None, algorithm="grid")
+        assert torch.equal(nb, ng2) and torch.equal(db, dg2)
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
