@@ -1021,6 +1021,46 @@ def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
     return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
 
 
+class _RmsNormRows(torch.autograd.Function):
+    """t / max(||t|| * C^-1/2, eps) * g over dense rows (eqf_rms_norm_fwd / _bwd, csrc/rmsnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, g, eps, acc_param):
+        _require_gpu(x, "rms_norm_rows")
+        x, gv = _f32c(x), _f32c(g.detach()).reshape(-1)
+        R, C = x.shape
+        out = torch.empty_like(x)
+        scale = float(torch.tensor(C ** -0.5, dtype=torch.float32))
+        hip.check(hip.lib().eqf_rms_norm_fwd(_ptr(x), _ptr(gv), R, C, scale, float(eps), _ptr(out), _stream(x.device)),
+                  "eqf_rms_norm_fwd")
+        ctx.save_for_backward(x, gv)
+        ctx.eps, ctx.scale, ctx.acc, ctx.gshape = float(eps), scale, acc_param, g.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gv = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        dx = torch.empty_like(x)
+        L = hip.lib()
+        ws_bytes = L.eqf_rms_norm_bwd_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x.device)
+        tg = _acc_target(ctx.acc)
+        dg = tg if tg is not None else torch.empty(ctx.gshape, dtype=torch.float32, device=x.device)
+        hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dg),
+                                     1 if tg is not None else 0, _ptr(ws), ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
+        return dx, (None if tg is not None else dg), None, None
+
+
+def rms_norm_rows(x, g, eps: float):
+    """The degree-0 Norm of the Equiformer (equiformer_layer.py:194-225) for 2-D fp32 rows; ``g`` is the
+    ``transforms.0`` parameter [C, 1]."""
+    if torch.is_grad_enabled() and g.requires_grad and g.is_leaf:
+        (LINEAR_PARAMS if g.dim() == 2 else ACC_PARAMS)[id(g)] = g
+    return _RmsNormRows.apply(x, g, eps, g)
+
+
 class _RadialTrunk(torch.autograd.Function):
     """Linear(1,64) -> SiLU -> LN -> Linear(64,64) -> SiLU -> LN per edge, one launch each way
     (eqf_radial_trunk_fwd / _bwd, csrc/radial.hip); the backward recomputes the forward from ``dist``."""

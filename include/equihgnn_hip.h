@@ -250,6 +250,18 @@ int geo_knn_grid(const float* pos, int64_t N, int32_t k, int32_t mode, const int
                  float* dist, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Degree-0 branch of the Equiformer's `Norm` (equiformer_layer.py:194-225): out = t / max(rms, eps) * g with
+ * rms = ||t||_2 * scale (scale = C^-1/2 as fp32), g = transforms.0 [C].  bwd: dx and dg (overwritten, or added to
+ * with accumulate != 0); the clamp passes the gradient where rms >= eps.  C <= 1024, multiple of 4.
+ * ------------------------------------------------------------------------------------------- */
+int eqf_rms_norm_fwd(const float* x, const float* g, int64_t n_rows, int32_t C, float scale, float eps, float* out,
+                     void* stream);
+size_t eqf_rms_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C);
+int eqf_rms_norm_bwd(const float* x, const float* g, const float* dy, int64_t n_rows, int32_t C, float scale,
+                     float eps, float* dx, float* dg, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Trunk of the Equiformer radial network, `Radial.rp[0..5]` of equiformer_layer.py:451-479, per edge:
  * Linear(1,64) -> SiLU -> LayerNorm -> Linear(64,64) -> SiLU -> LayerNorm (the local LayerNorm of
  * :158-165: learnable gamma, beta a zero buffer).  dist [E]; params[8] = {w0 [64] (= rp.0.weight[:,0]),

@@ -851,6 +851,42 @@ def test_knn_grid_is_identical_to_brute_force(case, mode):
         assert torch.equal(nb, ng2) and torch.equal(db, dg2)
 
 
+@pytest.mark.parametrize("R,C", [(1, 64), (777, 256), (300, 1024)])
+def test_rms_norm_rows_matches_float64_reference(R, C):
+    """t / max(||t|| C^-1/2, eps) * g (equiformer_layer.py:194-225, degree 0): forward, dt and dg against float64,
+    including an all-zero row (the clamp closes: the output is 0 and dt = dy * g / eps)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    t, gam, w = torch.randn(R, C, generator=g), 1 + 0.3 * torch.randn(C, 1, generator=g), torch.randn(R, C, generator=g)
+    if R > 2:
+        t[1] = 0.0
+    eps = 1e-12
+    td, gd = t.double().requires_grad_(True), gam.double().requires_grad_(True)
+    rms = td.norm(dim=-1, keepdim=True) * (C ** -0.5)
+    ref = td / rms.clamp(min=eps) * gd[:, 0]
+    (ref * w.double()).sum().backward()
+    tm, gm = t.to(DEV).requires_grad_(True), gam.to(DEV).requires_grad_(True)
+    out = ops.rms_norm_rows(tm, gm, eps)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=2e-6)
+    live = torch.ones(R, dtype=torch.bool)
+    if R > 2:
+        live[1] = False                                  # the zero row: gradient of size 1/eps, compared relatively
+        got, want = tm.grad[1].cpu().double(), td.grad[1]
+        assert float((got - want).abs().max() / want.abs().max()) < 1e-5
+    err = float((tm.grad.cpu().double()[live] - td.grad[live]).abs().max() / td.grad[live].abs().max())
+    assert err < 2e-5, err
+    errg = float((gm.grad.cpu().double() - gd.grad).abs().max() / gd.grad.abs().max())
+    assert errg < 2e-5, errg
+    gm.grad = None
+    gm._eqh_gbuf = torch.full_like(gm, 0.5)
+    out2 = ops.rms_norm_rows(t.to(DEV).requires_grad_(True), gm, eps)
+    (out2 * w.to(DEV)).sum().backward()
+    assert gm.grad is None
+    assert float(((gm._eqh_gbuf - 0.5).cpu().double() - gd.grad).abs().max() / gd.grad.abs().max()) < 2e-5
+    del gm._eqh_gbuf
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
