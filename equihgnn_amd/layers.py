@@ -98,12 +98,18 @@ class MLP(nn.Module):
             h = F.dropout(h, p=self.dropout, training=self.training)
         return h
 
+    def takes_first(self, x) -> bool:
+        """Whether forward(x, first=...) uses a precomputed first GEMM (hidden layers on the fused path)."""
+        return len(self.lins) > 1 and not self.InputNorm and self._fusable(x)
+
     def _fusable(self, x):
         return (x.is_cuda and x.dim() == 2 and not (self.training and self.dropout > 0)
                 and all(isinstance(n, nn.LayerNorm) for n in self.normalizations[1:])
                 and all(l.out_features % 4 == 0 and l.out_features <= 1024 for l in self.lins[:-1]))
 
-    def forward(self, x):
+    def forward(self, x, first=None):
+        """``first``: x @ lins[0].weight.T already computed by the caller (bias-free; only on the fused path,
+        see ``takes_first``)."""
         x = self.normalizations[0](x)
         if len(self.lins) == 1:
             return ops.linear(x, self.lins[0].weight, self.lins[0].bias)
@@ -112,7 +118,8 @@ class MLP(nn.Module):
             # the bias gradient, so no separate column-sum kernel runs)
             for i in range(len(self.lins) - 1):
                 lin, norm = self.lins[i], self.normalizations[i + 1]
-                x = ops.bias_relu_ln(ops.linear(x, lin.weight), lin.bias, norm.weight, norm.bias, norm.eps)
+                h = first if (i == 0 and first is not None) else ops.linear(x, lin.weight)
+                x = ops.bias_relu_ln(h, lin.bias, norm.weight, norm.bias, norm.eps)
             return ops.linear(x, self.lins[-1].weight, self.lins[-1].bias)
         h = self.hidden(ops.linear(x, self.lins[0].weight, self.lins[0].bias), 0)
         return ops.linear(h, self.lins[-1].weight, self.lins[-1].bias)
@@ -127,7 +134,7 @@ def _row_weight(out_csr, has_row, aggr, dtype):
 
 
 def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr,
-                  residual=None):
+                  residual=None, pa=None):
     """reduce_r( mlp(cat(a[idx_a], b[idx_b])) ) over the rows of ``out_csr`` — the
     per-incidence MLP + scatter of conv.py:90-93,96-97,175-177, restructured (module docstring).
 
@@ -138,7 +145,8 @@ def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_k
     lin0 = mlp.lins[0]
     ca = a.shape[-1]
     cin = lin0.weight.shape[1]
-    pa = ops.linear(a, lin0.weight, None, (0, ca))              # rows of a
+    if pa is None:                                              # (else: computed by the caller with another GEMM of a)
+        pa = ops.linear(a, lin0.weight, None, (0, ca))          # rows of a
     qb = ops.linear(b, lin0.weight, lin0.bias, (ca, cin))       # rows of b
     norm = mlp.normalizations[1] if len(mlp.lins) > 1 else None
     fused = (len(mlp.lins) == 2 and isinstance(norm, nn.LayerNorm) and pa.dim() == 2
@@ -267,11 +275,21 @@ class MHNNSConv(nn.Module):
 
     def forward(self, X, index: HyperIndex, X0, residual=None):
         ix = index
-        x_e = ops.reduce_gathered(self.W1(X), ix.by_e, ix.by_v, self.aggr)       # conv.py:172-173
-        if X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1:
+        fused = X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1
+        pa = None
+        if fused and self.W1.takes_first(X) and not self.W2.InputNorm:
+            # X feeds the first Linear of W1 and the node half of W2's first Linear: issued together, so that
+            # their two input gradients meet in one accumulating GEMM instead of an add kernel
+            c = X.shape[-1]
+            h1, pa = ops.linear2(X, self.W1.lins[0].weight, None, self.W2.lins[0].weight, (0, c))
+            w1x = self.W1(X, first=h1)
+        else:
+            w1x = self.W1(X)
+        x_e = ops.reduce_gathered(w1x, ix.by_e, ix.by_v, self.aggr)              # conv.py:172-173
+        if fused:
             res = residual if residual is not None else self.residual(X0, ix)
             mixed = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
-                                  ix.has_v, self.aggr, residual=res)             # conv.py:175-180
+                                  ix.has_v, self.aggr, residual=res, pa=pa)      # conv.py:175-180
             return self.W3(mixed)
         x_v = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                             ix.has_v, self.aggr)                                 # conv.py:175-177

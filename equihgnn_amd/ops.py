@@ -791,6 +791,37 @@ def wgrad(dy2, x2, alpha: float = 1.0, into=None):
     return None if into is not None else out
 
 
+def _linear_weight_grad(weight, c0, c1, dy2, x2):
+    """Weight gradient dy2.T @ x2 of a Linear over the column block [c0, c1) of ``weight``: added to the
+    parameter's persistent accumulator (in place, or recorded for the batched launch of defer_flush) when there
+    is one -- returns None then -- else returned for autograd (full parameter shape)."""
+    gbuf = getattr(weight, "_eqh_gbuf", None)
+    if gbuf is not None:
+        tgt = gbuf if c0 is None else gbuf[:, c0:c1]
+        side = wgrad_stream(dy2.device) if WGRAD_ON_SIDE_STREAM else None
+        if side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
+            pass
+        elif side is None and _wgrad_ok(dy2, x2):
+            wgrad(dy2, x2, into=tgt)
+        elif side is None:
+            tgt.addmm_(dy2.t(), x2)
+        else:
+            # weight gradients are off the critical path of the backward chain: issue them
+            # on a second HIP stream (a parallel branch of the captured graph); the trainer
+            # joins the stream before the optimiser
+            side.wait_stream(torch.cuda.current_stream(dy2.device))
+            with torch.cuda.stream(side):
+                tgt.addmm_(dy2.t(), x2)
+            dy2.record_stream(side)
+            x2.record_stream(side)
+        return None
+    if c0 is None:
+        return wgrad(dy2, x2) if _wgrad_ok(dy2, x2) else dy2.t() @ x2
+    dw = torch.zeros_like(weight)
+    dw[:, c0:c1] = dy2.t() @ x2
+    return dw
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W[:, c0:c1].T (+ bias): a library GEMM whose WEIGHT gradient, when the parameter
     carries a persistent accumulator (``param._eqh_gbuf``, same shape as the parameter), is
@@ -814,36 +845,47 @@ class _Linear(torch.autograd.Function):
         w = weight if c0 is None else weight[:, c0:c1]
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = (dy @ w) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            gbuf = getattr(weight, "_eqh_gbuf", None)
-            if gbuf is not None:
-                tgt = gbuf if c0 is None else gbuf[:, c0:c1]
-                side = wgrad_stream(dy.device) if WGRAD_ON_SIDE_STREAM else None
-                if side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
-                    pass
-                elif side is None and _wgrad_ok(dy2, x2):
-                    wgrad(dy2, x2, into=tgt)
-                elif side is None:
-                    tgt.addmm_(dy2.t(), x2)
-                else:
-                    # weight gradients are off the critical path of the backward chain: issue them
-                    # on a second HIP stream (a parallel branch of the captured graph); the trainer
-                    # joins the stream before the optimiser
-                    side.wait_stream(torch.cuda.current_stream(dy.device))
-                    with torch.cuda.stream(side):
-                        tgt.addmm_(dy2.t(), x2)
-                    dy2.record_stream(side)
-                    x2.record_stream(side)
-            elif c0 is None:
-                dw = wgrad(dy2, x2) if _wgrad_ok(dy2, x2) else dy2.t() @ x2
-            else:
-                dw = torch.zeros_like(weight)
-                dw[:, c0:c1] = dy2.t() @ x2
+        dw = _linear_weight_grad(weight, c0, c1, dy2, x2) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2, into=_acc_target(ctx.bias_param))   # None when accumulated in place
         return dx, dw, db, None, None
+
+
+class _Linear2(torch.autograd.Function):
+    """(x @ Wa[:, a0:a1].T, x @ Wb[:, b0:b1].T) for two bias-free Linears of the SAME input: the backward pass
+    receives both output gradients together, so the input gradient is one GEMM plus one accumulating GEMM
+    (addmm_, beta = 1) instead of two GEMMs and an add kernel.  Weight gradients as in _Linear."""
+
+    @staticmethod
+    def forward(ctx, x, wa, a0, a1, wb, b0, b1):
+        ctx.save_for_backward(x, wa, wb)
+        ctx.cols = (a0, a1, b0, b1)
+        ctx.set_materialize_grads(False)
+        return F.linear(x, wa if a0 is None else wa[:, a0:a1]), F.linear(x, wb if b0 is None else wb[:, b0:b1])
+
+    @staticmethod
+    def backward(ctx, dya, dyb):
+        x, wa, wb = ctx.saved_tensors
+        a0, a1, b0, b1 = ctx.cols
+        x2 = x.reshape(-1, x.shape[-1])
+        dx, dwa, dwb = None, None, None
+        for dy, w, c0, c1, slot in ((dya, wa, a0, a1, 1), (dyb, wb, b0, b1, 4)):
+            if dy is None:
+                continue
+            ws = w if c0 is None else w[:, c0:c1]
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if ctx.needs_input_grad[0]:
+                dx = dy2 @ ws if dx is None else dx.addmm_(dy2, ws)
+            if ctx.needs_input_grad[slot]:
+                g = _linear_weight_grad(w, c0, c1, dy2, x2)
+                if slot == 1:
+                    dwa = g
+                else:
+                    dwb = g
+        if dx is not None:
+            dx = dx.view_as(x)
+        return dx, dwa, None, None, dwb, None, None
 
 
 class _LinearAddC(torch.autograd.Function):
@@ -974,6 +1016,18 @@ def linear(x, weight, bias=None, cols=None):
     _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
     return _Linear.apply(x, weight, bias, c0, c1)
+
+
+def linear2(x, wa, cols_a, wb, cols_b):
+    """(F.linear(x, wa[:, cols_a]), F.linear(x, wb[:, cols_b])) for two bias-free Linears of one input (the
+    PARAMETERS are passed, not slices); see _Linear2."""
+    if torch.is_grad_enabled():
+        for w in (wa, wb):
+            if w.requires_grad and w.is_leaf:
+                LINEAR_PARAMS[id(w)] = w
+    a0, a1 = cols_a if cols_a is not None else (None, None)
+    b0, b1 = cols_b if cols_b is not None else (None, None)
+    return _Linear2.apply(x, wa, a0, a1, wb, b0, b1)
 
 
 def linear_add(x, weight, c, scale: float = 1.0):
