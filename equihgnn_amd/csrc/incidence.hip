@@ -361,8 +361,8 @@ k_inc_bwd_both(const float* __restrict__ pa, const float* __restrict__ qb, const
 template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
-            const float* __restrict__ dy, float* __restrict__ dh, float* __restrict__ slab, int n_rows,
-            int C, float eps) {
+            const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dh,
+            float* __restrict__ slab, int n_rows, int C, float eps) {
     __shared__ float4 s_red[THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
@@ -377,11 +377,12 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
     // wavefront walks ~5 rows; unpipelined, each waited a full memory latency for h and again for dy)
     const int stride = gridDim.x * WAVES;
     int r = blockIdx.x * WAVES + wave;
-    Row<NV> bias_row, nh, nd;
+    Row<NV> bias_row, nh, nd, na;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         bias_row.v[i] = (RELU && c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+        na.v[i] = f4_zero();
     }
     auto fetch = [&](int row) {
         const int rr = row < n_rows ? row : n_rows - 1;
@@ -390,11 +391,12 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
             const int c = (lane + 64 * i) * 4;
             nh.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)rr * C + c) : f4_zero();
             nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dy + (int64_t)rr * C + c) : f4_zero();
+            if (!RELU && add) na.v[i] = (c < C) ? *reinterpret_cast<const float4*>(add + (int64_t)rr * C + c) : f4_zero();
         }
     };
     if (r < n_rows) fetch(r);
     for (; r < n_rows; r += stride) {
-        const Row<NV> ch = nh, cd = nd;
+        const Row<NV> ch = nh, cd = nd, ca = na;
         fetch(r + stride);
         Row<NV> x, g;
         unsigned pos;
@@ -425,6 +427,7 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
             dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
             dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
             f4_add(a_db.v[i], dx);
+            if (!RELU) f4_add(dx, ca.v[i]);      // plain LayerNorm: a second gradient of the same input rides along
             if (c < C) *reinterpret_cast<float4*>(dh + (int64_t)r * C + c) = dx;
         }
     }
@@ -584,7 +587,8 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
     float* slab = static_cast<float*>(workspace);
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
-        hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy, dh, slab,
+        hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy,
+                           (const float*)nullptr, dh, slab,
                            (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
@@ -614,8 +618,8 @@ extern "C" size_t hg_layer_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C) {
     return hg_bias_relu_ln_bwd_workspace_bytes(n_rows, C) + (size_t)C * sizeof(float);  // + a discarded "d bias" row
 }
 
-extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t n_rows, int32_t C,
-                                 float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* add, int64_t n_rows,
+                                 int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
                                  void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = check(n_rows, C);
     if (rc) return rc;
@@ -627,7 +631,8 @@ extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float
         return eqh_zero_async(dbeta, C, stream);
     }
     if (!x || !gamma || !dy || !dx || !workspace) return EQH_ERR_ARG;
-    if (!eqh_aligned16(x) || !eqh_aligned16(dy) || !eqh_aligned16(dx) || !eqh_aligned16(workspace) || !eqh_aligned16(gamma))
+    if (!eqh_aligned16(x) || !eqh_aligned16(dy) || !eqh_aligned16(dx) || !eqh_aligned16(workspace) || !eqh_aligned16(gamma) ||
+        !eqh_aligned16(add))
         return EQH_ERR_ALIGN;
     if (workspace_bytes < hg_layer_norm_bwd_workspace_bytes(n_rows, C)) return EQH_ERR_ARG;
     const int blocks = rowln_blocks(n_rows);
@@ -636,7 +641,7 @@ extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_rowln_bwd<NV, false>), dim3(blocks), dim3(THREADS), 0, stream, x, (const float*)nullptr, gamma,
-                           dy, dx, slab, (int)n_rows, (int)C, eps);
+                           dy, add, dx, slab, (int)n_rows, (int)C, eps);
         EQH_CHECK_LAUNCH();
         // the slab's first segment (column sums of dx) has no consumer here; it goes to the discard row.  Never
         // deferred-with-accumulate for that segment's sake: accumulate applies to all three alike, harmlessly.

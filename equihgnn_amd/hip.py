@@ -40,7 +40,7 @@ SIGNATURES = {
                                                                                     c_void_p]),
     "hg_layer_norm_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "hg_layer_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hg_layer_norm_bwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_float] + [c_void_p] * 3
+    "hg_layer_norm_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 3
                           + [c_int32, c_void_p, c_size_t, c_void_p]),
     "eqf_radial_trunk_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "eqf_radial_trunk_bwd_workspace_bytes": (c_size_t, [c_int64]),

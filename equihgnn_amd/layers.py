@@ -338,17 +338,20 @@ class EGNN(nn.Module):
         # one launch re-lays the edge-MLP weights out as the kernels want them: w_cat = [W1_i ; W1_j],
         # b_cat = [b1 ; 0], wd = W1[:, 2C], W2 padded (ops.egnn_pack_weights, csrc/dense_aux.hip)
         w_cat, b_cat, w_d, w2 = ops.egnn_pack_weights(lin1.weight, lin1.bias, lin2.weight, hp)
-        # one node-level GEMM gives both halves: ab[:, :Hp] = W1_i f + b1 (receiver), ab[:, Hp:] = W1_j f
-        ab = ops.linear(feats, w_cat, b_cat)
+        # one node-level GEMM gives both halves: ab[:, :Hp] = W1_i f + b1 (receiver), ab[:, Hp:] = W1_j f.  The
+        # features feed three things (this GEMM, node_norm, the residual): one autograd node, so that their
+        # gradients are summed inside the LayerNorm backward kernel and an accumulating GEMM (ops._EgnnFeats)
+        nn_ = self.node_norm
+        if feats.dim() == 2 and c % 4 == 0 and c <= 1024:
+            ab, normed, res = ops.egnn_feats(feats, w_cat, b_cat, nn_)
+        else:
+            ab, normed, res = ops.linear(feats, w_cat, b_cat), nn_(feats), feats
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
-        nn_ = self.node_norm
-        normed = (ops.layer_norm_rows(feats, nn_.weight, nn_.bias, nn_.eps) if c % 4 == 0 and c <= 1024
-                  else nn_(feats))
         node_in = torch.cat((normed, m_i), -1)
         n0, n3 = self.node_mlp[0], self.node_mlp[3]
         hid = F.silu(ops.linear(node_in, n0.weight, n0.bias))
-        return ops.linear(hid, n3.weight, n3.bias) + feats     # egnn_layer.py:360-362
+        return ops.linear(hid, n3.weight, n3.bias) + res       # egnn_layer.py:360-362
 
 
 def pool_sum(x, index: HyperIndex):

@@ -417,13 +417,76 @@ class _LayerNormRows(torch.autograd.Function):
         ws = _workspace(ws_bytes, x.device)
         tg = [_acc_target(p) for p in ctx.acc]
         if all(t is not None for t in tg):
-            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
+            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), None, R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
                                           _ptr(tg[1]), 1, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
             return dx, None, None, None, None
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
+        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), None, R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
                                       _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
         return dx, small[0], small[1], None, None
+
+
+class _EgnnFeats(torch.autograd.Function):
+    """The three uses of the node features in an EGNN layer as ONE autograd node: ab = feats @ w_cat.T + b_cat
+    (both halves of the first edge Linear, egnn_layer.py:298-305 split by columns), LayerNorm(feats)
+    (node_norm, :192/:360) and feats itself for the residual (:362).  Their three input gradients arrive
+    together, so they meet inside the LayerNorm backward kernel (its ``add`` operand) and an accumulating
+    GEMM instead of two add kernels."""
+
+    @staticmethod
+    def forward(ctx, feats, w_cat, b_cat, gamma, beta, eps, acc_params):
+        _require_gpu(feats, "egnn_feats")
+        feats = _f32c(feats)
+        g, b = _f32c(gamma), _f32c(beta)
+        R, C = feats.shape
+        normed = torch.empty_like(feats)
+        hip.check(hip.lib().hg_layer_norm_fwd(_ptr(feats), _ptr(g), _ptr(b), R, C, float(eps), _ptr(normed),
+                                              _stream(feats.device)), "hg_layer_norm_fwd")
+        ab = torch.addmm(b_cat, feats, w_cat.t())
+        ctx.save_for_backward(feats, w_cat, g)
+        ctx.eps, ctx.acc = float(eps), acc_params
+        ctx.set_materialize_grads(False)
+        return ab, normed, feats.view_as(feats)
+
+    @staticmethod
+    def backward(ctx, d_ab, d_normed, d_res):
+        feats, w_cat, gamma = ctx.saved_tensors
+        R, C = feats.shape
+        dev = feats.device
+        L = hip.lib()
+        dgamma = dbeta = None
+        if d_normed is not None:
+            d_normed = _f32c(d_normed)
+            add = _f32c(d_res) if d_res is not None else None
+            dx = torch.empty_like(feats)
+            ws_bytes = L.hg_layer_norm_bwd_workspace_bytes(R, C)
+            ws = _workspace(ws_bytes, dev)
+            tg = [_acc_target(p) for p in ctx.acc]
+            in_place = all(t is not None for t in tg)
+            small = tg if in_place else list(torch.empty((2, C), dtype=torch.float32, device=dev))
+            hip.check(L.hg_layer_norm_bwd(_ptr(feats), _ptr(gamma), _ptr(d_normed), _ptr(add), R, C, ctx.eps, _ptr(dx),
+                                          _ptr(small[0]), _ptr(small[1]), 1 if in_place else 0, _ptr(ws), ws_bytes,
+                                          _stream(dev)), "hg_layer_norm_bwd")
+            if not in_place:
+                dgamma, dbeta = small
+        else:
+            dx = _f32c(d_res).clone() if d_res is not None else None
+        dw = db = None
+        if d_ab is not None:
+            d_ab = _f32c(d_ab)
+            dx = d_ab @ w_cat if dx is None else dx.addmm_(d_ab, w_cat)
+            if ctx.needs_input_grad[1]:
+                dw = d_ab.t() @ feats
+            if ctx.needs_input_grad[2]:
+                db = colsum(d_ab)
+        return dx, dw, db, dgamma, dbeta, None, None
+
+
+def egnn_feats(feats, w_cat, b_cat, norm):
+    """(feats @ w_cat.T + b_cat, LayerNorm(feats), feats) for 2-D fp32 ``feats`` [N, C] (C % 4 == 0, C <= 1024);
+    ``norm`` the nn.LayerNorm module.  See _EgnnFeats."""
+    _note_acc(norm.weight, norm.bias)
+    return _EgnnFeats.apply(feats, w_cat, b_cat, norm.weight, norm.bias, norm.eps, (norm.weight, norm.bias))
 
 
 WGRAD_ON_SIDE_STREAM = False

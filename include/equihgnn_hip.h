@@ -228,13 +228,15 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
 /* ---------------------------------------------------------------------------------------------
  * Plain LayerNorm over dense rows — nn.LayerNorm(dim) applied to node features at
  * egnn_layer.py:192 (node_norm) — one wave per row.  bwd: dx and, from the same pass, dgamma and
- * dbeta (C floats each; overwritten or, with accumulate != 0, added to).  C <= 1024, multiple of 4.
+ * dbeta (C floats each; overwritten or, with accumulate != 0, added to); add [n_rows, C] (may be NULL) is
+ * added to dx — a second gradient of the same input (the residual of egnn_layer.py:362) that would
+ * otherwise cost an add kernel.  C <= 1024, multiple of 4.
  * ------------------------------------------------------------------------------------------- */
 int hg_layer_norm_fwd(const float* x, const float* gamma, const float* beta, int64_t n_rows, int32_t C,
                       float eps, float* out, void* stream);
 size_t hg_layer_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C);
-int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t n_rows, int32_t C,
-                      float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* add, int64_t n_rows,
+                      int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
