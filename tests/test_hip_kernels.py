@@ -887,6 +887,56 @@ def test_rms_norm_rows_matches_float64_reference(R, C):
     del gm._eqh_gbuf
 
 
+def test_shared_input_nodes_match_float64_reference():
+    """ops.linear2 (two bias-free Linears of one input) and ops.egnn_feats (GEMM + LayerNorm + residual alias of
+    one input): outputs and every gradient against float64 autograd of the separate ops."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    N, C = 300, 128
+    x = torch.randn(N, C, generator=g)
+    wa, wb = torch.randn(64, C, generator=g) / 8, torch.randn(192, 2 * C, generator=g) / 8
+    u, v, r = torch.randn(N, 64, generator=g), torch.randn(N, 192, generator=g), torch.randn(N, C, generator=g)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max().clamp(min=1e-9))
+
+    t = [z.double().requires_grad_(True) for z in (x, wa, wb)]
+    ((t[0] @ t[1].t()) * u.double()).sum().backward(retain_graph=True)
+    ((t[0] @ t[2][:, C:].t()) * v.double()).sum().backward()
+    d = [z.to(DEV).requires_grad_(True) for z in (x, wa, wb)]
+    ya, yb = ops.linear2(d[0], d[1], None, d[2], (C, 2 * C))
+    ((ya * u.to(DEV)).sum() + (yb * v.to(DEV)).sum()).backward()
+    assert rel(ya.detach(), (t[0] @ t[1].t()).detach()) < 1e-5 and rel(yb.detach(), (t[0] @ t[2][:, C:].t()).detach()) < 1e-5
+    for a, b in zip(d, t):
+        assert rel(a.grad, b.grad) < 2e-5
+    assert float(d[2].grad[:, :C].abs().max()) == 0.0          # the unused column block gets an exact zero
+
+    norm = torch.nn.LayerNorm(C)
+    norm.weight.data.add_(0.2 * torch.randn(C, generator=g))
+    norm.bias.data.add_(0.2 * torch.randn(C, generator=g))
+    wc, bc = torch.randn(192, C, generator=g) / 8, torch.randn(192, generator=g)
+    nd = torch.nn.LayerNorm(C).double()
+    nd.load_state_dict({k: z.double() for k, z in norm.state_dict().items()})
+    t = [z.double().requires_grad_(True) for z in (x, wc, bc)]
+    ref = ((t[0] @ t[1].t() + t[2]) * v.double()).sum() + (nd(t[0]) * r.double()).sum() + (t[0] * (2 * r.double())).sum()
+    ref.backward()
+    norm = norm.to(DEV)
+    d = [z.to(DEV).requires_grad_(True) for z in (x, wc, bc)]
+    ab, normed, res = ops.egnn_feats(d[0], d[1], d[2], norm)
+    ((ab * v.to(DEV)).sum() + (normed * r.to(DEV)).sum() + (res * (2 * r.to(DEV))).sum()).backward()
+    assert rel(normed.detach(), nd(t[0]).detach()) < 1e-5 and torch.equal(res, d[0])
+    for a, b in zip(d, t):
+        assert rel(a.grad, b.grad) < 2e-5
+    assert rel(norm.weight.grad, nd.weight.grad) < 2e-5 and rel(norm.bias.grad, nd.bias.grad) < 2e-5
+    # only two of the three outputs used: the missing gradient is simply absent
+    d2 = x.to(DEV).requires_grad_(True)
+    _, normed2, res2 = ops.egnn_feats(d2, d[1], d[2], norm)
+    ((normed2 * r.to(DEV)).sum() + (res2 * (2 * r.to(DEV))).sum()).backward()
+    t0 = x.double().requires_grad_(True)
+    ((nd(t0) * r.double()).sum() + (t0 * (2 * r.double())).sum()).backward()
+    assert rel(d2.grad, t0.grad) < 2e-5
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
