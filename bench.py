@@ -73,6 +73,8 @@ def parse():
                    help="issue weight-gradient GEMMs on a second stream (parallel graph branch)")
     p.add_argument("--no-graph", action="store_true",
                    help="eager launches instead of hipGraph replay of the step")
+    p.add_argument("--only-roofline", action="store_true",
+                   help="only the scatter-kernel replay of `roofline` (the command the rocprofv3 --pmc passes profile)")
     p.add_argument("--only-saturation", action="store_true",
                    help="run just the cache-exceeding scatter probe (used for the rocprofv3 --pmc passes)")
     return p.parse_args()
@@ -146,6 +148,12 @@ def measure_scatter_roofline(model, batch, dev):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "launches_per_step": len(calls), "avg_launch_us": round(avg_ms * 1e3, 2),
             "alg_bytes_per_launch": int(tot_bytes / n)}
+
+
+# HBM bytes per launch of k_segment_reduce from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), collected
+# with rocprofv3 on `python3 bench.py --only-roofline` at the BASELINE workload: profiles/r01_pmc_scatter_workload.json.
+# A bench run cannot collect counters itself; the figure is attached only to the workload it was measured on.
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 11706695}
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
@@ -329,6 +337,9 @@ def main():
     model = MODELS[a.method](1, args_ns).to(dev)
     cfg_id = 2
     host_batches = [synth_batch(a.batch, cfg_id * 1000 + rank * 100 + i, a.flavour) for i in range(a.pool)]
+    if a.only_roofline:
+        print(json.dumps({"roofline": measure_scatter_roofline(model, host_batches[0].to(dev), dev)}), flush=True)
+        return
     # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
     # largest one (one dummy molecule owns the padding; exact for the LayerNorm models, and for the
     # BatchNorm ones because their statistics count the real atoms only).
@@ -396,6 +407,9 @@ def main():
         }
         if not a.no_roofline:
             result["roofline"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
+            result["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH.get((a.method, a.batch, a.flavour))
+            if result["roofline"]["traffic"] is not None:
+                result["roofline"]["traffic_source"] = "profiles/r01_pmc_scatter_workload.json (rocprofv3 --pmc, offline)"
             if world == 1:
                 result["roofline"]["saturation"] = saturation_probe(dev)
                 if a.method == "egnn_equihnns":
