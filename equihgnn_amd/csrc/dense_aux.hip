@@ -149,7 +149,8 @@ __global__ void k_pack_fwd(const float* __restrict__ w1, const float* __restrict
 
 __global__ void k_pack_bwd(const float* __restrict__ dw_cat, const float* __restrict__ db_cat,
                            const float* __restrict__ dwd, const float* __restrict__ dw2p, int H, int Hp,
-                           int C, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2) {
+                           int C, float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                           int accumulate) {
     const int in_ld = 2 * C + 1;
     const int64_t n_w1 = (int64_t)H * in_ld, n_b = H, n_w2 = (int64_t)16 * H;
     const int64_t total = n_w1 + n_b + n_w2;
@@ -161,13 +162,15 @@ __global__ void k_pack_bwd(const float* __restrict__ dw_cat, const float* __rest
             if (col < C) v = dw_cat[(int64_t)h * C + col];
             else if (col < 2 * C) v = dw_cat[(int64_t)(Hp + h) * C + (col - C)];
             else v = dwd[h];
-            dw1[i] = v;
+            dw1[i] = accumulate ? dw1[i] + v : v;
         } else if (i < n_w1 + n_b) {
-            db1[i - n_w1] = db_cat[i - n_w1];
+            const float v = db_cat[i - n_w1];
+            db1[i - n_w1] = accumulate ? db1[i - n_w1] + v : v;
         } else {
             const int64_t j = i - n_w1 - n_b;
             const int o = (int)(j / H), h = (int)(j - (int64_t)o * H);
-            dw2[j] = dw2p[(int64_t)o * Hp + h];
+            const float v = dw2p[(int64_t)o * Hp + h];
+            dw2[j] = accumulate ? dw2[j] + v : v;
         }
     }
 }
@@ -277,13 +280,13 @@ extern "C" int egnn_pack_weights_fwd(const float* w1, const float* b1, const flo
 
 extern "C" int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd,
                                      const float* dw2p, int32_t H, int32_t Hp, int32_t C, float* dw1,
-                                     float* db1, float* dw2, void* stream_) {
+                                     float* db1, float* dw2, int32_t accumulate, void* stream_) {
     if (H <= 0 || Hp < H || C <= 0 || !dw_cat || !db_cat || !dwd || !dw2p || !dw1 || !db1 || !dw2)
         return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int64_t total = (int64_t)H * (2 * C + 1) + H + (int64_t)16 * H;
     hipLaunchKernelGGL(k_pack_bwd, dim3(eqh_grid_for(total, 256, 2048)), dim3(256), 0, stream, dw_cat, db_cat, dwd,
-                       dw2p, (int)H, (int)Hp, (int)C, dw1, db1, dw2);
+                       dw2p, (int)H, (int)Hp, (int)C, dw1, db1, dw2, (int)accumulate);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

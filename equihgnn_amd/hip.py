@@ -85,7 +85,7 @@ SIGNATURES = {
     "hg_residual_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_int64, c_int32, c_void_p,
                                       c_void_p]),
     "egnn_pack_weights_fwd": (c_int32, [c_void_p] * 3 + [c_int32] * 3 + [c_void_p] * 5),
-    "egnn_pack_weights_bwd": (c_int32, [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 4),
+    "egnn_pack_weights_bwd": (c_int32, [c_void_p] * 4 + [c_int32] * 3 + [c_void_p] * 3 + [c_int32, c_void_p]),
     "geo_eigh3": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "hg_rowgemm_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
                                                 c_void_p]),

@@ -770,7 +770,7 @@ class _EgnnPackWeights(torch.autograd.Function):
     operand layout of the fused EGNN edge kernel, one launch each way."""
 
     @staticmethod
-    def forward(ctx, w1, b1, w2, Hp):
+    def forward(ctx, w1, b1, w2, Hp, acc_params):
         _require_gpu(w1, "egnn_pack_weights")
         w1, b1, w2 = _f32c(w1), _f32c(b1), _f32c(w2)
         H, in_ld = w1.shape
@@ -783,23 +783,35 @@ class _EgnnPackWeights(torch.autograd.Function):
         hip.check(hip.lib().egnn_pack_weights_fwd(_ptr(w1), _ptr(b1), _ptr(w2), H, Hp, C, _ptr(w_cat), _ptr(b_cat),
                                                   _ptr(wd), _ptr(w2p), _stream(dev)), "egnn_pack_weights_fwd")
         ctx.dims = (H, Hp, C)
+        ctx.acc = acc_params
         return w_cat, b_cat, wd, w2p
 
     @staticmethod
     def backward(ctx, dw_cat, db_cat, dwd, dw2p):
         H, Hp, C = ctx.dims
         dev = dw_cat.device
-        dw1 = torch.empty((H, 2 * C + 1), dtype=torch.float32, device=dev)
-        db1 = torch.empty(H, dtype=torch.float32, device=dev)
-        dw2 = torch.empty((16, H), dtype=torch.float32, device=dev)
+        tg = [_acc_target(p) for p in ctx.acc]
+        in_place = all(t is not None for t in tg)      # the parameters' accumulators: nothing left for autograd
+        if in_place:
+            dw1, db1, dw2 = tg
+        else:
+            dw1 = torch.empty((H, 2 * C + 1), dtype=torch.float32, device=dev)
+            db1 = torch.empty(H, dtype=torch.float32, device=dev)
+            dw2 = torch.empty((16, H), dtype=torch.float32, device=dev)
         hip.check(hip.lib().egnn_pack_weights_bwd(_ptr(_f32c(dw_cat)), _ptr(_f32c(db_cat)), _ptr(_f32c(dwd)),
                                                   _ptr(_f32c(dw2p)), H, Hp, C, _ptr(dw1), _ptr(db1), _ptr(dw2),
-                                                  _stream(dev)), "egnn_pack_weights_bwd")
-        return dw1, db1, dw2, None
+                                                  1 if in_place else 0, _stream(dev)), "egnn_pack_weights_bwd")
+        if in_place:
+            return None, None, None, None, None
+        return dw1, db1, dw2, None, None
 
 
 def egnn_pack_weights(w1, b1, w2, Hp):
-    return _EgnnPackWeights.apply(w1, b1, w2, Hp)
+    if torch.is_grad_enabled():
+        for w in (w1, b1, w2):
+            if w.requires_grad and w.is_leaf:
+                (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
+    return _EgnnPackWeights.apply(w1, b1, w2, Hp, (w1, b1, w2))
 
 
 # parameters seen by ops.linear since the last reset (the trainer decides which of them get a

@@ -319,7 +319,8 @@ int geo_eigh3(const float* a, int64_t B, float* w, float* v, void* stream);
  * egnn_pack_weights_fwd/bwd: layout change of the EGNN edge-MLP weights (egnn_layer.py:180-186) into
  *   what egnn_edge_fwd consumes: w1 [H, 2C+1], b1 [H], w2 [16, H]  ->  w_cat [2*Hp, C]
  *   (= [w1[:, :C] ; w1[:, C:2C]], zero rows from H to Hp), b_cat [2*Hp] (= [b1 ; 0]),
- *   wd [Hp] (= w1[:, 2C]), w2p [16, Hp]; bwd is the exact adjoint.
+ *   wd [Hp] (= w1[:, 2C]), w2p [16, Hp]; bwd is the exact adjoint (overwriting dw1 / db1 / dw2, or adding to
+ *   them with accumulate != 0).
  * ------------------------------------------------------------------------------------------- */
 /* Weight gradient of a Linear, dw[o*ldw + i] (+)= alpha * sum_k dy[k*O + o] * x[k*I + i]  (autograd's
  * grad_output.t() @ input, mlp.py:91-99 / conv.py:90-97,172-180): split-K fp32 MFMA, fixed summation
@@ -349,7 +350,7 @@ int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int
                           int32_t C, float* w_cat, float* b_cat, float* wd, float* w2p, void* stream);
 int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, const float* dwd, const float* dw2p,
                           int32_t H, int32_t Hp, int32_t C, float* dw1, float* db1, float* dw2,
-                          void* stream);
+                          int32_t accumulate, void* stream);
 
 #ifdef __cplusplus
 }
