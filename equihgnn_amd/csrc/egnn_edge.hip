@@ -290,7 +290,7 @@ __host__ __device__ inline int bw_chunks(int64_t n_items, int tiles) {
 __global__ void __launch_bounds__(THREADS)
 k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, float* __restrict__ dpre2,
                 float* __restrict__ dpre2_t, const int* __restrict__ t_perm, const int* __restrict__ nbr,
-                const float* __restrict__ d2, int4* __restrict__ rec, int N) {
+                const float* __restrict__ d2, int4* __restrict__ rec, float* __restrict__ slab_b2, int N) {
     // records for the sender pass: one 16-byte record per position p of the transposed CSR, (entry
     // e = i*16 + slot, sender j = nbr[e], d2[e], -), so that its pipeline has no dependent load chain
     // (t_perm -> nbr / d2) in front of the row gathers
@@ -300,6 +300,7 @@ k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, fl
         rec[p] = make_int4(e, nbr[e], __float_as_int(d2[e]), 0);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 acc_b2 = f4_zero();   // sum over this wavefront's nodes of dpre2[node][j = lane >> 2][o0 .. o0 + 3]
     for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
         const int jj = lane >> 2, o0 = (lane & 3) * 4;  // one float4 (4 consecutive o of one j) per lane
         const float4 p4 = *reinterpret_cast<const float4*>(pre2 + (int64_t)node * 256 + lane * 4);
@@ -316,6 +317,22 @@ k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, fl
         t[(o0 + 1) * KNB] = d4.y;
         t[(o0 + 2) * KNB] = d4.z;
         t[(o0 + 3) * KNB] = d4.w;
+        f4_add(acc_b2, d4);
+    }
+    if (slab_b2) {   // d b2[o] = sum over nodes and slots j of dpre2: lanes sharing (lane & 3), then the wavefronts
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) {
+            acc_b2.x += __shfl_xor(acc_b2.x, off); acc_b2.y += __shfl_xor(acc_b2.y, off);
+            acc_b2.z += __shfl_xor(acc_b2.z, off); acc_b2.w += __shfl_xor(acc_b2.w, off);
+        }
+        __shared__ float4 s_b2[WAVES][4];
+        if (lane < 4) s_b2[wave][lane] = acc_b2;
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float4 v = s_b2[0][threadIdx.x];
+            for (int w = 1; w < WAVES; ++w) f4_add(v, s_b2[w][threadIdx.x]);
+            *reinterpret_cast<float4*>(slab_b2 + (int64_t)blockIdx.x * MDIM + 4 * threadIdx.x) = v;
+        }
     }
 }
 
@@ -643,20 +660,23 @@ extern "C" int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, 
     return EQH_OK;
 }
 
+static inline int prep_blocks(int64_t N) { return eqh_grid_for(N, WAVES, 2048); }
+
 extern "C" size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp) {
     if (N < 0 || Hp <= 0) return 0;
     const int chunks = bw_chunks(N, Hp >> 6);
     // [chunks][16 + 1][Hp] partial slabs of dW2 / dwd, the transposed copy of dpre2 [N][16][16] and the
     // 16-byte records of the transposed CSR [16 N]
+    // ... and the per-workgroup partial sums of d b2 [prep blocks][16]
     return ((size_t)chunks * (size_t)(MDIM + 1) * (size_t)Hp + (size_t)(N > 0 ? N : 1) * 256 +
-            (size_t)(N > 0 ? N : 1) * KNB * 4) * sizeof(float);
+            (size_t)(N > 0 ? N : 1) * KNB * 4 + (size_t)prep_blocks(N) * MDIM) * sizeof(float);
 }
 
 extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
                              const float* d2, const float* pre2, const float* dm,
                              const int32_t* t_rowptr, const int32_t* t_perm, int64_t N, int32_t Hp,
-                             float* dab, float* dwd, float* dw2, float* dpre2, void* workspace,
-                             size_t workspace_bytes, void* stream_) {
+                             float* dab, float* dwd, float* dw2, float* dpre2, float* db2,
+                             int32_t db2_accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = check_common(N, Hp);
     if (rc) return rc;
     if (!dwd || !dw2) return EQH_ERR_ARG;
@@ -664,6 +684,7 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     if (N == 0) {
         if (eqh_zero_async(dwd, Hp, stream) || eqh_zero_async(dw2, (int64_t)MDIM * Hp, stream))
             return EQH_ERR_LAUNCH;
+        if (db2 && !db2_accumulate && eqh_zero_async(db2, MDIM, stream)) return EQH_ERR_LAUNCH;
         return EQH_OK;
     }
     if (!ab || !wd || !w2 || !nbr || !d2 || !pre2 || !dm || !t_rowptr || !t_perm || !dab || !dpre2 ||
@@ -682,9 +703,15 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     float* slab_wd = slab_w2 + (size_t)MDIM * Hp;
     float* dpre2_t = slab_w2 + (size_t)chunks * (MDIM + 1) * Hp;
     int4* rec = reinterpret_cast<int4*>(dpre2_t + (size_t)N * 256);
-    hipLaunchKernelGGL(k_edge_bwd_prep, dim3(eqh_grid_for(N, WAVES, 2048)), dim3(THREADS), 0, stream, pre2, dm,
-                       dpre2, dpre2_t, t_perm, nbr, d2, rec, (int)N);
+    float* slab_b2 = db2 ? reinterpret_cast<float*>(rec + (size_t)N * KNB) : nullptr;
+    const int pblocks = prep_blocks(N);
+    hipLaunchKernelGGL(k_edge_bwd_prep, dim3(pblocks), dim3(THREADS), 0, stream, pre2, dm,
+                       dpre2, dpre2_t, t_perm, nbr, d2, rec, slab_b2, (int)N);
     EQH_CHECK_LAUNCH();
+    if (db2) {   // (deferred into the step's batched reduction when it accumulates and a window is open)
+        rc = eqh_reduce_slabs_async(slab_b2, pblocks, MDIM, db2, stream, db2_accumulate);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_edge_bwd_recv, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, dpre2,
                        dpre2_t, dab, slab_w2, slab_wd, (int)N, (int)Hp, tiles, chunk_items);
     EQH_CHECK_LAUNCH();

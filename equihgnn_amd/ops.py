@@ -273,7 +273,7 @@ class _EgnnEdge(torch.autograd.Function):
     pre-activations; the per-edge hidden activations are recomputed in the backward."""
 
     @staticmethod
-    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR):
+    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR, b2_param=None):
         _require_gpu(ab, "egnn_edge")
         ab, wd, w2, b2 = _f32c(ab), _f32c(wd), _f32c(w2), _f32c(b2)
         N, Hp = ab.shape[0], ab.shape[1] // 2
@@ -284,7 +284,7 @@ class _EgnnEdge(torch.autograd.Function):
         hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
                                           _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd")
         ctx.save_for_backward(ab, wd, w2, pre2)
-        ctx.nbr, ctx.d2, ctx.csr_t = nbr, d2, csr_t
+        ctx.nbr, ctx.d2, ctx.csr_t, ctx.b2_param = nbr, d2, csr_t, b2_param
         return m
 
     @staticmethod
@@ -299,13 +299,14 @@ class _EgnnEdge(torch.autograd.Function):
         dpre2 = torch.empty_like(pre2)
         L = hip.lib()
         ws_bytes = L.egnn_edge_bwd_workspace_bytes(N, Hp)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = _workspace(ws_bytes, dev)   # holds the d b2 slabs: parked while reductions are deferred
+        tg = _acc_target(ctx.b2_param)   # d b2 = sum of dpre2 over nodes and slots, from the same pass
+        db2 = tg if tg is not None else torch.empty(16, dtype=torch.float32, device=dev)
         hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
                                   _ptr(dm), _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
-                                  _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(ws), ws_bytes, _stream(dev)),
-                  "egnn_edge_bwd")
-        db2 = colsum(dpre2.view(N, 256)).view(16, 16).sum(0)   # over nodes (kernel), then over the 16 slots
-        return dab, dwd, dw2, db2, None, None, None
+                                  _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0, _ptr(ws),
+                                  ws_bytes, _stream(dev)), "egnn_edge_bwd")
+        return dab, dwd, dw2, (None if tg is not None else db2), None, None, None, None
 
 
 class _IncidenceLnReduce(torch.autograd.Function):
@@ -1275,7 +1276,8 @@ def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
 
 
 def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
-    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t)
+    _note_acc(b2)
+    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2)
 
 
 

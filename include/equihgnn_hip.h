@@ -154,8 +154,9 @@ int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, 
  *   nbr  [N,16] int32, d2 [N,16]   geo_knn(mode 0) outputs
  * fwd:  m[i,:] = sum_j silu(W2 silu(ab[i,:Hp] + ab[nbr_ij,Hp:] + wd*d2_ij) + b2);  pre2 [N,16,16]
  *       (pre-activation of the second SiLU) is saved for the backward.
- * bwd:  given dm [N,16]: dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16] (db2 is its sum over
- *       the first two axes).  t_rowptr / t_perm: CSR of the transposed neighbour graph
+ * bwd:  given dm [N,16]: dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16], and db2 [16] = the sum
+ *       of dpre2 over its first two axes (NULL: not wanted; overwritten, or added to with
+ *       db2_accumulate != 0).  t_rowptr / t_perm: CSR of the transposed neighbour graph
  *       (hg_csr_build with key = nbr flattened, n_rows = N; entries are i*16+slot).
  * ------------------------------------------------------------------------------------------- */
 int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, const float* b2,
@@ -165,7 +166,8 @@ size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp);
 int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
                   const float* d2, const float* pre2, const float* dm, const int32_t* t_rowptr,
                   const int32_t* t_perm, int64_t N, int32_t Hp, float* dab, float* dwd, float* dw2,
-                  float* dpre2, void* workspace, size_t workspace_bytes, void* stream);
+                  float* dpre2, float* db2, int32_t db2_accumulate, void* workspace, size_t workspace_bytes,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CSR-grouped small GEMMs — the Equiformer's radial tensor product (equiformer_layer.py:376-383:
