@@ -186,7 +186,7 @@ def measure_edge_kernels(batch, dev, hidden=256, reps=20):
     wsb = L.egnn_edge_bwd_workspace_bytes(N, Hp)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     fwd = lambda: L.egnn_edge_fwd(p(ab), p(wd), p(w2), p(b2), p(nbr), p(d2), N, Hp, p(m), p(pre2), st)
-    bwd = lambda: L.egnn_edge_bwd(p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), p(csr_t.rowptr), p(csr_t.perm),
+    bwd = lambda: L.egnn_edge_bwd(p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), 16, p(csr_t.rowptr), p(csr_t.perm),
                                   N, Hp, p(dab), p(dwd), p(dw2), p(dpre2), None, 0, p(ws), wsb, st)
     busy = torch.randn(4096, 4096, device=dev)
     stream = torch.cuda.current_stream(dev)

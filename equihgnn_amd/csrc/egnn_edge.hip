@@ -290,7 +290,7 @@ __host__ __device__ inline int bw_chunks(int64_t n_items, int tiles) {
 __global__ void __launch_bounds__(THREADS)
 k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, float* __restrict__ dpre2,
                 float* __restrict__ dpre2_t, const int* __restrict__ t_perm, const int* __restrict__ nbr,
-                const float* __restrict__ d2, int4* __restrict__ rec, float* __restrict__ slab_b2, int N) {
+                const float* __restrict__ d2, int4* __restrict__ rec, float* __restrict__ slab_b2, int N, int64_t dm_ld) {
     // records for the sender pass: one 16-byte record per position p of the transposed CSR, (entry
     // e = i*16 + slot, sender j = nbr[e], d2[e], -), so that its pipeline has no dependent load chain
     // (t_perm -> nbr / d2) in front of the row gathers
@@ -304,7 +304,7 @@ k_edge_bwd_prep(const float* __restrict__ pre2, const float* __restrict__ dm, fl
     for (int node = blockIdx.x * WAVES + wave; node < N; node += gridDim.x * WAVES) {
         const int jj = lane >> 2, o0 = (lane & 3) * 4;  // one float4 (4 consecutive o of one j) per lane
         const float4 p4 = *reinterpret_cast<const float4*>(pre2 + (int64_t)node * 256 + lane * 4);
-        const float4 g4 = *reinterpret_cast<const float4*>(dm + (int64_t)node * MDIM + o0);
+        const float4 g4 = *reinterpret_cast<const float4*>(dm + (int64_t)node * dm_ld + o0);
         float ds;
         float4 d4;
         silu_grad(p4.x, &ds); d4.x = g4.x * ds;
@@ -673,7 +673,7 @@ extern "C" size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp) {
 }
 
 extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
-                             const float* d2, const float* pre2, const float* dm,
+                             const float* d2, const float* pre2, const float* dm, int64_t dm_ld,
                              const int32_t* t_rowptr, const int32_t* t_perm, int64_t N, int32_t Hp,
                              float* dab, float* dwd, float* dw2, float* dpre2, float* db2,
                              int32_t db2_accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
@@ -695,6 +695,7 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
         !eqh_aligned16(dab) || !eqh_aligned16(workspace))
         return EQH_ERR_ALIGN;
     if (workspace_bytes < egnn_edge_bwd_workspace_bytes(N, Hp)) return EQH_ERR_ARG;
+    if (dm_ld < MDIM || (dm_ld & 3)) return EQH_ERR_ARG;
     const int tiles = Hp >> 6;
     const int chunks = bw_chunks(N, tiles);
     const int chunk_items = (int)((N + chunks - 1) / chunks);
@@ -706,7 +707,7 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     float* slab_b2 = db2 ? reinterpret_cast<float*>(rec + (size_t)N * KNB) : nullptr;
     const int pblocks = prep_blocks(N);
     hipLaunchKernelGGL(k_edge_bwd_prep, dim3(pblocks), dim3(THREADS), 0, stream, pre2, dm,
-                       dpre2, dpre2_t, t_perm, nbr, d2, rec, slab_b2, (int)N);
+                       dpre2, dpre2_t, t_perm, nbr, d2, rec, slab_b2, (int)N, dm_ld);
     EQH_CHECK_LAUNCH();
     if (db2) {   // (deferred into the step's batched reduction when it accumulates and a window is open)
         rc = eqh_reduce_slabs_async(slab_b2, pblocks, MDIM, db2, stream, db2_accumulate);

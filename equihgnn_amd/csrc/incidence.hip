@@ -362,7 +362,7 @@ template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
             const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dh,
-            float* __restrict__ slab, int n_rows, int C, float eps) {
+            float* __restrict__ slab, int n_rows, int C, float eps, int64_t dy_ld) {
     __shared__ float4 s_red[THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
@@ -390,7 +390,7 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             nh.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)rr * C + c) : f4_zero();
-            nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dy + (int64_t)rr * C + c) : f4_zero();
+            nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dy + (int64_t)rr * dy_ld + c) : f4_zero();
             if (!RELU && add) na.v[i] = (c < C) ? *reinterpret_cast<const float4*>(add + (int64_t)rr * C + c) : f4_zero();
         }
     };
@@ -589,7 +589,7 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy,
                            (const float*)nullptr, dh, slab,
-                           (int)n_rows, (int)C, eps);
+                           (int)n_rows, (int)C, eps, (int64_t)C);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
     });
@@ -618,8 +618,8 @@ extern "C" size_t hg_layer_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C) {
     return hg_bias_relu_ln_bwd_workspace_bytes(n_rows, C) + (size_t)C * sizeof(float);  // + a discarded "d bias" row
 }
 
-extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* add, int64_t n_rows,
-                                 int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t dy_ld, const float* add,
+                                 int64_t n_rows, int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
                                  void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = check(n_rows, C);
     if (rc) return rc;
@@ -635,13 +635,14 @@ extern "C" int hg_layer_norm_bwd(const float* x, const float* gamma, const float
         !eqh_aligned16(add))
         return EQH_ERR_ALIGN;
     if (workspace_bytes < hg_layer_norm_bwd_workspace_bytes(n_rows, C)) return EQH_ERR_ARG;
+    if (dy_ld < C || (dy_ld & 3)) return EQH_ERR_ARG;
     const int blocks = rowln_blocks(n_rows);
     float* slab = static_cast<float*>(workspace);
     float* discard = slab + (size_t)blocks * 3 * C;
     return dispatch_nv(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_rowln_bwd<NV, false>), dim3(blocks), dim3(THREADS), 0, stream, x, (const float*)nullptr, gamma,
-                           dy, add, dx, slab, (int)n_rows, (int)C, eps);
+                           dy, add, dx, slab, (int)n_rows, (int)C, eps, dy_ld);
         EQH_CHECK_LAUNCH();
         // the slab's first segment (column sums of dx) has no consumer here; it goes to the discard row.  Never
         // deferred-with-accumulate for that segment's sake: accumulate applies to all three alike, harmlessly.

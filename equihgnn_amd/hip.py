@@ -31,7 +31,8 @@ SIGNATURES = {
     "geo_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "egnn_edge_fwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "egnn_edge_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "egnn_edge_bwd": (c_int32, [c_void_p] * 9 + [c_int64, c_int32] + [c_void_p] * 5 + [c_int32, c_void_p, c_size_t, c_void_p]),
+    "egnn_edge_bwd": (c_int32, [c_void_p] * 7 + [c_int64] + [c_void_p] * 2 + [c_int64, c_int32] + [c_void_p] * 5
+                      + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_rowgemm_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "hg_incidence_ln_reduce_fwd": (c_int32, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "hg_incidence_ln_reduce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
@@ -40,7 +41,7 @@ SIGNATURES = {
                                                                                     c_void_p]),
     "hg_layer_norm_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "hg_layer_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hg_layer_norm_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 3
+    "hg_layer_norm_bwd": (c_int32, [c_void_p] * 3 + [c_int64, c_void_p] + [c_int64, c_int32, c_float] + [c_void_p] * 3
                           + [c_int32, c_void_p, c_size_t, c_void_p]),
     "eqf_radial_trunk_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p]),
     "eqf_radial_trunk_bwd_workspace_bytes": (c_size_t, [c_int64]),

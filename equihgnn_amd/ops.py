@@ -267,6 +267,16 @@ class _EmbedSum(torch.autograd.Function):
         return (None, None) + tuple(parts)
 
 
+def _rows_ld(t):
+    """(tensor, row stride in floats) for a 2-D fp32 gradient that may be a column block of a wider matrix
+    (unit inner stride, 16-byte aligned rows): used as is; anything else is made contiguous first."""
+    if (t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]
+            and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+        return t, t.stride(0)
+    t = _f32c(t)
+    return t, t.shape[-1]
+
+
 class _EgnnEdge(torch.autograd.Function):
     """m_i = sum_j silu(W2 silu(A_i + B_j + wd d2_ij) + b2) — the fused EGNN edge update
     (egnn_layer.py:298-310,357-358).  Saves only ``ab`` and the 16x16 second-layer
@@ -290,7 +300,7 @@ class _EgnnEdge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dm):
         ab, wd, w2, pre2 = ctx.saved_tensors
-        dm = _f32c(dm)
+        dm, dm_ld = _rows_ld(dm)          # usually the last 16 columns of d node_in: read in place
         N, Hp = ab.shape[0], ab.shape[1] // 2
         dev = ab.device
         dab = torch.empty_like(ab)
@@ -303,7 +313,7 @@ class _EgnnEdge(torch.autograd.Function):
         tg = _acc_target(ctx.b2_param)   # d b2 = sum of dpre2 over nodes and slots, from the same pass
         db2 = tg if tg is not None else torch.empty(16, dtype=torch.float32, device=dev)
         hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
-                                  _ptr(dm), _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
+                                  _ptr(dm), dm_ld, _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
                                   _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0, _ptr(ws),
                                   ws_bytes, _stream(dev)), "egnn_edge_bwd")
         return dab, dwd, dw2, (None if tg is not None else db2), None, None, None, None
@@ -418,11 +428,11 @@ class _LayerNormRows(torch.autograd.Function):
         ws = _workspace(ws_bytes, x.device)
         tg = [_acc_target(p) for p in ctx.acc]
         if all(t is not None for t in tg):
-            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), None, R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
+            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, None, R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
                                           _ptr(tg[1]), 1, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
             return dx, None, None, None, None
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), None, R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
+        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, None, R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
                                       _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
         return dx, small[0], small[1], None, None
 
@@ -457,7 +467,7 @@ class _EgnnFeats(torch.autograd.Function):
         L = hip.lib()
         dgamma = dbeta = None
         if d_normed is not None:
-            d_normed = _f32c(d_normed)
+            d_normed, dy_ld = _rows_ld(d_normed)     # usually the first C columns of d node_in: read in place
             add = _f32c(d_res) if d_res is not None else None
             dx = torch.empty_like(feats)
             ws_bytes = L.hg_layer_norm_bwd_workspace_bytes(R, C)
@@ -465,7 +475,7 @@ class _EgnnFeats(torch.autograd.Function):
             tg = [_acc_target(p) for p in ctx.acc]
             in_place = all(t is not None for t in tg)
             small = tg if in_place else list(torch.empty((2, C), dtype=torch.float32, device=dev))
-            hip.check(L.hg_layer_norm_bwd(_ptr(feats), _ptr(gamma), _ptr(d_normed), _ptr(add), R, C, ctx.eps, _ptr(dx),
+            hip.check(L.hg_layer_norm_bwd(_ptr(feats), _ptr(gamma), _ptr(d_normed), dy_ld, _ptr(add), R, C, ctx.eps, _ptr(dx),
                                           _ptr(small[0]), _ptr(small[1]), 1 if in_place else 0, _ptr(ws), ws_bytes,
                                           _stream(dev)), "hg_layer_norm_bwd")
             if not in_place:

@@ -154,7 +154,7 @@ int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, 
  *   nbr  [N,16] int32, d2 [N,16]   geo_knn(mode 0) outputs
  * fwd:  m[i,:] = sum_j silu(W2 silu(ab[i,:Hp] + ab[nbr_ij,Hp:] + wd*d2_ij) + b2);  pre2 [N,16,16]
  *       (pre-activation of the second SiLU) is saved for the backward.
- * bwd:  given dm [N,16]: dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16], and db2 [16] = the sum
+ * bwd:  given dm [N,16] (row stride dm_ld floats, >= 16 and a multiple of 4): dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16], and db2 [16] = the sum
  *       of dpre2 over its first two axes (NULL: not wanted; overwritten, or added to with
  *       db2_accumulate != 0).  t_rowptr / t_perm: CSR of the transposed neighbour graph
  *       (hg_csr_build with key = nbr flattened, n_rows = N; entries are i*16+slot).
@@ -164,7 +164,7 @@ int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, const float
                   void* stream);
 size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp);
 int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
-                  const float* d2, const float* pre2, const float* dm, const int32_t* t_rowptr,
+                  const float* d2, const float* pre2, const float* dm, int64_t dm_ld, const int32_t* t_rowptr,
                   const int32_t* t_perm, int64_t N, int32_t Hp, float* dab, float* dwd, float* dw2,
                   float* dpre2, float* db2, int32_t db2_accumulate, void* workspace, size_t workspace_bytes,
                   void* stream);
@@ -232,13 +232,14 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
  * egnn_layer.py:192 (node_norm) — one wave per row.  bwd: dx and, from the same pass, dgamma and
  * dbeta (C floats each; overwritten or, with accumulate != 0, added to); add [n_rows, C] (may be NULL) is
  * added to dx — a second gradient of the same input (the residual of egnn_layer.py:362) that would
- * otherwise cost an add kernel.  C <= 1024, multiple of 4.
+ * otherwise cost an add kernel.  dy_ld: row stride of dy in floats (>= C, multiple of 4: dy may be a column
+ * block of a wider matrix).  C <= 1024, multiple of 4.
  * ------------------------------------------------------------------------------------------- */
 int hg_layer_norm_fwd(const float* x, const float* gamma, const float* beta, int64_t n_rows, int32_t C,
                       float eps, float* out, void* stream);
 size_t hg_layer_norm_bwd_workspace_bytes(int64_t n_rows, int32_t C);
-int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, const float* add, int64_t n_rows,
-                      int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
+int hg_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t dy_ld, const float* add,
+                      int64_t n_rows, int32_t C, float eps, float* dx, float* dgamma, float* dbeta, int32_t accumulate,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

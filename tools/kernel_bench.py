@@ -135,7 +135,7 @@ def main():
     wsb4 = L.egnn_edge_bwd_workspace_bytes(N, Hp)
     ws4 = torch.empty(wsb4, dtype=torch.uint8, device=dev)
     add("egnn_edge_bwd (recv + send + slabs)", timed(lambda: L.egnn_edge_bwd(
-        p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), p(csr_t.rowptr), p(csr_t.perm), N, Hp, p(dab), p(dwd), p(dw2),
+        p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), 16, p(csr_t.rowptr), p(csr_t.perm), N, Hp, p(dab), p(dwd), p(dw2),
         p(dpre2), None, 0, p(ws4), wsb4, st)), flops=N * 16 * Hp * (3 * 2 * 16 + 40) * 1.0)
     # weight gradient of a C x C Linear: split-K kernel against the library GEMM
     dY = torch.randn(N, C, device=dev, generator=g)
