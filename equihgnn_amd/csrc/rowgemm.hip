@@ -140,6 +140,141 @@ k_rowgemm_bwd_w(const float* __restrict__ z, const float* __restrict__ dout,
     }
 }
 
+// ---- workgroup-per-row variants: the row's [Kd, L] matrix is staged into LDS ONCE with coalesced float4 loads
+// (padded stride L + 4: the four k-groups of an MFMA operand land in different banks) and shared by the four
+// wavefronts, which split the output tiles.  The first versions above read it straight from global memory, one
+// 64-byte segment per operand fetch and again for every column tile: 72 us per call at the BASELINE batch
+// (2.4 k nodes x 64 KB) against the ~35 us of reading the matrices once.
+__device__ __forceinline__ void stage_matrix(const float* __restrict__ wr, float* __restrict__ s_w, int Kd, int L) {
+    const int ld = L + 4;
+    const int n4 = (Kd * L) >> 2;
+    // eight float4 requests per thread in flight before the first LDS store (the loop is the kernel's only
+    // long-latency part: one request at a time left the workgroup waiting a memory round trip per 4 KB)
+    for (int f0 = threadIdx.x; f0 < n4; f0 += 8 * THREADS) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = f0 + u * THREADS;
+            v[u] = f < n4 ? *reinterpret_cast<const float4*>(wr + ((int64_t)f << 2)) : f4_zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int f = f0 + u * THREADS;
+            if (f < n4) {
+                const int i = f << 2;
+                const int row = i / L, col = i - row * L;
+                *reinterpret_cast<float4*>(s_w + row * ld + col) = v[u];
+            }
+        }
+    }
+}
+
+template <int KSTEPS>   // Kd / 16
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_fwd_lds(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
+                  const int* __restrict__ perm, int R, int L, float* __restrict__ out, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    constexpr int Kd = KSTEPS * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int ctiles = L >> 4, ld = L + 4;
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        if (beg == end) continue;                     // block-uniform
+        __syncthreads();                              // the previous row's readers are done
+        stage_matrix(w + (int64_t)row * Kd * L, s_w, Kd, L);
+        __syncthreads();
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            const int e_r = entry_at(perm, g0 + r_, end);
+            int e_g[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+            float4 z4[KSTEPS];
+#pragma unroll
+            for (int t = 0; t < KSTEPS; ++t)
+                z4[t] = e_r >= 0 ? *reinterpret_cast<const float4*>(z + (int64_t)e_r * Kd + 16 * t + 4 * q) : f4_zero();
+            for (int ct = wave; ct < ctiles; ct += WAVES) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* __restrict__ sb = s_w + (4 * q) * ld + ct * 16 + r_;
+#pragma unroll
+                for (int t = 0; t < KSTEPS; ++t) {
+                    acc = mfma16(z4[t].x, sb[(16 * t + 0) * ld], acc);
+                    acc = mfma16(z4[t].y, sb[(16 * t + 1) * ld], acc);
+                    acc = mfma16(z4[t].z, sb[(16 * t + 2) * ld], acc);
+                    acc = mfma16(z4[t].w, sb[(16 * t + 3) * ld], acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (e_g[g] >= 0) {
+                        float* o = out + (int64_t)e_g[g] * L + ct * 16 + r_;
+                        *o = accumulate ? (*o + acc[g]) : acc[g];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KSTEPS>
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_bwd_z_lds(const float* __restrict__ dout, const float* __restrict__ w, const int* __restrict__ rowptr,
+                    const int* __restrict__ perm, int R, int L, float* __restrict__ dz, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];
+    constexpr int Kd = KSTEPS * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int lsteps = L >> 4, ld = L + 4;
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        if (beg == end) continue;
+        __syncthreads();
+        stage_matrix(w + (int64_t)row * Kd * L, s_w, Kd, L);
+        __syncthreads();
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            const int e_r = entry_at(perm, g0 + r_, end);
+            int e_g[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+            for (int kt = wave; kt < KSTEPS; kt += WAVES) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* __restrict__ sk = s_w + (kt * 16 + r_) * ld + 4 * q;
+                const float* __restrict__ dr = dout + (int64_t)(e_r >= 0 ? e_r : 0) * L + 4 * q;
+#pragma unroll 4
+                for (int t = 0; t < lsteps; ++t) {
+                    float4 d4 = *reinterpret_cast<const float4*>(dr + 16 * t);
+                    if (e_r < 0) d4 = f4_zero();
+                    const float4 w4 = *reinterpret_cast<const float4*>(sk + 16 * t);
+                    acc = mfma16(d4.x, w4.x, acc);
+                    acc = mfma16(d4.y, w4.y, acc);
+                    acc = mfma16(d4.z, w4.z, acc);
+                    acc = mfma16(d4.w, w4.w, acc);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (e_g[g] >= 0) {
+                        float* o = dz + (int64_t)e_g[g] * Kd + kt * 16 + r_;
+                        *o = accumulate ? (*o + acc[g]) : acc[g];
+                    }
+                }
+            }
+        }
+    }
+}
+
+constexpr size_t ROW_LDS_MAX = 80 * 1024;   // two workgroups per CU
+
+inline size_t row_lds_bytes(int Kd, int L) { return (size_t)Kd * (size_t)(L + 4) * sizeof(float); }
+
+template <typename K>
+int row_lds_attr(K kernel, bool* done) {
+    if (*done) return EQH_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ROW_LDS_MAX) != hipSuccess)
+        return EQH_ERR_LAUNCH;
+    *done = true;
+    return EQH_OK;
+}
+
 int check(int64_t R, int Kd, int L) {
     if (R < 0 || Kd <= 0 || L <= 0) return EQH_ERR_ARG;
     if ((Kd & 15) || (L & 15)) return EQH_ERR_ALIGN;
@@ -158,6 +293,22 @@ extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* row
     if (!z || !w || !rowptr || !out) return EQH_ERR_ARG;
     if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const size_t lds = row_lds_bytes(Kd, L);
+    if ((Kd == 64 || Kd == 192) && lds <= ROW_LDS_MAX) {   // the widths of the radial contraction (mid, 3 * mid)
+        static bool a4 = false, a12 = false;
+        const int blocks = eqh_grid_for(R, 1, 2048);
+        if (Kd == 64) {
+            if (row_lds_attr(k_rowgemm_fwd_lds<4>, &a4)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_fwd_lds<4>, dim3(blocks), dim3(THREADS), lds, stream, z, w, rowptr, perm, (int)R,
+                               (int)L, out, (int)accumulate);
+        } else {
+            if (row_lds_attr(k_rowgemm_fwd_lds<12>, &a12)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_fwd_lds<12>, dim3(blocks), dim3(THREADS), lds, stream, z, w, rowptr, perm, (int)R,
+                               (int)L, out, (int)accumulate);
+        }
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    }
     const int gy = (L >> 4) < 4 ? (L >> 4) : 4;
     dim3 grid(eqh_grid_for(R, WAVES, 4096), gy);
     hipLaunchKernelGGL(k_rowgemm_fwd, grid, dim3(THREADS), 0, stream, z, w, rowptr, perm, (int)R, (int)Kd,
@@ -175,7 +326,21 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
     if (!z || !w || !dout || !rowptr) return EQH_ERR_ARG;
     if (!eqh_aligned16(dout) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (dz) {
+    const size_t lds = row_lds_bytes(Kd, L);
+    if (dz && (Kd == 64 || Kd == 192) && lds <= ROW_LDS_MAX) {
+        static bool a4 = false, a12 = false;
+        const int blocks = eqh_grid_for(R, 1, 2048);
+        if (Kd == 64) {
+            if (row_lds_attr(k_rowgemm_bwd_z_lds<4>, &a4)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_bwd_z_lds<4>, dim3(blocks), dim3(THREADS), lds, stream, dout, w, rowptr, perm,
+                               (int)R, (int)L, dz, (int)accumulate_dz);
+        } else {
+            if (row_lds_attr(k_rowgemm_bwd_z_lds<12>, &a12)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_bwd_z_lds<12>, dim3(blocks), dim3(THREADS), lds, stream, dout, w, rowptr, perm,
+                               (int)R, (int)L, dz, (int)accumulate_dz);
+        }
+        EQH_CHECK_LAUNCH();
+    } else if (dz) {
         const int gy = (Kd >> 4) < 4 ? (Kd >> 4) : 4;
         dim3 grid(eqh_grid_for(R, WAVES, 4096), gy);
         hipLaunchKernelGGL(k_rowgemm_bwd_z, grid, dim3(THREADS), 0, stream, dout, w, rowptr, perm, (int)R,

@@ -578,7 +578,7 @@ def test_fused_ops_accumulate_into_parameter_buffers():
         assert torch.equal(p._eqh_gbuf, ref)
 
 
-@pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3)])
+@pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3), (30, 192, 256, 4)])
 def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     """hg_rowgemm_fwd/bwd: out[e] = z[e] @ w[row(e)] with rows from a CSR (empty rows, rows longer
     than one 16-entry MFMA tile, identity and permuted entry lists)."""
