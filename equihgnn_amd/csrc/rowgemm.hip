@@ -261,6 +261,63 @@ k_rowgemm_bwd_z_lds(const float* __restrict__ dout, const float* __restrict__ w,
     }
 }
 
+// dw[row] = sum_{e in row} z[e]^T (x) dout[e]: the rows of z and dout of up to 32 entries are staged into LDS
+// (coalesced float4 loads; the first version re-read 64-byte segments of them from global memory for each of the
+// (Kd/16) x (L/16) output tiles), every wavefront keeps its share of the output tiles in registers across chunks.
+constexpr int BW_CH = 32;
+template <int KSTEPS, int LTILES>
+__global__ void __launch_bounds__(THREADS)
+k_rowgemm_bwd_w_lds(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
+                    const int* __restrict__ perm, int R, float* __restrict__ dw) {
+    constexpr int Kd = KSTEPS * 16, L = LTILES * 16;
+    constexpr int LZ = Kd + 16, LD = L + 16;                 // row strides = 16 mod 64 banks
+    constexpr int TPW = KSTEPS * LTILES / WAVES;             // output tiles per wavefront
+    static_assert(KSTEPS * LTILES % WAVES == 0, "tiles split evenly");
+    __shared__ __attribute__((aligned(16))) float s_z[BW_CH * LZ];
+    __shared__ __attribute__((aligned(16))) float s_d[BW_CH * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c0 = beg; c0 < end; c0 += BW_CH) {
+            __syncthreads();
+            constexpr int Z4 = Kd / 4, D4 = L / 4;
+            for (int f = threadIdx.x; f < BW_CH * (Z4 + D4); f += THREADS) {
+                const int ent = f / (Z4 + D4), j = f - ent * (Z4 + D4);
+                const int e = entry_at(perm, c0 + ent, end);
+                float4 v = f4_zero();
+                if (j < Z4) {
+                    if (e >= 0) v = *reinterpret_cast<const float4*>(z + (int64_t)e * Kd + 4 * j);
+                    *reinterpret_cast<float4*>(s_z + ent * LZ + 4 * j) = v;
+                } else {
+                    if (e >= 0) v = *reinterpret_cast<const float4*>(dout + (int64_t)e * L + 4 * (j - Z4));
+                    *reinterpret_cast<float4*>(s_d + ent * LD + 4 * (j - Z4)) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                const int tile = wave * TPW + i;
+                const int kt = tile / LTILES, lt = tile - kt * LTILES;
+#pragma unroll
+                for (int s4 = 0; s4 < BW_CH / 4; ++s4)
+                    acc[i] = mfma16(s_z[(4 * s4 + q) * LZ + kt * 16 + r_], s_d[(4 * s4 + q) * LD + lt * 16 + r_], acc[i]);
+            }
+        }
+        float* __restrict__ dwr = dw + (int64_t)row * Kd * L;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int tile = wave * TPW + i;
+            const int kt = tile / LTILES, lt = tile - kt * LTILES;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dwr[(int64_t)(kt * 16 + 4 * q + g) * L + lt * 16 + r_] = acc[i][g];
+        }
+    }
+}
+
 constexpr size_t ROW_LDS_MAX = 80 * 1024;   // two workgroups per CU
 
 inline size_t row_lds_bytes(int Kd, int L) { return (size_t)Kd * (size_t)(L + 4) * sizeof(float); }
@@ -347,7 +404,19 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
                            (int)Kd, (int)L, dz, (int)accumulate_dz);
         EQH_CHECK_LAUNCH();
     }
-    if (dw) {
+    if (dw && ((Kd == 64 && (L == 256 || L == 64)) || (Kd == 192 && L == 64))) {
+        const int blocks = eqh_grid_for(R, 1, 2048);
+        if (Kd == 64 && L == 256)
+            hipLaunchKernelGGL((k_rowgemm_bwd_w_lds<4, 16>), dim3(blocks), dim3(THREADS), 0, stream, z, dout, rowptr, perm,
+                               (int)R, dw);
+        else if (Kd == 64)
+            hipLaunchKernelGGL((k_rowgemm_bwd_w_lds<4, 4>), dim3(blocks), dim3(THREADS), 0, stream, z, dout, rowptr, perm,
+                               (int)R, dw);
+        else
+            hipLaunchKernelGGL((k_rowgemm_bwd_w_lds<12, 4>), dim3(blocks), dim3(THREADS), 0, stream, z, dout, rowptr, perm,
+                               (int)R, dw);
+        EQH_CHECK_LAUNCH();
+    } else if (dw) {
         const int tiles = (Kd >> 4) * (L >> 4);
         dim3 grid(eqh_grid_for(R, WAVES, 2048), tiles < 8 ? tiles : 8);
         hipLaunchKernelGGL(k_rowgemm_bwd_w, grid, dim3(THREADS), 0, stream, z, dout, rowptr, perm, (int)R,
