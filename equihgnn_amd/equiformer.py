@@ -212,7 +212,9 @@ class DTPAttn(nn.Module):
         self.self_interact = FiberLinear((c, c), (d0, d1))
         self.to_out = FiberLinear((d0, d1), (d0, d1))
 
-    def forward(self, f0, f1, geo: EdgeGeometry):
+    def forward(self, f0, f1, geo: EdgeGeometry, joined: bool = True):
+        """[N, 1+K, 104] (self-interaction as slot 0), or with ``joined=False`` its two parts: the self rows
+        [N, 104] and the edge rows [E, 104]."""
         xi0, xj0 = f0 @ self.to_xi.w(0), f0 @ self.to_xj.w(0)
         xi1 = torch.einsum("ndm,de->nem", f1, self.to_xi.w(1))
         xj1 = torch.einsum("ndm,de->nem", f1, self.to_xj.w(1))
@@ -221,6 +223,8 @@ class DTPAttn(nn.Module):
         o10 = radial_contract(r10, r10.trunk(geo.dist), xj1, xi1, geo, zscale=geo.rhat)
         out = torch.cat((o00, o10), -1) @ self.to_out.w(0)                          # [E, 104]
         me = f0 @ self.self_interact.w(0)                                           # [N, 104]
+        if not joined:
+            return me, out
         return torch.cat((me[:, None, :], out.view(geo.N, geo.K, -1)), 1)           # [N, 1+K, 104]
 
 
@@ -241,7 +245,18 @@ class MLPAttention(nn.Module):
 
     def forward(self, x0, x1, geo: EdgeGeometry):
         f0, f1 = self.prenorm.norm0(x0), self.prenorm.norm1(x1)
-        inter = self.to_attn_and_v(f0, f1, geo)                                     # [N, 1+K, 104]
+        wl, wv = self.to_attn_logits[0][1].weight, self.to_values[1].w(0)
+        if geo.K == 16 and f0.is_cuda:
+            me, edge = self.to_attn_and_v(f0, f1, geo, joined=False)
+            if ops.attn_pool_supported(me, edge, geo.maskf, wl, wv, 8 + self.dh):
+                # logits, masked softmax over the 17 slots, SiLU gate + value Linear and the weighted sum in one
+                # launch each way; the [N, 17, 104] concatenation is never built (csrc/attn_pool.hip)
+                out = ops.attn_pool(me, edge, geo.maskf, wl, wv, 8 + self.dh, self.scale, 0.1)
+                gate = torch.sigmoid(self.attn_head_gates[1](f0))[:, :1]
+                return (out * gate) @ self.to_out.w(0)
+            inter = torch.cat((me[:, None, :], edge.view(geo.N, geo.K, -1)), 1)
+        else:
+            inter = self.to_attn_and_v(f0, f1, geo)                                 # [N, 1+K, 104]
         logits = self.to_attn_logits[0](inter[..., :4]) * self.scale                # [N, 1+K, 1]
         keep = F.pad(geo.mask, (1, 0), value=True)[..., None]                       # self always valid
         attn = logits.masked_fill(~keep, -torch.finfo(logits.dtype).max).softmax(dim=1)

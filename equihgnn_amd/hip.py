@@ -55,6 +55,11 @@ SIGNATURES = {
     "eqf_rms_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "eqf_rms_norm_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p,
                                    c_int32, c_void_p, c_size_t, c_void_p]),
+    "eqf_attn_pool_fwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_void_p,
+                                    c_void_p, c_void_p]),
+    "eqf_attn_pool_bwd_workspace_bytes": (c_size_t, [c_int64]),
+    "eqf_attn_pool_bwd": (c_int32, [c_void_p] * 7 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_float]
+                          + [c_void_p] * 4 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_readout_mse_supported": (c_int32, [c_int32, c_int32]),
     "hg_readout_mse_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "hg_readout_mse_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_float,

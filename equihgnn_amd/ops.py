@@ -1161,6 +1161,67 @@ def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
     return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
 
 
+class _AttnPool(torch.autograd.Function):
+    """Softmax over (self + 16 neighbour) slots of LeakyReLU-Linear logits, SiLU values, value Linear and the
+    weighted sum, per node, one launch each way (eqf_attn_pool_fwd / _bwd, csrc/attn_pool.hip)."""
+
+    @staticmethod
+    def forward(ctx, me, edge, maskf, w_logit, wv, v_off, scale, slope, acc_params):
+        _require_gpu(me, "attn_pool")
+        me, edge, maskf = _f32c(me), _f32c(edge), _f32c(maskf)
+        wl, wvv = _f32c(w_logit.detach()).reshape(-1), _f32c(wv.detach())
+        N, D = me.shape
+        K, V = maskf.shape[1], wvv.shape[0]
+        out = torch.empty((N, V), dtype=torch.float32, device=me.device)
+        attn = torch.empty((N, K + 1), dtype=torch.float32, device=me.device)
+        hip.check(hip.lib().eqf_attn_pool_fwd(_ptr(me), _ptr(edge), _ptr(maskf), _ptr(wl), _ptr(wvv), N, K, D, v_off, V,
+                                              float(scale), float(slope), _ptr(out), _ptr(attn), _stream(me.device)),
+                  "eqf_attn_pool_fwd")
+        ctx.save_for_backward(me, edge, maskf, wl, wvv, attn)
+        ctx.meta = (v_off, float(scale), float(slope), w_logit.shape)
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        me, edge, maskf, wl, wvv, attn = ctx.saved_tensors
+        v_off, scale, slope, wl_shape = ctx.meta
+        dout = _f32c(dout)
+        N, D = me.shape
+        K, V = maskf.shape[1], wvv.shape[0]
+        dev = me.device
+        dme, dedge = torch.empty_like(me), torch.empty_like(edge)
+        L = hip.lib()
+        ws_bytes = L.eqf_attn_pool_bwd_workspace_bytes(N)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(p) for p in ctx.acc]            # (w_logit, wv)
+        in_place = all(t is not None for t in tg)
+        dwl, dwv = tg if in_place else (torch.empty(wl_shape, dtype=torch.float32, device=dev), torch.empty_like(wvv))
+        hip.check(L.eqf_attn_pool_bwd(_ptr(me), _ptr(edge), _ptr(maskf), _ptr(wl), _ptr(wvv), _ptr(attn), _ptr(dout), N, K,
+                                      D, v_off, V, scale, slope, _ptr(dme), _ptr(dedge), _ptr(dwl), _ptr(dwv),
+                                      1 if in_place else 0, _ptr(ws), ws_bytes, _stream(dev)), "eqf_attn_pool_bwd")
+        if in_place:
+            return dme, dedge, None, None, None, None, None, None, None
+        return dme, dedge, None, dwl, dwv, None, None, None, None
+
+
+def attn_pool_supported(me, edge, maskf, w_logit, wv, v_off) -> bool:
+    return (me.is_cuda and me.dim() == 2 and edge.dim() == 2 and me.dtype == torch.float32 and maskf.dim() == 2
+            and maskf.shape[1] == 16 and edge.shape[0] == me.shape[0] * 16 and edge.shape[1] == me.shape[1]
+            and tuple(wv.shape) == (48, 48) and w_logit.numel() == 4 and me.shape[1] % 4 == 0 and v_off % 4 == 0
+            and v_off >= 4 and v_off + 48 <= me.shape[1])
+
+
+def attn_pool(me, edge, maskf, w_logit, wv, v_off: int, scale: float, slope: float):
+    """out[n] = sum_s softmax_s(scale * w_logit . leaky_relu(x_s[:4])) * (silu(x_s[v_off:v_off+48]) @ wv) over the
+    slots x_0 = me[n], x_1.. = edge[n*16 + s - 1] (valid where maskf[n, s-1] != 0; slot 0 always)."""
+    if torch.is_grad_enabled():
+        for w_ in (w_logit, wv):
+            if w_.requires_grad and w_.is_leaf:
+                LINEAR_PARAMS[id(w_)] = w_
+    return _AttnPool.apply(me, edge, maskf, w_logit, wv, v_off, scale, slope, (w_logit, wv))
+
+
 class _RmsNormRows(torch.autograd.Function):
     """t / max(||t|| * C^-1/2, eps) * g over dense rows (eqf_rms_norm_fwd / _bwd, csrc/rmsnorm.hip)."""
 

@@ -267,6 +267,24 @@ int eqf_rms_norm_bwd(const float* x, const float* g, const float* dy, int64_t n_
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Tail of the Equiformer's MLP attention (equiformer_layer.py:871-955, one head): per node n with its own row
+ * me[n, :D] (slot 0, always valid, :877-878) and its K = 16 edge rows edge[n*K + s, :D] (valid where
+ * mask[n, s] != 0):  logit_s = scale * w_logit . LeakyReLU_slope(x_s[0:4]);  attn = softmax over the valid slots
+ * (masked ones filled with -max, :912-915);  out[n, :V] = sum_s attn_s * (SiLU(x_s[v_off : v_off+V]) @ wv).
+ * attn [N, K+1] is saved for the backward.  bwd: dme / dedge (every column written: zeros outside the two
+ * column blocks that are read), dw_logit [4], dwv [V, V] (overwritten, or added to with accumulate != 0).
+ * K = 16, V = 48; D, v_off multiples of 4.
+ * ------------------------------------------------------------------------------------------- */
+int eqf_attn_pool_fwd(const float* me, const float* edge, const float* mask, const float* w_logit, const float* wv,
+                      int64_t N, int32_t K, int32_t D, int32_t v_off, int32_t V, float scale, float slope, float* out,
+                      float* attn, void* stream);
+size_t eqf_attn_pool_bwd_workspace_bytes(int64_t N);
+int eqf_attn_pool_bwd(const float* me, const float* edge, const float* mask, const float* w_logit, const float* wv,
+                      const float* attn, const float* dout, int64_t N, int32_t K, int32_t D, int32_t v_off, int32_t V,
+                      float scale, float slope, float* dme, float* dedge, float* dw_logit, float* dwv,
+                      int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Trunk of the Equiformer radial network, `Radial.rp[0..5]` of equiformer_layer.py:451-479, per edge:
  * Linear(1,64) -> SiLU -> LayerNorm -> Linear(64,64) -> SiLU -> LayerNorm (the local LayerNorm of
  * :158-165: learnable gamma, beta a zero buffer).  dist [E]; params[8] = {w0 [64] (= rp.0.weight[:,0]),

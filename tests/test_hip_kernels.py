@@ -937,6 +937,48 @@ def test_shared_input_nodes_match_float64_reference():
     assert rel(d2.grad, t0.grad) < 2e-5
 
 
+@pytest.mark.parametrize("N", [1, 37, 2000])
+def test_attn_pool_matches_float64_reference(N):
+    """Attention tail of equiformer_layer.py:871-955 (logits -> masked softmax over self + 16 slots -> SiLU values @ Wv ->
+    weighted sum) against the same expression in float64: output, both input gradients (zeros outside the columns that
+    are read), d w_logit, d Wv; nodes with every neighbour masked; accumulation into persistent buffers."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N)
+    K, D, V, v_off, scale, slope = 16, 104, 48, 56, 48 ** -0.5, 0.1
+    me, edge = torch.randn(N, D, generator=g), torch.randn(N * K, D, generator=g)
+    mask = torch.rand(N, K, generator=g) < 0.7
+    mask[0] = False                                       # only the self slot is valid
+    wl, wv, wo = 0.5 * torch.randn(1, 4, generator=g), torch.randn(V, V, generator=g) / V ** 0.5, torch.randn(N, V, generator=g)
+    t = [z.double().requires_grad_(True) for z in (me, edge, wl, wv)]
+    inter = torch.cat((t[0][:, None, :], t[1].view(N, K, D)), 1)
+    logits = torch.nn.functional.linear(torch.nn.functional.leaky_relu(inter[..., :4], slope), t[2]) * scale
+    keep = torch.nn.functional.pad(mask, (1, 0), value=True)[..., None]
+    attn = logits.masked_fill(~keep, -torch.finfo(torch.float64).max).softmax(dim=1)
+    ref = (attn * (torch.nn.functional.silu(inter[..., v_off:]) @ t[3])).sum(1)
+    (ref * wo.double()).sum().backward()
+    d = [z.to(DEV).requires_grad_(True) for z in (me, edge, wl, wv)]
+    maskf = mask.float().to(DEV)
+    assert ops.attn_pool_supported(d[0], d[1], maskf, d[2], d[3], v_off)
+    out = ops.attn_pool(d[0], d[1], maskf, d[2], d[3], v_off, scale, slope)
+    (out * wo.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=2e-5)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max().clamp(min=1e-9))
+
+    for a, b, name in zip(d, t, ("dme", "dedge", "dw_logit", "dwv")):
+        assert rel(a.grad, b.grad) < 3e-5, name
+    assert float(d[1].grad[:, 4:v_off].abs().max()) == 0.0 and float(d[0].grad[:, 4:v_off].abs().max()) == 0.0
+    for a in d[2:]:
+        a.grad = None
+        a._eqh_gbuf = torch.full_like(a, 0.5)
+    out2 = ops.attn_pool(me.to(DEV).requires_grad_(True), edge.to(DEV), maskf, d[2], d[3], v_off, scale, slope)
+    (out2 * wo.to(DEV)).sum().backward()
+    for a, b in zip(d[2:], t[2:]):
+        assert a.grad is None and rel(a._eqh_gbuf - 0.5, b.grad) < 3e-5
+        del a._eqh_gbuf
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
