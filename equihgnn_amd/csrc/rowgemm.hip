@@ -239,7 +239,6 @@ k_rowgemm_bwd_z_lds(const float* __restrict__ dout, const float* __restrict__ w,
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 const float* __restrict__ sk = s_w + (kt * 16 + r_) * ld + 4 * q;
                 const float* __restrict__ dr = dout + (int64_t)(e_r >= 0 ? e_r : 0) * L + 4 * q;
-#pragma unroll 4
                 for (int t = 0; t < lsteps; ++t) {
                     float4 d4 = *reinterpret_cast<const float4*>(dr + 16 * t);
                     if (e_r < 0) d4 = f4_zero();

@@ -54,6 +54,9 @@ class SwiGLUMLP(nn.Module):
         self.p = drop
 
     def hidden(self, pre):
+        if pre.is_cuda and pre.dtype == torch.float32 and pre.shape[-1] % 8 == 0:
+            # SiLU gate, product and dropout in one pass each way (no mask tensor, no chunk copies)
+            return _layer_norm(self.norm, ops.swiglu_dropout(pre, self.p if self.training else 0.0))
         a, b = pre.chunk(2, dim=-1)
         return _layer_norm(self.norm, F.dropout(F.silu(a) * b, self.p, self.training))
 
@@ -70,7 +73,10 @@ class SwiGLUMLP(nn.Module):
         pre = pre + (base if extra is None else base.unsqueeze(-2))
         h = self.hidden(pre)                                               # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
-            return F.dropout(self.fc2(h), self.p, True).mean(-2)
+            out = self.fc2(h)
+            if out.is_cuda and out.dtype == torch.float32 and out.shape[-1] % 4 == 0:
+                return ops.dropout_mean(out, self.p)                       # dropout + frame average, one pass
+            return F.dropout(out, self.p, True).mean(-2)
         return self.fc2(h.mean(-2))
 
 

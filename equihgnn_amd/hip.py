@@ -60,6 +60,10 @@ SIGNATURES = {
     "eqf_attn_pool_bwd_workspace_bytes": (c_size_t, [c_int64]),
     "eqf_attn_pool_bwd": (c_int32, [c_void_p] * 7 + [c_int64, c_int32, c_int32, c_int32, c_int32, c_float, c_float]
                           + [c_void_p] * 4 + [c_int32, c_void_p, c_size_t, c_void_p]),
+    "faf_swiglu_dropout_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_swiglu_dropout_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_dropout_mean_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_dropout_mean_bwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "hg_readout_mse_supported": (c_int32, [c_int32, c_int32]),
     "hg_readout_mse_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "hg_readout_mse_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_float,

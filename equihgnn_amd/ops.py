@@ -1161,6 +1161,77 @@ def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
     return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
 
 
+def _dropout_seed(device, p):
+    """A fresh int64 seed in device memory (drawn by torch's generator: graph-safe, a new value per replay)."""
+    if p <= 0.0:
+        return None
+    return torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
+
+
+class _SwigluDropout(torch.autograd.Function):
+    """dropout_p(silu(pre[:, :H]) * pre[:, H:]) in one pass each way (faf_swiglu_dropout_*, csrc/faformer_ew.hip)."""
+
+    @staticmethod
+    def forward(ctx, pre, p):
+        _require_gpu(pre, "swiglu_dropout")
+        pre2 = _f32c(pre).reshape(-1, pre.shape[-1])
+        R, H = pre2.shape[0], pre2.shape[1] // 2
+        seed = _dropout_seed(pre.device, p)
+        out = torch.empty((R, H), dtype=torch.float32, device=pre.device)
+        hip.check(hip.lib().faf_swiglu_dropout_fwd(_ptr(pre2), R, H, float(p), _ptr(seed), _ptr(out), _stream(pre.device)),
+                  "faf_swiglu_dropout_fwd")
+        ctx.save_for_backward(pre2)
+        ctx.seed, ctx.p, ctx.shape = seed, float(p), pre.shape
+        return out.view(*pre.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pre2,) = ctx.saved_tensors
+        R, H = pre2.shape[0], pre2.shape[1] // 2
+        dout = _f32c(dout).reshape(R, H)
+        dpre = torch.empty_like(pre2)
+        hip.check(hip.lib().faf_swiglu_dropout_bwd(_ptr(pre2), _ptr(dout), R, H, ctx.p, _ptr(ctx.seed), _ptr(dpre),
+                                                   _stream(pre2.device)), "faf_swiglu_dropout_bwd")
+        return dpre.view(ctx.shape), None
+
+
+class _DropoutMean(torch.autograd.Function):
+    """mean over dim -2 of dropout_p(x) in one pass each way (faf_dropout_mean_*)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        _require_gpu(x, "dropout_mean")
+        F_, C = x.shape[-2], x.shape[-1]
+        x2 = _f32c(x).reshape(-1, C)
+        R = x2.shape[0] // F_
+        seed = _dropout_seed(x.device, p)
+        out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out), _stream(x.device)),
+                  "faf_dropout_mean_fwd")
+        ctx.seed, ctx.p, ctx.shape = seed, float(p), x.shape
+        return out.view(*x.shape[:-2], C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        F_, C = ctx.shape[-2], ctx.shape[-1]
+        dout = _f32c(dout).reshape(-1, C)
+        R = dout.shape[0]
+        dx = torch.empty((R * F_, C), dtype=torch.float32, device=dout.device)
+        hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx), _stream(dout.device)),
+                  "faf_dropout_mean_bwd")
+        return dx.view(ctx.shape), None
+
+
+def swiglu_dropout(pre, p: float = 0.0):
+    """dropout_p(silu(a) * b) for pre = [a | b] along the last dim (fp32, last dim % 8 == 0)."""
+    return _SwigluDropout.apply(pre, p)
+
+
+def dropout_mean(x, p: float = 0.0):
+    """dropout_p(x).mean(-2) for fp32 x [..., F, C] (C % 4 == 0)."""
+    return _DropoutMean.apply(x, p)
+
+
 class _AttnPool(torch.autograd.Function):
     """Softmax over (self + 16 neighbour) slots of LeakyReLU-Linear logits, SiLU values, value Linear and the
     weighted sum, per node, one launch each way (eqf_attn_pool_fwd / _bwd, csrc/attn_pool.hip)."""

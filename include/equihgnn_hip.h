@@ -321,6 +321,23 @@ int hg_readout_mse_f32(const float* x, const int32_t* rowptr, int32_t n_graphs, 
                        size_t workspace_bytes, int32_t* state, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Elementwise passes of FAFormer's SwiGLU MLP (fa_former_layer.py:241-289) and its 8-frame average (:61-120):
+ *   faf_swiglu_dropout: out [R, H] = dropout_p(SiLU(pre[:, :H]) * pre[:, H:]),  pre [R, 2H];
+ *   faf_dropout_mean:   out [R, C] = mean over the F consecutive rows r*F .. r*F+F-1 of dropout_p(x),  x [R*F, C].
+ * p in [0, 1): 0 = no dropout (seed may be NULL); otherwise element i is kept (and scaled by 1/(1-p)) by a hash of
+ * (*seed, i), *seed an int64 in device memory; the backward recomputes the decisions from the same seed, nothing
+ * is stored.  H, C multiples of 4.
+ * ------------------------------------------------------------------------------------------- */
+int faf_swiglu_dropout_fwd(const float* pre, int64_t R, int32_t H, float p, const int64_t* seed, float* out,
+                           void* stream);
+int faf_swiglu_dropout_bwd(const float* pre, const float* dout, int64_t R, int32_t H, float p, const int64_t* seed,
+                           float* dpre, void* stream);
+int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed, float* out,
+                         void* stream);
+int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed, float* dx,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending
  * (may be NULL), v [B,3,3] eigenvectors in columns, largest component of each column positive.

@@ -979,6 +979,55 @@ def test_attn_pool_matches_float64_reference(N):
         del a._eqh_gbuf
 
 
+def test_faformer_elementwise_kernels():
+    """swiglu_dropout and dropout_mean (fa_former_layer.py:241-289 on the 8-frame tensors): exact against torch without
+    dropout; with p = 0.1 the kept fraction, the 1/(1-p) scaling, fresh masks per call, and a backward pass that uses
+    exactly the forward's (recomputed) mask."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    pre = torch.randn(300, 8, 256, generator=g)
+    w = torch.randn(300, 8, 128, generator=g)
+    t = pre.double().requires_grad_(True)
+    a, b = t.chunk(2, -1)
+    ref = torch.nn.functional.silu(a) * b
+    (ref * w.double()).sum().backward()
+    d = pre.to(DEV).requires_grad_(True)
+    out = ops.swiglu_dropout(d, 0.0)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=2e-6)
+    np.testing.assert_allclose(d.grad.cpu().numpy(), t.grad.numpy(), atol=5e-6, rtol=1e-5)
+    # dropout: mask recovered from the output, gradient must use the same one
+    d2 = pre.to(DEV).requires_grad_(True)
+    o1 = ops.swiglu_dropout(d2, 0.1)
+    keep = (o1.detach() != 0) | (out.detach() == 0)
+    frac = float(keep.float().mean())
+    assert 0.88 < frac < 0.92, frac
+    np.testing.assert_allclose(o1.detach()[keep].cpu().numpy(), (out.detach()[keep] / 0.9).cpu().numpy(), rtol=1e-6, atol=1e-7)
+    (o1 * w.to(DEV)).sum().backward()
+    kc = keep.cpu().double()
+    want = torch.cat(((w.double() * kc / 0.9) * b.detach() * (torch.sigmoid(a.detach()) * (1 + a.detach() * (1 - torch.sigmoid(a.detach())))),
+                      (w.double() * kc / 0.9) * torch.nn.functional.silu(a.detach())), -1)
+    np.testing.assert_allclose(d2.grad.cpu().numpy(), want.numpy(), atol=1e-5, rtol=1e-5)
+    o2 = ops.swiglu_dropout(d2.detach(), 0.1)
+    assert not torch.equal(o1.detach() != 0, o2 != 0)                      # a new mask per call
+    # dropout + frame mean
+    x = torch.randn(500, 8, 256, generator=g)
+    w2 = torch.randn(500, 256, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    m0 = ops.dropout_mean(xd, 0.0)
+    np.testing.assert_allclose(m0.detach().cpu().numpy(), x.double().mean(-2).numpy(), atol=1e-6, rtol=1e-6)
+    (m0 * w2.to(DEV)).sum().backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), (w2[:, None, :] / 8).expand(500, 8, 256).numpy(), atol=1e-7, rtol=1e-6)
+    xd2 = x.to(DEV).requires_grad_(True)
+    m1 = ops.dropout_mean(xd2, 0.1)
+    (m1 * w2.to(DEV)).sum().backward()
+    mask = xd2.grad != 0                                                   # w2 has no exact zeros
+    assert 0.88 < float(mask.float().mean()) < 0.92
+    np.testing.assert_allclose(m1.detach().cpu().numpy(), ((x.double() * mask.cpu().double() / 0.9).mean(-2)).numpy(), atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(xd2.grad[mask].cpu().numpy(), (w2[:, None, :] / 8 / 0.9).expand(500, 8, 256)[mask.cpu()].numpy(),
+                               atol=1e-7, rtol=1e-6)
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
