@@ -450,7 +450,9 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
     }
 }
 
-inline int rowln_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES * 4, 256); }
+// a slab of 3C partial sums per workgroup: few workgroups for the usual ~5 k rows, but the 2 M-row frame tensors of
+// FAFormer need the whole chip's worth of wavefronts in flight (each walks its rows one memory round trip at a time)
+inline int rowln_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES * 4, rows > 65536 ? 2048 : 256); }
 
 // rows per wavefront of the backward: about 2048 wavefronts per launch (two per SIMD)
 inline int bwd_rpw(int64_t rows) {
