@@ -187,3 +187,144 @@ extern "C" int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// First Linear of the frame-averaged MLP (fa_former_layer.py:61-120 with :241-289): for every row e (an edge or a
+// node) and each of the 8 sign frames f,   pre[e, f, :] = W3 (y_e * s_f) + base_e,   s_f = (+-1, +-1, +-1),
+// W3 = fc1.weight[:, :3], base_e = fc1.weight[:, 3:] extra_e + bias (computed once per row, not per frame).
+// As torch ops: build u = y * s [E, 8, 3], a K = 3 GEMM, a broadcast add -- and backward a [3 x 2M] . [2M x 256]
+// GEMM, a [2M x 256] . [256 x 3] GEMM and a sum over frames, each a pass over the 2 GB tensor.  Here the forward
+// forms t_d = y_d * W3[:, d] once per row and writes the 8 sign combinations; the backward reads d pre ONCE (a
+// wavefront per row) and yields d base = sum_f, r_d = sum_f s_fd d pre_f, dy_d = r_d . W3[:, d] and the row's
+// contribution y_d * r_d to d W3 (per-lane accumulators -> workgroup slabs -> fixed-order reducer).
+namespace {
+
+constexpr int FP_THREADS = 256;
+constexpr int FP_WAVES = FP_THREADS / 64;
+
+template <int CTRL>
+__device__ __forceinline__ float fp_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float fp_wave_sum(float v) {
+    v += fp_dpp<0xB1>(v);
+    v += fp_dpp<0x4E>(v);
+    v += fp_dpp<0x124>(v);
+    v += fp_dpp<0x128>(v);
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
+__device__ __forceinline__ float4 f4_combo(const float4& t0, const float4& t1, const float4& t2, const float4& b, int f) {
+    const float s0 = (f & 4) ? 1.f : -1.f, s1 = (f & 2) ? 1.f : -1.f, s2 = (f & 1) ? 1.f : -1.f;
+    return make_float4(fmaf(s0, t0.x, fmaf(s1, t1.x, fmaf(s2, t2.x, b.x))), fmaf(s0, t0.y, fmaf(s1, t1.y, fmaf(s2, t2.y, b.y))),
+                       fmaf(s0, t0.z, fmaf(s1, t1.z, fmaf(s2, t2.z, b.z))), fmaf(s0, t0.w, fmaf(s1, t1.w, fmaf(s2, t2.w, b.w))));
+}
+
+// H = 256: one float4 of h per lane, a wavefront per row
+__global__ void __launch_bounds__(FP_THREADS)
+k_frame_pre_fwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ base, int64_t E,
+                float* __restrict__ out) {
+    constexpr int H = 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane * 4;
+    float4 w0, w1, w2;   // W3[h .. h+3][d]
+    w0 = make_float4(w3[(h + 0) * 3 + 0], w3[(h + 1) * 3 + 0], w3[(h + 2) * 3 + 0], w3[(h + 3) * 3 + 0]);
+    w1 = make_float4(w3[(h + 0) * 3 + 1], w3[(h + 1) * 3 + 1], w3[(h + 2) * 3 + 1], w3[(h + 3) * 3 + 1]);
+    w2 = make_float4(w3[(h + 0) * 3 + 2], w3[(h + 1) * 3 + 2], w3[(h + 2) * 3 + 2], w3[(h + 3) * 3 + 2]);
+    for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
+        const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
+        const float4 b = *reinterpret_cast<const float4*>(base + e * H + h);
+        const float4 t0 = make_float4(y0 * w0.x, y0 * w0.y, y0 * w0.z, y0 * w0.w);
+        const float4 t1 = make_float4(y1 * w1.x, y1 * w1.y, y1 * w1.z, y1 * w1.w);
+        const float4 t2 = make_float4(y2 * w2.x, y2 * w2.y, y2 * w2.z, y2 * w2.w);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) *reinterpret_cast<float4*>(out + (e * 8 + f) * H + h) = f4_combo(t0, t1, t2, b, f);
+    }
+}
+
+__global__ void __launch_bounds__(FP_THREADS)
+k_frame_pre_bwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ dpre, int64_t E,
+                float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ slab) {
+    constexpr int H = 256;
+    __shared__ float4 s_red[FP_WAVES][3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane * 4;
+    float4 w0, w1, w2;
+    w0 = make_float4(w3[(h + 0) * 3 + 0], w3[(h + 1) * 3 + 0], w3[(h + 2) * 3 + 0], w3[(h + 3) * 3 + 0]);
+    w1 = make_float4(w3[(h + 0) * 3 + 1], w3[(h + 1) * 3 + 1], w3[(h + 2) * 3 + 1], w3[(h + 3) * 3 + 1]);
+    w2 = make_float4(w3[(h + 0) * 3 + 2], w3[(h + 1) * 3 + 2], w3[(h + 2) * 3 + 2], w3[(h + 3) * 3 + 2]);
+    float4 a0 = f4_zero(), a1 = f4_zero(), a2 = f4_zero();   // d W3[h .. h+3][d]
+    for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
+        float4 g[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) g[f] = *reinterpret_cast<const float4*>(dpre + (e * 8 + f) * H + h);
+        float4 sb = f4_zero(), r0 = f4_zero(), r1 = f4_zero(), r2 = f4_zero();
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            f4_add(sb, g[f]);
+            f4_fma(r0, g[f], (f & 4) ? 1.f : -1.f);
+            f4_fma(r1, g[f], (f & 2) ? 1.f : -1.f);
+            f4_fma(r2, g[f], (f & 1) ? 1.f : -1.f);
+        }
+        *reinterpret_cast<float4*>(dbase + e * H + h) = sb;
+        const float d0 = fp_wave_sum((r0.x * w0.x + r0.y * w0.y) + (r0.z * w0.z + r0.w * w0.w));
+        const float d1 = fp_wave_sum((r1.x * w1.x + r1.y * w1.y) + (r1.z * w1.z + r1.w * w1.w));
+        const float d2 = fp_wave_sum((r2.x * w2.x + r2.y * w2.y) + (r2.z * w2.z + r2.w * w2.w));
+        if (lane == 0) { dy[e * 3] = d0; dy[e * 3 + 1] = d1; dy[e * 3 + 2] = d2; }
+        const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
+        f4_fma(a0, r0, y0);
+        f4_fma(a1, r1, y1);
+        f4_fma(a2, r2, y2);
+    }
+    s_red[wave][0][lane] = a0; s_red[wave][1][lane] = a1; s_red[wave][2][lane] = a2;
+    __syncthreads();
+    if (wave == 0) {
+        float* __restrict__ sl = slab + (int64_t)blockIdx.x * (H * 3);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float4 t = s_red[0][d][lane];
+            for (int w = 1; w < FP_WAVES; ++w) f4_add(t, s_red[w][d][lane]);
+            sl[(h + 0) * 3 + d] = t.x; sl[(h + 1) * 3 + d] = t.y; sl[(h + 2) * 3 + d] = t.z; sl[(h + 3) * 3 + d] = t.w;
+        }
+    }
+}
+
+inline int fp_blocks(int64_t E) { return eqh_grid_for(E, FP_WAVES * 8, 1024); }
+
+}  // namespace
+
+extern "C" int faf_frame_pre_fwd(const float* y, const float* w3, const float* base, int64_t E, int32_t H, float* out,
+                                 void* stream_) {
+    if (E < 0 || H != 256) return EQH_ERR_ARG;
+    if (E == 0) return EQH_OK;
+    if (!y || !w3 || !base || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(base) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_frame_pre_fwd, dim3(eqh_grid_for(E, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, y, w3, base, E,
+                       out);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" size_t faf_frame_pre_bwd_workspace_bytes(int64_t E, int32_t H) {
+    if (E <= 0 || H != 256) return 0;
+    return (size_t)fp_blocks(E) * (size_t)H * 3 * sizeof(float);
+}
+
+extern "C" int faf_frame_pre_bwd(const float* y, const float* w3, const float* dpre, int64_t E, int32_t H, float* dy,
+                                 float* dbase, float* dw3, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                 void* stream_) {
+    if (E < 0 || H != 256 || !dw3) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E == 0) return accumulate ? EQH_OK : eqh_zero_async(dw3, (int64_t)H * 3, stream);
+    if (!y || !w3 || !dpre || !dy || !dbase || !workspace) return EQH_ERR_ARG;
+    if (!eqh_aligned16(dpre) || !eqh_aligned16(dbase) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_frame_pre_bwd_workspace_bytes(E, H)) return EQH_ERR_ARG;
+    const int blocks = fp_blocks(E);
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_frame_pre_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, dpre, E, dy, dbase, slab);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs_async(slab, blocks, (int64_t)H * 3, dw3, stream, accumulate);
+}

@@ -66,11 +66,14 @@ class SwiGLUMLP(nn.Module):
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
         w = self.fc1.weight
-        s = _sign_ops(y.device, y.dtype)                                   # [8, 3]
-        u = y.unsqueeze(-2) * s                                            # [..., 8, 3]
-        pre = F.linear(u, w[:, :3])                                        # [..., 8, H]
         base = self.fc1.bias if extra is None else F.linear(extra, w[:, 3:], self.fc1.bias)
-        pre = pre + (base if extra is None else base.unsqueeze(-2))
+        if y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256:
+            pre = ops.frame_pre(y, w[:, :3], base)                         # [..., 8, H] in one pass (csrc/faformer_ew.hip)
+        else:
+            s = _sign_ops(y.device, y.dtype)                               # [8, 3]
+            u = y.unsqueeze(-2) * s                                        # [..., 8, 3]
+            pre = F.linear(u, w[:, :3])                                    # [..., 8, H]
+            pre = pre + (base if extra is None else base.unsqueeze(-2))
         h = self.hidden(pre)                                               # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
             out = self.fc2(h)

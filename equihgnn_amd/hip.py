@@ -64,6 +64,10 @@ SIGNATURES = {
     "faf_swiglu_dropout_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_bwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_frame_pre_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "faf_frame_pre_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "faf_frame_pre_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                    c_void_p, c_size_t, c_void_p]),
     "hg_readout_mse_supported": (c_int32, [c_int32, c_int32]),
     "hg_readout_mse_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "hg_readout_mse_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_float,

@@ -1222,6 +1222,50 @@ class _DropoutMean(torch.autograd.Function):
         return dx.view(ctx.shape), None
 
 
+class _FramePre(torch.autograd.Function):
+    """pre[e, f, :] = w3 (y[e] * s_f) + base[e] over the 8 sign frames, one pass each way (faf_frame_pre_*)."""
+
+    @staticmethod
+    def forward(ctx, y, w3, base):
+        _require_gpu(y, "frame_pre")
+        lead = y.shape[:-1]
+        y2, w3c = _f32c(y).reshape(-1, 3), _f32c(w3)
+        H = w3c.shape[0]
+        base2 = _f32c(base.expand(*lead, H)).reshape(-1, H)
+        E = y2.shape[0]
+        out = torch.empty((E, 8, H), dtype=torch.float32, device=y.device)
+        hip.check(hip.lib().faf_frame_pre_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), E, H, _ptr(out), _stream(y.device)),
+                  "faf_frame_pre_fwd")
+        ctx.save_for_backward(y2, w3c)
+        ctx.lead, ctx.base_shape = lead, base.shape
+        return out.view(*lead, 8, H)
+
+    @staticmethod
+    def backward(ctx, dpre):
+        y2, w3c = ctx.saved_tensors
+        E, H = y2.shape[0], w3c.shape[0]
+        dpre = _f32c(dpre).reshape(E, 8, H)
+        dev = y2.device
+        dy = torch.empty_like(y2)
+        dbase = torch.empty((E, H), dtype=torch.float32, device=dev)
+        dw3 = torch.empty_like(w3c)
+        L = hip.lib()
+        ws_bytes = L.faf_frame_pre_bwd_workspace_bytes(E, H)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        hip.check(L.faf_frame_pre_bwd(_ptr(y2), _ptr(w3c), _ptr(dpre), E, H, _ptr(dy), _ptr(dbase), _ptr(dw3), 0, _ptr(ws),
+                                      ws_bytes, _stream(dev)), "faf_frame_pre_bwd")
+        dbase = dbase.view(*ctx.lead, H)
+        if tuple(ctx.base_shape) != tuple(dbase.shape):          # base was broadcast (a bias vector): sum it back
+            dbase = dbase.sum_to_size(ctx.base_shape)
+        return dy.view(*ctx.lead, 3), dw3, dbase
+
+
+def frame_pre(y, w3, base):
+    """First Linear of FAFormer's frame-averaged MLP: [..., 3] x [H, 3] (+ base [..., H] or [H]) -> [..., 8, H] over
+    the 8 sign frames in the order of fa_former_layer.py:70-84; H = 256."""
+    return _FramePre.apply(y, w3, base)
+
+
 def swiglu_dropout(pre, p: float = 0.0):
     """dropout_p(silu(a) * b) for pre = [a | b] along the last dim (fp32, last dim % 8 == 0)."""
     return _SwigluDropout.apply(pre, p)

@@ -336,6 +336,14 @@ int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_t C, float 
                          void* stream);
 int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed, float* dx,
                          void* stream);
+/* First Linear of the frame-averaged MLP: out[e, f, :] = w3 (y[e] * s_f) + base[e, :] for the 8 sign frames
+ * s_f = ((f&4 ? +1 : -1), (f&2 ? +1 : -1), (f&1 ? +1 : -1)) (fa_former_layer.py:70-84 order); y [E,3], w3 [H,3]
+ * (= fc1.weight[:, :3], contiguous), base [E,H], out [E,8,H].  bwd reads dpre [E,8,H] once: dy [E,3], dbase [E,H],
+ * dw3 [H,3] (overwritten, or added to with accumulate != 0).  H must be 256. */
+int faf_frame_pre_fwd(const float* y, const float* w3, const float* base, int64_t E, int32_t H, float* out, void* stream);
+size_t faf_frame_pre_bwd_workspace_bytes(int64_t E, int32_t H);
+int faf_frame_pre_bwd(const float* y, const float* w3, const float* dpre, int64_t E, int32_t H, float* dy, float* dbase,
+                      float* dw3, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at

@@ -1028,6 +1028,29 @@ def test_faformer_elementwise_kernels():
                                atol=1e-7, rtol=1e-6)
 
 
+def test_frame_pre_matches_float64_reference():
+    """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
+    dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
+    ops = _ops()
+    from equihgnn_amd.faformer import _sign_ops
+    g = torch.Generator().manual_seed(9)
+    for base_shape in ((70, 5, 256), (256,)):
+        y, w3, base = torch.randn(70, 5, 3, generator=g), torch.randn(256, 3, generator=g), torch.randn(*base_shape, generator=g)
+        wo = torch.randn(70, 5, 8, 256, generator=g)
+        t = [z.double().requires_grad_(True) for z in (y, w3, base)]
+        s = _sign_ops("cpu", torch.float64)
+        b = t[2] if len(base_shape) == 1 else t[2].unsqueeze(-2)
+        ref = torch.nn.functional.linear(t[0].unsqueeze(-2) * s, t[1]) + b
+        (ref * wo.double()).sum().backward()
+        d = [z.to(DEV).requires_grad_(True) for z in (y, w3, base)]
+        out = ops.frame_pre(d[0], d[1], d[2])
+        (out * wo.to(DEV)).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=1e-5, rtol=1e-5)
+        for a, r in zip(d, t):
+            err = float((a.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max())
+            assert err < 2e-5, (base_shape, tuple(a.shape), err)
+
+
 def test_eigh3_matches_lapack_up_to_sign():
     ops = _ops()
     g = torch.Generator().manual_seed(0)
