@@ -60,8 +60,13 @@ class SwiGLUMLP(nn.Module):
         a, b = pre.chunk(2, dim=-1)
         return _layer_norm(self.norm, F.dropout(F.silu(a) * b, self.p, self.training))
 
+    def _fc2(self, h):
+        if h.is_cuda:   # weight / bias gradients accumulate in place (ops._Linear), the bias sum is the row kernel
+            return ops.linear(h, self.fc2.weight, self.fc2.bias)
+        return self.fc2(h)
+
     def forward(self, x):
-        return F.dropout(self.fc2(self.hidden(self.fc1(x))), self.p, self.training)
+        return F.dropout(self._fc2(self.hidden(self.fc1(x))), self.p, self.training)
 
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
@@ -76,11 +81,11 @@ class SwiGLUMLP(nn.Module):
             pre = pre + (base if extra is None else base.unsqueeze(-2))
         h = self.hidden(pre)                                               # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
-            out = self.fc2(h)
+            out = self._fc2(h)
             if out.is_cuda and out.dtype == torch.float32 and out.shape[-1] % 4 == 0:
                 return ops.dropout_mean(out, self.p)                       # dropout + frame average, one pass
             return F.dropout(out, self.p, True).mean(-2)
-        return self.fc2(h.mean(-2))
+        return self._fc2(h.mean(-2))
 
 
 def _frame_axes(x, mask=None):

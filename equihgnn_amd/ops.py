@@ -751,8 +751,8 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None, scale: float = 1.0):
     """scale * sum_r w_r x[r, :] for a 2-D fp32 matrix through hg_colsum_f32 (bias gradients).  ``rowptr`` +
     ``weight_mode`` (1: [row non-empty], 2: row length) give the row weights; ``into`` is an accumulator
     the result is ADDED to (returns None then)."""
-    if not x.is_cuda or x.shape[-1] % 4 or x.dtype != torch.float32:
-        # widths the float4 kernel does not take (the 1-wide output head): the device's generic reduction
+    if not x.is_cuda or x.shape[-1] % 4 or x.dtype != torch.float32 or x.shape[0] > 2_000_000:
+        # widths the float4 kernel does not take (and row counts past its 65 535-chunk grid) (the 1-wide output head): the device's generic reduction
         if weight_mode:
             deg = rowptr[1:] - rowptr[:-1]
             x = x * ((deg > 0) if weight_mode == 1 else deg).to(x.dtype)[:, None]
@@ -842,7 +842,7 @@ DEFER_WGRAD = True            # batched weight gradients at defer_flush
 
 def _wgrad_shape_ok(dy2, x2):
     return (dy2.is_cuda and dy2.dtype == torch.float32 and x2.dtype == torch.float32
-            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and dy2.shape[0] >= 512)
+            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and 512 <= dy2.shape[0] <= 131072)
 
 
 def _wgrad_ok(dy2, x2):
