@@ -35,7 +35,11 @@ k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float*
     const int wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const int wave_stride = gridDim.x * waves_per_block;
     const int n_groups = (N + QPW - 1) / QPW;
-    for (int grp = wave0; grp < n_groups; grp += wave_stride) {
+    // the LAST queries first: a padded batch parks its padding atoms at the end of the cloud and far away from it,
+    // where every real atom is a near-tie candidate (many list insertions); started last, those few long-running
+    // wavefronts were the tail of the launch
+    for (int g_ = wave0; g_ < n_groups; g_ += wave_stride) {
+        const int grp = n_groups - 1 - g_;
         const int i0 = grp * QPW;
         float qx[QPW], qy[QPW], qz[QPW], ld[QPW], tau[QPW];
         int li[QPW];
