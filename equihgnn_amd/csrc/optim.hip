@@ -24,11 +24,16 @@ __global__ void __launch_bounds__(256)
 k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
        const float* __restrict__ lr_ptr, float beta1, float beta2, float eps, float wd, float gscale,
        AdamState* __restrict__ st) {
-    const float t = (float)(st->step + 1);
-    const float lr = *lr_ptr;
-    const float bc1 = 1.0f - powf(beta1, t);
-    const float bc2_sqrt = sqrtf(1.0f - powf(beta2, t));
-    const float step_size = lr / bc1;
+    // the bias corrections once per workgroup (two powf per THREAD were most of the kernel's instructions)
+    __shared__ float s_corr[2];
+    if (threadIdx.x == 0) {
+        const float t = (float)(st->step + 1);
+        s_corr[0] = *lr_ptr / (1.0f - powf(beta1, t));
+        s_corr[1] = sqrtf(1.0f - powf(beta2, t));
+    }
+    __syncthreads();
+    const float step_size = s_corr[0];
+    const float bc2_sqrt = s_corr[1];
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
