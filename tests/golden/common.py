@@ -60,9 +60,144 @@ def fill_state_dict(model: torch.nn.Module, seed: int) -> None:
     model.load_state_dict(new, strict=True)
 
 
+# ------------------------------------------------------------------------------------------
+# the cases: ONE table shared by the generator (make_golden.py) and the tests.  A case's inputs are
+# a pure function of its row (this repo's own synthetic generator, no reference involved), so
+# tests/test_golden_inputs.py re-derives them and compares them with what the .npz files hold.
+# ------------------------------------------------------------------------------------------
+# name: (method, hidden, seed, n_mols, train_mode, store_grads, options)
+#   options: flavour ("qm9" | "pcqm"); last_conj (the last molecule is forced to carry a conjugated
+#   hyperedge: the reference's mhnn / egnn_equihnn crash otherwise, mhnn.py:72-73 -- the six first-written
+#   fixture families predate that rule and keep their frozen generator); big (atoms of one extra-large
+#   molecule, PCQM4Mv2 / Molecule3D go up to ~60 heavy+H atoms); geometry ("degenerate": coincident atoms,
+#   an edge along exactly -y, edges within 1e-3 rad of -y: equiformer/basis.py:169-191); dropout0 (FAFormer's
+#   0.1 dropouts, active in training mode whatever --dropout says, forced to 0 so that a TRAIN-mode fixture
+#   is deterministic); depth (Equiformer depth, for the type-1 path).
+CASE_TABLE = {
+    "mhnnm_c64_train": ("mhnnm", 64, 11, 6, True, True, dict(last_conj=False)),
+    "mhnnm_c64_eval": ("mhnnm", 64, 12, 5, False, True, dict(last_conj=False)),
+    "mhnnm_c256_train": ("mhnnm", 256, 13, 4, True, False, dict(last_conj=False)),
+    "egnn_equihnns_c64": ("egnn_equihnns", 64, 21, 6, True, True, dict(last_conj=False)),
+    "egnn_equihnns_c64_b": ("egnn_equihnns", 64, 22, 10, True, True, dict(last_conj=False)),
+    "egnn_equihnns_c256": ("egnn_equihnns", 256, 23, 5, True, False, dict(last_conj=False)),
+    "mhnn_c64": ("mhnn", 64, 41, 6, True, True, {}),
+    "mhnns_c64": ("mhnns", 64, 42, 6, True, True, {}),
+    "egnn_equihnn_c64": ("egnn_equihnn", 64, 43, 6, True, True, {}),
+    "egnn_equihnnm_c64": ("egnn_equihnnm", 64, 44, 6, True, True, {}),
+    "faformer_equihnns_c64": ("faformer_equihnns", 64, 51, 6, False, True, {}),
+    "faformer_equihnns_c64_b": ("faformer_equihnns", 64, 52, 3, False, True, {}),
+    "faformer_equihnns_c256": ("faformer_equihnns", 256, 53, 2, False, False, {}),
+    "equiformer_equihnns_c64": ("equiformer_equihnns", 64, 31, 6, True, True, dict(last_conj=False)),
+    "equiformer_equihnns_c64_b": ("equiformer_equihnns", 64, 32, 3, True, True, dict(last_conj=False)),
+    "equiformer_equihnns_c256": ("equiformer_equihnns", 256, 33, 2, True, False, dict(last_conj=False)),
+    # round 2: the PCQM4Mv2-like / Molecule3D-like workloads of BASELINE configs 4 and 5
+    "egnn_equihnns_pcqm_c64": ("egnn_equihnns", 64, 61, 6, True, True, dict(flavour="pcqm", big=44)),
+    "egnn_equihnns_pcqm_c256": ("egnn_equihnns", 256, 62, 4, True, False, dict(flavour="pcqm", big=52)),
+    "faformer_equihnns_pcqm_c64": ("faformer_equihnns", 64, 63, 6, False, True, dict(flavour="pcqm", big=44)),
+    "faformer_equihnns_pcqm_c256": ("faformer_equihnns", 256, 64, 3, False, False, dict(flavour="pcqm", big=41)),
+    "mhnnm_pcqm_c64_train": ("mhnnm", 64, 65, 6, True, True, dict(flavour="pcqm", big=44)),
+    "equiformer_equihnns_pcqm_c64": ("equiformer_equihnns", 64, 66, 4, True, True, dict(flavour="pcqm", big=41)),
+    # FAFormer in TRAINING mode with its dropouts forced to p = 0
+    "faformer_equihnns_c64_train_p0": ("faformer_equihnns", 64, 67, 5, True, True, dict(dropout0=True)),
+    # degenerate edge geometry for the Equiformer's D construction
+    "equiformer_equihnns_c64_degenerate": ("equiformer_equihnns", 64, 68, 5, True, True, dict(geometry="degenerate")),
+}
+
+
+def case_spec(name: str) -> dict:
+    method, hidden, seed, n_mols, train, store, opt = CASE_TABLE[name]
+    spec = dict(name=name, method=method, hidden=hidden, seed=seed, n_mols=n_mols, train=train, store_grads=store,
+                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1)
+    spec.update(opt)
+    return spec
+
+
+def degenerate_positions(pos: np.ndarray, batch: np.ndarray) -> np.ndarray:
+    """Edit a batch's coordinates so that the Equiformer's neighbour graph contains the cases
+    rot_x_to_y_direction treats specially (equiformer/basis.py:169-191): two coincident atoms (rel_pos = 0),
+    one edge along exactly -y (and its reverse, exactly +y), and edges 2e-4 .. 9e-4 rad away from -y, inside
+    the |x_hat + y_hat|^2 < 1e-6 clamp.  Deterministic; atoms 1.. of molecule 0 and 1 are moved."""
+    pos = pos.copy()
+    first = lambda b: int(np.flatnonzero(batch == b)[0])
+    a = first(0)
+    pos[a + 1] = pos[a]                                                  # coincident pair
+    pos[a + 3] = pos[a + 2] + np.array([0.0, -1.25, 0.0], np.float32)    # exactly along -y (x, z bit-equal)
+    c = first(1)
+    pos[c + 1] = pos[c] + np.array([3.0e-4, -1.3, 2.0e-4], np.float32)   # s = |x_hat + y_hat|^2 ~ 7.7e-8
+    pos[c + 3] = pos[c + 2] + np.array([-6.0e-4, -1.2, 4.0e-4], np.float32)   # s ~ 3.6e-7 (largest deviation)
+    pos[c + 5] = pos[c + 4] + np.array([9.0e-4, -1.1, -6.0e-4], np.float32)   # s ~ 9.7e-7 (just inside)
+    return pos.astype(np.float32)
+
+
+def make_batch(spec_or_seed, n_mols=None, flavour="qm9", with_isolated=True, last_conj=True, big=None,
+               geometry=None):
+    """The synthetic batch of a case: seeded molecules (equihgnn_amd.batch.synth_molecule), molecule 0 with a
+    conjugated hyperedge of order >= 3, an isolated one-atom molecule in the middle, optionally one large
+    molecule and the degenerate-geometry edit."""
+    from equihgnn_amd.batch import collate, synth_molecule
+
+    if isinstance(spec_or_seed, dict):
+        sp = spec_or_seed
+        seed, n_mols, flavour, last_conj, big, geometry = (sp["seed"], sp["n_mols"], sp["flavour"], sp["last_conj"],
+                                                           sp["big"], sp["geometry"])
+    else:
+        seed = spec_or_seed
+    rng = np.random.default_rng(seed)
+    mols = [synth_molecule(rng, flavour) for _ in range(n_mols)]
+    mols[0] = synth_molecule(rng, flavour, n_atoms=9, force_conj=True)  # conj hyperedge, order>=3
+    if last_conj:
+        # the reference's mhnn / egnn_equihnn fail unless the LAST molecule has a hyperedge of order > 2
+        mols[-1] = synth_molecule(rng, flavour, force_conj=True)
+    if with_isolated:
+        lone = synth_molecule(rng, flavour, n_atoms=3, force_conj=False)
+        # a one-atom, zero-hyperedge molecule: its node row has no incidence at all
+        lone.x, lone.pos = lone.x[:1], np.zeros((1, 3), np.float32) + 0.25
+        lone.edge_index0 = lone.edge_index0[:0]
+        lone.edge_index1 = lone.edge_index1[:0]
+        lone.edge_attr = lone.edge_attr[:0]
+        lone.e_order = lone.e_order[:0]
+        mols.insert(n_mols // 2, lone)
+    if big:
+        mols[1] = synth_molecule(rng, flavour, n_atoms=int(big), force_conj=True)
+    out = collate(mols)
+    if geometry == "degenerate":
+        out.pos = torch.from_numpy(degenerate_positions(out.pos.numpy(), out.batch.numpy()))
+    elif geometry is not None:
+        raise ValueError(geometry)
+    return out
+
+
+def zero_dropouts(model: torch.nn.Module) -> None:
+    """Force every dropout probability inside a model to 0 (nn.Dropout modules in the reference and the oracle,
+    the ``p`` / ``attn_drop`` attributes of this repo's FAFormer)."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        else:
+            for attr in ("p", "attn_drop"):
+                if isinstance(getattr(m, attr, None), float):
+                    setattr(m, attr, 0.0)
+
+
+def assert_close(got, ref, tol=1e-5, what=""):
+    """The north_star tolerance, element by element: |got - ref| <= tol * max(1, |ref|) -- ABSOLUTE 1e-5 wherever
+    |ref| <= 1, the same relative budget above."""
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    if got.size == 0:
+        return
+    err = np.abs(got - ref) / np.maximum(1.0, np.abs(ref))
+    worst = int(np.argmax(err))
+    assert float(err.reshape(-1)[worst]) <= tol, (
+        f"{what}: |got - ref| / max(1, |ref|) = {err.reshape(-1)[worst]:.3e} > {tol:g} at flat index {worst} "
+        f"(got {got.reshape(-1)[worst]:.8g}, ref {ref.reshape(-1)[worst]:.8g})")
+
+
 def load_case(name: str) -> dict:
     with np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False) as z:
-        return {k: z[k] for k in z.files}
+        case = {k: z[k] for k in z.files}
+    case["meta_name"] = np.array(name)      # (not stored: the file name is the case name)
+    return case
 
 
 def batch_from_case(case: dict):

@@ -27,9 +27,10 @@ REF = os.environ.get("EQUIHGNN_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
-from common import fill_state_dict, golden_args  # noqa: E402
+from common import (CASE_TABLE, case_spec, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
+                    zero_dropouts)
 
-from equihgnn_amd.batch import ATOM_FEATURE_DIMS, collate, synth_molecule  # noqa: E402
+from equihgnn_amd.batch import ATOM_FEATURE_DIMS  # noqa: E402
 
 
 # ------------------------------------------------------------------------------------------
@@ -181,34 +182,19 @@ def import_reference(names=("equihnn_egnn", "mhnn")):
 
 
 # ------------------------------------------------------------------------------------------
-# cases
+# cases (the table, the batch generator and its options live in common.py: the tests re-derive the inputs)
 # ------------------------------------------------------------------------------------------
-def make_batch(seed, n_mols, flavour="qm9", with_isolated=True):
-    rng = np.random.default_rng(seed)
-    mols = [synth_molecule(rng, flavour) for _ in range(n_mols)]
-    mols[0] = synth_molecule(rng, flavour, n_atoms=9, force_conj=True)  # conj hyperedge, order>=3
-    # the reference's mhnn / egnn_equihnn fail unless the LAST molecule has a hyperedge of order > 2
-    mols[-1] = synth_molecule(rng, flavour, force_conj=True)
-    if with_isolated:
-        lone = synth_molecule(rng, flavour, n_atoms=3, force_conj=False)
-        # a one-atom, zero-hyperedge molecule: its node row has no incidence at all
-        lone.x, lone.pos = lone.x[:1], np.zeros((1, 3), np.float32) + 0.25
-        lone.edge_index0 = lone.edge_index0[:0]
-        lone.edge_index1 = lone.edge_index1[:0]
-        lone.edge_attr = lone.edge_attr[:0]
-        lone.e_order = lone.e_order[:0]
-        mols.insert(n_mols // 2, lone)
-    return collate(mols)
-
-
-def run_case(registry, method, hidden, seed, n_mols, train_mode=True, store_grads=True,
-             flavour="qm9"):
+def run_case(registry, spec):
+    method, hidden, seed, train_mode, store_grads = (spec["method"], spec["hidden"], spec["seed"], spec["train"],
+                                                     spec["store_grads"])
     torch.manual_seed(0)
     args = golden_args(method, hidden)
     model = registry.get_model_class(method)(1, args)
     fill_state_dict(model, seed)
     model.train(train_mode)
-    data = make_batch(seed, n_mols, flavour)
+    if spec["dropout0"]:
+        zero_dropouts(model)
+    data = make_batch(spec)
 
     taps = {}
     hooks = []
@@ -293,50 +279,76 @@ def run_case(registry, method, hidden, seed, n_mols, train_mode=True, store_grad
     return case
 
 
-CASES = [
-    # name, method, hidden, seed, n_mols, train_mode, store_grads
-    ("mhnnm_c64_train", "mhnnm", 64, 11, 6, True, True),
-    ("mhnnm_c64_eval", "mhnnm", 64, 12, 5, False, True),
-    ("mhnnm_c256_train", "mhnnm", 256, 13, 4, True, False),
-    ("egnn_equihnns_c64", "egnn_equihnns", 64, 21, 6, True, True),
-    ("egnn_equihnns_c64_b", "egnn_equihnns", 64, 22, 10, True, True),
-    ("egnn_equihnns_c256", "egnn_equihnns", 256, 23, 5, True, False),
-    ("mhnn_c64", "mhnn", 64, 41, 6, True, True),
-    ("mhnns_c64", "mhnns", 64, 42, 6, True, True),
-    ("egnn_equihnn_c64", "egnn_equihnn", 64, 43, 6, True, True),
-    ("egnn_equihnnm_c64", "egnn_equihnnm", 64, 44, 6, True, True),
-    ("faformer_equihnns_c64", "faformer_equihnns", 64, 51, 6, False, True),
-    ("faformer_equihnns_c64_b", "faformer_equihnns", 64, 52, 3, False, True),
-    ("faformer_equihnns_c256", "faformer_equihnns", 256, 53, 2, False, False),
-    ("equiformer_equihnns_c64", "equiformer_equihnns", 64, 31, 6, True, True),
-    ("equiformer_equihnns_c64_b", "equiformer_equihnns", 64, 32, 3, True, True),
-    ("equiformer_equihnns_c256", "equiformer_equihnns", 256, 33, 2, True, False),
-]
+def d_fixture():
+    """Known-answer vectors for the D construction alone (equiformer/basis.py:194-215): crafted rel_pos rows --
+    generic directions, the axes, exactly -y, rows inside the |x_hat + y_hat|^2 < 1e-6 clamp on a log scale of
+    deviations, a zero vector, tiny and huge norms -- and the reference's D[1] for them."""
+    basis = importlib.import_module("equihgnn.models.layers.equiformer.basis")
+    g = np.random.default_rng(77)
+    rows = [g.standard_normal(3) for _ in range(24)]
+    rows += [np.array(v, float) for v in ([1, 0, 0], [0, 1, 0], [0, 0, 1], [-1, 0, 0], [0, -1, 0], [0, 0, -1],
+                                          [0, -2.5, 0], [0, 0, 0], [1e-12, -3e-12, 2e-12], [3e3, -1e3, 2e3])]
+    for dev in (1e-5, 3e-5, 1e-4, 2e-4, 3e-4, 4e-4, 5e-4, 5.8e-4, 7e-4, 9e-4, 9.9e-4, 1.01e-3, 1.2e-3, 2e-3, 1e-2):
+        phi = g.uniform(0, 2 * np.pi)
+        rows.append(np.array([dev * np.cos(phi), -1.0, dev * np.sin(phi)]) * g.uniform(0.8, 3.0))
+    rel = torch.tensor(np.stack(rows), dtype=torch.float32)[None, :, None, :]      # [1, E, 1, 3], as at :1346
+    D = basis.get_D_to_from_z_axis(rel, 1)[1]
+    return {"rel_pos": rel.reshape(-1, 3).numpy(), "D1": D.reshape(-1, 3, 3).numpy()}
 
 
-def main(only=None):
-    torch.set_num_threads(8)
-    methods = {c[1] for c in CASES if only is None or c[0] in only}
+def compare(case, stored, name):
+    bad = []
+    for k in sorted((set(case) | set(stored)) - {"meta_name"}):
+        if k not in case or k not in stored:
+            bad.append(f"{k}: only on one side")
+        elif np.asarray(case[k]).dtype.kind in "US":
+            if str(case[k]) != str(stored[k]) and not np.array_equal(case[k], stored[k]):
+                bad.append(f"{k}: differs")
+        elif np.asarray(case[k]).shape != stored[k].shape or not np.array_equal(np.asarray(case[k]), stored[k]):
+            bad.append(f"{k}: differs (max |d| = "
+                       f"{np.abs(np.asarray(case[k], float) - stored[k].astype(float)).max() if np.asarray(case[k]).shape == stored[k].shape else 'shape'})")
+    print(f"{name}: " + ("identical to the committed file" if not bad else "DIFFERS: " + "; ".join(bad[:6])))
+    return not bad
+
+
+def main(only=None, check=False):
+    # one thread and deterministic kernels: the multi-threaded CPU backward sums gradient contributions in a
+    # run-dependent order (differences of 1e-8), and `--check` compares the regenerated arrays bit for bit
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+    names = [n for n in CASE_TABLE if only is None or n in only]
+    methods = {CASE_TABLE[n][0] for n in names}
     mods = []
     if methods & {"mhnnm", "mhnn", "mhnns"}:
         mods.append("mhnn")
     if methods & {"egnn_equihnns", "egnn_equihnn", "egnn_equihnnm"}:
         mods.append("equihnn_egnn")
-    if "equiformer_equihnns" in methods:
+    if "equiformer_equihnns" in methods or (only is None or "equiformer_D" in only):
         mods.append("equihnn_equiformer")
     if "faformer_equihnns" in methods:
         mods.append("equihnn_fa_former")
     registry = import_reference(tuple(mods))
-    for name, method, hidden, seed, n_mols, train_mode, store in CASES:
-        if only is not None and name not in only:
-            continue
-        case = run_case(registry, method, hidden, seed, n_mols, train_mode, store)
+    ok = True
+    for name in names:
+        case = run_case(registry, case_spec(name))
         path = os.path.join(HERE, name + ".npz")
+        if check:
+            ok &= compare(case, load_case(name), name)
+            continue
         np.savez_compressed(path, **case)
         print(f"{name}: N={case['in_x'].shape[0]} M={case['in_edge_attr'].shape[0]} "
               f"nnz={case['in_edge_index0'].shape[0]} out[:3]={case['out'][:3]} "
               f"loss={float(case['loss']):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+    if only is None or "equiformer_D" in only:
+        case = d_fixture()
+        if check:
+            ok &= compare(case, load_case("equiformer_D"), "equiformer_D")
+        else:
+            np.savez_compressed(os.path.join(HERE, "equiformer_D.npz"), **case)
+            print(f"equiformer_D: {case['rel_pos'].shape[0]} rows")
+    return ok
 
 
 if __name__ == "__main__":
-    main(set(sys.argv[1:]) or None)
+    argv = [a for a in sys.argv[1:] if a != "--check"]
+    sys.exit(0 if main(set(argv) or None, check="--check" in sys.argv) else 1)
