@@ -66,9 +66,13 @@ def parse():
     p.add_argument("--batch", type=int, default=256, help="molecules per rank per step")
     p.add_argument("--flavour", default="qm9")
     p.add_argument("--pool", type=int, default=8, help="distinct pre-collated batches per rank")
+    p.add_argument("--c4-steps", type=int, default=10,
+                   help="timed steps of the strong-scaling BASELINE config 4 leg (PCQM-like, global batch 1024); 0 = skip")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--timeline-replays", type=int, default=30,
+                   help="replays of the time-stamped graph that `roofline` averages over")
     p.add_argument("--wgrad-side-stream", action="store_true",
                    help="issue weight-gradient GEMMs on a second stream (parallel graph branch)")
     p.add_argument("--no-graph", action="store_true",
@@ -94,10 +98,91 @@ def seg_reduce_bytes(nnz, n_out, C, has_idx, has_ptr, has_w, n_src):
     return b
 
 
+SCATTER_KERNELS = ("k_segment_reduce", "k_segment_reduce<weighted>", "k_inc_fwd", "k_inc_bwd_both")
+
+
+def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
+    """In-graph durations of the hand-written aggregation kernels of ONE real training step, measured live: the
+    step is captured into a hipGraph exactly as in the timed run, with device-side time stamps (eqh_stamp, one-thread
+    kernels storing the 100 MHz wall clock) around every launch of k_segment_reduce / k_inc_fwd / k_inc_bwd_both and
+    the EGNN edge kernels; the graph is replayed `replays` times and the stamps are read after each replay.  HIP
+    events cannot do this -- launches inside a replayed graph are invisible to the launching stream.  A bracket
+    contains the kernel plus one launch slot; four back-to-back stamp pairs at the head of the graph measure that slot
+    and it is subtracted.  The rocprofv3 --kernel-trace --stats summary of this same command is in profiles/."""
+    from equihgnn_amd import ops
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+
+    ns = default_args(method=method, batch_size=batch_size)
+    torch.manual_seed(0)
+    model = MODELS[method](1, ns).to(dev)
+    host = synth_batch(batch_size, seed, flavour)
+    b = pad_batch(host, *bucket_sizes(host.num_nodes, host.num_hyperedges, host.nnz)).packed().to(dev)
+    b.num_real_graphs = batch_size
+    tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
+    tr.step(b)                                   # eager bootstrap
+    tl = ops.Timeline(dev)
+    ops.TIMELINE = tl
+    try:
+        tr.step(b)                               # capture (stamps included) + first replay
+    finally:
+        ops.TIMELINE = None
+    acc = {}
+    for _ in range(replays):
+        tr.step(b)
+        torch.cuda.synchronize(dev)
+        for i, (name, work, us) in enumerate(tl.read_us()):
+            acc.setdefault(i, [name, work, 0.0])[2] += us / replays
+    tr.close()
+    rows = [acc[i] for i in sorted(acc)]
+    slot = [r[2] for r in rows if r[0] == "stamp_pair"]
+    floor = sum(slot) / max(len(slot), 1)
+    per = {}
+    for name, work, us in rows:
+        if name == "stamp_pair":
+            continue
+        d = per.setdefault(name, {"launches_per_step": 0, "work": 0, "us": 0.0})
+        d["launches_per_step"] += 1
+        d["work"] += work
+        d["us"] += max(us - floor, 0.05)
+    return per, floor
+
+
+def scatter_roofline(per, floor):
+    """`roofline` of the bench line: the HBM-bound node<->hyperedge aggregation kernels as they run inside the
+    replayed training step: algorithmic bytes (formulas in DESIGN.md §4) / in-graph time."""
+    kernels = {}
+    tot_b = tot_us = 0.0
+    n = 0
+    for name in SCATTER_KERNELS:
+        d = per.get(name)
+        if not d:
+            continue
+        gbs = d["work"] / d["us"] / 1e3
+        kernels[name] = {"launches_per_step": d["launches_per_step"],
+                         "avg_launch_us": round(d["us"] / d["launches_per_step"], 2),
+                         "alg_bytes_per_launch": int(d["work"] / d["launches_per_step"]),
+                         "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        tot_b += d["work"]
+        tot_us += d["us"]
+        n += d["launches_per_step"]
+    achieved = tot_b / tot_us / 1e3 if tot_us > 0 else 0.0
+    return {"bound": "hbm", "kernel": "scatter kernels inside the replayed step: " + " + ".join(kernels),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "launches_per_step": n, "avg_launch_us": round(tot_us / max(n, 1), 2),
+            "alg_bytes_per_launch": int(tot_b / max(n, 1)),
+            "method": "device time stamps around each launch inside the hipGraph, averaged over replays; "
+                      f"launch slot {floor:.2f} us (stamp pair) subtracted",
+            "kernels": kernels}
+
+
 def measure_scatter_roofline(model, batch, dev):
-    """Record every hg_segment_reduce_f32 launch of one training step, then replay each launch
-    behind a busy prefix (so the queue is GPU-bound) bracketed by HIP events on the launching
-    stream.  Returns the roofline dict for that kernel."""
+    """The scatter kernel alone, warm and back to back (NOT the in-step figure: see measure_in_graph): every
+    hg_segment_reduce_f32 launch of one training step is recorded, then replayed 20x behind a busy prefix between
+    HIP events on the launching stream.  Kept as `roofline.back_to_back` for comparison with round 1."""
     from equihgnn_amd import hip, ops
 
     calls = []
@@ -143,10 +228,9 @@ def measure_scatter_roofline(model, batch, dev):
     n = max(len(calls), 1)
     avg_ms = tot_ms / n
     achieved = (tot_bytes / n) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    return {"bound": "hbm", "kernel": "k_segment_reduce (hg_segment_reduce_f32)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "launches_per_step": len(calls), "avg_launch_us": round(avg_ms * 1e3, 2),
+    return {"kernel": "k_segment_reduce (hg_segment_reduce_f32), eager launches of one step replayed back to back",
+            "achieved": round(achieved, 1), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "launches": len(calls), "avg_launch_us": round(avg_ms * 1e3, 2),
             "alg_bytes_per_launch": int(tot_bytes / n)}
 
 
@@ -154,60 +238,10 @@ def measure_scatter_roofline(model, batch, dev):
 # with rocprofv3 on `python3 bench.py --only-roofline` at the BASELINE workload: profiles/r01_pmc_scatter_workload.json.
 # A bench run cannot collect counters itself; the figure is attached only to the workload it was measured on.
 PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 11706695}
+PMC_TRAFFIC_SOURCE = "profiles/r01_pmc_scatter_workload.json (rocprofv3 --pmc on k_segment_reduce, offline)"
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
-
-
-def measure_edge_kernels(batch, dev, hidden=256, reps=20):
-    """The other hand-written hot kernels of the step, the fused EGNN edge update (egnn_edge_fwd / _bwd),
-    timed live with HIP events on the batch's own neighbour graph.  FLOPs per launch:
-    forward N*16*Hp*(2*16 + 12), backward N*16*Hp*(3*2*16 + 40); they are bound by fp32 MFMA + VALU issue
-    (the fp32 MFMA shares the VALU pipe, profiles/r01_edge_fwd_notes.md), so the fraction of the MFMA peak
-    is an upper-bound style figure, not a bandwidth one."""
-    from equihgnn_amd import hip, ops
-    from equihgnn_amd.index import HyperIndex
-
-    batch._hyper_index = None
-    ix = HyperIndex.from_batch(batch)
-    nbr, d2, csr_t = ix.knn(batch.pos, 16, 0)
-    N = ix.N
-    H = 2 * (2 * hidden + 1)
-    Hp = H + (-H) % 64
-    g = torch.Generator(device=dev).manual_seed(0)
-    ab = torch.randn(N, 2 * Hp, device=dev, generator=g)
-    wd = torch.randn(Hp, device=dev, generator=g) * 0.1
-    w2 = torch.randn(16, Hp, device=dev, generator=g) / Hp ** 0.5
-    b2 = torch.zeros(16, device=dev)
-    m, pre2 = torch.empty(N, 16, device=dev), torch.empty(N, 16, 16, device=dev)
-    dm = torch.randn(N, 16, device=dev, generator=g)
-    dab, dwd, dw2, dpre2 = torch.empty_like(ab), torch.empty_like(wd), torch.empty_like(w2), torch.empty_like(pre2)
-    L, p, st = hip.lib(), ops._ptr, ops._stream(dev)
-    wsb = L.egnn_edge_bwd_workspace_bytes(N, Hp)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-    fwd = lambda: L.egnn_edge_fwd(p(ab), p(wd), p(w2), p(b2), p(nbr), p(d2), N, Hp, p(m), p(pre2), st)
-    bwd = lambda: L.egnn_edge_bwd(p(ab), p(wd), p(w2), p(nbr), p(d2), p(pre2), p(dm), 16, p(csr_t.rowptr), p(csr_t.perm),
-                                  N, Hp, p(dab), p(dwd), p(dw2), p(dpre2), None, 0, p(ws), wsb, st)
-    busy = torch.randn(4096, 4096, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    out = {}
-    for name, fn, flops in (("egnn_edge_fwd", fwd, N * 16 * Hp * (2 * 16 + 12)),
-                            ("egnn_edge_bwd", bwd, N * 16 * Hp * (3 * 2 * 16 + 40))):
-        fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.mm(busy, busy)
-        e0.record(stream)
-        for _ in range(reps):
-            fn()
-        e1.record(stream)
-        e1.synchronize()
-        us = e0.elapsed_time(e1) / reps * 1e3
-        tf = flops / us / 1e6
-        out[name] = {"us": round(us, 1), "flops": int(flops), "achieved": round(tf, 1), "unit": "TFLOP/s",
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
-    out["bound"] = "mfma"
-    out["nodes"], out["Hp"] = N, Hp
-    return out
 
 
 def saturation_probe(dev, log2_nodes=20, C=256, reps=10, seed=0):
@@ -301,11 +335,41 @@ def cpu_baseline(method, args_ns, batch_cpu, seconds):
                       f"{el:.1f} s"}
 
 
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through
+    torch.distributed.run, as the reference's Trainer(devices="auto", strategy="ddp...") does (main.py:271-283).
+    Runs BEFORE anything in this process touches the GPU (importing torch and counting devices does not), and as a
+    child process -- a process that has initialised HIP must never be replaced by exec."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()
+    shared = os.environ.get("EQH_BACKEND", "nccl") != "nccl"      # gloo rehearsal: ranks may share one device
+    if n_dev < a.gpus and not shared:
+        print(f"bench.py: --gpus {a.gpus} but only {n_dev} device(s) are visible", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // a.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -333,55 +397,82 @@ def main():
         from equihgnn_amd import ops as _ops
         _ops.WGRAD_ON_SIDE_STREAM = True
     args_ns = default_args(method=a.method, batch_size=a.batch)
-    torch.manual_seed(0)
-    model = MODELS[a.method](1, args_ns).to(dev)
-    cfg_id = 2
-    host_batches = [synth_batch(a.batch, cfg_id * 1000 + rank * 100 + i, a.flavour) for i in range(a.pool)]
     if a.only_roofline:
-        print(json.dumps({"roofline": measure_scatter_roofline(model, host_batches[0].to(dev), dev)}), flush=True)
+        per, floor = measure_in_graph(a.method, a.batch, a.flavour, dev, a.timeline_replays)
+        print(json.dumps({"roofline": scatter_roofline(per, floor), "all_kernels_us": {k: round(v["us"], 2) for k, v in per.items()}}),
+              flush=True)
         return
-    # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
-    # largest one (one dummy molecule owns the padding; exact for the LayerNorm models, and for the
-    # BatchNorm ones because their statistics count the real atoms only).
     use_graph = (not a.no_graph) and a.method not in _EAGER_METHODS
-    if use_graph:
-        ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host_batches]
-        tgt = tuple(max(e[i] for e in ext) for i in range(3))
-        batches = [pad_batch(b, *tgt).packed().to(dev) for b in host_batches]   # one staging buffer per batch
-        for b in batches:
-            b.num_real_graphs = a.batch
-        trainer = GraphedTrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
-    else:
-        batches = [b.to(dev) for b in host_batches]
-        trainer = TrainStep(model, lr=args_ns.lr, weight_decay=args_ns.wd)
 
-        def fresh(b):  # every step sees a "new" batch: the index (CSR sort, kNN) is rebuilt
-            b._hyper_index = None
+    def timed_run(method, batch, flavour, steps, warmup, cfg_id):
+        """K timed steps of one workload on this rank (barrier + synchronize on both sides, MAX over ranks)."""
+        ns = default_args(method=method, batch_size=batch)
+        torch.manual_seed(0)
+        model = MODELS[method](1, ns).to(dev)
+        host = [synth_batch(batch, cfg_id * 1000 + rank * 100 + i, flavour) for i in range(a.pool)]
+        # hipGraph replay needs static shapes: the collate stage pads every batch to the bucket of the
+        # largest one (one dummy molecule owns the padding; exact for the LayerNorm models, and for the
+        # BatchNorm ones because their statistics count the real atoms only).
+        if use_graph:
+            ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz) for b in host]
+            tgt = tuple(max(e[i] for e in ext) for i in range(3))
+            if world > 1:   # every rank pads to the same bucket (one capture shape per job, like one DDP bucket plan)
+                tt = torch.tensor(tgt, dtype=torch.int64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tgt = tuple(int(v) for v in tt.tolist())
+            batches = [pad_batch(b, *tgt).packed().to(dev) for b in host]   # one staging buffer per batch
+            for b in batches:
+                b.num_real_graphs = batch
+            trainer = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
+            # set-up, not warm-up: the eager bootstrap step (lays out the flat buffers, tunes unseen GEMM shapes)
+            # and the capture step, so that the W warm-up and K timed steps below are all graph replays whatever W is
+            for i in range(2):
+                trainer.step(batches[i % a.pool])
+        else:
+            batches = [b.to(dev) for b in host]
+            trainer = TrainStep(model, lr=ns.lr, weight_decay=ns.wd)
 
-        trainer.on_batch = fresh
-    if use_graph:
-        # set-up, not warm-up: the eager bootstrap step (lays out the flat buffers, tunes unseen GEMM shapes)
-        # and the capture step, so that the W warm-up and K timed steps below are all graph replays whatever W is
-        for i in range(2):
+            def fresh(b):  # every step sees a "new" batch: the index (CSR sort, kNN) is rebuilt
+                b._hyper_index = None
+
+            trainer.on_batch = fresh
+        for i in range(warmup):
             trainer.step(batches[i % a.pool])
-    for i in range(a.warmup):
-        trainer.step(batches[i % a.pool])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = trainer.step(batches[i % a.pool])
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = trainer.step(batches[i % a.pool])
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return {"el": float(t.item()), "loss": float(loss), "host": host, "batches": batches, "model": model,
+                "trainer": trainer, "args": ns}
+
+    run = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2)
+    el, loss, host_batches, batches, model = run["el"], run["loss"], run["host"], run["batches"], run["model"]
+    run_args = run["args"]
+    observed_world = dist.get_world_size() if world > 1 else 1      # what the (RCCL) process group reports
+    assert observed_world == a.gpus, (observed_world, a.gpus)
+
+    # BASELINE config 4 as a STRONG-scaling point: PCQM4Mv2-like molecules, global batch 1024 split over the ranks
+    # (SURVEY.md §8d), beside the weak-scaling headline above.  Reported inside the same JSON line.
+    strong = None
+    if a.method == "egnn_equihnns" and a.flavour == "qm9" and a.c4_steps > 0 and 1024 % world == 0:
+        del run
+        r4 = timed_run("egnn_equihnns", 1024 // world, "pcqm", a.c4_steps, 2, 4)
+        strong = {"workload": "PCQM4Mv2-like synthetic molecules, --method egnn_equihnns, GLOBAL batch 1024 "
+                              f"({1024 // world}/rank), hidden 256", "scaling": "strong", "n_gpus": observed_world,
+                  "steps": a.c4_steps, "value": round(1024 * a.c4_steps / r4["el"], 1), "unit": "molecules/s",
+                  "ms_per_step": round(r4["el"] / a.c4_steps * 1e3, 3), "final_loss": round(r4["loss"], 6)}
+        del r4
 
     result = None
     if rank == 0:
@@ -392,7 +483,7 @@ def main():
             else f"training molecules/sec ({a.method})",
             "value": round(world * a.batch * a.steps / el, 1),
             "unit": "molecules/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": observed_world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -402,20 +493,34 @@ def main():
                        "batch_per_rank": a.batch, "global_batch": a.batch * world,
                        "avg_nodes": round(n_nodes, 1), "avg_incidences": round(nnz, 1),
                        "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay (padded static shapes)" if use_graph else "eager"},
+                       "launch": "hipGraph replay (padded static shapes)" if use_graph else "eager",
+                       "collective": (f"one flat-gradient all-reduce per step, backend {dist.get_backend()}"
+                                      if world > 1 else "none (single rank)")},
             "final_loss": round(float(loss), 6),
         }
-        if not a.no_roofline:
-            result["roofline"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
+        if strong is not None:
+            result["strong_scaling_c4"] = strong
+        if not a.no_roofline and use_graph:
+            per, floor = measure_in_graph(a.method, a.batch, a.flavour, dev, a.timeline_replays)
+            result["roofline"] = scatter_roofline(per, floor)
             result["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH.get((a.method, a.batch, a.flavour))
             if result["roofline"]["traffic"] is not None:
-                result["roofline"]["traffic_source"] = "profiles/r01_pmc_scatter_workload.json (rocprofv3 --pmc, offline)"
+                result["roofline"]["traffic_source"] = PMC_TRAFFIC_SOURCE
+            edge = {}
+            for name in ("egnn_edge_fwd", "egnn_edge_bwd"):
+                if name in per:     # fp32 MFMA flops only (the SiLU / gather VALU work is not counted)
+                    tf = per[name]["work"] / per[name]["us"] / 1e6
+                    edge[name] = {"us": round(per[name]["us"], 1), "mfma_flops": int(per[name]["work"]), "achieved": round(tf, 1),
+                                  "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                  "where": "inside the replayed step"}
+            if edge:
+                edge["bound"] = "mfma"
+                result["roofline"]["edge_kernels"] = edge
             if world == 1:
+                result["roofline"]["back_to_back"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
                 result["roofline"]["saturation"] = saturation_probe(dev)
-                if a.method == "egnn_equihnns":
-                    result["roofline"]["edge_kernels"] = measure_edge_kernels(batches[0], dev)
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(a.method, args_ns, host_batches[0], a.cpu_seconds)
+            result["cpu_baseline"] = cpu_baseline(a.method, run_args, host_batches[0], a.cpu_seconds)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -183,7 +183,8 @@ def pad_batch(b: HBatch, n_nodes: int, n_hyperedges: int, n_inc: int) -> HBatch:
     so no aggregation ever visits them and the padded nodes / hyperedges have no incidences at all.
     (Spreading them over the few padded rows instead gave those rows 20-40 incidences each against 2-3
     for real rows, and the wavefront that owned them ran 10x longer than the rest of the launch: 112 us
-    for a backward kernel that needs 10.)  `HyperIndex` clamps the int32 gather copies to row 0."""
+    for a backward kernel that needs 10.)  `HyperIndex` keeps them at -1 in its int32 gather copies, which the row-gather
+    kernel reads as zero rows (zero gradient for null incidences on the unfused per-incidence path too)."""
     N, M, nnz, B = b.x.shape[0], b.edge_attr.shape[0], b.edge_index0.shape[0], b.y.shape[0]
     if n_nodes <= N or n_hyperedges <= M or n_inc < nnz:
         raise ValueError("pad_batch: target extents must exceed the batch (nodes and hyperedges strictly)")

@@ -163,7 +163,29 @@ extern "C" int eqh_defer_flush(void* stream_) {
     return EQH_OK;
 }
 
-extern "C" int eqh_version(void) { return 1; }
+// Device-side time stamps for measuring kernels INSIDE a replayed hipGraph (where HIP events on the launching
+// stream see nothing): a one-thread kernel stores the constant-rate wall clock.  Two stamps around a launch give
+// its in-graph duration plus one launch slot, which a back-to-back pair of stamps calibrates (bench.py).
+namespace {
+__global__ void eqh_k_stamp(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+
+extern "C" int eqh_stamp(void* slot, void* stream_) {
+    if (!slot) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(eqh_k_stamp, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_),
+                       static_cast<unsigned long long*>(slot));
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int64_t eqh_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return -1;
+    return khz;
+}
+
+extern "C" int eqh_version(void) { return 2; }
 
 extern "C" const char* eqh_error_string(int code) {
     switch (code) {

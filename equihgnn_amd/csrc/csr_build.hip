@@ -366,7 +366,8 @@ __global__ void __launch_bounds__(LONG_THREADS) k_sort_long_batch(Batch b) {
 
 // per-batch index vectors every layer reads, in ONE launch (the torch expressions they replace were 13
 // elementwise launches per step): int32 copies of the incidence coordinates and of `batch` (null
-// incidences, -1, clamped to row 0) and the 0/1 "row has an incidence" masks of both CSRs
+// incidences stay -1: hg_segment_reduce_f32 reads a negative index as a zero row, and every other consumer
+// walks CSR rows, which never list them) and the 0/1 "row has an incidence" masks of both CSRs
 __global__ void k_index_aux(const int64_t* __restrict__ vertex, const int64_t* __restrict__ edges, int64_t nnz,
                             const int64_t* __restrict__ batch, int64_t n_nodes, int64_t n_edges,
                             const int* __restrict__ rowptr_v, const int* __restrict__ rowptr_e,
@@ -376,8 +377,8 @@ __global__ void k_index_aux(const int64_t* __restrict__ vertex, const int64_t* _
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t p = t0; p < nnz; p += stride) {
         const int64_t v = vertex[p], e = edges[p];
-        v32[p] = v > 0 ? (int)v : 0;
-        e32[p] = e > 0 ? (int)e : 0;
+        v32[p] = (v >= 0 && v < n_nodes && e >= 0 && e < n_edges) ? (int)v : -1;
+        e32[p] = (v >= 0 && v < n_nodes && e >= 0 && e < n_edges) ? (int)e : -1;
     }
     for (int64_t i = t0; i < n_nodes; i += stride) {
         if (batch32) batch32[i] = (int)batch[i];

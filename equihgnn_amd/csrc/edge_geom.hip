@@ -1,0 +1,94 @@
+// Per-edge geometry of the Equiformer front-end in ONE launch: rel_pos = x_i - x_j, the column of the degree-1
+// Wigner matrix D that the live tensor-product pairs read, the radius mask and the masked-mean weights.
+//
+// Replaces (reference) equiformer_layer.py:1250-1252,1317-1346 (rel_pos of the selected neighbours, the radius
+// mask) and equiformer/basis.py:194-215 -> :169-191 -> irr_repr.py:105-118,23-32 (rotation of r_ij onto the
+// y axis in float64, ZYZ Euler angles, D[1] = Z(a) J Z(b) J Z(c)), plus the mask/count arithmetic of
+// equiformer/utils.py:71-82 (masked_mean) -- ~10 elementwise launches in the first version of this repo.
+//
+// Which part of D is needed: only the pairs (0 -> 1) and (1 -> 0) reach the type-0 output, and
+// both read D[:, m = 0], the image of the y axis:  D e_1 = Z(a) J Z(b) J Z(c) e_1 = (sin a sin b, cos b, cos a sin b)
+// (Z(c) fixes e_1, J swaps e_0 and e_1 and flips e_2).  With v = normalize(R y) the Euler angles are
+// b = acos(v_y), a = atan2(v_x, v_z) (irr_repr.py:110-114), so the column is v again -- computed here through
+// the same fp32 acos / atan2 / sin / cos round trip as the reference, so that the rounding is the same.
+// For a generic direction v = r_hat.  It is NOT r_hat where the reference's rotation is degenerate
+// (basis.py:187-190): R = 2 (x + y)(x + y)^T / max(|x + y|^2, 1e-6) - I with x = r_hat (float64), which stops
+// being a rotation when |x + y|^2 < 1e-6 (r_hat within 1e-3 rad of -y): then R y = (s / 1e-6)(x + y) - y,
+// s = |x + y|^2, which slides from x (s = 1e-6) to -y (s = 0).  Coincident atoms give x = 0 and R y = y.
+// All of it is reproduced: tests/golden/equiformer_D.npz holds the reference's D for such rows.
+//
+// Layout: 16 lanes per node (lane = neighbour slot, K <= 16), four nodes per wavefront; the per-node count
+// of in-radius neighbours is a popcount of the wavefront ballot.  No gradient (positions are data and the
+// reference builds D under no_grad).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_edge_geom(const float* __restrict__ pos, const int* __restrict__ nbr, const float* __restrict__ dist, int64_t N, int K,
+            float radius, float* __restrict__ rhat, float* __restrict__ maskf, float* __restrict__ mean_w,
+            float* __restrict__ mean_w_rhat) {
+    const int lane = threadIdx.x & 63;
+    const int slot = lane & 15, sub = lane >> 4;
+    const int64_t node0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
+    const int64_t i = node0 + sub;
+    const bool live = i < N && slot < K;
+    float c0 = 0.f, c1 = 1.f, c2 = 0.f, d = INFINITY;
+    if (live) {
+        const int64_t e = i * K + slot;
+        const int j = nbr[e];
+        d = dist[e];
+        const float rx = __fsub_rn(pos[3 * i], pos[3 * j]);          // x_i - x_j, equiformer_layer.py:1250
+        const float ry = __fsub_rn(pos[3 * i + 1], pos[3 * j + 1]);
+        const float rz = __fsub_rn(pos[3 * i + 2], pos[3 * j + 2]);
+        // basis.py:183-190 in float64: x = l2norm(r) (F.normalize, eps 1e-12), xy = x + y, R y = 2 xy xy_1 / max(s, 1e-6) - y
+        const double x0 = rx, x1 = ry, x2 = rz;
+        double nrm = sqrt(x0 * x0 + x1 * x1 + x2 * x2);
+        nrm = nrm > 1e-12 ? nrm : 1e-12;
+        const double a0 = x0 / nrm, a1 = x1 / nrm + 1.0, a2 = x2 / nrm;
+        double s = a0 * a0 + a1 * a1 + a2 * a2;
+        s = s > 1e-6 ? s : 1e-6;
+        const double t = 2.0 * a1 / s;
+        const float u0 = (float)(t * a0), u1 = (float)(t * a1 - 1.0), u2 = (float)(t * a2);   // R.type(float32) @ y
+        // irr_repr.py:110-114 in float32: v = l2norm(R y).clamp(-1, 1); b = acos(v_y); a = atan2(v_x, v_z)
+        float n2 = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(u0, u0), __fmul_rn(u1, u1)), __fmul_rn(u2, u2)));
+        n2 = n2 > 1e-12f ? n2 : 1e-12f;
+        const float v0 = fminf(fmaxf(u0 / n2, -1.f), 1.f), v1 = fminf(fmaxf(u1 / n2, -1.f), 1.f),
+                    v2 = fminf(fmaxf(u2 / n2, -1.f), 1.f);
+        const float b = acosf(v1), a = atan2f(v0, v2);
+        const float sb = sinf(b);
+        c0 = __fmul_rn(sinf(a), sb);          // D[:, m=0] = (sin a sin b, cos b, cos a sin b)
+        c1 = cosf(b);
+        c2 = __fmul_rn(cosf(a), sb);
+    }
+    const bool in = live && d <= radius;                                  // neighbor_mask, :1339
+    const unsigned long long bal = __ballot(in);
+    const int cnt = __popcll((bal >> (16 * sub)) & 0xffffull);
+    if (live) {
+        const int64_t e = i * K + slot;
+        const float w = in ? 1.f / (float)cnt : 0.f;                      // masked mean weight; 0 for an empty set
+        rhat[3 * e] = c0; rhat[3 * e + 1] = c1; rhat[3 * e + 2] = c2;
+        maskf[e] = in ? 1.f : 0.f;
+        mean_w[e] = w;
+        mean_w_rhat[3 * e] = __fmul_rn(w, c0); mean_w_rhat[3 * e + 1] = __fmul_rn(w, c1); mean_w_rhat[3 * e + 2] = __fmul_rn(w, c2);
+    }
+}
+
+}  // namespace
+
+extern "C" int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, int64_t N, int32_t K,
+                                 float radius, float* rhat, float* maskf, float* mean_w, float* mean_w_rhat,
+                                 void* stream) {
+    if (N < 0 || K < 1 || K > 16) return EQH_ERR_ARG;
+    if (N == 0) return EQH_OK;
+    if (!pos || !nbr || !dist || !rhat || !maskf || !mean_w || !mean_w_rhat) return EQH_ERR_ARG;
+    const int64_t waves = (N + 3) / 4;
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffff) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(k_edge_geom, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos, nbr, dist, N, (int)K, radius,
+                       rhat, maskf, mean_w, mean_w_rhat);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

@@ -19,8 +19,17 @@ constexpr int THREADS = 256;
 
 __device__ __forceinline__ float src_weight(const int* __restrict__ wptr, int j) {
     if (!wptr) return 1.0f;
+    if (j < 0) return 0.0f;
     int d = wptr[j + 1] - wptr[j];
     return 1.0f / (float)(d > 1 ? d : 1);
+}
+
+// A NEGATIVE source index is a null entry (the padded incidences of a static-shape batch, batch.pad_batch): it
+// contributes a zero row.  In the gather form (rowptr == NULL) that makes the backward of a per-incidence scatter
+// hand null incidences a zero gradient instead of row 0's.
+__device__ __forceinline__ float4 load_row(const float* __restrict__ src, int j, int C, int c) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)(j < 0 ? 0 : j) * C + c);
+    return j < 0 ? f4_zero() : v;
 }
 
 // LPR = lanes per row (power of two, <= 64).  Column blocks of LPR*4 floats.
@@ -46,10 +55,8 @@ k_segment_reduce(const float* __restrict__ src, const int* __restrict__ idx,
                 int j0, j1, j2, j3;
                 if (idx) { j0 = idx[q]; j1 = idx[q + 1]; j2 = idx[q + 2]; j3 = idx[q + 3]; }
                 else { j0 = q; j1 = q + 1; j2 = q + 2; j3 = q + 3; }
-                const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)j0 * C + c);
-                const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)j1 * C + c);
-                const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)j2 * C + c);
-                const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)j3 * C + c);
+                const float4 v0 = load_row(src, j0, C, c), v1 = load_row(src, j1, C, c);
+                const float4 v2 = load_row(src, j2, C, c), v3 = load_row(src, j3, C, c);
                 if (WEIGHTED) {
                     f4_fma(acc, v0, src_weight(wptr, j0)); f4_fma(acc, v1, src_weight(wptr, j1));
                     f4_fma(acc, v2, src_weight(wptr, j2)); f4_fma(acc, v3, src_weight(wptr, j3));
@@ -59,7 +66,7 @@ k_segment_reduce(const float* __restrict__ src, const int* __restrict__ idx,
             }
             for (; q < end; ++q) {
                 const int j = idx ? idx[q] : q;
-                const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)j * C + c);
+                const float4 v = load_row(src, j, C, c);
                 if (WEIGHTED) f4_fma(acc, v, src_weight(wptr, j));
                 else f4_add(acc, v);
             }

@@ -120,24 +120,13 @@ class EdgeGeometry:
         nbr, dist, csr_t = index.knn(pos, self.K, 1)
         self.nbr, self.csr_t = nbr, csr_t
         self.nbr_flat = nbr.reshape(-1)
-        with torch.no_grad():
-            rel = pos[:, None, :] - pos[nbr.long()]                      # x_i - x_j, :1250
-            safe = dist.clamp(min=1e-30)[..., None]
-            rhat = rel / safe
-            # coincident points: the reference's rotation-to-y construction yields D[:, m=0] = y
-            yhat = torch.zeros_like(rhat)  # built on the device: no host copy inside a hipGraph capture
-            yhat[..., 1] = 1.0
-            rhat = torch.where((dist == 0)[..., None], yhat, rhat)
+        # rel_pos, D[:, m=0] (with the reference's clamped rotation near -y and for coincident atoms), radius mask and
+        # masked-mean weights: one launch (csrc/edge_geom.hip) instead of ~10 elementwise ones
+        self.rhat, self.maskf, mean_w, self.mean_w_rhat = ops.edge_geometry(pos, nbr, dist, radius)
         self.dist = dist.reshape(-1, 1)                                   # [E, 1] true distance
-        self.rhat = rhat.reshape(-1, 3)                                   # [E, 3] = D[:, m=0]
-        self.mask = (dist <= radius)                                      # [N, K]   :1307
-        self.cnt = self.mask.sum(1, keepdim=True).clamp(min=1).to(pos.dtype)
-        self.has = (self.mask.sum(1, keepdim=True) > 0).to(pos.dtype)
-        self.maskf = self.mask.to(pos.dtype)
+        self.mask = self.maskf > 0                                        # [N, K]   :1339 (only the unfused attention reads it)
         self.recv_rowptr = torch.arange(0, (n + 1) * self.K, self.K, dtype=torch.int32, device=pos.device)
-        # masked mean over the neighbour slots as a batched product: weights mask / count (0 for an empty set)
-        self.mean_w = (self.maskf * (self.has / self.cnt))[:, None, :]                        # [N, 1, K]
-        self.mean_w_rhat = (self.maskf * (self.has / self.cnt))[..., None] * rhat             # [N, K, 3]
+        self.mean_w = mean_w[:, None, :]                                  # [N, 1, K]  masked mean as a batched product
 
     def masked_mean(self, t):
         """equiformer/utils.py:71-82 over the K neighbour slots; t is [E, ...]."""

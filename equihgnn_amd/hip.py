@@ -12,6 +12,16 @@ from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libequihgnn_hip.so")
 
+class HgDenseProblem(ctypes.Structure):
+    """HgDenseProblem of include/equihgnn_hip.h (one dense-layer problem of hg_dense_batch_f32)."""
+    _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("bias", c_void_p),
+                ("c", c_void_p), ("ldc", c_int64), ("out", c_void_p), ("ldo", c_int64), ("m", c_int64),
+                ("n", c_int32), ("k", c_int32), ("b_is_nk", c_int32), ("alpha", c_float),
+                ("seg_rowptr", c_void_p), ("seg_idx", c_void_p), ("seg_wptr", c_void_p), ("seg_mean", c_int32),
+                ("ln_eps", c_float), ("ln_bias", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
+                ("a_out", c_void_p), ("ld_aout", c_int64)]
+
+
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
 SIGNATURES = {
     "eqh_version": (c_int32, []),
@@ -51,6 +61,7 @@ SIGNATURES = {
     "geo_knn_grid_workspace_bytes": (c_size_t, [c_int64]),
     "geo_knn_grid": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    "eqf_edge_geometry": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float] + [c_void_p] * 5),
     "eqf_rms_norm_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "eqf_rms_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "eqf_rms_norm_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p,
@@ -83,6 +94,9 @@ SIGNATURES = {
     "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "hg_dense_batch_f32": (c_int32, [c_int32, ctypes.POINTER(HgDenseProblem), c_void_p]),
+    "eqh_stamp": (c_int32, [c_void_p, c_void_p]),
+    "eqh_wall_clock_khz": (c_int64, []),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

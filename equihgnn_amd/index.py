@@ -36,9 +36,9 @@ class HyperIndex:
         if batch is not None:
             self.B = int(num_graphs)
             self.pool = built[2]
-        # gather indices per incidence (null incidences of a padded batch, -1, point at row 0 so that code
-        # walking ALL incidences stays in bounds), int32 `batch`, and the masks of rows a mean leaves at
-        # zero -- one launch (hg_index_aux)
+        # int32 gather indices per incidence (null incidences of a padded batch stay -1: the row-gather kernel
+        # reads them as zero rows, so they get a zero row forward and a zero gradient backward; the CSRs never
+        # list them), int32 `batch`, and the masks of rows a mean leaves at zero -- one launch (hg_index_aux)
         self.v32, self.e32, self.batch32, has_v, has_e = ops.index_aux(vertex, edges, batch, self.N, self.M,
                                                                        self.by_v.rowptr, self.by_e.rowptr)
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)

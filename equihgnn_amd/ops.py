@@ -129,16 +129,173 @@ def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr
     return v32, e32, b32, has_v, has_e
 
 
+class Timeline:
+    """Measurement aid for bench.py: while ``ops.TIMELINE`` is set, the launches of the aggregation kernels are
+    bracketed by device-side time stamps (eqh_stamp, one-thread kernels that store the wall clock).  The stamps are
+    ordinary launches on the current stream, so they are captured into a hipGraph with everything else and give the
+    IN-GRAPH duration of each bracketed launch on every replay -- where HIP events on the launching stream see
+    nothing.  ``entries``: (kernel name, algorithmic bytes or flops, slot before, slot after), in launch order."""
+
+    def __init__(self, device, capacity: int = 8192):
+        self.slots = torch.zeros(capacity, dtype=torch.int64, device=device)
+        self.entries = []
+        self.n = 0
+        self.khz = int(hip.lib().eqh_wall_clock_khz())
+
+    def stamp(self) -> int:
+        i = self.n
+        if i >= self.slots.numel():
+            raise RuntimeError("Timeline: out of slots")
+        self.n += 1
+        hip.check(hip.lib().eqh_stamp(_c_void_p(self.slots.data_ptr() + 8 * i), _stream(self.slots.device)), "eqh_stamp")
+        return i
+
+    def reset(self):
+        self.entries, self.n = [], 0
+
+    def pair(self, name: str = "stamp_pair"):
+        """Two stamps back to back: their distance is the launch slot every bracket includes once."""
+        a = self.stamp()
+        b = self.stamp()
+        self.entries.append((name, 0, a, b))
+
+    def read_us(self):
+        """[(name, work, microseconds)] from the stamps of the last run (synchronises)."""
+        t = self.slots[: self.n].cpu()
+        return [(n, w, float(t[b] - t[a]) * 1e3 / self.khz) for n, w, a, b in self.entries]
+
+
+TIMELINE: Optional[Timeline] = None
+
+
+def timed(name: str, work, launch):
+    """Run ``launch()``; under an active Timeline bracket it with stamps.  ``work``: algorithmic bytes (or flops)."""
+    tl = TIMELINE
+    if tl is None:
+        return launch()
+    a = tl.stamp()
+    out = launch()
+    b = tl.stamp()
+    tl.entries.append((name, int(work() if callable(work) else work), a, b))
+    return out
+
+
+def segment_reduce_bytes(nnz: int, n_out: int, C: int, has_idx: bool, has_ptr: bool, has_w: bool) -> int:
+    """Algorithmic bytes of one hg_segment_reduce_f32 launch: 4C*nnz gathered rows + 4*nnz index +
+    4*(R+1) rowptr + 4C*R output (+ 8*nnz for the mean-weight rowptr reads of the backward form)."""
+    return (4 * C * nnz + 4 * C * n_out + (4 * nnz if has_idx else 0) + (4 * (n_out + 1) if has_ptr else 0)
+            + (8 * nnz if has_w else 0))
+
+
 def _segment_reduce(src, idx, rowptr, wptr, n_out, mean: bool) -> torch.Tensor:
     """Raw launch of hg_segment_reduce_f32 on 2-D ``src`` [rows, C]."""
     _require_gpu(src, "segment_reduce")
     src = _f32c(src)
     C = src.shape[-1]
     out = torch.empty((n_out, C), dtype=torch.float32, device=src.device)
-    hip.check(hip.lib().hg_segment_reduce_f32(_ptr(src), _ptr(idx), _ptr(rowptr), _ptr(wptr), _ptr(out),
-                                              n_out, C, 1 if mean else 0, _stream(src.device)),
-              "hg_segment_reduce_f32")
+
+    def work():
+        nnz = int(idx.numel()) if idx is not None else (int(n_out) if rowptr is None else int(src.shape[0]))
+        return segment_reduce_bytes(nnz, int(n_out), C, idx is not None, rowptr is not None, wptr is not None)
+
+    timed("k_segment_reduce" + ("<weighted>" if wptr is not None else ""), work,
+          lambda: hip.check(hip.lib().hg_segment_reduce_f32(_ptr(src), _ptr(idx), _ptr(rowptr), _ptr(wptr), _ptr(out),
+                                                            n_out, C, 1 if mean else 0, _stream(src.device)),
+                            "hg_segment_reduce_f32"))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# dense layer (hg_dense_batch_f32, csrc/dense.hip)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class DenseProblem:
+    """One problem of a dense_batch launch: out = alpha * A' @ op(b) (+ bias) (+ c); see include/equihgnn_hip.h.
+    ``a``: [M, K] rows (or, with ``seg``, the SOURCE rows the CSR gathers from); ``b``: weight [N, K] if ``nk`` else
+    [K, N] (any 2-D view with unit inner stride); ``seg`` = (rowptr, idx or None, wptr or None, mean, n_rows);
+    ``ln`` = (bias, gamma, beta, eps); ``a_out``: True to receive the prologue's A'."""
+
+    a: torch.Tensor
+    b: torch.Tensor
+    nk: bool = True
+    bias: Optional[torch.Tensor] = None
+    c: Optional[torch.Tensor] = None
+    alpha: float = 1.0
+    seg: Optional[tuple] = None
+    ln: Optional[tuple] = None
+    a_out: bool = False
+    out: Optional[torch.Tensor] = None
+
+
+def _row_view(t, what):
+    """2-D fp32 device tensor usable as a matrix operand in place (unit inner stride, 16-byte aligned rows)."""
+    if not (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda):
+        raise TypeError(f"{what}: 2-D float32 device tensor expected")
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def dense_supported(k: int, n: int) -> bool:
+    return k % 4 == 0 and n % 4 == 0 and k > 0 and n > 0
+
+
+def dense_batch(problems):
+    """hg_dense_batch_f32: up to 8 independent dense layers in ONE launch.  Returns [(out, a_out or None)]."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgDenseProblem * n)()
+    keep, res = [], []
+    dev = problems[0].a.device
+    for i, pr in enumerate(problems):
+        a = _row_view(pr.a, "dense: a")
+        b = _row_view(pr.b, "dense: b")
+        K = a.shape[1]
+        N = b.shape[0] if pr.nk else b.shape[1]
+        if (b.shape[1] if pr.nk else b.shape[0]) != K:
+            raise ValueError(f"dense: a is [*, {K}] but b is {tuple(b.shape)} (nk={pr.nk})")
+        M = a.shape[0] if pr.seg is None else int(pr.seg[4])
+        if not dense_supported(K, N):
+            raise ValueError("dense: K and N must be multiples of 4")
+        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+        q = arr[i]
+        q.a, q.lda, q.b, q.ldb, q.b_is_nk = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 1 if pr.nk else 0
+        q.out, q.ldo, q.m, q.n, q.k, q.alpha = out.data_ptr(), out.stride(0), M, N, K, float(pr.alpha)
+        if pr.bias is not None:
+            bias = _f32c(pr.bias)
+            keep.append(bias)
+            q.bias = bias.data_ptr()
+        if pr.c is not None:
+            c = _row_view(pr.c, "dense: c")
+            keep.append(c)
+            q.c, q.ldc = c.data_ptr(), c.stride(0)
+        a_out = None
+        if pr.seg is not None:
+            rowptr, idx, wptr, mean = pr.seg[:4]
+            q.seg_rowptr = rowptr.data_ptr()
+            q.seg_idx = idx.data_ptr() if idx is not None else None
+            q.seg_wptr = wptr.data_ptr() if wptr is not None else None
+            q.seg_mean = 1 if mean else 0
+        if pr.ln is not None:
+            lb, lg, lbeta, eps = pr.ln
+            lb, lg, lbeta = _f32c(lb), _f32c(lg), _f32c(lbeta)
+            keep.extend((lb, lg, lbeta))
+            q.ln_bias, q.ln_gamma, q.ln_beta, q.ln_eps = lb.data_ptr(), lg.data_ptr(), lbeta.data_ptr(), float(eps)
+        if pr.a_out:
+            a_out = torch.empty((M, K), dtype=torch.float32, device=dev)
+            q.a_out, q.ld_aout = a_out.data_ptr(), K
+        keep.extend((a, b))
+        res.append((out, a_out))
+    probs = list(problems)
+    timed("k_dense", lambda: sum(2 * r[0].shape[0] * r[0].shape[1] * (pr.a.shape[1]) for r, pr in zip(res, probs)),
+          lambda: hip.check(hip.lib().hg_dense_batch_f32(n, arr, _stream(dev)), "hg_dense_batch_f32"))
+    return res
+
+
+def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=False, out=None):
+    """One dense layer through hg_dense_batch_f32; returns out, or (out, a_out) when ``a_out``."""
+    (o, ao), = dense_batch([DenseProblem(a, b, nk, bias, c, alpha, seg, ln, a_out, out)])
+    return (o, ao) if a_out else o
 
 
 def _as2d(t: torch.Tensor):
@@ -291,8 +448,10 @@ class _EgnnEdge(torch.autograd.Function):
             raise ValueError("egnn_edge: shapes must be ab[N,2Hp] wd[Hp] w2[16,Hp] b2[16] nbr[N,16]")
         m = torch.empty((N, 16), dtype=torch.float32, device=ab.device)
         pre2 = torch.empty((N, 16, 16), dtype=torch.float32, device=ab.device)
-        hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
-                                          _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd")
+        # MFMA flops only: 2 * 16 outputs per (edge, hidden unit)
+        timed("egnn_edge_fwd", N * 16 * Hp * 32,
+              lambda: hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
+                                                        _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd"))
         ctx.save_for_backward(ab, wd, w2, pre2)
         ctx.nbr, ctx.d2, ctx.csr_t, ctx.b2_param = nbr, d2, csr_t, b2_param
         return m
@@ -312,10 +471,11 @@ class _EgnnEdge(torch.autograd.Function):
         ws = _workspace(ws_bytes, dev)   # holds the d b2 slabs: parked while reductions are deferred
         tg = _acc_target(ctx.b2_param)   # d b2 = sum of dpre2 over nodes and slots, from the same pass
         db2 = tg if tg is not None else torch.empty(16, dtype=torch.float32, device=dev)
-        hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
-                                  _ptr(dm), dm_ld, _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
-                                  _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0, _ptr(ws),
-                                  ws_bytes, _stream(dev)), "egnn_edge_bwd")
+        timed("egnn_edge_bwd", N * 16 * Hp * 96,     # MFMA flops only: three 16-wide products per (edge, hidden unit)
+              lambda: hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
+                                                _ptr(dm), dm_ld, _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
+                                                _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0,
+                                                _ptr(ws), ws_bytes, _stream(dev)), "egnn_edge_bwd"))
         return dab, dwd, dw2, (None if tg is not None else db2), None, None, None, None
 
 
@@ -330,10 +490,12 @@ class _IncidenceLnReduce(torch.autograd.Function):
         pa, qb, gamma, beta = _f32c(pa), _f32c(qb), _f32c(gamma), _f32c(beta)
         C = pa.shape[1]
         out = torch.empty((out_csr.n_rows, C), dtype=torch.float32, device=pa.device)
-        hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
-            _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
-            _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
-            "hg_incidence_ln_reduce_fwd")
+        # algorithmic bytes: two gathered rows per incidence + one output row, three index words per incidence, rowptr
+        timed("k_inc_fwd", 4 * C * (2 * out_csr.nnz + out_csr.n_rows) + 12 * out_csr.nnz + 4 * (out_csr.n_rows + 1) + 8 * C,
+              lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
+                  _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
+                  _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
+                  "hg_incidence_ln_reduce_fwd"))
         ctx.save_for_backward(pa, qb, gamma)
         ctx.meta = (ia32, ib32, csr_a, csr_b, out_csr, okey32, mean, eps)
         ctx.acc = acc_params
@@ -352,11 +514,17 @@ class _IncidenceLnReduce(torch.autograd.Function):
         L = hip.lib()
         ws_bytes = L.hg_incidence_ln_reduce_bwd_workspace_bytes(csr_a.n_rows, C)
         ws = _workspace(ws_bytes, dev)
-        hip.check(L.hg_incidence_ln_reduce_bwd(
-            _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(csr_a.rowptr), _ptr(csr_a.perm), csr_a.n_rows,
-            _ptr(csr_b.rowptr), _ptr(csr_b.perm), csr_b.n_rows, _ptr(okey32), _ptr(out_csr.rowptr), _ptr(ds),
-            _ptr(gamma), C, 1 if mean else 0, float(eps), _ptr(dpa), _ptr(dqb), _ptr(dgamma),
-            1 if g_acc is not None else 0, _ptr(ws), ws_bytes, _stream(dev)), "hg_incidence_ln_reduce_bwd")
+        # algorithmic bytes: each operand side walks every incidence once and gathers, per incidence, the OTHER
+        # operand's row and the output-gradient row, reads its own row once and writes its own gradient row:
+        # 4C (4 nnz + 2 (Ra + Rb)) + five index words per incidence and side + both rowptrs
+        nnz_ = csr_a.nnz
+        timed("k_inc_bwd_both", 4 * C * (4 * nnz_ + 2 * (csr_a.n_rows + csr_b.n_rows)) + 2 * 20 * nnz_
+              + 4 * (csr_a.n_rows + csr_b.n_rows + 2),
+              lambda: hip.check(L.hg_incidence_ln_reduce_bwd(
+                  _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(csr_a.rowptr), _ptr(csr_a.perm), csr_a.n_rows,
+                  _ptr(csr_b.rowptr), _ptr(csr_b.perm), csr_b.n_rows, _ptr(okey32), _ptr(out_csr.rowptr), _ptr(ds),
+                  _ptr(gamma), C, 1 if mean else 0, float(eps), _ptr(dpa), _ptr(dqb), _ptr(dgamma),
+                  1 if g_acc is not None else 0, _ptr(ws), ws_bytes, _stream(dev)), "hg_incidence_ln_reduce_bwd"))
         # d beta = sum_r w_r ds[r], w_r = [row non-empty] (mean) or the row length (sum)
         dbeta = colsum(ds, out_csr.rowptr, 1 if mean else 2, into=b_acc)
         return (dpa, dqb, None if g_acc is not None else dgamma, dbeta) + (None,) * 9
@@ -398,7 +566,7 @@ class _BiasReluLn(torch.autograd.Function):
         hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
                                         _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), 0, _ptr(ws), ws_bytes,
                                         _stream(h.device)), "hg_bias_relu_ln_bwd")
-        return dh, small[0], small[1], small[2], None, None
+        return (dh, *_hand_out(list(small), tg), None, None)
 
 
 class _LayerNormRows(torch.autograd.Function):
@@ -434,7 +602,7 @@ class _LayerNormRows(torch.autograd.Function):
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
         hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, None, R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
                                       _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
-        return dx, small[0], small[1], None, None
+        return (dx, *_hand_out(list(small), tg), None, None)
 
 
 class _EgnnFeats(torch.autograd.Function):
@@ -479,7 +647,7 @@ class _EgnnFeats(torch.autograd.Function):
                                           _ptr(small[0]), _ptr(small[1]), 1 if in_place else 0, _ptr(ws), ws_bytes,
                                           _stream(dev)), "hg_layer_norm_bwd")
             if not in_place:
-                dgamma, dbeta = small
+                dgamma, dbeta = _hand_out(list(small), tg)
         else:
             dx = _f32c(d_res).clone() if d_res is not None else None
         dw = db = None
@@ -673,6 +841,7 @@ class _ReadoutMse(torch.autograd.Function):
                                        vp(*[g.data_ptr() for g in grads]), 1 if in_place else 0, _ptr(ws), ws_bytes,
                                        _ptr(_readout_state(dev)), _stream(dev)), "hg_readout_mse_f32")
         ctx.unit_grad, ctx.in_place = unit_grad, in_place
+        ctx.targets = tg if (unit_grad and not in_place) else [None] * 10
         ctx.held = (dx,) if in_place else (dx, *grads)
         ctx.mark_non_differentiable(y)
         return loss, y
@@ -683,7 +852,7 @@ class _ReadoutMse(torch.autograd.Function):
         if not ctx.unit_grad:
             held = tuple(h * dloss for h in held)
         dx = held[0]
-        dws = (None,) * 10 if ctx.in_place else tuple(g.view_as(g) for g in held[1:])
+        dws = (None,) * 10 if ctx.in_place else tuple(_hand_out([g.view_as(g) for g in held[1:]], ctx.targets))
         return (dx, None, None, None, None, None, None, None, *dws)
 
 
@@ -737,6 +906,19 @@ def copy_many(dsts, srcs):
 def _acc_target(param):
     """The persistent gradient accumulator of a parameter (set by the graphed trainer), or None."""
     return getattr(param, "_eqh_gbuf", None) if param is not None else None
+
+
+def _hand_out(grads, targets):
+    """Gradients of a parameter group computed into fresh tensors while only SOME of the group own a persistent
+    accumulator: those are added to in place (and autograd gets None for them), the rest go to autograd."""
+    out = []
+    for g, t in zip(grads, targets):
+        if t is not None:
+            t.add_(g.view_as(t))
+            out.append(None)
+        else:
+            out.append(g)
+    return out
 
 
 def _note_acc(*params):
@@ -814,7 +996,7 @@ class _EgnnPackWeights(torch.autograd.Function):
                                                   1 if in_place else 0, _stream(dev)), "egnn_pack_weights_bwd")
         if in_place:
             return None, None, None, None, None
-        return dw1, db1, dw2, None, None
+        return (*_hand_out([dw1, db1, dw2], tg), None, None)
 
 
 def egnn_pack_weights(w1, b1, w2, Hp):
@@ -1317,6 +1499,7 @@ class _AttnPool(torch.autograd.Function):
                                       1 if in_place else 0, _ptr(ws), ws_bytes, _stream(dev)), "eqf_attn_pool_bwd")
         if in_place:
             return dme, dedge, None, None, None, None, None, None, None
+        dwl, dwv = _hand_out([dwl, dwv], tg)
         return dme, dedge, None, dwl, dwv, None, None, None, None
 
 
@@ -1412,7 +1595,7 @@ class _RadialTrunk(torch.autograd.Function):
                                          _stream(dev)), "eqf_radial_trunk_bwd")
         if in_place:
             return (None,) * 11
-        dw0, db0, dg1, dw1, db1, dg2 = grads
+        dw0, db0, dg1, dw1, db1, dg2 = _hand_out(grads, tg)
         return None, None, None, dw0, db0, dg1, None, dw1, db1, dg2, None
 
 
@@ -1534,6 +1717,24 @@ def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto"):
     else:
         hip.check(L.geo_knn(_ptr(pos), N, k, mode, _ptr(nbr), _ptr(dist), _stream(pos.device)), "geo_knn")
     return nbr, dist
+
+
+def edge_geometry(pos, nbr, dist, radius: float):
+    """eqf_edge_geometry: (rhat [E,3] = D[:, m=0], maskf [N,K], mean_w [N,K], mean_w_rhat [N,K,3]) for the
+    self-excluded neighbour lists of geo_knn(mode 1); see csrc/edge_geom.hip.  No gradient."""
+    _require_gpu(pos, "edge_geometry")
+    pos, dist = _f32c(pos.detach()), _f32c(dist)
+    N, K = nbr.shape
+    if nbr.dtype != torch.int32 or dist.shape != (N, K) or pos.shape != (N, 3) or K > 16:
+        raise ValueError("edge_geometry: pos[N,3] fp32, nbr[N,K] int32, dist[N,K] fp32, K <= 16 expected")
+    dev = pos.device
+    rhat = torch.empty((N * K, 3), dtype=torch.float32, device=dev)
+    maskf = torch.empty((N, K), dtype=torch.float32, device=dev)
+    mean_w = torch.empty((N, K), dtype=torch.float32, device=dev)
+    mean_w_rhat = torch.empty((N, K, 3), dtype=torch.float32, device=dev)
+    hip.check(hip.lib().eqf_edge_geometry(_ptr(pos), _ptr(nbr.contiguous()), _ptr(dist), N, K, float(radius), _ptr(rhat),
+                                          _ptr(maskf), _ptr(mean_w), _ptr(mean_w_rhat), _stream(dev)), "eqf_edge_geometry")
+    return rhat, maskf, mean_w, mean_w_rhat
 
 
 def scatter(src, index, dim: int = -1, out=None, dim_size=None, reduce: str = "sum"):

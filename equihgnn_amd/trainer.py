@@ -166,9 +166,40 @@ class GraphedTrainStep:
         self.other_slots = []
         self.n_w = 0
         self.fused_head = "head" in inspect.signature(model.forward).parameters
+        self._has_buffers = _world() > 1 and any(True for _ in model.buffers())
+        for mod in model.modules():   # padded (null) incidences would enter the batch statistics of a per-incidence norm
+            if type(mod).__name__ == "MLP" and any(isinstance(n, nn.BatchNorm1d) for n in mod.normalizations):
+                raise NotImplementedError("GraphedTrainStep pads batches to static shapes; BatchNorm inside the "
+                                          "per-incidence MLPs (--normalization bn) would count the padding -- use TrainStep")
         if broadcast_from_rank0 and _world() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
+
+    def close(self):
+        """Detach this trainer from the model: the persistent gradient accumulators the kernels add into
+        (``param._eqh_gbuf``) belong to the trainer, and a later backward outside it (TrainStep, a user loop, another
+        GraphedTrainStep) must hand its gradients to autograd again."""
+        for p in self.model.parameters():
+            if hasattr(p, "_eqh_gbuf"):
+                del p._eqh_gbuf
+        self.gb_params, self.slots, self.live = [], {}, None
+
+    def _buffer_snapshot(self):
+        return [b.detach().clone() for b in self.model.buffers()]
+
+    def _buffer_restore(self, snap):
+        """The probe, warm-up and capture passes run the model in training mode without being optimiser steps: put the
+        BatchNorm running statistics / batch counters (mhnnm, egnn_equihnnm) back, so that they move once per step
+        as in the reference and in TrainStep."""
+        with torch.no_grad():
+            for b, s0 in zip(self.model.buffers(), snap):
+                b.copy_(s0)
+
+    def sync_buffers(self):
+        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics)."""
+        if _world() > 1:
+            for b in self.model.buffers():
+                dist.broadcast(b.data, src=0)
 
     @staticmethod
     def _key(b):
@@ -282,12 +313,17 @@ class GraphedTrainStep:
         the capturable fused Adam (also performs every lazy one-time initialisation of the HIP
         library and of the GEMM libraries before anything is captured)."""
         from . import ops
+        for p in self.model.parameters():      # accumulators of an earlier trainer on this model are stale
+            if hasattr(p, "_eqh_gbuf"):
+                del p._eqh_gbuf
         ops.LINEAR_PARAMS.clear()
         ops.ACC_PARAMS.clear()
         self.gflat = None
+        snap = self._buffer_snapshot()
         loss = self._fwd_bwd(data)
         self.live = [p for p in self.model.parameters() if p.grad is not None]
         self._setup_grad_buffers(data, self.live)
+        self._buffer_restore(snap)             # discovery + probe passes were not steps
         loss = self._fwd_bwd(data)
         # Adam is elementwise: one update over the flat tensor equals the per-parameter updates
         self.opt = FlatAdam(self.pflat, lr=self.lr, weight_decay=self.wd)
@@ -301,15 +337,24 @@ class GraphedTrainStep:
         world = _world()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        snap = self._buffer_snapshot()
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
             for _ in range(2):
                 self._fwd_bwd(static)
+            self._buffer_restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         for p in self.model.parameters():
             p.grad = None
         g_bwd = torch.cuda.CUDAGraph()
+        from . import ops
+        tl = ops.TIMELINE            # bench.py's in-graph kernel timing: only the captured pass is recorded
+        if tl is not None:
+            tl.reset()
         # thread_local: the RCCL watchdog thread may query events while this thread captures
         with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
+            if tl is not None:
+                for _ in range(4):
+                    tl.pair("stamp_pair")
             if self.wflat is not None:
                 self.wflat.zero_()
             loss = self._loss_backward(static)
@@ -345,6 +390,8 @@ class GraphedTrainStep:
                 if torch.is_tensor(v):
                     getattr(st, f).copy_(v, non_blocking=True)
         self.opt.sync_lr()
+        if self._has_buffers:
+            self.sync_buffers()
         slot["bwd"].replay()
         if slot["opt"] is not None:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)

@@ -59,6 +59,59 @@ int eqh_defer_begin(void* stream);
 int eqh_defer_flush(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Dense layer on the fp32 matrix cores (csrc/dense.hip) -- every nn.Linear / F.linear of the path (mlp.py:91-99,
+ * conv.py:169-182, egnn_layer.py:180-208) and its input-gradient product:
+ *
+ *     out[m, n] = alpha * sum_k A'[m, k] * Bop[k, n]  (+ bias[n])  (+ c[m, n])
+ *
+ *   b_is_nk != 0 : b is an nn.Linear weight [n, k] (row stride ldb): out = A' b^T           (forward)
+ *   b_is_nk == 0 : b is [k, n] (row stride ldb): out = A' b                                  (input gradient)
+ * A' is `a` [m, k] (row stride lda), or is produced while the operand tile is staged (at most one prologue):
+ *   segment  (seg_rowptr != NULL): A'[r] = s(r) * sum_{q in [seg_rowptr[r], seg_rowptr[r+1])} w(j_q) a[j_q],
+ *            j_q = seg_idx[q] (seg_idx NULL: j_q = q; negative: null entry), w(j) = 1 / max(seg_wptr[j+1] -
+ *            seg_wptr[j], 1) (seg_wptr NULL: 1), s(r) = 1 / max(row length, 1) if seg_mean else 1 -- the semantics
+ *            of hg_segment_reduce_f32, i.e. torch_scatter.scatter of gathered rows (conv.py:172-173) followed by
+ *            the Linear, in one launch;
+ *   relu_ln  (ln_gamma != NULL):   A'[r] = LayerNorm(relu(a[r] + ln_bias)) * ln_gamma + ln_beta over the k
+ *            columns (eps ln_eps): the hidden layer of mlp.py:91-99 followed by the next Linear.
+ * a_out (row stride ld_aout), if not NULL, receives A' (the backward pass needs it for the weight gradient).
+ * n, k multiples of 4; row strides multiples of 4 floats; pointers 16-byte aligned.  Up to 8 problems per launch
+ * (independent Linears of one layer, all with the same kind of prologue); results are bitwise reproducible.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct HgDenseProblem {
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    const float* bias;
+    const float* c;
+    int64_t ldc;
+    float* out;
+    int64_t ldo;
+    int64_t m;
+    int32_t n, k;
+    int32_t b_is_nk;
+    float alpha;
+    const int32_t* seg_rowptr;
+    const int32_t* seg_idx;
+    const int32_t* seg_wptr;
+    int32_t seg_mean;
+    float ln_eps;
+    const float* ln_bias;
+    const float* ln_gamma;
+    const float* ln_beta;
+    float* a_out;
+    int64_t ld_aout;
+} HgDenseProblem;
+int hg_dense_batch_f32(int32_t n_problems, const HgDenseProblem* problems, void* stream);
+
+/* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
+ * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch
+ * time it INSIDE a replayed hipGraph; eqh_wall_clock_khz is that clock's rate. */
+int eqh_stamp(void* slot, void* stream);
+int64_t eqh_wall_clock_khz(void);
+
+/* ---------------------------------------------------------------------------------------------
  * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of
  * torch_scatter.scatter (conv.py:91-93,97,173,177): the COO incidence list is sorted ONCE per
  * batch into a CSR so that every later aggregation is an atomic-free segmented reduction.
@@ -82,7 +135,8 @@ int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int6
 /* n independent builds at once (arrays of n pointers / sizes, same meaning as above): the three CSRs a
  * model step derives from the batch structure cost 3 launches instead of 18. */
 /* The per-batch index vectors the layers read besides the CSRs, in one launch: int32 copies of the
- * incidence coordinates (null incidences, -1, clamped to 0) and of `batch` (batch32 may be NULL), and
+ * incidence coordinates (null incidences -- either coordinate out of range -- become -1 in both) and of `batch`
+ * (batch32 may be NULL), and
  * the float 0/1 masks "row has at least one incidence" of the two CSRs (conv.py's mean leaves such rows
  * at zero, so the bias of the last Linear must not reach them). */
 int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
@@ -109,6 +163,7 @@ int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* cons
  *                      source rows in ANOTHER CSR — this is what the backward of a gathered
  *                      mean needs; NULL => w = 1.
  * Rows with no entry are written as zeros.  Summation order inside a row is the CSR order.
+ * A negative idx[q] is a null entry and contributes a zero row (padded incidences of a static-shape batch).
  * ------------------------------------------------------------------------------------------- */
 int hg_segment_reduce_f32(const float* src, const int32_t* idx, const int32_t* rowptr,
                           const int32_t* src_wptr, float* out, int64_t n_out_rows, int32_t C,
@@ -253,6 +308,22 @@ int64_t geo_knn_grid_max_points(void);
 size_t geo_knn_grid_workspace_bytes(int64_t N);
 int geo_knn_grid(const float* pos, int64_t N, int32_t k, int32_t mode, const int32_t* n_box, int32_t* nbr,
                  float* dist, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-edge geometry of the Equiformer front-end -- equiformer_layer.py:1250-1252,1317-1346 (rel_pos = x_i - x_j of
+ * the selected neighbours, neighbor_mask = dist <= radius), equiformer/basis.py:194-215 with :169-191 and
+ * irr_repr.py:105-118,23-32 (D[1] of the rotation taking r_ij onto y, built in float64 with the |x+y|^2 >= 1e-6
+ * clamp), equiformer/utils.py:71-82 (masked-mean weights).
+ *   pos [N,3]; nbr [N,K] int32 and dist [N,K] from geo_knn(mode 1); K <= 16
+ *   rhat        [N*K,3]  D[:, m=0], the only column of D the type-0 output depends on: r_hat for generic edges,
+ *                        y for coincident atoms, the clamped construction within 1e-3 rad of -y
+ *   maskf       [N,K]    1.0 where dist <= radius
+ *   mean_w      [N,K]    maskf / max(count, 1)  (all zero for a node without an in-radius neighbour)
+ *   mean_w_rhat [N,K,3]  mean_w * rhat
+ * No gradient (positions are data; the reference builds D under no_grad).
+ * ------------------------------------------------------------------------------------------- */
+int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, int64_t N, int32_t K, float radius,
+                      float* rhat, float* maskf, float* mean_w, float* mean_w_rhat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Degree-0 branch of the Equiformer's `Norm` (equiformer_layer.py:194-225): out = t / max(rms, eps) * g with

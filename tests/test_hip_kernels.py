@@ -1068,3 +1068,164 @@ def test_eigh3_matches_lapack_up_to_sign():
     assert float((eye - torch.eye(3, dtype=torch.double)).abs().max()) < 1e-5
     resid = torch.bmm(cov.double(), v) - v * w_ref.unsqueeze(1)
     assert float(resid.abs().max() / cov.abs().max()) < 1e-5
+
+
+def test_edge_geometry_matches_reference_D_fixture():
+    """eqf_edge_geometry's D[:, m=0] against the reference's own get_D_to_from_z_axis on crafted directions
+    (tests/golden/equiformer_D.npz: generic, axis-aligned, exactly -y, inside the |x_hat + y_hat|^2 < 1e-6 clamp of
+    equiformer/basis.py:187-190, zero, tiny, huge).  Each fixture row e becomes the edge (2e -> 2e+1) of a cloud in
+    which pos[2e] - pos[2e+1] = rel_pos[e] (the neighbour lists are handed to the kernel, so the pairs need not be
+    apart)."""
+    from common import load_case
+    ops = _ops()
+    case = load_case("equiformer_D")
+    rel, D = case["rel_pos"], case["D1"]
+    E = rel.shape[0]
+    pos = np.zeros((2 * E, 3), np.float32)
+    pos[0::2] = rel                                                      # x_i = rel, x_j = 0: x_i - x_j is rel exactly
+    back = pos[0::2] - pos[1::2]
+    keep = np.all(back == rel, axis=1)
+    nbr = np.zeros((2 * E, 1), np.int32)
+    nbr[0::2, 0] = np.arange(E) * 2 + 1
+    nbr[1::2, 0] = np.arange(E) * 2
+    dist = np.linalg.norm(pos - pos[nbr[:, 0]], axis=1).astype(np.float32)[:, None]
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    rhat, maskf, mean_w, mwr = ops.edge_geometry(t(pos), t(nbr), t(dist), 5.0)
+    got = rhat.cpu().numpy()[0::2]
+    assert keep.all()
+    np.testing.assert_allclose(got[keep], D[keep][:, :, 1], atol=2e-6, rtol=0)
+    # rows the offset did perturb (tiny components next to 1e4): against the oracle on the perturbed vector
+    from oracle.ref_equiformer import wigner_d1_to_y
+    want = wigner_d1_to_y(torch.from_numpy(back))[:, :, 1].numpy()
+    np.testing.assert_allclose(got, want, atol=2e-6, rtol=0)
+    m = (dist[:, 0] <= 5.0).astype(np.float32)
+    assert np.array_equal(maskf.cpu().numpy()[:, 0], m) and np.array_equal(mean_w.cpu().numpy()[:, 0], m)
+    np.testing.assert_array_equal(mwr.cpu().numpy()[:, 0], rhat.cpu().numpy() * m[:, None])
+
+
+@pytest.mark.parametrize("N,K", [(5, 4), (300, 16), (4700, 16)])
+def test_edge_geometry_matches_oracle_on_a_cloud(N, K):
+    """Neighbour lists, D column, radius mask and masked-mean weights against the oracle's restatement
+    (oracle/ref_equiformer.py: neighbours_self_excluded + wigner_d1_to_y) on a molecule-like cloud that includes a
+    coincident pair, an edge along -y and a far-away group with no neighbour inside the radius."""
+    from oracle.ref_equiformer import neighbours_self_excluded, wigner_d1_to_y
+    ops = _ops()
+    g = np.random.default_rng(N)
+    pos = (g.standard_normal((N, 3)) * (1.5 if N < 1000 else 6.0)).astype(np.float32)
+    pos[1] = pos[0]
+    pos[3] = pos[2] + np.array([0, -0.9, 0], np.float32)
+    if N > 100:
+        pos[-20:] = (1.0e3 + 10.0 * np.arange(20))[:, None].astype(np.float32)
+    p = torch.from_numpy(pos)
+    idx, dist, rel, mask = neighbours_self_excluded(p, K, 5.0)
+    nbr_d, dist_d = ops.knn(p.to(DEV), K, 1)
+    assert np.array_equal(np.sort(nbr_d.cpu().numpy(), 1), np.sort(idx.numpy(), 1))
+    rhat, maskf, mean_w, mwr = ops.edge_geometry(p.to(DEV), nbr_d, dist_d, 5.0)
+    nb = nbr_d.cpu().long()
+    want = wigner_d1_to_y(p[:, None, :] - p[nb])[..., :, 1]
+    np.testing.assert_allclose(rhat.cpu().numpy().reshape(N, K, 3), want.numpy(), atol=2e-6, rtol=0)
+    m = (dist_d.cpu() <= 5.0).float()
+    cnt = m.sum(1, keepdim=True)
+    assert torch.equal(maskf.cpu(), m)
+    np.testing.assert_allclose(mean_w.cpu().numpy(), (m / cnt.clamp(min=1)).numpy(), rtol=1e-6)
+    np.testing.assert_allclose(mwr.cpu().numpy(), ((m / cnt.clamp(min=1))[..., None] * rhat.cpu().view(N, K, 3)).numpy(),
+                               rtol=1e-6)
+    if N > 100:
+        assert float(mean_w[-20:].abs().max()) == 0.0                       # no in-radius neighbour: an all-zero row
+
+
+def test_null_entries_read_as_zero_rows():
+    """hg_segment_reduce_f32 with negative indices (padded incidences): zero rows in the gather form -- forward of
+    ops.gather_rows and the backward of ops.reduce_entries, with and without mean weights -- and hg_index_aux keeps
+    null incidences at -1 in BOTH int32 copies."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    nnz, N, M, C = 50, 9, 7, 8
+    v = torch.randint(0, N, (nnz,), generator=g)
+    e = torch.randint(0, M, (nnz,), generator=g)
+    v[40:] = -1
+    e[40:] = -1
+    vd, ed = v.to(DEV), e.to(DEV)
+    by_v, by_e = ops.csr_build_batch([(vd, ed, N), (ed, vd, M)])
+    v32, e32, _, has_v, has_e = ops.index_aux(vd, ed, None, N, M, by_v.rowptr, by_e.rowptr)
+    assert torch.equal(v32.cpu(), v.int()) and torch.equal(e32.cpu(), e.int())
+    X = torch.randn(N, C, generator=g).to(DEV).requires_grad_(True)
+    rows = ops.gather_rows(X, v32, by_v)
+    assert float(rows[40:].abs().max()) == 0.0 and torch.equal(rows[:40], X.detach()[v[:40].to(DEV)])
+    H = torch.randn(nnz, C, generator=g).to(DEV).requires_grad_(True)
+    for reduce in ("sum", "mean"):
+        H.grad = None
+        out = ops.reduce_entries(H, by_e, e32, reduce)
+        w = torch.randn(M, C, generator=g).to(DEV)
+        (out * w).sum().backward()
+        assert float(H.grad[40:].abs().max()) == 0.0
+        deg = torch.bincount(e[:40], minlength=M).clamp(min=1).float().to(DEV)
+        want = w[e[:40].to(DEV)] / (deg[e[:40].to(DEV)][:, None] if reduce == "mean" else 1.0)
+        np.testing.assert_allclose(H.grad[:40].cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("M,N,K,nk,bias,c,alpha", [(4736, 256, 256, True, False, False, 1.0), (4736, 256, 256, False, False, False, 1.0),
+                                                   (100, 64, 36, True, True, True, 0.5), (33, 68, 272, False, True, False, 1.0),
+                                                   (257, 512, 272, True, True, False, 1.0), (1, 4, 4, True, False, False, 1.0),
+                                                   (300, 2176, 256, True, True, False, 1.0), (300, 256, 2176, False, False, True, 2.0)])
+def test_dense_matches_float64(M, N, K, nk, bias, c, alpha):
+    """hg_dense_batch_f32 (fp32 MFMA dense layer, csrc/dense.hip): both weight layouts, ragged tiles in M / N / K,
+    bias, residual and scale epilogues, against a float64 product."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    a, b = rnd(M, K), (rnd(N, K) if nk else rnd(K, N))
+    bi, cc = (rnd(N) if bias else None), (rnd(M, N) if c else None)
+    out = ops.dense(a, b, nk, bi, cc, alpha)
+    ref = alpha * (a.double() @ (b.double().t() if nk else b.double()))
+    if bias:
+        ref = ref + bi.double()
+    if c:
+        ref = ref + cc.double()
+    err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
+    assert err < 4e-6 * max(1.0, (K / 256) ** 0.5), err
+    out2 = ops.dense(a, b, nk, bi, cc, alpha)
+    assert torch.equal(out, out2)                     # fixed summation order: bitwise reproducible
+
+
+def test_dense_prologues_and_batching():
+    """The row-op prologues of hg_dense_batch_f32 -- segmented gather-mean (torch_scatter.scatter of gathered rows,
+    conv.py:172-173, forward and mean-weighted backward form) and bias + ReLU + LayerNorm (mlp.py:91-99) -- against
+    the stand-alone kernels they fuse, a column-block weight view (W[:, c0:c1], no copy), and two problems in one
+    launch."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    M, S, K, N, nnz = 1203, 1100, 256, 192, 2600
+    key = torch.randint(0, M, (nnz,), device=DEV, generator=g)
+    col = torch.randint(0, S, (nnz,), device=DEV, generator=g)
+    key[:40] = 7                                       # one long row (more entries than the register gather holds)
+    csr = ops.csr_build(key, col, M)
+    csr_t = ops.csr_build(col, key, S)
+    src, w, bias = rnd(S, K), rnd(N, K), rnd(N)
+    out, a_out = ops.dense(src, w, True, bias, seg=(csr.rowptr, csr.col, None, True, M), a_out=True)
+    agg = ops._segment_reduce(src, csr.col, csr.rowptr, None, M, True)
+    np.testing.assert_allclose(a_out.cpu().numpy(), agg.cpu().numpy(), atol=2e-6, rtol=1e-6)
+    ref = agg.double() @ w.double().t() + bias.double()
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 4e-6
+    dy, wt = rnd(M, K), rnd(K, N)
+    out2, a2 = ops.dense(dy, wt, False, seg=(csr_t.rowptr, csr_t.col, csr.rowptr, False, S), a_out=True)
+    agg2 = ops._segment_reduce(dy, csr_t.col, csr_t.rowptr, csr.rowptr, S, False)
+    np.testing.assert_allclose(a2.cpu().numpy(), agg2.cpu().numpy(), atol=2e-6, rtol=1e-6)
+    ref2 = agg2.double() @ wt.double()
+    assert float((out2.double() - ref2).abs().max() / ref2.abs().max()) < 4e-6
+    h, pb, ga, be = rnd(M, K), rnd(K), rnd(K), rnd(K)
+    out3, a3 = ops.dense(h, w, True, bias, ln=(pb, ga, be, 1e-5), a_out=True)
+    xn = torch.nn.functional.layer_norm(torch.relu(h.double() + pb.double()), (K,), ga.double(), be.double(), 1e-5)
+    assert float((a3.double() - xn).abs().max()) < 1e-5
+    ref3 = xn @ w.double().t() + bias.double()
+    assert float((out3.double() - ref3).abs().max() / ref3.abs().max()) < 4e-6
+    wide = rnd(N, 2 * K)                               # Linear over cat(a, b): the second half of the weight, in place
+    out4 = ops.dense(h, wide[:, K:], True)
+    ref4 = h.double() @ wide[:, K:].double().t()
+    assert float((out4.double() - ref4).abs().max() / ref4.abs().max()) < 4e-6
+    (o5, _), (o6, _) = ops.dense_batch([ops.DenseProblem(h, w), ops.DenseProblem(dy, wt, nk=False, alpha=0.5)])
+    assert float((o5.double() - h.double() @ w.double().t()).abs().max()) < 2e-4
+    assert float((o6.double() - 0.5 * (dy.double() @ wt.double())).abs().max()) < 2e-4
+    with pytest.raises(Exception):                     # one kind of prologue per launch
+        ops.dense_batch([ops.DenseProblem(h, w), ops.DenseProblem(h, w, ln=(pb, ga, be, 1e-5))])

@@ -44,23 +44,42 @@ def test_hip_model_matches_reference_golden(name):
     check_against_case(model, case, data, grad_rtol=1e-2 if wide else (3e-3 if noisy else 3e-4))
 
 
-@pytest.mark.parametrize("method,bs,seed", [("mhnnm", 32, 1000), ("egnn_equihnns", 32, 2001),
-                                            ("egnn_equihnns", 256, 2000), ("equiformer_equihnns", 8, 3000)])
-def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed):
+# (method, molecules, seed, flavour, hidden, mode): the BASELINE workloads at sizes the CPU oracle still finishes in
+# seconds.  c1 mhnnm B=32; c2 egnn_equihnns B=256; c3 equiformer_equihnns B=128 (at the main.py:195 default width 64:
+# at 256 the oracle's per-edge radial weights alone are 9.7 GB per pair type); c4's PCQM-like molecules at B=300, where
+# the cloud (8.9 k atoms) is past the 8 192-atom switch to the four-queries-per-wavefront neighbour search; c5
+# faformer_equihnns on the Molecule3D-like batch of 512 molecules (15 k atoms) in eval mode, forward only.
+ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 32, 2001, "qm9", 256, "train"),
+                    ("egnn_equihnns", 256, 2000, "qm9", 256, "train"), ("equiformer_equihnns", 8, 3000, "qm9", 256, "train"),
+                    ("equiformer_equihnns", 128, 3001, "qm9", 64, "train"),
+                    ("egnn_equihnns", 300, 4000, "pcqm", 256, "train"),
+                    ("faformer_equihnns", 64, 5001, "pcqm", 256, "eval"),
+                    ("faformer_equihnns", 512, 5000, "pcqm", 256, "eval-forward")]
+
+
+@pytest.mark.parametrize("method,bs,seed,flavour,hidden,mode", ORACLE_WORKLOADS)
+def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed, flavour, hidden, mode):
     from equihgnn_amd.batch import synth_batch
     from equihgnn_amd.registry import default_args
     torch.manual_seed(0)
-    args = default_args(method=method)
+    args = default_args(method=method, MLP_hidden=hidden, output_hidden=hidden // 2)
     ref = O.MODELS[method](1, args)
     fill_state_dict(ref, seed)
     mine = _models()[method](1, args)
     mine.load_state_dict(ref.state_dict(), strict=True)
     mine.to(DEV)
-    data = synth_batch(bs, seed)
+    ref.train(mode == "train")
+    mine.train(mode == "train")
+    data = synth_batch(bs, seed, flavour)
+    d = data.to(DEV)
+    if mode == "eval-forward":
+        with torch.no_grad():
+            out_ref, out = ref(data), mine(d)
+        assert_close(out.cpu().numpy(), out_ref.numpy(), TOL, "out")
+        return
     out_ref = ref(data)
     loss_ref = torch.nn.functional.mse_loss(out_ref, data.y)
     loss_ref.backward()
-    d = data.to(DEV)
     out = mine(d)
     loss = torch.nn.functional.mse_loss(out, d.y)
     loss.backward()
@@ -191,16 +210,62 @@ def test_padded_batch_is_exact(method):
             assert float((q.grad - g0[n]).abs().max()) / scale < (2e-3 if bn else 1e-4), n
 
 
-def test_graphed_train_step_matches_eager():
-    """hipGraph replay of forward+backward and of the Adam update reproduces eager training."""
+@pytest.mark.parametrize("variant", ["mlp3", "no_norm", "mhnn_mlp3"])
+def test_padded_batch_is_exact_on_the_unfused_incidence_path(variant):
+    """The per-incidence MLPs leave the fused gather+add+ReLU+LN+reduce kernel when they have three layers or no
+    LayerNorm (layers._pair_message): then the [nnz, C] tensor exists, padded (null) incidences are rows of it, and
+    their gradient must be ZERO (hg_segment_reduce_f32 reads index -1 as a zero row) -- or the hidden Linear's weights,
+    biases and the LayerNorm vectors pick up contributions from row 0."""
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    kw = dict(MLP_hidden=64, output_hidden=32)
+    method = "egnn_equihnns"
+    if variant == "mlp3":
+        kw.update(MLP1_num_layers=3, MLP2_num_layers=3, MLP3_num_layers=3)
+    elif variant == "no_norm":
+        kw.update(normalization="None")
+    else:
+        method = "mhnn"
+        kw.update(MLP1_num_layers=3, MLP2_num_layers=3, MLP3_num_layers=3, MLP4_num_layers=3)
+    m = _models()[method](1, default_args(method=method, **kw))
+    fill_state_dict(m, 19)
+    m.to(DEV)
+    b = synth_batch(12, 4343)
+    n, mm, z = bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64)
+    p = pad_batch(b, n, mm, z + 64).to(DEV)             # plenty of null incidences
+    p.num_real_graphs = 12
+    b = b.to(DEV)
+    out = m(b)
+    torch.nn.functional.mse_loss(out, b.y).backward()
+    g0 = {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
+    for q in m.parameters():
+        q.grad = None
+    outp = m(p)
+    torch.nn.functional.mse_loss(outp[:12], p.y[:12]).backward()
+    np.testing.assert_allclose(outp[:12].detach().cpu().numpy(), out.detach().cpu().numpy(), atol=2e-6, rtol=1e-6)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k, q in m.named_parameters():
+        if k in g0:
+            scale = max(float(g0[k].abs().max()), 1e-3 * gmax) + 1e-12
+            assert float((q.grad - g0[k]).abs().max()) / scale < 1e-4, k
+
+
+@pytest.mark.parametrize("method", ["egnn_equihnns", "mhnnm", "egnn_equihnnm", "equiformer_equihnns", "faformer_equihnns",
+                                    "mhnns", "mhnn"])
+def test_graphed_train_step_matches_eager(method):
+    """hipGraph replay of forward+backward and of the Adam update reproduces eager training, for every method
+    bench.py steps through GraphedTrainStep -- parameters AND buffers (the BatchNorm running statistics of mhnnm /
+    egnn_equihnnm move once per optimiser step, not once per probe / warm-up / capture pass)."""
     import copy
 
+    from common import zero_dropouts
     from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
     from equihgnn_amd.registry import default_args
     from equihgnn_amd.trainer import GraphedTrainStep
-    args = default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32)
-    m1 = _models()["egnn_equihnns"](1, args)
+    args = default_args(method=method, MLP_hidden=64, output_hidden=32)
+    m1 = _models()[method](1, args)
     fill_state_dict(m1, 3)
+    zero_dropouts(m1)           # FAFormer's 0.1 dropouts are random in training mode
     m1.to(DEV)
     m2 = copy.deepcopy(m1)
     raw = [synth_batch(8, 900 + i) for i in range(4)]
@@ -212,7 +277,6 @@ def test_graphed_train_step_matches_eager():
     tr = GraphedTrainStep(m1, lr=1e-3)
     losses = [float(tr.step(padded[i % 4])) for i in range(6)]
     assert len(tr.slots) == 1
-    live = [p for p in m2.parameters()]
     opt = None
     ref_losses = []
     for i in range(6):
@@ -226,9 +290,48 @@ def test_graphed_train_step_matches_eager():
             opt = torch.optim.Adam([p for p in m2.parameters() if p.grad is not None], lr=1e-3)
         opt.step()
         ref_losses.append(float(loss))
-    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5, atol=1e-6)
+    bn = method in ("mhnnm", "egnn_equihnnm")
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-4 if bn else 2e-5, atol=1e-6)
     for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
-        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=2e-5, rtol=1e-4, err_msg=n)
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=1e-4 if bn else 2e-5,
+                                   rtol=1e-3 if bn else 1e-4, err_msg=n)
+    for (n, p), q in zip(m1.named_buffers(), m2.buffers()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), atol=1e-5, rtol=1e-4, err_msg=n)
+    # the accumulators belong to the trainer: after close() an ordinary backward reaches every live parameter again
+    tr.close()
+    assert not any(hasattr(p, "_eqh_gbuf") for p in m1.parameters())
+    for p in m1.parameters():
+        p.grad = None
+    b = padded[0]
+    b._hyper_index = None
+    torch.nn.functional.mse_loss(m1(b)[:8], b.y[:8]).backward()
+    assert sorted(n for n, p in m1.named_parameters() if p.grad is not None) == \
+        sorted(n for n, p in m2.named_parameters() if p.grad is not None)
+
+
+def test_second_trainer_on_the_same_model_trains_every_parameter():
+    """A new GraphedTrainStep on a model an earlier one had set up: stale accumulators must not swallow gradients
+    (they would leave p.grad None and drop the parameter from the new trainer's live set)."""
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+    m = _models()["egnn_equihnns"](1, default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32))
+    fill_state_dict(m, 4)
+    m.to(DEV)
+    b = synth_batch(8, 950)
+    p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64)).to(DEV)
+    p.num_real_graphs = 8
+    t1 = GraphedTrainStep(m, lr=1e-3)
+    for _ in range(3):
+        t1.step(p)
+    n_live = len(t1.live)
+    t2 = GraphedTrainStep(m, lr=1e-3)             # (t1 not closed on purpose)
+    before = {n: q.detach().clone() for n, q in m.named_parameters()}
+    for _ in range(3):
+        t2.step(p)
+    assert len(t2.live) == n_live
+    moved = [n for n, q in m.named_parameters() if not torch.equal(q.detach(), before[n])]
+    assert len(moved) == n_live
 
 
 def _two_rank_worker(rank, world, port, out_dir):

@@ -1,0 +1,158 @@
+"""BASELINE configs 4 and 5 at their FULL per-rank sizes, where the CPU oracle no longer fits (the reference's dense
+[N, N] neighbour search needs > 10 GB at 31 k atoms): size-independent properties of the HIP models on the very
+batches bench.py times -- PCQM4Mv2-like molecules, batch 1024 (egnn_equihnns; ~31 k atoms: cell-grid neighbour
+search, chip-wide CSR build for the 67 k incidences and the 490 k-entry transposed neighbour graph) and
+Molecule3D-like molecules, batch 512 (faformer_equihnns; ~15 k atoms: four-queries-per-wavefront search)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from common import fill_state_dict  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _setup(method, bs, seed, train=True):
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.registry import default_args
+    m = MODELS[method](1, default_args(method=method))
+    fill_state_dict(m, seed)
+    m.to(DEV).train(train)
+    return m, synth_batch(bs, seed, "pcqm")
+
+
+def _run(m, b, grads=True):
+    b._hyper_index = None
+    for p in m.parameters():
+        p.grad = None
+    out = m(b)
+    g = {}
+    if grads:
+        torch.nn.functional.mse_loss(out[: b.y.shape[0]], b.y).backward()
+        g = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    return out.detach().clone(), g
+
+
+def _np_csr(key, n_rows):
+    order = np.argsort(key, kind="stable")
+    rowptr = np.zeros(n_rows + 1, np.int64)
+    np.add.at(rowptr, key + 1, 1)
+    return np.cumsum(rowptr), order
+
+
+def test_c4_batch_index_structures_are_exact():
+    """The per-batch index build at the config-4 size: both incidence CSRs and the transposed neighbour graph
+    bit-identical to a stable sort (these exceed the 32 Ki-entry single-workgroup builder), neighbour lists of the
+    cell-grid search bit-identical to the brute-force kernel and -- on a sample of queries -- to a float64-free
+    restatement of the reference's arithmetic (squared distances (dx^2+dy^2)+dz^2 in fp32, ties by lower index)."""
+    from equihgnn_amd import ops
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.index import HyperIndex
+    b = synth_batch(1024, 4000, "pcqm")
+    N, M, nnz = b.num_nodes, b.num_hyperedges, b.nnz
+    assert N > ops.KNN_GRID_MIN_POINTS and nnz > 32768
+    d = b.to(DEV)
+    ix = HyperIndex.from_batch(d)
+    v, e = b.edge_index0.numpy(), b.edge_index1.numpy()
+    for csr, key, other, rows in ((ix.by_e, e, v, M), (ix.by_v, v, e, N)):
+        rp, perm = _np_csr(key, rows)
+        assert np.array_equal(csr.rowptr.cpu().numpy(), rp)
+        assert np.array_equal(csr.perm.cpu().numpy(), perm)
+        assert np.array_equal(csr.col.cpu().numpy(), other[perm])
+    nbr, d2, csr_t = ix.knn(d.pos, 16, 0)                       # auto -> grid at this size
+    nbr_b, d2_b = ops.knn(d.pos, 16, 0, algorithm="brute")
+    assert torch.equal(nbr, nbr_b) and torch.equal(d2, d2_b)
+    rp, perm = _np_csr(nbr.cpu().numpy().reshape(-1).astype(np.int64), N)
+    assert np.array_equal(csr_t.rowptr.cpu().numpy(), rp) and np.array_equal(csr_t.perm.cpu().numpy(), perm)
+    pos = b.pos.numpy()
+    for q in np.random.default_rng(0).integers(0, N, 64):
+        dx = (pos[q, 0] - pos[:, 0]).astype(np.float32)
+        dy = (pos[q, 1] - pos[:, 1]).astype(np.float32)
+        dz = (pos[q, 2] - pos[:, 2]).astype(np.float32)
+        dd = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) + (dz * dz).astype(np.float32)
+        order = np.lexsort((np.arange(N), dd))[:16]
+        assert np.array_equal(nbr[q].cpu().numpy(), order), q
+        assert np.array_equal(d2[q].cpu().numpy(), dd[order])
+
+
+def test_c4_full_batch_properties():
+    """egnn_equihnns, PCQM-like, 1024 molecules, hidden 256, training mode: bitwise run-to-run reproducibility of
+    outputs and gradients (no atomics anywhere), grid and brute-force neighbour search give the same model output
+    bit for bit, padding to hipGraph bucket shapes leaves outputs and gradients unchanged, a permutation of the
+    incidence list and a rigid motion of the coordinates change the outputs by rounding only."""
+    from equihgnn_amd import ops
+    from equihgnn_amd.batch import HBatch, bucket_sizes, pad_batch
+    m, b = _setup("egnn_equihnns", 1024, 4000)
+    d = b.to(DEV)
+    out, g = _run(m, d)
+    assert out.shape == (1024,) and bool(torch.isfinite(out).all())
+    out2, g2 = _run(m, d)
+    assert torch.equal(out, out2)
+    assert set(g) == set(g2) and all(torch.equal(g[n], g2[n]) for n in g)
+    assert "egnn_layer.coors_mlp.0.weight" not in g and "conv.W2.lins.0.weight" in g
+    saved = ops.KNN_GRID_MIN_POINTS
+    try:
+        ops.KNN_GRID_MIN_POINTS = 1 << 30                       # force the brute-force kernel
+        out_b, _ = _run(m, d, grads=False)
+    finally:
+        ops.KNN_GRID_MIN_POINTS = saved
+    assert torch.equal(out, out_b)
+    p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz)).to(DEV)
+    p.num_real_graphs = 1024
+    out_p, g_p = _run_padded(m, p, 1024)
+    scale = float(out.abs().max())
+    np.testing.assert_allclose(out_p[:1024].cpu().numpy(), out.cpu().numpy(), atol=2e-6 * max(1.0, scale), rtol=0)
+    gmax = max(float(t.abs().max()) for t in g.values())
+    for n in g:
+        assert float((g_p[n] - g[n]).abs().max()) <= 1e-4 * max(float(g[n].abs().max()), 1e-3 * gmax), n
+    # incidence order: the reference's scatter is order-independent up to fp32 rounding
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(b.nnz))
+    bp = HBatch(**{f: getattr(b, f) for f in b.__dataclass_fields__})
+    bp.edge_index0, bp.edge_index1 = b.edge_index0[perm], b.edge_index1[perm]
+    out_perm, _ = _run(m, bp.to(DEV), grads=False)
+    np.testing.assert_allclose(out_perm.cpu().numpy(), out.cpu().numpy(), atol=1e-5 * max(1.0, scale), rtol=0)
+    # rigid motion; the neighbour sets may change where two candidates are within rounding
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(0)))
+    br = HBatch(**{f: getattr(b, f) for f in b.__dataclass_fields__})
+    br.pos = b.pos @ q + torch.tensor([0.5, -1.0, 0.25])
+    out_r, _ = _run(m, br.to(DEV), grads=False)
+    err = (out_r - out).abs().cpu().numpy()
+    assert np.median(err) < 2e-5 * max(1.0, scale) and (err < 5e-4 * max(1.0, scale)).mean() > 0.98
+
+
+def _run_padded(m, p, n_real):
+    for q in m.parameters():
+        q.grad = None
+    p._hyper_index = None
+    out = m(p)
+    torch.nn.functional.mse_loss(out[:n_real], p.y[:n_real]).backward()
+    return out.detach(), {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}
+
+
+def test_c5_full_batch_properties():
+    """faformer_equihnns, Molecule3D-like, 512 molecules, hidden 256, eval mode (its dropouts are random in training
+    mode): reproducible bit for bit, unchanged by padding, and invariant to a rigid motion."""
+    from equihgnn_amd.batch import HBatch, bucket_sizes, pad_batch
+    m, b = _setup("faformer_equihnns", 512, 5000, train=False)
+    d = b.to(DEV)
+    assert b.num_nodes > 8192
+    out, g = _run(m, d)
+    out2, g2 = _run(m, d)
+    assert bool(torch.isfinite(out).all()) and torch.equal(out, out2)
+    assert all(torch.equal(g[n], g2[n]) for n in g)
+    p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz)).to(DEV)
+    p.num_real_graphs = 512
+    with torch.no_grad():
+        p._hyper_index = None
+        out_p = m(p)
+    scale = max(1.0, float(out.abs().max()))
+    np.testing.assert_allclose(out_p[:512].cpu().numpy(), out.cpu().numpy(), atol=1e-5 * scale, rtol=0)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))
+    br = HBatch(**{f: getattr(b, f) for f in b.__dataclass_fields__})
+    br.pos = b.pos @ q + torch.tensor([-0.5, 2.0, 0.75])
+    out_r, _ = _run(m, br.to(DEV), grads=False)
+    err = (out_r - out).abs().cpu().numpy()
+    assert np.median(err) < 5e-5 * scale and (err < 2e-3 * scale).mean() > 0.98
