@@ -91,8 +91,14 @@ class SwiGLUMLP(nn.Module):
 def _frame_axes(x, mask=None):
     """Centre and eigenvectors of the (masked) covariance — create_frame, :86-113.  x [B,P,3].
     Returns y = (x - c·mask)·V [B,P,3], V [B,3,3], centre [B,3]; no gradient through V (:98-99)."""
+    # A cloud-wide frame (the FFN's: one point set of N atoms) sums over ~15 k points at the Molecule3D batch size, and
+    # its eigenvalues lie within 3 % of each other (molecules of all orientations overlap around the origin): fp32
+    # accumulation of the centroid / covariance (1e-6 relative) turns the eigenvectors by 1e-4 rad, 5e-5 of the
+    # feature scale at batch 512.  Those two reductions are therefore accumulated in float64 (3 x N numbers).
+    wide = x.shape[1] > 64
+    acc = torch.float64 if wide else x.dtype
     if mask is None:
-        center = x.mean(1)
+        center = x.to(acc).mean(1).to(x.dtype)
         xc = x - center.unsqueeze(1)
         xm = xc
     else:
@@ -102,11 +108,12 @@ def _frame_axes(x, mask=None):
         # a point set with NO valid member (the far-away atoms of a padded batch: every neighbour is beyond the
         # radius) gets centre 0 instead of the reference's 0/0 = NaN, which would leak into the weight
         # gradients through 0 * NaN
-        center = torch.where(keep, x, zero).sum(1) / m.sum(1).clamp(min=1.0)  # (where, not *: masked rows may
+        center = (torch.where(keep, x, zero).to(acc).sum(1) / m.to(acc).sum(1).clamp(min=1.0)).to(x.dtype)  # (where, not *: masked rows may
         xc = x - center.unsqueeze(1) * m                                   #  hold anything; they keep raw x, :94)
         xm = torch.where(keep, xc, zero)
     with torch.no_grad():
-        vec = ops.eigh3(torch.bmm(xm.transpose(1, 2), xm))                 # geo_eigh3 (csrc/eigh3.hip)
+        xa = xm.to(acc)
+        vec = ops.eigh3(torch.bmm(xa.transpose(1, 2), xa).to(x.dtype))     # geo_eigh3 (csrc/eigh3.hip)
     return torch.bmm(xc, vec), vec, center
 
 
@@ -189,9 +196,10 @@ class MLPAttnEdgeAggregation(nn.Module):
         # geometric context: with the reference's frame-0 gather (module docstring) the signed frame
         # average cancels and what is left is the centroid of the cloud, for every atom
         if row_mask is None:
-            centre = geo.mean(0, keepdim=True)
+            centre = geo.double().mean(0, keepdim=True).to(geo.dtype)       # (float64 accumulation over the cloud, see _frame_axes)
         else:   # padded batch (hipGraph replay): the centroid of the real atoms
-            centre = torch.where(row_mask > 0, geo, geo.new_zeros(())).sum(0, keepdim=True) / row_mask.sum()
+            centre = (torch.where(row_mask > 0, geo, geo.new_zeros(())).double().sum(0, keepdim=True)
+                      / row_mask.double().sum()).to(geo.dtype)
         # W_frame_agg multiplies the cancelled term: its gradient is rounding noise in the reference;
         # keep it in the autograd graph with an exactly-zero contribution so it gets a (zero) gradient
         # like there, instead of None

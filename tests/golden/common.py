@@ -112,21 +112,40 @@ def case_spec(name: str) -> dict:
     return spec
 
 
+def _kth_neighbour_ties(pos: np.ndarray, k: int = 16) -> int:
+    """Rows whose k-th and (k+1)-th nearest other points are exactly equidistant in fp32 (torch.topk's pick among
+    them is implementation-defined, so a fixture must not contain such rows)."""
+    n = pos.shape[0]
+    bad = 0
+    for i in range(n):
+        d = pos[i] - pos
+        dd = ((d[:, 0] * d[:, 0]).astype(np.float32) + (d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32)
+        dd = np.sqrt((dd + (d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        dd[i] = np.inf
+        srt = np.sort(dd)
+        bad += int(n > k + 1 and srt[k - 1] == srt[k])
+    return bad
+
+
 def degenerate_positions(pos: np.ndarray, batch: np.ndarray) -> np.ndarray:
     """Edit a batch's coordinates so that the Equiformer's neighbour graph contains the cases
     rot_x_to_y_direction treats specially (equiformer/basis.py:169-191): two coincident atoms (rel_pos = 0),
     one edge along exactly -y (and its reverse, exactly +y), and edges 2e-4 .. 9e-4 rad away from -y, inside
-    the |x_hat + y_hat|^2 < 1e-6 clamp.  Deterministic; atoms 1.. of molecule 0 and 1 are moved."""
-    pos = pos.copy()
+    the |x_hat + y_hat|^2 < 1e-6 clamp.  Deterministic; atoms of molecules 0 and 1 are moved.  The coincident pair is
+    the first one (scanning molecule 0) that leaves NO atom with the two copies tied at its 16th-neighbour boundary."""
     first = lambda b: int(np.flatnonzero(batch == b)[0])
-    a = first(0)
-    pos[a + 1] = pos[a]                                                  # coincident pair
-    pos[a + 3] = pos[a + 2] + np.array([0.0, -1.25, 0.0], np.float32)    # exactly along -y (x, z bit-equal)
-    c = first(1)
-    pos[c + 1] = pos[c] + np.array([3.0e-4, -1.3, 2.0e-4], np.float32)   # s = |x_hat + y_hat|^2 ~ 7.7e-8
-    pos[c + 3] = pos[c + 2] + np.array([-6.0e-4, -1.2, 4.0e-4], np.float32)   # s ~ 3.6e-7 (largest deviation)
-    pos[c + 5] = pos[c + 4] + np.array([9.0e-4, -1.1, -6.0e-4], np.float32)   # s ~ 9.7e-7 (just inside)
-    return pos.astype(np.float32)
+    a, c = first(0), first(1)
+    for shift in range(6):
+        out = pos.copy()
+        out[a + shift + 1] = out[a + shift]                                                  # coincident pair
+        out[a + (shift + 3) % 8] = out[a + (shift + 2) % 8] + np.array([0.0, -1.25, 0.0], np.float32)   # exactly -y
+        out[c + 1] = out[c] + np.array([3.0e-4, -1.3, 2.0e-4], np.float32)                   # s = |x_hat + y_hat|^2 ~ 7.7e-8
+        out[c + 3] = out[c + 2] + np.array([-6.0e-4, -1.2, 4.0e-4], np.float32)              # s ~ 3.6e-7 (largest deviation)
+        out[c + 5] = out[c + 4] + np.array([9.0e-4, -1.1, -6.0e-4], np.float32)              # s ~ 9.7e-7 (just inside)
+        out = out.astype(np.float32)
+        if _kth_neighbour_ties(out) == 0:
+            return out
+    raise RuntimeError("degenerate_positions: no tie-free placement found")
 
 
 def make_batch(spec_or_seed, n_mols=None, flavour="qm9", with_isolated=True, last_conj=True, big=None,

@@ -1114,16 +1114,26 @@ def test_edge_geometry_matches_oracle_on_a_cloud(N, K):
     pos = (g.standard_normal((N, 3)) * (1.5 if N < 1000 else 6.0)).astype(np.float32)
     pos[1] = pos[0]
     pos[3] = pos[2] + np.array([0, -0.9, 0], np.float32)
-    if N > 100:
-        pos[-20:] = (1.0e3 + 10.0 * np.arange(20))[:, None].astype(np.float32)
+    if N > 100:   # a far-away group, jittered (equidistant points would tie at the 16th-neighbour boundary)
+        pos[-20:] = (1.0e3 + 10.0 * np.arange(20))[:, None].astype(np.float32) + g.standard_normal((20, 3)).astype(np.float32)
     p = torch.from_numpy(pos)
     idx, dist, rel, mask = neighbours_self_excluded(p, K, 5.0)
     nbr_d, dist_d = ops.knn(p.to(DEV), K, 1)
-    assert np.array_equal(np.sort(nbr_d.cpu().numpy(), 1), np.sort(idx.numpy(), 1))
+    # rows whose K-th and (K+1)-th candidates are exactly equidistant (every atom sees the coincident pair at one
+    # distance) are decided by a tie rule, which torch.topk does not define: the sets are compared on the others
+    full = (p[:, None, :] - p[None, :, :]).norm(dim=-1)
+    full.fill_diagonal_(float("inf"))
+    srt = full.sort(dim=1).values
+    clear = (srt[:, K - 1] != srt[:, K]).numpy() if N > K + 1 else np.ones(N, bool)
+    assert clear.sum() >= N - 8
+    assert np.array_equal(np.sort(nbr_d.cpu().numpy(), 1)[clear], np.sort(idx.numpy(), 1)[clear])
     rhat, maskf, mean_w, mwr = ops.edge_geometry(p.to(DEV), nbr_d, dist_d, 5.0)
     nb = nbr_d.cpu().long()
     want = wigner_d1_to_y(p[:, None, :] - p[nb])[..., :, 1]
-    np.testing.assert_allclose(rhat.cpu().numpy().reshape(N, K, 3), want.numpy(), atol=2e-6, rtol=0)
+    # 1e-5: the reference's round trip b = acos(v_y), sin(b) is ill-conditioned for directions near +-y (an fp32 ulp of
+    # v_y moves sin b by 6e-8 / sin b), so two correct libm implementations differ by a few 1e-6 there; the D fixture
+    # test above holds the generic and the degenerate directions to 2e-6
+    np.testing.assert_allclose(rhat.cpu().numpy().reshape(N, K, 3), want.numpy(), atol=1e-5, rtol=0)
     m = (dist_d.cpu() <= 5.0).float()
     cnt = m.sum(1, keepdim=True)
     assert torch.equal(maskf.cpu(), m)
