@@ -69,6 +69,7 @@ def parse():
     p.add_argument("--c4-steps", type=int, default=10,
                    help="timed steps of the strong-scaling BASELINE config 4 leg (PCQM-like, global batch 1024); 0 = skip")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-pipeline", action="store_true", help="skip the loader-fed run (`pipeline` in the JSON line)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--timeline-replays", type=int, default=30,
@@ -148,6 +149,48 @@ def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
         d["work"] += work
         d["us"] += max(us - floor, 0.05)
     return per, floor
+
+
+def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=6, batches_per_epoch=12):
+    """The same training step fed by the data pipeline instead of a resident pool: a MolStore of synthetic molecules,
+    `fit.BucketedLoader` (array-operation collate into pinned packed staging buffers on a prefetch thread, one
+    static bucket per epoch, one asynchronous host-to-device copy per batch) and GraphedTrainStep.  The first epoch
+    captures; the following ones are timed.  Also the loader's own single-thread collate rate."""
+    import numpy as np
+
+    from equihgnn_amd.batch import MolStore, synth_molecule
+    from equihgnn_amd.fit import BucketedLoader
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+
+    rng = np.random.default_rng(4242 + rank)
+    store = MolStore([synth_molecule(rng, flavour) for _ in range(batch_size * batches_per_epoch)])
+    ns = default_args(method=method, batch_size=batch_size)
+    torch.manual_seed(0)
+    model = MODELS[method](1, ns).to(dev)
+    tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
+    loader = BucketedLoader(store, batch_size, True, seed=1, device=dev)
+    for b in loader:                     # epoch 0: eager bootstrap + capture
+        tr.step(b)
+    torch.cuda.synchronize(dev)
+    c0, s0 = loader.collated, loader.collate_seconds
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(epochs - 1):
+        for b in loader:
+            tr.step(b)
+            n += b.num_real_graphs
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    n_graphs = len(tr.slots)
+    tr.close()
+    return {"value": round(n / el, 1), "unit": "molecules/s", "ms_per_step": round(el / (n / batch_size) * 1e3, 3),
+            "what": "training steps fed by MolStore -> BucketedLoader (prefetch thread, pinned packed staging, one H2D "
+                    "copy per batch) -> GraphedTrainStep; PCIe transfer and host collate included",
+            "graphs_captured": n_graphs,
+            "host_collate_molecules_per_s": round((loader.collated - c0) / max(loader.collate_seconds - s0, 1e-9), 1),
+            "host_collate_threads": 1}
 
 
 def scatter_roofline(per, floor):
@@ -519,6 +562,8 @@ def main():
             if world == 1:
                 result["roofline"]["back_to_back"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
                 result["roofline"]["saturation"] = saturation_probe(dev)
+        if not a.no_pipeline and use_graph and world == 1:
+            result["pipeline"] = measure_pipeline(a.method, a.batch, a.flavour, dev, rank)
         if world == 1 and not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(a.method, run_args, host_batches[0], a.cpu_seconds)
     if world > 1:

@@ -87,6 +87,27 @@ class HBatch:
             getattr(out, n).copy_(getattr(self, n))
         return out
 
+    @classmethod
+    def empty_packed(cls, n_nodes: int, n_hyperedges: int, n_inc: int, n_graphs: int, pin: bool = False) -> "HBatch":
+        """An uninitialised packed host batch of the given extents (one flat buffer, optionally pinned): the staging
+        buffer a loader thread collates into and the trainer's static inputs are refreshed from with ONE copy."""
+        spec = (("x", (n_nodes, 9), torch.int64), ("pos", (n_nodes, 3), torch.float32),
+                ("edge_index0", (n_inc,), torch.int64), ("edge_index1", (n_inc,), torch.int64),
+                ("edge_attr", (n_hyperedges, 1), torch.int64), ("n_e", (n_graphs,), torch.int64),
+                ("e_order", (n_hyperedges,), torch.int64), ("batch", (n_nodes,), torch.int64),
+                ("y", (n_graphs,), torch.float32))
+        layout, total = [], 0
+        for name, shape, dtype in spec:
+            layout.append((name, total, tuple(shape), dtype))
+            nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            total += (nbytes + 255) // 256 * 256
+        flat = torch.empty(max(total, 256), dtype=torch.uint8)
+        if pin:
+            flat = flat.pin_memory()
+        proto = cls(**{name: torch.empty(0) for name, _, _ in spec}, num_nodes=n_nodes, num_hyperedges=n_hyperedges,
+                    num_graphs=n_graphs)
+        return proto._from_flat(flat, tuple(layout))
+
     def _from_flat(self, flat, layout) -> "HBatch":
         kw = {f.name: getattr(self, f.name) for f in fields(self) if not torch.is_tensor(getattr(self, f.name))}
         for n, off, shape, dtype in layout:
@@ -160,6 +181,99 @@ def collate(mols: Sequence[HMol]) -> HBatch:
         num_hyperedges=m_off,
         num_graphs=len(mols),
     )
+
+
+class MolStore:
+    """A dataset of molecules as a structure of arrays -- the concatenated fields plus per-molecule offsets -- so
+    that a batch is assembled by array operations only (numpy gathers driven by ``cumsum`` offsets): no Python loop
+    over molecules, which at 256-1024 molecules per batch and > 100 k molecules/s per GPU would be the bottleneck of
+    the whole training step (the reference leaves this to PyG's ``Batch.from_data_list``, a per-molecule loop).
+    Field semantics as HBatch / HData (data/utils.py:150-178)."""
+
+    def __init__(self, mols: Sequence[HMol]):
+        n = np.array([m.x.shape[0] for m in mols], dtype=np.int64)
+        h = np.array([m.edge_attr.shape[0] for m in mols], dtype=np.int64)
+        z = np.array([m.edge_index0.shape[0] for m in mols], dtype=np.int64)
+        off = lambda c: np.concatenate(([0], np.cumsum(c)))
+        self.n_nodes, self.n_he, self.n_inc = n, h, z
+        self.node_off, self.he_off, self.inc_off = off(n), off(h), off(z)
+        cat = lambda xs, dt, shape: (np.concatenate(xs, 0).astype(dt) if len(xs) else np.zeros(shape, dt))
+        self.x = cat([m.x for m in mols], np.int64, (0, 9))
+        self.pos = cat([m.pos for m in mols], np.float32, (0, 3))
+        self.v = cat([m.edge_index0 for m in mols], np.int64, (0,))          # local node ids
+        self.e = cat([m.edge_index1 for m in mols], np.int64, (0,))          # local hyperedge ids
+        self.edge_attr = cat([m.edge_attr for m in mols], np.int64, (0, 1))
+        self.e_order = cat([m.e_order for m in mols], np.int64, (0,))
+        self.y = np.array([m.y for m in mols], dtype=np.float32)
+
+    def __len__(self) -> int:
+        return int(self.n_nodes.shape[0])
+
+    def extents(self, idx) -> tuple:
+        """(nodes, hyperedges, incidences) of the batch made of molecules ``idx``."""
+        idx = np.asarray(idx, dtype=np.int64)
+        return int(self.n_nodes[idx].sum()), int(self.n_he[idx].sum()), int(self.n_inc[idx].sum())
+
+    @staticmethod
+    def _ranges(starts, counts):
+        """Concatenation of arange(starts[i], starts[i] + counts[i]) and the owner i of every element."""
+        total = int(counts.sum())
+        owner = np.repeat(np.arange(counts.shape[0], dtype=np.int64), counts)
+        first = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        return starts[owner] + (np.arange(total, dtype=np.int64) - first[owner]), owner
+
+    def collate(self, idx, pad_to: Optional[tuple] = None, out: Optional["HBatch"] = None) -> "HBatch":
+        """The batch of molecules ``idx`` (HData.__inc__ offsets, data/utils.py:172-178), optionally padded to the
+        static extents ``pad_to`` = (nodes, hyperedges, incidences) exactly as ``pad_batch`` does (one dummy molecule
+        owns the padding, padded incidences are null), optionally written into the tensors of ``out`` (a packed,
+        pinned staging batch of those extents)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        B = idx.shape[0]
+        n, h, z = self.n_nodes[idx], self.n_he[idx], self.n_inc[idx]
+        src_n, own_n = self._ranges(self.node_off[idx], n)
+        src_h, _ = self._ranges(self.he_off[idx], h)
+        src_z, own_z = self._ranges(self.inc_off[idx], z)
+        N, M, Z = src_n.shape[0], src_h.shape[0], src_z.shape[0]
+        node_base = np.concatenate(([0], np.cumsum(n)[:-1]))
+        he_base = np.concatenate(([0], np.cumsum(h)[:-1]))
+        if pad_to is None:
+            PN, PM, PZ, PB = N, M, Z, B
+        else:
+            PN, PM, PZ = (int(v) for v in pad_to)
+            PB = B + 1
+            if PN <= N or PM <= M or PZ < Z:
+                raise ValueError("collate: pad_to must exceed the batch (nodes and hyperedges strictly)")
+        if out is None:
+            t = lambda shape, dt: torch.empty(shape, dtype=dt)
+            out = HBatch(x=t((PN, 9), torch.int64), pos=t((PN, 3), torch.float32), edge_index0=t((PZ,), torch.int64),
+                         edge_index1=t((PZ,), torch.int64), edge_attr=t((PM, 1), torch.int64), n_e=t((PB,), torch.int64),
+                         e_order=t((PM,), torch.int64), batch=t((PN,), torch.int64), y=t((PB,), torch.float32))
+        a = lambda name: getattr(out, name).numpy()
+        a("x")[:N] = self.x[src_n]
+        a("pos")[:N] = self.pos[src_n]
+        a("batch")[:N] = own_n
+        a("edge_index0")[:Z] = self.v[src_z] + node_base[own_z]
+        a("edge_index1")[:Z] = self.e[src_z] + he_base[own_z]
+        a("edge_attr")[:M] = self.edge_attr[src_h]
+        a("e_order")[:M] = self.e_order[src_h]
+        a("n_e")[:B] = h
+        a("y")[:B] = self.y[idx]
+        if pad_to is not None:
+            pn = PN - N
+            a("x")[N:] = 0
+            far = a("pos")[N:]
+            far[:] = 0.0
+            far[:, 0] = 1.0e4 + 10.0 * np.arange(pn, dtype=np.float32)      # as pad_batch: 10 A apart, 10^4 A away
+            a("batch")[N:] = B
+            a("edge_index0")[Z:] = -1
+            a("edge_index1")[Z:] = -1
+            a("edge_attr")[M:] = 0
+            a("e_order")[M:] = 0
+            a("n_e")[B] = PM - M
+            a("y")[B] = 0.0
+            out.num_real_graphs = B
+        out.num_nodes, out.num_hyperedges, out.num_graphs = PN, PM, PB
+        return out
 
 
 def bucket_sizes(n_nodes: int, n_hyperedges: int, n_inc: int, quantum: int = 128):

@@ -104,6 +104,20 @@ CASE_TABLE = {
 }
 
 
+# Training trajectories: the reference's own step -- forward, nn.MSELoss, backward,
+# Adam(model.parameters(), lr, weight_decay) (main.py:36,49-63,137-140) -- over `steps` different batches.
+# name: (method, hidden, seed, n_mols, steps, lr); batch t is make_batch(seed + t, n_mols).
+TRAJECTORY_TABLE = {
+    "trajectory_egnn_equihnns_c64": ("egnn_equihnns", 64, 81, 6, 3, 1e-3),
+    "trajectory_mhnnm_c64": ("mhnnm", 64, 85, 6, 3, 1e-3),
+}
+
+
+def trajectory_batches(name: str):
+    method, hidden, seed, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    return [make_batch(seed + t, n_mols) for t in range(steps)]
+
+
 def case_spec(name: str) -> dict:
     method, hidden, seed, n_mols, train, store, opt = CASE_TABLE[name]
     spec = dict(name=name, method=method, hidden=hidden, seed=seed, n_mols=n_mols, train=train, store_grads=store,

@@ -27,7 +27,7 @@ REF = os.environ.get("EQUIHGNN_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
-from common import (CASE_TABLE, case_spec, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
+from common import (CASE_TABLE, TRAJECTORY_TABLE, case_spec, trajectory_batches, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
                     zero_dropouts)
 
 from equihgnn_amd.batch import ATOM_FEATURE_DIMS  # noqa: E402
@@ -296,6 +296,41 @@ def d_fixture():
     return {"rel_pos": rel.reshape(-1, 3).numpy(), "D1": D.reshape(-1, 3, 3).numpy()}
 
 
+def run_trajectory(registry, name):
+    """`steps` optimiser steps of the reference model as LitModel runs them (main.py:49-63,137-140)."""
+    method, hidden, seed, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    torch.manual_seed(0)
+    model = registry.get_model_class(method)(1, golden_args(method, hidden))
+    fill_state_dict(model, seed)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
+    losses, outs = [], []
+    for data in trajectory_batches(name):
+        opt.zero_grad(set_to_none=True)
+        out = model(data)
+        loss = torch.nn.MSELoss()(out, data.y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        outs.append(out.detach().numpy().copy())
+    case = {"meta_method": np.array(method), "meta_hidden": np.array(hidden), "meta_seed": np.array(seed),
+            "meta_lr": np.array(lr), "loss": np.array(losses, dtype=np.float64),
+            "out": np.stack([np.pad(o, (0, max(len(x) for x in outs) - len(o))) for o in outs]),
+            "out_len": np.array([len(o) for o in outs])}
+    names, norms = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        norms.append(float(p.detach().norm()))
+        if p.numel() <= 5000:
+            case["param_" + n] = p.detach().numpy().copy()
+    case["param_names"] = np.array(names)
+    case["param_norms"] = np.array(norms, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            case["buf_" + k] = v.numpy().copy()
+    return case
+
+
 def compare(case, stored, name):
     bad = []
     for k in sorted((set(case) | set(stored)) - {"meta_name"}):
@@ -317,7 +352,8 @@ def main(only=None, check=False):
     torch.set_num_threads(1)
     torch.use_deterministic_algorithms(True)
     names = [n for n in CASE_TABLE if only is None or n in only]
-    methods = {CASE_TABLE[n][0] for n in names}
+    traj = [n for n in TRAJECTORY_TABLE if only is None or n in only]
+    methods = {CASE_TABLE[n][0] for n in names} | {TRAJECTORY_TABLE[n][0] for n in traj}
     mods = []
     if methods & {"mhnnm", "mhnn", "mhnns"}:
         mods.append("mhnn")
@@ -339,6 +375,13 @@ def main(only=None, check=False):
         print(f"{name}: N={case['in_x'].shape[0]} M={case['in_edge_attr'].shape[0]} "
               f"nnz={case['in_edge_index0'].shape[0]} out[:3]={case['out'][:3]} "
               f"loss={float(case['loss']):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+    for name in traj:
+        case = run_trajectory(registry, name)
+        if check:
+            ok &= compare(case, load_case(name), name)
+        else:
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **case)
+            print(f"{name}: losses {case['loss']}")
     if only is None or "equiformer_D" in only:
         case = d_fixture()
         if check:

@@ -11,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--batch", "32", "--steps", "2", "--warmup", "1", "--pool", "2", "--no-roofline", "--no-cpu-baseline",
-         "--c4-steps", "0"]
+         "--no-pipeline", "--c4-steps", "0"]
 
 
 def _bench(args, env_extra=None, timeout=600):

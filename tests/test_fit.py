@@ -2,6 +2,7 @@
 down, the LR schedule / early stopping / best-checkpoint bookkeeping follow main.py:137-151,259-267,
 the target normalisation reproduces utils/data_split.py:67-72, bootstrapped metrics behave."""
 import numpy as np
+import pytest
 import torch
 
 import oracle  # noqa: F401
@@ -92,3 +93,86 @@ def test_packed_batch_is_a_view_of_one_buffer_and_survives_to():
     q = p.to("cpu")
     assert q._layout == p._layout and torch.equal(q.pos, b.pos) and q.num_real_graphs == b.num_real_graphs
     assert (q.num_nodes, q.num_hyperedges, q.num_graphs) == (b.num_nodes, b.num_hyperedges, b.num_graphs)
+
+
+def test_vectorised_collate_equals_loop_collate():
+    """MolStore.collate (array operations only) against the per-molecule collate and pad_batch, field by field,
+    including a batch that contains the zero-hyperedge one-atom molecule."""
+    from equihgnn_amd.batch import MolStore, bucket_sizes, collate, pad_batch
+    mols = _mols(200, 9)
+    lone = mols[17]
+    lone.x, lone.pos = lone.x[:1], lone.pos[:1]
+    lone.edge_index0, lone.edge_index1 = lone.edge_index0[:0], lone.edge_index1[:0]
+    lone.edge_attr, lone.e_order = lone.edge_attr[:0], lone.e_order[:0]
+    store = MolStore(mols)
+    rng = np.random.default_rng(1)
+    fields = ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order", "batch", "y")
+    for trial in range(4):
+        idx = rng.permutation(200)[: 33 + trial]
+        if trial == 0:
+            idx[5] = 17
+        ref = collate([mols[i] for i in idx])
+        got = store.collate(idx)
+        for f in fields:
+            assert torch.equal(getattr(ref, f), getattr(got, f)), f
+        assert store.extents(idx) == (ref.num_nodes, ref.num_hyperedges, ref.nnz)
+        tgt = bucket_sizes(ref.num_nodes, ref.num_hyperedges, ref.nnz, 64)
+        refp, gotp = pad_batch(ref, *tgt), store.collate(idx, pad_to=tgt)
+        for f in fields:
+            assert torch.equal(getattr(refp, f), getattr(gotp, f)), f
+        assert gotp.num_real_graphs == len(idx) and gotp.num_graphs == len(idx) + 1
+
+
+def test_bucketed_loader_static_shapes_and_coverage():
+    """One static bucket per epoch (plus the smaller last batch), every molecule exactly once per epoch, packed
+    staging buffers, DistributedSampler sharding across two ranks."""
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    mols = _mols(230, 4)
+    for i, m in enumerate(mols):
+        m.y = float(i)
+    store = MolStore(mols)
+    seen = []
+    for rank in range(2):
+        ld = BucketedLoader(store, 32, True, seed=5, device=None, rank=rank, world=2, prefetch=2)
+        shapes = set()
+        for b in ld:
+            nb = b.num_real_graphs
+            seen.extend(int(v) for v in b.y[:nb].tolist())
+            shapes.add((b.x.shape[0], b.edge_attr.shape[0], b.edge_index0.shape[0], b.y.shape[0]))
+            assert getattr(b, "_flat", None) is not None and int(b.batch[-1]) == nb
+        assert len({s[:3] for s in shapes}) == 1 and len(shapes) <= 2
+        assert ld.collated == 115 and ld.collate_seconds > 0
+    assert sorted(seen) == list(range(230))
+
+
+@pytest.mark.gpu
+def test_fit_two_epochs_on_graphed_step():
+    """fit() with the hipGraph-replayed step (GraphedTrainStep) fed by the bucketed prefetching loader: two epochs,
+    a handful of captured graphs at most, the loss goes down, the scheduler's learning rate reaches the device, and
+    evaluation on padded batches scores the real molecules only."""
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    mols = _mols(400, 6)
+    y, std = normalize_targets_like_reference(torch.tensor([m.y for m in mols]))
+    for m, v in zip(mols, y.tolist()):
+        m.y = v
+    tr, va, te = split_80_10_10(len(mols), seed=1)
+    pick = lambda ids: MolStore([mols[i] for i in ids])
+    args = default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32)
+    model = MODELS["egnn_equihnns"](1, args).to("cuda:0")
+    fitter = Fitter(model, lr=2e-3, std=std, patience_lr=0, patience_stop=5, step_factory=GraphedTrainStep)
+    train = BucketedLoader(pick(tr), 32, True, seed=0, device="cuda:0")
+    res = fitter.fit(train, BucketedLoader(pick(va), 32, False, device="cuda:0"), epochs=3)
+    h = res.history
+    assert len(h) == 3 and h[-1]["train_loss"] < h[0]["train_loss"] and np.isfinite(h[-1]["val_mae_mean"])
+    assert len(fitter.step.slots) <= 4                          # a few static shapes, not one per batch
+    assert train.collated == 3 * 320
+    fitter.step.opt.sync_lr()                                   # (the trainer does this before every replay)
+    assert abs(float(fitter.step.opt.state[fitter.step.pflat]["lr"]) - fitter.step.opt.param_groups[0]["lr"]) < 1e-9
+    assert fitter.step.opt.param_groups[0]["lr"] <= 2e-3
+    metrics, table = fitter.test(BucketedLoader(pick(te), 32, False, device="cuda:0"), res.best_state)
+    assert table.shape == (40, 2) and np.isfinite(metrics["test_mae_mean"])

@@ -1,0 +1,87 @@
+"""The training step as the reference's LitModel runs it (main.py:36,49-63,137-140: nn.MSELoss, Adam(lr, wd)) over
+several different batches: the loss trajectory, the per-step predictions and the parameters after the last step are
+pinned by fixtures captured from the REFERENCE (tests/golden/make_golden.py::run_trajectory).  CPU: the oracle through
+this repo's TrainStep harness.  GPU: the HIP models through TrainStep (eager) and GraphedTrainStep (hipGraph replay of
+padded batches).  Tolerances: predictions of step 0 at 1e-5 (north_star), losses at 1e-4, parameters at 2e-4 of an
+Adam step's scale after three steps."""
+import numpy as np
+import pytest
+import torch
+
+from common import TRAJECTORY_TABLE, assert_close, fill_state_dict, golden_args, load_case, trajectory_batches
+
+import oracle  # noqa: F401
+from oracle import ref_models as O
+
+
+# mhnnm: Adam's first step moves EVERY entry by lr * sign(g), and with train-mode BatchNorm over ~100 atoms many
+# entries have gradients at rounding level, so the summation order decides their sign.  The reference itself run with
+# 8 threads instead of 1 gives losses [0.98132765, 0.8224023, 1.18963242] against the fixture's (1 thread)
+# [0.98132843, 0.82215947, 1.18972552] -- 3e-4 apart; egnn_equihnns (LayerNorm) repeats to 3e-7.
+LOSS_RTOL = {"trajectory_mhnnm_c64": 1e-3}
+
+
+def _check(name, step_fn, model, batches, lr, n_real=None):
+    case = load_case(name)
+    losses = []
+    for t, b in enumerate(batches):
+        losses.append(float(step_fn(b)))
+    np.testing.assert_allclose(losses, case["loss"], rtol=LOSS_RTOL.get(name, 1e-4), atol=1e-5)
+    assert abs(losses[0] - case["loss"][0]) <= 1e-5 * max(1.0, case["loss"][0])      # before any update: forward parity
+    noisy = name in LOSS_RTOL
+    params = dict(model.named_parameters())
+    assert sorted(params) == sorted(str(n) for n in case["param_names"])
+    for n, norm in zip(case["param_names"], case["param_norms"]):
+        p = params[str(n)].detach().cpu()
+        if not noisy:
+            np.testing.assert_allclose(float(p.norm()), norm, rtol=1e-4, atol=1e-6, err_msg=str(n))
+        key = "param_" + str(n)
+        if key in case:      # three Adam steps move an entry by <= 3 lr: held to 2 % of that (sign-flipped noise
+            atol = (2.2 * 3 * lr) if noisy else (0.02 * 3 * lr + 1e-6)      # entries of the BatchNorm model: 2 lr per step)
+            np.testing.assert_allclose(p.numpy(), case[key], atol=atol, rtol=1e-4, err_msg=str(n))
+    for k, v in model.state_dict().items():
+        if "running_" in k:
+            np.testing.assert_allclose(v.cpu().numpy(), case["buf_" + k], atol=1e-2 if k.endswith("running_mean") else 1e-3,
+                                       rtol=1e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("name", list(TRAJECTORY_TABLE))
+def test_oracle_train_step_reproduces_reference_trajectory(name):
+    from equihgnn_amd.trainer import TrainStep
+    method, hidden, seed, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    case = load_case(name)
+    model = O.MODELS[method](1, golden_args(method, hidden))
+    fill_state_dict(model, seed)
+    model.train()
+    batches = trajectory_batches(name)
+    if not any("running_" in k for k in model.state_dict()):      # (a forward in train mode moves BatchNorm buffers)
+        with torch.no_grad():
+            out0 = model(batches[0])
+        assert_close(out0.numpy(), case["out"][0][: int(case["out_len"][0])], 1e-5, "step-0 predictions")
+    tr = TrainStep(model, lr=lr)
+    _check(name, tr.step, model, batches, lr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(TRAJECTORY_TABLE))
+@pytest.mark.parametrize("graphed", [False, True])
+def test_hip_train_step_reproduces_reference_trajectory(name, graphed):
+    from equihgnn_amd.batch import bucket_sizes, pad_batch
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.trainer import GraphedTrainStep, TrainStep
+    method, hidden, seed, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    model = MODELS[method](1, golden_args(method, hidden))
+    fill_state_dict(model, seed)
+    model.to("cuda:0").train()
+    batches = trajectory_batches(name)
+    if graphed:
+        ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64) for b in batches]
+        tgt = tuple(max(e[i] for e in ext) for i in range(3))
+        dev = [pad_batch(b, *tgt).to("cuda:0") for b in batches]
+        tr = GraphedTrainStep(model, lr=lr)
+    else:
+        dev = [b.to("cuda:0") for b in batches]
+        tr = TrainStep(model, lr=lr)
+    _check(name, tr.step, model, dev, lr)
+    if graphed:
+        assert len(tr.slots) == 1           # step 0 bootstraps eagerly, steps 1.. replay ONE captured graph
