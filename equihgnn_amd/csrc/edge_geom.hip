@@ -29,7 +29,7 @@ namespace {
 __global__ void __launch_bounds__(256)
 k_edge_geom(const float* __restrict__ pos, const int* __restrict__ nbr, const float* __restrict__ dist, int64_t N, int K,
             float radius, float* __restrict__ rhat, float* __restrict__ maskf, float* __restrict__ mean_w,
-            float* __restrict__ mean_w_rhat) {
+            float* __restrict__ mean_w_rhat, float* __restrict__ dmat) {
     const int lane = threadIdx.x & 63;
     const int slot = lane & 15, sub = lane >> 4;
     const int64_t node0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4;
@@ -62,6 +62,34 @@ k_edge_geom(const float* __restrict__ pos, const int* __restrict__ nbr, const fl
         c0 = __fmul_rn(sinf(a), sb);          // D[:, m=0] = (sin a sin b, cos b, cos a sin b)
         c1 = cosf(b);
         c2 = __fmul_rn(cosf(a), sb);
+        if (dmat) {
+            // the whole D[1] = Z(a) J Z(b) J Z(c) (irr_repr.py:23-32), needed by the degree-1 outputs (depth > 1): the
+            // third angle comes from rot(a, b, 0)^T R (irr_repr.py:116-117), with R the float32 cast of the float64
+            // rotation above: R = t' xy xy^T - I, t' = 2 / max(s, 1e-6)
+            const double tt = 2.0 / s;
+            const double xy[3] = {a0, a1, a2};
+            float R[3][3];
+            for (int p = 0; p < 3; ++p)
+                for (int q = 0; q < 3; ++q) R[p][q] = (float)(tt * xy[p] * xy[q] - (p == q ? 1.0 : 0.0));
+            const float ca = cosf(a), sa = sinf(a), cb = cosf(b);
+            // first column of rot_z(a) rot_y(b) = (ca cb, sa cb, -sb); r2[0][j] = that column . R[:, j]
+            const float r00 = ca * cb * R[0][0] + sa * cb * R[1][0] - sb * R[2][0];
+            const float r02 = ca * cb * R[0][2] + sa * cb * R[1][2] - sb * R[2][2];
+            const float g = atan2f(r02, r00);
+            const float cg = cosf(g), sg = sinf(g);
+            // Z(t) = [[c,0,s],[0,1,0],[-s,0,c]], J = [[0,1,0],[1,0,0],[0,0,-1]]:  J Z(t) = [[0,1,0],[c,0,s],[s,0,-c]]
+            const float JB[3][3] = {{0.f, 1.f, 0.f}, {cb, 0.f, sb}, {sb, 0.f, -cb}};
+            const float JC[3][3] = {{0.f, 1.f, 0.f}, {cg, 0.f, sg}, {sg, 0.f, -cg}};
+            const float ZA[3][3] = {{ca, 0.f, sa}, {0.f, 1.f, 0.f}, {-sa, 0.f, ca}};
+            float M[3][3], Dm[3][3];
+            for (int p = 0; p < 3; ++p)
+                for (int q = 0; q < 3; ++q) M[p][q] = JB[p][0] * JC[0][q] + JB[p][1] * JC[1][q] + JB[p][2] * JC[2][q];
+            for (int p = 0; p < 3; ++p)
+                for (int q = 0; q < 3; ++q) Dm[p][q] = ZA[p][0] * M[0][q] + ZA[p][1] * M[1][q] + ZA[p][2] * M[2][q];
+            float* dst = dmat + 9 * e;
+            for (int p = 0; p < 3; ++p)
+                for (int q = 0; q < 3; ++q) dst[3 * p + q] = Dm[p][q];
+        }
     }
     const bool in = live && d <= radius;                                  // neighbor_mask, :1339
     const unsigned long long bal = __ballot(in);
@@ -80,7 +108,7 @@ k_edge_geom(const float* __restrict__ pos, const int* __restrict__ nbr, const fl
 
 extern "C" int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, int64_t N, int32_t K,
                                  float radius, float* rhat, float* maskf, float* mean_w, float* mean_w_rhat,
-                                 void* stream) {
+                                 float* dmat, void* stream) {
     if (N < 0 || K < 1 || K > 16) return EQH_ERR_ARG;
     if (N == 0) return EQH_OK;
     if (!pos || !nbr || !dist || !rhat || !maskf || !mean_w || !mean_w_rhat) return EQH_ERR_ARG;
@@ -88,7 +116,7 @@ extern "C" int eqf_edge_geometry(const float* pos, const int32_t* nbr, const flo
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffff) return EQH_ERR_ARG;
     hipLaunchKernelGGL(k_edge_geom, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pos, nbr, dist, N, (int)K, radius,
-                       rhat, maskf, mean_w, mean_w_rhat);
+                       rhat, maskf, mean_w, mean_w_rhat, dmat);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

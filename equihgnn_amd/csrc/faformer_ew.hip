@@ -328,3 +328,89 @@ extern "C" int faf_frame_pre_bwd(const float* y, const float* w3, const float* d
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(slab, blocks, (int64_t)H * 3, dw3, stream, accumulate);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention-weighted neighbour sum:  out[n, c] = sum_m attn[n, c / D, m] * x[n, m, c]      (c < H * D, m < K)
+//
+// Replaces (reference) the two einsums of fa_former_layer.py:497-506, "nhm,nmhd->nhd" over the gathered values and
+// over the edge values -- which torch runs as 2 x 30 k batched [1 x 16] x [16 x 128] products (0.46 ms each, 4.6 ms
+// per step with their backward) for what is one pass over x.  HBM-bound: 4 C K N bytes read, 4 C N written.
+// One sub-group of C / 4 lanes per node (float4 per lane; a wavefront holds 256 / C nodes), the K attention weights
+// of the lane's head in registers.  Backward: dx[n, m, c] = attn * dout[n, c];  dattn[n, h, m] = sum over the head's
+// channels of dout * x, a butterfly over the D / 4 lanes of the head (fixed order).  No atomics.
+namespace {
+
+constexpr int AS_MAXK = 16;
+
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_attn_sum(const float* __restrict__ attn, const float* __restrict__ x, const float* __restrict__ dout, int64_t N,
+           int K, int H, int D, float* __restrict__ out, float* __restrict__ dx, float* __restrict__ dattn) {
+    const int C = H * D, LPR = C / 4;                         // lanes per node
+    const int lane = threadIdx.x & 63;
+    const int per_wave = 64 / LPR;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int c = 4 * sl, h = c / D;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n = wave * per_wave + sub;
+    const bool live = n < N;
+    const int64_t nc = live ? n : 0;
+    float a[AS_MAXK];
+#pragma unroll
+    for (int m = 0; m < AS_MAXK; ++m) a[m] = (m < K) ? attn[(nc * H + h) * K + m] : 0.f;
+    const float* xr = x + nc * K * C + c;
+    if (!BWD) {
+        float4 acc = f4_zero();
+#pragma unroll 4
+        for (int m = 0; m < K; ++m) f4_fma(acc, *reinterpret_cast<const float4*>(xr + (int64_t)m * C), a[m]);
+        if (live) *reinterpret_cast<float4*>(out + n * C + c) = acc;
+    } else {
+        const float4 g = *reinterpret_cast<const float4*>(dout + nc * C + c);
+        float* dxr = dx + nc * K * C + c;
+        const int hl = D / 4;                                  // lanes per head (power of two)
+        for (int m = 0; m < K; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + (int64_t)m * C);
+            if (live) *reinterpret_cast<float4*>(dxr + (int64_t)m * C) = make_float4(a[m] * g.x, a[m] * g.y, a[m] * g.z, a[m] * g.w);
+            float p = (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+            for (int o = 1; o < hl; o <<= 1) p += __shfl_xor(p, o, 64);
+            if (live && (sl % hl) == 0) dattn[(n * H + h) * K + m] = p;
+        }
+    }
+}
+
+int attn_sum_check(int64_t N, int K, int H, int D) {
+    if (N < 0 || K < 1 || K > AS_MAXK || H < 1 || D < 4) return EQH_ERR_ARG;
+    const int C = H * D, lpr = C / 4, hl = D / 4;
+    if ((D & 3) || lpr > 64 || (lpr & (lpr - 1)) || (hl & (hl - 1))) return EQH_ERR_ARG;
+    return EQH_OK;
+}
+
+}  // namespace
+
+extern "C" int faf_attn_sum_fwd(const float* attn, const float* x, int64_t N, int32_t K, int32_t H, int32_t D, float* out,
+                                void* stream) {
+    const int rc = attn_sum_check(N, K, H, D);
+    if (rc) return rc;
+    if (N == 0) return EQH_OK;
+    if (!attn || !x || !out) return EQH_ERR_ARG;
+    const int per_wave = 64 / (H * D / 4);
+    const int64_t waves = (N + per_wave - 1) / per_wave;
+    hipLaunchKernelGGL(k_attn_sum<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, x,
+                       (const float*)nullptr, N, (int)K, (int)H, (int)D, out, (float*)nullptr, (float*)nullptr);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int faf_attn_sum_bwd(const float* attn, const float* x, const float* dout, int64_t N, int32_t K, int32_t H,
+                                int32_t D, float* dx, float* dattn, void* stream) {
+    const int rc = attn_sum_check(N, K, H, D);
+    if (rc) return rc;
+    if (N == 0) return EQH_OK;
+    if (!attn || !x || !dout || !dx || !dattn) return EQH_ERR_ARG;
+    const int per_wave = 64 / (H * D / 4);
+    const int64_t waves = (N + per_wave - 1) / per_wave;
+    hipLaunchKernelGGL(k_attn_sum<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, x, dout,
+                       N, (int)K, (int)H, (int)D, (float*)nullptr, dx, dattn);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

@@ -114,7 +114,7 @@ class EdgeGeometry:
     """Neighbour lists and per-edge geometry, built once per batch (no gradient: positions are
     data, and the reference builds D under no_grad, equiformer/basis.py:194)."""
 
-    def __init__(self, pos, index: HyperIndex, k: int, radius: float):
+    def __init__(self, pos, index: HyperIndex, k: int, radius: float, full_d: bool = False):
         n = pos.shape[0]
         self.N, self.K = n, int(min(k, n - 1))
         nbr, dist, csr_t = index.knn(pos, self.K, 1)
@@ -122,7 +122,9 @@ class EdgeGeometry:
         self.nbr_flat = nbr.reshape(-1)
         # rel_pos, D[:, m=0] (with the reference's clamped rotation near -y and for coincident atoms), radius mask and
         # masked-mean weights: one launch (csrc/edge_geom.hip) instead of ~10 elementwise ones
-        self.rhat, self.maskf, mean_w, self.mean_w_rhat = ops.edge_geometry(pos, nbr, dist, radius)
+        geo = ops.edge_geometry(pos, nbr, dist, radius, full_d)
+        self.rhat, self.maskf, mean_w, self.mean_w_rhat = geo[:4]
+        self.D = geo[4].view(n, self.K, 3, 3) if full_d else None        # whole D[1], for the degree-1 outputs
         self.dist = dist.reshape(-1, 1)                                   # [E, 1] true distance
         self.mask = self.maskf > 0                                        # [N, K]   :1339 (only the unfused attention reads it)
         self.recv_rowptr = torch.arange(0, (n + 1) * self.K, self.K, dtype=torch.int32, device=pos.device)
@@ -271,30 +273,103 @@ class FeedForward(nn.Module):
         return F.silu(h[..., self.mult * self.c:]) @ self.project_out.w(0)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Degree-1 outputs.  The reference's wrapper builds the layer with depth 1 and reads type 0 only, so
+# everything below is dead there; with depth > 1 block t+1's (1 -> 0) pair consumes block t's degree-1 output and it
+# all becomes live.  No registry name reaches this configuration, so it is written for correctness with torch
+# operations on the device tensors (per-edge radial weights materialised, as the reference does) on top of the same
+# HIP neighbour search / edge geometry / row gathers; tests/test_equiformer_layer.py pins it to the reference's layer
+# at depth 1-3.
+# ---------------------------------------------------------------------------------------------------------------
+def _mix1(lin: FiberLinear, t):
+    """Degree-1 channel mix [..., d, 3] -> [..., e, 3] (equiformer_layer.py:186-189)."""
+    return torch.einsum("...dm,de->...em", t, lin.w(1))
+
+
+def attention_degree1(att: "MLPAttention", f0, f1, me, edge, geo: EdgeGeometry, basis11):
+    """Degree-1 output of the attention block (equiformer_layer.py:871-955 with the (0->1) / (1->1) pairs of its DTP,
+    :385-418): [N, C, 3].  ``me`` [N, 104] / ``edge`` [E, 104] are the degree-0 intermediates (self rows, edge rows)."""
+    n, k, dh = geo.N, geo.K, att.dh
+    dtp = att.to_attn_and_v
+    D = geo.D
+    d = geo.dist.view(n, k, 1)
+    gat = lambda t: ops.gather_rows(t.reshape(n, -1), geo.nbr_flat, geo.csr_t).view(n, k, *t.shape[1:])
+    x0 = gat(f0 @ dtp.to_xj.w(0)) + (f0 @ dtp.to_xi.w(0))[:, None]                              # [N,K,C]
+    x1 = gat(_mix1(dtp.to_xj, f1)) + _mix1(dtp.to_xi, f1)[:, None]                               # [N,K,C,3]
+    x1r = torch.einsum("nkab,nkla->nklb", D, x1)                                                 # rotate in, :364-366
+    r01, r11 = dtp.kernel_unary["(0,1)"], dtp.kernel_unary["(1,1)"]
+    R01 = r01.rp(d).view(n, k, r01.nc_out, r01.nc_in)
+    R11 = r11.rp(d).view(n, k, r11.nc_out, r11.nc_in)
+    o01 = F.pad(torch.einsum("nkol,nkl->nko", R01, x0)[..., None], (1, 1))                       # result at m = 1, :407-409
+    xf = torch.stack((x1r, x1r.flip(-1), x1r), -1)                                               # [..., m, f], :389-399
+    o11 = torch.einsum("nkoi,mf,nkimf->nkom", R11, basis11, xf)                                  # :402-404
+    out1 = torch.einsum("nklm,nkam->nkla", torch.cat((o01, o11), 2), D)                          # rotate out, :416-418
+    inter1 = torch.cat((_mix1(dtp.self_interact, f1)[:, None], _mix1(dtp.to_out, out1)), 1)      # [N,1+K,48,3]
+    inter0 = torch.cat((me[:, None], edge.view(n, k, -1)), 1)                                    # [N,1+K,104]
+    logits = att.to_attn_logits[1](inter0[..., 4:8]) * att.scale                                 # degree-1 logits, :905-909
+    keep = F.pad(geo.mask, (1, 0), value=True)[..., None]
+    attn = logits.masked_fill(~keep, -torch.finfo(logits.dtype).max).softmax(dim=1)              # [N,1+K,1]
+    v1 = _mix1(att.to_values[1], inter1 * torch.sigmoid(inter0[..., 8:8 + dh])[..., None])      # Gate + Linear, :246,922
+    gate = torch.sigmoid(att.attn_head_gates[1](f0))[:, 1:2, None]
+    return _mix1(att.to_out, (attn[..., None] * v1).sum(1) * gate)
+
+
+def feed_forward_degree1(ff: "FeedForward", x0, x1):
+    """Degree-1 output of the feed-forward (equiformer_layer.py:517-529, Gate :228-257): [N, C, 3]."""
+    m = ff.mult * ff.c
+    h0 = ff.prenorm.norm0(x0) @ ff.project_in.w(0)
+    h1 = _mix1(ff.project_in, ff.prenorm.norm1(x1))
+    return _mix1(ff.project_out, h1 * torch.sigmoid(h0[..., :m])[..., None])
+
+
 class _Blocks(nn.Module):
-    def __init__(self, attn, ff):
+    def __init__(self, blocks):
         super().__init__()
-        self.blocks = nn.ModuleList([nn.ModuleList([attn, ff])])
+        self.blocks = nn.ModuleList([nn.ModuleList([attn, ff]) for attn, ff in blocks])
 
 
 class Equiformer(nn.Module):
-    def __init__(self, dim, dim_head=48, num_neighbors=16, valid_radius=5.0, radial_hidden_dim=64):
+    """equiformer_layer.py:961-1398 as equihnn_equiformer.py:37-49 configures it.  ``depth`` = 1 and ``type1`` = False
+    is that wrapper's use (type-0 output, the fused live path); ``type1`` = True returns (type0, type1), and any
+    ``depth`` > 1 evaluates the degree-1 paths between the blocks."""
+
+    def __init__(self, dim, dim_head=48, num_neighbors=16, valid_radius=5.0, radial_hidden_dim=64, depth=1, type1=False):
         super().__init__()
         self.k, self.radius = num_neighbors, float(valid_radius)
+        self.depth, self.type1 = int(depth), bool(type1)
         # the (1,1) basis of equiformer/basis.py:116-163 is a constant that only the (dead) (1,1)
         # path reads; it is carried as data for state_dict compatibility, never recomputed
         self.register_buffer("basis:(1,1)", torch.tensor([[0.57735027, 0.40824829, 0.18257419],
                                                             [0.57735027, 0.0, -0.36514837],
                                                             [0.57735027, -0.40824829, 0.18257419]]))
         self.tp_in = DTPIn(dim, radial_hidden_dim)
-        self.layers = _Blocks(MLPAttention(dim, dim_head, radial_hidden_dim), FeedForward(dim))
+        self.layers = _Blocks([(MLPAttention(dim, dim_head, radial_hidden_dim), FeedForward(dim)) for _ in range(self.depth)])
         self.norm = FiberNorm((dim, dim))
 
-    def forward(self, feats, coors, index: HyperIndex):
+    def forward(self, feats, coors, index: HyperIndex = None):
+        if index is None:           # the layer on its own (tests): a one-molecule index over the cloud
+            one = torch.zeros(1, dtype=torch.int64, device=feats.device)
+            index = HyperIndex(one, one, feats.shape[0], 1)
         feats = 0.5 * feats + 0.5 * feats.detach()                                  # :1183-1186
-        geo = EdgeGeometry(coors, index, self.k, self.radius)
+        full = self.type1 or self.depth > 1
+        geo = EdgeGeometry(coors, index, self.k, self.radius, full_d=full)
         x0, x1 = self.tp_in(feats, geo)
-        attn, ff = self.layers.blocks[0]
-        x0 = x0 + attn(x0, x1, geo)
-        x0 = x0 + ff(x0)
+        basis11 = getattr(self, "basis:(1,1)")
+        for i, (attn, ff) in enumerate(self.layers.blocks):                          # reversible.py:251-257
+            need1 = self.type1 or i + 1 < self.depth          # is this block's degree-1 output read by anything?
+            if need1:
+                f0, f1 = attn.prenorm.norm0(x0), attn.prenorm.norm1(x1)
+                me, edge = attn.to_attn_and_v(f0, f1, geo, joined=False)
+                a1 = attention_degree1(attn, f0, f1, me, edge, geo, basis11)
+            x0n = x0 + attn(x0, x1, geo)
+            if need1:
+                x1 = x1 + a1
+            x0 = x0n
+            if need1:
+                x1n = x1 + feed_forward_degree1(ff, x0, x1)
+            x0 = x0 + ff(x0)
+            if need1:
+                x1 = x1n
+        if self.type1:
+            return self.norm.norm0(x0), self.norm.norm1(x1)                          # :1378,1392-1398
         return self.norm.norm0(x0)

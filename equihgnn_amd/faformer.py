@@ -71,7 +71,12 @@ class SwiGLUMLP(nn.Module):
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
         w = self.fc1.weight
-        base = self.fc1.bias if extra is None else F.linear(extra, w[:, 3:], self.fc1.bias)
+        if extra is None:
+            base = self.fc1.bias
+        elif extra.shape[-1] == 1:      # one extra input (the squared distance): a broadcast multiply-add, not a K = 1 GEMM
+            base = torch.addcmul(self.fc1.bias, extra, w[:, 3])
+        else:
+            base = F.linear(extra, w[:, 3:], self.fc1.bias)
         if y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256:
             pre = ops.frame_pre(y, w[:, :3], base)                         # [..., 8, H] in one pass (csrc/faformer_ew.hip)
         else:
@@ -151,10 +156,14 @@ class EdgeModule(nn.Module):
         feats = self.coord_mlp.frame_mean(y, d2)                           # [N,K,C]
         # edge_mlp's first Linear split by input block: token_i / token_j parts at node level
         w, d = self.edge_mlp.fc1.weight, self.d
-        pre = (F.linear(tok, w[:, :d], self.edge_mlp.fc1.bias).unsqueeze(1)
-               + g.gather(F.linear(tok, w[:, d:2 * d])) + F.linear(feats, w[:, 2 * d:]))
-        pair = F.dropout(self.edge_mlp.fc2(self.edge_mlp.hidden(pre)), self.edge_mlp.p, self.training)
-        return pair * self.att_mlp(pair)
+        lin = ops.linear if tok.is_cuda else (lambda x, w_, b_=None, cols=None: F.linear(x, w_[:, cols[0]:cols[1]], b_))
+        pre = (lin(tok, w, self.edge_mlp.fc1.bias, cols=(0, d)).unsqueeze(1)
+               + g.gather(lin(tok, w, None, cols=(d, 2 * d))) + lin(feats, w, None, cols=(2 * d, w.shape[1])))
+        pair = F.dropout(self.edge_mlp._fc2(self.edge_mlp.hidden(pre)), self.edge_mlp.p, self.training)
+        # att_mlp = Linear(d, 1) + Sigmoid on ~250 k edge rows: a row-wise dot product (one multiply + one reduction
+        # pass over the rows) -- as a GEMM with ONE output column the library needs 2 ms for it
+        a = self.att_mlp[0]
+        return pair * torch.sigmoid((pair * a.weight.view(-1)).sum(-1, keepdim=True) + a.bias)
 
 
 def geo_pad(geo):
@@ -181,17 +190,39 @@ class MLPAttnEdgeAggregation(nn.Module):
 
     def forward(self, tok, geo, edge, g: EdgeGraph, row_mask=None):
         n, k, h = g.N, g.K, self.h
+        d, de = self.h * self.dh, self.h * self.deh
         q, kk, v = self.layernorm_qkv[1](_layer_norm(self.layernorm_qkv[0], tok)).chunk(3, -1)
-        kv = g.gather(torch.cat((kk, v), -1))                               # one gather for k and v
-        k_n, v_n = kv[..., :kk.shape[-1]], kv[..., kk.shape[-1]:]
-        qe, ve = self.layernorm_qkv_edge[1](_layer_norm(self.layernorm_qkv_edge[0], edge)).chunk(2, -1)
+        # The logits are LINEAR in their inputs (:483-489: Linear(dh, 1) of q_i + k_j, plus Linear(deh, 1) of the edge
+        # query), so they are evaluated where the inputs live instead of on [N, K, h, dh] edge tensors:
+        #   w . (q_i + k_j)      = a_q[i] + a_k[j]                  two dot products per ATOM and head; a_k is gathered
+        #                                                           as 16-byte rows beside v
+        #   w_e . (Wq_h x_e + b) = (Wq_h^T w_e) . x_e + w_e . b_h   one dot product per edge and head with a vector
+        #                                                           folded at weight level: the query half of
+        #                                                           layernorm_qkv_edge's Linear (32 GFLOP at the
+        #                                                           Molecule3D batch) is never formed
+        # (as GEMMs with one or two output columns these took 2 ms each in round 1).
+        w = self.mlp_attn.weight.view(-1)
+        a_q = (q.reshape(n, h, self.dh) * w).sum(-1)                                          # [N, h]
+        a_k = (kk.reshape(n, h, self.dh) * w).sum(-1)
+        v_n = g.gather(v)                                                                     # [N, K, d]
+        ak_n = g.gather(F.pad(a_k, (0, 4 - h)))[..., :h]                                      # [N, K, h] (16-byte rows)
+        lin_e = self.layernorm_qkv_edge[1]
+        xe = _layer_norm(self.layernorm_qkv_edge[0], edge)                                    # [N, K, de]
+        w_e = self.edge_attn.weight.view(-1)
+        u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)          # [h, de]
+        c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                              # [h]
+        le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c                     # [N, K, h]
+        ve = ops.linear(xe, lin_e.weight, lin_e.bias, rows=(de, 2 * de))                      # value half only
         gate = torch.sigmoid(self.W_gate(tok))
-        msg = (q.unsqueeze(1) + k_n).view(n, k, h, self.dh)
-        logits = self.mlp_attn(msg).squeeze(-1) + self.edge_attn(qe.view(n, k, h, self.deh)).squeeze(-1)
+        logits = a_q.unsqueeze(1) + ak_n + le
         logits = logits.masked_fill(~g.mask.unsqueeze(-1), -1e9)
         attn = F.dropout(logits.transpose(1, 2).softmax(-1), self.attn_drop, self.training)  # [N,h,K]
-        ctx = torch.einsum("nhm,nmhd->nhd", attn, v_n.view(n, k, h, self.dh)).reshape(n, -1)
-        ectx = torch.einsum("nhm,nmhd->nhd", attn, ve.view(n, k, h, self.deh)).reshape(n, -1)
+        if ops.attn_sum_supported(attn, ve):   # one pass over the values each (csrc/faformer_ew.hip::k_attn_sum)
+            ctx = ops.attn_sum(attn, v_n)
+            ectx = ops.attn_sum(attn, ve.reshape(n, k, -1))
+        else:
+            ctx = torch.einsum("nhm,nmhd->nhd", attn, v_n.reshape(n, k, h, self.dh)).reshape(n, -1)
+            ectx = torch.einsum("nhm,nmhd->nhd", attn, ve.reshape(n, k, h, self.deh)).reshape(n, -1)
         out = self.W_output(torch.cat((ctx, ectx), -1)) + tok
         # geometric context: with the reference's frame-0 gather (module docstring) the signed frame
         # average cancels and what is left is the centroid of the cloud, for every atom

@@ -61,7 +61,7 @@ SIGNATURES = {
     "geo_knn_grid_workspace_bytes": (c_size_t, [c_int64]),
     "geo_knn_grid": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
-    "eqf_edge_geometry": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float] + [c_void_p] * 5),
+    "eqf_edge_geometry": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float] + [c_void_p] * 6),
     "eqf_rms_norm_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "eqf_rms_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "eqf_rms_norm_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p,
@@ -75,6 +75,9 @@ SIGNATURES = {
     "faf_swiglu_dropout_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_bwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_attn_sum_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "faf_attn_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                   c_void_p]),
     "faf_frame_pre_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "faf_frame_pre_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "faf_frame_pre_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

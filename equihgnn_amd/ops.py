@@ -761,11 +761,20 @@ def defer_flush(device):
         for en in pending:
             by_shape.setdefault(tuple(en[3].shape), []).append(en)
         for group in by_shape.values():
-            if len(group) >= 3:
-                wgrad_batch(group)
+            # Deep reductions into a small output (FAFormer's per-edge / per-frame Linears: [256 x 2 M] . [2 M x 128])
+            # go one by one to the single-product split-K kernel, which cuts K into as many chunks as there are idle
+            # CUs (the batched kernel splits K three ways, right for the ~5 k-row products of the conv layers; the
+            # library has no split-K choice for such shapes: 2.1 ms for 129 GFLOP)
+            deep = [en for en in group if en[0].shape[0] >= 32768]
+            rest = [en for en in group if en[0].shape[0] < 32768]
+            with torch.no_grad():
+                for dy2, x2, alpha, into in deep:
+                    wgrad(dy2, x2, alpha, into=into)
+            if len(rest) >= 3:
+                wgrad_batch(rest)
             else:   # too few products of this shape to fill the chip together: the library GEMM is faster
                 with torch.no_grad():
-                    for dy2, x2, alpha, into in group:
+                    for dy2, x2, alpha, into in rest:
                         into.addmm_(dy2.t(), x2, alpha=alpha)
         colsum_batch(sums)
     finally:
@@ -1024,7 +1033,7 @@ DEFER_WGRAD = True            # batched weight gradients at defer_flush
 
 def _wgrad_shape_ok(dy2, x2):
     return (dy2.is_cuda and dy2.dtype == torch.float32 and x2.dtype == torch.float32
-            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and 512 <= dy2.shape[0] <= 131072)
+            and dy2.shape[1] % 64 == 0 and x2.shape[1] % 64 == 0 and 512 <= dy2.shape[0] <= (1 << 24))
 
 
 def _wgrad_ok(dy2, x2):
@@ -1059,13 +1068,15 @@ def wgrad(dy2, x2, alpha: float = 1.0, into=None):
     return None if into is not None else out
 
 
-def _linear_weight_grad(weight, c0, c1, dy2, x2):
+def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
     """Weight gradient dy2.T @ x2 of a Linear over the column block [c0, c1) of ``weight``: added to the
     parameter's persistent accumulator (in place, or recorded for the batched launch of defer_flush) when there
     is one -- returns None then -- else returned for autograd (full parameter shape)."""
     gbuf = getattr(weight, "_eqh_gbuf", None)
     if gbuf is not None:
         tgt = gbuf if c0 is None else gbuf[:, c0:c1]
+        if r0 is not None:
+            tgt = tgt[r0:r1]
         side = wgrad_stream(dy2.device) if WGRAD_ON_SIDE_STREAM else None
         if side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
             pass
@@ -1083,41 +1094,56 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2):
             dy2.record_stream(side)
             x2.record_stream(side)
         return None
-    if c0 is None:
+    if c0 is None and r0 is None:
         return wgrad(dy2, x2) if _wgrad_ok(dy2, x2) else dy2.t() @ x2
     dw = torch.zeros_like(weight)
-    dw[:, c0:c1] = dy2.t() @ x2
+    blk = dw if c0 is None else dw[:, c0:c1]
+    (blk if r0 is None else blk[r0:r1]).copy_(dy2.t() @ x2)
     return dw
 
 
 class _Linear(torch.autograd.Function):
-    """y = x @ W[:, c0:c1].T (+ bias): a library GEMM whose WEIGHT gradient, when the parameter
+    """y = x @ W[r0:r1, c0:c1].T (+ bias[r0:r1]): a library GEMM whose WEIGHT gradient, when the parameter
     carries a persistent accumulator (``param._eqh_gbuf``, same shape as the parameter), is
-    accumulated by the GEMM itself (addmm_ with beta = 1 into the accumulator's column block)
+    accumulated by the GEMM itself (addmm_ with beta = 1 into the accumulator's block)
     instead of being materialised and then added by autograd — shared weights (the conv layer is
     applied L times) and column-split weights (W·cat(a,b) = Wa·a + Wb·b) cost no extra kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, c0, c1):
+    def forward(ctx, x, weight, bias, c0, c1, r0=None, r1=None):
         w = weight if c0 is None else weight[:, c0:c1]
+        b = bias
+        if r0 is not None:
+            w = w[r0:r1]
+            b = bias[r0:r1] if bias is not None else None
         ctx.save_for_backward(x, weight)
-        ctx.cols = (c0, c1)
+        ctx.cols, ctx.rows = (c0, c1), (r0, r1)
         ctx.has_bias = bias is not None
         ctx.bias_param = bias
-        return F.linear(x, w, bias)
+        return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         c0, c1 = ctx.cols
+        r0, r1 = ctx.rows
         w = weight if c0 is None else weight[:, c0:c1]
+        if r0 is not None:
+            w = w[r0:r1]
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
         dx = (dy @ w) if ctx.needs_input_grad[0] else None
-        dw = _linear_weight_grad(weight, c0, c1, dy2, x2) if ctx.needs_input_grad[1] else None
+        dw = _linear_weight_grad(weight, c0, c1, dy2, x2, r0, r1) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy2, into=_acc_target(ctx.bias_param))   # None when accumulated in place
-        return dx, dw, db, None, None
+            acc = _acc_target(ctx.bias_param)
+            if r0 is None:
+                db = colsum(dy2, into=acc)   # None when accumulated in place
+            elif acc is not None:
+                colsum(dy2, into=acc[r0:r1])
+            else:
+                db = torch.zeros_like(ctx.bias_param)
+                db[r0:r1] = colsum(dy2)
+        return dx, dw, db, None, None, None, None
 
 
 class _Linear2(torch.autograd.Function):
@@ -1276,14 +1302,15 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
                                     reduce == "mean", eps, (gamma, beta))
 
 
-def linear(x, weight, bias=None, cols=None):
-    """F.linear(x, weight[:, cols[0]:cols[1]], bias) through _Linear (``weight`` is the PARAMETER,
-    not a slice of it, so that its gradient accumulator can be found)."""
+def linear(x, weight, bias=None, cols=None, rows=None):
+    """F.linear(x, weight[rows[0]:rows[1], cols[0]:cols[1]], bias[rows[0]:rows[1]]) through _Linear (``weight`` and
+    ``bias`` are the PARAMETERS, not slices of them, so that their gradient accumulators can be found)."""
     if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
         LINEAR_PARAMS[id(weight)] = weight
     _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
-    return _Linear.apply(x, weight, bias, c0, c1)
+    r0, r1 = rows if rows is not None else (None, None)
+    return _Linear.apply(x, weight, bias, c0, c1, r0, r1)
 
 
 def linear2(x, wa, cols_a, wb, cols_b):
@@ -1440,6 +1467,48 @@ class _FramePre(torch.autograd.Function):
         if tuple(ctx.base_shape) != tuple(dbase.shape):          # base was broadcast (a bias vector): sum it back
             dbase = dbase.sum_to_size(ctx.base_shape)
         return dy.view(*ctx.lead, 3), dw3, dbase
+
+
+class _AttnSum(torch.autograd.Function):
+    """out[n, c] = sum_m attn[n, c // D, m] * x[n, m, c] (faf_attn_sum_fwd / _bwd, csrc/faformer_ew.hip)."""
+
+    @staticmethod
+    def forward(ctx, attn, x):
+        _require_gpu(x, "attn_sum")
+        attn, x = _f32c(attn), _f32c(x)
+        N, H, K = attn.shape
+        C = x.shape[-1]
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_attn_sum_fwd(_ptr(attn), _ptr(x), N, K, H, C // H, _ptr(out), _stream(x.device)),
+                  "faf_attn_sum_fwd")
+        ctx.save_for_backward(attn, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        attn, x = ctx.saved_tensors
+        dout = _f32c(dout)
+        N, H, K = attn.shape
+        C = x.shape[-1]
+        dx, dattn = torch.empty_like(x), torch.empty_like(attn)
+        hip.check(hip.lib().faf_attn_sum_bwd(_ptr(attn), _ptr(x), _ptr(dout), N, K, H, C // H, _ptr(dx), _ptr(dattn),
+                                             _stream(x.device)), "faf_attn_sum_bwd")
+        return dattn, dx
+
+
+def attn_sum_supported(attn, x) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and attn.dim() == 3 and x.dim() == 3):
+        return False
+    n, h, k = attn.shape
+    c = x.shape[-1]
+    lpr, hl = c // 4, (c // h) // 4 if h else 0
+    return (x.shape[0] == n and x.shape[1] == k and k <= 16 and c % (4 * h) == 0 and 1 <= lpr <= 64
+            and lpr & (lpr - 1) == 0 and hl >= 1 and hl & (hl - 1) == 0)
+
+
+def attn_sum(attn, x):
+    """sum_m attn[n, h, m] * x[n, m, h*D:(h+1)*D] for attn [N, H, K], x [N, K, H*D] -> [N, H*D]."""
+    return _AttnSum.apply(attn, x)
 
 
 def frame_pre(y, w3, base):
@@ -1719,9 +1788,10 @@ def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto"):
     return nbr, dist
 
 
-def edge_geometry(pos, nbr, dist, radius: float):
+def edge_geometry(pos, nbr, dist, radius: float, full_d: bool = False):
     """eqf_edge_geometry: (rhat [E,3] = D[:, m=0], maskf [N,K], mean_w [N,K], mean_w_rhat [N,K,3]) for the
-    self-excluded neighbour lists of geo_knn(mode 1); see csrc/edge_geom.hip.  No gradient."""
+    self-excluded neighbour lists of geo_knn(mode 1), plus the whole D[1] [E,3,3] with ``full_d``; see
+    csrc/edge_geom.hip.  No gradient."""
     _require_gpu(pos, "edge_geometry")
     pos, dist = _f32c(pos.detach()), _f32c(dist)
     N, K = nbr.shape
@@ -1732,9 +1802,11 @@ def edge_geometry(pos, nbr, dist, radius: float):
     maskf = torch.empty((N, K), dtype=torch.float32, device=dev)
     mean_w = torch.empty((N, K), dtype=torch.float32, device=dev)
     mean_w_rhat = torch.empty((N, K, 3), dtype=torch.float32, device=dev)
+    dmat = torch.empty((N * K, 3, 3), dtype=torch.float32, device=dev) if full_d else None
     hip.check(hip.lib().eqf_edge_geometry(_ptr(pos), _ptr(nbr.contiguous()), _ptr(dist), N, K, float(radius), _ptr(rhat),
-                                          _ptr(maskf), _ptr(mean_w), _ptr(mean_w_rhat), _stream(dev)), "eqf_edge_geometry")
-    return rhat, maskf, mean_w, mean_w_rhat
+                                          _ptr(maskf), _ptr(mean_w), _ptr(mean_w_rhat), _ptr(dmat), _stream(dev)),
+              "eqf_edge_geometry")
+    return (rhat, maskf, mean_w, mean_w_rhat, dmat) if full_d else (rhat, maskf, mean_w, mean_w_rhat)
 
 
 def scatter(src, index, dim: int = -1, out=None, dim_size=None, reduce: str = "sum"):

@@ -310,6 +310,16 @@ int geo_knn_grid(const float* pos, int64_t N, int32_t k, int32_t mode, const int
                  float* dist, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Attention-weighted neighbour sum of FAFormer (fa_former_layer.py:497-506, einsum "nhm,nmhd->nhd"):
+ *   out[n, c] = sum_{m < K} attn[n, c / D, m] * x[n, m, c],   attn [N, H, K], x [N, K, H*D], out [N, H*D]
+ * bwd: dx [N, K, H*D] and dattn [N, H, K] from dout [N, H*D].  K <= 16; H*D / 4 and D / 4 powers of two, H*D <= 256.
+ * ------------------------------------------------------------------------------------------- */
+int faf_attn_sum_fwd(const float* attn, const float* x, int64_t N, int32_t K, int32_t H, int32_t D, float* out,
+                     void* stream);
+int faf_attn_sum_bwd(const float* attn, const float* x, const float* dout, int64_t N, int32_t K, int32_t H, int32_t D,
+                     float* dx, float* dattn, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-edge geometry of the Equiformer front-end -- equiformer_layer.py:1250-1252,1317-1346 (rel_pos = x_i - x_j of
  * the selected neighbours, neighbor_mask = dist <= radius), equiformer/basis.py:194-215 with :169-191 and
  * irr_repr.py:105-118,23-32 (D[1] of the rotation taking r_ij onto y, built in float64 with the |x+y|^2 >= 1e-6
@@ -320,10 +330,11 @@ int geo_knn_grid(const float* pos, int64_t N, int32_t k, int32_t mode, const int
  *   maskf       [N,K]    1.0 where dist <= radius
  *   mean_w      [N,K]    maskf / max(count, 1)  (all zero for a node without an in-radius neighbour)
  *   mean_w_rhat [N,K,3]  mean_w * rhat
+ *   dmat        [N*K,3,3] or NULL: the whole D[1] = Z(a) J Z(b) J Z(c) (degree-1 outputs, depth > 1)
  * No gradient (positions are data; the reference builds D under no_grad).
  * ------------------------------------------------------------------------------------------- */
 int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, int64_t N, int32_t K, float radius,
-                      float* rhat, float* maskf, float* mean_w, float* mean_w_rhat, void* stream);
+                      float* rhat, float* maskf, float* mean_w, float* mean_w_rhat, float* dmat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Degree-0 branch of the Equiformer's `Norm` (equiformer_layer.py:194-225): out = t / max(rms, eps) * g with

@@ -41,7 +41,7 @@ def fill_state_dict(model: torch.nn.Module, seed: int) -> None:
         leaf = name.rsplit(".", 1)[-1]
         rng = np.random.default_rng([seed, zlib.crc32(name.encode())])
         z = rng.standard_normal(shape if len(shape) else (1,)).astype(np.float32).reshape(shape)
-        if name == "equiformer_layer.basis:(1,1)" or leaf == "beta":
+        if name.endswith("basis:(1,1)") or leaf == "beta":
             new[name] = t.clone()  # data / fixed-zero buffers stay as constructed
         elif leaf == "running_var":
             v = np.abs(z) + 0.5
@@ -111,6 +111,32 @@ TRAJECTORY_TABLE = {
     "trajectory_egnn_equihnns_c64": ("egnn_equihnns", 64, 81, 6, 3, 1e-3),
     "trajectory_mhnnm_c64": ("mhnnm", 64, 85, 6, 3, 1e-3),
 }
+
+
+# The reference's Equiformer LAYER class at a depth its wrapper never uses (full type-1 outputs, the
+# (0->1) / (1->1) attention pairs, the (1,1) basis contraction): feats [N, C] and coordinates in, type-0 and type-1
+# features out, plus the gradients of a fixed linear functional of both outputs.
+# name: (hidden, depth, seed, atoms)
+LAYER_TABLE = {
+    "equiformer_layer_depth2_c32": (32, 2, 91, 60),
+    "equiformer_layer_depth1_c32": (32, 1, 92, 44),
+    "equiformer_layer_depth3_c64": (64, 3, 93, 70),
+}
+
+
+def layer_inputs(name: str):
+    """(feats [N, C], coors [N, 3], w0 [N, C], w1 [N, C, 3]) of a layer case: a molecule-like cloud (chain growth, so
+    every atom has in-radius neighbours; a far-away group has none) and the weights of the scalar functional."""
+    hidden, depth, seed, n = LAYER_TABLE[name]
+    g = np.random.default_rng(seed)
+    pos = np.zeros((n, 3))
+    for i in range(1, n):
+        u = g.standard_normal(3)
+        pos[i] = pos[int(g.integers(0, i))] + (1.4 + 0.1 * g.uniform(-1, 1)) * u / np.linalg.norm(u)
+    pos[-3:] += 40.0                                             # three atoms beyond everyone's radius
+    t = lambda a: torch.from_numpy(a.astype(np.float32))
+    return (t(g.standard_normal((n, hidden))), t(pos), t(g.standard_normal((n, hidden))),
+            t(g.standard_normal((n, hidden, 3))))
 
 
 def trajectory_batches(name: str):

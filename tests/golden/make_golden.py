@@ -27,7 +27,7 @@ REF = os.environ.get("EQUIHGNN_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
-from common import (CASE_TABLE, TRAJECTORY_TABLE, case_spec, trajectory_batches, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
+from common import (CASE_TABLE, LAYER_TABLE, TRAJECTORY_TABLE, layer_inputs, case_spec, trajectory_batches, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
                     zero_dropouts)
 
 from equihgnn_amd.batch import ATOM_FEATURE_DIMS  # noqa: E402
@@ -331,6 +331,39 @@ def run_trajectory(registry, name):
     return case
 
 
+def run_layer(name):
+    """The reference's Equiformer layer (equiformer_layer.py:961-1398) built as equihnn_equiformer.py:37-49 builds it,
+    except for the depth."""
+    hidden, depth, seed, n = LAYER_TABLE[name]
+    eq = importlib.import_module("equihgnn.models.layers.equiformer_layer")
+    torch.manual_seed(0)
+    layer = eq.Equiformer(dim=hidden, heads=1, depth=depth, dim_head=48, num_degrees=2, valid_radius=5, num_neighbors=16,
+                          l2_dist_attention=False, reduce_dim_out=False, attend_self=True, linear_out=True)
+    fill_state_dict(layer, seed)
+    feats, coors, w0, w1 = layer_inputs(name)
+    feats.requires_grad_(True)
+    out = layer(feats[None], coors[None], torch.ones(1, n, dtype=torch.bool))
+    t0, t1 = out.type0[0], out.type1[0]
+    ((t0 * w0).sum() + (t1 * w1).sum()).backward()
+    case = {"meta_hidden": np.array(hidden), "meta_depth": np.array(depth), "meta_seed": np.array(seed),
+            "in_feats": feats.detach().numpy(), "in_coors": coors.numpy(), "in_w0": w0.numpy(), "in_w1": w1.numpy(),
+            "type0": t0.detach().numpy(), "type1": t1.detach().numpy(), "grad_feats": feats.grad.numpy()}
+    names, has, stats = [], [], []
+    for n_, p in layer.named_parameters():
+        names.append(n_)
+        has.append(p.grad is not None)
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        stats.append([float(g.sum()), float(g.abs().sum()), float(g.norm())])
+        if p.grad is not None and p.numel() <= 6000:
+            case["grad_" + n_] = g.numpy()
+    case["grad_names"], case["grad_present"] = np.array(names), np.array(has)
+    case["grad_stats"] = np.array(stats, dtype=np.float64)
+    # the (1,1) basis is an SVD null-space vector per J whose SIGN is LAPACK's choice (equiformer/basis.py:41-53); it is
+    # a buffer of the state_dict, i.e. data: the fixture carries the one this run of the reference computed
+    case["buf_basis11"] = getattr(layer, "basis:(1,1)").numpy().copy()
+    return case
+
+
 def compare(case, stored, name):
     bad = []
     for k in sorted((set(case) | set(stored)) - {"meta_name"}):
@@ -353,13 +386,14 @@ def main(only=None, check=False):
     torch.use_deterministic_algorithms(True)
     names = [n for n in CASE_TABLE if only is None or n in only]
     traj = [n for n in TRAJECTORY_TABLE if only is None or n in only]
+    layers = [n for n in LAYER_TABLE if only is None or n in only]
     methods = {CASE_TABLE[n][0] for n in names} | {TRAJECTORY_TABLE[n][0] for n in traj}
     mods = []
     if methods & {"mhnnm", "mhnn", "mhnns"}:
         mods.append("mhnn")
     if methods & {"egnn_equihnns", "egnn_equihnn", "egnn_equihnnm"}:
         mods.append("equihnn_egnn")
-    if "equiformer_equihnns" in methods or (only is None or "equiformer_D" in only):
+    if "equiformer_equihnns" in methods or (only is None or "equiformer_D" in only) or layers:
         mods.append("equihnn_equiformer")
     if "faformer_equihnns" in methods:
         mods.append("equihnn_fa_former")
@@ -382,6 +416,14 @@ def main(only=None, check=False):
         else:
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **case)
             print(f"{name}: losses {case['loss']}")
+    for name in layers:
+        case = run_layer(name)
+        if check:
+            ok &= compare(case, load_case(name), name)
+        else:
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **case)
+            print(f"{name}: type0 {case['type0'].shape} |type1| {np.abs(case['type1']).max():.3f} "
+                  f"live grads {int(case['grad_present'].sum())}/{len(case['grad_present'])}")
     if only is None or "equiformer_D" in only:
         case = d_fixture()
         if check:

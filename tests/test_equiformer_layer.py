@@ -1,0 +1,90 @@
+"""The Equiformer LAYER with both output degrees at depth 1-3: type-1 outputs, the (0->1) and
+(1->1) pairs of the attention tensor product, the (1,1) basis contraction, degree-1 feed-forward and norm -- paths the
+depth-1 / type-0 wrapper never reads, live as soon as depth > 1.  Fixtures: the reference's own class
+(tests/golden/make_golden.py::run_layer).  CPU: the oracle (oracle/ref_equiformer_full.py).  GPU: the product layer
+(equihgnn_amd/equiformer.py, ``Equiformer(depth=..., type1=True)``)."""
+import numpy as np
+import pytest
+import torch
+
+from common import LAYER_TABLE, assert_close, fill_state_dict, layer_inputs, load_case
+
+
+def _load(model, case, seed):
+    fill_state_dict(model, seed)
+    with torch.no_grad():
+        getattr(model, "basis:(1,1)").copy_(torch.from_numpy(case["buf_basis11"]))
+
+
+def _check(model, case, name, dev="cpu", grad_rtol=2e-4):
+    feats, coors, w0, w1 = (t.to(dev) for t in layer_inputs(name))
+    assert np.array_equal(feats.cpu().numpy(), case["in_feats"]) and np.array_equal(coors.cpu().numpy(), case["in_coors"])
+    feats.requires_grad_(True)
+    t0, t1 = model(feats, coors)
+    assert_close(t0.detach().cpu().numpy(), case["type0"], 1e-5, "type0")
+    assert_close(t1.detach().cpu().numpy(), case["type1"], 1e-5, "type1")
+    ((t0 * w0).sum() + (t1 * w1).sum()).backward()
+    gscale = float(np.abs(case["grad_feats"]).max())
+    np.testing.assert_allclose(feats.grad.cpu().numpy(), case["grad_feats"], atol=grad_rtol * gscale, rtol=0)
+    params = dict(model.named_parameters())
+    assert sorted(params) == sorted(str(n) for n in case["grad_names"])
+    floor = 1e-3 * float(case["grad_stats"][:, 2].max())
+    for n, has, st in zip(case["grad_names"], case["grad_present"], case["grad_stats"]):
+        g = params[str(n)].grad
+        assert has and g is not None, n
+        key = "grad_" + str(n)
+        if key in case:
+            scale = max(floor, float(np.abs(case[key]).max()))
+            np.testing.assert_allclose(g.detach().cpu().numpy(), case[key], atol=grad_rtol * scale, rtol=0, err_msg=str(n))
+        else:
+            np.testing.assert_allclose(float(g.norm()), st[2], rtol=10 * grad_rtol, atol=grad_rtol * floor, err_msg=str(n))
+
+
+@pytest.mark.parametrize("name", list(LAYER_TABLE))
+def test_oracle_layer_matches_reference(name):
+    from oracle.ref_equiformer_full import EquiformerFull
+    hidden, depth, seed, n = LAYER_TABLE[name]
+    case = load_case(name)
+    model = EquiformerFull(hidden, depth=depth)
+    _load(model, case, seed)
+    _check(model, case, name)
+
+
+def test_full_oracle_agrees_with_the_type0_oracle_at_depth_1():
+    from oracle.ref_equiformer import Equiformer
+    from oracle.ref_equiformer_full import EquiformerFull
+    a, b = Equiformer(32), EquiformerFull(32, depth=1)
+    fill_state_dict(a, 3)
+    b.load_state_dict(a.state_dict(), strict=True)
+    x, pos = torch.randn(40, 32, generator=torch.Generator().manual_seed(0)), torch.randn(40, 3, generator=torch.Generator().manual_seed(1)) * 2
+    assert torch.equal(a(x, pos), b(x, pos)[0])
+
+
+def test_reference_layer_is_equivariant_with_the_reconstructed_J():
+    """The fixtures' type-1 outputs rotate with the coordinates (checked on the oracle, which reproduces the reference):
+    evidence that the reconstructed J_dense yields a valid (1,1) basis -- a wrong one breaks this at 1e-1."""
+    from oracle.ref_equiformer_full import EquiformerFull
+    name = "equiformer_layer_depth2_c32"
+    hidden, depth, seed, n = LAYER_TABLE[name]
+    model = EquiformerFull(hidden, depth=depth)
+    _load(model, load_case(name), seed)
+    feats, coors, _, _ = layer_inputs(name)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    with torch.no_grad():
+        a0, a1 = model(feats, coors)
+        b0, b1 = model(feats, coors @ q.T + 0.5)
+    assert float((a0 - b0).abs().max()) < 2e-5 and float((a1 @ q.T - b1).abs().max()) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(LAYER_TABLE))
+def test_hip_layer_matches_reference(name):
+    from equihgnn_amd.equiformer import Equiformer
+    hidden, depth, seed, n = LAYER_TABLE[name]
+    case = load_case(name)
+    model = Equiformer(hidden, depth=depth, type1=True)
+    _load(model, case, seed)
+    model.to("cuda:0")
+    _check(model, case, name, dev="cuda:0", grad_rtol=5e-4)

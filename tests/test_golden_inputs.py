@@ -15,7 +15,7 @@ FIELDS = ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order
 
 def test_every_case_has_a_file_and_every_file_a_case():
     files = {f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz")}
-    extra = {"equiformer_D"} | {f for f in files if f.startswith("trajectory_")}   # not model cases
+    extra = {"equiformer_D"} | {f for f in files if f.startswith(("trajectory_", "equiformer_layer_"))}   # not model cases
     assert files - extra == set(CASE_TABLE)
 
 

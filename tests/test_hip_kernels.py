@@ -423,7 +423,7 @@ def test_residual_mix_matches_float64(mode):
 
 
 @pytest.mark.parametrize("K,O,I", [(1, 64, 64), (70, 64, 128), (513, 128, 64), (4608, 256, 256), (9733, 256, 256),
-                                    (4864, 512, 256), (3000, 2176, 256)])
+                                    (4864, 512, 256), (3000, 2176, 256), (300007, 256, 128)])
 def test_wgrad_matches_float64(K, O, I):
     """hg_wgrad_f32: alpha * dy.T @ x against float64, fresh and accumulated into a column block of a
     wider matrix; bitwise reproducible."""
@@ -1090,9 +1090,14 @@ def test_edge_geometry_matches_reference_D_fixture():
     nbr[1::2, 0] = np.arange(E) * 2
     dist = np.linalg.norm(pos - pos[nbr[:, 0]], axis=1).astype(np.float32)[:, None]
     t = lambda a: torch.from_numpy(a).to(DEV)
-    rhat, maskf, mean_w, mwr = ops.edge_geometry(t(pos), t(nbr), t(dist), 5.0)
+    rhat, maskf, mean_w, mwr, dmat = ops.edge_geometry(t(pos), t(nbr), t(dist), 5.0, full_d=True)
     got = rhat.cpu().numpy()[0::2]
     assert keep.all()
+    # the whole D[1] (degree-1 outputs, depth > 1).  Where sin b ~ 0 (direction along +-y: Euler angles a and c are not
+    # separately determined) only a + c / a - c matter and the matrices agree through that; elsewhere entry by entry
+    dfull = dmat.cpu().numpy()[0::2]
+    np.testing.assert_allclose(dfull, D, atol=5e-6, rtol=0)
+    np.testing.assert_allclose(dfull[:, :, 1], got, atol=1e-6, rtol=0)
     np.testing.assert_allclose(got[keep], D[keep][:, :, 1], atol=2e-6, rtol=0)
     # rows the offset did perturb (tiny components next to 1e4): against the oracle on the perturbed vector
     from oracle.ref_equiformer import wigner_d1_to_y
@@ -1239,3 +1244,22 @@ def test_dense_prologues_and_batching():
     assert float((o6.double() - 0.5 * (dy.double() @ wt.double())).abs().max()) < 2e-4
     with pytest.raises(Exception):                     # one kind of prologue per launch
         ops.dense_batch([ops.DenseProblem(h, w), ops.DenseProblem(h, w, ln=(pb, ga, be, 1e-5))])
+
+
+@pytest.mark.parametrize("N,K,H,D", [(1, 16, 2, 128), (517, 16, 2, 128), (33, 16, 2, 32), (40, 7, 1, 64), (9, 16, 4, 16)])
+def test_attn_sum_matches_float64(N, K, H, D):
+    """faf_attn_sum_fwd / _bwd against the einsum of fa_former_layer.py:497-506 in float64, forward and both gradients."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + K + D)
+    attn = torch.randn(N, H, K, generator=g).softmax(-1).to(DEV).requires_grad_(True)
+    x = torch.randn(N, K, H * D, generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn(N, H * D, generator=g).to(DEV)
+    assert ops.attn_sum_supported(attn, x)
+    out = ops.attn_sum(attn, x)
+    (out * w).sum().backward()
+    a64, x64 = attn.detach().double().requires_grad_(True), x.detach().double().requires_grad_(True)
+    ref = torch.einsum("nhm,nmhd->nhd", a64, x64.view(N, K, H, D)).reshape(N, -1)
+    (ref * w.double()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(attn.grad.cpu().numpy(), a64.grad.cpu().numpy(), atol=2e-5, rtol=1e-5)
