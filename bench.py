@@ -71,6 +71,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pipeline", action="store_true", help="skip the loader-fed run (`pipeline` in the JSON line)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
+    p.add_argument("--cpu-batch", type=int, default=0,
+                   help="molecules in the CPU-baseline sample batch (0: the GPU batch, or a bounded sample for the methods "
+                        "whose oracle does not fit a CPU at the full batch)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--timeline-replays", type=int, default=30,
                    help="replays of the time-stamped graph that `roofline` averages over")
@@ -280,8 +283,9 @@ def measure_scatter_roofline(model, batch, dev):
 # HBM bytes per launch of k_segment_reduce from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), collected
 # with rocprofv3 on `python3 bench.py --only-roofline` at the BASELINE workload: profiles/r01_pmc_scatter_workload.json.
 # A bench run cannot collect counters itself; the figure is attached only to the workload it was measured on.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 11706695}
-PMC_TRAFFIC_SOURCE = "profiles/r01_pmc_scatter_workload.json (rocprofv3 --pmc on k_segment_reduce, offline)"
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 22633900}
+PMC_TRAFFIC_SOURCE = ("profiles/r02_pmc_scatter_workload.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
+                      "12 scatter launches per step, 2 x FETCH + WRITE, offline)")
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
@@ -549,6 +553,16 @@ def main():
             result["roofline"]["traffic"] = PMC_TRAFFIC_BYTES_PER_LAUNCH.get((a.method, a.batch, a.flavour))
             if result["roofline"]["traffic"] is not None:
                 result["roofline"]["traffic_source"] = PMC_TRAFFIC_SOURCE
+            mf = {}
+            for name in ("k_rowgemm_fwd", "k_rowgemm_bwd"):     # Equiformer's radial tensor product (fp32 MFMA)
+                if name in per:
+                    tf = per[name]["work"] / per[name]["us"] / 1e6
+                    mf[name] = {"launches_per_step": per[name]["launches_per_step"], "us": round(per[name]["us"], 1),
+                                "mfma_flops": int(per[name]["work"]), "achieved": round(tf, 1), "unit": "TFLOP/s",
+                                "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+            if mf:
+                mf["bound"] = "mfma"
+                result["roofline"]["rowgemm_kernels"] = mf
             edge = {}
             for name in ("egnn_edge_fwd", "egnn_edge_bwd"):
                 if name in per:     # fp32 MFMA flops only (the SiLU / gather VALU work is not counted)
@@ -565,7 +579,11 @@ def main():
         if not a.no_pipeline and use_graph and world == 1:
             result["pipeline"] = measure_pipeline(a.method, a.batch, a.flavour, dev, rank)
         if world == 1 and not a.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(a.method, run_args, host_batches[0], a.cpu_seconds)
+            # equiformer_equihnns at hidden 256 materialises 9.7 GB of radial weights per pair type at batch 128 on the
+            # CPU (as the reference does); FAFormer at 15 k atoms a dense [N, N] search: bounded samples for those
+            cb = a.cpu_batch or {"equiformer_equihnns": 8, "faformer_equihnns": 64}.get(a.method, a.batch)
+            sample = host_batches[0] if cb == a.batch else synth_batch(cb, 2000, a.flavour)
+            result["cpu_baseline"] = cpu_baseline(a.method, run_args, sample, a.cpu_seconds)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -372,9 +372,29 @@ __global__ void k_index_aux(const int64_t* __restrict__ vertex, const int64_t* _
                             const int64_t* __restrict__ batch, int64_t n_nodes, int64_t n_edges,
                             const int* __restrict__ rowptr_v, const int* __restrict__ rowptr_e,
                             int* __restrict__ v32, int* __restrict__ e32, int* __restrict__ batch32,
-                            float* __restrict__ has_v, float* __restrict__ has_e) {
+                            float* __restrict__ has_v, float* __restrict__ has_e,
+                            const int* __restrict__ col_v, const int* __restrict__ col_e, float* __restrict__ ew_v,
+                            float* __restrict__ ew_e) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // per-entry mean weights of the two CSRs with respect to each other's rows (the backward of a gathered mean reads
+    // w[q] next to col[q] instead of chasing col[q] -> rowptr): entry q of the node CSR lists hyperedge col_v[q]
+    if (ew_v) {
+        const int64_t nv = rowptr_v[n_nodes];
+        for (int64_t q = t0; q < nv; q += stride) {
+            const int e = col_v[q];
+            const int d = rowptr_e[e + 1] - rowptr_e[e];
+            ew_v[q] = 1.0f / (float)(d > 1 ? d : 1);
+        }
+    }
+    if (ew_e) {
+        const int64_t ne = rowptr_e[n_edges];
+        for (int64_t q = t0; q < ne; q += stride) {
+            const int v = col_e[q];
+            const int d = rowptr_v[v + 1] - rowptr_v[v];
+            ew_e[q] = 1.0f / (float)(d > 1 ? d : 1);
+        }
+    }
     for (int64_t p = t0; p < nnz; p += stride) {
         const int64_t v = vertex[p], e = edges[p];
         v32[p] = (v >= 0 && v < n_nodes && e >= 0 && e < n_edges) ? (int)v : -1;
@@ -554,7 +574,7 @@ extern "C" int hg_csr_build_batch(int32_t n, const int64_t* const* key, const in
 extern "C" int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
                             int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
                             int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e,
-                            void* stream_) {
+                            const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, void* stream_) {
     if (nnz < 0 || n_nodes < 0 || n_edges < 0) return EQH_ERR_ARG;
     if (nnz > 0 && (!vertex || !edges || !v32 || !e32)) return EQH_ERR_ARG;
     if (n_nodes > 0 && (!rowptr_v || !has_v || (batch32 && !batch))) return EQH_ERR_ARG;
@@ -562,7 +582,9 @@ extern "C" int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t
     const int64_t most = nnz > n_nodes ? (nnz > n_edges ? nnz : n_edges) : (n_nodes > n_edges ? n_nodes : n_edges);
     if (most == 0) return EQH_OK;
     hipLaunchKernelGGL(k_index_aux, dim3(eqh_grid_for(most, 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                       vertex, edges, nnz, batch, n_nodes, n_edges, rowptr_v, rowptr_e, v32, e32, batch32, has_v, has_e);
+                       vertex, edges, nnz, batch, n_nodes, n_edges, rowptr_v, rowptr_e, v32, e32, batch32, has_v, has_e,
+                       (ew_v && col_v) ? col_v : nullptr, (ew_e && col_e) ? col_e : nullptr, col_v ? ew_v : nullptr,
+                       col_e ? ew_e : nullptr);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

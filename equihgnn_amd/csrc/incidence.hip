@@ -158,6 +158,64 @@ k_inc_fwd(const float* __restrict__ pa, const float* __restrict__ qb, const int*
     }
 }
 
+// The same sum when the OUTPUT row is one of the two operands' indices (always the case in conv.py: messages are
+// reduced over the hyperedges or over the nodes of the incidences): row r's own operand row is r itself and the other
+// operand's row is the CSR's `col` entry, so the chain rowptr -> perm -> (ia, ib) -> rows shortens to rowptr -> col ->
+// rows, and the rows of incidence j+1 are gathered while incidence j is normalised.
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const int* __restrict__ rowptr,
+              const int* __restrict__ col, int row_is_a, const float* __restrict__ gamma, const float* __restrict__ beta,
+              float* __restrict__ out, int n_rows, int C, int mean, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        Row<NV> acc;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        for (int q0 = beg; q0 < end; q0 += 64) {
+            const int cnt = (end - q0 < 64) ? (end - q0) : 64;
+            const int my_o = (lane < cnt) ? col[q0 + lane] : 0;
+            Row<NV> u, w;
+            {
+                const int o = __shfl(my_o, 0, 64);
+                gather_pair<NV>(pa, qb, row_is_a ? r : o, row_is_a ? o : r, C, lane, u, w);
+            }
+            for (int j = 0; j < cnt; ++j) {
+                Row<NV> un, wn;
+                const int o = __shfl(my_o, (j + 1 < cnt) ? j + 1 : j, 64);
+                gather_pair<NV>(pa, qb, row_is_a ? r : o, row_is_a ? o : r, C, lane, un, wn);   // next (or the same) pair
+                Row<NV> x;
+                unsigned pos;
+                float rstd;
+                norm_pair<NV>(u, w, C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) f4_add(acc.v[i], x.v[i]);
+                u = un;
+                w = wn;
+            }
+        }
+        const int deg = end - beg;
+        const float den = (mean && deg > 1) ? (float)deg : 1.0f;
+        const float bscale = mean ? (deg > 0 ? 1.0f : 0.0f) : (float)deg;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                float4 o;
+                o.x = fmaf(g.x, acc.v[i].x / den, b.x * bscale);
+                o.y = fmaf(g.y, acc.v[i].y / den, b.y * bscale);
+                o.z = fmaf(g.z, acc.v[i].z / den, b.z * bscale);
+                o.w = fmaf(g.w, acc.v[i].w / den, b.w * bscale);
+                *reinterpret_cast<float4*>(out + (int64_t)r * C + c) = o;
+            }
+        }
+    }
+}
+
 // One side of the backward.  Rows of (side_rowptr, side_perm) group the incidences by the index of
 // the operand whose gradient is produced (SIDE_A: ia, else ib -- so the row of an incidence is simply
 // that index); `okey[p]` is the OUTPUT row of incidence p and `orowptr` the forward CSR's rowptr (for
@@ -497,6 +555,26 @@ extern "C" int hg_incidence_ln_reduce_fwd(const float* pa, const float* qb, cons
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_inc_fwd<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream,
                            pa, qb, ia, ib, rowptr, perm, gamma, beta, out, (int)n_rows, (int)C, (int)mean, eps);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" int hg_incidence_ln_reduce_fwd_col(const float* pa, const float* qb, const int32_t* rowptr, const int32_t* col,
+                                              int32_t row_is_a, const float* gamma, const float* beta, int64_t n_rows,
+                                              int32_t C, int32_t mean, float eps, float* out, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!pa || !qb || !rowptr || !col || !gamma || !beta || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(pa) || !eqh_aligned16(qb) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) ||
+        !eqh_aligned16(out))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_inc_fwd_col<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream,
+                           pa, qb, rowptr, col, (int)row_is_a, gamma, beta, out, (int)n_rows, (int)C, (int)mean, eps);
         EQH_CHECK_LAUNCH();
         return EQH_OK;
     });

@@ -33,6 +33,8 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "hg_segment_reduce_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                         c_int32, c_int32, c_void_p]),
+    "hg_entry_weights": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "hg_segment_reduce_w_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
     "hg_embed_sum_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64,
                                    c_void_p, c_void_p]),
     "hg_embed_sum_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int64]),
@@ -45,6 +47,8 @@ SIGNATURES = {
                       + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_rowgemm_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "hg_incidence_ln_reduce_fwd": (c_int32, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]),
+    "hg_incidence_ln_reduce_fwd_col": (c_int32, [c_void_p] * 4 + [c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float,
+                                                 c_void_p, c_void_p]),
     "hg_incidence_ln_reduce_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_incidence_ln_reduce_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_void_p, c_void_p, c_int64] + [c_void_p] * 4
                                    + [c_int32, c_int32, c_float] + [c_void_p] * 3 + [c_int32, c_void_p, c_size_t,
@@ -93,7 +97,7 @@ SIGNATURES = {
                             + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_csr_build_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
     "hg_csr_build_batch": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
-    "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 8),
+    "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 12),
     "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

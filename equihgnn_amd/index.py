@@ -40,7 +40,8 @@ class HyperIndex:
         # reads them as zero rows, so they get a zero row forward and a zero gradient backward; the CSRs never
         # list them), int32 `batch`, and the masks of rows a mean leaves at zero -- one launch (hg_index_aux)
         self.v32, self.e32, self.batch32, has_v, has_e = ops.index_aux(vertex, edges, batch, self.N, self.M,
-                                                                       self.by_v.rowptr, self.by_e.rowptr)
+                                                                       self.by_v.rowptr, self.by_e.rowptr,
+                                                                       self.by_v, self.by_e)
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
         self._he_pool = None

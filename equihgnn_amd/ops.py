@@ -53,6 +53,7 @@ class CSR:
     col: torch.Tensor
     n_rows: int
     nnz: int
+    entry_w: Optional[torch.Tensor] = None    # per-entry mean weights 1 / deg(col[q]) w.r.t. the TRANSPOSED CSR (entry_weights)
 
 
 def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1) -> CSR:
@@ -112,8 +113,10 @@ def csr_build_batch(problems):
     return [CSR(o[0], o[1][:o[4]], o[2][:o[4]], o[3], o[4]) for o in outs]
 
 
-def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr_e):
-    """hg_index_aux: (v32, e32, batch32 or None, has_v [N] float, has_e [M] float)."""
+def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr_e, by_v: Optional[CSR] = None,
+              by_e: Optional[CSR] = None):
+    """hg_index_aux: (v32, e32, batch32 or None, has_v [N] float, has_e [M] float).  With the two CSRs it also fills
+    their ``entry_w`` (per-entry mean weights with respect to each other's rows) in the same launch."""
     _require_gpu(vertex, "index_aux")
     dev = vertex.device
     vertex, edges = vertex.contiguous(), edges.contiguous()
@@ -123,9 +126,16 @@ def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr
     b32 = torch.empty(n_nodes, dtype=torch.int32, device=dev) if batch is not None else None
     has_v = torch.empty(n_nodes, dtype=torch.float32, device=dev)
     has_e = torch.empty(n_edges, dtype=torch.float32, device=dev)
+    col_v = col_e = ew_v = ew_e = None
+    if by_v is not None and by_e is not None:
+        col_v, col_e = by_v.col, by_e.col
+        ew_v = torch.empty(max(by_v.nnz, 1), dtype=torch.float32, device=dev)
+        ew_e = torch.empty(max(by_e.nnz, 1), dtype=torch.float32, device=dev)
+        by_v.entry_w, by_e.entry_w = ew_v, ew_e
     hip.check(hip.lib().hg_index_aux(_ptr(vertex), _ptr(edges), nnz, _ptr(batch.contiguous()) if batch is not None else None,
                                      n_nodes, n_edges, _ptr(rowptr_v), _ptr(rowptr_e), _ptr(v32), _ptr(e32), _ptr(b32),
-                                     _ptr(has_v), _ptr(has_e), _stream(dev)), "hg_index_aux")
+                                     _ptr(has_v), _ptr(has_e), _ptr(col_v), _ptr(col_e), _ptr(ew_v), _ptr(ew_e), _stream(dev)),
+              "hg_index_aux")
     return v32, e32, b32, has_v, has_e
 
 
@@ -298,6 +308,29 @@ def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=
     return (o, ao) if a_out else o
 
 
+def entry_weights(csr: CSR, csr_t: CSR) -> torch.Tensor:
+    """w[q] = 1 / max(deg_t(csr.col[q]), 1): the mean weights of csr's entries with respect to the rows of ``csr_t``
+    (hg_entry_weights), cached on ``csr``."""
+    if csr.entry_w is None:
+        w = torch.empty(max(csr.nnz, 1), dtype=torch.float32, device=csr.col.device)
+        hip.check(hip.lib().hg_entry_weights(_ptr(csr.col), _ptr(csr_t.rowptr), csr.nnz, _ptr(w), _stream(w.device)),
+                  "hg_entry_weights")
+        csr.entry_w = w
+    return csr.entry_w
+
+
+def _segment_reduce_w(src, csr: CSR, entry_w) -> torch.Tensor:
+    """out[r] = sum_{q in row r} entry_w[q] * src[csr.col[q]] (hg_segment_reduce_w_f32)."""
+    src = _f32c(src)
+    C = src.shape[-1]
+    out = torch.empty((csr.n_rows, C), dtype=torch.float32, device=src.device)
+    timed("k_segment_reduce<weighted>", segment_reduce_bytes(csr.nnz, csr.n_rows, C, True, True, False) + 4 * csr.nnz,
+          lambda: hip.check(hip.lib().hg_segment_reduce_w_f32(_ptr(src), _ptr(csr.col), _ptr(csr.rowptr), _ptr(entry_w),
+                                                              _ptr(out), csr.n_rows, C, _stream(src.device)),
+                            "hg_segment_reduce_w_f32"))
+    return out
+
+
 def _as2d(t: torch.Tensor):
     """The Equiformer wrapper carries a leading 1-dim (equihnn_equiformer.py:82-85); every op
     here reduces along dim -2, so flatten the leading dims of size 1."""
@@ -319,13 +352,16 @@ class _ReduceGathered(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, csr: CSR, csr_t: CSR, mean: bool):
         ctx.csr, ctx.csr_t, ctx.mean = csr, csr_t, mean
+        if mean:
+            ctx.ew = entry_weights(csr_t, csr)     # once per batch (cached on the CSR): built here, outside the backward
         return _segment_reduce(src, csr.col, csr.rowptr, None, csr.n_rows, mean)
 
     @staticmethod
     def backward(ctx, dout):
         csr, csr_t = ctx.csr, ctx.csr_t
-        dsrc = _segment_reduce(dout, csr_t.col, csr_t.rowptr, csr.rowptr if ctx.mean else None,
-                               csr_t.n_rows, False)
+        if ctx.mean:
+            return _segment_reduce_w(dout, csr_t, ctx.ew), None, None, None
+        dsrc = _segment_reduce(dout, csr_t.col, csr_t.rowptr, None, csr_t.n_rows, False)
         return dsrc, None, None, None
 
 
@@ -491,11 +527,18 @@ class _IncidenceLnReduce(torch.autograd.Function):
         C = pa.shape[1]
         out = torch.empty((out_csr.n_rows, C), dtype=torch.float32, device=pa.device)
         # algorithmic bytes: two gathered rows per incidence + one output row, three index words per incidence, rowptr
-        timed("k_inc_fwd", 4 * C * (2 * out_csr.nnz + out_csr.n_rows) + 12 * out_csr.nnz + 4 * (out_csr.n_rows + 1) + 8 * C,
-              lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
-                  _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
-                  _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
-                  "hg_incidence_ln_reduce_fwd"))
+        work = 4 * C * (2 * out_csr.nnz + out_csr.n_rows) + 12 * out_csr.nnz + 4 * (out_csr.n_rows + 1) + 8 * C
+        if okey32 is ia32 or okey32 is ib32:
+            # the output row is one operand's own index: (rowptr, col) of the output CSR says it all
+            timed("k_inc_fwd", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(
+                _ptr(pa), _ptr(qb), _ptr(out_csr.rowptr), _ptr(out_csr.col), 1 if okey32 is ia32 else 0, _ptr(gamma),
+                _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
+                "hg_incidence_ln_reduce_fwd_col"))
+        else:
+            timed("k_inc_fwd", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
+                _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
+                _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
+                "hg_incidence_ln_reduce_fwd"))
         ctx.save_for_backward(pa, qb, gamma)
         ctx.meta = (ia32, ib32, csr_a, csr_b, out_csr, okey32, mean, eps)
         ctx.acc = acc_params
@@ -1227,8 +1270,9 @@ class _RowGemm(torch.autograd.Function):
         if Kd2 != Kd or rowptr.numel() != R + 1:
             raise ValueError("rowgemm: z[E,Kd], w[R,Kd,L], rowptr[R+1] expected")
         out = torch.zeros((E, L), dtype=torch.float32, device=z.device)  # entries outside every row stay 0
-        hip.check(hip.lib().hg_rowgemm_fwd(_ptr(z), _ptr(w), _ptr(rowptr), _ptr(perm), R, Kd, L, _ptr(out), 0,
-                                           _stream(z.device)), "hg_rowgemm_fwd")
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(hip.lib().hg_rowgemm_fwd(_ptr(z), _ptr(w), _ptr(rowptr), _ptr(perm), R, Kd, L, _ptr(out), 0,
+                                                         _stream(z.device)), "hg_rowgemm_fwd"))
         ctx.save_for_backward(z, w)
         ctx.rowptr, ctx.perm = rowptr, perm
         return out
@@ -1262,10 +1306,12 @@ class _RowGemm2(torch.autograd.Function):
         out = torch.empty((E, L), dtype=torch.float32, device=z.device)
         L_ = hip.lib()
         st = _stream(z.device)
-        hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0, st),
-                  "hg_rowgemm_fwd")
-        hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1, st),
-                  "hg_rowgemm_fwd")
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0, st),
+                                "hg_rowgemm_fwd"))
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1, st),
+                                "hg_rowgemm_fwd"))
         ctx.save_for_backward(z, wa, wb)
         ctx.idx = (rowptr_a, perm_a, rowptr_b, perm_b)
         return out
@@ -1283,10 +1329,14 @@ class _RowGemm2(torch.autograd.Function):
         dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] else None
         L_ = hip.lib()
         st = _stream(z.device)
-        hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz), 0,
-                                    _ptr(dwa), st), "hg_rowgemm_bwd")
-        hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
-                                    _ptr(dwb), st), "hg_rowgemm_bwd")
+        E = z.shape[0]
+        nf = (2 if need_z else 0) * E * Kd * L
+        timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwa is not None else 0),
+              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz), 0,
+                                                  _ptr(dwa), st), "hg_rowgemm_bwd"))
+        timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwb is not None else 0),
+              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
+                                                  _ptr(dwb), st), "hg_rowgemm_bwd"))
         return dz, dwa, None, None, dwb, None, None
 
 

@@ -138,10 +138,13 @@ int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int6
  * incidence coordinates (null incidences -- either coordinate out of range -- become -1 in both) and of `batch`
  * (batch32 may be NULL), and
  * the float 0/1 masks "row has at least one incidence" of the two CSRs (conv.py's mean leaves such rows
- * at zero, so the bias of the last Linear must not reach them). */
+ * at zero, so the bias of the last Linear must not reach them).  Optional (NULL to skip): col_v / col_e, the `col`
+ * arrays of the two CSRs, and ew_v / ew_e, which receive the per-entry mean weights of each CSR with respect to the
+ * other's rows (ew_v[q] = 1 / max(deg_e(col_v[q]), 1)), as hg_entry_weights would. */
 int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
                  int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
-                 int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e, void* stream);
+                 int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e,
+                 const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, void* stream);
 size_t hg_csr_build_batch_workspace_bytes(int32_t n, const int64_t* nnz, const int64_t* n_rows);
 int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* const* other, const int64_t* nnz,
                        const int64_t* n_rows, const int32_t* col_div, int32_t* const* rowptr,
@@ -168,6 +171,12 @@ int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* cons
 int hg_segment_reduce_f32(const float* src, const int32_t* idx, const int32_t* rowptr,
                           const int32_t* src_wptr, float* out, int64_t n_out_rows, int32_t C,
                           int32_t mean, void* stream);
+/* Per-entry form of the mean weights: hg_entry_weights writes w[q] = 1 / max(wptr[idx[q]+1] - wptr[idx[q]], 1) (0 for a
+ * null entry) once per batch; hg_segment_reduce_w_f32 is hg_segment_reduce_f32 with w(idx[q]) read as w[q] (sum, no
+ * per-row scale): the backward of a gathered mean without the dependent rowptr lookups. */
+int hg_entry_weights(const int32_t* idx, const int32_t* wptr, int64_t nnz, float* w, void* stream);
+int hg_segment_reduce_w_f32(const float* src, const int32_t* idx, const int32_t* rowptr, const float* entry_w, float* out,
+                            int64_t n_out_rows, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Embedding-sum — ogb AtomEncoder (equihnn_egnn.py:121,157; mhnn.py:164,201) and
@@ -258,6 +267,11 @@ int hg_incidence_ln_reduce_fwd(const float* pa, const float* qb, const int32_t* 
                                const int32_t* rowptr, const int32_t* perm, const float* gamma,
                                const float* beta, int64_t n_rows, int32_t C, int32_t mean, float eps,
                                float* out, void* stream);
+/* the same forward when the output row IS the index of one operand (row_is_a != 0: ia[p] = r, ib[p] = col[q];
+ * else ib[p] = r, ia[p] = col[q]) -- (rowptr, col) is then the whole description of the incidences of a row */
+int hg_incidence_ln_reduce_fwd_col(const float* pa, const float* qb, const int32_t* rowptr, const int32_t* col,
+                                   int32_t row_is_a, const float* gamma, const float* beta, int64_t n_rows, int32_t C,
+                                   int32_t mean, float eps, float* out, void* stream);
 size_t hg_incidence_ln_reduce_bwd_workspace_bytes(int64_t n_a_rows, int32_t C);
 int hg_incidence_ln_reduce_bwd(const float* pa, const float* qb, const int32_t* ia, const int32_t* ib,
                                const int32_t* a_rowptr, const int32_t* a_perm, int64_t n_a_rows,

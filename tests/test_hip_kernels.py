@@ -610,31 +610,38 @@ def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
 
 @pytest.mark.parametrize("C", [64, 256, 320, 1024])
 @pytest.mark.parametrize("reduce", ["mean", "sum"])
-def test_incidence_ln_reduce_matches_float64_reference(C, reduce):
-    """hg_incidence_ln_reduce_fwd/bwd (gather+gather+add+ReLU+LayerNorm+segmented reduce in one
-    kernel) against the unfused formulation in float64, forward and all four gradients."""
+@pytest.mark.parametrize("path", ["generic", "rows_are_a", "rows_are_b"])
+def test_incidence_ln_reduce_matches_float64_reference(C, reduce, path):
+    """hg_incidence_ln_reduce_fwd / _fwd_col / _bwd (gather+gather+add+ReLU+LayerNorm+segmented reduce in one
+    kernel) against the unfused formulation in float64, forward and all four gradients; the output rows keyed by
+    either operand (the (rowptr, col) form of the forward) or by a separate key vector (the general form)."""
     ops = _ops()
     g = torch.Generator().manual_seed(C)
     N, M, nnz = 150, 140, 420
     v = torch.randint(0, N - 10, (nnz,), generator=g)      # the last 10 node rows have no incidence
     e = torch.randint(0, M, (nnz,), generator=g)
+    v[:70] = 3                                             # one long row (> 64 incidences)
     pa = torch.randn(N, C, generator=g)
     qb = torch.randn(M, C, generator=g)
     gamma = 1 + 0.2 * torch.randn(C, generator=g)
     beta = 0.3 * torch.randn(C, generator=g)
-    w = torch.randn(N, C, generator=g)
+    by_rows_of_b = path == "rows_are_b"
+    R = M if by_rows_of_b else N
+    w = torch.randn(R, C, generator=g)
     t = [x.double().requires_grad_(True) for x in (pa, qb, gamma, beta)]
     h = torch.nn.functional.layer_norm(torch.relu(t[0][v] + t[1][e]), (C,), t[2], t[3], 1e-5)
-    ref = O.segment_reduce(h, v, N, reduce)
+    ref = O.segment_reduce(h, e if by_rows_of_b else v, R, reduce)
     (ref * w.double()).sum().backward()
     by_v = ops.csr_build(v.to(DEV), e.to(DEV), N)
     by_e = ops.csr_build(e.to(DEV), v.to(DEV), M)
     d = [x.to(DEV).requires_grad_(True) for x in (pa, qb, gamma, beta)]
-    out = ops.incidence_ln_reduce(d[0], d[1], d[2], d[3], v.to(DEV).int(), e.to(DEV).int(), by_v, by_e, by_v,
-                                  v.to(DEV).int(), reduce)
+    v32, e32 = v.to(DEV).int(), e.to(DEV).int()
+    okey = {"generic": v.to(DEV).int(), "rows_are_a": v32, "rows_are_b": e32}[path]
+    out = ops.incidence_ln_reduce(d[0], d[1], d[2], d[3], v32, e32, by_v, by_e, by_e if by_rows_of_b else by_v, okey, reduce)
     (out * w.to(DEV)).sum().backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
-    assert float(out[-10:].abs().max()) == 0.0
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=3e-5, rtol=1e-5)
+    if not by_rows_of_b:
+        assert float(out[-10:].abs().max()) == 0.0
     for name, x, r in zip(("dpa", "dqb", "dgamma", "dbeta"), d, t):
         err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max())
         assert err < 2e-5, (name, err)
