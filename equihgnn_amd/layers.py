@@ -228,6 +228,9 @@ def batch_norm_rows(bn: nn.BatchNorm1d, x, mask):
     return y
 
 
+MERGE_LINEARS = True   # MHNNSConv: fold Linear -> (linear map) -> Linear pairs into one Linear (see _prepare_merged)
+
+
 class MHNNSConv(nn.Module):
     """conv.py:104-182 (node features only, W1..W3, alpha residual to X0)."""
 
@@ -270,11 +273,52 @@ class MHNNSConv(nn.Module):
     def prepare(self, X0, index: HyperIndex):
         """``residual`` for forward() when the fused path applies (call once per model forward)."""
         if X0.is_cuda and X0.dim() == 2 and len(self.W2.lins) > 1:
-            return self.residual(X0, index)
+            res = self.residual(X0, index)
+            if self._mergeable(X0) and res[1] is not None:
+                return self._prepare_merged(res)
+            return res
         return None
+
+    # -- merged path ------------------------------------------------------------------------------------------------
+    # Two places of conv.py:169-182 have two Linears with only a LINEAR map between them:
+    #   W1's last Linear -> mean over the hyperedge's nodes (:173) -> the hyperedge half of W2's first Linear (:176), and
+    #   W2's last Linear -> alpha-mix with X0 (:179-180) -> W3's first Linear.
+    # Each pair is one Linear with the product of the two weights, formed at weight level once per forward pass (the
+    # layer's weights are shared by its L applications): 5 instead of 7 [rows x C] x [C x C] products per application
+    # and direction, and the alpha-mix's X0 term goes through W3's first Linear once per forward instead of L times.
+    #   qb = mean_e(h1n) (W2b W1b)^T + (W2b b1 + b2)          h3 = (1 - a) s (W3a W2c)^T + c W3a^T,  c = a X0 + (1 - a) w_r b2c
+    def _mergeable(self, X) -> bool:
+        two = all(len(w.lins) == 2 for w in (self.W1, self.W2, self.W3))
+        return (MERGE_LINEARS and two and self.aggr == "mean" and X.is_cuda and X.dim() == 2 and X.dtype == torch.float32
+                and self.W1._fusable(X) and self.W2._fusable(X) and self.W3._fusable(X)
+                and not (self.W1.InputNorm or self.W2.InputNorm or self.W3.InputNorm))
+
+    def _prepare_merged(self, res):
+        c_dim = self.W1.lins[0].weight.shape[1]
+        w12, b12 = ops.merged_weight(self.W2.lins[0].weight, self.W1.lins[1].weight, self.W1.lins[1].bias,
+                                     self.W2.lins[0].bias, cols=(c_dim, 2 * c_dim))
+        w23, _ = ops.merged_weight(self.W3.lins[0].weight, self.W2.lins[1].weight)
+        cw = ops.linear(res[1], self.W3.lins[0].weight)                   # (a X0 + (1 - a) w_r b) W3a^T, layer-independent
+        return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw}
+
+    def _forward_merged(self, X, ix: HyperIndex, m):
+        c = X.shape[-1]
+        W1, W2, W3 = self.W1, self.W2, self.W3
+        h1, pa = ops.linear2(X, W1.lins[0].weight, None, W2.lins[0].weight, (0, c))
+        n1, n2, n3 = W1.normalizations[1], W2.normalizations[1], W3.normalizations[1]
+        h1n = ops.bias_relu_ln(h1, W1.lins[0].bias, n1.weight, n1.bias, n1.eps)
+        hbar = ops.reduce_gathered(h1n, ix.by_e, ix.by_v, "mean")                              # conv.py:172-173
+        qb = ops.linear(hbar, m["w12"], m["b12"])
+        s = ops.incidence_ln_reduce(pa, qb, n2.weight, n2.bias, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
+                                    "mean", n2.eps)                                            # conv.py:175-177
+        h3 = ops.linear_add(s, m["w23"], m["cw"], m["scale"])                                  # conv.py:179-180 + W3's first Linear
+        x = ops.bias_relu_ln(h3, W3.lins[0].bias, n3.weight, n3.bias, n3.eps)
+        return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias)
 
     def forward(self, X, index: HyperIndex, X0, residual=None):
         ix = index
+        if isinstance(residual, dict):
+            return self._forward_merged(X, ix, residual)
         fused = X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1
         pa = None
         if fused and self.W1.takes_first(X) and not self.W2.InputNorm:

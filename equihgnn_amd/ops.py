@@ -8,6 +8,7 @@ has a CPU fallback: tensors must live on a HIP device.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -727,7 +728,7 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": []}
+_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": [], "merged": []}
 
 
 def _workspace(nbytes, device):
@@ -824,6 +825,12 @@ def defer_flush(device):
         _DEFER["active"] = False
         hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
         _DEFER["keep"].clear()
+    # merged weights (ops.merged_weight): their accumulated gradients are complete now; one backward through each
+    # weight-level product hands them on to the parameters
+    merged = _DEFER["merged"]
+    _DEFER["merged"] = []
+    for outs, accs in merged:
+        torch.autograd.backward(outs, accs)
 
 
 class _MseLoss(torch.autograd.Function):
@@ -977,7 +984,7 @@ def _note_acc(*params):
     """Remember 1-D parameters whose gradient the kernels can accumulate in place."""
     if torch.is_grad_enabled():
         for p in params:
-            if p is not None and p.requires_grad and p.is_leaf:
+            if p is not None and p.requires_grad and p.is_leaf and not hasattr(p, "_eqh_transient"):
                 ACC_PARAMS[id(p)] = p
 
 
@@ -1143,6 +1150,108 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
     blk = dw if c0 is None else dw[:, c0:c1]
     (blk if r0 is None else blk[r0:r1]).copy_(dy2.t() @ x2)
     return dw
+
+
+class _MergedWeight(torch.autograd.Function):
+    """Wc = A[:, a0:a1] @ B and bc = A[:, a0:a1] @ bb + bo: the weight and bias of TWO consecutive Linears with only a
+    linear map between them (y = A_blk (B x + bb) + bo), formed at weight level ([C x C] x [C x C]: 33 MFLOP instead of
+    a [rows x C] x [C x C] product per application and per direction).  A, B, bb, bo are the PARAMETERS.  Backward:
+    dA_blk = dWc B^T + dbc bb^T, dB = A_blk^T dWc, dbb = A_blk^T dbc, dbo = dbc -- added to the parameters' persistent
+    accumulators when they have them."""
+
+    @staticmethod
+    def forward(ctx, A, B, bb, bo, a0, a1):
+        blk = A if a0 is None else A[:, a0:a1]
+        ctx.save_for_backward(A, B, bb, bo)
+        ctx.set_materialize_grads(False)
+        ctx.cols = (a0, a1)
+        wc = blk @ B
+        if bb is None:
+            return wc, None
+        bc = torch.mv(blk, bb)
+        if bo is not None:
+            bc = bc + bo
+        return wc, bc
+
+    @staticmethod
+    def backward(ctx, dwc, dbc):
+        A, B, bb, bo = ctx.saved_tensors
+        a0, a1 = ctx.cols
+        blk = A if a0 is None else A[:, a0:a1]
+        ga, gb = _acc_target(A), _acc_target(B)
+        if dwc is None and dbc is None:
+            return None, None, None, None, None, None
+        if dwc is None:
+            dwc = torch.zeros((blk.shape[0], B.shape[1]), dtype=B.dtype, device=B.device)
+        # A
+        if ga is not None:
+            tgt = ga if a0 is None else ga[:, a0:a1]
+            tgt.addmm_(dwc, B.t())
+            if dbc is not None and bb is not None:
+                tgt.addr_(dbc, bb)
+            dA = None
+        else:
+            dblk = dwc @ B.t()
+            if dbc is not None and bb is not None:
+                dblk = dblk.addr_(dbc, bb)
+            if a0 is None:
+                dA = dblk
+            else:
+                dA = torch.zeros_like(A)
+                dA[:, a0:a1] = dblk
+        # B
+        if gb is not None:
+            gb.addmm_(blk.t(), dwc)
+            dB = None
+        else:
+            dB = blk.t() @ dwc
+        dbb = dbo = None
+        if bb is not None and dbc is not None:
+            t = _acc_target(bb)
+            if t is not None:
+                t.addmv_(blk.t(), dbc)
+            else:
+                dbb = torch.mv(blk.t(), dbc)
+            if bo is not None:
+                t = _acc_target(bo)
+                if t is not None:
+                    t.add_(dbc)
+                else:
+                    dbo = dbc
+        return dA, dB, dbb, dbo, None, None
+
+
+def merged_weight(A, B, bb=None, bo=None, cols=None):
+    """(Wc, bc) with Wc = A[:, cols] @ B and bc = A[:, cols] @ bb + bo (bc None without bb) for parameters A [O, *],
+    B [K, I], bb [K], bo [O]: see _MergedWeight.  While gradient reductions are deferred (graphed trainer) the two
+    results carry accumulators of their own, so the weight gradients of the Linears that use them join the batched
+    launch of defer_flush like any parameter's, and defer_flush then back-propagates them to A, B, bb, bo."""
+    if torch.is_grad_enabled():
+        for w in (A, B):
+            if w.requires_grad and w.is_leaf:
+                LINEAR_PARAMS[id(w)] = w
+        _note_acc(bb, bo)
+    a0, a1 = cols if cols is not None else (None, None)
+    wc, bc = _MergedWeight.apply(A, B, bb, bo, a0, a1)
+    if _DEFER["active"] and torch.is_grad_enabled() and wc.requires_grad and not os.environ.get("EQH_MERGED_PLAIN"):
+        # the Linears see detached leaves with accumulators; the weight-level product stays out of the main backward
+        O, I = wc.shape
+        ld = (I + 3) // 4 * 4
+        acc = torch.zeros((O + 1, max(ld, O)), dtype=torch.float32, device=wc.device)   # rows 0..O-1: dWc; row O: dbc
+        outs, accs = [wc], [acc[:O, :I]]
+        wl = wc.detach().requires_grad_()
+        wl._eqh_transient = True
+        wl._eqh_gbuf = acc[:O, :I]
+        bl = None
+        if bc is not None:
+            bl = bc.detach().requires_grad_()
+            bl._eqh_transient = True
+            bl._eqh_gbuf = acc[O, :O]
+            outs.append(bc)
+            accs.append(acc[O, :O])
+        _DEFER["merged"].append((outs, accs))
+        return wl, bl
+    return wc, bc
 
 
 class _Linear(torch.autograd.Function):
@@ -1355,7 +1464,7 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
 def linear(x, weight, bias=None, cols=None, rows=None):
     """F.linear(x, weight[rows[0]:rows[1], cols[0]:cols[1]], bias[rows[0]:rows[1]]) through _Linear (``weight`` and
     ``bias`` are the PARAMETERS, not slices of them, so that their gradient accumulators can be found)."""
-    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
         LINEAR_PARAMS[id(weight)] = weight
     _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
@@ -1377,7 +1486,7 @@ def linear2(x, wa, cols_a, wb, cols_b):
 
 def linear_add(x, weight, c, scale: float = 1.0):
     """scale * F.linear(x, weight) + c with the addition done by the GEMM epilogue (2-D x, c)."""
-    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf:
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
         LINEAR_PARAMS[id(weight)] = weight
     return _LinearAddC.apply(x, weight, c, scale)
 
