@@ -1233,7 +1233,7 @@ def merged_weight(A, B, bb=None, bo=None, cols=None):
         _note_acc(bb, bo)
     a0, a1 = cols if cols is not None else (None, None)
     wc, bc = _MergedWeight.apply(A, B, bb, bo, a0, a1)
-    if _DEFER["active"] and torch.is_grad_enabled() and wc.requires_grad and not os.environ.get("EQH_MERGED_PLAIN"):
+    if _DEFER["active"] and torch.is_grad_enabled() and wc.requires_grad:
         # the Linears see detached leaves with accumulators; the weight-level product stays out of the main backward
         O, I = wc.shape
         ld = (I + 3) // 4 * 4
