@@ -102,7 +102,8 @@ def seg_reduce_bytes(nnz, n_out, C, has_idx, has_ptr, has_w, n_src):
     return b
 
 
-SCATTER_KERNELS = ("k_segment_reduce", "k_segment_reduce<weighted>", "k_inc_fwd", "k_inc_bwd_both")
+SCATTER_KERNELS = ("k_segment_reduce", "k_segment_reduce<weighted>", "k_gather_ln_fwd", "k_gather_ln_bwd", "k_inc_fwd",
+                   "k_inc_bwd_both")
 
 
 def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):

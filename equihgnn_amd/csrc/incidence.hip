@@ -169,31 +169,50 @@ k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const 
               float* __restrict__ out, int n_rows, int C, int mean, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
+    const float* __restrict__ own = row_is_a ? pa : qb;      // the operand indexed by the output row
+    const float* __restrict__ oth = row_is_a ? qb : pa;      // the operand indexed by the CSR's col
+    Row<NV> gam, bet;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
+        bet.v[i] = (c < C) ? *reinterpret_cast<const float4*>(beta + c) : f4_zero();
+    }
+    auto fetch = [&](const float* __restrict__ base, int o, Row<NV>& u) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            u.v[i] = (c < C) ? *reinterpret_cast<const float4*>(base + (int64_t)o * C + c) : f4_zero();
+        }
+    };
     for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
         const int beg = rowptr[r], end = rowptr[r + 1];
-        Row<NV> acc;
+        Row<NV> acc, mine;
+        fetch(own, r, mine);                                 // once per row (it does not wait for the index chain)
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        auto add_norm = [&](const Row<NV>& w) {
+            Row<NV> x;
+            unsigned pos;
+            float rstd;
+            norm_pair<NV>(mine, w, C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) f4_add(acc.v[i], x.v[i]);
+        };
         for (int q0 = beg; q0 < end; q0 += 64) {
             const int cnt = (end - q0 < 64) ? (end - q0) : 64;
             const int my_o = (lane < cnt) ? col[q0 + lane] : 0;
-            Row<NV> u, w;
-            {
-                const int o = __shfl(my_o, 0, 64);
-                gather_pair<NV>(pa, qb, row_is_a ? r : o, row_is_a ? o : r, C, lane, u, w);
-            }
-            for (int j = 0; j < cnt; ++j) {
-                Row<NV> un, wn;
-                const int o = __shfl(my_o, (j + 1 < cnt) ? j + 1 : j, 64);
-                gather_pair<NV>(pa, qb, row_is_a ? r : o, row_is_a ? o : r, C, lane, un, wn);   // next (or the same) pair
-                Row<NV> x;
-                unsigned pos;
-                float rstd;
-                norm_pair<NV>(u, w, C, lane, inv_c, eps, x, pos, &rstd);
-#pragma unroll
-                for (int i = 0; i < NV; ++i) f4_add(acc.v[i], x.v[i]);
-                u = un;
-                w = wn;
+            for (int j = 0; j < cnt; j += 4) {               // four entries' rows in flight together
+                Row<NV> w0, w1, w2, w3;
+                const int last = cnt - 1;
+                fetch(oth, __shfl(my_o, j, 64), w0);
+                fetch(oth, __shfl(my_o, (j + 1 < cnt) ? j + 1 : last, 64), w1);
+                fetch(oth, __shfl(my_o, (j + 2 < cnt) ? j + 2 : last, 64), w2);
+                fetch(oth, __shfl(my_o, (j + 3 < cnt) ? j + 3 : last, 64), w3);
+                add_norm(w0);
+                if (j + 1 < cnt) add_norm(w1);
+                if (j + 2 < cnt) add_norm(w2);
+                if (j + 3 < cnt) add_norm(w3);
             }
         }
         const int deg = end - beg;
@@ -203,8 +222,83 @@ k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const 
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (c < C) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                const float4 b = *reinterpret_cast<const float4*>(beta + c);
+                const float4 g = gam.v[i], b = bet.v[i];
+                float4 o;
+                o.x = fmaf(g.x, acc.v[i].x / den, b.x * bscale);
+                o.y = fmaf(g.y, acc.v[i].y / den, b.y * bscale);
+                o.z = fmaf(g.z, acc.v[i].z / den, b.z * bscale);
+                o.w = fmaf(g.w, acc.v[i].w / den, b.w * bscale);
+                *reinterpret_cast<float4*>(out + (int64_t)r * C + c) = o;
+            }
+        }
+    }
+}
+
+// ONE gathered operand: out[r] = gamma * reduce_{q in row r} xhat(relu(h[col[q]] + bias)) + beta * [..] -- a dense-row hidden
+// layer (Linear -> ReLU -> LayerNorm, mlp.py:91-99) whose output is only ever consumed through the gathered reduction
+// that follows it (conv.py:172-173: scatter(W1(X)[vertex], edges) after moving W1's last Linear behind the mean).
+// The [N, C] normalised tensor is never written: k_rowln_fwd + k_segment_reduce in one launch.
+template <int NV>
+__global__ void __launch_bounds__(THREADS)
+k_gather_ln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const int* __restrict__ rowptr,
+                const int* __restrict__ col, const float* __restrict__ gamma, const float* __restrict__ beta,
+                float* __restrict__ out, int n_rows, int C, int mean, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    Row<NV> bias_row, gam, bet;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        bias_row.v[i] = (c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+        gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
+        bet.v[i] = (c < C) ? *reinterpret_cast<const float4*>(beta + c) : f4_zero();
+    }
+    auto fetch = [&](int o, Row<NV>& u) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            u.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)o * C + c) : f4_zero();
+        }
+    };
+    for (int r = blockIdx.x * WAVES + wave; r < n_rows; r += gridDim.x * WAVES) {
+        const int beg = rowptr[r], end = rowptr[r + 1];
+        Row<NV> acc;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        auto add_norm = [&](const Row<NV>& u) {
+            Row<NV> x;
+            unsigned pos;
+            float rstd;
+            norm_pair<NV>(u, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) f4_add(acc.v[i], x.v[i]);
+        };
+        for (int q0 = beg; q0 < end; q0 += 64) {
+            const int cnt = (end - q0 < 64) ? (end - q0) : 64;
+            const int my_o = (lane < cnt) ? col[q0 + lane] : 0;
+            // the rows of up to four entries are requested together (hyperedges have 2-3 nodes: one round trip per
+            // row instead of one per entry); entries past the end re-read the last one and are not added
+            for (int j = 0; j < cnt; j += 4) {
+                Row<NV> u0, u1, u2, u3;
+                const int last = cnt - 1;
+                fetch(__shfl(my_o, j, 64), u0);
+                fetch(__shfl(my_o, (j + 1 < cnt) ? j + 1 : last, 64), u1);
+                fetch(__shfl(my_o, (j + 2 < cnt) ? j + 2 : last, 64), u2);
+                fetch(__shfl(my_o, (j + 3 < cnt) ? j + 3 : last, 64), u3);
+                add_norm(u0);
+                if (j + 1 < cnt) add_norm(u1);
+                if (j + 2 < cnt) add_norm(u2);
+                if (j + 3 < cnt) add_norm(u3);
+            }
+        }
+        const int deg = end - beg;
+        const float den = (mean && deg > 1) ? (float)deg : 1.0f;
+        const float bscale = mean ? (deg > 0 ? 1.0f : 0.0f) : (float)deg;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) {
+                const float4 g = gam.v[i], b = bet.v[i];
                 float4 o;
                 o.x = fmaf(g.x, acc.v[i].x / den, b.x * bscale);
                 o.y = fmaf(g.y, acc.v[i].y / den, b.y * bscale);
@@ -508,6 +602,148 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
     }
 }
 
+// Backward of k_gather_ln_fwd.  The LayerNorm backward is linear in its upstream gradient and every incidence of source
+// row v shares v's statistics, so  dh[v] = LNbwd_v( sum_{q in row v of the TRANSPOSED CSR} w[q] * dout[col[q]] ):
+// the weighted gathered reduction (k_segment_reduce<weighted>) and k_rowln_bwd in one launch, no [N, C] gradient between
+// them.  w[q] = 1 / deg(col[q]) for the mean (hg_entry_weights), NULL for the sum.  A wavefront owns a range of
+// consecutive rows: one chain fetches the row ends and up to 64 entries of the range (a lane each), the next gathered row
+// and the next h row are in flight while the current ones are used.  Slab layout as k_rowln_bwd: [dbias | dgamma | dbeta].
+constexpr int GL_WAVES = 8;    // wavefronts per workgroup of k_gather_ln_bwd (one slab per workgroup)
+template <int NV>
+__global__ void __launch_bounds__(GL_WAVES * 64)
+k_gather_ln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
+                const float* __restrict__ dout, const int* __restrict__ t_rowptr, const int* __restrict__ t_col,
+                const float* __restrict__ t_w, float* __restrict__ dh, float* __restrict__ slab, int n_rows, int C,
+                float eps, int rows_per_wave) {
+    __shared__ float4 s_red[GL_WAVES * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inv_c = 1.0f / (float)C;
+    Row<NV> gam, a_db, a_dg, a_dbeta, bias_row;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        gam.v[i] = (c < C) ? *reinterpret_cast<const float4*>(gamma + c) : f4_zero();
+        bias_row.v[i] = (c < C) ? *reinterpret_cast<const float4*>(bias + c) : f4_zero();
+        a_db.v[i] = a_dg.v[i] = a_dbeta.v[i] = f4_zero();
+    }
+    const int64_t s_beg64 = (int64_t)(blockIdx.x * GL_WAVES + wave) * rows_per_wave;   // rows_per_wave <= 64
+    const int s_beg = (s_beg64 < n_rows) ? (int)s_beg64 : n_rows;
+    const int s_end = (s_beg + rows_per_wave < n_rows) ? s_beg + rows_per_wave : n_rows;
+    if (s_beg < s_end) {
+        const int p_beg = t_rowptr[s_beg];
+        const int my_rend = (s_beg + lane < s_end) ? t_rowptr[s_beg + lane + 1] : 0;   // lane i: end of row s_beg + i
+        const int p_end = t_rowptr[s_end];
+        auto fetch_h = [&](int row, Row<NV>& u) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                u.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)row * C + c) : f4_zero();
+            }
+        };
+        auto fetch_d = [&](int e, Row<NV>& u) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                u.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dout + (int64_t)e * C + c) : f4_zero();
+            }
+        };
+        Row<NV> nh;
+        fetch_h(s_beg, nh);                        // does not wait for the index chain
+        int q0 = p_beg;
+        int cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+        int my_c = (lane < cnt) ? t_col[q0 + lane] : 0;
+        float my_w = (t_w && lane < cnt) ? t_w[q0 + lane] : 1.0f;
+        int q = p_beg;
+        for (int row = s_beg; row < s_end; ++row) {
+            const int rend = __builtin_amdgcn_readlane(my_rend, row - s_beg);
+            const Row<NV> ch = nh;
+            fetch_h(row + 1 < s_end ? row + 1 : row, nh);
+            Row<NV> dsum;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) dsum.v[i] = f4_zero();
+            while (q < rend) {
+                if (q - q0 >= 64) {     // next chunk of the range's entries (rare: ranges hold a few short rows)
+                    q0 += 64;
+                    cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+                    my_c = (lane < cnt) ? t_col[q0 + lane] : 0;
+                    my_w = (t_w && lane < cnt) ? t_w[q0 + lane] : 1.0f;
+                }
+                // up to four of the row's entries in flight together (those past the row / chunk end re-read the
+                // last valid one with weight 0)
+                const int j = q - q0;
+                int lim = rend - q0;
+                if (lim > cnt) lim = cnt;
+                const int n = (lim - j < 4) ? lim - j : 4;
+                Row<NV> d0, d1, d2, d3;
+                const int j1 = (n > 1) ? j + 1 : j, j2 = (n > 2) ? j + 2 : j, j3 = (n > 3) ? j + 3 : j;
+                fetch_d(__builtin_amdgcn_readlane(my_c, j), d0);
+                fetch_d(__builtin_amdgcn_readlane(my_c, j1), d1);
+                fetch_d(__builtin_amdgcn_readlane(my_c, j2), d2);
+                fetch_d(__builtin_amdgcn_readlane(my_c, j3), d3);
+                const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+                const float w1 = (n > 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j1)) : 0.f;
+                const float w2 = (n > 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j2)) : 0.f;
+                const float w3 = (n > 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j3)) : 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    f4_fma(dsum.v[i], d0.v[i], w0);
+                    f4_fma(dsum.v[i], d1.v[i], w1);
+                    f4_fma(dsum.v[i], d2.v[i], w2);
+                    f4_fma(dsum.v[i], d3.v[i], w3);
+                }
+                q += n;
+            }
+            Row<NV> x, g;
+            unsigned pos;
+            float rstd;
+            norm_pair<NV>(ch, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                float4 d = dsum.v[i];
+                f4_add(a_dbeta.v[i], d);
+                a_dg.v[i].x = fmaf(d.x, x.v[i].x, a_dg.v[i].x); a_dg.v[i].y = fmaf(d.y, x.v[i].y, a_dg.v[i].y);
+                a_dg.v[i].z = fmaf(d.z, x.v[i].z, a_dg.v[i].z); a_dg.v[i].w = fmaf(d.w, x.v[i].w, a_dg.v[i].w);
+                d.x *= gam.v[i].x; d.y *= gam.v[i].y; d.z *= gam.v[i].z; d.w *= gam.v[i].w;
+                g.v[i] = d;
+                m1 += (d.x + d.y) + (d.z + d.w);
+                m2 += (d.x * x.v[i].x + d.y * x.v[i].y) + (d.z * x.v[i].z + d.w * x.v[i].w);
+            }
+            wave_sum2(m1, m2);
+            m1 *= inv_c;
+            m2 *= inv_c;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 4;
+                const unsigned b = pos >> (4 * i);
+                float4 dx;
+                dx.x = (b & 1u) ? rstd * (g.v[i].x - m1 - x.v[i].x * m2) : 0.f;
+                dx.y = (b & 2u) ? rstd * (g.v[i].y - m1 - x.v[i].y * m2) : 0.f;
+                dx.z = (b & 4u) ? rstd * (g.v[i].z - m1 - x.v[i].z * m2) : 0.f;
+                dx.w = (b & 8u) ? rstd * (g.v[i].w - m1 - x.v[i].w * m2) : 0.f;
+                f4_add(a_db.v[i], dx);
+                if (c < C) *reinterpret_cast<float4*>(dh + (int64_t)row * C + c) = dx;
+            }
+        }
+    }
+    float* __restrict__ sl = slab + (int64_t)blockIdx.x * 3 * C;
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s_red[threadIdx.x] = which == 0 ? a_db.v[i] : (which == 1 ? a_dg.v[i] : a_dbeta.v[i]);
+            __syncthreads();
+            if (wave == 0) {
+                float4 t = s_red[lane];
+                for (int w2 = 1; w2 < GL_WAVES; ++w2) f4_add(t, s_red[w2 * 64 + lane]);
+                const int c = (lane + 64 * i) * 4;
+                if (c < C) *reinterpret_cast<float4*>(sl + which * C + c) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // a slab of 3C partial sums per workgroup: few workgroups for the usual ~5 k rows, but the 2 M-row frame tensors of
 // FAFormer need the whole chip's worth of wavefronts in flight (each walks its rows one memory round trip at a time)
 inline int rowln_blocks(int64_t rows) { return eqh_grid_for(rows, WAVES * 4, rows > 65536 ? 2048 : 256); }
@@ -519,6 +755,15 @@ inline int bwd_rpw(int64_t rows) {
 }
 inline int bwd_blocks(int64_t rows) {
     const int64_t per_block = (int64_t)bwd_rpw(rows) * WAVES;
+    const int64_t b = (rows + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// k_gather_ln_bwd keeps its range's row ends one per lane
+// (about 8192 wavefronts per launch: the chip's worth, so that every index chain is in flight at once)
+inline int gl_rpw(int64_t rows) { const int64_t r = (rows + 8191) / 8192; return r > 64 ? 64 : (r < 1 ? 1 : (int)r); }
+inline int gl_blocks(int64_t rows) {
+    const int64_t per_block = (int64_t)gl_rpw(rows) * GL_WAVES;
     const int64_t b = (rows + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : b);
 }
@@ -670,6 +915,63 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
         hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy,
                            (const float*)nullptr, dh, slab,
                            (int)n_rows, (int)C, eps, (int64_t)C);
+        EQH_CHECK_LAUNCH();
+        return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
+    });
+}
+
+/* Linear -> ReLU -> LayerNorm hidden layer on dense rows, consumed only through a gathered reduction (see k_gather_ln_fwd):
+   out[r] = gamma * reduce_{q in row r} xhat(relu(h[col[q]] + bias)) + beta * (mean ? [deg r > 0] : deg r) */
+extern "C" int hg_gather_ln_reduce_fwd(const float* h, const float* bias, const float* gamma, const float* beta,
+                                       const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t C, int32_t mean,
+                                       float eps, float* out, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!h || !bias || !gamma || !beta || !rowptr || !col || !out) return EQH_ERR_ARG;
+    if (!eqh_aligned16(h) || !eqh_aligned16(bias) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) || !eqh_aligned16(out))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_gather_ln_fwd<NV>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, h, bias,
+                           rowptr, col, gamma, beta, out, (int)n_rows, (int)C, (int)mean, eps);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t hg_gather_ln_reduce_bwd_workspace_bytes(int64_t n_src_rows, int32_t C) {
+    if (n_src_rows < 0 || C <= 0) return 0;
+    return (size_t)gl_blocks(n_src_rows) * 3 * (size_t)C * sizeof(float);
+}
+
+/* backward: (t_rowptr, t_col) = the TRANSPOSED CSR (rows = rows of h), t_w = per-entry weights 1 / deg(col) for the mean
+   (hg_entry_weights) or NULL for the sum; dout = gradient of the forward output */
+extern "C" int hg_gather_ln_reduce_bwd(const float* h, const float* bias, const float* gamma, const float* dout,
+                                       const int32_t* t_rowptr, const int32_t* t_col, const float* t_w, int64_t n_src_rows,
+                                       int32_t C, float eps, float* dh, float* dbias, float* dgamma, float* dbeta,
+                                       int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
+    int rc = check(n_src_rows, C);
+    if (rc) return rc;
+    if (!dbias || !dgamma || !dbeta) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n_src_rows == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dbias, C, stream) || eqh_zero_async(dgamma, C, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(dbeta, C, stream);
+    }
+    if (!h || !bias || !gamma || !dout || !t_rowptr || !t_col || !dh || !workspace) return EQH_ERR_ARG;
+    if (!eqh_aligned16(h) || !eqh_aligned16(dout) || !eqh_aligned16(dh) || !eqh_aligned16(workspace) ||
+        !eqh_aligned16(bias) || !eqh_aligned16(gamma))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < hg_gather_ln_reduce_bwd_workspace_bytes(n_src_rows, C)) return EQH_ERR_ARG;
+    const int blocks = gl_blocks(n_src_rows);
+    float* slab = static_cast<float*>(workspace);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_gather_ln_bwd<NV>), dim3(blocks), dim3(GL_WAVES * 64), 0, stream, h, bias, gamma, dout, t_rowptr,
+                           t_col, t_w, dh, slab, (int)n_src_rows, (int)C, eps, gl_rpw(n_src_rows));
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
     });

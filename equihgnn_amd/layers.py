@@ -306,8 +306,8 @@ class MHNNSConv(nn.Module):
         W1, W2, W3 = self.W1, self.W2, self.W3
         h1, pa = ops.linear2(X, W1.lins[0].weight, None, W2.lins[0].weight, (0, c))
         n1, n2, n3 = W1.normalizations[1], W2.normalizations[1], W3.normalizations[1]
-        h1n = ops.bias_relu_ln(h1, W1.lins[0].bias, n1.weight, n1.bias, n1.eps)
-        hbar = ops.reduce_gathered(h1n, ix.by_e, ix.by_v, "mean")                              # conv.py:172-173
+        # W1's hidden layer + the mean over the hyperedge's nodes (conv.py:172-173) in one launch each way
+        hbar = ops.gather_ln_reduce(h1, W1.lins[0].bias, n1.weight, n1.bias, ix.by_e, ix.by_v, "mean", n1.eps)
         qb = ops.linear(hbar, m["w12"], m["b12"])
         s = ops.incidence_ln_reduce(pa, qb, n2.weight, n2.bias, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                                     "mean", n2.eps)                                            # conv.py:175-177

@@ -613,6 +613,59 @@ class _BiasReluLn(torch.autograd.Function):
         return (dh, *_hand_out(list(small), tg), None, None)
 
 
+class _GatherLnReduce(torch.autograd.Function):
+    """out[r] = gamma * reduce_{q in row r of csr} xhat(relu(h[csr.col[q]] + bias)) + beta * [..]: the hidden layer of an
+    MLP on dense rows followed by the gathered reduction that is its only consumer, one launch each way
+    (hg_gather_ln_reduce_*; csrc/incidence.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, bias, gamma, beta, csr, csr_t, mean, eps, acc_params):
+        _require_gpu(h, "gather_ln_reduce")
+        h, bias, gamma, beta = _f32c(h), _f32c(bias), _f32c(gamma), _f32c(beta)
+        R, C = h.shape
+        if csr_t.n_rows != R:
+            raise ValueError("gather_ln_reduce: the transposed CSR must have one row per row of h")
+        out = torch.empty((csr.n_rows, C), dtype=torch.float32, device=h.device)
+        timed("k_gather_ln_fwd", segment_reduce_bytes(csr.nnz, csr.n_rows, C, True, True, False),
+              lambda: hip.check(hip.lib().hg_gather_ln_reduce_fwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(beta),
+                                                                  _ptr(csr.rowptr), _ptr(csr.col), csr.n_rows, C, int(mean),
+                                                                  float(eps), _ptr(out), _stream(h.device)),
+                                "hg_gather_ln_reduce_fwd"))
+        ctx.save_for_backward(h, bias, gamma)
+        ctx.eps, ctx.acc, ctx.csr_t = eps, acc_params, csr_t
+        ctx.ew = entry_weights(csr_t, csr) if mean else None    # once per batch (cached on the CSR)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, bias, gamma = ctx.saved_tensors
+        dout = _f32c(dout)
+        R, C = h.shape
+        t = ctx.csr_t
+        dh = torch.empty_like(h)
+        L = hip.lib()
+        ws_bytes = L.hg_gather_ln_reduce_bwd_workspace_bytes(R, C)
+        ws = _workspace(ws_bytes, h.device)
+        tg = [_acc_target(p) for p in ctx.acc]
+        acc = all(x is not None for x in tg)
+        small = None if acc else torch.empty((3, C), dtype=torch.float32, device=h.device)
+        o = tg if acc else list(small)
+        timed("k_gather_ln_bwd", segment_reduce_bytes(t.nnz, R, C, True, True, False) + 4 * t.nnz + 4 * C * R,
+              lambda: hip.check(L.hg_gather_ln_reduce_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dout), _ptr(t.rowptr),
+                                                          _ptr(t.col), _ptr(ctx.ew), R, C, float(ctx.eps), _ptr(dh),
+                                                          _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws),
+                                                          ws_bytes, _stream(h.device)), "hg_gather_ln_reduce_bwd"))
+        if acc:
+            return (dh,) + (None,) * 8
+        return (dh, *_hand_out(list(small), tg), None, None, None, None, None)
+
+
+def gather_ln_reduce(h, bias, gamma, beta, csr: CSR, csr_t: CSR, reduce: str = "mean", eps: float = 1e-5):
+    """reduce_gathered(bias_relu_ln(h, bias, gamma, beta), csr, csr_t, reduce) in one launch each way (2-D h)."""
+    _note_acc(bias, gamma, beta)
+    return _GatherLnReduce.apply(h, bias, gamma, beta, csr, csr_t, reduce == "mean", eps, (bias, gamma, beta))
+
+
 class _LayerNormRows(torch.autograd.Function):
     """Plain LayerNorm over dense rows; one launch each way, dgamma/dbeta from the backward pass."""
 

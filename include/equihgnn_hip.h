@@ -297,6 +297,24 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
                         void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The same hidden layer when its output is consumed ONLY through a gathered reduction -- conv.py:172-173,
+ * scatter(W1(X)[..., vertex, :], edges, reduce) with W1's last Linear moved behind the (linear) reduction:
+ *   out[r] = gamma * reduce_{q in row r} xhat(relu(h[col[q]] + bias)) + beta * (mean ? [deg r > 0] : deg r)
+ * One launch instead of hg_bias_relu_ln_fwd + hg_segment_reduce_f32; the [rows of h, C] normalised tensor
+ * is never written.  bwd: (t_rowptr, t_col) is the TRANSPOSED CSR (its rows are the rows of h), t_w the
+ * per-entry weights of hg_entry_weights for the mean (NULL: sum); dh [n_src_rows, C], dbias / dgamma / dbeta
+ * as for hg_bias_relu_ln_bwd.  Replaces torch_scatter.scatter + mlp.py:93-97 and their autograd.
+ * ------------------------------------------------------------------------------------------- */
+int hg_gather_ln_reduce_fwd(const float* h, const float* bias, const float* gamma, const float* beta,
+                            const int32_t* rowptr, const int32_t* col, int64_t n_rows, int32_t C, int32_t mean,
+                            float eps, float* out, void* stream);
+size_t hg_gather_ln_reduce_bwd_workspace_bytes(int64_t n_src_rows, int32_t C);
+int hg_gather_ln_reduce_bwd(const float* h, const float* bias, const float* gamma, const float* dout,
+                            const int32_t* t_rowptr, const int32_t* t_col, const float* t_w, int64_t n_src_rows,
+                            int32_t C, float eps, float* dh, float* dbias, float* dgamma, float* dbeta,
+                            int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Plain LayerNorm over dense rows — nn.LayerNorm(dim) applied to node features at
  * egnn_layer.py:192 (node_norm) — one wave per row.  bwd: dx and, from the same pass, dgamma and
  * dbeta (C floats each; overwritten or, with accumulate != 0, added to); add [n_rows, C] (may be NULL) is

@@ -647,6 +647,43 @@ def test_incidence_ln_reduce_matches_float64_reference(C, reduce, path):
         assert err < 2e-5, (name, err)
 
 
+@pytest.mark.parametrize("N,C", [(150, 64), (150, 320), (9000, 256), (300, 1024)])
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+def test_gather_ln_reduce_matches_float64_reference(N, C, reduce):
+    """hg_gather_ln_reduce_fwd / _bwd: LayerNorm(relu(h + bias)) on dense rows consumed through a gathered reduction
+    (conv.py:172-173 after mlp.py:93-97), one launch each way, against the unfused float64 formulation -- rows without
+    entries on either side, a source row with more entries than one 64-lane chunk, enough rows for several per wavefront."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + C)
+    M, nnz = N - 7, 3 * N
+    v = torch.randint(0, N - 10, (nnz,), generator=g)      # the last 10 source rows are never gathered
+    e = torch.randint(0, M - 5, (nnz,), generator=g)       # the last 5 output rows are empty
+    v[:150] = 3                                            # a source row with 150 entries
+    e[200:300] = 11                                        # an output row with 100 entries
+    h, b = torch.randn(N, C, generator=g), 0.3 * torch.randn(C, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    w = torch.randn(M, C, generator=g)
+    t = [x.double().requires_grad_(True) for x in (h, b, gamma, beta)]
+    y = torch.nn.functional.layer_norm(torch.relu(t[0] + t[1]), (C,), t[2], t[3], 1e-5)
+    ref = O.segment_reduce(y[v], e, M, reduce)
+    (ref * w.double()).sum().backward()
+    by_v = ops.csr_build(v.to(DEV), e.to(DEV), N)
+    by_e = ops.csr_build(e.to(DEV), v.to(DEV), M)
+    d = [x.to(DEV).requires_grad_(True) for x in (h, b, gamma, beta)]
+    out = ops.gather_ln_reduce(d[0], d[1], d[2], d[3], by_e, by_v, reduce)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=3e-5, rtol=1e-5)
+    assert float(out[-5:].abs().max()) == 0.0
+    assert float(d[0].grad[-10:].abs().max()) == 0.0
+    for name, x, r in zip(("dh", "dbias", "dgamma", "dbeta"), d, t):
+        err = float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
+        assert err < 3e-5, (name, err)
+    # and the two-launch composition it replaces gives the same numbers
+    d2 = [x.to(DEV).requires_grad_(True) for x in (h, b, gamma, beta)]
+    out2 = ops.reduce_gathered(ops.bias_relu_ln(d2[0], d2[1], d2[2], d2[3]), by_e, by_v, reduce)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out2.detach().cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("R,C", [(1, 64), (37, 128), (1000, 256), (300, 1024)])
 def test_bias_relu_ln_matches_float64_reference(R, C):
     ops = _ops()
