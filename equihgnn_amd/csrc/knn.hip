@@ -10,8 +10,9 @@
 // streamed 64 at a time (one per lane);
 // the running k-best list lives in lanes 0..k-1 of two registers (distance, index), sorted by
 // (distance, index).  A candidate beats the list only if it is strictly closer than the current
-// k-th entry; insertion is O(1) wave operations (ballot -> popcount -> shuffle-up), and happens
-// ~k*ln(N/k) times per query, so the loop is dominated by the distance evaluations.
+// k-th entry; insertion is O(1) wave operations (ballot -> popcount -> shuffle-up).  A first pass over the
+// candidates bounds the k-th distance from above (the k-th smallest of the 64 per-lane minima), so the second pass
+// inserts about k + a few candidates instead of ~k*ln(N/k) + 64.
 // Distance arithmetic: (dx*dx + dy*dy) + dz*dz with separately rounded products (no FMA).
 // (Measured and not kept: holding all positions of a <= 12 k-atom cloud in LDS -- 64-84 us against 47 us at
 // 4.7 k atoms.  The molecules of a batch overlap in space, so the k-th distance shrinks slowly and a query
@@ -30,18 +31,31 @@ namespace {
 template <int MODE, int QPW>
 __global__ void __launch_bounds__(256)
 k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float* __restrict__ dist) {
+    // Candidates reach the wavefronts through LDS: the workgroup's four wavefronts (four query groups) walk the same
+    // candidate stream, so each block of 256 candidates is fetched from memory once per workgroup, as one 12-byte
+    // strided load per thread, instead of once per wavefront (those strided loads -- 36 cache-line accesses per
+    // 64 candidates -- kept the CU's L1 busy for the whole kernel once the insertion chain was shortened).
+    __shared__ float s_pos[2][3][256];
     const int lane = threadIdx.x & 63;
-    const int waves_per_block = blockDim.x >> 6;
-    const int wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;   // 4
     const int wave_stride = gridDim.x * waves_per_block;
     const int n_groups = (N + QPW - 1) / QPW;
+    auto stage = [&](int buf, int c0) {
+        const int j = c0 + (int)threadIdx.x;
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (j < N) { x = pos[3 * j]; y = pos[3 * j + 1]; z = pos[3 * j + 2]; }
+        s_pos[buf][0][threadIdx.x] = x; s_pos[buf][1][threadIdx.x] = y; s_pos[buf][2][threadIdx.x] = z;
+    };
     // the LAST queries first: a padded batch parks its padding atoms at the end of the cloud and far away from it,
     // where every real atom is a near-tie candidate (many list insertions); started last, those few long-running
     // wavefronts were the tail of the launch
-    for (int g_ = wave0; g_ < n_groups; g_ += wave_stride) {
-        const int grp = n_groups - 1 - g_;
+    for (int base = blockIdx.x * waves_per_block; base < n_groups; base += wave_stride) {   // workgroup-uniform
+        const int g_ = base + wave;
+        const bool active = g_ < n_groups;
+        const int grp = active ? n_groups - 1 - g_ : 0;
         const int i0 = grp * QPW;
-        float qx[QPW], qy[QPW], qz[QPW], ld[QPW], tau[QPW];
+        float qx[QPW], qy[QPW], qz[QPW], ld[QPW], tau[QPW], lmin[QPW], T[QPW];
         int li[QPW];
 #pragma unroll
         for (int t = 0; t < QPW; ++t) {
@@ -50,43 +64,81 @@ k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float*
             ld[t] = INFINITY;   // list: distance (lanes >= k stay +inf and never take part)
             li[t] = -1;         //       index
             tau[t] = INFINITY;
+            lmin[t] = INFINITY;
+            T[t] = INFINITY;
         }
-        for (int c0 = 0; c0 < N; c0 += 64) {
-            const int j = c0 + lane;
-            const bool in_range = j < N;
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (in_range) { px = pos[3 * j]; py = pos[3 * j + 1]; pz = pos[3 * j + 2]; }
+        // Pass A: every lane keeps the smallest distance among ITS candidates (j = lane mod 64).  The 64 lane minima belong
+        // to 64 distinct points, so their k-th smallest, T, is an upper bound of the final k-th distance: pass B only has to
+        // offer candidates with d <= T to the list (about k + a few instead of ~k ln(N/k) + 64 serial insertions of ~25
+        // wavefront instructions each, which bound the one-pass form).  The final list is the same: it is the k smallest
+        // (distance, index) pairs either way.
+        for (int pass = 0; pass < 2; ++pass) {
+            __syncthreads();                       // the previous stream's last buffer is free
+            stage(0, 0);
+            for (int c0 = 0, buf = 0; c0 < N; c0 += 256, buf ^= 1) {
+                __syncthreads();                   // buffer `buf` is staged; the other one is free
+                if (c0 + 256 < N) stage(buf ^ 1, c0 + 256);
+                if (!active) continue;
 #pragma unroll
-            for (int t = 0; t < QPW; ++t) {
-                bool valid = in_range;
-                if (MODE == 1) valid = valid && (j != i0 + t);
-                const float dx = __fsub_rn(qx[t], px);
-                const float dy = __fsub_rn(qy[t], py);
-                const float dz = __fsub_rn(qz[t], pz);
-                float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                if (MODE == 1) d = __fsqrt_rn(d);
-                unsigned long long mask = __ballot(valid && d < tau[t]);
-                while (mask) {
-                    const int bsel = __ffsll((long long)mask) - 1;  // lowest lane = lowest index first
-                    mask &= mask - 1;
-                    const float xd = __shfl(d, bsel, 64);
-                    if (!(xd < tau[t])) continue;
-                    const int p = __popcll(__ballot(lane < k && ld[t] <= xd));
-                    const float ud = __shfl_up(ld[t], 1, 64);
-                    const int ui = __shfl_up(li[t], 1, 64);
-                    if (lane < k) {
-                        if (lane > p) { ld[t] = ud; li[t] = ui; }
-                        else if (lane == p) { ld[t] = xd; li[t] = c0 + bsel; }
+                for (int sub = 0; sub < 4; ++sub) {
+                    const int j = c0 + 64 * sub + lane;
+                    if (c0 + 64 * sub >= N) break;
+                    const bool in_range = j < N;
+                    const float px = s_pos[buf][0][64 * sub + lane], py = s_pos[buf][1][64 * sub + lane];
+                    const float pz = s_pos[buf][2][64 * sub + lane];
+#pragma unroll
+                    for (int t = 0; t < QPW; ++t) {
+                        bool valid = in_range;
+                        if (MODE == 1) valid = valid && (j != i0 + t);
+                        const float dx = __fsub_rn(qx[t], px);
+                        const float dy = __fsub_rn(qy[t], py);
+                        const float dz = __fsub_rn(qz[t], pz);
+                        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                        if (MODE == 1) d = __fsqrt_rn(d);
+                        if (pass == 0) {
+                            if (valid && d < lmin[t]) lmin[t] = d;
+                            continue;
+                        }
+                        unsigned long long mask = __ballot(valid && d <= T[t] && d < tau[t]);
+                        while (mask) {
+                            const int bsel = __ffsll((long long)mask) - 1;  // lowest lane = lowest index first
+                            mask &= mask - 1;
+                            const float xd = __shfl(d, bsel, 64);
+                            if (!(xd < tau[t])) continue;
+                            const int p = __popcll(__ballot(lane < k && ld[t] <= xd));
+                            const float ud = __shfl_up(ld[t], 1, 64);
+                            const int ui = __shfl_up(li[t], 1, 64);
+                            if (lane < k) {
+                                if (lane > p) { ld[t] = ud; li[t] = ui; }
+                                else if (lane == p) { ld[t] = xd; li[t] = c0 + 64 * sub + bsel; }
+                            }
+                            tau[t] = __shfl(ld[t], k - 1, 64);
+                        }
                     }
-                    tau[t] = __shfl(ld[t], k - 1, 64);
+                }
+            }
+            if (pass == 0) {
+#pragma unroll
+                for (int t = 0; t < QPW; ++t) {
+                    // rank of this lane's minimum among the 64 (ties by lane); the lane of rank k - 1 holds T
+                    // (+inf when fewer than k lanes saw a point: no filtering then)
+                    int rank = 0;
+                    for (int l = 0; l < 64; ++l) {
+                        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin[t]), l));
+                        rank += (o < lmin[t] || (o == lmin[t] && l < lane)) ? 1 : 0;
+                    }
+                    const unsigned long long sel = __ballot(rank == k - 1);
+                    T[t] = __shfl(lmin[t], __ffsll((long long)sel) - 1, 64);
                 }
             }
         }
+        if (active) {
 #pragma unroll
-        for (int t = 0; t < QPW; ++t) {
-            if (i0 + t < N && lane < k) {
-                nbr[(int64_t)(i0 + t) * k + lane] = li[t];
-                dist[(int64_t)(i0 + t) * k + lane] = ld[t];
+            for (int t = 0; t < QPW; ++t) {
+                if (i0 + t < N && lane < k) {
+                    nbr[(int64_t)(i0 + t) * k + lane] = li[t];
+                    dist[(int64_t)(i0 + t) * k + lane] = ld[t];
+                }
             }
         }
     }
