@@ -253,7 +253,7 @@ class MHNNSConv(nn.Module):
         for w in (self.W1, self.W2, self.W3):
             w.reset_parameters()
 
-    def residual(self, X0, index: HyperIndex):
+    def residual(self, X0, index: HyperIndex, passthrough: bool = False):
         """The layer-independent part of conv.py:179-180's mix, built once per forward pass:
         (1-a) * x_v + a * X0 with x_v = W2_last(s) + rows * b  ==  (1-a) * W2_last_nobias(s) + c,
         c = a * X0 + (1-a) * rows * b.  ``c`` enters the last GEMM of W2 as its beta = 1 operand, so
@@ -263,6 +263,9 @@ class MHNNSConv(nn.Module):
         a = self.alpha
         if X0.is_cuda and X0.dim() == 2 and X0.shape[-1] % 4 == 0 and X0.dtype == torch.float32:
             mode = 1 if self.aggr == "mean" else 2     # one launch; backward: one mul + a batched column sum
+            if passthrough:
+                c, x0p = ops.residual_mix(X0, self.W2.lins[-1].bias, index.by_v.rowptr, mode, a, passthrough=True)
+                return (1.0 - a, c, None, x0p)
             return (1.0 - a, ops.residual_mix(X0, self.W2.lins[-1].bias, index.by_v.rowptr, mode, a), None)
         x0a = X0 * a
         if X0.dim() != 2:
@@ -273,10 +276,10 @@ class MHNNSConv(nn.Module):
     def prepare(self, X0, index: HyperIndex):
         """``residual`` for forward() when the fused path applies (call once per model forward)."""
         if X0.is_cuda and X0.dim() == 2 and len(self.W2.lins) > 1:
-            res = self.residual(X0, index)
-            if self._mergeable(X0) and res[1] is not None:
-                return self._prepare_merged(res)
-            return res
+            if self._mergeable(X0):
+                # (X0 is also the first application's input: it reaches that application through the residual's autograd node)
+                return self._prepare_merged(self.residual(X0, index, passthrough=True), X0)
+            return self.residual(X0, index)
         return None
 
     # -- merged path ------------------------------------------------------------------------------------------------
@@ -293,16 +296,18 @@ class MHNNSConv(nn.Module):
                 and self.W1._fusable(X) and self.W2._fusable(X) and self.W3._fusable(X)
                 and not (self.W1.InputNorm or self.W2.InputNorm or self.W3.InputNorm))
 
-    def _prepare_merged(self, res):
+    def _prepare_merged(self, res, X0):
         c_dim = self.W1.lins[0].weight.shape[1]
         w12, b12 = ops.merged_weight(self.W2.lins[0].weight, self.W1.lins[1].weight, self.W1.lins[1].bias,
                                      self.W2.lins[0].bias, cols=(c_dim, 2 * c_dim))
         w23, _ = ops.merged_weight(self.W3.lins[0].weight, self.W2.lins[1].weight)
         cw = ops.linear(res[1], self.W3.lins[0].weight)                   # (a X0 + (1 - a) w_r b) W3a^T, layer-independent
-        return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw}
+        return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw, "x0": X0, "x0_pass": res[3]}
 
-    def _forward_merged(self, X, ix: HyperIndex, m):
+    def _forward_merged(self, X, ix: HyperIndex, m, relu_out=False):
         c = X.shape[-1]
+        if X is m["x0"]:
+            X = m["x0_pass"]
         W1, W2, W3 = self.W1, self.W2, self.W3
         h1, pa = ops.linear2(X, W1.lins[0].weight, None, W2.lins[0].weight, (0, c))
         n1, n2, n3 = W1.normalizations[1], W2.normalizations[1], W3.normalizations[1]
@@ -313,12 +318,15 @@ class MHNNSConv(nn.Module):
                                     "mean", n2.eps)                                            # conv.py:175-177
         h3 = ops.linear_add(s, m["w23"], m["cw"], m["scale"])                                  # conv.py:179-180 + W3's first Linear
         x = ops.bias_relu_ln(h3, W3.lins[0].bias, n3.weight, n3.bias, n3.eps)
-        return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias)
+        return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias, relu=relu_out)
 
-    def forward(self, X, index: HyperIndex, X0, residual=None):
+    def forward(self, X, index: HyperIndex, X0, residual=None, relu_out=False):
+        """``relu_out``: return relu(output) (the wrappers' activation, fused into the last GEMM); only with the
+        dict ``residual`` of the merged path."""
         ix = index
         if isinstance(residual, dict):
-            return self._forward_merged(X, ix, residual)
+            return self._forward_merged(X, ix, residual, relu_out)
+        assert not relu_out
         fused = X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1
         pa = None
         if fused and self.W1.takes_first(X) and not self.W2.InputNorm:

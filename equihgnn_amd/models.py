@@ -55,11 +55,13 @@ class EGNNEquiHNNS(nn.Module):
             taps["front_end"] = x
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
+        fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res)
+            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
             if taps is not None:
                 taps[f"conv{i}"] = x
-            x = self.act(x)
+            if not fuse_act:
+                x = self.act(x)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -149,11 +151,13 @@ class EquiformerEquiHNNS(nn.Module):
             taps["front_end"] = x
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
+        fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res)
+            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
             if taps is not None:
                 taps[f"conv{i}"] = x
-            x = self.act(x)
+            if not fuse_act:
+                x = self.act(x)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -249,11 +253,13 @@ class MHNNS(nn.Module):
         x = self.atom_encoder(data.x)
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
+        fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res)
+            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
             if taps is not None:
                 taps[f"conv{i}"] = x
-            x = self.act(x)
+            if not fuse_act:
+                x = self.act(x)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -320,11 +326,13 @@ class FAFormerEquiHNNS(nn.Module):
             taps["front_end"] = x
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
+        fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
         for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res)
+            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
             if taps is not None:
                 taps[f"conv{i}"] = x
-            x = self.act(x)
+            if not fuse_act:
+                x = self.act(x)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 

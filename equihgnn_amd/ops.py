@@ -781,7 +781,7 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": [], "merged": []}
+_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": [], "merged": [], "zslab": None}
 
 
 def _workspace(nbytes, device):
@@ -882,6 +882,7 @@ def defer_flush(device):
     # weight-level product hands them on to the parameters
     merged = _DEFER["merged"]
     _DEFER["merged"] = []
+    _DEFER["zslab"] = None
     for outs, accs in merged:
         torch.autograd.backward(outs, accs)
 
@@ -1274,6 +1275,19 @@ class _MergedWeight(torch.autograd.Function):
         return dA, dB, dbb, dbo, None, None
 
 
+def _merged_acc(shape, device):
+    """A zeroed accumulator for a merged weight: carved from one zero-filled slab per deferral window (one fill kernel
+    for all merged weights of a step)."""
+    n = shape[0] * shape[1]
+    slab = _DEFER.get("zslab")
+    if slab is None or slab[1] + n > slab[0].numel() or slab[0].device != device:
+        slab = [torch.zeros(max(4 * n, 1 << 18), dtype=torch.float32, device=device), 0]
+        _DEFER["zslab"] = slab
+    out = slab[0][slab[1]:slab[1] + n].view(shape)
+    slab[1] += (n + 63) // 64 * 64
+    return out
+
+
 def merged_weight(A, B, bb=None, bo=None, cols=None):
     """(Wc, bc) with Wc = A[:, cols] @ B and bc = A[:, cols] @ bb + bo (bc None without bb) for parameters A [O, *],
     B [K, I], bb [K], bo [O]: see _MergedWeight.  While gradient reductions are deferred (graphed trainer) the two
@@ -1290,7 +1304,7 @@ def merged_weight(A, B, bb=None, bo=None, cols=None):
         # the Linears see detached leaves with accumulators; the weight-level product stays out of the main backward
         O, I = wc.shape
         ld = (I + 3) // 4 * 4
-        acc = torch.zeros((O + 1, max(ld, O)), dtype=torch.float32, device=wc.device)   # rows 0..O-1: dWc; row O: dbc
+        acc = _merged_acc((O + 1, max(ld, O)), wc.device)   # rows 0..O-1: dWc; row O: dbc
         outs, accs = [wc], [acc[:O, :I]]
         wl = wc.detach().requires_grad_()
         wl._eqh_transient = True
@@ -1315,21 +1329,30 @@ class _Linear(torch.autograd.Function):
     applied L times) and column-split weights (W·cat(a,b) = Wa·a + Wb·b) cost no extra kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, c0, c1, r0=None, r1=None):
+    def forward(ctx, x, weight, bias, c0, c1, r0=None, r1=None, relu=False):
         w = weight if c0 is None else weight[:, c0:c1]
         b = bias
         if r0 is not None:
             w = w[r0:r1]
             b = bias[r0:r1] if bias is not None else None
-        ctx.save_for_backward(x, weight)
         ctx.cols, ctx.rows = (c0, c1), (r0, r1)
         ctx.has_bias = bias is not None
         ctx.bias_param = bias
+        ctx.relu = bool(relu)
+        if relu:    # relu(x W^T + b) with the activation in the GEMM's epilogue (2-D x, bias given: checked by linear())
+            y = torch._addmm_activation(b, x, w.t(), use_gelu=False)
+            ctx.save_for_backward(x, weight, y)
+            return y
+        ctx.save_for_backward(x, weight)
         return F.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        if ctx.relu:
+            x, weight, y = ctx.saved_tensors
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)
+        else:
+            x, weight = ctx.saved_tensors
         c0, c1 = ctx.cols
         r0, r1 = ctx.rows
         w = weight if c0 is None else weight[:, c0:c1]
@@ -1348,7 +1371,7 @@ class _Linear(torch.autograd.Function):
             else:
                 db = torch.zeros_like(ctx.bias_param)
                 db[r0:r1] = colsum(dy2)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _Linear2(torch.autograd.Function):
@@ -1514,15 +1537,18 @@ def incidence_ln_reduce(pa, qb, gamma, beta, ia32, ib32, csr_a: CSR, csr_b: CSR,
                                     reduce == "mean", eps, (gamma, beta))
 
 
-def linear(x, weight, bias=None, cols=None, rows=None):
+def linear(x, weight, bias=None, cols=None, rows=None, relu=False):
     """F.linear(x, weight[rows[0]:rows[1], cols[0]:cols[1]], bias[rows[0]:rows[1]]) through _Linear (``weight`` and
-    ``bias`` are the PARAMETERS, not slices of them, so that their gradient accumulators can be found)."""
+    ``bias`` are the PARAMETERS, not slices of them, so that their gradient accumulators can be found).  ``relu``:
+    relu(...) with the activation in the GEMM epilogue (2-D fp32 x on the GPU with a bias; else a separate kernel)."""
+    if relu and not (x.is_cuda and x.dim() == 2 and bias is not None and x.dtype == torch.float32):
+        return torch.relu(linear(x, weight, bias, cols, rows))
     if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
         LINEAR_PARAMS[id(weight)] = weight
     _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
     r0, r1 = rows if rows is not None else (None, None)
-    return _Linear.apply(x, weight, bias, c0, c1, r0, r1)
+    return _Linear.apply(x, weight, bias, c0, c1, r0, r1, relu)
 
 
 def linear2(x, wa, cols_a, wb, cols_b):
@@ -1555,7 +1581,7 @@ class _ResidualMix(torch.autograd.Function):
     as a scaled, row-weighted column sum (batched with the other bias gradients of the step)."""
 
     @staticmethod
-    def forward(ctx, x0, bias, rowptr, weight_mode, alpha, bias_param):
+    def forward(ctx, x0, bias, rowptr, weight_mode, alpha, bias_param, passthrough=False):
         _require_gpu(x0, "residual_mix")
         x0, bias = _f32c(x0), _f32c(bias)
         R, C = x0.shape
@@ -1563,23 +1589,32 @@ class _ResidualMix(torch.autograd.Function):
         hip.check(hip.lib().hg_residual_mix_f32(_ptr(x0), _ptr(bias), _ptr(rowptr), weight_mode, float(alpha), R, C,
                                                 _ptr(out), _stream(x0.device)), "hg_residual_mix_f32")
         ctx.rowptr, ctx.mode, ctx.alpha, ctx.bias_param = rowptr, weight_mode, float(alpha), bias_param
+        ctx.set_materialize_grads(False)
+        if passthrough:     # x0 again, for its OTHER consumer: both gradients then meet here, in one kernel
+            return out, x0.view_as(x0)
         return out
 
     @staticmethod
-    def backward(ctx, dc):
-        dc = _f32c(dc)
-        dx0 = dc * ctx.alpha if ctx.needs_input_grad[0] else None
-        db = None
-        if ctx.needs_input_grad[1]:
-            db = colsum(dc, ctx.rowptr, ctx.mode, into=_acc_target(ctx.bias_param), scale=1.0 - ctx.alpha)
-        return dx0, db, None, None, None, None
+    def backward(ctx, dc, dpass=None):
+        dx0 = db = None
+        if dc is not None:
+            dc = _f32c(dc)
+            if ctx.needs_input_grad[0]:
+                dx0 = dc * ctx.alpha if dpass is None else torch.add(dpass, dc, alpha=ctx.alpha)
+            if ctx.needs_input_grad[1]:
+                db = colsum(dc, ctx.rowptr, ctx.mode, into=_acc_target(ctx.bias_param), scale=1.0 - ctx.alpha)
+        elif dpass is not None and ctx.needs_input_grad[0]:
+            dx0 = dpass
+        return dx0, db, None, None, None, None, None
 
 
-def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float):
+def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float, passthrough: bool = False):
     """alpha * x0 + (1 - alpha) * w_r * bias for 2-D x0 [rows, C] (C % 4 == 0); w_r from the int32 CSR ``rowptr``
-    (weight_mode 1: [row non-empty], 2: row length)."""
+    (weight_mode 1: [row non-empty], 2: row length).  ``passthrough``: also return x0 itself as a second output of the
+    same autograd node -- hand THAT to x0's other consumer and the two gradients of x0 are combined by one kernel here
+    instead of a multiply plus autograd's add."""
     _note_acc(bias)
-    return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias)
+    return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias, passthrough)
 
 
 def _dropout_seed(device, p):
