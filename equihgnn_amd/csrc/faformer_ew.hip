@@ -291,6 +291,178 @@ k_frame_pre_bwd(const float* __restrict__ y, const float* __restrict__ w3, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The whole hidden layer of the frame-averaged MLP in one kernel each way:
+//   hn[e, f, :] = LayerNorm( dropout( SiLU(a_f) * b_f ) ),   [a_f | b_f] = W3 (y_e * s_f) + base_e      (H = 256 -> 128)
+// i.e. k_frame_pre + k_swiglu_drop + the row LayerNorm without the two intermediate tensors: at the Molecule3D batch the
+// edge MLP's [E * 8, 256] pre-activations (2 GB) and [E * 8, 128] gated values (1 GB) were written and read back by
+// three kernels forward (1.6 ms) and three backward (2.3 ms); here the forward reads y and base (one row per EDGE, not
+// per frame) and writes hn, the backward reads d hn and writes d base / dy -- the eight frames of a row live in registers.
+// A wavefront per row e; lane l owns hidden units j = 2l, 2l+1, i.e. pre-activation channels a: 2l, 2l+1 and b: 128 + 2l,
+// 128 + 2l + 1, so the SwiGLU product needs no cross-lane traffic and the stores are 8-byte pieces of one 512-byte row.
+// Dropout decisions: the same hash of (seed, element of the [E * 8, 128] tensor) as k_swiglu_drop.
+__device__ __forceinline__ float fh_combo(float t0, float t1, float t2, float b, int f) {
+    const float s0 = (f & 4) ? 1.f : -1.f, s1 = (f & 2) ? 1.f : -1.f, s2 = (f & 1) ? 1.f : -1.f;
+    return fmaf(s0, t0, fmaf(s1, t1, fmaf(s2, t2, b)));
+}
+
+struct FhLane {          // per-lane constants: W3 rows of the four channels, gamma / beta of the two hidden units
+    float wa0[3], wa1[3], wb0[3], wb1[3];
+    float g0, g1, be0, be1;
+};
+__device__ __forceinline__ FhLane fh_load(const float* __restrict__ w3, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, int lane) {
+    FhLane L;
+    const int ca = 2 * lane, cb = 128 + 2 * lane;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        L.wa0[d] = w3[ca * 3 + d]; L.wa1[d] = w3[(ca + 1) * 3 + d];
+        L.wb0[d] = w3[cb * 3 + d]; L.wb1[d] = w3[(cb + 1) * 3 + d];
+    }
+    L.g0 = gamma[2 * lane]; L.g1 = gamma[2 * lane + 1];
+    L.be0 = beta ? beta[2 * lane] : 0.f; L.be1 = beta ? beta[2 * lane + 1] : 0.f;
+    return L;
+}
+
+__global__ void __launch_bounds__(FP_THREADS)
+k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ base, int64_t base_ld,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, int64_t E,
+                   const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
+                   float* __restrict__ out) {
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const FhLane L = fh_load(w3, gamma, beta, lane);
+    for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
+        const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
+        const float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
+        const float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        const float ta0[3] = {y0 * L.wa0[0], y1 * L.wa0[1], y2 * L.wa0[2]}, ta1[3] = {y0 * L.wa1[0], y1 * L.wa1[1], y2 * L.wa1[2]};
+        const float tb0[3] = {y0 * L.wb0[0], y1 * L.wb0[1], y2 * L.wb0[2]}, tb1[3] = {y0 * L.wb1[0], y1 * L.wb1[1], y2 * L.wb1[2]};
+        float v0[8], v1[8], mu[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float a0 = fh_combo(ta0[0], ta0[1], ta0[2], ba.x, f), a1 = fh_combo(ta1[0], ta1[1], ta1[2], ba.y, f);
+            const float b0 = fh_combo(tb0[0], tb0[1], tb0[2], bb.x, f), b1 = fh_combo(tb1[0], tb1[1], tb1[2], bb.y, f);
+            float h0 = a0 * sigmoid_fast(a0) * b0, h1 = a1 * sigmoid_fast(a1) * b1;
+            if (threshold) {
+                const uint64_t idx = (uint64_t)((e * 8 + f) * 128 + 2 * lane);
+                h0 *= keep_scale(seed, idx, threshold, inv_keep);
+                h1 *= keep_scale(seed, idx + 1, threshold, inv_keep);
+            }
+            v0[f] = h0; v1[f] = h1;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) mu[f] = fp_wave_sum(v0[f] + v1[f]) * (1.0f / 128.0f);
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float d0 = v0[f] - mu[f], d1 = v1[f] - mu[f];
+            const float r = 1.0f / sqrtf(fp_wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f) + eps);
+            float2 o;
+            o.x = fmaf(L.g0, d0 * r, L.be0);
+            o.y = fmaf(L.g1, d1 * r, L.be1);
+            *reinterpret_cast<float2*>(out + (e * 8 + f) * 128 + 2 * lane) = o;
+        }
+    }
+}
+
+// slab per workgroup: [d W3 (256 x 3) | d gamma (128) | d beta (128)]
+constexpr int FH_SLAB = 256 * 3 + 128 + 128;
+
+__global__ void __launch_bounds__(FP_THREADS)
+k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ base, int64_t base_ld,
+                   const float* __restrict__ gamma, const float* __restrict__ dhn, int64_t E,
+                   const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
+                   float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ slab) {
+    __shared__ float s_red[FP_WAVES][16][64];
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const FhLane L = fh_load(w3, gamma, nullptr, lane);
+    float aw[4][3];              // d W3 of channels (a0, a1, b0, b1) x d
+    float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;   // d gamma, d beta of the two hidden units
+#pragma unroll
+    for (int c = 0; c < 4; ++c) aw[c][0] = aw[c][1] = aw[c][2] = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
+        const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
+        const float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
+        const float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        float2 g[8];
+#pragma unroll
+        for (int f = 0; f < 8; ++f) g[f] = *reinterpret_cast<const float2*>(dhn + (e * 8 + f) * 128 + 2 * lane);
+        const float ta0[3] = {y0 * L.wa0[0], y1 * L.wa0[1], y2 * L.wa0[2]}, ta1[3] = {y0 * L.wa1[0], y1 * L.wa1[1], y2 * L.wa1[2]};
+        const float tb0[3] = {y0 * L.wb0[0], y1 * L.wb0[1], y2 * L.wb0[2]}, tb1[3] = {y0 * L.wb1[0], y1 * L.wb1[1], y2 * L.wb1[2]};
+        float sb[4] = {0.f, 0.f, 0.f, 0.f};           // sum over frames of d pre (a0, a1, b0, b1)
+        float r[4][3];                                // sum over frames of s_fd * d pre
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c][0] = r[c][1] = r[c][2] = 0.f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float a0 = fh_combo(ta0[0], ta0[1], ta0[2], ba.x, f), a1 = fh_combo(ta1[0], ta1[1], ta1[2], ba.y, f);
+            const float b0 = fh_combo(tb0[0], tb0[1], tb0[2], bb.x, f), b1 = fh_combo(tb1[0], tb1[1], tb1[2], bb.y, f);
+            const float sg0 = sigmoid_fast(a0), sg1 = sigmoid_fast(a1);
+            const float s0 = a0 * sg0, s1 = a1 * sg1;
+            float k0 = 1.f, k1 = 1.f;
+            if (threshold) {
+                const uint64_t idx = (uint64_t)((e * 8 + f) * 128 + 2 * lane);
+                k0 = keep_scale(seed, idx, threshold, inv_keep);
+                k1 = keep_scale(seed, idx + 1, threshold, inv_keep);
+            }
+            const float h0 = s0 * b0 * k0, h1 = s1 * b1 * k1;
+            const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);
+            const float d0 = h0 - mu, d1 = h1 - mu;
+            const float rstd = 1.0f / sqrtf(fp_wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f) + eps);
+            const float x0 = d0 * rstd, x1 = d1 * rstd;
+            ab0 += g[f].x; ab1 += g[f].y;
+            ag0 = fmaf(g[f].x, x0, ag0); ag1 = fmaf(g[f].y, x1, ag1);
+            const float q0 = g[f].x * L.g0, q1 = g[f].y * L.g1;
+            const float m1 = fp_wave_sum(q0 + q1) * (1.0f / 128.0f);
+            const float m2 = fp_wave_sum(q0 * x0 + q1 * x1) * (1.0f / 128.0f);
+            const float dh0 = rstd * (q0 - m1 - x0 * m2) * k0, dh1 = rstd * (q1 - m1 - x1 * m2) * k1;
+            const float dp[4] = {dh0 * b0 * fmaf(s0, 1.0f - sg0, sg0), dh1 * b1 * fmaf(s1, 1.0f - sg1, sg1), dh0 * s0, dh1 * s1};
+            const float sg[3] = {(f & 4) ? 1.f : -1.f, (f & 2) ? 1.f : -1.f, (f & 1) ? 1.f : -1.f};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sb[c] += dp[c];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) r[c][d] = fmaf(sg[d], dp[c], r[c][d]);
+            }
+        }
+        *reinterpret_cast<float2*>(dbase + e * 256 + 2 * lane) = make_float2(sb[0], sb[1]);
+        *reinterpret_cast<float2*>(dbase + e * 256 + 128 + 2 * lane) = make_float2(sb[2], sb[3]);
+        const float dd0 = fp_wave_sum((r[0][0] * L.wa0[0] + r[1][0] * L.wa1[0]) + (r[2][0] * L.wb0[0] + r[3][0] * L.wb1[0]));
+        const float dd1 = fp_wave_sum((r[0][1] * L.wa0[1] + r[1][1] * L.wa1[1]) + (r[2][1] * L.wb0[1] + r[3][1] * L.wb1[1]));
+        const float dd2 = fp_wave_sum((r[0][2] * L.wa0[2] + r[1][2] * L.wa1[2]) + (r[2][2] * L.wb0[2] + r[3][2] * L.wb1[2]));
+        if (lane == 0) { dy[e * 3] = dd0; dy[e * 3 + 1] = dd1; dy[e * 3 + 2] = dd2; }
+        const float yv[3] = {y0, y1, y2};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) aw[c][d] = fmaf(r[c][d], yv[d], aw[c][d]);
+    }
+    // workgroup slab: the four wavefronts' accumulators meet in LDS, summed in wavefront order
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) s_red[wave][c * 3 + d][lane] = aw[c][d];
+    s_red[wave][12][lane] = ag0; s_red[wave][13][lane] = ag1; s_red[wave][14][lane] = ab0; s_red[wave][15][lane] = ab1;
+    __syncthreads();
+    if (wave == 0) {
+        float* __restrict__ sl = slab + (int64_t)blockIdx.x * FH_SLAB;
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            t[q] = s_red[0][q][lane];
+            for (int w = 1; w < FP_WAVES; ++w) t[q] += s_red[w][q][lane];
+        }
+        const int ch[4] = {2 * lane, 2 * lane + 1, 128 + 2 * lane, 128 + 2 * lane + 1};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sl[ch[c] * 3 + d] = t[c * 3 + d];
+        sl[768 + 2 * lane] = t[12]; sl[768 + 2 * lane + 1] = t[13];
+        sl[896 + 2 * lane] = t[14]; sl[896 + 2 * lane + 1] = t[15];
+    }
+}
+
 inline int fp_blocks(int64_t E) { return eqh_grid_for(E, FP_WAVES * 8, 1024); }
 
 }  // namespace
@@ -327,6 +499,52 @@ extern "C" int faf_frame_pre_bwd(const float* y, const float* w3, const float* d
     hipLaunchKernelGGL(k_frame_pre_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, dpre, E, dy, dbase, slab);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(slab, blocks, (int64_t)H * 3, dw3, stream, accumulate);
+}
+
+/* frame_pre + SwiGLU + dropout + LayerNorm in one launch each way (see k_frame_hidden_fwd): hn [E, 8, 128] from y [E, 3],
+   w3 [256, 3], base ([E, 256] with base_ld = 256, or one row with base_ld = 0), gamma / beta [128].  bwd: dy [E, 3],
+   dbase [E, 256] (per row, also for a broadcast base), dw3 [256, 3], dgamma, dbeta [128] (overwritten or accumulated). */
+extern "C" int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
+                                    const float* beta, int64_t E, float p, const int64_t* seed, float eps, float* out,
+                                    void* stream_) {
+    if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256)) return EQH_ERR_ARG;
+    if (E == 0) return EQH_OK;
+    if (!y || !w3 || !base || !gamma || !beta || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_frame_hidden_fwd, dim3(eqh_grid_for(E, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, y, w3, base,
+                       base_ld, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E) {
+    if (E <= 0) return 0;
+    return (size_t)fp_blocks(E) * (size_t)FH_SLAB * sizeof(float);
+}
+
+extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
+                                    const float* dhn, int64_t E, float p, const int64_t* seed, float eps, float* dy,
+                                    float* dbase, float* dw3, float* dgamma, float* dbeta, int32_t accumulate,
+                                    void* workspace, size_t workspace_bytes, void* stream_) {
+    if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256) || !dw3 || !dgamma || !dbeta) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (E == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dw3, 768, stream) || eqh_zero_async(dgamma, 128, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(dbeta, 128, stream);
+    }
+    if (!y || !w3 || !base || !gamma || !dhn || !dy || !dbase || !workspace || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(dhn) & 7) ||
+        (reinterpret_cast<uintptr_t>(dbase) & 7) || !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_frame_hidden_bwd_workspace_bytes(E)) return EQH_ERR_ARG;
+    const int blocks = fp_blocks(E);
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_frame_hidden_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, gamma, dhn, E, seed,
+                       ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, slab);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

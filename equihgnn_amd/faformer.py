@@ -43,6 +43,9 @@ def _layer_norm(mod: nn.LayerNorm, x):
     return mod(x)
 
 
+FUSE_FRAME_HIDDEN = True    # SwiGLUMLP.frame_mean: one launch for the hidden layer over the 8 sign frames (ops.frame_hidden)
+
+
 class SwiGLUMLP(nn.Module):
     """fa_former_layer.py:241-289: fc1 -> (silu(x1) * x2) -> drop -> LayerNorm -> fc2 -> drop."""
 
@@ -77,14 +80,20 @@ class SwiGLUMLP(nn.Module):
             base = torch.addcmul(self.fc1.bias, extra, w[:, 3])
         else:
             base = F.linear(extra, w[:, 3:], self.fc1.bias)
-        if y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256:
+        if y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256 and FUSE_FRAME_HIDDEN:
+            # first Linear over the sign frames + SwiGLU + dropout + LayerNorm in one launch (csrc/faformer_ew.hip)
+            h = ops.frame_hidden(y, w[:, :3], base, self.norm.weight, self.norm.bias, self.norm.eps,
+                                 self.p if self.training else 0.0)
+            pre = None
+        elif y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256:
             pre = ops.frame_pre(y, w[:, :3], base)                         # [..., 8, H] in one pass (csrc/faformer_ew.hip)
         else:
             s = _sign_ops(y.device, y.dtype)                               # [8, 3]
             u = y.unsqueeze(-2) * s                                        # [..., 8, 3]
             pre = F.linear(u, w[:, :3])                                    # [..., 8, H]
             pre = pre + (base if extra is None else base.unsqueeze(-2))
-        h = self.hidden(pre)                                               # [..., 8, H/2]
+        if pre is not None:
+            h = self.hidden(pre)                                           # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
             out = self._fc2(h)
             if out.is_cuda and out.dtype == torch.float32 and out.shape[-1] % 4 == 0:

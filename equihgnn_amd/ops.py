@@ -1628,11 +1628,11 @@ class _SwigluDropout(torch.autograd.Function):
     """dropout_p(silu(pre[:, :H]) * pre[:, H:]) in one pass each way (faf_swiglu_dropout_*, csrc/faformer_ew.hip)."""
 
     @staticmethod
-    def forward(ctx, pre, p):
+    def forward(ctx, pre, p, seed=None):
         _require_gpu(pre, "swiglu_dropout")
         pre2 = _f32c(pre).reshape(-1, pre.shape[-1])
         R, H = pre2.shape[0], pre2.shape[1] // 2
-        seed = _dropout_seed(pre.device, p)
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(pre.device, p)
         out = torch.empty((R, H), dtype=torch.float32, device=pre.device)
         hip.check(hip.lib().faf_swiglu_dropout_fwd(_ptr(pre2), R, H, float(p), _ptr(seed), _ptr(out), _stream(pre.device)),
                   "faf_swiglu_dropout_fwd")
@@ -1648,7 +1648,7 @@ class _SwigluDropout(torch.autograd.Function):
         dpre = torch.empty_like(pre2)
         hip.check(hip.lib().faf_swiglu_dropout_bwd(_ptr(pre2), _ptr(dout), R, H, ctx.p, _ptr(ctx.seed), _ptr(dpre),
                                                    _stream(pre2.device)), "faf_swiglu_dropout_bwd")
-        return dpre.view(ctx.shape), None
+        return dpre.view(ctx.shape), None, None
 
 
 class _DropoutMean(torch.autograd.Function):
@@ -1716,6 +1716,59 @@ class _FramePre(torch.autograd.Function):
         return dy.view(*ctx.lead, 3), dw3, dbase
 
 
+class _FrameHidden(torch.autograd.Function):
+    """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = w3 (y * s_f) + base over the 8 sign frames: frame_pre, swiglu_dropout
+    and the row LayerNorm in one launch each way (faf_frame_hidden_*); the [.., 8, 256] pre-activations never exist."""
+
+    @staticmethod
+    def forward(ctx, y, w3, base, gamma, beta, eps, p, seed, acc_params):
+        _require_gpu(y, "frame_hidden")
+        lead = y.shape[:-1]
+        y2, w3c, gamma, beta = _f32c(y).reshape(-1, 3), _f32c(w3), _f32c(gamma), _f32c(beta)
+        if w3c.shape[0] != 256 or gamma.numel() != 128:
+            raise ValueError("frame_hidden: fc1 with 256 outputs expected")
+        E = y2.shape[0]
+        if base.dim() == 1:
+            base2, ld = _f32c(base), 0
+        else:
+            base2, ld = _f32c(base).reshape(-1, 256), 256
+            if base2.shape[0] != E:
+                raise ValueError("frame_hidden: one base row per point expected")
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(y.device, p)
+        out = torch.empty((E, 8, 128), dtype=torch.float32, device=y.device)
+        hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(gamma), _ptr(beta), E, float(p),
+                                                 _ptr(seed), float(eps), _ptr(out), _stream(y.device)), "faf_frame_hidden_fwd")
+        ctx.save_for_backward(y2, w3c, base2, gamma)
+        ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape))
+        ctx.acc = acc_params
+        return out.view(*lead, 8, 128)
+
+    @staticmethod
+    def backward(ctx, dhn):
+        y2, w3c, base2, gamma = ctx.saved_tensors
+        lead, ld, eps, p, seed, base_shape = ctx.meta
+        E = y2.shape[0]
+        dev = y2.device
+        dhn = _f32c(dhn).reshape(E, 8, 128)
+        dy = torch.empty_like(y2)
+        dbase = torch.empty((E, 256), dtype=torch.float32, device=dev)
+        dw3 = torch.empty_like(w3c)
+        L = hip.lib()
+        ws_bytes = L.faf_frame_hidden_bwd_workspace_bytes(E)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(q) for q in ctx.acc]            # (gamma, beta)
+        small = torch.empty((2, 128), dtype=torch.float32, device=dev)
+        hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(gamma), _ptr(dhn), E, p, _ptr(seed), eps,
+                                         _ptr(dy), _ptr(dbase), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, _ptr(ws), ws_bytes,
+                                         _stream(dev)), "faf_frame_hidden_bwd")
+        dgam, dbet = _hand_out(list(small), tg)
+        if ld == 0:
+            dbase = colsum(dbase)
+        else:
+            dbase = dbase.view(base_shape)
+        return dy.view(*lead, 3), dw3, dbase, dgam, dbet, None, None, None, None
+
+
 class _AttnSum(torch.autograd.Function):
     """out[n, c] = sum_m attn[n, c // D, m] * x[n, m, c] (faf_attn_sum_fwd / _bwd, csrc/faformer_ew.hip)."""
 
@@ -1764,9 +1817,17 @@ def frame_pre(y, w3, base):
     return _FramePre.apply(y, w3, base)
 
 
-def swiglu_dropout(pre, p: float = 0.0):
-    """dropout_p(silu(a) * b) for pre = [a | b] along the last dim (fp32, last dim % 8 == 0)."""
-    return _SwigluDropout.apply(pre, p)
+def frame_hidden(y, w3, base, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None):
+    """LayerNorm(dropout_p(SiLU(a) * b)) with [a | b] = w3 (y * s_f) + base over the 8 sign frames of y [..., 3] ->
+    [..., 8, 128]; w3 [256, 3], base [..., 256] or [256], gamma / beta [128] (the PARAMETERS)."""
+    _note_acc(gamma, beta)
+    return _FrameHidden.apply(y, w3, base, gamma, beta, eps, p, seed, (gamma, beta))
+
+
+def swiglu_dropout(pre, p: float = 0.0, seed=None):
+    """dropout_p(silu(a) * b) for pre = [a | b] along the last dim (fp32, last dim % 8 == 0).  ``seed``: an int64 device
+    tensor [1] to take the dropout decisions from (default: a fresh draw)."""
+    return _SwigluDropout.apply(pre, p, seed)
 
 
 def dropout_mean(x, p: float = 0.0):

@@ -459,6 +459,19 @@ size_t faf_frame_pre_bwd_workspace_bytes(int64_t E, int32_t H);
 int faf_frame_pre_bwd(const float* y, const float* w3, const float* dpre, int64_t E, int32_t H, float* dy, float* dbase,
                       float* dw3, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The hidden layer of the frame-averaged MLP in ONE launch each way (fa_former_layer.py:61-120 with :241-289):
+ *   hn[e, f, :] = LayerNorm( dropout_p( SiLU(a_f) * b_f ) ),  [a_f | b_f] = w3 (y_e * s_f) + base_e,  256 -> 128 channels
+ * = faf_frame_pre_fwd + faf_swiglu_dropout_fwd + hg_layer_norm_fwd without the [E * 8, 256] and [E * 8, 128]
+ * intermediates (same dropout hash over the [E * 8, 128] tensor as faf_swiglu_dropout_*).  base: [E, 256] (base_ld 256)
+ * or one row broadcast (base_ld 0).  bwd: dy [E, 3], dbase [E, 256], dw3 [256, 3], dgamma / dbeta [128]. */
+int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
+                         const float* beta, int64_t E, float p, const int64_t* seed, float eps, float* out, void* stream);
+size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E);
+int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
+                         const float* dhn, int64_t E, float p, const int64_t* seed, float eps, float* dy, float* dbase,
+                         float* dw3, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending

@@ -1072,6 +1072,49 @@ def test_faformer_elementwise_kernels():
                                atol=1e-7, rtol=1e-6)
 
 
+@pytest.mark.parametrize("E,p,bcast", [(37, 0.0, False), (1000, 0.1, False), (300, 0.1, True), (5, 0.0, True)])
+def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):
+    """faf_frame_hidden_fwd / _bwd = frame_pre -> swiglu_dropout -> LayerNorm rows in one launch each way, with the SAME
+    dropout decisions (same hash, same seed): outputs and all five gradients against the unfused composition, and with
+    p = 0 against float64 torch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(E)
+    y = torch.randn(E, 3, generator=g)
+    w3 = 0.5 * torch.randn(256, 3, generator=g)
+    base = 0.5 * torch.randn(256, generator=g) if bcast else 0.5 * torch.randn(E, 256, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
+    wgt = torch.randn(E, 8, 128, generator=g)
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+
+    def run(fused):
+        d = [t.to(DEV).requires_grad_(True) for t in (y, w3, base, gamma, beta)]
+        if fused:
+            out = ops.frame_hidden(d[0], d[1], d[2], d[3], d[4], 1e-5, p, seed)
+        else:
+            pre = ops.frame_pre(d[0], d[1], d[2])
+            out = ops.layer_norm_rows(ops.swiglu_dropout(pre, p, seed).reshape(-1, 128), d[3], d[4], 1e-5).view(E, 8, 128)
+        (out * wgt.to(DEV)).sum().backward()
+        return out.detach().cpu(), [t.grad.cpu() for t in d]
+
+    of, gf = run(True)
+    ou, gu = run(False)
+    np.testing.assert_allclose(of.numpy(), ou.numpy(), atol=2e-5, rtol=1e-5)
+    for name, a, b in zip(("dy", "dw3", "dbase", "dgamma", "dbeta"), gf, gu):
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-9))
+        assert err < 5e-5, (name, err)
+    if p == 0.0:
+        t = [x.double().requires_grad_(True) for x in (y, w3, base, gamma, beta)]
+        s8 = torch.tensor([[a, b_, c] for a in (-1, 1) for b_ in (-1, 1) for c in (-1, 1)], dtype=torch.float64)
+        pre = torch.einsum("efd,hd->efh", t[0][:, None, :] * s8[None], t[1]) + (t[2] if bcast else t[2][:, None, :])
+        hid = torch.nn.functional.silu(pre[..., :128]) * pre[..., 128:]
+        ref = torch.nn.functional.layer_norm(hid, (128,), t[3], t[4], 1e-5)
+        (ref * wgt.double()).sum().backward()
+        np.testing.assert_allclose(of.numpy(), ref.detach().numpy(), atol=3e-5, rtol=1e-5)
+        for name, a, r in zip(("dy", "dw3", "dbase", "dgamma", "dbeta"), gf, t):
+            err = float((a.double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
+            assert err < 5e-5, (name, err)
+
+
 def test_frame_pre_matches_float64_reference():
     """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
     dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
