@@ -632,3 +632,333 @@ extern "C" int faf_attn_sum_bwd(const float* attn, const float* x, const float* 
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-wise dot products and the sigmoid gate built on one: Linear(C, J) with J <= 4 outputs on ~250 k edge rows
+// (fa_former_layer.py:340-400 att_mlp = Linear(d, 1) + Sigmoid; :483-489 the per-head edge logits).  As GEMMs with one or
+// two output columns the library needs ~2 ms each; as torch ops (multiply, then reduce) every one is two passes over a
+// 250 MB tensor forward and five backward.  Here: a wavefront per row, the row in registers, J butterfly sums.
+//   rowdot:  y[r, j] = x[r, :] . U[j, :] + b[j]          bwd: dx[r, :] = (dx_add[r, :] +) sum_j dy[r, j] U[j, :],  dU, (db = colsum dy)
+//   gate:    out[r, :] = (res[r, :] +) xd[r, :] * sigmoid(xd[r, :] . w + b),  xd = dropout_p(x)   (dropout hash as above)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int RD_THREADS = 256;
+constexpr int RD_WAVES = RD_THREADS / 64;
+
+template <int NV>
+struct RdRow {
+    float4 v[NV];
+};
+template <int NV>
+__device__ __forceinline__ void rd_load(const float* __restrict__ p, int C, int lane, RdRow<NV>& r) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        r.v[i] = (c < C) ? *reinterpret_cast<const float4*>(p + c) : f4_zero();
+    }
+}
+template <int NV>
+__device__ __forceinline__ float rd_dot(const RdRow<NV>& a, const RdRow<NV>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        s += (a.v[i].x * b.v[i].x + a.v[i].y * b.v[i].y) + (a.v[i].z * b.v[i].z + a.v[i].w * b.v[i].w);
+    return fp_wave_sum(s);
+}
+
+template <int NV, int J>
+__global__ void __launch_bounds__(RD_THREADS)
+k_rowdot_fwd(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ bias, int64_t R, int C,
+             float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RdRow<NV> u[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) rd_load<NV>(U + (int64_t)j * C, C, lane, u[j]);
+    for (int64_t r = (int64_t)blockIdx.x * RD_WAVES + wave; r < R; r += (int64_t)gridDim.x * RD_WAVES) {
+        RdRow<NV> xr;
+        rd_load<NV>(x + r * C, C, lane, xr);
+        float o[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) o[j] = rd_dot<NV>(xr, u[j]) + (bias ? bias[j] : 0.f);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < J; ++j) y[r * J + j] = o[j];
+        }
+    }
+}
+
+template <int NV, int J>
+__global__ void __launch_bounds__(RD_THREADS)
+k_rowdot_bwd(const float* __restrict__ x, const float* __restrict__ U, const float* __restrict__ dy,
+             const float* __restrict__ dx_add, int64_t R, int C, float* __restrict__ dx, float* __restrict__ slab) {
+    __shared__ float4 s_red[RD_THREADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RdRow<NV> u[J], au[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        rd_load<NV>(U + (int64_t)j * C, C, lane, u[j]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) au[j].v[i] = f4_zero();
+    }
+    for (int64_t r = (int64_t)blockIdx.x * RD_WAVES + wave; r < R; r += (int64_t)gridDim.x * RD_WAVES) {
+        RdRow<NV> xr, acc;
+        rd_load<NV>(x + r * C, C, lane, xr);
+        if (dx_add) rd_load<NV>(dx_add + r * C, C, lane, acc);
+        else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float g = dy[r * J + j];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                f4_fma(acc.v[i], u[j].v[i], g);
+                f4_fma(au[j].v[i], xr.v[i], g);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) *reinterpret_cast<float4*>(dx + r * C + c) = acc.v[i];
+        }
+    }
+    float* __restrict__ sl = slab + (int64_t)blockIdx.x * J * C;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s_red[threadIdx.x] = au[j].v[i];
+            __syncthreads();
+            if (wave == 0) {
+                float4 t = s_red[lane];
+                for (int w = 1; w < RD_WAVES; ++w) f4_add(t, s_red[w * 64 + lane]);
+                const int c = (lane + 64 * i) * 4;
+                if (c < C) *reinterpret_cast<float4*>(sl + (int64_t)j * C + c) = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void rd_dropout(RdRow<NV>& xr, uint64_t seed, int64_t r, int C, int lane, uint32_t threshold,
+                                           float inv_keep) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const uint64_t e = (uint64_t)(r * C + c);
+        xr.v[i].x *= keep_scale(seed, e, threshold, inv_keep); xr.v[i].y *= keep_scale(seed, e + 1, threshold, inv_keep);
+        xr.v[i].z *= keep_scale(seed, e + 2, threshold, inv_keep); xr.v[i].w *= keep_scale(seed, e + 3, threshold, inv_keep);
+    }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(RD_THREADS)
+k_gate_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ res,
+           int64_t R, int C, const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float* __restrict__ out) {
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RdRow<NV> wr;
+    rd_load<NV>(w, C, lane, wr);
+    const float b0 = b[0];
+    for (int64_t r = (int64_t)blockIdx.x * RD_WAVES + wave; r < R; r += (int64_t)gridDim.x * RD_WAVES) {
+        RdRow<NV> xr, rr;
+        rd_load<NV>(x + r * C, C, lane, xr);
+        if (res) rd_load<NV>(res + r * C, C, lane, rr);
+        if (threshold) rd_dropout<NV>(xr, seed, r, C, lane, threshold, inv_keep);
+        const float g = sigmoid_fast(rd_dot<NV>(xr, wr) + b0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            float4 o = make_float4(xr.v[i].x * g, xr.v[i].y * g, xr.v[i].z * g, xr.v[i].w * g);
+            if (res) f4_add(o, rr.v[i]);
+            if (c < C) *reinterpret_cast<float4*>(out + r * C + c) = o;
+        }
+    }
+}
+
+// slab per workgroup: [dw (C) | db, 0, 0, 0]
+template <int NV>
+__global__ void __launch_bounds__(RD_THREADS)
+k_gate_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ dout,
+           int64_t R, int C, const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float* __restrict__ dx,
+           float* __restrict__ slab) {
+    __shared__ float4 s_red[RD_THREADS];
+    __shared__ float s_b[RD_WAVES];
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RdRow<NV> wr, aw;
+    rd_load<NV>(w, C, lane, wr);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) aw.v[i] = f4_zero();
+    float ab = 0.f;
+    const float b0 = b[0];
+    for (int64_t r = (int64_t)blockIdx.x * RD_WAVES + wave; r < R; r += (int64_t)gridDim.x * RD_WAVES) {
+        RdRow<NV> xr, dr;
+        rd_load<NV>(x + r * C, C, lane, xr);
+        rd_load<NV>(dout + r * C, C, lane, dr);
+        if (threshold) rd_dropout<NV>(xr, seed, r, C, lane, threshold, inv_keep);
+        const float g = sigmoid_fast(rd_dot<NV>(xr, wr) + b0);
+        const float coef = rd_dot<NV>(dr, xr) * g * (1.0f - g);      // d loss / d (xd . w + b)
+        ab += coef;
+        RdRow<NV> dxd;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            dxd.v[i] = make_float4(fmaf(dr.v[i].x, g, coef * wr.v[i].x), fmaf(dr.v[i].y, g, coef * wr.v[i].y),
+                                   fmaf(dr.v[i].z, g, coef * wr.v[i].z), fmaf(dr.v[i].w, g, coef * wr.v[i].w));
+            f4_fma(aw.v[i], xr.v[i], coef);
+        }
+        if (threshold) rd_dropout<NV>(dxd, seed, r, C, lane, threshold, inv_keep);    // d x = keep * d xd
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) *reinterpret_cast<float4*>(dx + r * C + c) = dxd.v[i];
+        }
+    }
+    float* __restrict__ sl = slab + (int64_t)blockIdx.x * (C + 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        s_red[threadIdx.x] = aw.v[i];
+        __syncthreads();
+        if (wave == 0) {
+            float4 t = s_red[lane];
+            for (int q = 1; q < RD_WAVES; ++q) f4_add(t, s_red[q * 64 + lane]);
+            const int c = (lane + 64 * i) * 4;
+            if (c < C) *reinterpret_cast<float4*>(sl + c) = t;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) s_b[wave] = ab;      // (ab is wavefront-uniform: coef comes out of a butterfly sum)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = s_b[0];
+        for (int q = 1; q < RD_WAVES; ++q) t += s_b[q];
+        *reinterpret_cast<float4*>(sl + C) = make_float4(t, 0.f, 0.f, 0.f);
+    }
+}
+
+inline int rd_blocks(int64_t R) { return eqh_grid_for(R, RD_WAVES * 16, 1024); }
+inline int rd_check(int64_t R, int32_t C) {
+    if (R < 0 || C <= 0) return EQH_ERR_ARG;
+    if ((C & 3) || C > 1024) return EQH_ERR_ALIGN;
+    return EQH_OK;
+}
+template <typename F>
+int rd_dispatch(int C, F&& f) {
+    if (C <= 256) return f(std::integral_constant<int, 1>{});
+    if (C <= 512) return f(std::integral_constant<int, 2>{});
+    return f(std::integral_constant<int, 4>{});
+}
+
+}  // namespace
+
+extern "C" int faf_rowdot_fwd(const float* x, const float* U, const float* bias, int64_t R, int32_t C, int32_t J, float* y,
+                              void* stream_) {
+    int rc = rd_check(R, C);
+    if (rc) return rc;
+    if (J < 1 || J > 4) return EQH_ERR_ARG;
+    if (R == 0) return EQH_OK;
+    if (!x || !U || !y) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(U)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const dim3 grid(eqh_grid_for(R, RD_WAVES, 8192));
+    return rd_dispatch(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        switch (J) {
+            case 1: hipLaunchKernelGGL((k_rowdot_fwd<NV, 1>), grid, dim3(RD_THREADS), 0, stream, x, U, bias, R, (int)C, y); break;
+            case 2: hipLaunchKernelGGL((k_rowdot_fwd<NV, 2>), grid, dim3(RD_THREADS), 0, stream, x, U, bias, R, (int)C, y); break;
+            case 3: hipLaunchKernelGGL((k_rowdot_fwd<NV, 3>), grid, dim3(RD_THREADS), 0, stream, x, U, bias, R, (int)C, y); break;
+            default: hipLaunchKernelGGL((k_rowdot_fwd<NV, 4>), grid, dim3(RD_THREADS), 0, stream, x, U, bias, R, (int)C, y); break;
+        }
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t faf_rowdot_bwd_workspace_bytes(int64_t R, int32_t C, int32_t J) {
+    if (R <= 0 || C <= 0 || J < 1) return 0;
+    return (size_t)rd_blocks(R) * (size_t)J * (size_t)C * sizeof(float);
+}
+
+/* dx [R, C] = (dx_add, may be NULL) + dy U;  dU [J, C] overwritten or accumulated */
+extern "C" int faf_rowdot_bwd(const float* x, const float* U, const float* dy, const float* dx_add, int64_t R, int32_t C,
+                              int32_t J, float* dx, float* dU, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                              void* stream_) {
+    int rc = rd_check(R, C);
+    if (rc) return rc;
+    if (J < 1 || J > 4 || !dU) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (R == 0) return accumulate ? EQH_OK : eqh_zero_async(dU, (int64_t)J * C, stream);
+    if (!x || !U || !dy || !dx || !workspace) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(U) || !eqh_aligned16(dx) || !eqh_aligned16(dx_add) || !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_rowdot_bwd_workspace_bytes(R, C, J)) return EQH_ERR_ARG;
+    const int blocks = rd_blocks(R);
+    float* slab = static_cast<float*>(workspace);
+    return rd_dispatch(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        switch (J) {
+            case 1: hipLaunchKernelGGL((k_rowdot_bwd<NV, 1>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, U, dy, dx_add, R, (int)C, dx, slab); break;
+            case 2: hipLaunchKernelGGL((k_rowdot_bwd<NV, 2>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, U, dy, dx_add, R, (int)C, dx, slab); break;
+            case 3: hipLaunchKernelGGL((k_rowdot_bwd<NV, 3>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, U, dy, dx_add, R, (int)C, dx, slab); break;
+            default: hipLaunchKernelGGL((k_rowdot_bwd<NV, 4>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, U, dy, dx_add, R, (int)C, dx, slab); break;
+        }
+        EQH_CHECK_LAUNCH();
+        return eqh_reduce_slabs_async(slab, blocks, (int64_t)J * C, dU, stream, accumulate);
+    });
+}
+
+extern "C" int faf_gate_fwd(const float* x, const float* w, const float* b, const float* res, int64_t R, int32_t C, float p,
+                            const int64_t* seed, float* out, void* stream_) {
+    int rc = rd_check(R, C);
+    if (rc) return rc;
+    if (!(p >= 0.f) || !(p < 1.f)) return EQH_ERR_ARG;
+    if (R == 0) return EQH_OK;
+    if (!x || !w || !b || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(w) || !eqh_aligned16(res) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return rd_dispatch(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_gate_fwd<NV>), dim3(eqh_grid_for(R, RD_WAVES, 8192)), dim3(RD_THREADS), 0, stream, x, w, b, res, R,
+                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" size_t faf_gate_bwd_workspace_bytes(int64_t R, int32_t C) {
+    if (R <= 0 || C <= 0) return 0;
+    return ((size_t)rd_blocks(R) * (size_t)(C + 4) + 4) * sizeof(float);   // + a discard row for the slab's padding floats
+}
+
+/* dx [R, C]; dw [C] and db [1] overwritten or accumulated (the gradient of `res` is dout itself) */
+extern "C" int faf_gate_bwd(const float* x, const float* w, const float* b, const float* dout, int64_t R, int32_t C, float p,
+                            const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, void* workspace,
+                            size_t workspace_bytes, void* stream_) {
+    int rc = rd_check(R, C);
+    if (rc) return rc;
+    if (!(p >= 0.f) || !(p < 1.f) || !dw || !db) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (R == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dw, C, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(db, 1, stream);
+    }
+    if (!x || !w || !b || !dout || !dx || !workspace || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(w) || !eqh_aligned16(dout) || !eqh_aligned16(dx) || !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_gate_bwd_workspace_bytes(R, C)) return EQH_ERR_ARG;
+    const int blocks = rd_blocks(R);
+    float* slab = static_cast<float*>(workspace);
+    return rd_dispatch(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_gate_bwd<NV>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, w, b, dout, R, (int)C, seed,
+                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
+        EQH_CHECK_LAUNCH();
+        // segments: dw (C), db (1), the slab row's three padding floats (to the discard row)
+        return eqh_reduce_slabs3_async(slab, blocks, (int64_t)C + 4, dw, db, slab + (size_t)blocks * (C + 4), C, 1, accumulate,
+                                       stream);
+    });
+}

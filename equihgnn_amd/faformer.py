@@ -158,7 +158,8 @@ class EdgeModule(nn.Module):
         self.att_mlp = nn.Sequential(nn.Linear(d, 1), nn.Sigmoid())
         self.d = d
 
-    def forward(self, tok, geo, g: EdgeGraph):
+    def forward(self, tok, geo, g: EdgeGraph, res=None):
+        """``res``: the edge features this module's output is added to (:602-604), folded into the gate kernel."""
         rel = geo.unsqueeze(1) - g.gather(geo_pad(geo))[..., :3]           # x_i - x_j  [N,K,3]
         d2 = (rel ** 2).sum(-1, keepdim=True)
         y, _, _ = _frame_axes(rel, g.mask)
@@ -168,11 +169,17 @@ class EdgeModule(nn.Module):
         lin = ops.linear if tok.is_cuda else (lambda x, w_, b_=None, cols=None: F.linear(x, w_[:, cols[0]:cols[1]], b_))
         pre = (lin(tok, w, self.edge_mlp.fc1.bias, cols=(0, d)).unsqueeze(1)
                + g.gather(lin(tok, w, None, cols=(d, 2 * d))) + lin(feats, w, None, cols=(2 * d, w.shape[1])))
-        pair = F.dropout(self.edge_mlp._fc2(self.edge_mlp.hidden(pre)), self.edge_mlp.p, self.training)
-        # att_mlp = Linear(d, 1) + Sigmoid on ~250 k edge rows: a row-wise dot product (one multiply + one reduction
-        # pass over the rows) -- as a GEMM with ONE output column the library needs 2 ms for it
+        pair = self.edge_mlp._fc2(self.edge_mlp.hidden(pre))
+        # att_mlp = Linear(d, 1) + Sigmoid on ~250 k edge rows: a row-wise dot product -- as a GEMM with ONE output column the
+        # library needs 2 ms for it.  The dropout in front of it, the dot product, the gate and the residual add behind it
+        # are one pass each way (ops.gate_rows, csrc/faformer_ew.hip)
         a = self.att_mlp[0]
-        return pair * torch.sigmoid((pair * a.weight.view(-1)).sum(-1, keepdim=True) + a.bias)
+        p = self.edge_mlp.p if self.training else 0.0
+        if pair.is_cuda and pair.dtype == torch.float32 and pair.shape[-1] % 4 == 0 and pair.shape[-1] <= 1024:
+            return ops.gate_rows(pair, a.weight, a.bias, res, p)
+        pair = F.dropout(pair, p, self.training)
+        out = pair * torch.sigmoid((pair * a.weight.view(-1)).sum(-1, keepdim=True) + a.bias)
+        return out if res is None else res + out
 
 
 def geo_pad(geo):
@@ -220,7 +227,10 @@ class MLPAttnEdgeAggregation(nn.Module):
         w_e = self.edge_attn.weight.view(-1)
         u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)          # [h, de]
         c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                              # [h]
-        le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c                     # [N, K, h]
+        if ops.rowdot_supported(xe, h):   # one pass over xe each way; xe's second gradient (from ve) rides along
+            le, xe = ops.rowdot(xe, u, c, passthrough=True)                                   # [N, K, h]
+        else:
+            le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c
         ve = ops.linear(xe, lin_e.weight, lin_e.bias, rows=(de, 2 * de))                      # value half only
         gate = torch.sigmoid(self.W_gate(tok))
         logits = a_q.unsqueeze(1) + ak_n + le
@@ -272,7 +282,7 @@ class FAFormerEncoderLayer(nn.Module):
     def forward(self, tok, geo, edge, g, last, row_mask=None):
         tok, geo = self.self_attn(tok, geo, edge, g, row_mask)
         if not last:
-            edge = edge + self.edge_module(tok, geo, g)                     # :602-604
+            edge = self.edge_module(tok, geo, g, res=edge)                  # edge + edge_module(...), :602-604
         return tok + self.ffn(tok, geo, row_mask), geo, edge                # :606
 
 

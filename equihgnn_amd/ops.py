@@ -1655,12 +1655,12 @@ class _DropoutMean(torch.autograd.Function):
     """mean over dim -2 of dropout_p(x) in one pass each way (faf_dropout_mean_*)."""
 
     @staticmethod
-    def forward(ctx, x, p):
+    def forward(ctx, x, p, seed=None):
         _require_gpu(x, "dropout_mean")
         F_, C = x.shape[-2], x.shape[-1]
         x2 = _f32c(x).reshape(-1, C)
         R = x2.shape[0] // F_
-        seed = _dropout_seed(x.device, p)
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
         out = torch.empty((R, C), dtype=torch.float32, device=x.device)
         hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out), _stream(x.device)),
                   "faf_dropout_mean_fwd")
@@ -1675,7 +1675,7 @@ class _DropoutMean(torch.autograd.Function):
         dx = torch.empty((R * F_, C), dtype=torch.float32, device=dout.device)
         hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx), _stream(dout.device)),
                   "faf_dropout_mean_bwd")
-        return dx.view(ctx.shape), None
+        return dx.view(ctx.shape), None, None
 
 
 class _FramePre(torch.autograd.Function):
@@ -1769,6 +1769,106 @@ class _FrameHidden(torch.autograd.Function):
         return dy.view(*lead, 3), dw3, dbase, dgam, dbet, None, None, None, None
 
 
+class _RowDot(torch.autograd.Function):
+    """y = x @ U.T + bias for a FEW output columns (J <= 4), one pass over x each way (faf_rowdot_*).  With
+    ``passthrough`` the node also returns x itself for x's OTHER consumer, and the backward adds that consumer's gradient
+    in the same pass (no autograd add over the [rows, C] tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, U, bias, passthrough):
+        _require_gpu(x, "rowdot")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        Uc = _f32c(U)
+        R, C = x2.shape
+        J = Uc.shape[0]
+        y = torch.empty((R, J), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_rowdot_fwd(_ptr(x2), _ptr(Uc), _ptr(_f32c(bias) if bias is not None else None), R, C, J,
+                                           _ptr(y), _stream(x.device)), "faf_rowdot_fwd")
+        ctx.save_for_backward(x2, Uc)
+        ctx.shape, ctx.has_bias = x.shape, bias is not None
+        ctx.set_materialize_grads(False)
+        y = y.view(*x.shape[:-1], J)
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dpass=None):
+        x2, Uc = ctx.saved_tensors
+        R, C = x2.shape
+        J = Uc.shape[0]
+        if dy is None:
+            return dpass, None, None, None
+        dy2 = _f32c(dy).reshape(R, J)
+        add = _f32c(dpass).reshape(R, C) if dpass is not None else None
+        dx = torch.empty_like(x2)
+        dU = torch.empty_like(Uc)
+        L = hip.lib()
+        ws_bytes = L.faf_rowdot_bwd_workspace_bytes(R, C, J)
+        ws = _workspace(max(ws_bytes, 16), x2.device)
+        hip.check(L.faf_rowdot_bwd(_ptr(x2), _ptr(Uc), _ptr(dy2), _ptr(add), R, C, J, _ptr(dx), _ptr(dU), 0, _ptr(ws),
+                                   ws_bytes, _stream(x2.device)), "faf_rowdot_bwd")
+        db = dy2.sum(0) if ctx.has_bias else None
+        return dx.view(ctx.shape), dU, db, None
+
+
+def rowdot(x, U, bias=None, passthrough: bool = False):
+    """x [..., C] @ U [J, C].T + bias [J] -> [..., J] for J <= 4 (fp32, C % 4 == 0, C <= 1024); see _RowDot."""
+    return _RowDot.apply(x, U, bias, passthrough)
+
+
+def rowdot_supported(x, J: int) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and 1 <= J <= 4
+
+
+class _GateRows(torch.autograd.Function):
+    """out = res + xd * sigmoid(xd . w + b), xd = dropout_p(x): EdgeModule's gate with the dropout in front of it and the
+    residual behind it, one pass each way (faf_gate_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, p, seed, acc_params):
+        _require_gpu(x, "gate_rows")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        wc, bc = _f32c(w).reshape(-1), _f32c(b).reshape(-1)
+        R, C = x2.shape
+        r2 = _f32c(res).reshape(R, C) if res is not None else None
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
+        out = torch.empty_like(x2)
+        hip.check(hip.lib().faf_gate_fwd(_ptr(x2), _ptr(wc), _ptr(bc), _ptr(r2), R, C, float(p), _ptr(seed), _ptr(out),
+                                         _stream(x.device)), "faf_gate_fwd")
+        ctx.save_for_backward(x2, wc, bc)
+        ctx.meta = (x.shape, float(p), seed, res is not None, w.shape, b.shape)
+        ctx.acc = acc_params
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, wc, bc = ctx.saved_tensors
+        shape, p, seed, has_res, w_shape, b_shape = ctx.meta
+        R, C = x2.shape
+        dout2 = _f32c(dout).reshape(R, C)
+        dx = torch.empty_like(x2)
+        L = hip.lib()
+        ws_bytes = L.faf_gate_bwd_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x2.device)
+        tg = [_acc_target(q) for q in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty(C + 4, dtype=torch.float32, device=x2.device)
+        dw_t = tg[0].reshape(-1) if acc else small[:C]
+        db_t = tg[1].reshape(-1) if acc else small[C:C + 1]
+        hip.check(L.faf_gate_bwd(_ptr(x2), _ptr(wc), _ptr(bc), _ptr(dout2), R, C, p, _ptr(seed), _ptr(dx), _ptr(dw_t),
+                                 _ptr(db_t), 1 if acc else 0, _ptr(ws), ws_bytes, _stream(x2.device)), "faf_gate_bwd")
+        if acc:
+            dw = db = None
+        else:
+            dw, db = _hand_out([small[:C].view(w_shape), small[C:C + 1].view(b_shape)], tg)
+        return dx.view(shape), dw, db, (dout if has_res else None), None, None, None
+
+
+def gate_rows(x, w, b, res=None, p: float = 0.0, seed=None):
+    """res + dropout_p(x) * sigmoid(dropout_p(x) . w + b) over the last dim; w [C] (or [1, C]) and b [1] are the PARAMETERS."""
+    _note_acc(w, b)
+    return _GateRows.apply(x, w, b, res, p, seed, (w, b))
+
+
 class _AttnSum(torch.autograd.Function):
     """out[n, c] = sum_m attn[n, c // D, m] * x[n, m, c] (faf_attn_sum_fwd / _bwd, csrc/faformer_ew.hip)."""
 
@@ -1830,9 +1930,9 @@ def swiglu_dropout(pre, p: float = 0.0, seed=None):
     return _SwigluDropout.apply(pre, p, seed)
 
 
-def dropout_mean(x, p: float = 0.0):
+def dropout_mean(x, p: float = 0.0, seed=None):
     """dropout_p(x).mean(-2) for fp32 x [..., F, C] (C % 4 == 0)."""
-    return _DropoutMean.apply(x, p)
+    return _DropoutMean.apply(x, p, seed)
 
 
 class _AttnPool(torch.autograd.Function):

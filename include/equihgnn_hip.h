@@ -472,6 +472,25 @@ int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int
                          float* dw3, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Row-wise dot products -- nn.Linear(C, J) with J <= 4 outputs on edge rows (fa_former_layer.py:340-400 att_mlp,
+ * :483-489 the per-head edge logits): y [R, J] = x [R, C] . U [J, C]^T + bias [J] (may be NULL), a wavefront per row.
+ * bwd: dx [R, C] = dx_add (may be NULL: a second gradient of x that rides along) + dy U; dU [J, C] overwritten or
+ * accumulated.  C % 4 == 0, C <= 1024. */
+int faf_rowdot_fwd(const float* x, const float* U, const float* bias, int64_t R, int32_t C, int32_t J, float* y, void* stream);
+size_t faf_rowdot_bwd_workspace_bytes(int64_t R, int32_t C, int32_t J);
+int faf_rowdot_bwd(const float* x, const float* U, const float* dy, const float* dx_add, int64_t R, int32_t C, int32_t J,
+                   float* dx, float* dU, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The sigmoid gate of EdgeModule (fa_former_layer.py:340-400: pair * att_mlp(pair)) with the dropout in front of it and the
+ * residual behind it:  out = res (may be NULL) + xd * sigmoid(xd . w + b),  xd = dropout_p(x)  (hash of (seed, element)).
+ * bwd: dx [R, C], dw [C], db [1] (overwritten or accumulated); the gradient of res is dout itself. */
+int faf_gate_fwd(const float* x, const float* w, const float* b, const float* res, int64_t R, int32_t C, float p,
+                 const int64_t* seed, float* out, void* stream);
+size_t faf_gate_bwd_workspace_bytes(int64_t R, int32_t C);
+int faf_gate_bwd(const float* x, const float* w, const float* b, const float* dout, int64_t R, int32_t C, float p,
+                 const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending

@@ -1115,6 +1115,58 @@ def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):
             assert err < 5e-5, (name, err)
 
 
+@pytest.mark.parametrize("R,C,J", [(1, 64, 1), (1000, 256, 2), (333, 320, 4), (50, 1024, 3)])
+def test_rowdot_matches_float64(R, C, J):
+    """faf_rowdot_fwd / _bwd: y = x U^T + b for J <= 4 outputs, and the pass-through form whose backward adds the other
+    consumer's gradient of x in the same pass."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C + J)
+    x, U, b = torch.randn(R, C, generator=g), torch.randn(J, C, generator=g), torch.randn(J, generator=g)
+    wy, wx = torch.randn(R, J, generator=g), torch.randn(R, C, generator=g)
+    t = [a.double().requires_grad_(True) for a in (x, U, b)]
+    ((t[0] @ t[1].T + t[2]) * wy.double()).sum().backward(retain_graph=True)
+    for passthrough in (False, True):
+        d = [a.to(DEV).requires_grad_(True) for a in (x, U, b)]
+        if passthrough:
+            y, xp = ops.rowdot(d[0], d[1], d[2], passthrough=True)
+            ((y * wy.to(DEV)).sum() + (xp * wx.to(DEV)).sum()).backward()
+            ref_dx = t[0].grad + wx.double()
+        else:
+            y = ops.rowdot(d[0], d[1], d[2])
+            (y * wy.to(DEV)).sum().backward()
+            ref_dx = t[0].grad
+        np.testing.assert_allclose(y.detach().cpu().numpy(), (x.double() @ U.double().T + b.double()).numpy(), atol=3e-5, rtol=1e-5)
+        for name, a, r in (("dx", d[0].grad, ref_dx), ("dU", d[1].grad, t[1].grad), ("db", d[2].grad, t[2].grad)):
+            err = float((a.cpu().double() - r).abs().max() / r.abs().max().clamp(min=1e-9))
+            assert err < 3e-5, (name, passthrough, err)
+
+
+@pytest.mark.parametrize("R,C,p,with_res", [(1, 64, 0.0, False), (1000, 256, 0.1, True), (333, 320, 0.0, True), (50, 1024, 0.2, False)])
+def test_gate_rows_matches_float64(R, C, p, with_res):
+    """faf_gate_fwd / _bwd: res + xd * sigmoid(xd . w + b) with xd = dropout_p(x); the dropout decisions are reproduced for
+    the reference through faf_dropout_mean (same hash of (seed, element), one frame)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    x, w, b = torch.randn(R, C, generator=g), 0.2 * torch.randn(1, C, generator=g), torch.randn(1, generator=g)
+    res = torch.randn(R, C, generator=g) if with_res else None
+    wo = torch.randn(R, C, generator=g)
+    seed = torch.tensor([987654321], dtype=torch.int64, device=DEV)
+    keep = (ops.dropout_mean(torch.ones(R, 1, C, device=DEV), p, seed).cpu().double() if p > 0 else torch.ones(R, C, dtype=torch.float64))
+    t = [a.double().requires_grad_(True) for a in ((x, w, b) + ((res,) if with_res else ()))]
+    xd = t[0] * keep
+    ref = xd * torch.sigmoid(xd @ t[1].reshape(-1, 1) + t[2])
+    if with_res:
+        ref = ref + t[3]
+    (ref * wo.double()).sum().backward()
+    d = [a.to(DEV).requires_grad_(True) for a in ((x, w, b) + ((res,) if with_res else ()))]
+    out = ops.gate_rows(d[0], d[1], d[2], d[3] if with_res else None, p, seed)
+    (out * wo.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=3e-5, rtol=1e-5)
+    for name, a, r in zip(("dx", "dw", "db", "dres"), d, t):
+        err = float((a.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
+        assert err < 3e-5, (name, err)
+
+
 def test_frame_pre_matches_float64_reference():
     """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
     dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
