@@ -324,18 +324,31 @@ __device__ __forceinline__ FhLane fh_load(const float* __restrict__ w3, const fl
     return L;
 }
 
+// `base`: one row per point (base_ld = 256), or -- with wx -- the bias vector of fc1, the point's row being
+// bias + extra[e] * wx (the K = 1 Linear of the squared distance, fc1.weight[:, 3]; extra NULL: the bias alone)
 __global__ void __launch_bounds__(FP_THREADS)
 k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ base, int64_t base_ld,
+                   const float* __restrict__ extra, const float* __restrict__ wx,
                    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t E,
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
                    float* __restrict__ out) {
     const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FhLane L = fh_load(w3, gamma, beta, lane);
+    float2 wxa = make_float2(0.f, 0.f), wxb = make_float2(0.f, 0.f);
+    if (wx) {
+        wxa = *reinterpret_cast<const float2*>(wx + 2 * lane);
+        wxb = *reinterpret_cast<const float2*>(wx + 128 + 2 * lane);
+    }
     for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
         const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
-        const float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
-        const float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
+        float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        if (wx && extra) {
+            const float ex = extra[e];
+            ba.x = fmaf(ex, wxa.x, ba.x); ba.y = fmaf(ex, wxa.y, ba.y);
+            bb.x = fmaf(ex, wxb.x, bb.x); bb.y = fmaf(ex, wxb.y, bb.y);
+        }
         const float ta0[3] = {y0 * L.wa0[0], y1 * L.wa0[1], y2 * L.wa0[2]}, ta1[3] = {y0 * L.wa1[0], y1 * L.wa1[1], y2 * L.wa1[2]};
         const float tb0[3] = {y0 * L.wb0[0], y1 * L.wb0[1], y2 * L.wb0[2]}, tb1[3] = {y0 * L.wb1[0], y1 * L.wb1[1], y2 * L.wb1[2]};
         float v0[8], v1[8], mu[8];
@@ -365,26 +378,41 @@ k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, co
     }
 }
 
-// slab per workgroup: [d W3 (256 x 3) | d gamma (128) | d beta (128)]
+// slab per workgroup: [d W3 (256 x 3) | d gamma (128) | d beta (128)]; in the vector-base form a second slab array behind
+// the first holds [d bias (256) | d wx (256)] per workgroup
 constexpr int FH_SLAB = 256 * 3 + 128 + 128;
+constexpr int FH_SLAB_VEC = FH_SLAB + 256 + 256;
 
+template <bool VEC>
 __global__ void __launch_bounds__(FP_THREADS)
 k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, const float* __restrict__ base, int64_t base_ld,
+                   const float* __restrict__ extra, const float* __restrict__ wx,
                    const float* __restrict__ gamma, const float* __restrict__ dhn, int64_t E,
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
-                   float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ slab) {
-    __shared__ float s_red[FP_WAVES][16][64];
+                   float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ dextra, float* __restrict__ slab) {
+    __shared__ float s_red[FP_WAVES][VEC ? 24 : 16][64];
     const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FhLane L = fh_load(w3, gamma, nullptr, lane);
     float aw[4][3];              // d W3 of channels (a0, a1, b0, b1) x d
     float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;   // d gamma, d beta of the two hidden units
+    float adb[4] = {0.f, 0.f, 0.f, 0.f}, adx[4] = {0.f, 0.f, 0.f, 0.f};   // VEC: d bias, d wx of the four channels
+    float wxv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (VEC) {
+        wxv[0] = wx[2 * lane]; wxv[1] = wx[2 * lane + 1]; wxv[2] = wx[128 + 2 * lane]; wxv[3] = wx[128 + 2 * lane + 1];
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) aw[c][0] = aw[c][1] = aw[c][2] = 0.f;
     for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
         const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
-        const float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
-        const float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        float2 ba = *reinterpret_cast<const float2*>(base + e * base_ld + 2 * lane);
+        float2 bb = *reinterpret_cast<const float2*>(base + e * base_ld + 128 + 2 * lane);
+        float ex = 0.f;
+        if (VEC && extra) {
+            ex = extra[e];
+            ba.x = fmaf(ex, wxv[0], ba.x); ba.y = fmaf(ex, wxv[1], ba.y);
+            bb.x = fmaf(ex, wxv[2], bb.x); bb.y = fmaf(ex, wxv[3], bb.y);
+        }
         float2 g[8];
 #pragma unroll
         for (int f = 0; f < 8; ++f) g[f] = *reinterpret_cast<const float2*>(dhn + (e * 8 + f) * 128 + 2 * lane);
@@ -426,8 +454,20 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
                 for (int d = 0; d < 3; ++d) r[c][d] = fmaf(sg[d], dp[c], r[c][d]);
             }
         }
-        *reinterpret_cast<float2*>(dbase + e * 256 + 2 * lane) = make_float2(sb[0], sb[1]);
-        *reinterpret_cast<float2*>(dbase + e * 256 + 128 + 2 * lane) = make_float2(sb[2], sb[3]);
+        if (!VEC) {
+            *reinterpret_cast<float2*>(dbase + e * 256 + 2 * lane) = make_float2(sb[0], sb[1]);
+            *reinterpret_cast<float2*>(dbase + e * 256 + 128 + 2 * lane) = make_float2(sb[2], sb[3]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                adb[c] += sb[c];
+                adx[c] = fmaf(sb[c], ex, adx[c]);
+            }
+            if (extra) {
+                const float de = fp_wave_sum((sb[0] * wxv[0] + sb[1] * wxv[1]) + (sb[2] * wxv[2] + sb[3] * wxv[3]));
+                if (lane == 0) dextra[e] = de;
+            }
+        }
         const float dd0 = fp_wave_sum((r[0][0] * L.wa0[0] + r[1][0] * L.wa1[0]) + (r[2][0] * L.wb0[0] + r[3][0] * L.wb1[0]));
         const float dd1 = fp_wave_sum((r[0][1] * L.wa0[1] + r[1][1] * L.wa1[1]) + (r[2][1] * L.wb0[1] + r[3][1] * L.wb1[1]));
         const float dd2 = fp_wave_sum((r[0][2] * L.wa0[2] + r[1][2] * L.wa1[2]) + (r[2][2] * L.wb0[2] + r[3][2] * L.wb1[2]));
@@ -444,12 +484,18 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
 #pragma unroll
         for (int d = 0; d < 3; ++d) s_red[wave][c * 3 + d][lane] = aw[c][d];
     s_red[wave][12][lane] = ag0; s_red[wave][13][lane] = ag1; s_red[wave][14][lane] = ab0; s_red[wave][15][lane] = ab1;
+    if (VEC) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s_red[wave][16 + c][lane] = adb[c]; s_red[wave][20 + c][lane] = adx[c]; }
+    }
     __syncthreads();
     if (wave == 0) {
+        constexpr int NQ = VEC ? 24 : 16;
         float* __restrict__ sl = slab + (int64_t)blockIdx.x * FH_SLAB;
-        float t[16];
+        float* __restrict__ sl2 = slab + (int64_t)gridDim.x * FH_SLAB + (int64_t)blockIdx.x * 512;   // VEC: [d bias | d wx]
+        float t[NQ];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             t[q] = s_red[0][q][lane];
             for (int w = 1; w < FP_WAVES; ++w) t[q] += s_red[w][q][lane];
         }
@@ -460,6 +506,10 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
             for (int d = 0; d < 3; ++d) sl[ch[c] * 3 + d] = t[c * 3 + d];
         sl[768 + 2 * lane] = t[12]; sl[768 + 2 * lane + 1] = t[13];
         sl[896 + 2 * lane] = t[14]; sl[896 + 2 * lane + 1] = t[15];
+        if (VEC) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { sl2[ch[c]] = t[16 + c]; sl2[256 + ch[c]] = t[20 + c]; }
+        }
     }
 }
 
@@ -504,34 +554,41 @@ extern "C" int faf_frame_pre_bwd(const float* y, const float* w3, const float* d
 /* frame_pre + SwiGLU + dropout + LayerNorm in one launch each way (see k_frame_hidden_fwd): hn [E, 8, 128] from y [E, 3],
    w3 [256, 3], base ([E, 256] with base_ld = 256, or one row with base_ld = 0), gamma / beta [128].  bwd: dy [E, 3],
    dbase [E, 256] (per row, also for a broadcast base), dw3 [256, 3], dgamma, dbeta [128] (overwritten or accumulated). */
-extern "C" int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
-                                    const float* beta, int64_t E, float p, const int64_t* seed, float eps, float* out,
-                                    void* stream_) {
-    if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256)) return EQH_ERR_ARG;
+extern "C" int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
+                                    const float* wx, const float* gamma, const float* beta, int64_t E, float p,
+                                    const int64_t* seed, float eps, float* out, void* stream_) {
+    if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256) || (wx && base_ld != 0) || (extra && !wx))
+        return EQH_ERR_ARG;
     if (E == 0) return EQH_OK;
     if (!y || !w3 || !base || !gamma || !beta || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7)) return EQH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(wx) & 7))
+        return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_frame_hidden_fwd, dim3(eqh_grid_for(E, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, y, w3, base,
-                       base_ld, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
+                       base_ld, extra, wx, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
 
 extern "C" size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E) {
     if (E <= 0) return 0;
-    return (size_t)fp_blocks(E) * (size_t)FH_SLAB * sizeof(float);
+    return (size_t)fp_blocks(E) * (size_t)FH_SLAB_VEC * sizeof(float);
 }
 
-extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
-                                    const float* dhn, int64_t E, float p, const int64_t* seed, float eps, float* dy,
-                                    float* dbase, float* dw3, float* dgamma, float* dbeta, int32_t accumulate,
-                                    void* workspace, size_t workspace_bytes, void* stream_) {
+/* Row form (wx NULL): dbase [E, 256] is written (also for a broadcast base).  Vector form (wx given, base = the bias vector,
+   base_ld 0): dbase receives d bias [256] and dwx d wx [256] instead, dextra [E] the gradient of extra (extra may be NULL). */
+extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
+                                    const float* wx, const float* gamma, const float* dhn, int64_t E, float p,
+                                    const int64_t* seed, float eps, float* dy, float* dbase, float* dwx, float* dextra,
+                                    float* dw3, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                                    size_t workspace_bytes, void* stream_) {
     if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256) || !dw3 || !dgamma || !dbeta) return EQH_ERR_ARG;
+    if ((wx && (base_ld != 0 || !dwx || !dbase)) || (extra && (!wx || !dextra))) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (E == 0) {
         if (accumulate) return EQH_OK;
         if (eqh_zero_async(dw3, 768, stream) || eqh_zero_async(dgamma, 128, stream)) return EQH_ERR_LAUNCH;
+        if (wx && (eqh_zero_async(dbase, 256, stream) || eqh_zero_async(dwx, 256, stream))) return EQH_ERR_LAUNCH;
         return eqh_zero_async(dbeta, 128, stream);
     }
     if (!y || !w3 || !base || !gamma || !dhn || !dy || !dbase || !workspace || (p > 0.f && !seed)) return EQH_ERR_ARG;
@@ -541,10 +598,18 @@ extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float
     if (workspace_bytes < faf_frame_hidden_bwd_workspace_bytes(E)) return EQH_ERR_ARG;
     const int blocks = fp_blocks(E);
     float* slab = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_frame_hidden_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, gamma, dhn, E, seed,
-                       ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, slab);
+    if (!wx) {
+        hipLaunchKernelGGL(k_frame_hidden_bwd<false>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx,
+                           gamma, dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab);
+        EQH_CHECK_LAUNCH();
+        return eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
+    }
+    hipLaunchKernelGGL(k_frame_hidden_bwd<true>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx, gamma,
+                       dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab);
     EQH_CHECK_LAUNCH();
-    return eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
+    int rc = eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
+    if (rc) return rc;
+    return eqh_reduce_slabs3_async(slab + (size_t)blocks * FH_SLAB, blocks, 512, dbase, dwx, nullptr, 256, 256, accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

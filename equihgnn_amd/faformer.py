@@ -74,14 +74,22 @@ class SwiGLUMLP(nn.Module):
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
         w = self.fc1.weight
-        if extra is None:
+        fused = y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256 and FUSE_FRAME_HIDDEN
+        if fused and (extra is None or extra.shape[-1] == 1):
+            # first Linear over the sign frames (the squared distance's K = 1 column included) + SwiGLU + dropout + LayerNorm
+            # in one launch each way (csrc/faformer_ew.hip)
+            h = ops.frame_hidden(y, w[:, :3], self.fc1.bias, self.norm.weight, self.norm.bias, self.norm.eps,
+                                 self.p if self.training else 0.0, None, extra, None if extra is None else w[:, 3])
+            pre = base = None
+        elif extra is None:
             base = self.fc1.bias
         elif extra.shape[-1] == 1:      # one extra input (the squared distance): a broadcast multiply-add, not a K = 1 GEMM
             base = torch.addcmul(self.fc1.bias, extra, w[:, 3])
         else:
             base = F.linear(extra, w[:, 3:], self.fc1.bias)
-        if y.is_cuda and y.dtype == torch.float32 and w.shape[0] == 256 and FUSE_FRAME_HIDDEN:
-            # first Linear over the sign frames + SwiGLU + dropout + LayerNorm in one launch (csrc/faformer_ew.hip)
+        if base is None:
+            pass
+        elif fused:
             h = ops.frame_hidden(y, w[:, :3], base, self.norm.weight, self.norm.bias, self.norm.eps,
                                  self.p if self.training else 0.0)
             pre = None

@@ -86,11 +86,11 @@ SIGNATURES = {
     "faf_frame_pre_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "faf_frame_pre_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_size_t, c_void_p]),
-    "faf_frame_hidden_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_float,
-                                       c_void_p, c_void_p]),
+    "faf_frame_hidden_fwd": (c_int32, [c_void_p] * 3 + [c_int64] + [c_void_p] * 4 + [c_int64, c_float, c_void_p, c_float,
+                                                                                   c_void_p, c_void_p]),
     "faf_frame_hidden_bwd_workspace_bytes": (c_size_t, [c_int64]),
-    "faf_frame_hidden_bwd": (c_int32, [c_void_p] * 3 + [c_int64, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_float]
-                             + [c_void_p] * 5 + [c_int32, c_void_p, c_size_t, c_void_p]),
+    "faf_frame_hidden_bwd": (c_int32, [c_void_p] * 3 + [c_int64] + [c_void_p] * 4 + [c_int64, c_float, c_void_p, c_float]
+                             + [c_void_p] * 7 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "faf_rowdot_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "faf_rowdot_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "faf_rowdot_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_size_t,

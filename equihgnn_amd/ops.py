@@ -1718,55 +1718,66 @@ class _FramePre(torch.autograd.Function):
 
 class _FrameHidden(torch.autograd.Function):
     """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = w3 (y * s_f) + base over the 8 sign frames: frame_pre, swiglu_dropout
-    and the row LayerNorm in one launch each way (faf_frame_hidden_*); the [.., 8, 256] pre-activations never exist."""
+    and the row LayerNorm in one launch each way (faf_frame_hidden_*); the [.., 8, 256] pre-activations never exist.
+    ``base``: rows [..., 256], or (vector form) fc1's bias [256] with the optional K = 1 Linear extra [..., 1] * wx [256]
+    evaluated inside the kernel."""
 
     @staticmethod
-    def forward(ctx, y, w3, base, gamma, beta, eps, p, seed, acc_params):
+    def forward(ctx, y, w3, base, extra, wx, gamma, beta, eps, p, seed, acc_params):
         _require_gpu(y, "frame_hidden")
         lead = y.shape[:-1]
         y2, w3c, gamma, beta = _f32c(y).reshape(-1, 3), _f32c(w3), _f32c(gamma), _f32c(beta)
         if w3c.shape[0] != 256 or gamma.numel() != 128:
             raise ValueError("frame_hidden: fc1 with 256 outputs expected")
         E = y2.shape[0]
-        if base.dim() == 1:
+        vec = base.dim() == 1
+        if vec:
             base2, ld = _f32c(base), 0
+            wxc = _f32c(wx) if wx is not None else torch.zeros(256, dtype=torch.float32, device=y.device)
+            ex = _f32c(extra).reshape(-1) if extra is not None else None
+            if ex is not None and ex.shape[0] != E:
+                raise ValueError("frame_hidden: one extra value per point expected")
         else:
-            base2, ld = _f32c(base).reshape(-1, 256), 256
+            base2, ld, wxc, ex = _f32c(base).reshape(-1, 256), 256, None, None
             if base2.shape[0] != E:
                 raise ValueError("frame_hidden: one base row per point expected")
         seed = seed if (seed is not None and p > 0) else _dropout_seed(y.device, p)
         out = torch.empty((E, 8, 128), dtype=torch.float32, device=y.device)
-        hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(gamma), _ptr(beta), E, float(p),
-                                                 _ptr(seed), float(eps), _ptr(out), _stream(y.device)), "faf_frame_hidden_fwd")
-        ctx.save_for_backward(y2, w3c, base2, gamma)
-        ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape))
+        hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma), _ptr(beta),
+                                                 E, float(p), _ptr(seed), float(eps), _ptr(out), _stream(y.device)),
+                  "faf_frame_hidden_fwd")
+        ctx.save_for_backward(y2, w3c, base2, gamma, ex, wxc)
+        ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape), None if extra is None else tuple(extra.shape),
+                    wx is not None)
         ctx.acc = acc_params
         return out.view(*lead, 8, 128)
 
     @staticmethod
     def backward(ctx, dhn):
-        y2, w3c, base2, gamma = ctx.saved_tensors
-        lead, ld, eps, p, seed, base_shape = ctx.meta
+        y2, w3c, base2, gamma, ex, wxc = ctx.saved_tensors
+        lead, ld, eps, p, seed, base_shape, extra_shape, has_wx = ctx.meta
         E = y2.shape[0]
         dev = y2.device
+        vec = wxc is not None
         dhn = _f32c(dhn).reshape(E, 8, 128)
         dy = torch.empty_like(y2)
-        dbase = torch.empty((E, 256), dtype=torch.float32, device=dev)
+        dbase = torch.empty((256,) if vec else (E, 256), dtype=torch.float32, device=dev)
+        dwx = torch.empty(256, dtype=torch.float32, device=dev) if vec else None
+        dex = torch.empty(E, dtype=torch.float32, device=dev) if ex is not None else None
         dw3 = torch.empty_like(w3c)
         L = hip.lib()
         ws_bytes = L.faf_frame_hidden_bwd_workspace_bytes(E)
         ws = _workspace(max(ws_bytes, 16), dev)
         tg = [_acc_target(q) for q in ctx.acc]            # (gamma, beta)
         small = torch.empty((2, 128), dtype=torch.float32, device=dev)
-        hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(gamma), _ptr(dhn), E, p, _ptr(seed), eps,
-                                         _ptr(dy), _ptr(dbase), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, _ptr(ws), ws_bytes,
-                                         _stream(dev)), "faf_frame_hidden_bwd")
+        hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma), _ptr(dhn), E, p,
+                                         _ptr(seed), eps, _ptr(dy), _ptr(dbase), _ptr(dwx), _ptr(dex), _ptr(dw3), _ptr(small[0]),
+                                         _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(dev)), "faf_frame_hidden_bwd")
         dgam, dbet = _hand_out(list(small), tg)
-        if ld == 0:
-            dbase = colsum(dbase)
-        else:
+        if not vec:
             dbase = dbase.view(base_shape)
-        return dy.view(*lead, 3), dw3, dbase, dgam, dbet, None, None, None, None
+        return (dy.view(*lead, 3), dw3, dbase, None if dex is None else dex.view(extra_shape), dwx if has_wx else None,
+                dgam, dbet, None, None, None, None)
 
 
 class _RowDot(torch.autograd.Function):
@@ -1917,11 +1928,12 @@ def frame_pre(y, w3, base):
     return _FramePre.apply(y, w3, base)
 
 
-def frame_hidden(y, w3, base, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None):
+def frame_hidden(y, w3, base, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None, extra=None, wx=None):
     """LayerNorm(dropout_p(SiLU(a) * b)) with [a | b] = w3 (y * s_f) + base over the 8 sign frames of y [..., 3] ->
-    [..., 8, 128]; w3 [256, 3], base [..., 256] or [256], gamma / beta [128] (the PARAMETERS)."""
+    [..., 8, 128]; w3 [256, 3], gamma / beta [128] (the PARAMETERS).  ``base``: rows [..., 256]; or fc1's bias [256], then
+    the row of a point is bias + extra * wx (extra [..., 1], wx [256] = fc1.weight[:, 3]; both optional)."""
     _note_acc(gamma, beta)
-    return _FrameHidden.apply(y, w3, base, gamma, beta, eps, p, seed, (gamma, beta))
+    return _FrameHidden.apply(y, w3, base, extra, wx, gamma, beta, eps, p, seed, (gamma, beta))
 
 
 def swiglu_dropout(pre, p: float = 0.0, seed=None):

@@ -464,13 +464,16 @@ int faf_frame_pre_bwd(const float* y, const float* w3, const float* dpre, int64_
  * = faf_frame_pre_fwd + faf_swiglu_dropout_fwd + hg_layer_norm_fwd without the [E * 8, 256] and [E * 8, 128]
  * intermediates (same dropout hash over the [E * 8, 128] tensor as faf_swiglu_dropout_*).  base: [E, 256] (base_ld 256)
  * or one row broadcast (base_ld 0).  bwd: dy [E, 3], dbase [E, 256], dw3 [256, 3], dgamma / dbeta [128]. */
-int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
-                         const float* beta, int64_t E, float p, const int64_t* seed, float eps, float* out, void* stream);
+int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
+                         const float* wx, const float* gamma, const float* beta, int64_t E, float p, const int64_t* seed,
+                         float eps, float* out, void* stream);
 size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E);
-int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* gamma,
-                         const float* dhn, int64_t E, float p, const int64_t* seed, float eps, float* dy, float* dbase,
-                         float* dw3, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
-                         size_t workspace_bytes, void* stream);
+/* vector form (wx != NULL; base = fc1's bias vector, base_ld 0; the point's row is bias + extra[e] * wx, extra may be
+ * NULL): dbase receives d bias [256], dwx d wx [256], dextra [E] the gradient of extra; row form: dbase [E, 256]. */
+int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
+                         const float* wx, const float* gamma, const float* dhn, int64_t E, float p, const int64_t* seed,
+                         float eps, float* dy, float* dbase, float* dwx, float* dextra, float* dw3, float* dgamma,
+                         float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Row-wise dot products -- nn.Linear(C, J) with J <= 4 outputs on edge rows (fa_former_layer.py:340-400 att_mlp,
  * :483-489 the per-head edge logits): y [R, J] = x [R, C] . U [J, C]^T + bias [J] (may be NULL), a wavefront per row.

@@ -1072,7 +1072,8 @@ def test_faformer_elementwise_kernels():
                                atol=1e-7, rtol=1e-6)
 
 
-@pytest.mark.parametrize("E,p,bcast", [(37, 0.0, False), (1000, 0.1, False), (300, 0.1, True), (5, 0.0, True)])
+@pytest.mark.parametrize("E,p,bcast", [(37, 0.0, False), (1000, 0.1, False), (300, 0.1, True), (5, 0.0, True),
+                                       (700, 0.1, "extra"), (33, 0.0, "extra")])
 def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):
     """faf_frame_hidden_fwd / _bwd = frame_pre -> swiglu_dropout -> LayerNorm rows in one launch each way, with the SAME
     dropout decisions (same hash, same seed): outputs and all five gradients against the unfused composition, and with
@@ -1085,6 +1086,21 @@ def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):
     gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
     wgt = torch.randn(E, 8, 128, generator=g)
     seed = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    if bcast == "extra":     # the vector form: row of point e = bias + extra[e] * wx, formed inside the kernel
+        extra, wx = torch.rand(E, 1, generator=g) * 4, 0.3 * torch.randn(256, generator=g)
+        d = [t.to(DEV).requires_grad_(True) for t in (y, w3, base, gamma, beta, extra, wx)]
+        out = ops.frame_hidden(d[0], d[1], d[2], d[3], d[4], 1e-5, p, seed, d[5], d[6])
+        (out * wgt.to(DEV)).sum().backward()
+        u = [t.to(DEV).requires_grad_(True) for t in (y, w3, base, gamma, beta, extra, wx)]
+        rows = torch.addcmul(u[2], u[5], u[6])
+        pre = ops.frame_pre(u[0], u[1], rows)
+        ref = ops.layer_norm_rows(ops.swiglu_dropout(pre, p, seed).reshape(-1, 128), u[3], u[4], 1e-5).view(E, 8, 128)
+        (ref * wgt.to(DEV)).sum().backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-5, rtol=1e-5)
+        for name, a, b in zip(("dy", "dw3", "dbias", "dgamma", "dbeta", "dextra", "dwx"), d, u):
+            err = float((a.grad - b.grad).abs().max() / b.grad.abs().max().clamp(min=1e-9))
+            assert err < 5e-5, (name, err)
+        return
 
     def run(fused):
         d = [t.to(DEV).requires_grad_(True) for t in (y, w3, base, gamma, beta)]
