@@ -103,7 +103,7 @@ def seg_reduce_bytes(nnz, n_out, C, has_idx, has_ptr, has_w, n_src):
 
 
 SCATTER_KERNELS = ("k_segment_reduce", "k_segment_reduce<weighted>", "k_gather_ln_fwd", "k_gather_ln_bwd", "k_inc_fwd",
-                   "k_inc_bwd_both")
+                   "k_inc_fwd_col", "k_inc_bwd_both")
 
 
 def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
@@ -284,9 +284,9 @@ def measure_scatter_roofline(model, batch, dev):
 # HBM bytes per launch of k_segment_reduce from the PMC counters (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE), collected
 # with rocprofv3 on `python3 bench.py --only-roofline` at the BASELINE workload: profiles/r01_pmc_scatter_workload.json.
 # A bench run cannot collect counters itself; the figure is attached only to the workload it was measured on.
-PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 22633900}
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {("egnn_equihnns", 256, "qm9"): 23856754}
 PMC_TRAFFIC_SOURCE = ("profiles/r02_pmc_scatter_workload.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same "
-                      "12 scatter launches per step, 2 x FETCH + WRITE, offline)")
+                      "12 scatter launches per step -- k_gather_ln_fwd/bwd, k_inc_fwd_col, k_inc_bwd_both --, 2 x FETCH + WRITE, offline)")
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak

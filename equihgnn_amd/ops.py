@@ -531,7 +531,7 @@ class _IncidenceLnReduce(torch.autograd.Function):
         work = 4 * C * (2 * out_csr.nnz + out_csr.n_rows) + 12 * out_csr.nnz + 4 * (out_csr.n_rows + 1) + 8 * C
         if okey32 is ia32 or okey32 is ib32:
             # the output row is one operand's own index: (rowptr, col) of the output CSR says it all
-            timed("k_inc_fwd", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(
+            timed("k_inc_fwd_col", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(
                 _ptr(pa), _ptr(qb), _ptr(out_csr.rowptr), _ptr(out_csr.col), 1 if okey32 is ia32 else 0, _ptr(gamma),
                 _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
                 "hg_incidence_ln_reduce_fwd_col"))
