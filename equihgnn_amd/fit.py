@@ -26,6 +26,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+import contextlib
 import queue
 import threading
 
@@ -155,16 +156,26 @@ class BucketedLoader:
         ring = self._ring               # (pinning host memory costs milliseconds per buffer: allocate once per shape)
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
 
+        cuda = self.device is not None and torch.device(self.device).type == "cuda"
+        side = None
+        if cuda:    # host-to-device copies are issued by the prefetch thread on a stream of their own: they overlap the
+            #         previous step's kernels and leave the training thread one stream-wait per batch
+            side = self._side = getattr(self, "_side", None) or torch.cuda.Stream(self.device)
+
         def stage(n_mols):
-            """a free staging buffer for a batch of n_mols molecules (ring of prefetch + 2 per shape)"""
+            """a free staging pair (pinned host buffer, device buffer) for a batch of n_mols molecules (ring of
+            prefetch + 3 per shape): [host, h2d_done, device, consumed]"""
             slot = ring.setdefault((tgt, n_mols), {"bufs": [], "next": 0})
-            if len(slot["bufs"]) < self.prefetch + 2:
-                slot["bufs"].append([HBatch.empty_packed(tgt[0], tgt[1], tgt[2], n_mols + 1, pin=self.pin), None])
+            if len(slot["bufs"]) < self.prefetch + 3:
+                host = HBatch.empty_packed(tgt[0], tgt[1], tgt[2], n_mols + 1, pin=self.pin)
+                with torch.cuda.stream(side) if cuda else contextlib.nullcontext():
+                    devb = host.to(self.device) if cuda else None
+                slot["bufs"].append([host, None, devb, None])
                 return slot["bufs"][-1]
             ent = slot["bufs"][slot["next"] % len(slot["bufs"])]
             slot["next"] += 1
             if ent[1] is not None:
-                ent[1].synchronize()          # its previous host-to-device copy has finished
+                ent[1].synchronize()          # its previous host-to-device copy has finished (the host buffer is free)
             return ent
 
         def produce():
@@ -175,26 +186,39 @@ class BucketedLoader:
                     self.store.collate(b, pad_to=tgt, out=ent[0])
                     self.collate_seconds += time.perf_counter() - t0
                     self.collated += len(b)
+                    if cuda:
+                        with torch.cuda.stream(side):
+                            if ent[3] is not None:
+                                side.wait_event(ent[3])      # the trainer has taken the device buffer's previous content
+                            ent[2]._flat.copy_(ent[0]._flat, non_blocking=True)
+                            ent[2].num_real_graphs = getattr(ent[0], "num_real_graphs", None)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            ent[1] = ev
                     q.put(ent)
             finally:
                 q.put(None)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
+        prev = None
         while True:
             ent = q.get()
-            if ent is None:
-                break
-            host = ent[0]
-            if self.device is None:
-                yield host
-                continue
-            dev = host.to(self.device, non_blocking=True)
-            if torch.device(self.device).type == "cuda":
+            if prev is not None and cuda:     # whatever the consumer enqueued for the previous batch reads it before this point
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(self.device))
-                ent[1] = ev
-            yield dev
+                prev[3] = ev
+            if ent is None:
+                break
+            if self.device is None:
+                yield ent[0]
+                continue
+            if not cuda:
+                yield ent[0].to(self.device)
+                continue
+            torch.cuda.current_stream(self.device).wait_event(ent[1])
+            prev = ent
+            yield ent[2]
         th.join()
 
 
