@@ -1027,3 +1027,181 @@ extern "C" int faf_gate_bwd(const float* x, const float* w, const float* b, cons
                                        stream);
     });
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Hidden layer of EdgeModule's edge MLP (fa_former_layer.py:340-400 with :241-289) on the kNN edges:
+//   hn[i, k, :] = LayerNorm( dropout( SiLU(a) * b ) ),   [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k]          (256 -> 128)
+// with the first Linear of the MLP split by input block (layers of faformer.py): A = W_tok_i tok + bias and B = W_tok_j tok
+// at node level, Cf = W_feat feats per edge.  As separate launches: a row gather, two broadcast adds, the SwiGLU pass and
+// the row LayerNorm (five [16N, 256] tensors forward, as many backward).  Here a wavefront walks the K edges of a node:
+// A[i] once, B rows gathered directly, lane = two hidden units as in k_frame_hidden; the backward recomputes the forward,
+// writes d pre (the gradient of Cf, and of B through the transposed kNN CSR) and sums d A[i] over the node's edges in
+// registers.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct EhRow { float2 a, b; };   // this lane's two a-channels and two b-channels of a 256-wide row
+
+__device__ __forceinline__ EhRow eh_load(const float* __restrict__ row, int lane) {
+    EhRow r;
+    r.a = *reinterpret_cast<const float2*>(row + 2 * lane);
+    r.b = *reinterpret_cast<const float2*>(row + 128 + 2 * lane);
+    return r;
+}
+
+__global__ void __launch_bounds__(FP_THREADS)
+k_edge_hidden_fwd(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cf,
+                  const int* __restrict__ nbr, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t N, int K,
+                  const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps, float* __restrict__ out) {
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g0 = gamma[2 * lane], g1 = gamma[2 * lane + 1], be0 = beta[2 * lane], be1 = beta[2 * lane + 1];
+    for (int64_t i = (int64_t)blockIdx.x * FP_WAVES + wave; i < N; i += (int64_t)gridDim.x * FP_WAVES) {
+        const EhRow ra = eh_load(A + i * 256, lane);
+        const int my_j = (lane < K) ? nbr[i * K + lane] : 0;
+        EhRow nb = eh_load(B + (int64_t)__builtin_amdgcn_readlane(my_j, 0) * 256, lane);
+        EhRow nc = eh_load(Cf + (i * K) * 256, lane);
+        for (int k = 0; k < K; ++k) {
+            const EhRow rb = nb, rc = nc;
+            const int kn = (k + 1 < K) ? k + 1 : k;
+            nb = eh_load(B + (int64_t)__builtin_amdgcn_readlane(my_j, kn) * 256, lane);
+            nc = eh_load(Cf + (i * K + kn) * 256, lane);
+            const float a0 = (ra.a.x + rb.a.x) + rc.a.x, a1 = (ra.a.y + rb.a.y) + rc.a.y;
+            const float b0 = (ra.b.x + rb.b.x) + rc.b.x, b1 = (ra.b.y + rb.b.y) + rc.b.y;
+            float h0 = a0 * sigmoid_fast(a0) * b0, h1 = a1 * sigmoid_fast(a1) * b1;
+            const int64_t r = i * K + k;
+            if (threshold) {
+                const uint64_t idx = (uint64_t)(r * 128 + 2 * lane);
+                h0 *= keep_scale(seed, idx, threshold, inv_keep);
+                h1 *= keep_scale(seed, idx + 1, threshold, inv_keep);
+            }
+            const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);
+            const float d0 = h0 - mu, d1 = h1 - mu;
+            const float rstd = 1.0f / sqrtf(fp_wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f) + eps);
+            *reinterpret_cast<float2*>(out + r * 128 + 2 * lane) = make_float2(fmaf(g0, d0 * rstd, be0), fmaf(g1, d1 * rstd, be1));
+        }
+    }
+}
+
+// slab per workgroup: [d gamma (128) | d beta (128)]
+__global__ void __launch_bounds__(FP_THREADS)
+k_edge_hidden_bwd(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cf,
+                  const int* __restrict__ nbr, const float* __restrict__ gamma, const float* __restrict__ dhn, int64_t N, int K,
+                  const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
+                  float* __restrict__ dpre, float* __restrict__ dA, float* __restrict__ slab) {
+    __shared__ float s_red[FP_WAVES][4][64];
+    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float g0 = gamma[2 * lane], g1 = gamma[2 * lane + 1];
+    float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * FP_WAVES + wave; i < N; i += (int64_t)gridDim.x * FP_WAVES) {
+        const EhRow ra = eh_load(A + i * 256, lane);
+        const int my_j = (lane < K) ? nbr[i * K + lane] : 0;
+        EhRow nb = eh_load(B + (int64_t)__builtin_amdgcn_readlane(my_j, 0) * 256, lane);
+        EhRow nc = eh_load(Cf + (i * K) * 256, lane);
+        float2 ng = *reinterpret_cast<const float2*>(dhn + (i * K) * 128 + 2 * lane);
+        float sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f;      // d A[i] = sum over the node's edges of d pre
+        for (int k = 0; k < K; ++k) {
+            const EhRow rb = nb, rc = nc;
+            const float2 g = ng;
+            const int kn = (k + 1 < K) ? k + 1 : k;
+            nb = eh_load(B + (int64_t)__builtin_amdgcn_readlane(my_j, kn) * 256, lane);
+            nc = eh_load(Cf + (i * K + kn) * 256, lane);
+            ng = *reinterpret_cast<const float2*>(dhn + (i * K + kn) * 128 + 2 * lane);
+            const float a0 = (ra.a.x + rb.a.x) + rc.a.x, a1 = (ra.a.y + rb.a.y) + rc.a.y;
+            const float b0 = (ra.b.x + rb.b.x) + rc.b.x, b1 = (ra.b.y + rb.b.y) + rc.b.y;
+            const float sg0 = sigmoid_fast(a0), sg1 = sigmoid_fast(a1);
+            const float s0 = a0 * sg0, s1 = a1 * sg1;
+            const int64_t r = i * K + k;
+            float k0 = 1.f, k1 = 1.f;
+            if (threshold) {
+                const uint64_t idx = (uint64_t)(r * 128 + 2 * lane);
+                k0 = keep_scale(seed, idx, threshold, inv_keep);
+                k1 = keep_scale(seed, idx + 1, threshold, inv_keep);
+            }
+            const float h0 = s0 * b0 * k0, h1 = s1 * b1 * k1;
+            const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);
+            const float d0 = h0 - mu, d1 = h1 - mu;
+            const float rstd = 1.0f / sqrtf(fp_wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f) + eps);
+            const float x0 = d0 * rstd, x1 = d1 * rstd;
+            ab0 += g.x; ab1 += g.y;
+            ag0 = fmaf(g.x, x0, ag0); ag1 = fmaf(g.y, x1, ag1);
+            const float q0 = g.x * g0, q1 = g.y * g1;
+            const float m1 = fp_wave_sum(q0 + q1) * (1.0f / 128.0f);
+            const float m2 = fp_wave_sum(q0 * x0 + q1 * x1) * (1.0f / 128.0f);
+            const float dh0 = rstd * (q0 - m1 - x0 * m2) * k0, dh1 = rstd * (q1 - m1 - x1 * m2) * k1;
+            const float da0 = dh0 * b0 * fmaf(s0, 1.0f - sg0, sg0), da1 = dh1 * b1 * fmaf(s1, 1.0f - sg1, sg1);
+            const float db0 = dh0 * s0, db1 = dh1 * s1;
+            *reinterpret_cast<float2*>(dpre + r * 256 + 2 * lane) = make_float2(da0, da1);
+            *reinterpret_cast<float2*>(dpre + r * 256 + 128 + 2 * lane) = make_float2(db0, db1);
+            sa0 += da0; sa1 += da1; sb0 += db0; sb1 += db1;
+        }
+        *reinterpret_cast<float2*>(dA + i * 256 + 2 * lane) = make_float2(sa0, sa1);
+        *reinterpret_cast<float2*>(dA + i * 256 + 128 + 2 * lane) = make_float2(sb0, sb1);
+    }
+    s_red[wave][0][lane] = ag0; s_red[wave][1][lane] = ag1; s_red[wave][2][lane] = ab0; s_red[wave][3][lane] = ab1;
+    __syncthreads();
+    if (wave == 0) {
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t[q] = s_red[0][q][lane];
+            for (int w = 1; w < FP_WAVES; ++w) t[q] += s_red[w][q][lane];
+        }
+        float* __restrict__ sl = slab + (int64_t)blockIdx.x * 256;
+        sl[2 * lane] = t[0]; sl[2 * lane + 1] = t[1];
+        sl[128 + 2 * lane] = t[2]; sl[128 + 2 * lane + 1] = t[3];
+    }
+}
+
+inline int eh_blocks(int64_t N) { return eqh_grid_for(N, FP_WAVES, 1024); }
+
+}  // namespace
+
+extern "C" int faf_edge_hidden_fwd(const float* A, const float* B, const float* Cf, const int32_t* nbr, const float* gamma,
+                                   const float* beta, int64_t N, int32_t K, float p, const int64_t* seed, float eps, float* out,
+                                   void* stream_) {
+    if (N < 0 || K < 1 || K > 64 || !(p >= 0.f) || !(p < 1.f)) return EQH_ERR_ARG;
+    if (N == 0) return EQH_OK;
+    if (!A || !B || !Cf || !nbr || !gamma || !beta || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 7) || (reinterpret_cast<uintptr_t>(B) & 7) || (reinterpret_cast<uintptr_t>(Cf) & 7) ||
+        (reinterpret_cast<uintptr_t>(out) & 7))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    hipLaunchKernelGGL(k_edge_hidden_fwd, dim3(eqh_grid_for(N, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, A, B, Cf, nbr, gamma,
+                       beta, N, (int)K, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" size_t faf_edge_hidden_bwd_workspace_bytes(int64_t N) {
+    if (N <= 0) return 0;
+    return (size_t)eh_blocks(N) * 256 * sizeof(float);
+}
+
+/* dpre [N * K, 256] (the gradient of Cf; reduce it over the transposed neighbour CSR for d B), dA [N, 256],
+   dgamma / dbeta [128] (overwritten or accumulated) */
+extern "C" int faf_edge_hidden_bwd(const float* A, const float* B, const float* Cf, const int32_t* nbr, const float* gamma,
+                                   const float* dhn, int64_t N, int32_t K, float p, const int64_t* seed, float eps, float* dpre,
+                                   float* dA, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                                   size_t workspace_bytes, void* stream_) {
+    if (N < 0 || K < 1 || K > 64 || !(p >= 0.f) || !(p < 1.f) || !dgamma || !dbeta) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (N == 0) {
+        if (accumulate) return EQH_OK;
+        if (eqh_zero_async(dgamma, 128, stream)) return EQH_ERR_LAUNCH;
+        return eqh_zero_async(dbeta, 128, stream);
+    }
+    if (!A || !B || !Cf || !nbr || !gamma || !dhn || !dpre || !dA || !workspace || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 7) || (reinterpret_cast<uintptr_t>(B) & 7) || (reinterpret_cast<uintptr_t>(Cf) & 7) ||
+        (reinterpret_cast<uintptr_t>(dhn) & 7) || (reinterpret_cast<uintptr_t>(dpre) & 7) || (reinterpret_cast<uintptr_t>(dA) & 7) ||
+        !eqh_aligned16(workspace))
+        return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_edge_hidden_bwd_workspace_bytes(N)) return EQH_ERR_ARG;
+    const int blocks = eh_blocks(N);
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_edge_hidden_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, A, B, Cf, nbr, gamma, dhn, N, (int)K, seed,
+                       ew_threshold(p), 1.0f / (1.0f - p), eps, dpre, dA, slab);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs3_async(slab, blocks, 256, dgamma, dbeta, nullptr, 128, 128, accumulate, stream);
+}

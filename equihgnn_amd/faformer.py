@@ -43,6 +43,7 @@ def _layer_norm(mod: nn.LayerNorm, x):
     return mod(x)
 
 
+FUSE_EDGE_HIDDEN = True     # EdgeModule: gather + adds + SwiGLU + dropout + LayerNorm of the edge MLP's hidden layer in one launch
 FUSE_FRAME_HIDDEN = True    # SwiGLUMLP.frame_mean: one launch for the hidden layer over the 8 sign frames (ops.frame_hidden)
 
 
@@ -175,9 +176,17 @@ class EdgeModule(nn.Module):
         # edge_mlp's first Linear split by input block: token_i / token_j parts at node level
         w, d = self.edge_mlp.fc1.weight, self.d
         lin = ops.linear if tok.is_cuda else (lambda x, w_, b_=None, cols=None: F.linear(x, w_[:, cols[0]:cols[1]], b_))
-        pre = (lin(tok, w, self.edge_mlp.fc1.bias, cols=(0, d)).unsqueeze(1)
-               + g.gather(lin(tok, w, None, cols=(d, 2 * d))) + lin(feats, w, None, cols=(2 * d, w.shape[1])))
-        pair = self.edge_mlp._fc2(self.edge_mlp.hidden(pre))
+        a_i = lin(tok, w, self.edge_mlp.fc1.bias, cols=(0, d))             # [N, H]  receiver part (+ bias)
+        b_j = lin(tok, w, None, cols=(d, 2 * d))                           # [N, H]  sender part, gathered per edge
+        c_ij = lin(feats, w, None, cols=(2 * d, w.shape[1]))               # [N, K, H]
+        mlp = self.edge_mlp
+        if tok.is_cuda and tok.dtype == torch.float32 and w.shape[0] == 256 and FUSE_EDGE_HIDDEN:
+            # gather + the two adds + SwiGLU + dropout + LayerNorm in one launch each way (csrc/faformer_ew.hip)
+            hid = ops.edge_hidden(a_i, b_j, c_ij, g.nbr, g.csr_t, mlp.norm.weight, mlp.norm.bias, mlp.norm.eps,
+                                  mlp.p if self.training else 0.0)
+        else:
+            hid = mlp.hidden(a_i.unsqueeze(1) + g.gather(b_j) + c_ij)
+        pair = mlp._fc2(hid)
         # att_mlp = Linear(d, 1) + Sigmoid on ~250 k edge rows: a row-wise dot product -- as a GEMM with ONE output column the
         # library needs 2 ms for it.  The dropout in front of it, the dot product, the gate and the residual add behind it
         # are one pass each way (ops.gate_rows, csrc/faformer_ew.hip)

@@ -1780,6 +1780,58 @@ class _FrameHidden(torch.autograd.Function):
                 dgam, dbet, None, None, None, None)
 
 
+class _EdgeHidden(torch.autograd.Function):
+    """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k] on the kNN edges, one launch each way
+    (faf_edge_hidden_*): the gathered / summed [N, K, 256] pre-activations and the [N, K, 128] gated values never exist."""
+
+    @staticmethod
+    def forward(ctx, A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, acc_params):
+        _require_gpu(A, "edge_hidden")
+        A, B, gamma, beta = _f32c(A), _f32c(B), _f32c(gamma), _f32c(beta)
+        N, K = nbr.shape
+        Cf2 = _f32c(Cf).reshape(N * K, 256)
+        if A.shape != (N, 256) or B.shape != (N, 256) or gamma.numel() != 128 or nbr.dtype != torch.int32:
+            raise ValueError("edge_hidden: A, B [N, 256], Cf [N * K, 256], nbr int32 [N, K], gamma [128] expected")
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(A.device, p)
+        out = torch.empty((N, K, 128), dtype=torch.float32, device=A.device)
+        hip.check(hip.lib().faf_edge_hidden_fwd(_ptr(A), _ptr(B), _ptr(Cf2), _ptr(nbr), _ptr(gamma), _ptr(beta), N, K, float(p),
+                                                _ptr(seed), float(eps), _ptr(out), _stream(A.device)), "faf_edge_hidden_fwd")
+        ctx.save_for_backward(A, B, Cf2, gamma)
+        ctx.meta = (nbr, csr_t, float(eps), float(p), seed, Cf.shape)
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dhn):
+        A, B, Cf2, gamma = ctx.saved_tensors
+        nbr, csr_t, eps, p, seed, cf_shape = ctx.meta
+        N, K = nbr.shape
+        dev = A.device
+        dhn = _f32c(dhn).reshape(N * K, 128)
+        dpre = torch.empty_like(Cf2)
+        dA = torch.empty_like(A)
+        L = hip.lib()
+        ws_bytes = L.faf_edge_hidden_bwd_workspace_bytes(N)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(q) for q in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty((2, 128), dtype=torch.float32, device=dev)
+        o = tg if acc else list(small)
+        hip.check(L.faf_edge_hidden_bwd(_ptr(A), _ptr(B), _ptr(Cf2), _ptr(nbr), _ptr(gamma), _ptr(dhn), N, K, p, _ptr(seed), eps,
+                                        _ptr(dpre), _ptr(dA), _ptr(o[0]), _ptr(o[1]), 1 if acc else 0, _ptr(ws), ws_bytes,
+                                        _stream(dev)), "faf_edge_hidden_bwd")
+        dB = _segment_reduce(dpre, csr_t.perm, csr_t.rowptr, None, csr_t.n_rows, False)     # rows of d pre by sender
+        dgam, dbet = (None, None) if acc else _hand_out(list(small), tg)
+        return dA, dB, dpre.view(cf_shape), None, None, dgam, dbet, None, None, None, None
+
+
+def edge_hidden(A, B, Cf, nbr, csr_t: CSR, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None):
+    """LayerNorm(dropout_p(SiLU(a) * b)) with [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k]: A, B [N, 256], Cf [N, K, 256], nbr int32
+    [N, K], csr_t the transposed neighbour CSR (rows = senders), gamma / beta [128] (the PARAMETERS) -> [N, K, 128]."""
+    _note_acc(gamma, beta)
+    return _EdgeHidden.apply(A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, (gamma, beta))
+
+
 class _RowDot(torch.autograd.Function):
     """y = x @ U.T + bias for a FEW output columns (J <= 4), one pass over x each way (faf_rowdot_*).  With
     ``passthrough`` the node also returns x itself for x's OTHER consumer, and the backward adds that consumer's gradient

@@ -494,6 +494,18 @@ int faf_gate_bwd(const float* x, const float* w, const float* b, const float* do
                  const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, void* workspace,
                  size_t workspace_bytes, void* stream);
 
+/* Hidden layer of EdgeModule's edge MLP on the kNN edges (fa_former_layer.py:340-400 with :241-289), first Linear split by
+ * input block:  hn[i, k, :] = LayerNorm(dropout_p(SiLU(a) * b)),  [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k]  (256 -> 128).
+ * One launch each way instead of gather + two adds + SwiGLU + LayerNorm.  bwd: dpre [N * K, 256] (= d Cf; d B is its
+ * reduction over the transposed neighbour CSR), dA [N, 256], dgamma / dbeta [128]. */
+int faf_edge_hidden_fwd(const float* A, const float* B, const float* Cf, const int32_t* nbr, const float* gamma,
+                        const float* beta, int64_t N, int32_t K, float p, const int64_t* seed, float eps, float* out,
+                        void* stream);
+size_t faf_edge_hidden_bwd_workspace_bytes(int64_t N);
+int faf_edge_hidden_bwd(const float* A, const float* B, const float* Cf, const int32_t* nbr, const float* gamma,
+                        const float* dhn, int64_t N, int32_t K, float p, const int64_t* seed, float eps, float* dpre, float* dA,
+                        float* dgamma, float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending

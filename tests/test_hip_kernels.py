@@ -1183,6 +1183,39 @@ def test_gate_rows_matches_float64(R, C, p, with_res):
         assert err < 3e-5, (name, err)
 
 
+@pytest.mark.parametrize("N,p", [(40, 0.0), (700, 0.1)])
+def test_edge_hidden_matches_the_unfused_composition(N, p):
+    """faf_edge_hidden_fwd / _bwd against gather_rows + adds + swiglu_dropout + LayerNorm rows (same dropout seed): output and
+    the gradients of A, B (through the transposed neighbour CSR), Cf, gamma, beta."""
+    ops = _ops()
+    K = 16
+    g = torch.Generator().manual_seed(N)
+    A, B, Cf = torch.randn(N, 256, generator=g), torch.randn(N, 256, generator=g), torch.randn(N, K, 256, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(128, generator=g), 0.3 * torch.randn(128, generator=g)
+    wgt = torch.randn(N, K, 128, generator=g)
+    pos = torch.randn(N, 3, generator=g).to(DEV)
+    nbr, _ = ops.knn(pos, K, 1)
+    csr_t = ops.csr_build(nbr.reshape(-1), None, N)
+    seed = torch.tensor([24680], dtype=torch.int64, device=DEV)
+
+    def run(fused):
+        d = [t.to(DEV).requires_grad_(True) for t in (A, B, Cf, gamma, beta)]
+        if fused:
+            out = ops.edge_hidden(d[0], d[1], d[2], nbr, csr_t, d[3], d[4], 1e-5, p, seed)
+        else:
+            pre = d[0].unsqueeze(1) + ops.gather_rows(d[1], nbr.reshape(-1), csr_t).view(N, K, 256) + d[2]
+            out = ops.layer_norm_rows(ops.swiglu_dropout(pre, p, seed).reshape(-1, 128), d[3], d[4], 1e-5).view(N, K, 128)
+        (out * wgt.to(DEV)).sum().backward()
+        return out.detach().cpu(), [t.grad.cpu() for t in d]
+
+    of, gf = run(True)
+    ou, gu = run(False)
+    np.testing.assert_allclose(of.numpy(), ou.numpy(), atol=2e-5, rtol=1e-5)
+    for name, a, b in zip(("dA", "dB", "dCf", "dgamma", "dbeta"), gf, gu):
+        err = float((a - b).abs().max() / b.abs().max().clamp(min=1e-9))
+        assert err < 5e-5, (name, err)
+
+
 def test_frame_pre_matches_float64_reference():
     """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
     dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
