@@ -134,10 +134,14 @@ def _frame_axes(x, mask=None):
         center = (torch.where(keep, x, zero).to(acc).sum(1) / m.to(acc).sum(1).clamp(min=1.0)).to(x.dtype)  # (where, not *: masked rows may
         xc = x - center.unsqueeze(1) * m                                   #  hold anything; they keep raw x, :94)
         xm = torch.where(keep, xc, zero)
+    # the 3 x 3 products as broadcast multiply + sum: batched GEMMs of these shapes ([15 k x 3 x 16] . [15 k x 16 x 3], or one
+    # [3 x 15 k] . [15 k x 3] in float64) took 0.1-0.4 ms each in the library, 1.5 ms per step together
     with torch.no_grad():
         xa = xm.to(acc)
-        vec = ops.eigh3(torch.bmm(xa.transpose(1, 2), xa).to(x.dtype))     # geo_eigh3 (csrc/eigh3.hip)
-    return torch.bmm(xc, vec), vec, center
+        cov = (xa.unsqueeze(-1) * xa.unsqueeze(-2)).sum(1)                 # [B, 3, 3] = X^T X
+        vec = ops.eigh3(cov.to(x.dtype))                                   # geo_eigh3 (csrc/eigh3.hip)
+    y = (xc.unsqueeze(-1) * vec.unsqueeze(1)).sum(-2)                      # [B, P, 3] = xc V
+    return y, vec, center
 
 
 class EdgeGraph:
@@ -249,7 +253,10 @@ class MLPAttnEdgeAggregation(nn.Module):
         else:
             le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c
         ve = ops.linear(xe, lin_e.weight, lin_e.bias, rows=(de, 2 * de))                      # value half only
-        gate = torch.sigmoid(self.W_gate(tok))
+        if ops.rowdot_supported(tok, 1):   # Linear(d, 1) on the atom rows: a row-wise dot product, not a one-column GEMM
+            gate = torch.sigmoid(ops.rowdot(tok, self.W_gate.weight, self.W_gate.bias))
+        else:
+            gate = torch.sigmoid(self.W_gate(tok))
         logits = a_q.unsqueeze(1) + ak_n + le
         logits = logits.masked_fill(~g.mask.unsqueeze(-1), -1e9)
         attn = F.dropout(logits.transpose(1, 2).softmax(-1), self.attn_drop, self.training)  # [N,h,K]
