@@ -126,7 +126,7 @@ def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
     host = synth_batch(batch_size, seed, flavour)
     b = pad_batch(host, *bucket_sizes(host.num_nodes, host.num_hyperedges, host.nnz)).packed().to(dev)
     b.num_real_graphs = batch_size
-    tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
+    tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd, collective=False)   # rank-local: the other ranks wait
     tr.step(b)                                   # eager bootstrap
     tl = ops.Timeline(dev)
     ops.TIMELINE = tl

@@ -153,8 +153,11 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
-                 broadcast_from_rank0: bool = True):
+                 broadcast_from_rank0: bool = True, collective: bool = True):
+        """``collective=False``: a rank-local trainer inside a multi-rank job (no broadcast, no all-reduce) -- what a
+        measurement on ONE rank needs while the other ranks wait at a barrier."""
         self.model, self.lr, self.wd = model, lr, weight_decay
+        self.collective = collective
         self.live = None
         self.opt = None
         self.slots = {}
@@ -166,14 +169,17 @@ class GraphedTrainStep:
         self.other_slots = []
         self.n_w = 0
         self.fused_head = "head" in inspect.signature(model.forward).parameters
-        self._has_buffers = _world() > 1 and any(True for _ in model.buffers())
+        self._has_buffers = self._w() > 1 and any(True for _ in model.buffers())
         for mod in model.modules():   # padded (null) incidences would enter the batch statistics of a per-incidence norm
             if type(mod).__name__ == "MLP" and any(isinstance(n, nn.BatchNorm1d) for n in mod.normalizations):
                 raise NotImplementedError("GraphedTrainStep pads batches to static shapes; BatchNorm inside the "
                                           "per-incidence MLPs (--normalization bn) would count the padding -- use TrainStep")
-        if broadcast_from_rank0 and _world() > 1:
+        if broadcast_from_rank0 and self._w() > 1:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
+
+    def _w(self) -> int:
+        return _world() if self.collective else 1
 
     def close(self):
         """Detach this trainer from the model: the persistent gradient accumulators the kernels add into
@@ -197,7 +203,7 @@ class GraphedTrainStep:
 
     def sync_buffers(self):
         """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics)."""
-        if _world() > 1:
+        if self._w() > 1:
             for b in self.model.buffers():
                 dist.broadcast(b.data, src=0)
 
@@ -327,14 +333,14 @@ class GraphedTrainStep:
         loss = self._fwd_bwd(data)
         # Adam is elementwise: one update over the flat tensor equals the per-parameter updates
         self.opt = FlatAdam(self.pflat, lr=self.lr, weight_decay=self.wd)
-        if _world() > 1:
+        if self._w() > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
-            self.opt.grad_scale = 1.0 / _world()     # the average is folded into the update
+            self.opt.grad_scale = 1.0 / self._w()     # the average is folded into the update
         self.opt.step()
         return loss.detach()
 
     def _capture(self, static):
-        world = _world()
+        world = self._w()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snap = self._buffer_snapshot()

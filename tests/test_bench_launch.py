@@ -49,6 +49,17 @@ def test_launcher_starts_two_ranks_gloo_on_one_device():
 
 
 @pytest.mark.gpu
+def test_two_ranks_with_the_roofline_measurement():
+    """The in-graph roofline measurement runs on rank 0 alone while the other ranks wait at the final barrier: its trainer
+    must be rank-local (GraphedTrainStep(collective=False)) -- a collective there has no partner and the job hangs."""
+    args = [a for a in SMALL if a != "--no-roofline"] + ["--timeline-replays", "2"]
+    r = _bench(["--gpus", "2"] + args, {"EQH_BACKEND": "gloo"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["roofline"]["launches_per_step"] == 12 and 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL)")
 def test_launcher_starts_two_ranks_rccl():
     r = _bench(["--gpus", "2"] + SMALL + ["--c4-steps", "2"])
