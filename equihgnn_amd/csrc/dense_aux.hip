@@ -290,3 +290,44 @@ extern "C" int egnn_pack_weights_bwd(const float* dw_cat, const float* db_cat, c
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched 2-D transposition with free strides: dst[b * dB + x * dX + y] = src[b * sB + y * sY + x] for x < nX, y < nY,
+// b < nB (the source is contiguous along x, the destination along y), and dst[b, x, y] = 0 for nY <= y < nY_pad.
+// Used for the radial network's last weight (equiformer_layer.py:451-479): nn.Linear(64, lo * li).weight is
+// [(lo, li), k]; the node-level GEMM of the re-associated tensor product wants [li, (k, lo_pad)] -- a 3-D permutation
+// of 16 MB at hidden 256 that torch's strided copy moves at 0.7 TB/s, every step, forward and (the gradient) backward.
+// A 64 x 64 tile goes through LDS so that both sides see 256-byte runs.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ void __launch_bounds__(256)
+k_permute_tiles(const float* __restrict__ src, float* __restrict__ dst, int nX, int nY, int nY_pad, int64_t sY, int64_t sB,
+                int64_t dX, int64_t dB) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+    for (int j = ty; j < 64; j += 4) {
+        const int x = x0 + tx, y = y0 + j;
+        tile[j][tx] = (x < nX && y < nY) ? src[(int64_t)b * sB + (int64_t)y * sY + x] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 64; j += 4) {
+        const int x = x0 + j, y = y0 + tx;
+        if (x < nX && y < nY_pad) dst[(int64_t)b * dB + (int64_t)x * dX + y] = tile[tx][j];
+    }
+}
+
+}  // namespace
+
+extern "C" int eqh_permute_tiles_f32(const float* src, float* dst, int32_t nX, int32_t nY, int32_t nY_pad, int32_t nB, int64_t sY,
+                                     int64_t sB, int64_t dX, int64_t dB, void* stream_) {
+    if (nX < 0 || nY < 0 || nB < 0 || nY_pad < nY) return EQH_ERR_ARG;
+    if (nX == 0 || nY_pad == 0 || nB == 0) return EQH_OK;
+    if (!src || !dst || nB > 65535) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(k_permute_tiles, dim3((nX + 63) / 64, (nY_pad + 63) / 64, nB), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), src, dst, (int)nX, (int)nY, (int)nY_pad, sY, sB, dX, dB);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

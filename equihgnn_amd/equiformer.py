@@ -104,6 +104,9 @@ class Radial(nn.Module):
         b3 as [lo, li]."""
         lo, li, mid = self.nc_out, self.nc_in, self.mid
         lo_p = -(-lo // 16) * 16
+        if self.rp[6].weight.is_cuda and self.rp[6].weight.dtype == torch.float32:
+            # one tiled transposition each way (16 MB at hidden 256; torch's strided copy moves it at 0.7 TB/s)
+            return ops.radial_weight_layout(self.rp[6].weight, lo, li, mid, lo_p), self.rp[6].bias.view(lo, li), lo_p
         w = self.rp[6].weight.view(lo, li, mid).permute(1, 2, 0)
         if lo_p != lo:
             w = F.pad(w, (0, lo_p - lo))

@@ -103,6 +103,8 @@ SIGNATURES = {
     "faf_edge_hidden_bwd_workspace_bytes": (c_size_t, [c_int64]),
     "faf_edge_hidden_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_void_p, c_float] + [c_void_p] * 4
                             + [c_int32, c_void_p, c_size_t, c_void_p]),
+    "eqh_permute_tiles_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,
+                                        c_void_p]),
     "hg_readout_mse_supported": (c_int32, [c_int32, c_int32]),
     "hg_readout_mse_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "hg_readout_mse_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_float,

@@ -1832,6 +1832,37 @@ def edge_hidden(A, B, Cf, nbr, csr_t: CSR, gamma, beta, eps: float = 1e-5, p: fl
     return _EdgeHidden.apply(A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, (gamma, beta))
 
 
+class _RadialWeightLayout(torch.autograd.Function):
+    """nn.Linear(mid, lo * li).weight [(lo, li), mid] -> [li, mid * lo_p] with columns ordered (k, lo) and lo zero-padded to lo_p:
+    w.view(lo, li, mid).permute(1, 2, 0) (+ pad) as one tiled transposition each way (eqh_permute_tiles_f32)."""
+
+    @staticmethod
+    def forward(ctx, w, lo, li, mid, lo_p):
+        _require_gpu(w, "radial_weight_layout")
+        w = _f32c(w)
+        out = torch.empty((li, mid * lo_p), dtype=torch.float32, device=w.device)
+        # b = li, x = k (contiguous in the source), y = lo (contiguous in the destination)
+        hip.check(hip.lib().eqh_permute_tiles_f32(_ptr(w), _ptr(out), mid, lo, lo_p, li, li * mid, mid, lo_p, mid * lo_p,
+                                                  _stream(w.device)), "eqh_permute_tiles_f32")
+        ctx.dims = (lo, li, mid, lo_p, tuple(w.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lo, li, mid, lo_p, shape = ctx.dims
+        dout = _f32c(dout)
+        dw = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        # b = li, x = lo (contiguous in the source), y = k (contiguous in the destination)
+        hip.check(hip.lib().eqh_permute_tiles_f32(_ptr(dout), _ptr(dw), lo, mid, mid, li, lo_p, mid * lo_p, li * mid, mid,
+                                                  _stream(dout.device)), "eqh_permute_tiles_f32")
+        return dw, None, None, None, None
+
+
+def radial_weight_layout(w, lo: int, li: int, mid: int, lo_p: int):
+    """See _RadialWeightLayout; ``w`` is the [lo * li, mid] weight PARAMETER of the radial network's last Linear."""
+    return _RadialWeightLayout.apply(w, lo, li, mid, lo_p)
+
+
 class _RowDot(torch.autograd.Function):
     """y = x @ U.T + bias for a FEW output columns (J <= 4), one pass over x each way (faf_rowdot_*).  With
     ``passthrough`` the node also returns x itself for x's OTHER consumer, and the backward adds that consumer's gradient

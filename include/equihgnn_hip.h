@@ -506,6 +506,13 @@ int faf_edge_hidden_bwd(const float* A, const float* B, const float* Cf, const i
                         const float* dhn, int64_t N, int32_t K, float p, const int64_t* seed, float eps, float* dpre, float* dA,
                         float* dgamma, float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Batched transposition with free strides: dst[b * dB + x * dX + y] = src[b * sB + y * sY + x] (x < nX, y < nY, b < nB;
+ * the source is contiguous along x, the destination along y), zero for nY <= y < nY_pad.  Re-lays the radial network's
+ * last weight nn.Linear(64, lo * li).weight [(lo, li), k] (equiformer_layer.py:451-479) out as [li, (k, lo_pad)] for the
+ * node-level GEMM, and its gradient back. */
+int eqh_permute_tiles_f32(const float* src, float* dst, int32_t nX, int32_t nY, int32_t nY_pad, int32_t nB, int64_t sY,
+                          int64_t sB, int64_t dX, int64_t dB, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Batched symmetric 3x3 eigen-decomposition — torch.linalg.eigh(C, UPLO="U") at
  * fa_former_layer.py:100 (frame averaging).  a [B,3,3] (upper triangle read), w [B,3] ascending

@@ -1216,6 +1216,22 @@ def test_edge_hidden_matches_the_unfused_composition(N, p):
         assert err < 5e-5, (name, err)
 
 
+@pytest.mark.parametrize("lo,li,mid", [(256, 256, 64), (52, 256, 64), (48, 3, 64), (1, 7, 5)])
+def test_radial_weight_layout_is_the_permutation(lo, li, mid):
+    """eqh_permute_tiles_f32: W [(lo, li), k] -> [li, (k, lo_pad)] and the gradient back, bit-exact against torch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(lo + li)
+    lo_p = -(-lo // 16) * 16
+    w = torch.randn(lo * li, mid, generator=g).to(DEV).requires_grad_(True)
+    out = ops.radial_weight_layout(w, lo, li, mid, lo_p)
+    ref = torch.nn.functional.pad(w.detach().view(lo, li, mid).permute(1, 2, 0), (0, lo_p - lo)).reshape(li, mid * lo_p)
+    assert torch.equal(out.detach(), ref)
+    gr = torch.randn(li, mid * lo_p, generator=g).to(DEV)
+    out.backward(gr)
+    ref_g = gr.view(li, mid, lo_p)[:, :, :lo].permute(2, 0, 1).reshape(lo * li, mid)
+    assert torch.equal(w.grad, ref_g)
+
+
 def test_frame_pre_matches_float64_reference():
     """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
     dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
