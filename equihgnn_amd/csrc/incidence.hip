@@ -205,10 +205,10 @@ k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const 
             for (int j = 0; j < cnt; j += 4) {               // four entries' rows in flight together
                 Row<NV> w0, w1, w2, w3;
                 const int last = cnt - 1;
-                fetch(oth, __shfl(my_o, j, 64), w0);
-                fetch(oth, __shfl(my_o, (j + 1 < cnt) ? j + 1 : last, 64), w1);
-                fetch(oth, __shfl(my_o, (j + 2 < cnt) ? j + 2 : last, 64), w2);
-                fetch(oth, __shfl(my_o, (j + 3 < cnt) ? j + 3 : last, 64), w3);
+                fetch(oth, __builtin_amdgcn_readlane(my_o, j), w0);
+                fetch(oth, __builtin_amdgcn_readlane(my_o, (j + 1 < cnt) ? j + 1 : last), w1);
+                fetch(oth, __builtin_amdgcn_readlane(my_o, (j + 2 < cnt) ? j + 2 : last), w2);
+                fetch(oth, __builtin_amdgcn_readlane(my_o, (j + 3 < cnt) ? j + 3 : last), w3);
                 add_norm(w0);
                 if (j + 1 < cnt) add_norm(w1);
                 if (j + 2 < cnt) add_norm(w2);
@@ -281,10 +281,10 @@ k_gather_ln_fwd(const float* __restrict__ h, const float* __restrict__ bias, con
             for (int j = 0; j < cnt; j += 4) {
                 Row<NV> u0, u1, u2, u3;
                 const int last = cnt - 1;
-                fetch(__shfl(my_o, j, 64), u0);
-                fetch(__shfl(my_o, (j + 1 < cnt) ? j + 1 : last, 64), u1);
-                fetch(__shfl(my_o, (j + 2 < cnt) ? j + 2 : last, 64), u2);
-                fetch(__shfl(my_o, (j + 3 < cnt) ? j + 3 : last, 64), u3);
+                fetch(__builtin_amdgcn_readlane(my_o, j), u0);
+                fetch(__builtin_amdgcn_readlane(my_o, (j + 1 < cnt) ? j + 1 : last), u1);
+                fetch(__builtin_amdgcn_readlane(my_o, (j + 2 < cnt) ? j + 2 : last), u2);
+                fetch(__builtin_amdgcn_readlane(my_o, (j + 3 < cnt) ? j + 3 : last), u3);
                 add_norm(u0);
                 if (j + 1 < cnt) add_norm(u1);
                 if (j + 2 < cnt) add_norm(u2);

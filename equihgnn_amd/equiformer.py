@@ -144,16 +144,25 @@ class EdgeGeometry:
         return torch.bmm(t.view(self.N, self.K, -1).transpose(1, 2), self.mean_w_rhat)
 
 
+def _fan(x, *ws):
+    """(x @ w for w in ws) as one autograd node on the GPU (ops.matmul_fan: the input's gradient without add kernels, leaf
+    weight gradients batched); plain matmuls elsewhere."""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+        return ops.matmul_fan(x, *ws)
+    return tuple(x @ w for w in ws)
+
+
 def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
     """out[e, lo] = sum_li R_e[lo, li] (xj[j_e, li] + xi[i_e, li]) without forming R_e.
     xj / xi: [N, li] (degree 0) or [N, li, 3] (degree 1, with ``zscale`` = r_hat [E, 3])."""
     w, b3, lo_p = radial.node_weights()
     n, lo, mid = geo.N, radial.nc_out, radial.mid
     if zscale is None:
-        p = (xj @ w).view(n, mid, lo_p)
-        q = (xi @ w).view(n, mid, lo_p)
+        b3t = b3.t()
+        p, pb = _fan(xj, w, b3t)                                                    # [N, mid*lo_p], [N, lo]
+        q, qb = _fan(xi, w, b3t)
+        p, q = p.view(n, mid, lo_p), q.view(n, mid, lo_p)
         ze = z
-        pb, qb = xj @ b3.t(), xi @ b3.t()                                           # [N, lo]
         bias = ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, lo) + qb[:, None, :]
         bias = bias.reshape(-1, lo)
     else:
@@ -181,13 +190,13 @@ class DTPIn(nn.Module):
         self.to_out = FiberLinear((c, c), (c, c))
 
     def forward(self, x0, geo: EdgeGeometry):
-        xi, xj = x0 @ self.to_xi.w(0), x0 @ self.to_xj.w(0)
+        xi, xj, si = _fan(x0, self.to_xi.w(0), self.to_xj.w(0), self.self_interact.w(0))
         r00, r01 = self.kernel_unary["(0,0)"], self.kernel_unary["(0,1)"]
         o0 = radial_contract(r00, r00.trunk(geo.dist), xj, xi, geo)                 # [E, C]
         o1 = radial_contract(r01, r01.trunk(geo.dist), xj, xi, geo)                 # [E, C]
         p0 = geo.masked_mean(o0)                                                    # [N, C]
         p1 = geo.masked_mean_times_rhat(o1)                                         # [N, C, 3]
-        out0 = p0 @ self.to_out.w(0) + x0 @ self.self_interact.w(0)
+        out0 = _fan(p0, self.to_out.w(0))[0] + si
         out1 = torch.einsum("ndm,de->nem", p1, self.to_out.w(1))
         return out0, out1
 
@@ -209,14 +218,13 @@ class DTPAttn(nn.Module):
     def forward(self, f0, f1, geo: EdgeGeometry, joined: bool = True):
         """[N, 1+K, 104] (self-interaction as slot 0), or with ``joined=False`` its two parts: the self rows
         [N, 104] and the edge rows [E, 104]."""
-        xi0, xj0 = f0 @ self.to_xi.w(0), f0 @ self.to_xj.w(0)
+        xi0, xj0, me = _fan(f0, self.to_xi.w(0), self.to_xj.w(0), self.self_interact.w(0))
         xi1 = torch.einsum("ndm,de->nem", f1, self.to_xi.w(1))
         xj1 = torch.einsum("ndm,de->nem", f1, self.to_xj.w(1))
         r00, r10 = self.kernel_unary["(0,0)"], self.kernel_unary["(1,0)"]
         o00 = radial_contract(r00, r00.trunk(geo.dist), xj0, xi0, geo)
         o10 = radial_contract(r10, r10.trunk(geo.dist), xj1, xi1, geo, zscale=geo.rhat)
-        out = torch.cat((o00, o10), -1) @ self.to_out.w(0)                          # [E, 104]
-        me = f0 @ self.self_interact.w(0)                                           # [N, 104]
+        out = _fan(torch.cat((o00, o10), -1), self.to_out.w(0))[0]                  # [E, 104]
         if not joined:
             return me, out
         return torch.cat((me[:, None, :], out.view(geo.N, geo.K, -1)), 1)           # [N, 1+K, 104]
@@ -247,7 +255,7 @@ class MLPAttention(nn.Module):
                 # launch each way; the [N, 17, 104] concatenation is never built (csrc/attn_pool.hip)
                 out = ops.attn_pool(me, edge, geo.maskf, wl, wv, 8 + self.dh, self.scale, 0.1)
                 gate = torch.sigmoid(self.attn_head_gates[1](f0))[:, :1]
-                return (out * gate) @ self.to_out.w(0)
+                return _fan(out * gate, self.to_out.w(0))[0]
             inter = torch.cat((me[:, None, :], edge.view(geo.N, geo.K, -1)), 1)
         else:
             inter = self.to_attn_and_v(f0, f1, geo)                                 # [N, 1+K, 104]
@@ -272,8 +280,8 @@ class FeedForward(nn.Module):
         self.project_out.init_zero_()                                               # :514-515
 
     def forward(self, x0):
-        h = self.prenorm.norm0(x0) @ self.project_in.w(0)
-        return F.silu(h[..., self.mult * self.c:]) @ self.project_out.w(0)
+        h = _fan(self.prenorm.norm0(x0), self.project_in.w(0))[0]
+        return _fan(F.silu(h[..., self.mult * self.c:]), self.project_out.w(0))[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------

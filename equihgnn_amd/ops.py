@@ -1832,6 +1832,60 @@ def edge_hidden(A, B, Cf, nbr, csr_t: CSR, gamma, beta, eps: float = 1e-5, p: fl
     return _EdgeHidden.apply(A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, (gamma, beta))
 
 
+class _MatmulFan(torch.autograd.Function):
+    """ys[i] = x @ Ws[i] for weights stored [in, out_i] (the FiberLinear layout of equiformer_layer.py:168-191): ONE autograd
+    node for all products of the same input, so that its gradient is one GEMM plus accumulating GEMMs (no add kernels), and
+    the weight gradients x^T dy_i of leaf weights with a persistent accumulator join the batched launch of defer_flush."""
+
+    @staticmethod
+    def forward(ctx, x, *Ws):
+        ctx.save_for_backward(x, *Ws)
+        ctx.set_materialize_grads(False)
+        return tuple(x @ W for W in Ws)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, *Ws = ctx.saved_tensors
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = None
+        dWs = []
+        for k, (W, dy) in enumerate(zip(Ws, dys)):
+            if dy is None:
+                dWs.append(None)
+                continue
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = dy2 @ W.t()
+                else:
+                    dx.addmm_(dy2, W.t())
+            if not ctx.needs_input_grad[1 + k]:
+                dWs.append(None)
+                continue
+            tgt = _acc_target(W)
+            if tgt is not None:
+                if not _wgrad_deferred(x2, dy2, 1.0, tgt):      # into [in, out] += x2^T dy2
+                    tgt.addmm_(x2.t(), dy2)
+                dWs.append(None)
+            else:
+                dWs.append(x2.t() @ dy2)
+        return (dx.view(x.shape) if dx is not None else None, *dWs)
+
+
+def matmul_fan(x, *Ws):
+    """(x @ W for W in Ws), weights [in, out_i]; see _MatmulFan.  Leaf weights are registered for persistent accumulators."""
+    if torch.is_grad_enabled():
+        for W in Ws:
+            if W.requires_grad and W.is_leaf and W.dim() == 2 and not hasattr(W, "_eqh_transient"):
+                LINEAR_PARAMS[id(W)] = W
+    return _MatmulFan.apply(x, *Ws)
+
+
+def matmul(x, W):
+    """x @ W for a weight stored [in, out] through _MatmulFan (batched / in-place weight gradient)."""
+    return matmul_fan(x, W)[0]
+
+
 class _RadialWeightLayout(torch.autograd.Function):
     """nn.Linear(mid, lo * li).weight [(lo, li), mid] -> [li, mid * lo_p] with columns ordered (k, lo) and lo zero-padded to lo_p:
     w.view(lo, li, mid).permute(1, 2, 0) (+ pad) as one tiled transposition each way (eqh_permute_tiles_f32)."""
