@@ -214,6 +214,8 @@ def batch_norm_rows(bn: nn.BatchNorm1d, x, mask):
     with it a padded batch gives the real rows the same outputs, the parameters the same gradients and the
     running buffers the same updates as the unpadded one, so the BatchNorm models can run under hipGraph
     replay too.  Everything stays on the device (the row count is a device scalar: it changes per batch)."""
+    if ops.batch_norm_rows_supported(x, bn):       # one launch each way (csrc/bn_rows.hip), masked or not
+        return ops.batch_norm_rows(x, mask, bn)
     if mask is None or not bn.training or not bn.track_running_stats or bn.momentum is None:
         return bn(x)
     n = mask.sum()

@@ -666,6 +666,52 @@ def gather_ln_reduce(h, bias, gamma, beta, csr: CSR, csr_t: CSR, reduce: str = "
     return _GatherLnReduce.apply(h, bias, gamma, beta, csr, csr_t, reduce == "mean", eps, (bias, gamma, beta))
 
 
+class _BatchNormRows(torch.autograd.Function):
+    """Training-mode BatchNorm1d over rows with the batch statistics taken over the masked (real) rows only and the running
+    buffers updated in the same launch (hg_batch_norm_rows_*; csrc/bn_rows.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, mask, gamma, beta, running_mean, running_var, n_tracked, momentum, eps, acc_params):
+        _require_gpu(x, "batch_norm_rows")
+        x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
+        R, C = x.shape
+        m = _f32c(mask).reshape(-1) if mask is not None else None
+        y = torch.empty_like(x)
+        stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().hg_batch_norm_rows_fwd(_ptr(x), _ptr(m), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                                   _ptr(n_tracked), float(momentum), float(eps), R, C, _ptr(y), _ptr(stats[0]),
+                                                   _ptr(stats[1]), _stream(x.device)), "hg_batch_norm_rows_fwd")
+        ctx.save_for_backward(x, m, gamma, stats)
+        ctx.acc = acc_params
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, m, gamma, stats = ctx.saved_tensors
+        R, C = x.shape
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        small = torch.empty((2, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().hg_batch_norm_rows_bwd(_ptr(x), _ptr(dy), _ptr(m), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), R, C,
+                                                   _ptr(dx), _ptr(small[0]), _ptr(small[1]), _stream(x.device)),
+                  "hg_batch_norm_rows_bwd")
+        dgam, dbet = _hand_out(list(small), [_acc_target(p) for p in ctx.acc])
+        return dx, None, dgam, dbet, None, None, None, None, None, None
+
+
+def batch_norm_rows(x, mask, bn):
+    """Training-mode ``bn`` (nn.BatchNorm1d with running statistics) on 2-D fp32 rows ``x`` with the statistics over the rows
+    where ``mask`` [R, 1] is > 0 (None: all rows); running_mean / running_var / num_batches_tracked are updated in place."""
+    _note_acc(bn.weight, bn.bias)
+    return _BatchNormRows.apply(x, mask, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                bn.momentum, bn.eps, (bn.weight, bn.bias))
+
+
+def batch_norm_rows_supported(x, bn) -> bool:
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and bn.training and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and x.shape[0] > 1)
+
+
 class _LayerNormRows(torch.autograd.Function):
     """Plain LayerNorm over dense rows; one launch each way, dgamma/dbeta from the backward pass."""
 

@@ -1232,6 +1232,43 @@ def test_radial_weight_layout_is_the_permutation(lo, li, mid):
     assert torch.equal(w.grad, ref_g)
 
 
+@pytest.mark.parametrize("R,C,n_real", [(500, 64, None), (4736, 256, 4600), (37, 128, 20)])
+def test_batch_norm_rows_matches_torch(R, C, n_real):
+    """hg_batch_norm_rows_fwd / _bwd: training-mode BatchNorm1d with the statistics over the first n_real rows (a padded
+    batch) against nn.BatchNorm1d on those rows alone -- outputs of the real rows, running buffers, and the gradients of
+    x (real rows; padded rows get the gradient of an affine map), gamma and beta."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g) * 2 + 0.5
+    w = torch.randn(R, C, generator=g)
+    nr = R if n_real is None else n_real
+    if n_real is not None:
+        w[nr:] = 0          # padded rows reach no loss
+    bn_ref = torch.nn.BatchNorm1d(C).double()
+    with torch.no_grad():
+        bn_ref.weight.copy_(1 + 0.2 * torch.randn(C, generator=g)); bn_ref.bias.copy_(0.3 * torch.randn(C, generator=g))
+        bn_ref.running_mean.copy_(torch.randn(C, generator=g)); bn_ref.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    bn = torch.nn.BatchNorm1d(C)
+    bn.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in bn_ref.state_dict().items()})
+    bn.to(DEV).train()
+    bn_ref.train()
+    xr = x[:nr].double().requires_grad_(True)
+    y_ref = bn_ref(xr)                                  # ONE training-mode call: the running buffers move once
+    (y_ref * w[:nr].double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    mask = None if n_real is None else (torch.arange(R) < nr).float()[:, None].to(DEV)
+    assert ops.batch_norm_rows_supported(xd, bn)
+    y = ops.batch_norm_rows(xd, mask, bn)
+    (y * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(y[:nr].detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    for name in ("running_mean", "running_var"):
+        np.testing.assert_allclose(getattr(bn, name).cpu().numpy(), getattr(bn_ref, name).numpy(), atol=1e-5, rtol=1e-5, err_msg=name)
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+    for name, a, r in (("dx", xd.grad[:nr], xr.grad), ("dgamma", bn.weight.grad, bn_ref.weight.grad), ("dbeta", bn.bias.grad, bn_ref.bias.grad)):
+        err = float((a.cpu().double() - r).abs().max() / r.abs().max().clamp(min=1e-9))
+        assert err < 3e-5, (name, err)
+
+
 def test_frame_pre_matches_float64_reference():
     """pre[e, f] = W3 (y_e * s_f) + base_e over the 8 sign frames (fa_former_layer.py:61-120): forward and dy, dW3,
     dbase against float64 autograd of the unfused expression, with a per-row base and with a broadcast bias."""
