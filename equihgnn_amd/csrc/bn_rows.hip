@@ -70,7 +70,7 @@ k_bn_rows_fwd(const float* __restrict__ x, const float* __restrict__ mask, const
         *reinterpret_cast<float4*>(save_mean + c) = mean;
         *reinterpret_cast<float4*>(save_rstd + c) = rstd;
         if (run_mean) {
-            const float unb = n / (n - 1.0f);       // nn.BatchNorm1d stores the unbiased variance
+            const float unb = n > 1.0f ? n / (n - 1.0f) : 1.0f;   // nn.BatchNorm1d stores the unbiased variance
             float4 rm = *reinterpret_cast<const float4*>(run_mean + c), rv = *reinterpret_cast<const float4*>(run_var + c);
             rm.x += momentum * (mean.x - rm.x); rm.y += momentum * (mean.y - rm.y);
             rm.z += momentum * (mean.z - rm.z); rm.w += momentum * (mean.w - rm.w);

@@ -844,6 +844,8 @@ def defer_begin(device):
     (eqh_defer_begin); they all run in one launch at defer_flush()."""
     hip.check(hip.lib().eqh_defer_begin(_stream(device)), "eqh_defer_begin")
     _DEFER["active"] = True
+    _DEFER["merged"] = []       # (a window that ended in an exception must not leak its records into this one)
+    _DEFER["zslab"] = None
 
 
 def wgrad_batch(entries):
