@@ -112,33 +112,56 @@ __global__ void k_scan_apply(int* __restrict__ cnt, int64_t n_items,
     }
 }
 
-// whole scan in ONE launch for n_items <= 64 Ki: a single 1024-thread block walks the counters in
-// chunks with a running carry (saves two launches per CSR at training batch sizes)
+// whole scan in ONE launch for n_items <= 64 Ki: a single 1024-thread block walks the counters in chunks of 4096 (four
+// consecutive counters per thread: coalesced 16-byte accesses) with a running carry; 36 -> ~10 us at the 31 k rows of a
+// PCQM batch of 1024 molecules.  (Measured and not kept: one contiguous segment per thread -- 62 dependent strided
+// loads per thread, 65 us.)
 __global__ void __launch_bounds__(1024)
 k_scan_small(int* __restrict__ cnt, int n_items, int* __restrict__ rowptr) {
-    __shared__ int s_wave[16];
-    __shared__ int s_carry;
+    __shared__ int s_wave[2][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int c0 = 0; c0 < n_items; c0 += 1024) {
-        const int i = c0 + threadIdx.x;
-        const int v = i < n_items ? cnt[i] : 0;
-        int inc = v;
+    int carry = 0;
+    int buf = 0;
+    const bool vec = (((uintptr_t)cnt | (uintptr_t)rowptr) & 15) == 0;     // 16-byte accesses need aligned arrays
+    for (int c0 = 0; c0 < n_items; c0 += 4096, buf ^= 1) {
+        const int i = c0 + 4 * threadIdx.x;
+        int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (vec && i + 3 < n_items) {
+            const int4 v = *reinterpret_cast<const int4*>(cnt + i);
+            v0 = v.x; v1 = v.y; v2 = v.z; v3 = v.w;
+        } else {
+            if (i < n_items) v0 = cnt[i];
+            if (i + 1 < n_items) v1 = cnt[i + 1];
+            if (i + 2 < n_items) v2 = cnt[i + 2];
+            if (i + 3 < n_items) v3 = cnt[i + 3];
+        }
+        const int sum = (v0 + v1) + (v2 + v3);
+        int inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int t = __shfl_up(inc, d, 64);
             if (lane >= d) inc += t;
         }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        int base = s_carry;
-        for (int w = 0; w < wave; ++w) base += s_wave[w];
-        const int ex = base + inc - v;
-        if (i < n_items) { rowptr[i] = ex; cnt[i] = ex; }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = ex + v;
-        __syncthreads();
+        if (lane == 63) s_wave[buf][wave] = inc;
+        __syncthreads();                      // (double-buffered wave sums: one barrier per chunk)
+        int base = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int t = s_wave[buf][w];
+            if (w < wave) base += t;
+            total += t;
+        }
+        const int e0 = base + inc - sum, e1 = e0 + v0, e2 = e1 + v1, e3 = e2 + v2;
+        if (vec && i + 3 < n_items) {
+            *reinterpret_cast<int4*>(rowptr + i) = make_int4(e0, e1, e2, e3);
+            *reinterpret_cast<int4*>(cnt + i) = make_int4(e0, e1, e2, e3);
+        } else {
+            if (i < n_items) { rowptr[i] = e0; cnt[i] = e0; }
+            if (i + 1 < n_items) { rowptr[i + 1] = e1; cnt[i + 1] = e1; }
+            if (i + 2 < n_items) { rowptr[i + 2] = e2; cnt[i + 2] = e2; }
+            if (i + 3 < n_items) { rowptr[i + 3] = e3; cnt[i + 3] = e3; }
+        }
+        carry += total;
     }
 }
 
