@@ -199,27 +199,35 @@ class BucketedLoader:
             finally:
                 q.put(None)
 
+        # two Python threads share the interpreter lock; with the default 5 ms switch interval the training thread (a few
+        # hundred microseconds of work per 1.5 ms step) can wait milliseconds for the collating thread to yield it
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(old_interval, 2e-4))
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         prev = None
-        while True:
-            ent = q.get()
-            if prev is not None and cuda:     # whatever the consumer enqueued for the previous batch reads it before this point
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                prev[3] = ev
-            if ent is None:
-                break
-            if self.device is None:
-                yield ent[0]
-                continue
-            if not cuda:
-                yield ent[0].to(self.device)
-                continue
-            torch.cuda.current_stream(self.device).wait_event(ent[1])
-            prev = ent
-            yield ent[2]
-        th.join()
+        try:
+            while True:
+                ent = q.get()
+                if prev is not None and cuda:     # whatever the consumer enqueued for the previous batch reads it before this point
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    prev[3] = ev
+                if ent is None:
+                    break
+                if self.device is None:
+                    yield ent[0]
+                    continue
+                if not cuda:
+                    yield ent[0].to(self.device)
+                    continue
+                torch.cuda.current_stream(self.device).wait_event(ent[1])
+                prev = ent
+                yield ent[2]
+            th.join()
+        finally:
+            sys.setswitchinterval(old_interval)
 
 
 def _real(out, data):
