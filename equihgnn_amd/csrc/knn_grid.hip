@@ -174,9 +174,25 @@ __device__ __forceinline__ void best_reset(Best& b) {
 }
 
 // offer the candidates sorted[s .. e) to the list of query (qx, qy, qz, qi)
+// smallest distance among this lane's candidates of sorted[s .. e) (first pass: see k_knn_grid)
+template <int MODE>
+__device__ __forceinline__ void min_segment(const float4* __restrict__ sorted, int s, int e, float qx, float qy,
+                                            float qz, int qi, int lane, float& lmin) {
+    for (int c0 = s; c0 < e; c0 += 64) {
+        const int j = c0 + lane;
+        bool valid = j < e;
+        const float4 p = sorted[valid ? j : s];
+        if (MODE == 1) valid = valid && (__float_as_int(p.w) != qi);
+        const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
+        float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        if (MODE == 1) d = __fsqrt_rn(d);
+        if (valid && d < lmin) lmin = d;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void scan_segment(const float4* __restrict__ sorted, int s, int e, float qx, float qy,
-                                             float qz, int qi, int k, int lane, Best& b) {
+                                             float qz, int qi, int k, int lane, Best& b, const float T = INFINITY) {
     for (int c0 = s; c0 < e; c0 += 64) {
         const int j = c0 + lane;
         bool valid = j < e;
@@ -186,7 +202,7 @@ __device__ __forceinline__ void scan_segment(const float4* __restrict__ sorted, 
         const float dx = __fsub_rn(qx, p.x), dy = __fsub_rn(qy, p.y), dz = __fsub_rn(qz, p.z);
         float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
         if (MODE == 1) d = __fsqrt_rn(d);
-        unsigned long long mask = __ballot(valid && (d < b.tau || (d == b.tau && pi < b.tau_i)));
+        unsigned long long mask = __ballot(valid && d <= T && (d < b.tau || (d == b.tau && pi < b.tau_i)));
         while (mask) {
             const int sel = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
@@ -232,38 +248,65 @@ k_knn_grid(const float4* __restrict__ sorted, const int* __restrict__ cell_start
     Best b;
     best_reset(b);
     bool done = false;
+    // slots of shell r: two per (dz, dy) row of the cube; a row on the cube's boundary (or every row at r = 1, where the
+    // whole 3 x 3 x 3 cube is new) is one full x-run, an inner row the two end cells
+    auto slot_segment = [&](int r, int slot, int& seg_s, int& seg_e) {
+        const int w = 2 * r + 1;
+        seg_s = seg_e = 0;
+        if (slot < 2 * w * w) {
+            const int row = slot >> 1, second = slot & 1;
+            const int dz = row / w - r, dy = row % w - r;
+            const int z = cc[2] + dz, y = cc[1] + dy;
+            if (z >= 0 && z < gz && y >= 0 && y < gy) {
+                const bool full = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
+                int x0, x1;
+                if (full) { x0 = cc[0] - r; x1 = second ? x0 - 1 : cc[0] + r; }
+                else { x0 = second ? cc[0] + r : cc[0] - r; x1 = x0; }
+                if (x0 < 0 && x1 >= 0 && full) x0 = 0;
+                if (x1 > gx - 1 && x0 <= gx - 1 && full) x1 = gx - 1;
+                if (x0 >= 0 && x1 <= gx - 1 && x0 <= x1) {
+                    const int base = (z * gy + y) * gx;
+                    seg_s = cell_start[base + x0];
+                    seg_e = cell_start[base + x1 + 1];
+                }
+            }
+        }
+    };
+    // First pass over the 3 x 3 x 3 cube (as in k_knn): every lane keeps the smallest distance among ITS candidates; the
+    // k-th smallest of the 64 lane minima, T, bounds the final k-th distance from above, so the list below is only offered
+    // candidates with d <= T -- about k + a few serial insertions per query instead of ~k ln(n / k) + k of the several
+    // hundred atoms the central cells of a batch hold.  Fewer than k lanes with a candidate: T = +inf, no filtering.
+    float T = INFINITY;
+    if (inside) {
+        float lmin = INFINITY;
+        int seg_s, seg_e;
+        slot_segment(1, lane, seg_s, seg_e);               // 18 slots
+        unsigned long long live = __ballot(seg_e > seg_s);
+        while (live) {
+            const int sl = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            min_segment<MODE>(sorted, __shfl(seg_s, sl, 64), __shfl(seg_e, sl, 64), qx, qy, qz, qi, lane, lmin);
+        }
+        int rank = 0;
+        for (int l = 0; l < 64; ++l) {
+            const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lmin), l));
+            rank += (o < lmin || (o == lmin && l < lane)) ? 1 : 0;
+        }
+        const unsigned long long sel = __ballot(rank == k - 1);
+        T = __shfl(lmin, __ffsll((long long)sel) - 1, 64);
+    }
     if (inside) {
         for (int r = 1; r <= R_CAP && !done; ++r) {
-            // slots of shell r: two per (dz, dy) row of the cube; a row on the cube's boundary (or every row at
-            // r = 1, where the whole 3 x 3 x 3 cube is new) is one full x-run, an inner row the two end cells
             const int w = 2 * r + 1;
             const int n_slots = 2 * w * w;
             for (int s0 = 0; s0 < n_slots; s0 += 64) {
-                const int slot = s0 + lane;
-                int seg_s = 0, seg_e = 0;
-                if (slot < n_slots) {
-                    const int row = slot >> 1, second = slot & 1;
-                    const int dz = row / w - r, dy = row % w - r;
-                    const int z = cc[2] + dz, y = cc[1] + dy;
-                    if (z >= 0 && z < gz && y >= 0 && y < gy) {
-                        const bool full = r == 1 || dz == -r || dz == r || dy == -r || dy == r;
-                        int x0, x1;
-                        if (full) { x0 = cc[0] - r; x1 = second ? x0 - 1 : cc[0] + r; }
-                        else { x0 = second ? cc[0] + r : cc[0] - r; x1 = x0; }
-                        if (x0 < 0 && x1 >= 0 && full) x0 = 0;
-                        if (x1 > gx - 1 && x0 <= gx - 1 && full) x1 = gx - 1;
-                        if (x0 >= 0 && x1 <= gx - 1 && x0 <= x1) {
-                            const int base = (z * gy + y) * gx;
-                            seg_s = cell_start[base + x0];
-                            seg_e = cell_start[base + x1 + 1];
-                        }
-                    }
-                }
+                int seg_s, seg_e;
+                slot_segment(r, s0 + lane, seg_s, seg_e);
                 unsigned long long live = __ballot(seg_e > seg_s);
                 while (live) {
                     const int sl = __ffsll((long long)live) - 1;
                     live &= live - 1;
-                    scan_segment<MODE>(sorted, __shfl(seg_s, sl, 64), __shfl(seg_e, sl, 64), qx, qy, qz, qi, k, lane, b);
+                    scan_segment<MODE>(sorted, __shfl(seg_s, sl, 64), __shfl(seg_e, sl, 64), qx, qy, qz, qi, k, lane, b, T);
                 }
             }
             const float covered = (float)r * g.h * 0.9999f;
