@@ -2362,11 +2362,12 @@ def embed_sum(x, tables, offsets=None):
     return _EmbedSum.apply(x, tuple(int(o) for o in offsets), *tables)
 
 
-# Measured on MI355X (mode 0, k = 16): 4.6 k atoms brute 50 us / grid 75 us, 15 k atoms 244 / 243 us, 31 k atoms
-# 520 / 470 us.  The molecules of a batch overlap around the origin, so the central cells stay crowded at the finest
-# grid the LDS counters allow, and the wavefront-per-query list insertion dominates either way: the grid only
-# pays at the largest batches.
-KNN_GRID_MIN_POINTS = 24576
+# Measured on MI355X (k = 16, both kernels with the k-th-distance bound of round 2; mode 0 / mode 1, eager launches
+# including the grid build): 4.7 k atoms brute 43 / 50 us, grid 97 / 99; 8.3 k (QM9-like) 170 / 205 vs 124 / 126; 9.1 k
+# (PCQM-like) 185 / 223 vs 194 / 199; 15 k 332 / 413 vs 251 / 258; 31 k 1028 / 1347 vs 418 / 436.  The molecules of a
+# batch overlap around the origin, so the central cells stay crowded at the finest grid the LDS counters allow: the grid
+# pays from ~10 k atoms.
+KNN_GRID_MIN_POINTS = 10240
 
 
 def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto"):
