@@ -10,15 +10,21 @@
 
 namespace {
 
-__device__ __forceinline__ uint32_t mix64(uint64_t x) {   // splitmix64 finaliser, top 32 bits
-    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27; x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return (uint32_t)(x >> 32);
+// Dropout decision of element i: 32-bit avalanche (the murmur3 finaliser) of the element index combined with the two
+// halves of the 64-bit seed.  (Round 1 used the 64-bit splitmix finaliser: ~25 instructions per element with its 64-bit
+// multiplies -- on the [E * 8, 256] frame tensors the hash, not the memory pass, bounded drop_mean and the fused
+// hidden-layer kernels; this one is 8.)
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
 }
 // keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
 __device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t i, uint32_t threshold, float inv_keep) {
-    return mix64(seed + i * 0x9E3779B97F4A7C15ull) >= threshold ? inv_keep : 0.f;
+    const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
+    const uint32_t h = mix32((lo ^ (uint32_t)seed) + hi * 0x9E3779B1u) ^ (uint32_t)(seed >> 32);
+    return h >= threshold ? inv_keep : 0.f;
 }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
