@@ -81,10 +81,13 @@ k_swiglu_drop_bwd(const float* __restrict__ pre, const float* __restrict__ dout,
     }
 }
 
-// out[r, :] = (1 / F) * sum_f dropout(x[r * F + f, :])
+// out[r, :] = (1 / F) * sum_f dropout(x[r * F + f, :]);  FT = F at compile time (0: any F) so that the F row loads of an
+// output element are all in flight together (FAFormer's 8 sign frames)
+template <int FT>
 __global__ void __launch_bounds__(256)
-k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F, int C, const int64_t* __restrict__ seed_ptr,
+k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F_rt, int C, const int64_t* __restrict__ seed_ptr,
                 uint32_t threshold, float inv_keep, float* __restrict__ out) {
+    const int F = FT ? FT : F_rt;
     const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
     const int c4 = C >> 2;
     const int64_t total = R * c4;
@@ -93,6 +96,7 @@ k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F, int C, const int6
         const int64_t r = i / c4;
         const int c = (int)(i - r * c4) * 4;
         float4 acc = f4_zero();
+#pragma unroll
         for (int f = 0; f < F; ++f) {
             const int64_t row = r * F + f;
             float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
@@ -174,8 +178,12 @@ extern "C" int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_
     if (!x || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
     if (!eqh_aligned16(x) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(k_drop_mean_fwd, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
-                       (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+    if (F == 8)
+        hipLaunchKernelGGL(k_drop_mean_fwd<8>, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
+                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+    else
+        hipLaunchKernelGGL(k_drop_mean_fwd<0>, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
+                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
