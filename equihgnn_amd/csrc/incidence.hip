@@ -514,7 +514,8 @@ template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
             const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dh,
-            float* __restrict__ slab, int n_rows, int C, float eps, int64_t dy_ld) {
+            float* __restrict__ slab, int n_rows, int C, float eps, int64_t dy_ld, float* __restrict__ acc_out = nullptr,
+            int acc_first = 0) {
     __shared__ float4 s_red[THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
@@ -581,6 +582,11 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
             f4_add(a_db.v[i], dx);
             if (!RELU) f4_add(dx, ca.v[i]);      // plain LayerNorm: a second gradient of the same input rides along
             if (c < C) *reinterpret_cast<float4*>(dh + (int64_t)r * C + c) = dx;
+            if (acc_out && c < C) {              // the same gradient summed over several applications (see hg_bias_relu_ln_bwd_acc)
+                float4 t = dx;
+                if (!acc_first) f4_add(t, *reinterpret_cast<const float4*>(acc_out + (int64_t)r * C + c));
+                *reinterpret_cast<float4*>(acc_out + (int64_t)r * C + c) = t;
+            }
         }
     }
     // combine the workgroup's four wavefronts in a fixed order, one slab row per quantity
@@ -890,10 +896,10 @@ extern "C" size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C)
     return (size_t)rowln_blocks(n_rows) * 3 * (size_t)C * sizeof(float);
 }
 
-extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
-                                   int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
-                                   float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                                   void* stream_) {
+static int bias_relu_ln_bwd_impl(const float* h, const float* bias, const float* gamma, const float* dy,
+                                 int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                                 float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                 float* acc_out, int32_t acc_first, void* stream_) {
     int rc = check(n_rows, C);
     if (rc) return rc;
     if (!dbias || !dgamma || !dbeta) return EQH_ERR_ARG;
@@ -914,10 +920,30 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy,
                            (const float*)nullptr, dh, slab,
-                           (int)n_rows, (int)C, eps, (int64_t)C);
+                           (int)n_rows, (int)C, eps, (int64_t)C, acc_out, (int)acc_first);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
     });
+}
+
+extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, const float* dy,
+                                   int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                                   float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    return bias_relu_ln_bwd_impl(h, bias, gamma, dy, n_rows, C, eps, dh, dbias, dgamma, dbeta, accumulate, workspace,
+                                 workspace_bytes, nullptr, 0, stream_);
+}
+
+/* the same, and dh is also summed into acc_out [n_rows, C] (overwritten when acc_first != 0, else added to): the gradient
+   of a tensor that is ADDED to the input of several applications of the layer (the layer-independent term of
+   conv.py:179-180, layers.MHNNSConv) is collected here instead of by add kernels */
+extern "C" int hg_bias_relu_ln_bwd_acc(const float* h, const float* bias, const float* gamma, const float* dy,
+                                       int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                                       float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                       float* acc_out, int32_t acc_first, void* stream_) {
+    if (!acc_out || !eqh_aligned16(acc_out)) return EQH_ERR_ARG;
+    return bias_relu_ln_bwd_impl(h, bias, gamma, dy, n_rows, C, eps, dh, dbias, dgamma, dbeta, accumulate, workspace,
+                                 workspace_bytes, acc_out, acc_first, stream_);
 }
 
 /* Linear -> ReLU -> LayerNorm hidden layer on dense rows, consumed only through a gathered reduction (see k_gather_ln_fwd):

@@ -304,7 +304,8 @@ class MHNNSConv(nn.Module):
                                      self.W2.lins[0].bias, cols=(c_dim, 2 * c_dim))
         w23, _ = ops.merged_weight(self.W3.lins[0].weight, self.W2.lins[1].weight)
         cw = ops.linear(res[1], self.W3.lins[0].weight)                   # (a X0 + (1 - a) w_r b) W3a^T, layer-independent
-        return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw, "x0": X0, "x0_pass": res[3]}
+        cw, fan = ops.fanout(cw)          # its gradient is summed over the L applications by their LayerNorm backward kernels
+        return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw, "fan": fan, "x0": X0, "x0_pass": res[3]}
 
     def _forward_merged(self, X, ix: HyperIndex, m, relu_out=False):
         c = X.shape[-1]
@@ -318,8 +319,8 @@ class MHNNSConv(nn.Module):
         qb = ops.linear(hbar, m["w12"], m["b12"])
         s = ops.incidence_ln_reduce(pa, qb, n2.weight, n2.bias, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                                     "mean", n2.eps)                                            # conv.py:175-177
-        h3 = ops.linear_add(s, m["w23"], m["cw"], m["scale"])                                  # conv.py:179-180 + W3's first Linear
-        x = ops.bias_relu_ln(h3, W3.lins[0].bias, n3.weight, n3.bias, n3.eps)
+        h3 = ops.linear_add(s, m["w23"], m["cw"], m["scale"], fan=m["fan"])                    # conv.py:179-180 + W3's first Linear
+        x = ops.bias_relu_ln(h3, W3.lins[0].bias, n3.weight, n3.bias, n3.eps, fan=m["fan"])
         return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias, relu=relu_out)
 
     def forward(self, X, index: HyperIndex, X0, residual=None, relu_out=False):

@@ -579,7 +579,7 @@ class _BiasReluLn(torch.autograd.Function):
     same pass, the bias / gamma / beta gradients (csrc/incidence.hip)."""
 
     @staticmethod
-    def forward(ctx, h, bias, gamma, beta, eps, acc_params):
+    def forward(ctx, h, bias, gamma, beta, eps, acc_params, fan=None):
         _require_gpu(h, "bias_relu_ln")
         h, bias, gamma, beta = _f32c(h), _f32c(bias), _f32c(gamma), _f32c(beta)
         R, C = h.shape
@@ -589,6 +589,7 @@ class _BiasReluLn(torch.autograd.Function):
         ctx.save_for_backward(h, bias, gamma)
         ctx.eps = eps
         ctx.acc = acc_params  # the Parameter objects (their accumulators are looked up at backward time)
+        ctx.fan = fan
         return out
 
     @staticmethod
@@ -601,16 +602,56 @@ class _BiasReluLn(torch.autograd.Function):
         ws_bytes = L.hg_bias_relu_ln_bwd_workspace_bytes(R, C)
         ws = _workspace(ws_bytes, h.device)
         tg = [_acc_target(p) for p in ctx.acc]
-        if all(t is not None for t in tg):   # all three accumulate in place: nothing for autograd to add
-            hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps),
-                                            _ptr(dh), _ptr(tg[0]), _ptr(tg[1]), _ptr(tg[2]), 1, _ptr(ws), ws_bytes,
+        acc = all(t is not None for t in tg)   # all three accumulate in place: nothing for autograd to add
+        small = None if acc else torch.empty((3, C), dtype=torch.float32, device=h.device)
+        o = tg if acc else list(small)
+        fan = ctx.fan
+        if fan is not None:     # dh is also the gradient of the fanned-out addend of this layer's input: summed in the kernel
+            if fan.buf is None:
+                fan.buf = torch.empty_like(h)
+            hip.check(L.hg_bias_relu_ln_bwd_acc(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
+                                                _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws), ws_bytes,
+                                                _ptr(fan.buf), 1 if fan.n == 0 else 0, _stream(h.device)),
+                      "hg_bias_relu_ln_bwd_acc")
+            fan.n += 1
+        else:
+            hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
+                                            _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws), ws_bytes,
                                             _stream(h.device)), "hg_bias_relu_ln_bwd")
-            return dh, None, None, None, None, None
-        small = torch.empty((3, C), dtype=torch.float32, device=h.device)
-        hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
-                                        _ptr(small[0]), _ptr(small[1]), _ptr(small[2]), 0, _ptr(ws), ws_bytes,
-                                        _stream(h.device)), "hg_bias_relu_ln_bwd")
-        return (dh, *_hand_out(list(small), tg), None, None)
+        if acc:
+            return dh, None, None, None, None, None, None
+        return (dh, *_hand_out(list(small), tg), None, None, None)
+
+
+class GradFan:
+    """Collector for the gradient of a tensor that is added, unchanged, to the input of several bias_relu_ln layers (the
+    layer-independent term of conv.py:179-180 over the L applications of the shared conv): the LayerNorm backward kernels
+    sum it (hg_bias_relu_ln_bwd_acc), and _FanSource hands the sum to the tensor's producer."""
+
+    def __init__(self):
+        self.buf, self.n = None, 0
+
+
+class _FanSource(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, fan):
+        ctx.fan = fan
+        ctx.set_materialize_grads(False)
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        fan = ctx.fan
+        if fan.buf is None:          # no consumer used the collector
+            return g, None
+        return (fan.buf if g is None else fan.buf + g), None
+
+
+def fanout(t):
+    """(t as a new autograd leaf-of-this-node, GradFan): consumers that register with the GradFan (linear_add(..., fan=),
+    bias_relu_ln(..., fan=)) deliver their gradient of ``t`` through it instead of through autograd's adds."""
+    fan = GradFan()
+    return _FanSource.apply(t, fan), fan
 
 
 class _GatherLnReduce(torch.autograd.Function):
@@ -1464,9 +1505,10 @@ class _LinearAddC(torch.autograd.Function):
     backward GEMMs take ``scale`` as their alpha, so no scaling kernel runs either way."""
 
     @staticmethod
-    def forward(ctx, x, weight, c, scale):
+    def forward(ctx, x, weight, c, scale, fan=None):
         ctx.save_for_backward(x, weight)
         ctx.scale = float(scale)
+        ctx.fan = fan
         return torch.addmm(c, x, weight.t(), beta=1.0, alpha=ctx.scale)
 
     @staticmethod
@@ -1487,7 +1529,8 @@ class _LinearAddC(torch.autograd.Function):
                 dw = wgrad(dy, x, a)
             else:
                 dw = torch.addmm(weight, dy.t(), x, beta=0.0, alpha=a)
-        return dx, dw, (dy if ctx.needs_input_grad[2] else None), None
+        # (with a GradFan the gradient of c -- dy itself -- is summed by the LayerNorm backward that produced dy)
+        return dx, dw, (dy if ctx.needs_input_grad[2] and ctx.fan is None else None), None, None
 
 
 class _RowGemm(torch.autograd.Function):
@@ -1611,17 +1654,18 @@ def linear2(x, wa, cols_a, wb, cols_b):
     return _Linear2.apply(x, wa, a0, a1, wb, b0, b1)
 
 
-def linear_add(x, weight, c, scale: float = 1.0):
-    """scale * F.linear(x, weight) + c with the addition done by the GEMM epilogue (2-D x, c)."""
+def linear_add(x, weight, c, scale: float = 1.0, fan=None):
+    """scale * F.linear(x, weight) + c with the addition done by the GEMM epilogue (2-D x, c).  ``fan``: the GradFan of
+    ``c`` when the result goes straight into bias_relu_ln(..., fan=fan), whose backward then collects c's gradient."""
     if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
         LINEAR_PARAMS[id(weight)] = weight
-    return _LinearAddC.apply(x, weight, c, scale)
+    return _LinearAddC.apply(x, weight, c, scale, fan)
 
 
-def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5):
-    """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C]."""
+def bias_relu_ln(h, bias, gamma, beta, eps: float = 1e-5, fan=None):
+    """LayerNorm(relu(h + bias)) for 2-D ``h`` [rows, C].  ``fan``: see linear_add / GradFan (h = linear_add(..., c, fan=fan))."""
     _note_acc(bias, gamma, beta)
-    return _BiasReluLn.apply(h, bias, gamma, beta, eps, (bias, gamma, beta))
+    return _BiasReluLn.apply(h, bias, gamma, beta, eps, (bias, gamma, beta), fan)
 
 
 class _ResidualMix(torch.autograd.Function):
