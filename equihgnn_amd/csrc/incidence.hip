@@ -455,7 +455,8 @@ inc_bwd_body(const int block, float4* s_g, const float* __restrict__ pa, const f
 template <int NV, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 k_rowln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
-            const float* __restrict__ beta, float* __restrict__ out, int n_rows, int C, float eps) {
+            const float* __restrict__ beta, float* __restrict__ out, int n_rows, int C, float eps,
+            const float* __restrict__ pre_add = nullptr, float h_scale = 1.0f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
     Row<NV> bias_row;
@@ -472,6 +473,11 @@ k_rowln_fwd(const float* __restrict__ h, const float* __restrict__ bias, const f
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             hr.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)r * C + c) : f4_zero();
+            if (pre_add) {      // pre-activation = h_scale * h + pre_add[r] (+ bias): a GEMM's beta = 1 addend applied here
+                const float4 a = (c < C) ? *reinterpret_cast<const float4*>(pre_add + (int64_t)r * C + c) : f4_zero();
+                hr.v[i] = make_float4(fmaf(h_scale, hr.v[i].x, a.x), fmaf(h_scale, hr.v[i].y, a.y),
+                                      fmaf(h_scale, hr.v[i].z, a.z), fmaf(h_scale, hr.v[i].w, a.w));
+            }
         }
         norm_pair<NV, RELU>(hr, bias_row, C, lane, inv_c, eps, x, pos, &rstd);
 #pragma unroll
@@ -515,7 +521,7 @@ __global__ void __launch_bounds__(THREADS)
 k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const float* __restrict__ gamma,
             const float* __restrict__ dy, const float* __restrict__ add, float* __restrict__ dh,
             float* __restrict__ slab, int n_rows, int C, float eps, int64_t dy_ld, float* __restrict__ acc_out = nullptr,
-            int acc_first = 0) {
+            int acc_first = 0, const float* __restrict__ pre_add = nullptr, float h_scale = 1.0f) {
     __shared__ float4 s_red[THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float inv_c = 1.0f / (float)C;
@@ -543,6 +549,11 @@ k_rowln_bwd(const float* __restrict__ h, const float* __restrict__ bias, const f
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             nh.v[i] = (c < C) ? *reinterpret_cast<const float4*>(h + (int64_t)rr * C + c) : f4_zero();
+            if (RELU && pre_add) {
+                const float4 a = (c < C) ? *reinterpret_cast<const float4*>(pre_add + (int64_t)rr * C + c) : f4_zero();
+                nh.v[i] = make_float4(fmaf(h_scale, nh.v[i].x, a.x), fmaf(h_scale, nh.v[i].y, a.y),
+                                      fmaf(h_scale, nh.v[i].z, a.z), fmaf(h_scale, nh.v[i].w, a.w));
+            }
             nd.v[i] = (c < C) ? *reinterpret_cast<const float4*>(dy + (int64_t)rr * dy_ld + c) : f4_zero();
             if (!RELU && add) na.v[i] = (c < C) ? *reinterpret_cast<const float4*>(add + (int64_t)rr * C + c) : f4_zero();
         }
@@ -899,7 +910,7 @@ extern "C" size_t hg_bias_relu_ln_bwd_workspace_bytes(int64_t n_rows, int32_t C)
 static int bias_relu_ln_bwd_impl(const float* h, const float* bias, const float* gamma, const float* dy,
                                  int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
                                  float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                                 float* acc_out, int32_t acc_first, void* stream_) {
+                                 float* acc_out, int32_t acc_first, const float* pre_add, float h_scale, void* stream_) {
     int rc = check(n_rows, C);
     if (rc) return rc;
     if (!dbias || !dgamma || !dbeta) return EQH_ERR_ARG;
@@ -920,7 +931,7 @@ static int bias_relu_ln_bwd_impl(const float* h, const float* bias, const float*
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_rowln_bwd<NV, true>), dim3(blocks), dim3(THREADS), 0, stream, h, bias, gamma, dy,
                            (const float*)nullptr, dh, slab,
-                           (int)n_rows, (int)C, eps, (int64_t)C, acc_out, (int)acc_first);
+                           (int)n_rows, (int)C, eps, (int64_t)C, acc_out, (int)acc_first, pre_add, h_scale);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, 3 * (int64_t)C, dbias, dgamma, dbeta, C, C, accumulate, stream);
     });
@@ -931,19 +942,40 @@ extern "C" int hg_bias_relu_ln_bwd(const float* h, const float* bias, const floa
                                    float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
                                    void* stream_) {
     return bias_relu_ln_bwd_impl(h, bias, gamma, dy, n_rows, C, eps, dh, dbias, dgamma, dbeta, accumulate, workspace,
-                                 workspace_bytes, nullptr, 0, stream_);
+                                 workspace_bytes, nullptr, 0, nullptr, 1.0f, stream_);
 }
 
-/* the same, and dh is also summed into acc_out [n_rows, C] (overwritten when acc_first != 0, else added to): the gradient
-   of a tensor that is ADDED to the input of several applications of the layer (the layer-independent term of
-   conv.py:179-180, layers.MHNNSConv) is collected here instead of by add kernels */
-extern "C" int hg_bias_relu_ln_bwd_acc(const float* h, const float* bias, const float* gamma, const float* dy,
-                                       int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
-                                       float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                                       float* acc_out, int32_t acc_first, void* stream_) {
-    if (!acc_out || !eqh_aligned16(acc_out)) return EQH_ERR_ARG;
+/* Generalised form: the pre-activation is h_scale * h + pre_add[r] + bias (pre_add [n_rows, C] may be NULL: then h_scale
+   must be 1) -- the beta = 1 addend and the alpha of the GEMM that produced h, applied here instead of by a copy of the
+   addend into the GEMM's output -- and dh (the gradient of the PRE-ACTIVATION: the caller's GEMMs carry h_scale) is also
+   summed into acc_out [n_rows, C] when given (overwritten if acc_first != 0, else added to): the gradient of pre_add over
+   several applications of the layer (the layer-independent term of conv.py:179-180) without add kernels. */
+extern "C" int hg_bias_relu_ln_fwd_ex(const float* h, float h_scale, const float* pre_add, const float* bias, const float* gamma,
+                                      const float* beta, int64_t n_rows, int32_t C, float eps, float* out, void* stream_) {
+    int rc = check(n_rows, C);
+    if (rc) return rc;
+    if (n_rows == 0) return EQH_OK;
+    if (!h || !bias || !gamma || !beta || !out || (!pre_add && h_scale != 1.0f)) return EQH_ERR_ARG;
+    if (!eqh_aligned16(h) || !eqh_aligned16(bias) || !eqh_aligned16(gamma) || !eqh_aligned16(beta) || !eqh_aligned16(out) ||
+        !eqh_aligned16(pre_add))
+        return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    return dispatch_nv(C, [&](auto nv) {
+        constexpr int NV = decltype(nv)::value;
+        hipLaunchKernelGGL((k_rowln_fwd<NV, true>), dim3(eqh_grid_for(n_rows, WAVES, 4096)), dim3(THREADS), 0, stream, h,
+                           bias, gamma, beta, out, (int)n_rows, (int)C, eps, pre_add, h_scale);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    });
+}
+
+extern "C" int hg_bias_relu_ln_bwd_ex(const float* h, float h_scale, const float* pre_add, const float* bias, const float* gamma,
+                                      const float* dy, int64_t n_rows, int32_t C, float eps, float* dh, float* dbias,
+                                      float* dgamma, float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                      float* acc_out, int32_t acc_first, void* stream_) {
+    if ((!pre_add && h_scale != 1.0f) || !eqh_aligned16(pre_add) || !eqh_aligned16(acc_out)) return EQH_ERR_ARG;
     return bias_relu_ln_bwd_impl(h, bias, gamma, dy, n_rows, C, eps, dh, dbias, dgamma, dbeta, accumulate, workspace,
-                                 workspace_bytes, acc_out, acc_first, stream_);
+                                 workspace_bytes, acc_out, acc_first, pre_add, h_scale, stream_);
 }
 
 /* Linear -> ReLU -> LayerNorm hidden layer on dense rows, consumed only through a gathered reduction (see k_gather_ln_fwd):

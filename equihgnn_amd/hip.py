@@ -120,8 +120,9 @@ SIGNATURES = {
     "hg_bias_relu_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4
                             + [c_int32, c_void_p, c_size_t, c_void_p]),
-    "hg_bias_relu_ln_bwd_acc": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4
-                                + [c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
+    "hg_bias_relu_ln_fwd_ex": (c_int32, [c_void_p, c_float] + [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p]),
+    "hg_bias_relu_ln_bwd_ex": (c_int32, [c_void_p, c_float] + [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4
+                               + [c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "hg_csr_build_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
     "hg_csr_build_batch": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 12),

@@ -319,8 +319,8 @@ class MHNNSConv(nn.Module):
         qb = ops.linear(hbar, m["w12"], m["b12"])
         s = ops.incidence_ln_reduce(pa, qb, n2.weight, n2.bias, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
                                     "mean", n2.eps)                                            # conv.py:175-177
-        h3 = ops.linear_add(s, m["w23"], m["cw"], m["scale"], fan=m["fan"])                    # conv.py:179-180 + W3's first Linear
-        x = ops.bias_relu_ln(h3, W3.lins[0].bias, n3.weight, n3.bias, n3.eps, fan=m["fan"])
+        # conv.py:179-180 + W3's first Linear and hidden layer: scale * (s Wd^T) + cw + bias -> ReLU -> LayerNorm
+        x = ops.linear_add_relu_ln(s, m["w23"], m["cw"], m["scale"], W3.lins[0].bias, n3.weight, n3.bias, n3.eps, fan=m["fan"])
         return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias, relu=relu_out)
 
     def forward(self, X, index: HyperIndex, X0, residual=None, relu_out=False):

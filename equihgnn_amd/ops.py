@@ -609,10 +609,10 @@ class _BiasReluLn(torch.autograd.Function):
         if fan is not None:     # dh is also the gradient of the fanned-out addend of this layer's input: summed in the kernel
             if fan.buf is None:
                 fan.buf = torch.empty_like(h)
-            hip.check(L.hg_bias_relu_ln_bwd_acc(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
-                                                _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws), ws_bytes,
-                                                _ptr(fan.buf), 1 if fan.n == 0 else 0, _stream(h.device)),
-                      "hg_bias_relu_ln_bwd_acc")
+            hip.check(L.hg_bias_relu_ln_bwd_ex(_ptr(h), 1.0, None, _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
+                                               _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws), ws_bytes,
+                                               _ptr(fan.buf), 1 if fan.n == 0 else 0, _stream(h.device)),
+                      "hg_bias_relu_ln_bwd_ex")
             fan.n += 1
         else:
             hip.check(L.hg_bias_relu_ln_bwd(_ptr(h), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, float(ctx.eps), _ptr(dh),
@@ -621,6 +621,77 @@ class _BiasReluLn(torch.autograd.Function):
         if acc:
             return dh, None, None, None, None, None, None
         return (dh, *_hand_out(list(small), tg), None, None, None)
+
+
+class _LinearAddReluLn(torch.autograd.Function):
+    """LayerNorm(relu(scale * (x @ W.T) + c + bias)): the GEMM writes x @ W.T, the addend c (beta = 1 in _LinearAddC, which
+    costs a copy of c into the GEMM's output per call) and the scale enter in the LayerNorm kernel
+    (hg_bias_relu_ln_fwd_ex / _bwd_ex).  Backward: the kernel returns the gradient of the pre-activation; the two GEMMs
+    take ``scale`` as their alpha; c's gradient goes to its GradFan (summed over the applications) or to autograd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, c, scale, bias, gamma, beta, eps, fan, acc_params):
+        _require_gpu(x, "linear_add_relu_ln")
+        x, c, bias, gamma, beta = _f32c(x), _f32c(c), _f32c(bias), _f32c(gamma), _f32c(beta)
+        h = x @ weight.t()
+        R, C = h.shape
+        out = torch.empty_like(h)
+        hip.check(hip.lib().hg_bias_relu_ln_fwd_ex(_ptr(h), float(scale), _ptr(c), _ptr(bias), _ptr(gamma), _ptr(beta), R, C,
+                                                   float(eps), _ptr(out), _stream(x.device)), "hg_bias_relu_ln_fwd_ex")
+        ctx.save_for_backward(x, weight, h, c, bias, gamma)
+        ctx.meta = (float(scale), float(eps), fan)
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, h, c, bias, gamma = ctx.saved_tensors
+        a, eps, fan = ctx.meta
+        dy = _f32c(dy)
+        R, C = h.shape
+        dpre = torch.empty_like(h)
+        L = hip.lib()
+        ws_bytes = L.hg_bias_relu_ln_bwd_workspace_bytes(R, C)
+        ws = _workspace(ws_bytes, h.device)
+        tg = [_acc_target(p) for p in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty((3, C), dtype=torch.float32, device=h.device)
+        o = tg if acc else list(small)
+        if fan is not None and fan.buf is None:
+            fan.buf = torch.empty_like(h)
+        hip.check(L.hg_bias_relu_ln_bwd_ex(_ptr(h), a, _ptr(c), _ptr(bias), _ptr(gamma), _ptr(dy), R, C, eps, _ptr(dpre),
+                                           _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), 1 if acc else 0, _ptr(ws), ws_bytes,
+                                           _ptr(fan.buf) if fan is not None else None, 1 if (fan is not None and fan.n == 0) else 0,
+                                           _stream(h.device)), "hg_bias_relu_ln_bwd_ex")
+        if fan is not None:
+            fan.n += 1
+        dx = torch.addmm(x, dpre, weight, beta=0.0, alpha=a) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            gbuf = getattr(weight, "_eqh_gbuf", None)
+            if gbuf is not None and _wgrad_deferred(dpre, x, a, gbuf):
+                pass
+            elif gbuf is not None and _wgrad_ok(dpre, x):
+                wgrad(dpre, x, a, into=gbuf)
+            elif gbuf is not None:
+                gbuf.addmm_(dpre.t(), x, alpha=a)
+            elif _wgrad_ok(dpre, x):
+                dw = wgrad(dpre, x, a)
+            else:
+                dw = torch.addmm(weight, dpre.t(), x, beta=0.0, alpha=a)
+        dc = dpre if (fan is None and ctx.needs_input_grad[2]) else None
+        if acc:
+            return dx, dw, dc, None, None, None, None, None, None, None
+        return (dx, dw, dc, None, *_hand_out(list(small), tg), None, None, None)
+
+
+def linear_add_relu_ln(x, weight, c, scale, bias, gamma, beta, eps: float = 1e-5, fan=None):
+    """bias_relu_ln(linear_add(x, weight, c, scale), bias, gamma, beta) with the addend and the scale applied inside the
+    LayerNorm kernel (2-D fp32 x, c on the GPU); see _LinearAddReluLn."""
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
+        LINEAR_PARAMS[id(weight)] = weight
+    _note_acc(bias, gamma, beta)
+    return _LinearAddReluLn.apply(x, weight, c, scale, bias, gamma, beta, eps, fan, (bias, gamma, beta))
 
 
 class GradFan:

@@ -295,12 +295,16 @@ int hg_bias_relu_ln_bwd(const float* h, const float* bias, const float* gamma, c
                         int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
                         float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
                         void* stream);
-/* the same, with dh also summed into acc_out [n_rows, C] (overwritten if acc_first != 0, else added to): collects the
- * gradient of a term that is added to this layer's input in several applications (conv.py:179-180) without add kernels */
-int hg_bias_relu_ln_bwd_acc(const float* h, const float* bias, const float* gamma, const float* dy,
-                            int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
-                            float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes,
-                            float* acc_out, int32_t acc_first, void* stream);
+/* generalised form: pre-activation = h_scale * h + pre_add[r] + bias (pre_add [n_rows, C] may be NULL with h_scale 1): the
+ * beta = 1 addend and the alpha of the GEMM that produced h, applied here (conv.py:179-180 ahead of W3, mlp.py:91-99);
+ * bwd: dh is the gradient of the pre-activation, also summed into acc_out [n_rows, C] when given (overwritten if
+ * acc_first != 0, else added to) -- the gradient of pre_add over several applications of the layer */
+int hg_bias_relu_ln_fwd_ex(const float* h, float h_scale, const float* pre_add, const float* bias, const float* gamma,
+                           const float* beta, int64_t n_rows, int32_t C, float eps, float* out, void* stream);
+int hg_bias_relu_ln_bwd_ex(const float* h, float h_scale, const float* pre_add, const float* bias, const float* gamma,
+                           const float* dy, int64_t n_rows, int32_t C, float eps, float* dh, float* dbias, float* dgamma,
+                           float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes, float* acc_out,
+                           int32_t acc_first, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The same hidden layer when its output is consumed ONLY through a gathered reduction -- conv.py:172-173,
