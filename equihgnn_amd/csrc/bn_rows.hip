@@ -6,6 +6,10 @@
 // workgroup owns FOUR columns and walks all rows three times (mean, variance, output; the [R, C] matrix is a few MB and
 // stays in L2), so the column statistics never leave the workgroup, nothing is atomic and the results are bitwise
 // reproducible.  Backward: dgamma = sum dy xhat, dbeta = sum dy, dx = gamma rstd (dy - m dbeta / n - m xhat dgamma / n).
+// Degenerate masks: nn.BatchNorm1d refuses a training batch of fewer than two rows ("Expected more than 1 value per
+// channel").  A kernel inside a replayed graph cannot raise, so: n is clamped to >= 1 in both directions (a mask that
+// selects no row gives mean 0, var 0 and finite outputs instead of NaN), and the running buffers and the batch counter are
+// left untouched when n < 2 (no unbiased variance exists; nothing is written that would poison later evaluations).
 #include "common.h"
 
 namespace {
@@ -45,7 +49,8 @@ k_bn_rows_fwd(const float* __restrict__ x, const float* __restrict__ mask, const
         cnt += m;
     }
     const float4 tot = bn_block_sum(s, s_red);
-    const float n = bn_block_sum(make_float4(cnt, 0.f, 0.f, 0.f), s_red).x;
+    const float n_rows = bn_block_sum(make_float4(cnt, 0.f, 0.f, 0.f), s_red).x;
+    const float n = fmaxf(n_rows, 1.0f);
     const float inv_n = 1.0f / n;
     const float4 mean = make_float4(tot.x * inv_n, tot.y * inv_n, tot.z * inv_n, tot.w * inv_n);
     float4 ss = f4_zero();
@@ -69,8 +74,8 @@ k_bn_rows_fwd(const float* __restrict__ x, const float* __restrict__ mask, const
     if (threadIdx.x == 0) {
         *reinterpret_cast<float4*>(save_mean + c) = mean;
         *reinterpret_cast<float4*>(save_rstd + c) = rstd;
-        if (run_mean) {
-            const float unb = n > 1.0f ? n / (n - 1.0f) : 1.0f;   // nn.BatchNorm1d stores the unbiased variance
+        if (run_mean && n_rows >= 2.0f) {
+            const float unb = n / (n - 1.0f);                     // nn.BatchNorm1d stores the unbiased variance
             float4 rm = *reinterpret_cast<const float4*>(run_mean + c), rv = *reinterpret_cast<const float4*>(run_var + c);
             rm.x += momentum * (mean.x - rm.x); rm.y += momentum * (mean.y - rm.y);
             rm.z += momentum * (mean.z - rm.z); rm.w += momentum * (mean.w - rm.w);
@@ -100,7 +105,7 @@ k_bn_rows_bwd(const float* __restrict__ x, const float* __restrict__ dy, const f
         cnt += mask ? mask[i] : 1.0f;
     }
     const float4 db = bn_block_sum(s1, s_red), dg = bn_block_sum(s2, s_red);
-    const float inv_n = 1.0f / bn_block_sum(make_float4(cnt, 0.f, 0.f, 0.f), s_red).x;
+    const float inv_n = 1.0f / fmaxf(bn_block_sum(make_float4(cnt, 0.f, 0.f, 0.f), s_red).x, 1.0f);
     const float4 g4 = *reinterpret_cast<const float4*>(gamma + c);
     const float4 sc = make_float4(rstd.x * g4.x, rstd.y * g4.y, rstd.z * g4.z, rstd.w * g4.w);
     for (int64_t i = threadIdx.x; i < R; i += BN_THREADS) {

@@ -10,20 +10,33 @@
 
 namespace {
 
-// Dropout decision of element i: 32-bit avalanche (the murmur3 finaliser) of the element index combined with the two
-// halves of the 64-bit seed.  (Round 1 used the 64-bit splitmix finaliser: ~25 instructions per element with its 64-bit
-// multiplies -- on the [E * 8, 256] frame tensors the hash, not the memory pass, bounded drop_mean and the fused
-// hidden-layer kernels; this one is 8.)
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85EBCA6Bu;
-    h ^= h >> 13; h *= 0xC2B2AE35u;
-    h ^= h >> 16;
-    return h;
+// Dropout decision of element i: 32-bit avalanche (the murmur3 finaliser) of the element index, keyed by the 64-bit
+// seed.  (Round 1 used the 64-bit splitmix finaliser per ELEMENT: ~25 instructions with its 64-bit multiplies -- on the
+// [E * 8, 256] frame tensors the hash, not the memory pass, bounded drop_mean and the fused hidden-layer kernels; this
+// one is 8.)  The seed enters through a key that is derived ONCE per thread by the full 64-bit mix: an XOR offset of
+// the index AND the first multiplier of the avalanche.  With the seed only XOR-ed in before / after a fixed avalanche
+// (round 2) the masks of two steps, or of two dropout sites, were XOR-translates of one fixed pattern; a seed-dependent
+// odd multiplier makes them different functions of the index at no cost per element.
+struct DropKey {
+    uint32_t x, m, a;   // index offset, odd multiplier, addend of the high index word
+};
+__device__ __forceinline__ DropKey drop_key(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;            // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint64_t y = z + 0x9E3779B97F4A7C15ull;
+    y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
+    y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
+    y ^= y >> 31;
+    return DropKey{(uint32_t)z, (uint32_t)(z >> 32) | 1u, (uint32_t)y | 1u};
 }
 // keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
-__device__ __forceinline__ float keep_scale(uint64_t seed, uint64_t i, uint32_t threshold, float inv_keep) {
-    const uint32_t lo = (uint32_t)i, hi = (uint32_t)(i >> 32);
-    const uint32_t h = mix32((lo ^ (uint32_t)seed) + hi * 0x9E3779B1u) ^ (uint32_t)(seed >> 32);
+__device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
+    uint32_t h = ((uint32_t)i ^ key.x) + (uint32_t)(i >> 32) * key.a;
+    h ^= h >> 16; h *= key.m;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
     return h >= threshold ? inv_keep : 0.f;
 }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
@@ -31,7 +44,7 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 __global__ void __launch_bounds__(256)
 k_swiglu_drop_fwd(const float* __restrict__ pre, int64_t R, int H, const int64_t* __restrict__ seed_ptr,
                   uint32_t threshold, float inv_keep, float* __restrict__ out) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int h4 = H >> 2;
     const int64_t total = R * h4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -53,7 +66,7 @@ k_swiglu_drop_fwd(const float* __restrict__ pre, int64_t R, int H, const int64_t
 __global__ void __launch_bounds__(256)
 k_swiglu_drop_bwd(const float* __restrict__ pre, const float* __restrict__ dout, int64_t R, int H,
                   const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float* __restrict__ dpre) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int h4 = H >> 2;
     const int64_t total = R * h4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(256)
 k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F_rt, int C, const int64_t* __restrict__ seed_ptr,
                 uint32_t threshold, float inv_keep, float* __restrict__ out) {
     const int F = FT ? FT : F_rt;
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int c4 = C >> 2;
     const int64_t total = R * c4;
     const float inv_f = 1.0f / (float)F;
@@ -115,7 +128,7 @@ k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F_rt, int C, const i
 __global__ void __launch_bounds__(256)
 k_drop_mean_bwd(const float* __restrict__ dout, int64_t R, int F, int C, const int64_t* __restrict__ seed_ptr,
                 uint32_t threshold, float inv_keep, float* __restrict__ dx) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int c4 = C >> 2;
     const int64_t total = R * F * c4;
     const float inv_f = 1.0f / (float)F;
@@ -346,7 +359,7 @@ k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, co
                    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t E,
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
                    float* __restrict__ out) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FhLane L = fh_load(w3, gamma, beta, lane);
     float2 wxa = make_float2(0.f, 0.f), wxb = make_float2(0.f, 0.f);
@@ -405,7 +418,7 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
                    float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ dextra, float* __restrict__ slab) {
     __shared__ float s_red[FP_WAVES][VEC ? 24 : 16][64];
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const FhLane L = fh_load(w3, gamma, nullptr, lane);
     float aw[4][3];              // d W3 of channels (a0, a1, b0, b1) x d
@@ -822,7 +835,7 @@ k_rowdot_bwd(const float* __restrict__ x, const float* __restrict__ U, const flo
 }
 
 template <int NV>
-__device__ __forceinline__ void rd_dropout(RdRow<NV>& xr, uint64_t seed, int64_t r, int C, int lane, uint32_t threshold,
+__device__ __forceinline__ void rd_dropout(RdRow<NV>& xr, const DropKey& seed, int64_t r, int C, int lane, uint32_t threshold,
                                            float inv_keep) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -837,7 +850,7 @@ template <int NV>
 __global__ void __launch_bounds__(RD_THREADS)
 k_gate_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ res,
            int64_t R, int C, const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float* __restrict__ out) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RdRow<NV> wr;
     rd_load<NV>(w, C, lane, wr);
@@ -866,7 +879,7 @@ k_gate_bwd(const float* __restrict__ x, const float* __restrict__ w, const float
            float* __restrict__ slab) {
     __shared__ float4 s_red[RD_THREADS];
     __shared__ float s_b[RD_WAVES];
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RdRow<NV> wr, aw;
     rd_load<NV>(w, C, lane, wr);
@@ -1067,7 +1080,7 @@ __global__ void __launch_bounds__(FP_THREADS)
 k_edge_hidden_fwd(const float* __restrict__ A, const float* __restrict__ B, const float* __restrict__ Cf,
                   const int* __restrict__ nbr, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t N, int K,
                   const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps, float* __restrict__ out) {
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float g0 = gamma[2 * lane], g1 = gamma[2 * lane + 1], be0 = beta[2 * lane], be1 = beta[2 * lane + 1];
     for (int64_t i = (int64_t)blockIdx.x * FP_WAVES + wave; i < N; i += (int64_t)gridDim.x * FP_WAVES) {
@@ -1104,7 +1117,7 @@ k_edge_hidden_bwd(const float* __restrict__ A, const float* __restrict__ B, cons
                   const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
                   float* __restrict__ dpre, float* __restrict__ dA, float* __restrict__ slab) {
     __shared__ float s_red[FP_WAVES][4][64];
-    const uint64_t seed = threshold ? (uint64_t)*seed_ptr : 0;
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float g0 = gamma[2 * lane], g1 = gamma[2 * lane + 1];
     float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;

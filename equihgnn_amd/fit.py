@@ -178,9 +178,25 @@ class BucketedLoader:
                 ent[1].synchronize()          # its previous host-to-device copy has finished (the host buffer is free)
             return ent
 
+        stop = threading.Event()        # set when the consumer leaves early: the producer must not block on q.put
+
+        def put(item) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def produce():
+            # An exception here (pinned-memory OOM, a HIP error on the side stream, a ValueError from collate) must end
+            # the epoch LOUDLY: it travels through the queue and is re-raised by the consumer.  Swallowed, the epoch
+            # would just be shorter on this rank, and under data parallelism the next all-reduce would hang.
             try:
                 for b in batches:
+                    if stop.is_set():
+                        return
                     ent = stage(len(b))
                     t0 = time.perf_counter()
                     self.store.collate(b, pad_to=tgt, out=ent[0])
@@ -195,9 +211,11 @@ class BucketedLoader:
                             ev = torch.cuda.Event()
                             ev.record(side)
                             ent[1] = ev
-                    q.put(ent)
-            finally:
-                q.put(None)
+                    if not put(ent):
+                        return
+                put(None)
+            except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
+                put(exc)
 
         # two Python threads share the interpreter lock; with the default 5 ms switch interval the training thread (a few
         # hundred microseconds of work per 1.5 ms step) can wait milliseconds for the collating thread to yield it
@@ -207,6 +225,14 @@ class BucketedLoader:
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         prev = None
+
+        def fresh(b):
+            # The ring hands the SAME HBatch objects out again and again (prefetch + 3 per shape, kept across epochs),
+            # and HyperIndex.from_batch caches the batch's CSRs / kNN lists on the object: a refilled buffer must not
+            # carry the index of the molecules it held before.
+            b._hyper_index = None
+            return b
+
         try:
             while True:
                 ent = q.get()
@@ -216,18 +242,32 @@ class BucketedLoader:
                     prev[3] = ev
                 if ent is None:
                     break
+                if isinstance(ent, BaseException):
+                    raise RuntimeError("BucketedLoader: the prefetch thread failed") from ent
                 if self.device is None:
-                    yield ent[0]
+                    yield fresh(ent[0])
                     continue
                 if not cuda:
                     yield ent[0].to(self.device)
                     continue
                 torch.cuda.current_stream(self.device).wait_event(ent[1])
                 prev = ent
-                yield ent[2]
-            th.join()
+                yield fresh(ent[2])
         finally:
+            # also reached when the consumer abandons the generator (an exception in step(), a `break`): release the
+            # producer, which may be blocked on a full queue holding ring entries the next __iter__ shares
+            stop.set()
+            th.join()
             sys.setswitchinterval(old_interval)
+
+
+def _drop_index(data):
+    """A loader may hand the same batch OBJECT out with new contents: the per-batch index cached on it
+    (HyperIndex.from_batch) belongs to the previous contents."""
+    try:
+        data._hyper_index = None
+    except Exception:
+        pass
 
 
 def _real(out, data):
@@ -264,6 +304,7 @@ class Fitter:
         scale = self.std if self.std else 1.0          # main.py:67-70: `if self.std:`
         with torch.no_grad():
             for data in loader:
+                _drop_index(data)
                 out, y = _real(self.model(data), data)
                 self.metrics.update(out * scale, y * scale)
         self.model.train()
@@ -307,6 +348,7 @@ class Fitter:
         preds, truth = [], []
         with torch.no_grad():
             for data in test_loader:
+                _drop_index(data)
                 out, y = _real(self.model(data), data)
                 self.metrics.update(out * scale, y * scale)
                 preds.append(out.detach().float().cpu())

@@ -55,6 +55,7 @@ class CSR:
     n_rows: int
     nnz: int
     entry_w: Optional[torch.Tensor] = None    # per-entry mean weights 1 / deg(col[q]) w.r.t. the TRANSPOSED CSR (entry_weights)
+    entry_w_of: Optional[torch.Tensor] = None  # the rowptr tensor of the partner CSR `entry_w` was computed against
 
 
 def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1) -> CSR:
@@ -133,6 +134,7 @@ def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr
         ew_v = torch.empty(max(by_v.nnz, 1), dtype=torch.float32, device=dev)
         ew_e = torch.empty(max(by_e.nnz, 1), dtype=torch.float32, device=dev)
         by_v.entry_w, by_e.entry_w = ew_v, ew_e
+        by_v.entry_w_of, by_e.entry_w_of = by_e.rowptr, by_v.rowptr
     hip.check(hip.lib().hg_index_aux(_ptr(vertex), _ptr(edges), nnz, _ptr(batch.contiguous()) if batch is not None else None,
                                      n_nodes, n_edges, _ptr(rowptr_v), _ptr(rowptr_e), _ptr(v32), _ptr(e32), _ptr(b32),
                                      _ptr(has_v), _ptr(has_e), _ptr(col_v), _ptr(col_e), _ptr(ew_v), _ptr(ew_e), _stream(dev)),
@@ -312,11 +314,12 @@ def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=
 def entry_weights(csr: CSR, csr_t: CSR) -> torch.Tensor:
     """w[q] = 1 / max(deg_t(csr.col[q]), 1): the mean weights of csr's entries with respect to the rows of ``csr_t``
     (hg_entry_weights), cached on ``csr``."""
-    if csr.entry_w is None:
+    if csr.entry_w is None or csr.entry_w_of is not csr_t.rowptr:
+        # (the cache is only valid for the partner it was built against: another csr_t has other degrees)
         w = torch.empty(max(csr.nnz, 1), dtype=torch.float32, device=csr.col.device)
         hip.check(hip.lib().hg_entry_weights(_ptr(csr.col), _ptr(csr_t.rowptr), csr.nnz, _ptr(w), _stream(w.device)),
                   "hg_entry_weights")
-        csr.entry_w = w
+        csr.entry_w, csr.entry_w_of = w, csr_t.rowptr
     return csr.entry_w
 
 

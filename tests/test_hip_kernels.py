@@ -1072,6 +1072,32 @@ def test_faformer_elementwise_kernels():
                                atol=1e-7, rtol=1e-6)
 
 
+def test_dropout_masks_of_different_seeds_are_independent():
+    """with the seed merely XOR-ed around a fixed avalanche, the masks of two steps / two dropout sites are
+    XOR-translates of one pattern (mask_s(i) = M(i ^ d) ^ c).  The seed now keys the avalanche's multiplier: for seed
+    pairs that differ in the low word only, in the high word only, and in one bit, (i) the masks agree on the
+    p^2 + (1-p)^2 fraction of elements independence predicts, and (ii) no index translation i -> i ^ d aligns them."""
+    ops = _ops()
+    n, p = 1 << 18, 0.25
+    ones = torch.ones(n // 256, 1, 256, device=DEV)
+
+    def mask(seed):
+        s = torch.tensor([seed], dtype=torch.int64, device=DEV)
+        return (ops.dropout_mean(ones, p, s).reshape(-1) != 0).cpu().numpy()
+
+    expect = p * p + (1 - p) * (1 - p)
+    sigma = (expect * (1 - expect) / n) ** 0.5
+    base = 0x1234_5678_9ABC_DEF0
+    for other in (base ^ 0x5A5A, base ^ (0x77 << 32), base ^ 1, base + (1 << 40), 0, 1):
+        a, b = mask(base), mask(other)
+        assert abs(a.mean() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+        assert abs((a == b).mean() - expect) < 6 * sigma, hex(other)
+        d = (base ^ other) & (n - 1)                       # the translation the round-2 hash would have needed
+        idx = np.arange(n) ^ d
+        assert abs((a[idx] == b).mean() - expect) < 6 * sigma, hex(other)
+        assert abs((a[idx] != b).mean() - (1 - expect)) < 6 * sigma     # (nor its complement: no XOR of the hash value)
+
+
 @pytest.mark.parametrize("E,p,bcast", [(37, 0.0, False), (1000, 0.1, False), (300, 0.1, True), (5, 0.0, True),
                                        (700, 0.1, "extra"), (33, 0.0, "extra")])
 def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):

@@ -1,4 +1,5 @@
-"""BASELINE configs 4 and 5 at their FULL per-rank sizes, where the CPU oracle no longer fits (the reference's dense
+"""BASELINE configs 3, 4 and 5 at their FULL per-rank sizes (config 3: equiformer_equihnns, QM9-like, batch 128 at
+the scripts' hidden width 256, where the oracle's per-edge radial weights are 9.7 GB per pair type), and 4 / 5 where the CPU oracle no longer fits (the reference's dense
 [N, N] neighbour search needs > 10 GB at 31 k atoms): size-independent properties of the HIP models on the very
 batches bench.py times -- PCQM4Mv2-like molecules, batch 1024 (egnn_equihnns; ~31 k atoms: cell-grid neighbour
 search, chip-wide CSR build for the 67 k incidences and the 490 k-entry transposed neighbour graph) and
@@ -14,14 +15,14 @@ from common import fill_state_dict  # noqa: E402
 DEV = "cuda:0"
 
 
-def _setup(method, bs, seed, train=True):
+def _setup(method, bs, seed, train=True, flavour="pcqm"):
     from equihgnn_amd.batch import synth_batch
     from equihgnn_amd.models import MODELS
     from equihgnn_amd.registry import default_args
     m = MODELS[method](1, default_args(method=method))
     fill_state_dict(m, seed)
     m.to(DEV).train(train)
-    return m, synth_batch(bs, seed, "pcqm")
+    return m, synth_batch(bs, seed, flavour)
 
 
 def _run(m, b, grads=True):
@@ -156,3 +157,80 @@ def test_c5_full_batch_properties():
     out_r, _ = _run(m, br.to(DEV), grads=False)
     err = (out_r - out).abs().cpu().numpy()
     assert np.median(err) < 5e-5 * scale and (err < 2e-3 * scale).mean() > 0.98
+
+
+def test_c3_full_batch_properties():
+    """BASELINE config 3 at its own size: equiformer_equihnns, QM9-like, 128 molecules, hidden 256 (the width of
+    scripts/run_qm9_3d.sh:10-31; equihnn_equiformer.py:37-49), training mode.  Bitwise run-to-run reproducibility of
+    outputs and every gradient, padding to the hipGraph bucket shapes leaves outputs and gradients unchanged, a rigid
+    motion of the coordinates moves the outputs by rounding only, a permutation of the incidence list likewise."""
+    from equihgnn_amd.batch import HBatch, bucket_sizes, pad_batch
+    from equihgnn_amd.registry import default_args
+    assert default_args(method="equiformer_equihnns").MLP_hidden == 256
+    m, b = _setup("equiformer_equihnns", 128, 3000, flavour="qm9")
+    d = b.to(DEV)
+    out, g = _run(m, d)
+    assert out.shape == (128,) and bool(torch.isfinite(out).all())
+    assert float(out.std()) > 1e-3                               # the molecules are told apart: the checks below bite
+    out2, g2 = _run(m, d)
+    assert torch.equal(out, out2)
+    assert set(g) == set(g2) and all(torch.equal(g[n], g2[n]) for n in g)
+    assert all(bool(torch.isfinite(t).all()) for t in g.values())
+    p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz)).to(DEV)
+    p.num_real_graphs = 128
+    out_p, g_p = _run_padded(m, p, 128)
+    scale = max(1.0, float(out.abs().max()))
+    np.testing.assert_allclose(out_p[:128].cpu().numpy(), out.cpu().numpy(), atol=1e-5 * scale, rtol=0)
+    gmax = max(float(t.abs().max()) for t in g.values())
+    assert set(g_p) == set(g)
+    for n in g:
+        assert float((g_p[n] - g[n]).abs().max()) <= 2e-4 * max(float(g[n].abs().max()), 1e-3 * gmax), n
+    perm = torch.from_numpy(np.random.default_rng(1).permutation(b.nnz))
+    bp = HBatch(**{f: getattr(b, f) for f in b.__dataclass_fields__})
+    bp.edge_index0, bp.edge_index1 = b.edge_index0[perm], b.edge_index1[perm]
+    out_perm, _ = _run(m, bp.to(DEV), grads=False)
+    np.testing.assert_allclose(out_perm.cpu().numpy(), out.cpu().numpy(), atol=1e-5 * scale, rtol=0)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(2)))
+    br = HBatch(**{f: getattr(b, f) for f in b.__dataclass_fields__})
+    br.pos = b.pos @ q + torch.tensor([0.25, 1.5, -0.75])
+    out_r, _ = _run(m, br.to(DEV), grads=False)
+    err = (out_r - out).abs().cpu().numpy()
+    assert np.median(err) < 2e-5 * scale and (err < 1e-3 * scale).mean() > 0.98
+
+
+def test_c3_full_batch_graphed_step_matches_eager():
+    """Config 3 at its own size through the product's training path: three Adam steps of GraphedTrainStep (bootstrap,
+    capture, replay) on the padded batch against eager autograd + torch.optim.Adam on a copy of the model."""
+    import copy
+
+    from equihgnn_amd.batch import bucket_sizes, pad_batch
+    from equihgnn_amd.trainer import GraphedTrainStep
+    m1, b = _setup("equiformer_equihnns", 128, 3000, flavour="qm9")
+    m2 = copy.deepcopy(m1)
+    p = pad_batch(b, *bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz)).to(DEV)
+    p.num_real_graphs = 128
+    tr = GraphedTrainStep(m1, lr=1e-4)
+    losses = [float(tr.step(p)) for _ in range(4)]
+    ref, opt, g_first = [], None, {}
+    for _ in range(4):
+        for q in m2.parameters():
+            q.grad = None
+        p._hyper_index = None
+        loss = torch.nn.functional.mse_loss(m2(p)[:128], p.y[:128])
+        loss.backward()
+        if opt is None:
+            opt = torch.optim.Adam([q for q in m2.parameters() if q.grad is not None], lr=1e-4)
+            g_first = {n: q.grad.detach().abs().clone() for n, q in m2.named_parameters() if q.grad is not None}
+        opt.step()
+        ref.append(float(loss))
+    tr.close()
+    np.testing.assert_allclose(losses, ref, rtol=5e-5, atol=1e-6)
+    assert losses[-1] < losses[0]
+    gmax = max(float(t.max()) for t in g_first.values())
+    for (n, a), r in zip(m1.named_parameters(), m2.parameters()):
+        if n not in g_first:
+            assert torch.equal(a.detach(), r.detach()), n
+            continue
+        sig = (g_first[n] > 1e-4 * gmax).cpu().numpy()       # (entries whose gradient is rounding noise move by +-lr)
+        np.testing.assert_allclose(a.detach().cpu().numpy()[sig], r.detach().cpu().numpy()[sig], atol=2e-5, rtol=1e-4,
+                                   err_msg=n)
