@@ -1,0 +1,477 @@
+// fp32 GEMM on the bf16 matrix cores with fp32-grade results ("x6": six bf16 products per fp32 product):
+//
+//     C[M,N] = act( alpha * op(A)[M,K] . op(B)[K,N]  (+ beta * D[M,N])  (+ bias[N]) )
+//
+// Stands where the reference has nn.Linear / F.linear and autograd's input-gradient products (mlp.py:91-99,
+// conv.py:169-182, egnn_layer.py:180-208,298-310,360-362, equiformer_layer.py:376-383, fa_former_layer.py:241-289): the
+// "dense per-type linear mixes" of the north star.
+//
+// Why.  gfx950 has no TF32-like mode; its fp32-input MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 VALU rate,
+// 64 FLOP/clk/SIMD = 157 TFLOP/s, and the tuned library reaches 100-129 TFLOP/s of it on this model's shapes.  The
+// bf16 MFMA (v_mfma_f32_16x16x32_bf16) is 16x faster.  An fp32 number splits EXACTLY into three bf16 numbers,
+//     a = a0 + a1 + a2,   a0 = top 16 bits of a (truncated: 8 significand bits),  a1 = top 16 bits of (a - a0),
+//                         a2 = a - a0 - a1  (at most 8 significant bits are left: exactly a bf16 number),
+// so a.b = sum_ij ai.bj, and the six products with i + j <= 2 (a0b0; a0b1, a1b0; a0b2, a2b0, a1b1) carry everything
+// down to 2^-16 of |a||b|; the three dropped ones are below 2^-22 |a||b| (typically 2^-24: one fp32 rounding of the
+// product).  Every bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result has the error
+// of an fp32 dot product (tests/test_hip_kernels.py compares it with the fp32-MFMA library GEMM against float64: the
+// same error or less) at 16 / 6 = 2.7x the fp32 matrix rate.  No fp16 variant: its exponent range would need scaling.
+//
+// Structure.  256 threads = 4 wavefronts as 2 x 2; block tile 64 x 64 (wave tile 32 x 32) or 128 x 128 (64 x 64);
+// K walked 32 at a time (one MFMA K).  Per K step the A and B tiles go global (fp32, coalesced 128-B row segments)
+// -> registers (issued before the MFMAs of the previous step) -> split into the three bf16 planes (5.5 VALU
+// operations per element: and, sub, and, sub and three byte permutes per element pair) -> LDS in MFMA OPERAND ORDER:
+// the 16 rows x 32 k of one operand fragment are 1 KiB, lane (q = k / 8, r = row) owns 16 bytes at slot
+// q * 16 + (r ^ 2q) -- the xor keeps both the 8-byte split writes (a 16-lane group covers two rows x four q) and the
+// ds_read_b128 fragment reads (hardware lane groups {0-3, 12-15, 20-27}, ...) free of bank conflicts.  A wavefront
+// reads its fragments with one ds_read_b128 each and issues 6 MFMAs per output tile and K step.  Operands whose K index
+// is the slow one in memory (B of an input gradient dY . W, both operands of a weight gradient) are transposed in
+// registers on the way in (a thread loads a 4 x RR block and packs along k).
+//
+// The MFMA is issued with the operands swapped (D' = Bfrag . Afrag = C^T tile): a lane then holds four CONSECUTIVE
+// columns of one output row, so the epilogue reads the addend / bias and stores the result as float4.
+//
+// Results are bitwise reproducible (fixed k order, no atomics, no split-K).  Up to 8 problems share a launch.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GX_THREADS = 768;      // wavefronts 0-3 multiply (2 x 2), wavefronts 4-11 load, split and stage (two groups)
+constexpr int GX_BK = 32;
+constexpr int GX_MAXP = 8;
+
+enum : int { GX_TRANS_A = 1, GX_TRANS_B = 2, GX_RELU = 4 };
+
+struct GxProb {
+    const float* A;      // !TRANS_A: [M, K] (lda);  TRANS_A: [K, M] (lda)
+    const float* B;      // TRANS_B:  [N, K] (ldb) -- an nn.Linear weight used as x W^T;  !TRANS_B: [K, N] (ldb)
+    const float* D;      // optional addend [M, N] (ldd), may alias C
+    const float* bias;   // optional [N]
+    float* C;            // [M, N] (ldc)
+    int64_t lda, ldb, ldc, ldd;
+    int M, N, K;
+    float alpha, beta;
+    int flags;
+    int first_tile, tiles_n, n_tiles;
+};
+
+struct GxBatch {
+    GxProb p[GX_MAXP];
+    int n;
+    int total_tiles;
+};
+
+#ifdef GX_STAMPS   // diagnostic build only (tools/gemm_stamps.py): per-wavefront s_memtime stamps of the pipeline phases
+__device__ unsigned long long* gx_stamp_buf = nullptr;
+#define GX_STAMP(slot)                                                                                  \
+    do {                                                                                                \
+        if (gx_stamp_buf && (threadIdx.x & 63) == 0 && (slot) < 64)                                      \
+            gx_stamp_buf[((size_t)blockIdx.x * 12 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GX_STAMP(slot) do { } while (0)
+#endif
+
+__device__ __forceinline__ uint32_t fbits(float x) { return __float_as_uint(x); }
+
+// (x0, x1) -> their three bf16 planes, packed as bf16x2 (x0 in the low half)
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+#ifdef GX_ABLATE_SPLIT
+    p0 = fbits(x0); p1 = fbits(x1); p2 = fbits(x0) ^ fbits(x1);
+    return;
+#endif
+    const uint32_t u0 = fbits(x0), u1 = fbits(x1);
+    p0 = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+    const uint32_t v0 = fbits(r0), v1 = fbits(r1);
+    p1 = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u), s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+    p2 = __builtin_amdgcn_perm(fbits(s1), fbits(s0), 0x07060302u);
+}
+
+// LDS image of one operand tile (R rows x 32 k): [plane 3][row block R / 32][k half 2][slot 64] x 16 bytes -- the
+// 1 KiB of one v_mfma_f32_32x32x16_bf16 operand fragment (32 rows x 16 k) is contiguous, lane (h = k / 8, r = row)
+// owns 16 bytes at slot h * 32 + (r ^ 2q), q = 2 * (k half) + h.  `k4` = k / 4 in 0 .. 7.
+template <int R>
+__device__ __forceinline__ int slot_index(int plane, int row, int k4) {
+    const int q = k4 >> 1;                      // 2 * khalf + h
+    return ((plane * (R / 32) + (row >> 5)) * 2 + (k4 >> 2)) * 64 + (q & 1) * 32 + ((row & 31) ^ (2 * q));
+}
+
+// A tile's global loads never branch: rows / columns past the matrix edge are CLAMPED to the last valid one (their
+// products only reach output rows / columns that the epilogue does not store), and only the last, partial K step of a
+// K that is not a multiple of 32 zero-fills (an unconditional load from a clamped address, then a select).
+// (Measured and not kept: two tiles per wavefront in flight -- three register sets in rotation, or inline-asm loads
+// with hand-counted vmcnt.  hipcc drains every outstanding load before the first use of the older tile, and with the
+// waits counted by hand the stager step did not get shorter either: what bounds a step is LDS bandwidth, 6 bytes
+// written and 12 read per staged element, not memory latency.)
+
+// ---- operand whose K index is CONTIGUOUS in memory: rows [row0, row0 + R) of src[rows_total][K] -------------------
+// a wavefront-load covers 8 rows x 128 bytes (whole cache lines)
+template <int R>
+struct LoadKC {
+    static constexpr int NL = R / 32;
+    const float* p[NL];
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld, int row0, int rows_total) {
+        const int t = threadIdx.x & 255;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int row = row0 + (t >> 3) + 32 * i;
+            row = row < rows_total ? row : rows_total - 1;
+            p[i] = src + (int64_t)row * ld + (t & 7) * 4;
+        }
+    }
+    struct Regs { float4 v[NL]; };
+    __device__ __forceinline__ void fetch(Regs& r, int kt) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) r.v[i] = *reinterpret_cast<const float4*>(p[i] + kt * GX_BK);
+    }
+    __device__ __forceinline__ void fetch_tail(Regs& r, int kt, int rem) const {   // rem = K - kt * 32 in (0, 32)
+        const int koff = (int)(threadIdx.x & 7) * 4;
+        const bool ok = koff < rem;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {       // lanes past K re-read the step's first columns, then select zero
+            const float4 x = *reinterpret_cast<const float4*>(p[i] + kt * GX_BK - (ok ? 0 : koff));
+            r.v[i] = ok ? x : f4_zero();
+        }
+    }
+    static __device__ __forceinline__ void store(const Regs& r, uint4* __restrict__ s) {
+        const int t = threadIdx.x & 255, k4 = t & 7;
+        uint2* d = reinterpret_cast<uint2*>(s);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = (t >> 3) + 32 * i;
+            uint32_t a0, a1, a2, b0, b1, b2;
+            split_pair(r.v[i].x, r.v[i].y, a0, a1, a2);
+            split_pair(r.v[i].z, r.v[i].w, b0, b1, b2);
+            d[slot_index<R>(0, row, k4) * 2 + (k4 & 1)] = make_uint2(a0, b0);
+            d[slot_index<R>(1, row, k4) * 2 + (k4 & 1)] = make_uint2(a1, b1);
+            d[slot_index<R>(2, row, k4) * 2 + (k4 & 1)] = make_uint2(a2, b2);
+        }
+    }
+};
+
+// ---- operand whose K index is the SLOW one: columns [col0, col0 + R) of src[K][cols_total] ----------------------------
+// a thread takes 4 (k) x 2 (columns) per pass of 64 columns; the 4 k values of a column are packed along k on the way
+// into LDS (a wavefront-load covers 2 k rows x 256 bytes)
+template <int R>
+struct LoadKS {
+    static constexpr int NP = R / 64;
+    const float* p[NP];
+    int64_t ld;
+    __device__ __forceinline__ void init(const float* __restrict__ src, int64_t ld_, int col0, int cols_total) {
+        const int t = threadIdx.x & 255;
+        ld = ld_;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            int c = col0 + 64 * i + (t & 31) * 2;
+            c = c < cols_total ? c : cols_total - 2;          // (cols_total is a multiple of 4)
+            p[i] = src + (int64_t)((t >> 5) * 4) * ld_ + c;
+        }
+    }
+    struct Regs { float2 v[NP][4]; };
+    __device__ __forceinline__ void fetch(Regs& r, int kt) const {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                r.v[i][kk] = *reinterpret_cast<const float2*>(p[i] + ((int64_t)kt * GX_BK + kk) * ld);
+    }
+    __device__ __forceinline__ void fetch_tail(Regs& r, int kt, int rem) const {
+        const int kb4 = (int)((threadIdx.x & 255) >> 5) * 4, n_ok = rem - kb4;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {   // rows past K re-read the step's first row, then select zero
+                const bool ok = kk < n_ok;
+                const float2 x = *reinterpret_cast<const float2*>(p[i] + ((int64_t)kt * GX_BK + (ok ? kk : -kb4)) * ld);
+                r.v[i][kk] = ok ? x : make_float2(0.f, 0.f);
+            }
+    }
+    static __device__ __forceinline__ void store(const Regs& r, uint4* __restrict__ s) {
+        const int t = threadIdx.x & 255, k4 = t >> 5;
+        uint2* d = reinterpret_cast<uint2*>(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            uint32_t a0, a1, a2, b0, b1, b2;
+            const int row = 64 * i + (t & 31) * 2;
+            split_pair(r.v[i][0].x, r.v[i][1].x, a0, a1, a2);
+            split_pair(r.v[i][2].x, r.v[i][3].x, b0, b1, b2);
+            d[slot_index<R>(0, row, k4) * 2 + (k4 & 1)] = make_uint2(a0, b0);
+            d[slot_index<R>(1, row, k4) * 2 + (k4 & 1)] = make_uint2(a1, b1);
+            d[slot_index<R>(2, row, k4) * 2 + (k4 & 1)] = make_uint2(a2, b2);
+            split_pair(r.v[i][0].y, r.v[i][1].y, a0, a1, a2);
+            split_pair(r.v[i][2].y, r.v[i][3].y, b0, b1, b2);
+            d[slot_index<R>(0, row + 1, k4) * 2 + (k4 & 1)] = make_uint2(a0, b0);
+            d[slot_index<R>(1, row + 1, k4) * 2 + (k4 & 1)] = make_uint2(a1, b1);
+            d[slot_index<R>(2, row + 1, k4) * 2 + (k4 & 1)] = make_uint2(a2, b2);
+        }
+    }
+};
+
+template <int R, bool KS> struct Loader;
+template <int R> struct Loader<R, false> : LoadKC<R> {};
+template <int R> struct Loader<R, true> : LoadKS<R> {};
+
+// block id -> logical tile such that consecutive logical tiles (the column tiles of one row tile, which share the A
+// rows) run on ONE XCD's L2 (blocks are dealt round-robin over the 8 XCDs; bijective for any grid size)
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int xcd = b & 7, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// MT x NT: 32 x 32 MFMA tiles per multiplying wavefront; the four of them sit 2 x 2: block tile 64 MT x 64 NT
+template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS>
+__global__ void __launch_bounds__(GX_THREADS, MINW)
+k_gemm_x6(const GxBatch batch) {
+    constexpr int BM = 64 * MT, BN = 64 * NT;
+    constexpr int SA = 3 * (BM / 32) * 2 * 64, SB = 3 * (BN / 32) * 2 * 64;       // uint4 per stage
+    __shared__ uint4 s_mem[S * (SA + SB)];                                         // ring of stages, each [A | B]
+
+    const int lt = xcd_remap((int)blockIdx.x, batch.total_tiles);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GX_MAXP; ++i)
+        if (i < batch.n && lt >= batch.p[i].first_tile) pi = i;
+    const GxProb P = batch.p[pi];                  // a COPY in registers: a reference is re-read from the kernarg
+                                                   // segment after every global store (possible alias), behind vmcnt(0)
+    const int tile = lt - P.first_tile;
+    const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
+    const int M = P.M, N = P.N, K = P.K;
+    const int KT = K / GX_BK, rem = K - KT * GX_BK;
+    const int NS = KT + (rem > 0 ? 1 : 0);                  // K steps; the last one may be partial (zero-filled)
+
+    // Two roles, one barrier per K step.  During step k the four MULTIPLIERS (wavefronts 0-3) read the fragments of
+    // tile k from ring stage k % S and issue its MFMAs; the STAGERS (wavefronts 4-11, two groups of four) keep the
+    // ring S - 1 tiles ahead: the group whose turn it is splits tile k + S - 1 -- which it requested from global memory
+    // during the PREVIOUS step -- into stage (k + S - 1) % S, the stage the multipliers left at the last barrier, while
+    // the other group requests tile k + S.  A stager is plain synchronous code (load, wait, split, store): the two
+    // groups alternating hide the memory latency, not a register pipeline, so the compiler's own waits are exact.
+    // A SIMD hosts one multiplier and two stagers per resident block; the hardware interleaves the stagers' VALU work
+    // with the multipliers' MFMAs (the 32 x 32 x 16 MFMA holds the vector issue port for 8 of its 32 cycles).
+    GX_STAMP(0);
+    if (threadIdx.x >= 256) {
+        using LA = Loader<BM, A_KS>;
+        using LB = Loader<BN, B_KS>;
+        LA la;
+        LB lb;
+        la.init(P.A, P.lda, m0, M);
+        lb.init(P.B, P.ldb, n0, N);
+        typename LA::Regs ra;
+        typename LB::Regs rb;
+        const int grp = (int)(threadIdx.x >> 8) - 1;        // 0 or 1 (wavefront-uniform)
+        auto fetch = [&](int w) {
+            if (w < KT) {
+                la.fetch(ra, w);
+                lb.fetch(rb, w);
+            } else if (w < NS) {
+                la.fetch_tail(ra, w, rem);
+                lb.fetch_tail(rb, w, rem);
+            }
+        };
+        auto stage = [&](int w) {
+            if (w >= NS) return;
+            uint4* st = s_mem + (w % S) * (SA + SB);
+            LA::store(ra, st);
+            LB::store(rb, st + SA);
+        };
+        // tiles 0 .. S-2 before the first barrier (even tiles by group 0, odd ones by group 1), and the request for
+        // tile S - 1, which is split during step 0
+#pragma unroll
+        for (int w = 0; w < S - 1; ++w)
+            if ((w & 1) == grp) { fetch(w); stage(w); }
+        if (((S - 1) & 1) == grp) fetch(S - 1);
+        GX_STAMP(1);
+        __syncthreads();
+        GX_STAMP(2);
+        for (int k = 0; k < NS; ++k) {
+            const int w = k + S - 1;
+            if ((w & 1) == grp) stage(w);
+            else fetch(w + 1);
+            GX_STAMP(k < 14 ? 3 + 2 * k : 63);
+            __syncthreads();
+            GX_STAMP(k < 14 ? 4 + 2 * k : 63);
+        }
+        GX_STAMP(31);
+        return;
+    }
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fh = lane >> 5, fr = lane & 31;
+    const int frag_off0 = fh * 32 + (fr ^ (2 * fh)), frag_off1 = 64 + fh * 32 + (fr ^ (2 * (2 + fh)));   // k halves
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+    GX_STAMP(1);
+    __syncthreads();
+    GX_STAMP(2);
+    for (int k = 0; k < NS; ++k) {
+        // one K step from ring stage k % S: 6 x (MT + NT) fragment reads, 12 x MT x NT MFMAs (smallest terms first)
+        const uint4* __restrict__ sa = s_mem + (k % S) * (SA + SB);
+        const uint4* __restrict__ sb = sa + SA;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {            // the two 16-deep halves of the step, one after the other (registers)
+            const int off = kh ? frag_off1 : frag_off0;
+            bf16x8 fa[3][MT], fb[3][NT];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    fa[p][m] = __builtin_bit_cast(bf16x8, sa[(p * (BM / 32) + wm * MT + m) * 128 + off]);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    fb[p][n] = __builtin_bit_cast(bf16x8, sb[(p * (BN / 32) + wn * NT + n) * 128 + off]);
+            }
+#define GX_MM(PA, PB)                                                                                              \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                             \
+            _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                             \
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][n], fa[PA][m], acc[m][n], 0, 0, 0);
+#ifndef GX_ABLATE_MFMA
+            GX_MM(1, 1) GX_MM(0, 2) GX_MM(2, 0) GX_MM(0, 1) GX_MM(1, 0) GX_MM(0, 0)
+#else
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+                _Pragma("unroll") for (int m = 0; m < MT; ++m) { asm volatile("" :: "v"(fa[p][m])); }
+                _Pragma("unroll") for (int n = 0; n < NT; ++n) { asm volatile("" :: "v"(fb[p][n])); }
+            }
+#endif
+#undef GX_MM
+        }
+        GX_STAMP(k < 14 ? 3 + 2 * k : 63);
+        __syncthreads();
+        GX_STAMP(k < 14 ? 4 + 2 * k : 63);
+    }
+
+    // epilogue.  The MFMA ran with the operands swapped (D' = C^T tile): lane (fr, fh) holds row fr of the 32 x 32 tile
+    // and, in register group g, the four consecutive columns 8 g + 4 fh .. + 3.  Stored like that a wavefront-store would
+    // touch 32 rows x 32 bytes (quarter cache lines: the write path, not the MFMA, then bounds short-K products), so
+    // the tile goes through the wavefront's own piece of LDS (the ring is dead after the last barrier) and comes back
+    // as 8 rows x 128 bytes per instruction: whole lines for the addend, the bias and the result.
+    const float alpha = P.alpha, beta = P.beta;
+    const bool relu = (P.flags & GX_RELU) != 0;
+    const float* __restrict__ D = P.D;
+    const float* __restrict__ bias = P.bias;
+    constexpr int EP_LD = 36;                                  // floats per staged row (32 + 4: conflict-free b128 writes)
+    float* ep = reinterpret_cast<float*>(s_mem) + wave * (32 * EP_LD);
+    const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8 i, columns ec .. ec + 3
+    // (the addend / bias loads are unconditional, from clamped addresses, in their own instantiation: loads inside
+    // branches make the compiler wait vmcnt(0) -- i.e. for every earlier STORE too -- before each use)
+    auto finish = [&](auto has_d, auto has_bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                        make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+                const int col = n0 + (wn * NT + n) * 32 + ec;
+                const int colc = col < N ? col : N - 4;
+                const int row0 = m0 + (wm * MT + m) * 32 + er;
+                float4 bv = f4_zero(), dv[4];
+                if constexpr (decltype(has_bias)::value) bv = *reinterpret_cast<const float4*>(bias + colc);
+                if constexpr (decltype(has_d)::value) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = row0 + 8 * i;
+                        dv[i] = *reinterpret_cast<const float4*>(D + (int64_t)(row < M ? row : M - 1) * P.ldd + colc);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + 8 * i;
+                    const float4 a = *reinterpret_cast<const float4*>(ep + (er + 8 * i) * EP_LD + ec);
+                    float4 o = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+                    if constexpr (decltype(has_d)::value) {
+                        o.x = fmaf(beta, dv[i].x, o.x); o.y = fmaf(beta, dv[i].y, o.y);
+                        o.z = fmaf(beta, dv[i].z, o.z); o.w = fmaf(beta, dv[i].w, o.w);
+                    }
+                    o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+                    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (row < M && col < N) *reinterpret_cast<float4*>(P.C + (int64_t)row * P.ldc + col) = o;
+                }
+            }
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (D) { if (bias) finish(T_{}, T_{}); else finish(T_{}, F_{}); }
+    else   { if (bias) finish(F_{}, T_{}); else finish(F_{}, F_{}); }
+    GX_STAMP(31);
+}
+
+template <int MT, int NT, int S, int MINW>
+int launch(const GxBatch& b, bool a_ks, bool b_ks, hipStream_t stream) {
+    const dim3 grid(b.total_tiles), block(GX_THREADS);
+    if (!a_ks && !b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false>), grid, block, 0, stream, b);
+    else if (!a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, true>), grid, block, 0, stream, b);
+    else if (a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, true>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, false>), grid, block, 0, stream, b);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+}  // namespace
+
+#ifdef GX_STAMPS
+extern "C" int hg_gemm_x6_debug_stamps(void* buf) {
+    unsigned long long* p = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(gx_stamp_buf), &p, sizeof(p)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
+#endif
+
+extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int32_t tile, void* stream_) {
+    if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return EQH_ERR_ARG;
+    GxBatch b;
+    b.n = n_problems;
+    const bool a_ks = pr[0].trans_a != 0, b_ks = pr[0].trans_b == 0;
+    int64_t tiles_big = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const HgGemmProblem& q = pr[i];
+        if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || !q.b || !q.c) return EQH_ERR_ARG;
+        if ((q.trans_a != 0) != a_ks || (q.trans_b == 0) != b_ks) return EQH_ERR_ARG;   // one operand layout per launch
+        if (q.m >= (1ll << 31) - 256) return EQH_ERR_RANGE;
+        // float4 / float2 accesses: the contiguous extents and the row strides are multiples of 4 floats
+        if ((q.n & 3) || (q.lda & 3) || (q.ldb & 3) || (q.ldc & 3) || (q.d && (q.ldd & 3))) return EQH_ERR_ALIGN;
+        if ((!a_ks && (q.k & 3)) || (a_ks && (q.m & 3)) || (!b_ks && (q.k & 3))) return EQH_ERR_ALIGN;
+        if (!eqh_aligned16(q.a) || !eqh_aligned16(q.b) || !eqh_aligned16(q.c) || !eqh_aligned16(q.d) || !eqh_aligned16(q.bias))
+            return EQH_ERR_ALIGN;
+        tiles_big += ((q.m + 127) / 128) * ((q.n + 63) / 64);
+    }
+    const int huge = tile == 256;           // 128 x 128 tiles, one workgroup per CU (long-K products)
+    // 128 x 64 tiles amortise the operand split better, 64 x 64 tiles fill the chip at this model's ~5 k-row batches
+    const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 1024);
+    const int TM = big ? 128 : 64, TN = huge ? 128 : 64;
+    int64_t first = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const HgGemmProblem& q = pr[i];
+        GxProb& p = b.p[i];
+        p.A = q.a; p.B = q.b; p.D = q.d; p.bias = q.bias; p.C = q.c;
+        p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldd = q.ldd;
+        p.M = (int)q.m; p.N = q.n; p.K = q.k;
+        p.alpha = q.alpha; p.beta = q.beta;
+        p.flags = (q.trans_a ? GX_TRANS_A : 0) | (q.trans_b ? GX_TRANS_B : 0) | (q.relu ? GX_RELU : 0);
+        p.tiles_n = (q.n + TN - 1) / TN;
+        p.n_tiles = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
+        p.first_tile = (int)first;
+        first += p.n_tiles;
+        if (first >= (1ll << 31) - 1) return EQH_ERR_RANGE;
+    }
+    for (int i = n_problems; i < GX_MAXP; ++i) b.p[i] = b.p[0], b.p[i].first_tile = 0x7fffffff;
+    b.total_tiles = (int)first;
+    if (first == 0) return EQH_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (huge) return launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
+    return big ? launch<2, 1, 2, 6>(b, a_ks, b_ks, stream) : launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
+}

@@ -22,8 +22,16 @@ class HgDenseProblem(ctypes.Structure):
                 ("a_out", c_void_p), ("ld_aout", c_int64)]
 
 
+class HgGemmProblem(ctypes.Structure):
+    """HgGemmProblem of include/equihgnn_hip.h (one problem of hg_gemm_x6_batch)."""
+    _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("d", c_void_p), ("ldd", c_int64),
+                ("bias", c_void_p), ("c", c_void_p), ("ldc", c_int64), ("m", c_int64), ("n", c_int32), ("k", c_int32),
+                ("trans_a", c_int32), ("trans_b", c_int32), ("relu", c_int32), ("alpha", c_float), ("beta", c_float)]
+
+
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
 SIGNATURES = {
+    "hg_gemm_x6_batch": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32, c_void_p]),
     "eqh_version": (c_int32, []),
     "eqh_error_string": (c_char_p, [c_int32]),
     "hg_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -311,6 +311,83 @@ def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=
     return (o, ao) if a_out else o
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# fp32 GEMM on the bf16 matrix cores (csrc/gemm_x6.hip): every dense product of the models goes through here
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GemmProblem:
+    """c = act(alpha * op(a) @ op(b) + beta * d + bias); see hg_gemm_x6_batch in include/equihgnn_hip.h.
+    ``trans_a``: a is stored [K, M]; ``trans_b``: b is stored [N, K] (an nn.Linear weight).  ``d`` may be ``out``."""
+
+    a: torch.Tensor
+    b: torch.Tensor
+    trans_a: bool = False
+    trans_b: bool = True
+    bias: Optional[torch.Tensor] = None
+    d: Optional[torch.Tensor] = None
+    alpha: float = 1.0
+    beta: float = 1.0
+    relu: bool = False
+    out: Optional[torch.Tensor] = None
+
+
+GEMM_TILE = 0          # 0: chosen per launch; 64 / 128 force a block tile (tools/gemm_bench.py)
+
+
+def gemm_supported(a, b, trans_a=False, trans_b=True) -> bool:
+    """Shapes hg_gemm_x6_batch takes in place: 2-D fp32 device operands whose contiguous extents are multiples of 4."""
+    if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32):
+        return False
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != k:
+        return False
+    return n % 4 == 0 and k > 0 and (m % 4 == 0 if trans_a else k % 4 == 0) and (k % 4 == 0 or not trans_b)
+
+
+def gemm_batch(problems):
+    """Up to 8 GEMMs with the same operand layout in ONE launch; returns the outputs."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgGemmProblem * n)()
+    keep, outs = [], []
+    dev = problems[0].a.device
+    flops = 0
+    for i, pr in enumerate(problems):
+        a, b = _row_view(pr.a, "gemm: a"), _row_view(pr.b, "gemm: b")
+        M, K = (a.shape[1], a.shape[0]) if pr.trans_a else a.shape
+        N = b.shape[0] if pr.trans_b else b.shape[1]
+        if (b.shape[1] if pr.trans_b else b.shape[0]) != K:
+            raise ValueError(f"gemm: op(a) is [{M}, {K}] but b is {tuple(b.shape)} (trans_b={pr.trans_b})")
+        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+        assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+        q = arr[i]
+        q.a, q.lda, q.b, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+        q.c, q.ldc, q.m, q.n, q.k = out.data_ptr(), out.stride(0), M, N, K
+        q.trans_a, q.trans_b, q.relu = int(bool(pr.trans_a)), int(bool(pr.trans_b)), int(bool(pr.relu))
+        q.alpha, q.beta = float(pr.alpha), float(pr.beta)
+        if pr.d is not None:
+            d = pr.d if pr.d is out else _row_view(pr.d, "gemm: d")
+            assert d.shape == (M, N)
+            keep.append(d)
+            q.d, q.ldd = d.data_ptr(), d.stride(0)
+        if pr.bias is not None:
+            bias = _f32c(pr.bias)
+            assert bias.numel() == N
+            keep.append(bias)
+            q.bias = bias.data_ptr()
+        keep.extend((a, b))
+        outs.append(out)
+        flops += 2 * M * N * K
+    timed("k_gemm_x6", flops, lambda: hip.check(hip.lib().hg_gemm_x6_batch(n, arr, GEMM_TILE, _stream(dev)), "hg_gemm_x6_batch"))
+    return outs
+
+
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None):
+    """One GEMM through hg_gemm_x6_batch (see GemmProblem)."""
+    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out)])[0]
+
+
 def entry_weights(csr: CSR, csr_t: CSR) -> torch.Tensor:
     """w[q] = 1 / max(deg_t(csr.col[q]), 1): the mean weights of csr's entries with respect to the rows of ``csr_t``
     (hg_entry_weights), cached on ``csr``."""

@@ -105,6 +105,41 @@ typedef struct HgDenseProblem {
 } HgDenseProblem;
 int hg_dense_batch_f32(int32_t n_problems, const HgDenseProblem* problems, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * fp32 GEMM with fp32-grade results on the bf16 matrix cores (csrc/gemm_x6.hip):
+ *
+ *     c[m, n] = act( alpha * op(a)[m, k] . op(b)[k, n]  (+ beta * d[m, n])  (+ bias[n]) )
+ *
+ * Replaces the library GEMMs behind nn.Linear / F.linear and autograd's input- and weight-gradient products
+ * (mlp.py:91-99, conv.py:169-182, egnn_layer.py:180-208,360-362, equiformer_layer.py:376-383,
+ * fa_former_layer.py:241-289).  Every fp32 operand element is split exactly into three bf16 numbers while its tile is
+ * staged into LDS and the six significant bf16 x bf16 products are accumulated in fp32 by v_mfma_f32_16x16x32_bf16:
+ * the error against exact arithmetic is that of an fp32 dot product (no larger than the fp32-input MFMA's), at 2.7x
+ * its rate.  All matrices fp32 row-major:
+ *   trans_a == 0: a is [m, k] (row stride lda);   trans_a != 0: a is [k, m]  (a weight gradient dY^T . X)
+ *   trans_b != 0: b is [n, k] (row stride ldb) -- an nn.Linear weight used as x W^T;   trans_b == 0: b is [k, n]
+ *   d: optional addend [m, n] (row stride ldd; may be c itself: accumulate), bias: optional [n], relu != 0: max(., 0).
+ * n, the contiguous extents of a and b (k, or m for trans_a) and all row strides are multiples of 4 floats; pointers
+ * 16-byte aligned.  Up to 8 problems with the same (trans_a, trans_b) share one launch.  tile: 0 = choose, 64 or 128
+ * (block tile edge).  Bitwise reproducible; no workspace; capturable.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct HgGemmProblem {
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    const float* d;
+    int64_t ldd;
+    const float* bias;
+    float* c;
+    int64_t ldc;
+    int64_t m;
+    int32_t n, k;
+    int32_t trans_a, trans_b, relu;
+    float alpha, beta;
+} HgGemmProblem;
+int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* problems, int32_t tile, void* stream);
+
 /* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
  * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch
  * time it INSIDE a replayed hipGraph; eqh_wall_clock_khz is that clock's rate. */

@@ -1530,3 +1530,91 @@ def test_attn_sum_matches_float64(N, K, H, D):
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-6, rtol=1e-6)
     np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), atol=2e-6, rtol=1e-6)
     np.testing.assert_allclose(attn.grad.cpu().numpy(), a64.grad.cpu().numpy(), atol=2e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp32 GEMM on the bf16 matrix cores (csrc/gemm_x6.hip)
+# ------------------------------------------------------------------------------------------------------------------
+def _gemm_ref64(a, b, ta, tb, bias, d, alpha, beta, relu):
+    A = a.double().t() if ta else a.double()
+    B = b.double().t() if tb else b.double()
+    c = alpha * (A @ B)
+    if d is not None:
+        c = c + beta * d.double()
+    if bias is not None:
+        c = c + bias.double()
+    return torch.relu(c) if relu else c
+
+
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("M,N,K,ta,tb", [(4736, 256, 256, False, True), (4736, 256, 256, False, False),
+                                         (256, 256, 4736, True, False), (300, 64, 272, False, True),
+                                         (77, 132, 36, False, False), (1, 4, 4, False, True), (516, 2176, 256, False, True),
+                                         (2176, 256, 1000, True, False), (100, 68, 44, True, True)])
+def test_gemm_x6_matches_float64_and_is_no_worse_than_the_fp32_mfma(M, N, K, ta, tb, tile):
+    """hg_gemm_x6_batch against float64, for every operand layout the models use (x W^T, dY W, dY^T X) and ragged
+    shapes.  VERDICT r2 #7's acceptance rule for a split-bf16 product: its error against float64 must be no larger
+    than the fp32 MFMA's (the library GEMM torch.mm runs) on the same inputs."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    a *= torch.exp(2.0 * torch.randn(a.shape, generator=g))             # a wide dynamic range inside every dot product
+    ref = _gemm_ref64(a, b, ta, tb, None, None, 1.0, 1.0, False)
+    ad, bd = a.to(DEV), b.to(DEV)
+    old = ops.GEMM_TILE
+    try:
+        ops.GEMM_TILE = tile
+        out = ops.gemm(ad, bd, trans_a=ta, trans_b=tb).cpu().double()
+    finally:
+        ops.GEMM_TILE = old
+    lib = ((ad.t() if ta else ad) @ (bd.t() if tb else bd)).cpu().double()
+    scale = ((a.double().abs().t() if ta else a.double().abs()) @ (b.double().abs().t() if tb else b.double().abs()))
+    err = ((out - ref).abs() / scale).max().item()
+    err_lib = ((lib - ref).abs() / scale).max().item()
+    rms = ((out - ref) / scale).pow(2).mean().sqrt().item()
+    rms_lib = ((lib - ref) / scale).pow(2).mean().sqrt().item()
+    # errors in units of sum_k |a||b| (fp32 eps = 6e-8; the log-normal magnitudes make a few terms dominate each sum, so
+    # the fp32 chains themselves sit near 1e-6 here): the root-mean-square error no worse than the fp32 MFMA's, the
+    # largest one within the scatter of a maximum over 1e6 entries
+    assert rms <= max(1.05 * rms_lib, 6e-8), (rms, rms_lib)              # (6e-8 = one fp32 rounding: the 4-entry case)
+    assert err <= 1.5 * err_lib + 2e-7, (err, err_lib)
+    print(f"gemm_x6 [{M}x{N}x{K} ta={ta} tb={tb} tile={tile}]: max {err:.2e} (lib {err_lib:.2e}), rms {rms:.2e} (lib {rms_lib:.2e})")
+
+
+def test_gemm_x6_epilogues_batches_and_views():
+    """alpha / beta * addend (also in place: accumulate) / bias / relu; column-block views of wider matrices (row
+    stride > width); eight problems in one launch; bitwise reproducibility."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(333, 96, generator=g).to(DEV)
+    wide = torch.randn(64, 192, generator=g).to(DEV)
+    w = wide[:, 96:]                                                      # [64, 96] view, row stride 192
+    bias = torch.randn(64, generator=g).to(DEV)
+    add = torch.randn(333, 64, generator=g).to(DEV)
+    out = ops.gemm(x, w, bias=bias, d=add, alpha=0.5, beta=2.0, relu=True)
+    ref = torch.relu(0.5 * (x.double() @ w.double().t()) + 2.0 * add.double() + bias.double())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    acc = add.clone()
+    ops.gemm(x, w, d=acc, out=acc, alpha=1.0, beta=1.0)                   # acc += x w^T
+    np.testing.assert_allclose(acc.cpu().numpy(), (add.double() + x.double() @ w.double().t()).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    big = torch.zeros(333, 256, device=DEV)
+    ops.gemm(x, w, out=big[:, 128:192])                                   # into a column block
+    np.testing.assert_allclose(big[:, 128:192].cpu().numpy(), (x.double() @ w.double().t()).cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert float(big[:, :128].abs().max()) == 0.0 and float(big[:, 192:].abs().max()) == 0.0
+    probs = []
+    for i in range(8):
+        a = torch.randn(100 + 37 * i, 32 + 4 * i, generator=g).to(DEV)
+        b = torch.randn(16 + 4 * i, 32 + 4 * i, generator=g).to(DEV)
+        probs.append(ops.GemmProblem(a, b))
+    outs = ops.gemm_batch(probs)
+    outs2 = ops.gemm_batch(probs)
+    for pr, o, o2 in zip(probs, outs, outs2):
+        np.testing.assert_allclose(o.cpu().numpy(), (pr.a.double() @ pr.b.double().t()).cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert torch.equal(o, o2)
+    # exactness on small integers (asymmetric operands: catches a transposed tile or a permuted k)
+    ai = torch.randint(-8, 9, (72, 40), generator=g).float().to(DEV)
+    bi = torch.randint(-8, 9, (40, 36), generator=g).float().to(DEV)
+    assert torch.equal(ops.gemm(ai, bi, trans_b=False), ai @ bi)
+    assert torch.equal(ops.gemm(ai.t().contiguous(), bi, trans_a=True, trans_b=False), ai @ bi)
+    assert torch.equal(ops.gemm(ai, bi.t().contiguous(), trans_b=True), ai @ bi)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a workgroup of k_gemm_x6 spends its cycles.  Builds csrc/gemm_x6.hip with -DGX_STAMPS into a
+scratch library (the product library carries no stamps), runs one problem and prints, per role, the median cycle
+counts of the pipeline phases (s_memtime) over the workgroups launched in the middle of the grid."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from equihgnn_amd import hip
+
+
+def main():
+    M, N, K, tile = [int(x) for x in sys.argv[1:5]]
+    ta = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    tb = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+    so = os.path.join(os.environ.get("TMPDIR", "/tmp"), "libgemm_stamps.so")
+    extra = [f"-D{d}" for d in os.environ.get("GX_DEFS", "").split() if d]
+    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DGX_STAMPS", *extra,
+                           "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "equihgnn_amd", "csrc"),
+                           os.path.join(ROOT, "equihgnn_amd", "csrc", "gemm_x6.hip"), "-o", so])
+    L = ctypes.CDLL(so)
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
+    B = torch.randn((N, K) if tb else (K, N), device=dev, generator=g)
+    C = torch.empty(M, N, device=dev)
+    tm = 128 if tile == 128 else 64
+    n_blocks = ((M + tm - 1) // tm) * ((N + 63) // 64)
+    buf = torch.zeros(n_blocks * 12 * 64, dtype=torch.int64, device=dev)
+    pr = (hip.HgGemmProblem * 1)()
+    q = pr[0]
+    q.a, q.lda, q.b, q.ldb, q.c, q.ldc = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0)
+    q.m, q.n, q.k, q.trans_a, q.trans_b, q.alpha, q.beta = M, N, K, ta, tb, 1.0, 0.0
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    L.hg_gemm_x6_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(hip.HgGemmProblem), ctypes.c_int32, ctypes.c_void_p]
+    for _ in range(3):
+        assert L.hg_gemm_x6_batch(1, pr, tile, stream) == 0
+    torch.cuda.synchronize()
+    assert L.hg_gemm_x6_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+    assert L.hg_gemm_x6_batch(1, pr, tile, stream) == 0
+    torch.cuda.synchronize()
+    ref = (A.t() if ta else A) @ (B.t() if tb else B)
+    print("max |err|", float((C - ref).abs().max()))
+    st = buf.cpu().numpy().reshape(n_blocks, 12, 64).astype(np.int64)
+    t0 = st[:, :, 0].min()
+    print(f"blocks {n_blocks}; kernel span {int(st[:, :, 31].max() - t0)} cycles")
+    steps = min((K + 31) // 32, 13)                 # (the stamp record holds 32 slots per wavefront)
+    lo, hi = n_blocks // 3, 2 * n_blocks // 3 + 1
+    for role, waves in (("multiplier", range(0, 4)), ("stager g0", range(4, 8)), ("stager g1", range(8, 12))):
+        s = st[lo:hi][:, list(waves), :]
+        med = lambda x: float(np.median(x))
+        print(f"--- {role} (median over blocks {lo}..{hi})")
+        print(f"  start -> first barrier reached : {med(s[:, :, 1] - s[:, :, 0]):9.0f}")
+        print(f"  first barrier wait             : {med(s[:, :, 2] - s[:, :, 1]):9.0f}")
+        work, wait = [], []
+        for k in range(steps):
+            prev = s[:, :, 2 + 2 * k]
+            work.append(med(s[:, :, 3 + 2 * k] - prev))
+            wait.append(med(s[:, :, 4 + 2 * k] - s[:, :, 3 + 2 * k]))
+        print("  per step work :", " ".join(f"{w:6.0f}" for w in work))
+        print("  per step wait :", " ".join(f"{w:6.0f}" for w in wait))
+        if (K + 31) // 32 <= 13:
+            print(f"  last barrier -> end            : {med(s[:, :, 31] - s[:, :, 2 + 2 * steps]):9.0f}")
+        print(f"  lifetime                       : {med(s[:, :, 31] - s[:, :, 0]):9.0f}")
+    # launch cadence: start times of consecutive blocks on the same slot are unknown; print the distribution of starts
+    starts = np.sort(st[:, 0, 0] - t0)
+    print("block start percentiles (cycles):", [int(np.percentile(starts, p)) for p in (0, 10, 25, 50, 75, 90, 100)])
+
+
+if __name__ == "__main__":
+    main()
