@@ -57,7 +57,10 @@ struct GxProb {
     int M, N, K;
     float alpha, beta;
     int flags;
-    int first_tile, tiles_n, n_tiles;
+    int first_tile, tiles_n, n_tiles;   // n_tiles = row tiles x column tiles x splits
+    int tiles_mn;                       // row tiles x column tiles
+    int chunk_steps;                    // K steps (of 32) per split
+    float* slab;                        // splits > 1: [splits][M][N] partial products (alpha applied), else null
 };
 
 struct GxBatch {
@@ -240,11 +243,15 @@ k_gemm_x6(const GxBatch batch) {
         if (i < batch.n && lt >= batch.p[i].first_tile) pi = i;
     const GxProb P = batch.p[pi];                  // a COPY in registers: a reference is re-read from the kernarg
                                                    // segment after every global store (possible alias), behind vmcnt(0)
-    const int tile = lt - P.first_tile;
+    const int local = lt - P.first_tile;
+    const int tile = local % P.tiles_mn, split = local / P.tiles_mn;
     const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
     const int M = P.M, N = P.N, K = P.K;
-    const int KT = K / GX_BK, rem = K - KT * GX_BK;
-    const int NS = KT + (rem > 0 ? 1 : 0);                  // K steps; the last one may be partial (zero-filled)
+    const int KT = K / GX_BK, rem = K - KT * GX_BK;         // full K steps; the last step may be partial (zero-filled)
+    // split-K: this workgroup multiplies K steps [kt0, kt0 + NS) and, with more than one split, leaves its partial tile
+    // in a slab that a fixed-order reduction sums afterwards (weight gradients: few output tiles, millions of rows)
+    const int kt0 = split * P.chunk_steps;
+    const int NS = min(KT + (rem > 0 ? 1 : 0) - kt0, P.chunk_steps);
 
     // Two roles, one barrier per K step.  During step k the four MULTIPLIERS (wavefronts 0-3) read the fragments of
     // tile k from ring stage k % S and issue its MFMAs; the STAGERS (wavefronts 4-11, two groups of four) keep the
@@ -265,13 +272,14 @@ k_gemm_x6(const GxBatch batch) {
         typename LA::Regs ra;
         typename LB::Regs rb;
         const int grp = (int)(threadIdx.x >> 8) - 1;        // 0 or 1 (wavefront-uniform)
-        auto fetch = [&](int w) {
-            if (w < KT) {
-                la.fetch(ra, w);
-                lb.fetch(rb, w);
-            } else if (w < NS) {
-                la.fetch_tail(ra, w, rem);
-                lb.fetch_tail(rb, w, rem);
+        auto fetch = [&](int w) {                           // w: step within this split
+            if (w >= NS) return;
+            if (kt0 + w < KT) {
+                la.fetch(ra, kt0 + w);
+                lb.fetch(rb, kt0 + w);
+            } else {
+                la.fetch_tail(ra, kt0 + w, rem);
+                lb.fetch_tail(rb, kt0 + w, rem);
             }
         };
         auto stage = [&](int w) {
@@ -406,7 +414,27 @@ k_gemm_x6(const GxBatch batch) {
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (D) { if (bias) finish(T_{}, T_{}); else finish(T_{}, F_{}); }
+    if (P.slab) {                       // split-K partial: alpha * acc, no addend / bias / activation (the reduction adds them)
+        float* __restrict__ sl = P.slab + (int64_t)split * M * N;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                        make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+                const int col = n0 + (wn * NT + n) * 32 + ec;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = m0 + (wm * MT + m) * 32 + er + 8 * i;
+                    const float4 a = *reinterpret_cast<const float4*>(ep + (er + 8 * i) * EP_LD + ec);
+                    if (row < M && col < N)
+                        *reinterpret_cast<float4*>(sl + (int64_t)row * N + col) = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+                }
+            }
+        }
+    } else if (D) { if (bias) finish(T_{}, T_{}); else finish(T_{}, F_{}); }
     else   { if (bias) finish(F_{}, T_{}); else finish(F_{}, F_{}); }
     GX_STAMP(31);
 }
@@ -431,14 +459,51 @@ extern "C" int hg_gemm_x6_debug_stamps(void* buf) {
 }
 #endif
 
-extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int32_t tile, void* stream_) {
+// split-K plan of one problem: splits > 1 when the output tiles alone leave most of the chip idle and K is long
+static inline void gx_plan(int64_t m, int n, int k, int TM, int TN, int* splits, int* chunk_steps) {
+    const int64_t tiles = ((m + TM - 1) / TM) * ((n + TN - 1) / TN);
+    const int steps = (k + GX_BK - 1) / GX_BK;
+    int sp = 1;
+    if (tiles < 256 && steps >= 64) {
+        const int64_t want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in all
+        sp = (int)(want < steps / 16 ? want : steps / 16);        // at least 16 steps per split
+        if (sp < 1) sp = 1;
+        if (sp > 4096) sp = 4096;
+    }
+    int ch = (steps + sp - 1) / sp;
+    sp = (steps + ch - 1) / ch;
+    *splits = sp;
+    *chunk_steps = ch;
+}
+
+extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* pr, int32_t tile) {
+    if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return 0;
+    size_t best = 0;
+    const int tms[3] = {64, 128, 128}, tns[3] = {64, 64, 128};
+    for (int c = 0; c < 3; ++c) {           // the launch chooses its tile from the shapes: room for whichever it takes
+        if ((tile == 64 && c != 0) || (tile == 128 && c != 1) || (tile == 256 && c != 2)) continue;
+        size_t total = 0;
+        for (int i = 0; i < n_problems; ++i) {
+            int sp, ch;
+            gx_plan(pr[i].m, pr[i].n, pr[i].k, tms[c], tns[c], &sp, &ch);
+            if (sp > 1 && !pr[i].bias && !pr[i].relu) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
+        }
+        if (total > best) best = total;
+    }
+    return best;
+}
+
+extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int32_t tile, void* workspace, size_t workspace_bytes,
+                                void* stream_) {
     if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return EQH_ERR_ARG;
     GxBatch b;
     b.n = n_problems;
     const bool a_ks = pr[0].trans_a != 0, b_ks = pr[0].trans_b == 0;
     int64_t tiles_big = 0;
+    bool deep = true;                       // every problem: few output tiles, long k (the split-K regime)
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
+        deep = deep && q.m >= 128 && q.n >= 128 && ((q.m + 127) / 128) * ((q.n + 127) / 128) < 128 && q.k >= 16384 && !q.bias && !q.relu;
         if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || !q.b || !q.c) return EQH_ERR_ARG;
         if ((q.trans_a != 0) != a_ks || (q.trans_b == 0) != b_ks) return EQH_ERR_ARG;   // one operand layout per launch
         if (q.m >= (1ll << 31) - 256) return EQH_ERR_RANGE;
@@ -449,11 +514,15 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
             return EQH_ERR_ALIGN;
         tiles_big += ((q.m + 127) / 128) * ((q.n + 63) / 64);
     }
-    const int huge = tile == 256;           // 128 x 128 tiles, one workgroup per CU (long-K products)
+    // 128 x 128 tiles, one workgroup per CU: long-K products (a weight gradient over ~10^5-10^6 rows is split along k
+    // into hundreds of workgroups anyway: the largest tile has the least LDS traffic per MFMA, 142 against 103-124 TFLOP/s)
+    const int huge = tile == 256 || (tile == 0 && deep && workspace != nullptr);
     // 128 x 64 tiles amortise the operand split better, 64 x 64 tiles fill the chip at this model's ~5 k-row batches
     const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 1024);
     const int TM = big ? 128 : 64, TN = huge ? 128 : 64;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
     int64_t first = 0;
+    size_t ws_used = 0;
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
         GxProb& p = b.p[i];
@@ -463,7 +532,24 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         p.alpha = q.alpha; p.beta = q.beta;
         p.flags = (q.trans_a ? GX_TRANS_A : 0) | (q.trans_b ? GX_TRANS_B : 0) | (q.relu ? GX_RELU : 0);
         p.tiles_n = (q.n + TN - 1) / TN;
-        p.n_tiles = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
+        p.tiles_mn = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
+        int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;
+        p.slab = nullptr;
+        if (!q.bias && !q.relu) {
+            gx_plan(q.m, q.n, q.k, TM, TN, &sp, &ch);
+            if (sp > 1) {
+                const size_t need = (size_t)sp * (size_t)q.m * (size_t)q.n * sizeof(float);
+                if (!workspace || ws_used + need > workspace_bytes) {   // no room: one pass over the whole K
+                    sp = 1;
+                    ch = (q.k + GX_BK - 1) / GX_BK;
+                } else {
+                    p.slab = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_used);
+                    ws_used += need;
+                }
+            }
+        }
+        p.chunk_steps = ch;
+        p.n_tiles = p.tiles_mn * sp;
         p.first_tile = (int)first;
         first += p.n_tiles;
         if (first >= (1ll << 31) - 1) return EQH_ERR_RANGE;
@@ -471,7 +557,20 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     for (int i = n_problems; i < GX_MAXP; ++i) b.p[i] = b.p[0], b.p[i].first_tile = 0x7fffffff;
     b.total_tiles = (int)first;
     if (first == 0) return EQH_OK;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (huge) return launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
-    return big ? launch<2, 1, 2, 6>(b, a_ks, b_ks, stream) : launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
+    int rc;
+    if (huge) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
+    else rc = big ? launch<2, 1, 2, 6>(b, a_ks, b_ks, stream) : launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
+    if (rc) return rc;
+    // split-K problems: c = beta * d + sum of the slabs, in slab order (bitwise reproducible); beta * d with d == c and
+    // beta == 1 is the accumulating form the weight gradients use
+    for (int i = 0; i < n_problems; ++i) {
+        const GxProb& p = b.p[i];
+        if (!p.slab) continue;
+        const int sp = p.n_tiles / p.tiles_mn;
+        const bool acc = p.D == p.C && p.beta == 1.0f;
+        if (p.D && !acc) return EQH_ERR_ARG;                   // (split-K with a separate addend is not needed by the models)
+        rc = eqh_reduce_slabs2d_async(p.slab, sp, p.M, p.N, p.C, p.ldc, acc ? 1 : 0, stream);
+        if (rc) return rc;
+    }
+    return EQH_OK;
 }

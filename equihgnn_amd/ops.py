@@ -379,13 +379,70 @@ def gemm_batch(problems):
         keep.extend((a, b))
         outs.append(out)
         flops += 2 * M * N * K
-    timed("k_gemm_x6", flops, lambda: hip.check(hip.lib().hg_gemm_x6_batch(n, arr, GEMM_TILE, _stream(dev)), "hg_gemm_x6_batch"))
+    L = hip.lib()
+    ws_bytes = L.hg_gemm_x6_workspace_bytes(n, arr, GEMM_TILE)
+    ws = _workspace(ws_bytes, dev) if ws_bytes else None
+    timed("k_gemm_x6", flops, lambda: hip.check(L.hg_gemm_x6_batch(n, arr, GEMM_TILE, _ptr(ws), ws_bytes, _stream(dev)),
+                                               "hg_gemm_x6_batch"))
     return outs
 
 
 def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None):
     """One GEMM through hg_gemm_x6_batch (see GemmProblem)."""
     return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out)])[0]
+
+
+# Where the x6 kernel replaces the library GEMM (measured on MI355X against the TunableOp-selected hipBLASLt kernels,
+# tools/gemm_bench.py -> profiles/r03_gemm_bench.txt): from ~8 M output elements per launch it is 15-25 % faster
+# (145-150 against 117-125 TFLOP/s at the Molecule3D / PCQM / Equiformer sizes); below that -- the [4.7 k x 256] x
+# [256 x 256] products of a QM9 batch, one workgroup per CU and eight K steps -- the tuned library is 10-30 % ahead.
+X6_MIN_OUTPUTS = 6_000_000
+X6_MAX_K = 1024
+USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
+
+
+def _x6_ok(a, b, trans_b, out_elems, k) -> bool:
+    return (USE_X6 and out_elems >= X6_MIN_OUTPUTS and k <= X6_MAX_K and a.is_cuda and a.dtype == torch.float32
+            and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and gemm_supported(a, b, False, trans_b))
+
+
+def mm_nt(x, w, bias=None, d=None, alpha: float = 1.0, beta: float = 1.0, relu: bool = False):
+    """act(alpha * x @ w.T + beta * d + bias) for x [M, K], w [N, K] (an nn.Linear weight or a view of one): the x6
+    kernel where it is the faster one, else the library GEMM."""
+    if _x6_ok(x, w, True, x.shape[0] * w.shape[0], x.shape[1]):
+        return gemm(x, w, trans_b=True, bias=bias, d=d, alpha=alpha, beta=beta, relu=relu)
+    if d is None and alpha == 1.0:
+        if relu and bias is not None:
+            return torch._addmm_activation(bias, x, w.t(), use_gelu=False)
+        y = F.linear(x, w, bias)
+        return torch.relu(y) if relu else y
+    if d is not None:
+        y = torch.addmm(d, x, w.t(), beta=beta, alpha=alpha)
+    else:
+        y = torch.mm(x, w.t()) * alpha
+    if bias is not None:
+        y = y + bias
+    return torch.relu(y) if relu else y
+
+
+def mm_nn(x, w, d=None, alpha: float = 1.0, beta: float = 1.0, out=None):
+    """alpha * x @ w + beta * d for x [M, K], w [K, N] (an input gradient dY W, or a weight stored [in, out]); ``out``
+    (which may be ``d``: accumulate) receives the result."""
+    if _x6_ok(x, w, False, x.shape[0] * w.shape[1], x.shape[1]):
+        return gemm(x, w, trans_b=False, d=d, alpha=alpha, beta=beta, out=out)
+    if d is None:
+        y = torch.mm(x, w) if alpha == 1.0 else torch.mm(x, w) * alpha
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    if out is not None and out is d:
+        return d.addmm_(x, w, beta=beta, alpha=alpha)
+    y = torch.addmm(d, x, w, beta=beta, alpha=alpha)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def entry_weights(csr: CSR, csr_t: CSR) -> torch.Tensor:
@@ -713,7 +770,7 @@ class _LinearAddReluLn(torch.autograd.Function):
     def forward(ctx, x, weight, c, scale, bias, gamma, beta, eps, fan, acc_params):
         _require_gpu(x, "linear_add_relu_ln")
         x, c, bias, gamma, beta = _f32c(x), _f32c(c), _f32c(bias), _f32c(gamma), _f32c(beta)
-        h = x @ weight.t()
+        h = mm_nt(x, weight)
         R, C = h.shape
         out = torch.empty_like(h)
         hip.check(hip.lib().hg_bias_relu_ln_fwd_ex(_ptr(h), float(scale), _ptr(c), _ptr(bias), _ptr(gamma), _ptr(beta), R, C,
@@ -745,7 +802,7 @@ class _LinearAddReluLn(torch.autograd.Function):
                                            _stream(h.device)), "hg_bias_relu_ln_bwd_ex")
         if fan is not None:
             fan.n += 1
-        dx = torch.addmm(x, dpre, weight, beta=0.0, alpha=a) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(dpre, weight, alpha=a) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             gbuf = getattr(weight, "_eqh_gbuf", None)
@@ -956,7 +1013,7 @@ class _EgnnFeats(torch.autograd.Function):
         normed = torch.empty_like(feats)
         hip.check(hip.lib().hg_layer_norm_fwd(_ptr(feats), _ptr(g), _ptr(b), R, C, float(eps), _ptr(normed),
                                               _stream(feats.device)), "hg_layer_norm_fwd")
-        ab = torch.addmm(b_cat, feats, w_cat.t())
+        ab = mm_nt(feats, w_cat, bias=b_cat)
         ctx.save_for_backward(feats, w_cat, g)
         ctx.eps, ctx.acc = float(eps), acc_params
         ctx.set_materialize_grads(False)
@@ -988,7 +1045,7 @@ class _EgnnFeats(torch.autograd.Function):
         dw = db = None
         if d_ab is not None:
             d_ab = _f32c(d_ab)
-            dx = d_ab @ w_cat if dx is None else dx.addmm_(d_ab, w_cat)
+            dx = mm_nn(d_ab, w_cat) if dx is None else mm_nn(d_ab, w_cat, d=dx, out=dx)
             if ctx.needs_input_grad[1]:
                 dw = d_ab.t() @ feats
             if ctx.needs_input_grad[2]:
@@ -1106,7 +1163,12 @@ def defer_flush(device):
             rest = [en for en in group if en[0].shape[0] < 32768]
             with torch.no_grad():
                 for dy2, x2, alpha, into in deep:
-                    wgrad(dy2, x2, alpha, into=into)
+                    if USE_X6 and gemm_supported(dy2, x2, True, False):
+                        # split-K on the bf16 matrix cores: 140-150 TFLOP/s against 75 (hg_wgrad_f32) / 60-70 (library)
+                        _DEFER["keep"].extend((dy2, x2))
+                        gemm(dy2, x2, trans_a=True, trans_b=False, d=into, out=into, alpha=alpha)
+                    else:
+                        wgrad(dy2, x2, alpha, into=into)
             if len(rest) >= 3:
                 wgrad_batch(rest)
             else:   # too few products of this shape to fill the chip together: the library GEMM is faster
@@ -1580,10 +1642,14 @@ class _Linear(torch.autograd.Function):
         ctx.bias_param = bias
         ctx.relu = bool(relu)
         if relu:    # relu(x W^T + b) with the activation in the GEMM's epilogue (2-D x, bias given: checked by linear())
-            y = torch._addmm_activation(b, x, w.t(), use_gelu=False)
+            y = mm_nt(x, w, bias=b, relu=True)
             ctx.save_for_backward(x, weight, y)
             return y
         ctx.save_for_backward(x, weight)
+        if x.dim() == 2:
+            return mm_nt(x, w, bias=b)
+        if x.is_contiguous() and x.is_cuda:
+            return mm_nt(x.reshape(-1, x.shape[-1]), w, bias=b).view(*x.shape[:-1], w.shape[0])
         return F.linear(x, w, b)
 
     @staticmethod
@@ -1599,7 +1665,9 @@ class _Linear(torch.autograd.Function):
         if r0 is not None:
             w = w[r0:r1]
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = (dy @ w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = mm_nn(dy2, w).view(*dy.shape[:-1], w.shape[1]) if dy2.is_cuda else dy @ w
         dw = _linear_weight_grad(weight, c0, c1, dy2, x2, r0, r1) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -1624,7 +1692,10 @@ class _Linear2(torch.autograd.Function):
         ctx.save_for_backward(x, wa, wb)
         ctx.cols = (a0, a1, b0, b1)
         ctx.set_materialize_grads(False)
-        return F.linear(x, wa if a0 is None else wa[:, a0:a1]), F.linear(x, wb if b0 is None else wb[:, b0:b1])
+        wa_, wb_ = (wa if a0 is None else wa[:, a0:a1]), (wb if b0 is None else wb[:, b0:b1])
+        if x.dim() == 2 and x.is_cuda:
+            return mm_nt(x, wa_), mm_nt(x, wb_)
+        return F.linear(x, wa_), F.linear(x, wb_)
 
     @staticmethod
     def backward(ctx, dya, dyb):
@@ -1638,7 +1709,7 @@ class _Linear2(torch.autograd.Function):
             ws = w if c0 is None else w[:, c0:c1]
             dy2 = dy.reshape(-1, dy.shape[-1])
             if ctx.needs_input_grad[0]:
-                dx = dy2 @ ws if dx is None else dx.addmm_(dy2, ws)
+                dx = mm_nn(dy2, ws) if dx is None else mm_nn(dy2, ws, d=dx, out=dx)
             if ctx.needs_input_grad[slot]:
                 g = _linear_weight_grad(w, c0, c1, dy2, x2)
                 if slot == 1:
@@ -1660,13 +1731,13 @@ class _LinearAddC(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.scale = float(scale)
         ctx.fan = fan
-        return torch.addmm(c, x, weight.t(), beta=1.0, alpha=ctx.scale)
+        return mm_nt(x, weight, d=c, alpha=ctx.scale, beta=1.0)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         a = ctx.scale
-        dx = torch.addmm(x, dy, weight, beta=0.0, alpha=a) if ctx.needs_input_grad[0] else None
+        dx = mm_nn(dy, weight, alpha=a) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             gbuf = getattr(weight, "_eqh_gbuf", None)
@@ -2084,6 +2155,9 @@ class _MatmulFan(torch.autograd.Function):
     def forward(ctx, x, *Ws):
         ctx.save_for_backward(x, *Ws)
         ctx.set_materialize_grads(False)
+        if x.is_cuda and x.is_contiguous():
+            x2 = x.reshape(-1, x.shape[-1])
+            return tuple(mm_nn(x2, W).view(*x.shape[:-1], W.shape[1]) for W in Ws)
         return tuple(x @ W for W in Ws)
 
     @staticmethod
@@ -2099,7 +2173,9 @@ class _MatmulFan(torch.autograd.Function):
             dy2 = dy.reshape(-1, dy.shape[-1])
             if ctx.needs_input_grad[0]:
                 if dx is None:
-                    dx = dy2 @ W.t()
+                    dx = mm_nt(dy2, W) if dy2.is_cuda else dy2 @ W.t()
+                elif dy2.is_cuda:
+                    dx = mm_nt(dy2, W, d=dx)
                 else:
                     dx.addmm_(dy2, W.t())
             if not ctx.needs_input_grad[1 + k]:

@@ -1612,6 +1612,18 @@ def test_gemm_x6_epilogues_batches_and_views():
     for pr, o, o2 in zip(probs, outs, outs2):
         np.testing.assert_allclose(o.cpu().numpy(), (pr.a.double() @ pr.b.double().t()).cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert torch.equal(o, o2)
+    # split-K (few output tiles, long k: a weight gradient dY^T X accumulated into its buffer), twice: bitwise equal
+    dy = torch.randn(9000, 128, generator=g).to(DEV)
+    xx = torch.randn(9000, 64, generator=g).to(DEV)
+    acc0 = torch.randn(128, 64, generator=g).to(DEV)
+    accs = []
+    for _ in range(2):
+        acc1 = acc0.clone()
+        ops.gemm(dy, xx, trans_a=True, trans_b=False, d=acc1, out=acc1, alpha=0.5)
+        accs.append(acc1)
+    want = acc0.double() + 0.5 * dy.double().t() @ xx.double()
+    np.testing.assert_allclose(accs[0].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-4)
+    assert torch.equal(accs[0], accs[1])
     # exactness on small integers (asymmetric operands: catches a transposed tile or a permuted k)
     ai = torch.randint(-8, 9, (72, 40), generator=g).float().to(DEV)
     bi = torch.randint(-8, 9, (40, 36), generator=g).float().to(DEV)

@@ -23,6 +23,9 @@ SHAPES = [("c2 conv fwd x W^T", 4736, 256, 256, 0, 1), ("c2 conv dgrad dY W", 47
           ("c2 egnn ab wgrad", 2176, 256, 4736, 1, 0), ("c2 node mlp", 4736, 512, 272, 0, 1),
           ("c4 conv fwd", 31232, 256, 256, 0, 1), ("c4 egnn ab fwd", 31232, 2176, 256, 0, 1),
           ("c3 P/Q node product", 2432, 16384, 64, 0, 1), ("c3 big", 38912, 1024, 256, 0, 1),
+          ("c5 frame fc1", 1971840, 256, 128, 0, 1), ("c5 frame dgrad", 1971840, 128, 256, 0, 0),
+          ("c5 frame wgrad", 256, 128, 1971840, 1, 0), ("c3 dgrad K=16384", 2312, 256, 16384, 0, 0),
+          ("c3 wgrad N=16384", 256, 16384, 2312, 1, 0),
           ("c5 fc", 245760, 256, 256, 0, 1), ("c5 fc dgrad", 245760, 256, 256, 0, 0), ("c5 wgrad", 256, 256, 245760, 1, 0),
           ("square 4096", 4096, 4096, 4096, 0, 1)]
 

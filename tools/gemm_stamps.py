@@ -39,12 +39,13 @@ def main():
     q.a, q.lda, q.b, q.ldb, q.c, q.ldc = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0)
     q.m, q.n, q.k, q.trans_a, q.trans_b, q.alpha, q.beta = M, N, K, ta, tb, 1.0, 0.0
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    L.hg_gemm_x6_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(hip.HgGemmProblem), ctypes.c_int32, ctypes.c_void_p]
+    L.hg_gemm_x6_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(hip.HgGemmProblem), ctypes.c_int32, ctypes.c_void_p,
+                                   ctypes.c_size_t, ctypes.c_void_p]
     for _ in range(3):
-        assert L.hg_gemm_x6_batch(1, pr, tile, stream) == 0
+        assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
     torch.cuda.synchronize()
     assert L.hg_gemm_x6_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
-    assert L.hg_gemm_x6_batch(1, pr, tile, stream) == 0
+    assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
     torch.cuda.synchronize()
     ref = (A.t() if ta else A) @ (B.t() if tb else B)
     print("max |err|", float((C - ref).abs().max()))
