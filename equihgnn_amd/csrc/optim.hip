@@ -21,9 +21,9 @@ struct AdamState {       // device memory, 16 bytes, zero-initialised by the cal
 };
 
 __global__ void __launch_bounds__(256)
-k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
        const float* __restrict__ lr_ptr, float beta1, float beta2, float eps, float wd, float gscale,
-       AdamState* __restrict__ st) {
+       AdamState* __restrict__ st, int zero_grad, float* __restrict__ zero_also, int64_t zero_also_n) {
     // the bias corrections once per workgroup (two powf per THREAD were most of the kernel's instructions)
     __shared__ float s_corr[2];
     if (threadIdx.x == 0) {
@@ -54,7 +54,11 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = f4_zero();   // the next step's kernels accumulate into zeros
     }
+    // a second buffer cleared on the way (accumulators that are not parameter gradients: the merged weights' scratch)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (zero_also_n >> 2); i += stride)
+        reinterpret_cast<float4*>(zero_also)[i] = f4_zero();
     if (blockIdx.x == 0) {  // ragged tail (n not a multiple of 4)
         for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
             float gr = g[i] * gscale;
@@ -64,6 +68,7 @@ k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m
             m[i] = mi;
             v[i] = vi;
             p[i] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+            if (zero_grad) g[i] = 0.f;
         }
     }
     // the last workgroup to finish advances the step counter: every workgroup read it before finishing
@@ -129,18 +134,20 @@ extern "C" int eqh_mse_fwd_bwd(const float* pred, const float* target, int32_t n
     return EQH_OK;
 }
 
-extern "C" int eqh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+extern "C" int eqh_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              const float* lr, float beta1, float beta2, float eps, float weight_decay,
-                             float grad_scale, void* state, void* stream_) {
+                             float grad_scale, void* state, int32_t zero_grad, float* zero_also, int64_t zero_also_n,
+                             void* stream_) {
     if (n < 0 || !lr || !state) return EQH_ERR_ARG;
     if (n == 0) return EQH_OK;
     if (!param || !grad || !exp_avg || !exp_avg_sq) return EQH_ERR_ARG;
+    if (zero_also_n < 0 || (zero_also_n > 0 && !zero_also) || (zero_also_n & 3) || !eqh_aligned16(zero_also)) return EQH_ERR_ARG;
     if (!eqh_aligned16(param) || !eqh_aligned16(grad) || !eqh_aligned16(exp_avg) || !eqh_aligned16(exp_avg_sq) ||
         ((uintptr_t)state & 7))
         return EQH_ERR_ALIGN;
     hipLaunchKernelGGL(k_adam, dim3(eqh_grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, grad_scale,
-                       static_cast<AdamState*>(state));
+                       static_cast<AdamState*>(state), (int)zero_grad, zero_also, zero_also_n);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

@@ -22,6 +22,14 @@ class HgDenseProblem(ctypes.Structure):
                 ("a_out", c_void_p), ("ld_aout", c_int64)]
 
 
+class HgSmallMM(ctypes.Structure):
+    """HgSmallMM of include/equihgnn_hip.h (one problem of hg_small_mm_batch)."""
+    _fields_ = [("a", c_void_p), ("a_rs", c_int64), ("a_cs", c_int64), ("b", c_void_p), ("b_rs", c_int64), ("b_cs", c_int64),
+                ("c", c_void_p), ("ldc", c_int64), ("u", c_void_p), ("v", c_void_p), ("x", c_void_p), ("z", c_void_p),
+                ("y", c_void_p), ("w", c_void_p), ("m", c_int32), ("n", c_int32), ("k", c_int32), ("alpha", c_float),
+                ("accumulate_c", c_int32), ("accumulate_y", c_int32)]
+
+
 class HgGemmProblem(ctypes.Structure):
     """HgGemmProblem of include/equihgnn_hip.h (one problem of hg_gemm_x6_batch)."""
     _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("d", c_void_p), ("ldd", c_int64),
@@ -31,6 +39,7 @@ class HgGemmProblem(ctypes.Structure):
 
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
 SIGNATURES = {
+    "hg_small_mm_batch": (c_int32, [c_int32, ctypes.POINTER(HgSmallMM), c_void_p]),
     "hg_gemm_x6_workspace_bytes": (c_size_t, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32]),
     "hg_gemm_x6_batch": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32, c_void_p, c_size_t, c_void_p]),
     "eqh_version": (c_int32, []),
@@ -135,7 +144,7 @@ SIGNATURES = {
     "hg_csr_build_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
     "hg_csr_build_batch": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 12),
-    "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_void_p]),
+    "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "hg_dense_batch_f32": (c_int32, [c_int32, ctypes.POINTER(HgDenseProblem), c_void_p]),

@@ -300,9 +300,9 @@ class MHNNSConv(nn.Module):
 
     def _prepare_merged(self, res, X0):
         c_dim = self.W1.lins[0].weight.shape[1]
-        w12, b12 = ops.merged_weight(self.W2.lins[0].weight, self.W1.lins[1].weight, self.W1.lins[1].bias,
-                                     self.W2.lins[0].bias, cols=(c_dim, 2 * c_dim))
-        w23, _ = ops.merged_weight(self.W3.lins[0].weight, self.W2.lins[1].weight)
+        (w12, b12), (w23, _) = ops.merged_weights([
+            (self.W2.lins[0].weight, self.W1.lins[1].weight, self.W1.lins[1].bias, self.W2.lins[0].bias, (c_dim, 2 * c_dim)),
+            (self.W3.lins[0].weight, self.W2.lins[1].weight, None, None, None)])      # one launch each way
         cw = ops.linear(res[1], self.W3.lins[0].weight)                   # (a X0 + (1 - a) w_r b) W3a^T, layer-independent
         cw, fan = ops.fanout(cw)          # its gradient is summed over the L applications by their LayerNorm backward kernels
         return {"scale": res[0], "w12": w12, "b12": b12, "w23": w23, "cw": cw, "fan": fan, "x0": X0, "x0_pass": res[3]}

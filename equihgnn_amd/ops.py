@@ -1095,6 +1095,7 @@ def defer_begin(device):
     _DEFER["active"] = True
     _DEFER["merged"] = []       # (a window that ended in an exception must not leak its records into this one)
     _DEFER["zslab"] = None
+    MERGED_SCRATCH["cur"] = 0
 
 
 def wgrad_batch(entries):
@@ -1577,10 +1578,181 @@ class _MergedWeight(torch.autograd.Function):
         return dA, dB, dbb, dbo, None, None
 
 
+def small_mm_batch(problems):
+    """hg_small_mm_batch: up to 8 small products in one launch.  Each problem is a dict with
+    a, b (2-D tensors, any strides), ta / tb (use the transpose), c (2-D out, unit inner stride), accumulate, alpha,
+    and optionally u, v (c += u v^T), x, z, y, acc_y (y (+)= op(a) x + z), w (w += u)."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgSmallMM * n)()
+    keep = []
+    for q, pr in zip(arr, problems):
+        a, b, c = pr["a"], pr["b"], pr["c"]
+        if pr.get("ta"):
+            a = a.t()
+        if pr.get("tb"):
+            b = b.t()
+        M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K and c.shape == (M, N) and c.stride(1) == 1 and a.dtype == b.dtype == c.dtype == torch.float32
+        q.a, q.a_rs, q.a_cs = a.data_ptr(), a.stride(0), a.stride(1)
+        q.b, q.b_rs, q.b_cs = b.data_ptr(), b.stride(0), b.stride(1)
+        q.c, q.ldc, q.m, q.n, q.k = c.data_ptr(), c.stride(0), M, N, K
+        q.alpha, q.accumulate_c, q.accumulate_y = float(pr.get("alpha", 1.0)), int(bool(pr.get("accumulate"))), int(bool(pr.get("acc_y")))
+        for name in ("u", "v", "x", "z", "y", "w"):
+            t = pr.get(name)
+            if t is not None:
+                assert t.dim() == 1 and t.stride(0) == 1 and t.dtype == torch.float32
+                setattr(q, name, t.data_ptr())
+                keep.append(t)
+        keep.extend((a, b, c))
+    dev = problems[0]["c"].device
+    hip.check(hip.lib().hg_small_mm_batch(n, arr, _stream(dev)), "hg_small_mm_batch")
+
+
+class _MergedWeights(torch.autograd.Function):
+    """Several merged weights (see _MergedWeight) in ONE launch each way (hg_small_mm_batch): forward
+    Wc_i = A_i[:, cols_i] @ B_i, bc_i = A_i[:, cols_i] @ bb_i + bo_i; backward dA_i, dB_i, dbb_i, dbo_i straight into the
+    parameters' accumulators where they have them.  apply(cols, A_0, B_0, bb_0, bo_0, A_1, ...) -> (Wc_0, bc_0, Wc_1, ...)
+    (bc_i is None without bb_i)."""
+
+    @staticmethod
+    def forward(ctx, cols, *ts):
+        n = len(ts) // 4
+        ctx.cols, ctx.n = cols, n
+        ctx.save_for_backward(*[t for t in ts if t is not None])
+        ctx.present = [t is not None for t in ts]
+        ctx.set_materialize_grads(False)
+        outs, probs = [], []
+        for i in range(n):
+            A, B, bb, bo = ts[4 * i:4 * i + 4]
+            a0, a1 = cols[i] if cols[i] is not None else (None, None)
+            blk = A if a0 is None else A[:, a0:a1]
+            wc = torch.empty((blk.shape[0], B.shape[1]), dtype=torch.float32, device=A.device)
+            bc = torch.empty(blk.shape[0], dtype=torch.float32, device=A.device) if bb is not None else None
+            pr = dict(a=blk, b=B, c=wc)
+            if bb is not None:
+                pr.update(x=bb, z=bo, y=bc)
+            probs.append(pr)
+            outs.extend((wc, bc))
+        small_mm_batch(probs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        it = iter(ctx.saved_tensors)
+        ts = [next(it) if p else None for p in ctx.present]
+        grads, probs = [None], []
+        for i in range(ctx.n):
+            A, B, bb, bo = ts[4 * i:4 * i + 4]
+            dwc, dbc = douts[2 * i], douts[2 * i + 1]
+            a0, a1 = ctx.cols[i] if ctx.cols[i] is not None else (None, None)
+            blk = A if a0 is None else A[:, a0:a1]
+            if dwc is None and dbc is None:
+                grads.extend((None, None, None, None))
+                continue
+            if dwc is None:
+                dwc = torch.zeros((blk.shape[0], B.shape[1]), dtype=B.dtype, device=B.device)
+            dwc = dwc if dwc.stride(1) == 1 else dwc.contiguous()
+            use_b = bb is not None and dbc is not None
+            if use_b:
+                dbc = dbc.contiguous()
+            ga, gb = _acc_target(A), _acc_target(B)
+            # dA[:, cols] (+)= dWc B^T (+ dbc (x) bb);  dbo += dbc rides along
+            if ga is not None:
+                tgt, dA = (ga if a0 is None else ga[:, a0:a1]), None
+            else:
+                dA = torch.zeros_like(A)
+                tgt = dA if a0 is None else dA[:, a0:a1]
+            p1 = dict(a=dwc, b=B, tb=True, c=tgt, accumulate=ga is not None)
+            dbo = None
+            if use_b:
+                p1.update(u=dbc, v=bb)
+                if bo is not None:
+                    t = _acc_target(bo)
+                    if t is not None:
+                        p1.update(w=t)
+                    else:
+                        dbo = dbc
+            # dB (+)= A_blk^T dWc;  dbb (+)= A_blk^T dbc rides along
+            dB = None if gb is not None else torch.empty_like(B)
+            p2 = dict(a=blk, ta=True, b=dwc, c=gb if gb is not None else dB, accumulate=gb is not None)
+            dbb = None
+            if use_b:
+                t = _acc_target(bb)
+                if t is None:
+                    dbb = torch.empty_like(bb)
+                p2.update(x=dbc, y=t if t is not None else dbb, acc_y=t is not None)
+            probs.extend((p1, p2))
+            grads.extend((dA, dB, dbb, dbo))
+        for j in range(0, len(probs), 8):
+            small_mm_batch(probs[j:j + 8])
+        return tuple(grads)
+
+
+def merged_weights(items):
+    """[(Wc, bc)] for items = [(A, B, bb, bo, cols)]: Wc = A[:, cols] @ B, bc = A[:, cols] @ bb + bo (None without bb), all in
+    one launch (and one for the whole backward).  While gradient reductions are deferred (graphed trainer) the results
+    carry accumulators of their own, so the weight gradients of the Linears that use them join the batched launch of
+    defer_flush like any parameter's, and defer_flush then back-propagates them to the parameters."""
+    flat, cols = [], []
+    for A, B, bb, bo, c in items:
+        if torch.is_grad_enabled():
+            for w in (A, B):
+                if w.requires_grad and w.is_leaf:
+                    LINEAR_PARAMS[id(w)] = w
+            _note_acc(bb, bo)
+        flat.extend((A, B, bb, bo))
+        cols.append(tuple(c) if c is not None else None)
+    res = _MergedWeights.apply(tuple(cols), *flat)
+    pairs = [(res[2 * i], res[2 * i + 1]) for i in range(len(items))]
+    if not (_DEFER["active"] and torch.is_grad_enabled() and any(w.requires_grad for w, _ in pairs)):
+        return pairs
+    outs, accs, leaves = [], [], []
+    for wc, bc in pairs:
+        # the Linears see detached leaves with accumulators; the weight-level products stay out of the main backward
+        O, I = wc.shape
+        ld = (I + 3) // 4 * 4
+        acc = _merged_acc((O + 1, max(ld, O)), wc.device)   # rows 0..O-1: dWc; row O: dbc
+        outs.append(wc)
+        accs.append(acc[:O, :I])
+        wl = wc.detach().requires_grad_()
+        wl._eqh_transient = True
+        wl._eqh_gbuf = acc[:O, :I]
+        bl = None
+        if bc is not None:
+            bl = bc.detach().requires_grad_()
+            bl._eqh_transient = True
+            bl._eqh_gbuf = acc[O, :O]
+            outs.append(bc)
+            accs.append(acc[O, :O])
+        leaves.append((wl, bl))
+    _DEFER["merged"].append((outs, accs))
+    return leaves
+
+
+# Persistent scratch for the merged weights' accumulators: with MERGED_SCRATCH["static"] (set by the graphed trainer) the
+# accumulators are carved from ONE buffer that lives across steps and is cleared by the update kernel (eqh_adam_step's
+# zero_also), instead of a fresh zero-filled slab -- a fill launch -- per step.
+MERGED_SCRATCH = {"buf": None, "cur": 0, "static": False}
+
+
 def _merged_acc(shape, device):
-    """A zeroed accumulator for a merged weight: carved from one zero-filled slab per deferral window (one fill kernel
-    for all merged weights of a step)."""
+    """A zeroed accumulator for a merged weight: carved from the persistent scratch (graphed trainer) or from one
+    zero-filled slab per deferral window (one fill kernel for all merged weights of a step)."""
     n = shape[0] * shape[1]
+    ms = MERGED_SCRATCH
+    if ms["static"]:
+        need = ms["cur"] + (n + 63) // 64 * 64
+        if ms["buf"] is None or ms["buf"].numel() < need or ms["buf"].device != device:
+            assert not torch.cuda.is_current_stream_capturing(), "merged-weight scratch must exist before graph capture"
+            old = ms["buf"]
+            ms["buf"] = torch.zeros(max(2 * need, 1 << 18), dtype=torch.float32, device=device)
+            if old is not None and old.device == device:
+                ms["buf"][:old.numel()].copy_(old)
+        out = ms["buf"][ms["cur"]:ms["cur"] + n].view(shape)
+        ms["cur"] = need
+        return out
     slab = _DEFER.get("zslab")
     if slab is None or slab[1] + n > slab[0].numel() or slab[0].device != device:
         slab = [torch.zeros(max(4 * n, 1 << 18), dtype=torch.float32, device=device), 0]

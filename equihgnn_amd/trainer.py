@@ -106,6 +106,7 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, param, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__([param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
+        self.zero_grad_in_step = False      # clear the flat gradient inside the update kernel (GraphedTrainStep)
         self._lr_dev = None
         st = self.state[param]
         st["exp_avg"] = torch.zeros_like(param.data)
@@ -129,9 +130,12 @@ class FlatAdam(torch.optim.Optimizer):
         p = g["params"][0]
         st = self.state[p]
         b1, b2 = g["betas"]
+        zs = ops.MERGED_SCRATCH["buf"] if (self.zero_grad_in_step and ops.MERGED_SCRATCH["static"]) else None
         hip.check(hip.lib().eqh_adam_step(ops._ptr(p.data), ops._ptr(p.grad), ops._ptr(st["exp_avg"]),
                                           ops._ptr(st["exp_avg_sq"]), p.numel(), ops._ptr(st["lr"]), b1, b2, g["eps"],
                                           g["weight_decay"], self.grad_scale, ops._ptr(st["step_block"]),
+                                          1 if self.zero_grad_in_step else 0,
+                                          ops._ptr(zs) if zs is not None else None, zs.numel() if zs is not None else 0,
                                           ops._stream(p.device)), "eqh_adam_step")
 
 
@@ -153,11 +157,14 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
-                 broadcast_from_rank0: bool = True, collective: bool = True):
+                 broadcast_from_rank0: bool = True, collective: bool = True, keep_grads: bool = False):
         """``collective=False``: a rank-local trainer inside a multi-rank job (no broadcast, no all-reduce) -- what a
-        measurement on ONE rank needs while the other ranks wait at a barrier."""
+        measurement on ONE rank needs while the other ranks wait at a barrier.  ``keep_grads``: leave the gradients of the
+        last step readable in ``p.grad`` after ``step()`` (tests); by default the update kernel clears the flat gradient
+        buffer as it consumes it -- optimizer.zero_grad() without the fill launch at the head of every replayed step."""
         self.model, self.lr, self.wd = model, lr, weight_decay
         self.collective = collective
+        self.keep_grads = keep_grads
         self.live = None
         self.opt = None
         self.slots = {}
@@ -228,6 +235,9 @@ class GraphedTrainStep:
             p.grad = None
         if self.wflat is not None:
             self.wflat.zero_()
+        from . import ops
+        if ops.MERGED_SCRATCH["buf"] is not None:
+            ops.MERGED_SCRATCH["buf"].zero_()
         return self._loss_backward(data)
 
     def _loss_backward(self, data):
@@ -237,6 +247,8 @@ class GraphedTrainStep:
         from . import ops
         dev = data.y.device
         defer = self.gflat is not None and dev.type == "cuda"
+        # accumulators of merged weights: a persistent scratch that the update kernel clears (no fill launch per step)
+        ops.MERGED_SCRATCH["static"] = defer and not self.keep_grads
         if defer:
             ops.defer_begin(dev)
         try:
@@ -333,6 +345,7 @@ class GraphedTrainStep:
         loss = self._fwd_bwd(data)
         # Adam is elementwise: one update over the flat tensor equals the per-parameter updates
         self.opt = FlatAdam(self.pflat, lr=self.lr, weight_decay=self.wd)
+        self.opt.zero_grad_in_step = not self.keep_grads
         if self._w() > 1:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
             self.opt.grad_scale = 1.0 / self._w()     # the average is folded into the update
@@ -361,7 +374,7 @@ class GraphedTrainStep:
             if tl is not None:
                 for _ in range(4):
                     tl.pair("stamp_pair")
-            if self.wflat is not None:
+            if self.wflat is not None and self.keep_grads:
                 self.wflat.zero_()
             loss = self._loss_backward(static)
             if world == 1:          # nothing happens between backward and update: one graph, one launch
@@ -371,6 +384,10 @@ class GraphedTrainStep:
             g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 self.opt.step()
+        if self.wflat is not None and not self.keep_grads:
+            self.wflat.zero_()       # what the captured update leaves behind after every replay: zeros to accumulate into
+            if ops.MERGED_SCRATCH["buf"] is not None:
+                ops.MERGED_SCRATCH["buf"].zero_()
         return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss}
 
     def step(self, data) -> torch.Tensor:

@@ -39,11 +39,13 @@ const char* eqh_error_string(int code);
 /* Optimiser-side helpers of a training step over flat parameter / gradient buffers (main.py:137-140:
  * torch.optim.Adam).  eqh_adam_step: p, exp_avg, exp_avg_sq updated in place from grad * grad_scale
  * (+ weight_decay * p); `lr` is a DEVICE float and `state` a 16-byte zero-initialised device block holding
- * the step counter (advanced by the kernel), so a captured hipGraph follows a learning-rate schedule.
+ * the step counter (advanced by the kernel), so a captured hipGraph follows a learning-rate schedule; zero_grad != 0
+ * clears `grad` after reading it (optimizer.zero_grad() of the next step without a fill launch) and, with zero_also, a
+ * second buffer of zero_also_n floats (a multiple of 4; accumulators that are not parameter gradients).
  * eqh_copy_many: count device-to-device float copies (n[i] elements each) in one launch. */
-int eqh_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+int eqh_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                   const float* lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
-                  void* state, void* stream);
+                  void* state, int32_t zero_grad, float* zero_also, int64_t zero_also_n, void* stream);
 int eqh_copy_many(int32_t count, const float* const* src, float* const* dst, const int64_t* n, void* stream);
 /* Mean-squared-error loss of main.py:36,49-63 and its gradient in one launch: loss[0] = mean((pred - target)^2)
  * over n values, grad[i] = 2 (pred[i] - target[i]) / n.  n <= 65536 (one workgroup; a batch of molecules). */
@@ -144,6 +146,33 @@ typedef struct HgGemmProblem {
 size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* problems, int32_t tile);
 int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* problems, int32_t tile, void* workspace, size_t workspace_bytes,
                      void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched small matrix products with riders (csrc/small_mm.hip), one launch for up to 8 problems:
+ *     c[m, n] (+)= alpha * sum_k A(m, k) B(k, n) (+ u[m] v[n])      A(m, k) = a[m * a_rs + k * a_cs]
+ *     y[m]    (+)= sum_k A(m, k) x[k] (+ z[m])                       B(k, n) = b[k * b_rs + n * b_cs]
+ *     w[m]     += u[m]
+ * The weight-level products of two merged Linears and their backward (layers.MHNNSConv._prepare_merged; conv.py:172-181):
+ * any transposition through the strides; u/v, x/z/y, w optional (NULL).  fp32 FMA, fixed order: reproducible.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct HgSmallMM {
+    const float* a;
+    int64_t a_rs, a_cs;
+    const float* b;
+    int64_t b_rs, b_cs;
+    float* c;
+    int64_t ldc;
+    const float* u;
+    const float* v;
+    const float* x;
+    const float* z;
+    float* y;
+    float* w;
+    int32_t m, n, k;
+    float alpha;
+    int32_t accumulate_c, accumulate_y;
+} HgSmallMM;
+int hg_small_mm_batch(int32_t n_problems, const HgSmallMM* problems, void* stream);
 
 /* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
  * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch

@@ -1630,3 +1630,31 @@ def test_gemm_x6_epilogues_batches_and_views():
     assert torch.equal(ops.gemm(ai, bi, trans_b=False), ai @ bi)
     assert torch.equal(ops.gemm(ai.t().contiguous(), bi, trans_a=True, trans_b=False), ai @ bi)
     assert torch.equal(ops.gemm(ai, bi.t().contiguous(), trans_b=True), ai @ bi)
+
+
+def test_small_mm_batch_products_riders_and_accumulation():
+    """hg_small_mm_batch against float64: transposed operands through the strides, column-block views, the rank-1 addend,
+    the matrix-vector rider, accumulation into existing values, several problems in one launch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17)
+    A = torch.randn(96, 200, generator=g).to(DEV)            # use the column block [:, 40:140]
+    B = torch.randn(100, 72, generator=g).to(DEV)
+    bb, bo = torch.randn(100, generator=g).to(DEV), torch.randn(96, generator=g).to(DEV)
+    blk = A[:, 40:140]
+    wc, bc = torch.empty(96, 72, device=DEV), torch.empty(96, device=DEV)
+    dwc, dbc = torch.randn(96, 72, generator=g).to(DEV), torch.randn(96, generator=g).to(DEV)
+    gA = torch.randn(96, 200, generator=g).to(DEV)
+    gB, gbb, gbo = torch.randn(100, 72, generator=g).to(DEV), torch.randn(100, generator=g).to(DEV), torch.randn(96, generator=g).to(DEV)
+    gA0, gB0, gbb0, gbo0 = gA.clone(), gB.clone(), gbb.clone(), gbo.clone()
+    ops.small_mm_batch([dict(a=blk, b=B, c=wc, x=bb, z=bo, y=bc),
+                        dict(a=dwc, b=B, tb=True, c=gA[:, 40:140], accumulate=True, u=dbc, v=bb, w=gbo, alpha=0.5),
+                        dict(a=blk, ta=True, b=dwc, c=gB, accumulate=True, x=dbc, y=gbb, acc_y=True)])
+    d = lambda t: t.double().cpu()
+    np.testing.assert_allclose(d(wc), d(blk) @ d(B), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(d(bc), d(blk) @ d(bb) + d(bo), rtol=1e-5, atol=1e-4)
+    want = d(gA0).clone()
+    want[:, 40:140] += 0.5 * d(dwc) @ d(B).t() + torch.outer(d(dbc), d(bb))
+    np.testing.assert_allclose(d(gA), want, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(d(gB), d(gB0) + d(blk).t() @ d(dwc), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(d(gbb), d(gbb0) + d(blk).t() @ d(dbc), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(d(gbo), d(gbo0) + d(dbc), rtol=1e-6, atol=1e-6)

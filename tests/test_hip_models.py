@@ -291,7 +291,7 @@ def test_merged_linears_match_the_layer_by_layer_conv(graphed, monkeypatch):
         model = copy.deepcopy(model)
         b._hyper_index = None
         if graphed:
-            tr = GraphedTrainStep(model, lr=0.0)
+            tr = GraphedTrainStep(model, lr=0.0, keep_grads=True)
             tr.step(b)                      # bootstrap (eager)
             tr.step(b)                      # capture
             tr.step(b)                      # replay
