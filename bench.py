@@ -68,6 +68,9 @@ def parse():
     p.add_argument("--pool", type=int, default=8, help="distinct pre-collated batches per rank")
     p.add_argument("--c4-steps", type=int, default=10,
                    help="timed steps of the strong-scaling BASELINE config 4 leg (PCQM-like, global batch 1024); 0 = skip")
+    p.add_argument("--blocks", type=int, default=3,
+                   help="timed blocks of --steps steps each (every block bracketed by barrier + synchronize); the line "
+                        "reports the MEDIAN block, so that one outlier in a ~40 ms window does not move the headline")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pipeline", action="store_true", help="skip the loader-fed run (`pipeline` in the JSON line)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -486,26 +489,30 @@ def main():
             trainer.on_batch = fresh
         for i in range(warmup):
             trainer.step(batches[i % a.pool])
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for i in range(steps):
-            loss = trainer.step(batches[i % a.pool])
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return {"el": float(t.item()), "loss": float(loss), "host": host, "batches": batches, "model": model,
-                "trainer": trainer, "args": ns}
+        els = []
+        for blk in range(max(1, a.blocks)):
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                loss = trainer.step(batches[(blk * steps + i) % a.pool])
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's clock, per block
+            els.append(float(t.item()))
+        return {"el": sorted(els)[len(els) // 2], "els": els, "loss": float(loss), "host": host, "batches": batches,
+                "model": model, "trainer": trainer, "args": ns}
 
     run = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2)
     el, loss, host_batches, batches, model = run["el"], run["loss"], run["host"], run["batches"], run["model"]
+    block_ms = [round(e / a.steps * 1e3, 3) for e in run["els"]]
     run_args = run["args"]
     observed_world = dist.get_world_size() if world > 1 else 1      # what the (RCCL) process group reports
     assert observed_world == a.gpus, (observed_world, a.gpus)
@@ -533,6 +540,7 @@ def main():
             "unit": "molecules/s",
             "n_gpus": observed_world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3),
+            "timed_blocks_ms_per_step": block_ms,        # every block = --steps steps between barrier + synchronize; value = median
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.flavour}-like synthetic molecules, --method {a.method}, "

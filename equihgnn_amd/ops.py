@@ -418,8 +418,9 @@ def mm_nt(x, w, bias=None, d=None, alpha: float = 1.0, beta: float = 1.0, relu: 
         return torch.relu(y) if relu else y
     if d is not None:
         y = torch.addmm(d, x, w.t(), beta=beta, alpha=alpha)
-    else:
-        y = torch.mm(x, w.t()) * alpha
+    else:       # (beta = 0: the input is ignored -- alpha rides the GEMM instead of a scaling kernel)
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
+        torch.addmm(y, x, w.t(), beta=0.0, alpha=alpha, out=y)
     if bias is not None:
         y = y + bias
     return torch.relu(y) if relu else y
@@ -431,11 +432,11 @@ def mm_nn(x, w, d=None, alpha: float = 1.0, beta: float = 1.0, out=None):
     if _x6_ok(x, w, False, x.shape[0] * w.shape[1], x.shape[1]):
         return gemm(x, w, trans_b=False, d=d, alpha=alpha, beta=beta, out=out)
     if d is None:
-        y = torch.mm(x, w) if alpha == 1.0 else torch.mm(x, w) * alpha
-        if out is not None:
-            out.copy_(y)
-            return out
-        return y
+        if out is None:
+            out = torch.empty((x.shape[0], w.shape[1]), dtype=x.dtype, device=x.device)
+        if alpha == 1.0:
+            return torch.mm(x, w, out=out)
+        return torch.addmm(out, x, w, beta=0.0, alpha=alpha, out=out)   # (beta = 0: the input is ignored)
     if out is not None and out is d:
         return d.addmm_(x, w, beta=beta, alpha=alpha)
     y = torch.addmm(d, x, w, beta=beta, alpha=alpha)

@@ -253,7 +253,10 @@ class GraphedTrainStep:
             ops.defer_begin(dev)
         try:
             loss = self._loss(data)
-            loss.backward()
+            unit = getattr(self, "_unit", None)         # (loss.backward() would fill a fresh ones_like(loss) every step)
+            if unit is None or unit.device != loss.device or unit.dtype != loss.dtype:
+                unit = self._unit = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(unit)
         finally:
             if defer:
                 ops.defer_flush(dev)
