@@ -158,7 +158,7 @@ def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
     return per, floor
 
 
-def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=6, batches_per_epoch=12):
+def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=4, batches_per_epoch=40):
     """The same training step fed by the data pipeline instead of a resident pool: a MolStore of synthetic molecules,
     `fit.BucketedLoader` (array-operation collate into pinned packed staging buffers on a prefetch thread, one
     static bucket per epoch, one asynchronous host-to-device copy per batch) and GraphedTrainStep.  The first epoch
