@@ -2149,8 +2149,9 @@ class _DropoutMean(torch.autograd.Function):
         R = x2.shape[0] // F_
         seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
         out = torch.empty((R, C), dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out), _stream(x.device)),
-                  "faf_dropout_mean_fwd")
+        timed("k_drop_mean_fwd", 4 * C * R * (F_ + 1),        # one read of [R * F, C], one write of [R, C]
+              lambda: hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out),
+                                                               _stream(x.device)), "faf_dropout_mean_fwd"))
         ctx.seed, ctx.p, ctx.shape = seed, float(p), x.shape
         return out.view(*x.shape[:-2], C)
 
@@ -2160,8 +2161,9 @@ class _DropoutMean(torch.autograd.Function):
         dout = _f32c(dout).reshape(-1, C)
         R = dout.shape[0]
         dx = torch.empty((R * F_, C), dtype=torch.float32, device=dout.device)
-        hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx), _stream(dout.device)),
-                  "faf_dropout_mean_bwd")
+        timed("k_drop_mean_bwd", 4 * C * R * (F_ + 1),
+              lambda: hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx),
+                                                               _stream(dout.device)), "faf_dropout_mean_bwd"))
         return dx.view(ctx.shape), None, None
 
 
@@ -2230,9 +2232,11 @@ class _FrameHidden(torch.autograd.Function):
                 raise ValueError("frame_hidden: one base row per point expected")
         seed = seed if (seed is not None and p > 0) else _dropout_seed(y.device, p)
         out = torch.empty((E, 8, 128), dtype=torch.float32, device=y.device)
-        hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma), _ptr(beta),
-                                                 E, float(p), _ptr(seed), float(eps), _ptr(out), _stream(y.device)),
-                  "faf_frame_hidden_fwd")
+        # algorithmic bytes: 12 B of coordinates (+ a [256] base row when it is per point) in, [8, 128] out
+        timed("k_frame_hidden_fwd", E * (12 + (0 if ld == 0 else 1024) + 4096),
+              lambda: hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
+                                                               _ptr(beta), E, float(p), _ptr(seed), float(eps), _ptr(out),
+                                                               _stream(y.device)), "faf_frame_hidden_fwd"))
         ctx.save_for_backward(y2, w3c, base2, gamma, ex, wxc)
         ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape), None if extra is None else tuple(extra.shape),
                     wx is not None)
@@ -2257,9 +2261,11 @@ class _FrameHidden(torch.autograd.Function):
         ws = _workspace(max(ws_bytes, 16), dev)
         tg = [_acc_target(q) for q in ctx.acc]            # (gamma, beta)
         small = torch.empty((2, 128), dtype=torch.float32, device=dev)
-        hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma), _ptr(dhn), E, p,
-                                         _ptr(seed), eps, _ptr(dy), _ptr(dbase), _ptr(dwx), _ptr(dex), _ptr(dw3), _ptr(small[0]),
-                                         _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(dev)), "faf_frame_hidden_bwd")
+        timed("k_frame_hidden_bwd", E * (12 + (0 if ld == 0 else 2048) + 4096),     # d hidden in, (d base out)
+              lambda: hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
+                                                       _ptr(dhn), E, p, _ptr(seed), eps, _ptr(dy), _ptr(dbase), _ptr(dwx),
+                                                       _ptr(dex), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, _ptr(ws),
+                                                       ws_bytes, _stream(dev)), "faf_frame_hidden_bwd"))
         dgam, dbet = _hand_out(list(small), tg)
         if not vec:
             dbase = dbase.view(base_shape)
