@@ -123,17 +123,21 @@ class BucketedLoader:
     the training process's own thread."""
 
     def __init__(self, store: MolStore, batch_size: int, shuffle: bool, seed: int = 0, device=None, rank: int = 0,
-                 world: int = 1, quantum: int = 128, prefetch: int = 3, pin: Optional[bool] = None):
+                 world: int = 1, quantum: int = 128, prefetch: int = 3, pin: Optional[bool] = None, levels: int = 4):
         self.store, self.bs, self.shuffle, self.seed = store, batch_size, shuffle, seed
         self.device, self.rank, self.world, self.quantum, self.prefetch = device, rank, world, quantum, prefetch
         self.pin = (device is not None and torch.device(device).type == "cuda") if pin is None else pin
+        self.levels = max(1, int(levels))     # static shape buckets per run: a ladder below the largest batch (see plan)
         self.epoch = 0
         self.collate_seconds = 0.0      # host time spent assembling batches (all epochs), for the bench line
         self.collated = 0               # molecules assembled
         self._ring = {}                 # (extents, molecules) -> pinned staging buffers, kept across epochs
 
     def plan(self):
-        """This epoch's batches (index arrays) and the static extents all full batches are padded to."""
+        """This epoch's batches (index arrays) and, per batch, the static extents it is padded to: the top bucket holds
+        the largest batch of the run, and ``levels - 1`` smaller buckets one quantum apart below it take the batches
+        that fit -- a batch is padded by half a quantum on average instead of by (largest - mean) atoms, ~5 % of a
+        256-molecule QM9 batch, all of it GPU work; each bucket is one captured hipGraph."""
         idx = np.asarray(shard_indices(len(self.store), self.rank, self.world, self.seed, self.epoch, self.shuffle),
                          dtype=np.int64)
         self.epoch += 1
@@ -154,11 +158,22 @@ class BucketedLoader:
                for i, (e, s_) in enumerate(zip(ext, stat))]
         if nb == self.bs:
             self._envelope = ext
-        return batches, bucket_sizes(ext[0], ext[1], ext[2], self.quantum)
+        top = bucket_sizes(ext[0], ext[1], ext[2], self.quantum)
+        q = (self.quantum, self.quantum, 2 * self.quantum)
+        ladder = [tuple(t - l * qq for t, qq in zip(top, q)) for l in range(self.levels)]      # ladder[0] = top
+        sizes = [np.diff(pre(c)[cut]) for c in (self.store.n_nodes, self.store.n_he, self.store.n_inc)]
+        tgts = []
+        for i in range(len(batches)):
+            need = [int(sz[i]) + 1 for sz in sizes]          # (one spare slot: the padding molecule's own node / hyperedge)
+            lvl = 0
+            while lvl + 1 < len(ladder) and all(n <= t and t > 0 for n, t in zip(need, ladder[lvl + 1])):
+                lvl += 1
+            tgts.append(ladder[lvl])
+        return batches, tgts
 
     def __iter__(self):
         import time
-        batches, tgt = self.plan()
+        batches, tgts = self.plan()
         ring = self._ring               # (pinning host memory costs milliseconds per buffer: allocate once per shape)
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
 
@@ -168,7 +183,7 @@ class BucketedLoader:
             #         previous step's kernels and leave the training thread one stream-wait per batch
             side = self._side = getattr(self, "_side", None) or torch.cuda.Stream(self.device)
 
-        def stage(n_mols):
+        def stage(tgt, n_mols):
             """a free staging pair (pinned host buffer, device buffer) for a batch of n_mols molecules (ring of
             prefetch + 3 per shape): [host, h2d_done, device, consumed]"""
             slot = ring.setdefault((tgt, n_mols), {"bufs": [], "next": 0})
@@ -200,10 +215,10 @@ class BucketedLoader:
             # the epoch LOUDLY: it travels through the queue and is re-raised by the consumer.  Swallowed, the epoch
             # would just be shorter on this rank, and under data parallelism the next all-reduce would hang.
             try:
-                for b in batches:
+                for b, tgt in zip(batches, tgts):
                     if stop.is_set():
                         return
-                    ent = stage(len(b))
+                    ent = stage(tgt, len(b))
                     t0 = time.perf_counter()
                     self.store.collate(b, pad_to=tgt, out=ent[0])
                     self.collate_seconds += time.perf_counter() - t0

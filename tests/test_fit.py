@@ -124,8 +124,8 @@ def test_vectorised_collate_equals_loop_collate():
 
 
 def test_bucketed_loader_static_shapes_and_coverage():
-    """One static bucket per epoch (plus the smaller last batch), every molecule exactly once per epoch, packed
-    staging buffers, DistributedSampler sharding across two ranks."""
+    """A few static buckets per run (a ladder of `levels` shapes one quantum apart; exactly one with levels=1), every
+    molecule exactly once per epoch, packed staging buffers, DistributedSampler sharding across two ranks."""
     from equihgnn_amd.batch import MolStore
     from equihgnn_amd.fit import BucketedLoader
     mols = _mols(230, 4)
@@ -134,14 +134,17 @@ def test_bucketed_loader_static_shapes_and_coverage():
     store = MolStore(mols)
     seen = []
     for rank in range(2):
-        ld = BucketedLoader(store, 32, True, seed=5, device=None, rank=rank, world=2, prefetch=2)
+        ld = BucketedLoader(store, 32, True, seed=5, device=None, rank=rank, world=2, prefetch=2, levels=1 + 2 * rank)
         shapes = set()
         for b in ld:
             nb = b.num_real_graphs
             seen.extend(int(v) for v in b.y[:nb].tolist())
             shapes.add((b.x.shape[0], b.edge_attr.shape[0], b.edge_index0.shape[0], b.y.shape[0]))
             assert getattr(b, "_flat", None) is not None and int(b.batch[-1]) == nb
-        assert len({s[:3] for s in shapes}) == 1 and len(shapes) <= 2
+        buckets = sorted({s[:3] for s in shapes})
+        assert 1 <= len(buckets) <= ld.levels                 # rank 0: one bucket; rank 1: a ladder of up to three
+        for lo, hi in zip(buckets, buckets[1:]):              # neighbouring ladder steps: (q, q, 2 q) apart
+            assert (hi[0] - lo[0]) % ld.quantum == 0 and hi[2] - lo[2] == 2 * (hi[0] - lo[0]) and hi[1] - lo[1] == hi[0] - lo[0]
         assert ld.collated == 115 and ld.collate_seconds > 0
     assert sorted(seen) == list(range(230))
 
@@ -165,11 +168,11 @@ def test_fit_two_epochs_on_graphed_step():
     args = default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32)
     model = MODELS["egnn_equihnns"](1, args).to("cuda:0")
     fitter = Fitter(model, lr=2e-3, std=std, patience_lr=0, patience_stop=5, step_factory=GraphedTrainStep)
-    train = BucketedLoader(pick(tr), 32, True, seed=0, device="cuda:0")
-    res = fitter.fit(train, BucketedLoader(pick(va), 32, False, device="cuda:0"), epochs=3)
+    train = BucketedLoader(pick(tr), 32, True, seed=0, device="cuda:0", levels=2)
+    res = fitter.fit(train, BucketedLoader(pick(va), 32, False, device="cuda:0", levels=1), epochs=3)
     h = res.history
     assert len(h) == 3 and h[-1]["train_loss"] < h[0]["train_loss"] and np.isfinite(h[-1]["val_mae_mean"])
-    assert len(fitter.step.slots) <= 4                          # a few static shapes, not one per batch
+    assert len(fitter.step.slots) <= 4                          # a few static shapes (a two-step ladder), not one per batch
     assert train.collated == 3 * 320
     fitter.step.opt.sync_lr()                                   # (the trainer does this before every replay)
     assert abs(float(fitter.step.opt.state[fitter.step.pflat]["lr"]) - fitter.step.opt.param_groups[0]["lr"]) < 1e-9
