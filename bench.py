@@ -161,7 +161,7 @@ def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
     return per, floor
 
 
-def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=4, batches_per_epoch=40):
+def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=3, batches_per_epoch=100):
     """The same training step fed by the data pipeline instead of a resident pool: a MolStore of synthetic molecules,
     `fit.BucketedLoader` (array-operation collate into pinned packed staging buffers on a prefetch thread, one
     static bucket per epoch, one asynchronous host-to-device copy per batch) and GraphedTrainStep.  The first epoch
@@ -181,8 +181,15 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=4, batches_p
     model = MODELS[method](1, ns).to(dev)
     tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
     loader = BucketedLoader(store, batch_size, True, seed=1, device=dev)
-    for b in loader:                     # epoch 0: eager bootstrap + capture
-        tr.step(b)
+    # untimed: eager bootstrap, then epochs until every bucket of the loader's ladder has been captured (a capture costs
+    # ~0.3 s; a training run pays it once per bucket in its first epoch or two)
+    seen = -1
+    for _ in range(6):
+        for b in loader:
+            tr.step(b)
+        if len(tr.slots) == seen:
+            break
+        seen = len(tr.slots)
     torch.cuda.synchronize(dev)
     c0, s0 = loader.collated, loader.collate_seconds
     t0 = time.perf_counter()
@@ -219,7 +226,7 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=4, batches_p
             "bucket": list(resident[0].x.shape[:1]) + [int(resident[0].edge_attr.shape[0]), int(resident[0].edge_index0.shape[0])],
             "what": "training steps fed by MolStore -> BucketedLoader (prefetch thread, pinned packed staging, one H2D "
                     "copy per batch) -> GraphedTrainStep; PCIe transfer and host collate included",
-            "graphs_captured": n_graphs,
+            "graphs_captured": n_graphs, "graphs_captured_while_timed": n_graphs - seen,
             "host_collate_molecules_per_s": round((loader.collated - c0) / max(loader.collate_seconds - s0, 1e-9), 1),
             "host_collate_threads": 1}
 

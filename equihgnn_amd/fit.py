@@ -123,11 +123,17 @@ class BucketedLoader:
     the training process's own thread."""
 
     def __init__(self, store: MolStore, batch_size: int, shuffle: bool, seed: int = 0, device=None, rank: int = 0,
-                 world: int = 1, quantum: int = 128, prefetch: int = 3, pin: Optional[bool] = None, levels: int = 4):
+                 world: int = 1, quantum: int = 64, prefetch: int = 3, pin: Optional[bool] = None, levels: int = 1):
         self.store, self.bs, self.shuffle, self.seed = store, batch_size, shuffle, seed
         self.device, self.rank, self.world, self.quantum, self.prefetch = device, rank, world, quantum, prefetch
         self.pin = (device is not None and torch.device(device).type == "cuda") if pin is None else pin
-        self.levels = max(1, int(levels))     # static shape buckets per run: a ladder below the largest batch (see plan)
+        # static shape buckets per run: a ladder below the largest batch (see plan).  Default ONE: measured on MI355X /
+        # ROCm 7.2, replaying a DIFFERENT captured hipGraph than the previous step costs ~0.8 ms (2.28 against 1.49 ms
+        # per step when consecutive batches alternate between three buckets), far more than the ~3 % of padded rows a
+        # ladder saves; it pays only for a sampler that keeps equal-bucket batches together.
+        self.levels = max(1, int(levels))
+        self.lookahead = True           # start collating the next epoch before the current one is consumed (see _start_epoch)
+        self._pending = None
         self.epoch = 0
         self.collate_seconds = 0.0      # host time spent assembling batches (all epochs), for the bench line
         self.collated = 0               # molecules assembled
@@ -162,21 +168,34 @@ class BucketedLoader:
         q = (self.quantum, self.quantum, 2 * self.quantum)
         ladder = [tuple(t - l * qq for t, qq in zip(top, q)) for l in range(self.levels)]      # ladder[0] = top
         sizes = [np.diff(pre(c)[cut]) for c in (self.store.n_nodes, self.store.n_he, self.store.n_inc)]
-        tgts = []
+        # the rungs in use are those the FIRST epoch populated (each is then captured in that epoch); later epochs choose
+        # among them only, so a rare small or large batch never triggers a capture (seconds, with GEMM tuning) mid-run
+        known = getattr(self, "_rungs", None)
+        if known is not None and known[0] != top:
+            known = None                                      # the envelope grew: a new ladder
+        tgts, used = [], {0}
         for i in range(len(batches)):
             need = [int(sz[i]) + 1 for sz in sizes]          # (one spare slot: the padding molecule's own node / hyperedge)
             lvl = 0
-            while lvl + 1 < len(ladder) and all(n <= t and t > 0 for n, t in zip(need, ladder[lvl + 1])):
-                lvl += 1
+            for cand in range(1, len(ladder)):
+                if known is not None and cand not in known[1]:
+                    continue
+                if all(n <= t and t > 0 for n, t in zip(need, ladder[cand])):
+                    lvl = cand
+                else:
+                    break
+            used.add(lvl)
             tgts.append(ladder[lvl])
+        if known is None and nb == self.bs:
+            self._rungs = (top, used)
         return batches, tgts
 
-    def __iter__(self):
+    def _start_epoch(self):
+        """Plan the next epoch and start its prefetch thread; returns the epoch's (queue, thread, stop flag)."""
         import time
         batches, tgts = self.plan()
         ring = self._ring               # (pinning host memory costs milliseconds per buffer: allocate once per shape)
         q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
-
         cuda = self.device is not None and torch.device(self.device).type == "cuda"
         side = None
         if cuda:    # host-to-device copies are issued by the prefetch thread on a stream of their own: they overlap the
@@ -234,17 +253,33 @@ class BucketedLoader:
                             ent[1] = ev
                     if not put(ent):
                         return
-                put(None)
+                if put(None) and self.lookahead and not stop.is_set():
+                    # the next epoch's first batches are collated and shipped while the trainer still works through the
+                    # tail of this one: no pipeline drain (a few milliseconds of idle GPU) at the epoch boundary
+                    self._pending = self._start_epoch()
             except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
                 put(exc)
 
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        return {"q": q, "th": th, "stop": stop, "cuda": cuda}
+
+    def close(self):
+        """Stop a prefetch thread that was started ahead for an epoch that will not be consumed."""
+        pend, self._pending = getattr(self, "_pending", None), None
+        if pend is not None:
+            pend["stop"].set()
+            pend["th"].join()
+
+    def __iter__(self):
+        pend, self._pending = getattr(self, "_pending", None), None
+        ep = pend if pend is not None else self._start_epoch()
+        q, th, stop, cuda = ep["q"], ep["th"], ep["stop"], ep["cuda"]
         # two Python threads share the interpreter lock; with the default 5 ms switch interval the training thread (a few
         # hundred microseconds of work per 1.5 ms step) can wait milliseconds for the collating thread to yield it
         import sys
         old_interval = sys.getswitchinterval()
         sys.setswitchinterval(min(old_interval, 2e-4))
-        th = threading.Thread(target=produce, daemon=True)
-        th.start()
         prev = None
 
         def fresh(b):
@@ -254,6 +289,7 @@ class BucketedLoader:
             b._hyper_index = None
             return b
 
+        done = False
         try:
             while True:
                 ent = q.get()
@@ -262,6 +298,7 @@ class BucketedLoader:
                     ev.record(torch.cuda.current_stream(self.device))
                     prev[3] = ev
                 if ent is None:
+                    done = True
                     break
                 if isinstance(ent, BaseException):
                     raise RuntimeError("BucketedLoader: the prefetch thread failed") from ent
@@ -277,8 +314,11 @@ class BucketedLoader:
         finally:
             # also reached when the consumer abandons the generator (an exception in step(), a `break`): release the
             # producer, which may be blocked on a full queue holding ring entries the next __iter__ shares
-            stop.set()
-            th.join()
+            if not done:
+                stop.set()
+            th.join()                   # (a finished producer has also started the next epoch by now: see _start_epoch)
+            if not done:
+                self.close()            # (an epoch started ahead of an abandoned one is abandoned too)
             sys.setswitchinterval(old_interval)
 
 
