@@ -219,6 +219,7 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=3, batches_p
             tr.step(b)
     torch.cuda.synchronize(dev)
     res_ms = (time.perf_counter() - t1) / (reps * len(resident)) * 1e3
+    loader.close()
     tr.close()
     return {"value": round(n / el, 1), "unit": "molecules/s", "ms_per_step": round(el / (n / batch_size) * 1e3, 3),
             "resident_same_bucket_ms_per_step": round(res_ms, 3),

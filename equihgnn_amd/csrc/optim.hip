@@ -24,6 +24,18 @@ __global__ void __launch_bounds__(256)
 k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
        const float* __restrict__ lr_ptr, float beta1, float beta2, float eps, float wd, float gscale,
        AdamState* __restrict__ st, int zero_grad, float* __restrict__ zero_also, int64_t zero_also_n) {
+    // this thread's first quad is requested BEFORE the bias corrections are worked out (the grid is sized for one quad
+    // per thread: the step counter's load, two powf and a barrier otherwise sit in front of every memory request)
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 pp, gg, mm, vv;
+    if (i < n4) {
+        pp = reinterpret_cast<float4*>(p)[i];
+        gg = reinterpret_cast<const float4*>(g)[i];
+        mm = reinterpret_cast<float4*>(m)[i];
+        vv = reinterpret_cast<float4*>(v)[i];
+    }
     // the bias corrections once per workgroup (two powf per THREAD were most of the kernel's instructions)
     __shared__ float s_corr[2];
     if (threadIdx.x == 0) {
@@ -34,13 +46,7 @@ k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, floa
     __syncthreads();
     const float step_size = s_corr[0];
     const float bc2_sqrt = s_corr[1];
-    const int64_t n4 = n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        float4 gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+    for (; i < n4; i += stride) {
         float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -55,6 +61,12 @@ k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, floa
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = f4_zero();   // the next step's kernels accumulate into zeros
+        if (i + stride < n4) {
+            pp = reinterpret_cast<float4*>(p)[i + stride];
+            gg = reinterpret_cast<const float4*>(g)[i + stride];
+            mm = reinterpret_cast<float4*>(m)[i + stride];
+            vv = reinterpret_cast<float4*>(v)[i + stride];
+        }
     }
     // a second buffer cleared on the way (accumulators that are not parameter gradients: the merged weights' scratch)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (zero_also_n >> 2); i += stride)

@@ -29,6 +29,8 @@ import torch.distributed as dist
 import contextlib
 import queue
 import threading
+import weakref
+import atexit
 
 from .batch import HBatch, HMol, MolStore, bucket_sizes, collate, shard_indices
 from .trainer import TrainStep, _world
@@ -112,6 +114,9 @@ class MolLoader:
             yield b.to(self.device) if self.device is not None else b
 
 
+_LIVE_LOADERS: "weakref.WeakSet" = weakref.WeakSet()
+
+
 class BucketedLoader:
     """The loader of the graphed training step: per-rank batches with DistributedSampler semantics, assembled by array
     operations (``MolStore.collate``), padded to ONE static bucket per epoch -- the largest batch of the epoch, rounded
@@ -134,6 +139,7 @@ class BucketedLoader:
         self.levels = max(1, int(levels))
         self.lookahead = True           # start collating the next epoch before the current one is consumed (see _start_epoch)
         self._pending = None
+        _LIVE_LOADERS.add(self)         # (closed at interpreter exit: see _close_live_loaders)
         self.epoch = 0
         self.collate_seconds = 0.0      # host time spent assembling batches (all epochs), for the bench line
         self.collated = 0               # molecules assembled
@@ -219,6 +225,7 @@ class BucketedLoader:
             return ent
 
         stop = threading.Event()        # set when the consumer leaves early: the producer must not block on q.put
+        adopted = threading.Event()     # set when a consumer starts on this epoch (__iter__)
 
         def put(item) -> bool:
             while not stop.is_set():
@@ -253,16 +260,21 @@ class BucketedLoader:
                             ent[1] = ev
                     if not put(ent):
                         return
-                if put(None) and self.lookahead and not stop.is_set():
+                if put(None) and self.lookahead:
                     # the next epoch's first batches are collated and shipped while the trainer still works through the
-                    # tail of this one: no pipeline drain (a few milliseconds of idle GPU) at the epoch boundary
-                    self._pending = self._start_epoch()
+                    # tail of this one: no pipeline drain (a few milliseconds of idle GPU) at the epoch boundary.  ONE
+                    # epoch ahead only: an epoch that fits in the queue whole finishes before anybody consumes it, and
+                    # must not go on to start the one after it (and so on, without end)
+                    while not stop.is_set() and not adopted.wait(0.05):
+                        pass
+                    if not stop.is_set():
+                        self._pending = self._start_epoch()
             except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
                 put(exc)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        return {"q": q, "th": th, "stop": stop, "cuda": cuda}
+        return {"q": q, "th": th, "stop": stop, "cuda": cuda, "adopted": adopted}
 
     def close(self):
         """Stop a prefetch thread that was started ahead for an epoch that will not be consumed."""
@@ -275,6 +287,7 @@ class BucketedLoader:
         pend, self._pending = getattr(self, "_pending", None), None
         ep = pend if pend is not None else self._start_epoch()
         q, th, stop, cuda = ep["q"], ep["th"], ep["stop"], ep["cuda"]
+        ep["adopted"].set()
         # two Python threads share the interpreter lock; with the default 5 ms switch interval the training thread (a few
         # hundred microseconds of work per 1.5 ms step) can wait milliseconds for the collating thread to yield it
         import sys
@@ -320,6 +333,19 @@ class BucketedLoader:
             if not done:
                 self.close()            # (an epoch started ahead of an abandoned one is abandoned too)
             sys.setswitchinterval(old_interval)
+
+
+def _close_live_loaders():
+    """At interpreter exit: stop and join every prefetch thread that was started ahead.  A daemon thread killed inside a
+    HIP call (an event record, a pinned copy) while the runtime is torn down aborts the process."""
+    for ld in list(_LIVE_LOADERS):
+        try:
+            ld.close()
+        except Exception:  # noqa: BLE001 -- nothing useful can be done at exit
+            pass
+
+
+atexit.register(_close_live_loaders)
 
 
 def _drop_index(data):
@@ -372,6 +398,14 @@ class Fitter:
         return self.metrics.compute()
 
     def fit(self, train_loader, valid_loader, epochs: int) -> FitResult:
+        try:
+            return self._fit(train_loader, valid_loader, epochs)
+        finally:    # the loaders may have started an epoch ahead (BucketedLoader.lookahead) that nobody will consume
+            for ld in (train_loader, valid_loader):
+                if hasattr(ld, "close"):
+                    ld.close()
+
+    def _fit(self, train_loader, valid_loader, epochs: int) -> FitResult:
         res = FitResult()
         bad = 0
         for epoch in range(epochs):
@@ -407,13 +441,17 @@ class Fitter:
         self.metrics.reset()
         scale = self.std if self.std else 1.0
         preds, truth = [], []
-        with torch.no_grad():
-            for data in test_loader:
-                _drop_index(data)
-                out, y = _real(self.model(data), data)
-                self.metrics.update(out * scale, y * scale)
-                preds.append(out.detach().float().cpu())
-                truth.append(y.detach().float().cpu())
+        try:
+            with torch.no_grad():
+                for data in test_loader:
+                    _drop_index(data)
+                    out, y = _real(self.model(data), data)
+                    self.metrics.update(out * scale, y * scale)
+                    preds.append(out.detach().float().cpu())
+                    truth.append(y.detach().float().cpu())
+        finally:
+            if hasattr(test_loader, "close"):       # (one pass only: drop the epoch a BucketedLoader started ahead)
+                test_loader.close()
         p, t = torch.cat(preds), torch.cat(truth)
         if _world() > 1:  # self.all_gather(preds)
             gp = [None] * _world()

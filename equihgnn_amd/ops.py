@@ -1261,11 +1261,14 @@ class _ReadoutMse(torch.autograd.Function):
         ctx.targets = tg if (unit_grad and not in_place) else [None] * 10
         ctx.held = (dx,) if in_place else (dx, *grads)
         ctx.mark_non_differentiable(y)
+        ctx.set_materialize_grads(False)        # (no zero-filled gradient tensor for the predictions: one launch per step)
         return loss, y
 
     @staticmethod
     def backward(ctx, dloss, _dy):
         held = ctx.held
+        if dloss is None:
+            return (None,) * 18
         if not ctx.unit_grad:
             held = tuple(h * dloss for h in held)
         dx = held[0]

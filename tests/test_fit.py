@@ -135,6 +135,7 @@ def test_bucketed_loader_static_shapes_and_coverage():
     seen = []
     for rank in range(2):
         ld = BucketedLoader(store, 32, True, seed=5, device=None, rank=rank, world=2, prefetch=2, levels=1 + 2 * rank)
+        ld.lookahead = False                                    # (count exactly one epoch's collation below)
         shapes = set()
         for b in ld:
             nb = b.num_real_graphs
@@ -173,7 +174,7 @@ def test_fit_two_epochs_on_graphed_step():
     h = res.history
     assert len(h) == 3 and h[-1]["train_loss"] < h[0]["train_loss"] and np.isfinite(h[-1]["val_mae_mean"])
     assert len(fitter.step.slots) <= 4                          # a few static shapes (a two-step ladder), not one per batch
-    assert train.collated == 3 * 320
+    assert train.collated >= 3 * 320                            # (+ what was collated ahead for a fourth epoch)
     fitter.step.opt.sync_lr()                                   # (the trainer does this before every replay)
     assert abs(float(fitter.step.opt.state[fitter.step.pflat]["lr"]) - fitter.step.opt.param_groups[0]["lr"]) < 1e-9
     assert fitter.step.opt.param_groups[0]["lr"] <= 2e-3
@@ -233,6 +234,24 @@ def test_bucketed_loader_releases_its_thread_when_the_consumer_leaves_early():
             break                                             # generator closed: its finally-block stops the producer
     assert threading.active_count() == before
     assert sum(1 for _ in ld) == 10                           # and the next epoch is complete
+
+
+def test_bucketed_loader_runs_one_epoch_ahead_and_no_further():
+    """The prefetch thread starts the NEXT epoch when it has queued the current one; an epoch that fits in the queue
+    whole must not go on to start the one after it.  close() joins whatever was started ahead."""
+    import threading
+    import time
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    store = MolStore(_mols(32, 3))
+    before = threading.active_count()
+    ld = BucketedLoader(store, 16, True, seed=1, device=None, prefetch=3)        # 2 batches per epoch < queue depth
+    assert sum(1 for _ in ld) == 2
+    time.sleep(0.4)
+    assert 32 <= ld.collated <= 64                           # this epoch + at most the one started ahead
+    assert sum(b.num_real_graphs for b in ld) == 32          # which is the epoch the next pass consumes
+    ld.close()
+    assert threading.active_count() == before
 
 
 @pytest.mark.gpu
