@@ -69,8 +69,13 @@ class SwiGLUMLP(nn.Module):
             return ops.linear(h, self.fc2.weight, self.fc2.bias)
         return self.fc2(h)
 
+    def _fc1(self, x):
+        if x.is_cuda:   # as _fc2: the weight gradient joins the batched launch at the end of the backward pass
+            return ops.linear(x, self.fc1.weight, self.fc1.bias)
+        return self.fc1(x)
+
     def forward(self, x):
-        return F.dropout(self._fc2(self.hidden(self.fc1(x))), self.p, self.training)
+        return F.dropout(self._fc2(self.hidden(self._fc1(x))), self.p, self.training)
 
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
@@ -228,7 +233,8 @@ class MLPAttnEdgeAggregation(nn.Module):
     def forward(self, tok, geo, edge, g: EdgeGraph, row_mask=None):
         n, k, h = g.N, g.K, self.h
         d, de = self.h * self.dh, self.h * self.deh
-        q, kk, v = self.layernorm_qkv[1](_layer_norm(self.layernorm_qkv[0], tok)).chunk(3, -1)
+        qkv_in, qkv_lin = _layer_norm(self.layernorm_qkv[0], tok), self.layernorm_qkv[1]
+        q, kk, v = (ops.linear(qkv_in, qkv_lin.weight, qkv_lin.bias) if tok.is_cuda else qkv_lin(qkv_in)).chunk(3, -1)
         # The logits are LINEAR in their inputs (:483-489: Linear(dh, 1) of q_i + k_j, plus Linear(deh, 1) of the edge
         # query), so they are evaluated where the inputs live instead of on [N, K, h, dh] edge tensors:
         #   w . (q_i + k_j)      = a_q[i] + a_k[j]                  two dot products per ATOM and head; a_k is gathered

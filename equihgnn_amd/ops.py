@@ -398,6 +398,8 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1
 # [256 x 256] products of a QM9 batch, one workgroup per CU and eight K steps -- the tuned library is 10-30 % ahead.
 X6_MIN_OUTPUTS = 6_000_000
 X6_MAX_K = 1024
+X6_DEEP_ROWS = 32768        # weight gradients dY^T X over at least this many rows: the split-K form of the x6 kernel
+X6_WGRAD_ROWS = 8192        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
 USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
 
 
@@ -1154,6 +1156,7 @@ def defer_flush(device):
     _DEFER["colsum"] = []
     try:
         by_shape = {}
+        x6_mid = []
         for en in pending:
             by_shape.setdefault(tuple(en[3].shape), []).append(en)
         for group in by_shape.values():
@@ -1161,8 +1164,8 @@ def defer_flush(device):
             # go one by one to the single-product split-K kernel, which cuts K into as many chunks as there are idle
             # CUs (the batched kernel splits K three ways, right for the ~5 k-row products of the conv layers; the
             # library has no split-K choice for such shapes: 2.1 ms for 129 GFLOP)
-            deep = [en for en in group if en[0].shape[0] >= 32768]
-            rest = [en for en in group if en[0].shape[0] < 32768]
+            deep = [en for en in group if en[0].shape[0] >= X6_DEEP_ROWS]
+            rest = [en for en in group if en[0].shape[0] < X6_DEEP_ROWS]
             with torch.no_grad():
                 for dy2, x2, alpha, into in deep:
                     if USE_X6 and gemm_supported(dy2, x2, True, False):
@@ -1171,12 +1174,25 @@ def defer_flush(device):
                         gemm(dy2, x2, trans_a=True, trans_b=False, d=into, out=into, alpha=alpha)
                     else:
                         wgrad(dy2, x2, alpha, into=into)
+            # ~10^4-row products (FAFormer's atom-level Linears): whatever their shapes, up to eight of them share one x6
+            # launch whose split-K plan fills the chip per product (the library runs a [256 x 15 k].[15 k x 128] product on
+            # 8 tiles: 100 us for 1 GFLOP; hg_wgrad_batch_f32 reaches 75 TFLOP/s on the fp32 MFMA)
+            mid = [en for en in rest if USE_X6 and en[0].shape[0] >= X6_WGRAD_ROWS and gemm_supported(en[0], en[1], True, False)]
+            if mid:
+                x6_mid.extend(mid)
+                rest = [en for en in rest if not any(en is m for m in mid)]
             if len(rest) >= 3:
                 wgrad_batch(rest)
             else:   # too few products of this shape to fill the chip together: the library GEMM is faster
                 with torch.no_grad():
                     for dy2, x2, alpha, into in rest:
                         into.addmm_(dy2.t(), x2, alpha=alpha)
+        with torch.no_grad():
+            for i in range(0, len(x6_mid), 8):
+                chunk = x6_mid[i:i + 8]
+                for dy2, x2, _, _ in chunk:
+                    _DEFER["keep"].extend((dy2, x2))
+                gemm_batch([GemmProblem(dy2, x2, True, False, None, into, alpha, 1.0, False, into) for dy2, x2, alpha, into in chunk])
         colsum_batch(sums)
     finally:
         _DEFER["active"] = False
@@ -1505,11 +1521,21 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
             dy2.record_stream(side)
             x2.record_stream(side)
         return None
+    # no accumulator (the parameter also receives gradients from plain autograd ops): the gradient goes to autograd.  A
+    # deep product ([256 x 250 k].[250 k x 256] on FAFormer's edge rows) takes the split-K x6 kernel: 0.21 against the
+    # library's 0.71 ms
+    deep = USE_X6 and dy2.is_cuda and dy2.shape[0] >= X6_DEEP_ROWS and gemm_supported(dy2, x2, True, False)
     if c0 is None and r0 is None:
+        if deep:
+            return gemm(_f32c(dy2), _f32c(x2), trans_a=True, trans_b=False)
         return wgrad(dy2, x2) if _wgrad_ok(dy2, x2) else dy2.t() @ x2
     dw = torch.zeros_like(weight)
     blk = dw if c0 is None else dw[:, c0:c1]
-    (blk if r0 is None else blk[r0:r1]).copy_(dy2.t() @ x2)
+    blk = blk if r0 is None else blk[r0:r1]
+    if deep and blk.stride(1) == 1:
+        gemm(_f32c(dy2), _f32c(x2), trans_a=True, trans_b=False, out=blk)
+    else:
+        blk.copy_(dy2.t() @ x2)
     return dw
 
 
