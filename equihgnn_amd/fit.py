@@ -196,12 +196,17 @@ class BucketedLoader:
             self._rungs = (top, used)
         return batches, tgts
 
-    def _start_epoch(self):
-        """Plan the next epoch and start its prefetch thread; returns the epoch's (queue, thread, stop flag)."""
+    def _start_epoch(self, q=None):
+        """Plan the next epoch and start its prefetch thread; returns the epoch's (queue, thread, stop flag).  ``q``: the
+        queue of the epoch this one is started AHEAD of.  Both epochs then share it, so the bound on batches in flight
+        (queue depth + the one being staged + the two the consumer holds <= the ring of prefetch + 3 buffers) also holds
+        across the epoch boundary -- with a queue of its own the new epoch would refill ring buffers that still wait,
+        unconsumed, in the old one."""
         import time
         batches, tgts = self.plan()
         ring = self._ring               # (pinning host memory costs milliseconds per buffer: allocate once per shape)
-        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        if q is None:
+            q = queue.Queue(maxsize=self.prefetch)
         cuda = self.device is not None and torch.device(self.device).type == "cuda"
         side = None
         if cuda:    # host-to-device copies are issued by the prefetch thread on a stream of their own: they overlap the
@@ -268,7 +273,7 @@ class BucketedLoader:
                     while not stop.is_set() and not adopted.wait(0.05):
                         pass
                     if not stop.is_set():
-                        self._pending = self._start_epoch()
+                        self._pending = self._start_epoch(q)
             except BaseException as exc:  # noqa: BLE001 -- handed to the consumer, which re-raises it
                 put(exc)
 

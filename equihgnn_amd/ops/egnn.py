@@ -1,0 +1,178 @@
+"""EGNN front end: fused edge MLP kernels, feature GEMM + LayerNorm node, weight packing (egnn_layer.py).
+
+Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fallback).
+"""
+from __future__ import annotations
+
+
+import torch
+
+from .. import hip
+from ._base import (
+    ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream,
+    _workspace, timed)
+from .scatter import (CSR)
+from .gemm import (mm_nn, mm_nt)
+from .grads import (colsum)
+
+
+class _EgnnEdge(torch.autograd.Function):
+    """m_i = sum_j silu(W2 silu(A_i + B_j + wd d2_ij) + b2) — the fused EGNN edge update
+    (egnn_layer.py:298-310,357-358).  Saves only ``ab`` and the 16x16 second-layer
+    pre-activations; the per-edge hidden activations are recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR, b2_param=None):
+        _require_gpu(ab, "egnn_edge")
+        ab, wd, w2, b2 = _f32c(ab), _f32c(wd), _f32c(w2), _f32c(b2)
+        N, Hp = ab.shape[0], ab.shape[1] // 2
+        if nbr.shape != (N, 16) or w2.shape != (16, Hp) or wd.shape != (Hp,) or b2.shape != (16,):
+            raise ValueError("egnn_edge: shapes must be ab[N,2Hp] wd[Hp] w2[16,Hp] b2[16] nbr[N,16]")
+        m = torch.empty((N, 16), dtype=torch.float32, device=ab.device)
+        pre2 = torch.empty((N, 16, 16), dtype=torch.float32, device=ab.device)
+        # MFMA flops only: 2 * 16 outputs per (edge, hidden unit)
+        timed("egnn_edge_fwd", N * 16 * Hp * 32,
+              lambda: hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
+                                                        _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd"))
+        ctx.save_for_backward(ab, wd, w2, pre2)
+        ctx.nbr, ctx.d2, ctx.csr_t, ctx.b2_param = nbr, d2, csr_t, b2_param
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        ab, wd, w2, pre2 = ctx.saved_tensors
+        dm, dm_ld = _rows_ld(dm)          # usually the last 16 columns of d node_in: read in place
+        N, Hp = ab.shape[0], ab.shape[1] // 2
+        dev = ab.device
+        dab = torch.empty_like(ab)
+        dwd = torch.empty_like(wd)
+        dw2 = torch.empty_like(w2)
+        dpre2 = torch.empty_like(pre2)
+        L = hip.lib()
+        ws_bytes = L.egnn_edge_bwd_workspace_bytes(N, Hp)
+        ws = _workspace(ws_bytes, dev)   # holds the d b2 slabs: parked while reductions are deferred
+        tg = _acc_target(ctx.b2_param)   # d b2 = sum of dpre2 over nodes and slots, from the same pass
+        db2 = tg if tg is not None else torch.empty(16, dtype=torch.float32, device=dev)
+        timed("egnn_edge_bwd", N * 16 * Hp * 96,     # MFMA flops only: three 16-wide products per (edge, hidden unit)
+              lambda: hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
+                                                _ptr(dm), dm_ld, _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
+                                                _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0,
+                                                _ptr(ws), ws_bytes, _stream(dev)), "egnn_edge_bwd"))
+        return dab, dwd, dw2, (None if tg is not None else db2), None, None, None, None
+
+
+class _EgnnFeats(torch.autograd.Function):
+    """The three uses of the node features in an EGNN layer as ONE autograd node: ab = feats @ w_cat.T + b_cat
+    (both halves of the first edge Linear, egnn_layer.py:298-305 split by columns), LayerNorm(feats)
+    (node_norm, :192/:360) and feats itself for the residual (:362).  Their three input gradients arrive
+    together, so they meet inside the LayerNorm backward kernel (its ``add`` operand) and an accumulating
+    GEMM instead of two add kernels."""
+
+    @staticmethod
+    def forward(ctx, feats, w_cat, b_cat, gamma, beta, eps, acc_params):
+        _require_gpu(feats, "egnn_feats")
+        feats = _f32c(feats)
+        g, b = _f32c(gamma), _f32c(beta)
+        R, C = feats.shape
+        normed = torch.empty_like(feats)
+        hip.check(hip.lib().hg_layer_norm_fwd(_ptr(feats), _ptr(g), _ptr(b), R, C, float(eps), _ptr(normed),
+                                              _stream(feats.device)), "hg_layer_norm_fwd")
+        ab = mm_nt(feats, w_cat, bias=b_cat)
+        ctx.save_for_backward(feats, w_cat, g)
+        ctx.eps, ctx.acc = float(eps), acc_params
+        ctx.set_materialize_grads(False)
+        return ab, normed, feats.view_as(feats)
+
+    @staticmethod
+    def backward(ctx, d_ab, d_normed, d_res):
+        feats, w_cat, gamma = ctx.saved_tensors
+        R, C = feats.shape
+        dev = feats.device
+        L = hip.lib()
+        dgamma = dbeta = None
+        if d_normed is not None:
+            d_normed, dy_ld = _rows_ld(d_normed)     # usually the first C columns of d node_in: read in place
+            add = _f32c(d_res) if d_res is not None else None
+            dx = torch.empty_like(feats)
+            ws_bytes = L.hg_layer_norm_bwd_workspace_bytes(R, C)
+            ws = _workspace(ws_bytes, dev)
+            tg = [_acc_target(p) for p in ctx.acc]
+            in_place = all(t is not None for t in tg)
+            small = tg if in_place else list(torch.empty((2, C), dtype=torch.float32, device=dev))
+            hip.check(L.hg_layer_norm_bwd(_ptr(feats), _ptr(gamma), _ptr(d_normed), dy_ld, _ptr(add), R, C, ctx.eps, _ptr(dx),
+                                          _ptr(small[0]), _ptr(small[1]), 1 if in_place else 0, _ptr(ws), ws_bytes,
+                                          _stream(dev)), "hg_layer_norm_bwd")
+            if not in_place:
+                dgamma, dbeta = _hand_out(list(small), tg)
+        else:
+            dx = _f32c(d_res).clone() if d_res is not None else None
+        dw = db = None
+        if d_ab is not None:
+            d_ab = _f32c(d_ab)
+            dx = mm_nn(d_ab, w_cat) if dx is None else mm_nn(d_ab, w_cat, d=dx, out=dx)
+            if ctx.needs_input_grad[1]:
+                dw = d_ab.t() @ feats
+            if ctx.needs_input_grad[2]:
+                db = colsum(d_ab)
+        return dx, dw, db, dgamma, dbeta, None, None
+
+
+def egnn_feats(feats, w_cat, b_cat, norm):
+    """(feats @ w_cat.T + b_cat, LayerNorm(feats), feats) for 2-D fp32 ``feats`` [N, C] (C % 4 == 0, C <= 1024);
+    ``norm`` the nn.LayerNorm module.  See _EgnnFeats."""
+    _note_acc(norm.weight, norm.bias)
+    return _EgnnFeats.apply(feats, w_cat, b_cat, norm.weight, norm.bias, norm.eps, (norm.weight, norm.bias))
+
+
+class _EgnnPackWeights(torch.autograd.Function):
+    """(lin1.weight [H,2C+1], lin1.bias [H], lin2.weight [16,H]) -> (w_cat, b_cat, wd, w2p): the
+    operand layout of the fused EGNN edge kernel, one launch each way."""
+
+    @staticmethod
+    def forward(ctx, w1, b1, w2, Hp, acc_params):
+        _require_gpu(w1, "egnn_pack_weights")
+        w1, b1, w2 = _f32c(w1), _f32c(b1), _f32c(w2)
+        H, in_ld = w1.shape
+        C = (in_ld - 1) // 2
+        dev = w1.device
+        w_cat = torch.empty((2 * Hp, C), dtype=torch.float32, device=dev)
+        b_cat = torch.empty(2 * Hp, dtype=torch.float32, device=dev)
+        wd = torch.empty(Hp, dtype=torch.float32, device=dev)
+        w2p = torch.empty((16, Hp), dtype=torch.float32, device=dev)
+        hip.check(hip.lib().egnn_pack_weights_fwd(_ptr(w1), _ptr(b1), _ptr(w2), H, Hp, C, _ptr(w_cat), _ptr(b_cat),
+                                                  _ptr(wd), _ptr(w2p), _stream(dev)), "egnn_pack_weights_fwd")
+        ctx.dims = (H, Hp, C)
+        ctx.acc = acc_params
+        return w_cat, b_cat, wd, w2p
+
+    @staticmethod
+    def backward(ctx, dw_cat, db_cat, dwd, dw2p):
+        H, Hp, C = ctx.dims
+        dev = dw_cat.device
+        tg = [_acc_target(p) for p in ctx.acc]
+        in_place = all(t is not None for t in tg)      # the parameters' accumulators: nothing left for autograd
+        if in_place:
+            dw1, db1, dw2 = tg
+        else:
+            dw1 = torch.empty((H, 2 * C + 1), dtype=torch.float32, device=dev)
+            db1 = torch.empty(H, dtype=torch.float32, device=dev)
+            dw2 = torch.empty((16, H), dtype=torch.float32, device=dev)
+        hip.check(hip.lib().egnn_pack_weights_bwd(_ptr(_f32c(dw_cat)), _ptr(_f32c(db_cat)), _ptr(_f32c(dwd)),
+                                                  _ptr(_f32c(dw2p)), H, Hp, C, _ptr(dw1), _ptr(db1), _ptr(dw2),
+                                                  1 if in_place else 0, _stream(dev)), "egnn_pack_weights_bwd")
+        if in_place:
+            return None, None, None, None, None
+        return (*_hand_out([dw1, db1, dw2], tg), None, None)
+
+
+def egnn_pack_weights(w1, b1, w2, Hp):
+    if torch.is_grad_enabled():
+        for w in (w1, b1, w2):
+            if w.requires_grad and w.is_leaf:
+                (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
+    return _EgnnPackWeights.apply(w1, b1, w2, Hp, (w1, b1, w2))
+
+
+def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
+    _note_acc(b2)
+    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2)

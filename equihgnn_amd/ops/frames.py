@@ -1,0 +1,411 @@
+"""FAFormer operators: frame-averaged SwiGLU MLP pieces, edge hidden layer, row dots, gates, attention sums, 3x3 eigh
+(fa_former_layer.py).
+
+Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fallback).
+"""
+from __future__ import annotations
+
+
+import torch
+
+from .. import hip
+from ._base import (_acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
+from .scatter import (CSR, _segment_reduce)
+
+
+def _dropout_seed(device, p):
+    """A fresh int64 seed in device memory (drawn by torch's generator: graph-safe, a new value per replay)."""
+    if p <= 0.0:
+        return None
+    return torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
+
+
+class _SwigluDropout(torch.autograd.Function):
+    """dropout_p(silu(pre[:, :H]) * pre[:, H:]) in one pass each way (faf_swiglu_dropout_*, csrc/faformer_ew.hip)."""
+
+    @staticmethod
+    def forward(ctx, pre, p, seed=None):
+        _require_gpu(pre, "swiglu_dropout")
+        pre2 = _f32c(pre).reshape(-1, pre.shape[-1])
+        R, H = pre2.shape[0], pre2.shape[1] // 2
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(pre.device, p)
+        out = torch.empty((R, H), dtype=torch.float32, device=pre.device)
+        hip.check(hip.lib().faf_swiglu_dropout_fwd(_ptr(pre2), R, H, float(p), _ptr(seed), _ptr(out), _stream(pre.device)),
+                  "faf_swiglu_dropout_fwd")
+        ctx.save_for_backward(pre2)
+        ctx.seed, ctx.p, ctx.shape = seed, float(p), pre.shape
+        return out.view(*pre.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pre2,) = ctx.saved_tensors
+        R, H = pre2.shape[0], pre2.shape[1] // 2
+        dout = _f32c(dout).reshape(R, H)
+        dpre = torch.empty_like(pre2)
+        hip.check(hip.lib().faf_swiglu_dropout_bwd(_ptr(pre2), _ptr(dout), R, H, ctx.p, _ptr(ctx.seed), _ptr(dpre),
+                                                   _stream(pre2.device)), "faf_swiglu_dropout_bwd")
+        return dpre.view(ctx.shape), None, None
+
+
+class _DropoutMean(torch.autograd.Function):
+    """mean over dim -2 of dropout_p(x) in one pass each way (faf_dropout_mean_*)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed=None):
+        _require_gpu(x, "dropout_mean")
+        F_, C = x.shape[-2], x.shape[-1]
+        x2 = _f32c(x).reshape(-1, C)
+        R = x2.shape[0] // F_
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
+        out = torch.empty((R, C), dtype=torch.float32, device=x.device)
+        timed("k_drop_mean_fwd", 4 * C * R * (F_ + 1),        # one read of [R * F, C], one write of [R, C]
+              lambda: hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out),
+                                                               _stream(x.device)), "faf_dropout_mean_fwd"))
+        ctx.seed, ctx.p, ctx.shape = seed, float(p), x.shape
+        return out.view(*x.shape[:-2], C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        F_, C = ctx.shape[-2], ctx.shape[-1]
+        dout = _f32c(dout).reshape(-1, C)
+        R = dout.shape[0]
+        dx = torch.empty((R * F_, C), dtype=torch.float32, device=dout.device)
+        timed("k_drop_mean_bwd", 4 * C * R * (F_ + 1),
+              lambda: hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx),
+                                                               _stream(dout.device)), "faf_dropout_mean_bwd"))
+        return dx.view(ctx.shape), None, None
+
+
+class _FramePre(torch.autograd.Function):
+    """pre[e, f, :] = w3 (y[e] * s_f) + base[e] over the 8 sign frames, one pass each way (faf_frame_pre_*)."""
+
+    @staticmethod
+    def forward(ctx, y, w3, base):
+        _require_gpu(y, "frame_pre")
+        lead = y.shape[:-1]
+        y2, w3c = _f32c(y).reshape(-1, 3), _f32c(w3)
+        H = w3c.shape[0]
+        base2 = _f32c(base.expand(*lead, H)).reshape(-1, H)
+        E = y2.shape[0]
+        out = torch.empty((E, 8, H), dtype=torch.float32, device=y.device)
+        hip.check(hip.lib().faf_frame_pre_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), E, H, _ptr(out), _stream(y.device)),
+                  "faf_frame_pre_fwd")
+        ctx.save_for_backward(y2, w3c)
+        ctx.lead, ctx.base_shape = lead, base.shape
+        return out.view(*lead, 8, H)
+
+    @staticmethod
+    def backward(ctx, dpre):
+        y2, w3c = ctx.saved_tensors
+        E, H = y2.shape[0], w3c.shape[0]
+        dpre = _f32c(dpre).reshape(E, 8, H)
+        dev = y2.device
+        dy = torch.empty_like(y2)
+        dbase = torch.empty((E, H), dtype=torch.float32, device=dev)
+        dw3 = torch.empty_like(w3c)
+        L = hip.lib()
+        ws_bytes = L.faf_frame_pre_bwd_workspace_bytes(E, H)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        hip.check(L.faf_frame_pre_bwd(_ptr(y2), _ptr(w3c), _ptr(dpre), E, H, _ptr(dy), _ptr(dbase), _ptr(dw3), 0, _ptr(ws),
+                                      ws_bytes, _stream(dev)), "faf_frame_pre_bwd")
+        dbase = dbase.view(*ctx.lead, H)
+        if tuple(ctx.base_shape) != tuple(dbase.shape):          # base was broadcast (a bias vector): sum it back
+            dbase = dbase.sum_to_size(ctx.base_shape)
+        return dy.view(*ctx.lead, 3), dw3, dbase
+
+
+class _FrameHidden(torch.autograd.Function):
+    """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = w3 (y * s_f) + base over the 8 sign frames: frame_pre, swiglu_dropout
+    and the row LayerNorm in one launch each way (faf_frame_hidden_*); the [.., 8, 256] pre-activations never exist.
+    ``base``: rows [..., 256], or (vector form) fc1's bias [256] with the optional K = 1 Linear extra [..., 1] * wx [256]
+    evaluated inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, y, w3, base, extra, wx, gamma, beta, eps, p, seed, acc_params):
+        _require_gpu(y, "frame_hidden")
+        lead = y.shape[:-1]
+        y2, w3c, gamma, beta = _f32c(y).reshape(-1, 3), _f32c(w3), _f32c(gamma), _f32c(beta)
+        if w3c.shape[0] != 256 or gamma.numel() != 128:
+            raise ValueError("frame_hidden: fc1 with 256 outputs expected")
+        E = y2.shape[0]
+        vec = base.dim() == 1
+        if vec:
+            base2, ld = _f32c(base), 0
+            wxc = _f32c(wx) if wx is not None else torch.zeros(256, dtype=torch.float32, device=y.device)
+            ex = _f32c(extra).reshape(-1) if extra is not None else None
+            if ex is not None and ex.shape[0] != E:
+                raise ValueError("frame_hidden: one extra value per point expected")
+        else:
+            base2, ld, wxc, ex = _f32c(base).reshape(-1, 256), 256, None, None
+            if base2.shape[0] != E:
+                raise ValueError("frame_hidden: one base row per point expected")
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(y.device, p)
+        out = torch.empty((E, 8, 128), dtype=torch.float32, device=y.device)
+        # algorithmic bytes: 12 B of coordinates (+ a [256] base row when it is per point) in, [8, 128] out
+        timed("k_frame_hidden_fwd", E * (12 + (0 if ld == 0 else 1024) + 4096),
+              lambda: hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
+                                                               _ptr(beta), E, float(p), _ptr(seed), float(eps), _ptr(out),
+                                                               _stream(y.device)), "faf_frame_hidden_fwd"))
+        ctx.save_for_backward(y2, w3c, base2, gamma, ex, wxc)
+        ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape), None if extra is None else tuple(extra.shape),
+                    wx is not None)
+        ctx.acc = acc_params
+        return out.view(*lead, 8, 128)
+
+    @staticmethod
+    def backward(ctx, dhn):
+        y2, w3c, base2, gamma, ex, wxc = ctx.saved_tensors
+        lead, ld, eps, p, seed, base_shape, extra_shape, has_wx = ctx.meta
+        E = y2.shape[0]
+        dev = y2.device
+        vec = wxc is not None
+        dhn = _f32c(dhn).reshape(E, 8, 128)
+        dy = torch.empty_like(y2)
+        dbase = torch.empty((256,) if vec else (E, 256), dtype=torch.float32, device=dev)
+        dwx = torch.empty(256, dtype=torch.float32, device=dev) if vec else None
+        dex = torch.empty(E, dtype=torch.float32, device=dev) if ex is not None else None
+        dw3 = torch.empty_like(w3c)
+        L = hip.lib()
+        ws_bytes = L.faf_frame_hidden_bwd_workspace_bytes(E)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(q) for q in ctx.acc]            # (gamma, beta)
+        small = torch.empty((2, 128), dtype=torch.float32, device=dev)
+        timed("k_frame_hidden_bwd", E * (12 + (0 if ld == 0 else 2048) + 4096),     # d hidden in, (d base out)
+              lambda: hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
+                                                       _ptr(dhn), E, p, _ptr(seed), eps, _ptr(dy), _ptr(dbase), _ptr(dwx),
+                                                       _ptr(dex), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, _ptr(ws),
+                                                       ws_bytes, _stream(dev)), "faf_frame_hidden_bwd"))
+        dgam, dbet = _hand_out(list(small), tg)
+        if not vec:
+            dbase = dbase.view(base_shape)
+        return (dy.view(*lead, 3), dw3, dbase, None if dex is None else dex.view(extra_shape), dwx if has_wx else None,
+                dgam, dbet, None, None, None, None)
+
+
+class _EdgeHidden(torch.autograd.Function):
+    """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k] on the kNN edges, one launch each way
+    (faf_edge_hidden_*): the gathered / summed [N, K, 256] pre-activations and the [N, K, 128] gated values never exist."""
+
+    @staticmethod
+    def forward(ctx, A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, acc_params):
+        _require_gpu(A, "edge_hidden")
+        A, B, gamma, beta = _f32c(A), _f32c(B), _f32c(gamma), _f32c(beta)
+        N, K = nbr.shape
+        Cf2 = _f32c(Cf).reshape(N * K, 256)
+        if A.shape != (N, 256) or B.shape != (N, 256) or gamma.numel() != 128 or nbr.dtype != torch.int32:
+            raise ValueError("edge_hidden: A, B [N, 256], Cf [N * K, 256], nbr int32 [N, K], gamma [128] expected")
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(A.device, p)
+        out = torch.empty((N, K, 128), dtype=torch.float32, device=A.device)
+        hip.check(hip.lib().faf_edge_hidden_fwd(_ptr(A), _ptr(B), _ptr(Cf2), _ptr(nbr), _ptr(gamma), _ptr(beta), N, K, float(p),
+                                                _ptr(seed), float(eps), _ptr(out), _stream(A.device)), "faf_edge_hidden_fwd")
+        ctx.save_for_backward(A, B, Cf2, gamma)
+        ctx.meta = (nbr, csr_t, float(eps), float(p), seed, Cf.shape)
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dhn):
+        A, B, Cf2, gamma = ctx.saved_tensors
+        nbr, csr_t, eps, p, seed, cf_shape = ctx.meta
+        N, K = nbr.shape
+        dev = A.device
+        dhn = _f32c(dhn).reshape(N * K, 128)
+        dpre = torch.empty_like(Cf2)
+        dA = torch.empty_like(A)
+        L = hip.lib()
+        ws_bytes = L.faf_edge_hidden_bwd_workspace_bytes(N)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(q) for q in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty((2, 128), dtype=torch.float32, device=dev)
+        o = tg if acc else list(small)
+        hip.check(L.faf_edge_hidden_bwd(_ptr(A), _ptr(B), _ptr(Cf2), _ptr(nbr), _ptr(gamma), _ptr(dhn), N, K, p, _ptr(seed), eps,
+                                        _ptr(dpre), _ptr(dA), _ptr(o[0]), _ptr(o[1]), 1 if acc else 0, _ptr(ws), ws_bytes,
+                                        _stream(dev)), "faf_edge_hidden_bwd")
+        dB = _segment_reduce(dpre, csr_t.perm, csr_t.rowptr, None, csr_t.n_rows, False)     # rows of d pre by sender
+        dgam, dbet = (None, None) if acc else _hand_out(list(small), tg)
+        return dA, dB, dpre.view(cf_shape), None, None, dgam, dbet, None, None, None, None
+
+
+def edge_hidden(A, B, Cf, nbr, csr_t: CSR, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None):
+    """LayerNorm(dropout_p(SiLU(a) * b)) with [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k]: A, B [N, 256], Cf [N, K, 256], nbr int32
+    [N, K], csr_t the transposed neighbour CSR (rows = senders), gamma / beta [128] (the PARAMETERS) -> [N, K, 128]."""
+    _note_acc(gamma, beta)
+    return _EdgeHidden.apply(A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, (gamma, beta))
+
+
+class _RowDot(torch.autograd.Function):
+    """y = x @ U.T + bias for a FEW output columns (J <= 4), one pass over x each way (faf_rowdot_*).  With
+    ``passthrough`` the node also returns x itself for x's OTHER consumer, and the backward adds that consumer's gradient
+    in the same pass (no autograd add over the [rows, C] tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, U, bias, passthrough):
+        _require_gpu(x, "rowdot")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        Uc = _f32c(U)
+        R, C = x2.shape
+        J = Uc.shape[0]
+        y = torch.empty((R, J), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_rowdot_fwd(_ptr(x2), _ptr(Uc), _ptr(_f32c(bias) if bias is not None else None), R, C, J,
+                                           _ptr(y), _stream(x.device)), "faf_rowdot_fwd")
+        ctx.save_for_backward(x2, Uc)
+        ctx.shape, ctx.has_bias = x.shape, bias is not None
+        ctx.set_materialize_grads(False)
+        y = y.view(*x.shape[:-1], J)
+        return (y, x.view_as(x)) if passthrough else y
+
+    @staticmethod
+    def backward(ctx, dy, dpass=None):
+        x2, Uc = ctx.saved_tensors
+        R, C = x2.shape
+        J = Uc.shape[0]
+        if dy is None:
+            return dpass, None, None, None
+        dy2 = _f32c(dy).reshape(R, J)
+        add = _f32c(dpass).reshape(R, C) if dpass is not None else None
+        dx = torch.empty_like(x2)
+        dU = torch.empty_like(Uc)
+        L = hip.lib()
+        ws_bytes = L.faf_rowdot_bwd_workspace_bytes(R, C, J)
+        ws = _workspace(max(ws_bytes, 16), x2.device)
+        hip.check(L.faf_rowdot_bwd(_ptr(x2), _ptr(Uc), _ptr(dy2), _ptr(add), R, C, J, _ptr(dx), _ptr(dU), 0, _ptr(ws),
+                                   ws_bytes, _stream(x2.device)), "faf_rowdot_bwd")
+        db = dy2.sum(0) if ctx.has_bias else None
+        return dx.view(ctx.shape), dU, db, None
+
+
+def rowdot(x, U, bias=None, passthrough: bool = False):
+    """x [..., C] @ U [J, C].T + bias [J] -> [..., J] for J <= 4 (fp32, C % 4 == 0, C <= 1024); see _RowDot."""
+    return _RowDot.apply(x, U, bias, passthrough)
+
+
+def rowdot_supported(x, J: int) -> bool:
+    return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and 1 <= J <= 4
+
+
+class _GateRows(torch.autograd.Function):
+    """out = res + xd * sigmoid(xd . w + b), xd = dropout_p(x): EdgeModule's gate with the dropout in front of it and the
+    residual behind it, one pass each way (faf_gate_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, res, p, seed, acc_params):
+        _require_gpu(x, "gate_rows")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        wc, bc = _f32c(w).reshape(-1), _f32c(b).reshape(-1)
+        R, C = x2.shape
+        r2 = _f32c(res).reshape(R, C) if res is not None else None
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
+        out = torch.empty_like(x2)
+        hip.check(hip.lib().faf_gate_fwd(_ptr(x2), _ptr(wc), _ptr(bc), _ptr(r2), R, C, float(p), _ptr(seed), _ptr(out),
+                                         _stream(x.device)), "faf_gate_fwd")
+        ctx.save_for_backward(x2, wc, bc)
+        ctx.meta = (x.shape, float(p), seed, res is not None, w.shape, b.shape)
+        ctx.acc = acc_params
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, wc, bc = ctx.saved_tensors
+        shape, p, seed, has_res, w_shape, b_shape = ctx.meta
+        R, C = x2.shape
+        dout2 = _f32c(dout).reshape(R, C)
+        dx = torch.empty_like(x2)
+        L = hip.lib()
+        ws_bytes = L.faf_gate_bwd_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x2.device)
+        tg = [_acc_target(q) for q in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty(C + 4, dtype=torch.float32, device=x2.device)
+        dw_t = tg[0].reshape(-1) if acc else small[:C]
+        db_t = tg[1].reshape(-1) if acc else small[C:C + 1]
+        hip.check(L.faf_gate_bwd(_ptr(x2), _ptr(wc), _ptr(bc), _ptr(dout2), R, C, p, _ptr(seed), _ptr(dx), _ptr(dw_t),
+                                 _ptr(db_t), 1 if acc else 0, _ptr(ws), ws_bytes, _stream(x2.device)), "faf_gate_bwd")
+        if acc:
+            dw = db = None
+        else:
+            dw, db = _hand_out([small[:C].view(w_shape), small[C:C + 1].view(b_shape)], tg)
+        return dx.view(shape), dw, db, (dout if has_res else None), None, None, None
+
+
+def gate_rows(x, w, b, res=None, p: float = 0.0, seed=None):
+    """res + dropout_p(x) * sigmoid(dropout_p(x) . w + b) over the last dim; w [C] (or [1, C]) and b [1] are the PARAMETERS."""
+    _note_acc(w, b)
+    return _GateRows.apply(x, w, b, res, p, seed, (w, b))
+
+
+class _AttnSum(torch.autograd.Function):
+    """out[n, c] = sum_m attn[n, c // D, m] * x[n, m, c] (faf_attn_sum_fwd / _bwd, csrc/faformer_ew.hip)."""
+
+    @staticmethod
+    def forward(ctx, attn, x):
+        _require_gpu(x, "attn_sum")
+        attn, x = _f32c(attn), _f32c(x)
+        N, H, K = attn.shape
+        C = x.shape[-1]
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_attn_sum_fwd(_ptr(attn), _ptr(x), N, K, H, C // H, _ptr(out), _stream(x.device)),
+                  "faf_attn_sum_fwd")
+        ctx.save_for_backward(attn, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        attn, x = ctx.saved_tensors
+        dout = _f32c(dout)
+        N, H, K = attn.shape
+        C = x.shape[-1]
+        dx, dattn = torch.empty_like(x), torch.empty_like(attn)
+        hip.check(hip.lib().faf_attn_sum_bwd(_ptr(attn), _ptr(x), _ptr(dout), N, K, H, C // H, _ptr(dx), _ptr(dattn),
+                                             _stream(x.device)), "faf_attn_sum_bwd")
+        return dattn, dx
+
+
+def attn_sum_supported(attn, x) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and attn.dim() == 3 and x.dim() == 3):
+        return False
+    n, h, k = attn.shape
+    c = x.shape[-1]
+    lpr, hl = c // 4, (c // h) // 4 if h else 0
+    return (x.shape[0] == n and x.shape[1] == k and k <= 16 and c % (4 * h) == 0 and 1 <= lpr <= 64
+            and lpr & (lpr - 1) == 0 and hl >= 1 and hl & (hl - 1) == 0)
+
+
+def attn_sum(attn, x):
+    """sum_m attn[n, h, m] * x[n, m, h*D:(h+1)*D] for attn [N, H, K], x [N, K, H*D] -> [N, H*D]."""
+    return _AttnSum.apply(attn, x)
+
+
+def frame_pre(y, w3, base):
+    """First Linear of FAFormer's frame-averaged MLP: [..., 3] x [H, 3] (+ base [..., H] or [H]) -> [..., 8, H] over
+    the 8 sign frames in the order of fa_former_layer.py:70-84; H = 256."""
+    return _FramePre.apply(y, w3, base)
+
+
+def frame_hidden(y, w3, base, gamma, beta, eps: float = 1e-5, p: float = 0.0, seed=None, extra=None, wx=None):
+    """LayerNorm(dropout_p(SiLU(a) * b)) with [a | b] = w3 (y * s_f) + base over the 8 sign frames of y [..., 3] ->
+    [..., 8, 128]; w3 [256, 3], gamma / beta [128] (the PARAMETERS).  ``base``: rows [..., 256]; or fc1's bias [256], then
+    the row of a point is bias + extra * wx (extra [..., 1], wx [256] = fc1.weight[:, 3]; both optional)."""
+    _note_acc(gamma, beta)
+    return _FrameHidden.apply(y, w3, base, extra, wx, gamma, beta, eps, p, seed, (gamma, beta))
+
+
+def swiglu_dropout(pre, p: float = 0.0, seed=None):
+    """dropout_p(silu(a) * b) for pre = [a | b] along the last dim (fp32, last dim % 8 == 0).  ``seed``: an int64 device
+    tensor [1] to take the dropout decisions from (default: a fresh draw)."""
+    return _SwigluDropout.apply(pre, p, seed)
+
+
+def dropout_mean(x, p: float = 0.0, seed=None):
+    """dropout_p(x).mean(-2) for fp32 x [..., F, C] (C % 4 == 0)."""
+    return _DropoutMean.apply(x, p, seed)
+
+
+def eigh3(cov):
+    """Eigenvectors (columns, ascending eigenvalues) of a batch of symmetric 3x3 matrices [B,3,3];
+    no gradient (the reference detaches the covariance, fa_former_layer.py:98-99)."""
+    _require_gpu(cov, "eigh3")
+    cov = _f32c(cov.detach())
+    vec = torch.empty_like(cov)
+    hip.check(hip.lib().geo_eigh3(_ptr(cov), cov.shape[0], None, _ptr(vec), _stream(cov.device)), "geo_eigh3")
+    return vec

@@ -1,0 +1,269 @@
+"""Dense products: the x6 GEMM (csrc/gemm_x6.hip), the fp32-MFMA dense batch, the dispatch between them and the
+library, weight-level small products.
+
+Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fallback).
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from .. import hip
+from ._base import (_f32c, _ptr, _row_view, _stream, _workspace, timed)
+
+
+# --------------------------------------------------------------------------------------------
+# dense layer (hg_dense_batch_f32, csrc/dense.hip)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class DenseProblem:
+    """One problem of a dense_batch launch: out = alpha * A' @ op(b) (+ bias) (+ c); see include/equihgnn_hip.h.
+    ``a``: [M, K] rows (or, with ``seg``, the SOURCE rows the CSR gathers from); ``b``: weight [N, K] if ``nk`` else
+    [K, N] (any 2-D view with unit inner stride); ``seg`` = (rowptr, idx or None, wptr or None, mean, n_rows);
+    ``ln`` = (bias, gamma, beta, eps); ``a_out``: True to receive the prologue's A'."""
+
+    a: torch.Tensor
+    b: torch.Tensor
+    nk: bool = True
+    bias: Optional[torch.Tensor] = None
+    c: Optional[torch.Tensor] = None
+    alpha: float = 1.0
+    seg: Optional[tuple] = None
+    ln: Optional[tuple] = None
+    a_out: bool = False
+    out: Optional[torch.Tensor] = None
+
+
+def dense_supported(k: int, n: int) -> bool:
+    return k % 4 == 0 and n % 4 == 0 and k > 0 and n > 0
+
+
+def dense_batch(problems):
+    """hg_dense_batch_f32: up to 8 independent dense layers in ONE launch.  Returns [(out, a_out or None)]."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgDenseProblem * n)()
+    keep, res = [], []
+    dev = problems[0].a.device
+    for i, pr in enumerate(problems):
+        a = _row_view(pr.a, "dense: a")
+        b = _row_view(pr.b, "dense: b")
+        K = a.shape[1]
+        N = b.shape[0] if pr.nk else b.shape[1]
+        if (b.shape[1] if pr.nk else b.shape[0]) != K:
+            raise ValueError(f"dense: a is [*, {K}] but b is {tuple(b.shape)} (nk={pr.nk})")
+        M = a.shape[0] if pr.seg is None else int(pr.seg[4])
+        if not dense_supported(K, N):
+            raise ValueError("dense: K and N must be multiples of 4")
+        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+        q = arr[i]
+        q.a, q.lda, q.b, q.ldb, q.b_is_nk = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 1 if pr.nk else 0
+        q.out, q.ldo, q.m, q.n, q.k, q.alpha = out.data_ptr(), out.stride(0), M, N, K, float(pr.alpha)
+        if pr.bias is not None:
+            bias = _f32c(pr.bias)
+            keep.append(bias)
+            q.bias = bias.data_ptr()
+        if pr.c is not None:
+            c = _row_view(pr.c, "dense: c")
+            keep.append(c)
+            q.c, q.ldc = c.data_ptr(), c.stride(0)
+        a_out = None
+        if pr.seg is not None:
+            rowptr, idx, wptr, mean = pr.seg[:4]
+            q.seg_rowptr = rowptr.data_ptr()
+            q.seg_idx = idx.data_ptr() if idx is not None else None
+            q.seg_wptr = wptr.data_ptr() if wptr is not None else None
+            q.seg_mean = 1 if mean else 0
+        if pr.ln is not None:
+            lb, lg, lbeta, eps = pr.ln
+            lb, lg, lbeta = _f32c(lb), _f32c(lg), _f32c(lbeta)
+            keep.extend((lb, lg, lbeta))
+            q.ln_bias, q.ln_gamma, q.ln_beta, q.ln_eps = lb.data_ptr(), lg.data_ptr(), lbeta.data_ptr(), float(eps)
+        if pr.a_out:
+            a_out = torch.empty((M, K), dtype=torch.float32, device=dev)
+            q.a_out, q.ld_aout = a_out.data_ptr(), K
+        keep.extend((a, b))
+        res.append((out, a_out))
+    probs = list(problems)
+    timed("k_dense", lambda: sum(2 * r[0].shape[0] * r[0].shape[1] * (pr.a.shape[1]) for r, pr in zip(res, probs)),
+          lambda: hip.check(hip.lib().hg_dense_batch_f32(n, arr, _stream(dev)), "hg_dense_batch_f32"))
+    return res
+
+
+def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=False, out=None):
+    """One dense layer through hg_dense_batch_f32; returns out, or (out, a_out) when ``a_out``."""
+    (o, ao), = dense_batch([DenseProblem(a, b, nk, bias, c, alpha, seg, ln, a_out, out)])
+    return (o, ao) if a_out else o
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fp32 GEMM on the bf16 matrix cores (csrc/gemm_x6.hip): every dense product of the models goes through here
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class GemmProblem:
+    """c = act(alpha * op(a) @ op(b) + beta * d + bias); see hg_gemm_x6_batch in include/equihgnn_hip.h.
+    ``trans_a``: a is stored [K, M]; ``trans_b``: b is stored [N, K] (an nn.Linear weight).  ``d`` may be ``out``."""
+
+    a: torch.Tensor
+    b: torch.Tensor
+    trans_a: bool = False
+    trans_b: bool = True
+    bias: Optional[torch.Tensor] = None
+    d: Optional[torch.Tensor] = None
+    alpha: float = 1.0
+    beta: float = 1.0
+    relu: bool = False
+    out: Optional[torch.Tensor] = None
+
+
+GEMM_TILE = 0          # 0: chosen per launch; 64 / 128 force a block tile (tools/gemm_bench.py)
+
+
+def gemm_supported(a, b, trans_a=False, trans_b=True) -> bool:
+    """Shapes hg_gemm_x6_batch takes in place: 2-D fp32 device operands whose contiguous extents are multiples of 4."""
+    if not (a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32):
+        return False
+    m, k = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    n = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != k:
+        return False
+    return n % 4 == 0 and k > 0 and (m % 4 == 0 if trans_a else k % 4 == 0) and (k % 4 == 0 or not trans_b)
+
+
+def gemm_batch(problems):
+    """Up to 8 GEMMs with the same operand layout in ONE launch; returns the outputs."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgGemmProblem * n)()
+    keep, outs = [], []
+    dev = problems[0].a.device
+    flops = 0
+    for i, pr in enumerate(problems):
+        a, b = _row_view(pr.a, "gemm: a"), _row_view(pr.b, "gemm: b")
+        M, K = (a.shape[1], a.shape[0]) if pr.trans_a else a.shape
+        N = b.shape[0] if pr.trans_b else b.shape[1]
+        if (b.shape[1] if pr.trans_b else b.shape[0]) != K:
+            raise ValueError(f"gemm: op(a) is [{M}, {K}] but b is {tuple(b.shape)} (trans_b={pr.trans_b})")
+        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
+        assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+        q = arr[i]
+        q.a, q.lda, q.b, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
+        q.c, q.ldc, q.m, q.n, q.k = out.data_ptr(), out.stride(0), M, N, K
+        q.trans_a, q.trans_b, q.relu = int(bool(pr.trans_a)), int(bool(pr.trans_b)), int(bool(pr.relu))
+        q.alpha, q.beta = float(pr.alpha), float(pr.beta)
+        if pr.d is not None:
+            d = pr.d if pr.d is out else _row_view(pr.d, "gemm: d")
+            assert d.shape == (M, N)
+            keep.append(d)
+            q.d, q.ldd = d.data_ptr(), d.stride(0)
+        if pr.bias is not None:
+            bias = _f32c(pr.bias)
+            assert bias.numel() == N
+            keep.append(bias)
+            q.bias = bias.data_ptr()
+        keep.extend((a, b))
+        outs.append(out)
+        flops += 2 * M * N * K
+    L = hip.lib()
+    ws_bytes = L.hg_gemm_x6_workspace_bytes(n, arr, GEMM_TILE)
+    ws = _workspace(ws_bytes, dev) if ws_bytes else None
+    timed("k_gemm_x6", flops, lambda: hip.check(L.hg_gemm_x6_batch(n, arr, GEMM_TILE, _ptr(ws), ws_bytes, _stream(dev)),
+                                               "hg_gemm_x6_batch"))
+    return outs
+
+
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None):
+    """One GEMM through hg_gemm_x6_batch (see GemmProblem)."""
+    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out)])[0]
+
+
+# Where the x6 kernel replaces the library GEMM (measured on MI355X against the TunableOp-selected hipBLASLt kernels,
+# tools/gemm_bench.py -> profiles/r03_gemm_bench.txt): from ~8 M output elements per launch it is 15-25 % faster
+# (145-150 against 117-125 TFLOP/s at the Molecule3D / PCQM / Equiformer sizes); below that -- the [4.7 k x 256] x
+# [256 x 256] products of a QM9 batch, one workgroup per CU and eight K steps -- the tuned library is 10-30 % ahead.
+X6_MIN_OUTPUTS = 6_000_000
+X6_MAX_K = 1024
+X6_DEEP_ROWS = 32768        # weight gradients dY^T X over at least this many rows: the split-K form of the x6 kernel
+X6_WGRAD_ROWS = 8192        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
+USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
+
+
+def _x6_ok(a, b, trans_b, out_elems, k) -> bool:
+    return (USE_X6 and out_elems >= X6_MIN_OUTPUTS and k <= X6_MAX_K and a.is_cuda and a.dtype == torch.float32
+            and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and gemm_supported(a, b, False, trans_b))
+
+
+def mm_nt(x, w, bias=None, d=None, alpha: float = 1.0, beta: float = 1.0, relu: bool = False):
+    """act(alpha * x @ w.T + beta * d + bias) for x [M, K], w [N, K] (an nn.Linear weight or a view of one): the x6
+    kernel where it is the faster one, else the library GEMM."""
+    if _x6_ok(x, w, True, x.shape[0] * w.shape[0], x.shape[1]):
+        return gemm(x, w, trans_b=True, bias=bias, d=d, alpha=alpha, beta=beta, relu=relu)
+    if d is None and alpha == 1.0:
+        if relu and bias is not None:
+            return torch._addmm_activation(bias, x, w.t(), use_gelu=False)
+        y = F.linear(x, w, bias)
+        return torch.relu(y) if relu else y
+    if d is not None:
+        y = torch.addmm(d, x, w.t(), beta=beta, alpha=alpha)
+    else:       # (beta = 0: the input is ignored -- alpha rides the GEMM instead of a scaling kernel)
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=x.dtype, device=x.device)
+        torch.addmm(y, x, w.t(), beta=0.0, alpha=alpha, out=y)
+    if bias is not None:
+        y = y + bias
+    return torch.relu(y) if relu else y
+
+
+def mm_nn(x, w, d=None, alpha: float = 1.0, beta: float = 1.0, out=None):
+    """alpha * x @ w + beta * d for x [M, K], w [K, N] (an input gradient dY W, or a weight stored [in, out]); ``out``
+    (which may be ``d``: accumulate) receives the result."""
+    if _x6_ok(x, w, False, x.shape[0] * w.shape[1], x.shape[1]):
+        return gemm(x, w, trans_b=False, d=d, alpha=alpha, beta=beta, out=out)
+    if d is None:
+        if out is None:
+            out = torch.empty((x.shape[0], w.shape[1]), dtype=x.dtype, device=x.device)
+        if alpha == 1.0:
+            return torch.mm(x, w, out=out)
+        return torch.addmm(out, x, w, beta=0.0, alpha=alpha, out=out)   # (beta = 0: the input is ignored)
+    if out is not None and out is d:
+        return d.addmm_(x, w, beta=beta, alpha=alpha)
+    y = torch.addmm(d, x, w, beta=beta, alpha=alpha)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def small_mm_batch(problems):
+    """hg_small_mm_batch: up to 8 small products in one launch.  Each problem is a dict with
+    a, b (2-D tensors, any strides), ta / tb (use the transpose), c (2-D out, unit inner stride), accumulate, alpha,
+    and optionally u, v (c += u v^T), x, z, y, acc_y (y (+)= op(a) x + z), w (w += u)."""
+    n = len(problems)
+    assert 1 <= n <= 8
+    arr = (hip.HgSmallMM * n)()
+    keep = []
+    for q, pr in zip(arr, problems):
+        a, b, c = pr["a"], pr["b"], pr["c"]
+        if pr.get("ta"):
+            a = a.t()
+        if pr.get("tb"):
+            b = b.t()
+        M, K = a.shape
+        N = b.shape[1]
+        assert b.shape[0] == K and c.shape == (M, N) and c.stride(1) == 1 and a.dtype == b.dtype == c.dtype == torch.float32
+        q.a, q.a_rs, q.a_cs = a.data_ptr(), a.stride(0), a.stride(1)
+        q.b, q.b_rs, q.b_cs = b.data_ptr(), b.stride(0), b.stride(1)
+        q.c, q.ldc, q.m, q.n, q.k = c.data_ptr(), c.stride(0), M, N, K
+        q.alpha, q.accumulate_c, q.accumulate_y = float(pr.get("alpha", 1.0)), int(bool(pr.get("accumulate"))), int(bool(pr.get("acc_y")))
+        for name in ("u", "v", "x", "z", "y", "w"):
+            t = pr.get(name)
+            if t is not None:
+                assert t.dim() == 1 and t.stride(0) == 1 and t.dtype == torch.float32
+                setattr(q, name, t.data_ptr())
+                keep.append(t)
+        keep.extend((a, b, c))
+    dev = problems[0]["c"].device
+    hip.check(hip.lib().hg_small_mm_batch(n, arr, _stream(dev)), "hg_small_mm_batch")

@@ -1,0 +1,319 @@
+"""Equiformer operators: row GEMMs of the radial tensor product, radial trunk, attention pooling, RMS norm, edge
+geometry (equiformer_layer.py).
+
+Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import hip
+from ._base import (
+    ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _ptr, _require_gpu, _stream, _workspace, timed)
+
+
+class _RowGemm(torch.autograd.Function):
+    """out[e] = z[e] @ w[row(e)] — hg_rowgemm_fwd/bwd (the radial tensor product of
+    equiformer_layer.py:376-383 re-associated; see csrc/rowgemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, z, w, rowptr, perm):
+        _require_gpu(z, "rowgemm")
+        z, w = _f32c(z), _f32c(w)
+        E, Kd = z.shape
+        R, Kd2, L = w.shape
+        if Kd2 != Kd or rowptr.numel() != R + 1:
+            raise ValueError("rowgemm: z[E,Kd], w[R,Kd,L], rowptr[R+1] expected")
+        out = torch.zeros((E, L), dtype=torch.float32, device=z.device)  # entries outside every row stay 0
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(hip.lib().hg_rowgemm_fwd(_ptr(z), _ptr(w), _ptr(rowptr), _ptr(perm), R, Kd, L, _ptr(out), 0,
+                                                         _stream(z.device)), "hg_rowgemm_fwd"))
+        ctx.save_for_backward(z, w)
+        ctx.rowptr, ctx.perm = rowptr, perm
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, w = ctx.saved_tensors
+        dout = _f32c(dout)
+        R, Kd, L = w.shape
+        dz = torch.zeros_like(z) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w) if ctx.needs_input_grad[1] else None
+        hip.check(hip.lib().hg_rowgemm_bwd(_ptr(z), _ptr(w), _ptr(dout), _ptr(ctx.rowptr), _ptr(ctx.perm), R, Kd,
+                                           L, _ptr(dz), 0, _ptr(dw), _stream(z.device)), "hg_rowgemm_bwd")
+        return dz, dw, None, None
+
+
+class _RowGemm2(torch.autograd.Function):
+    """out[e] = z[e] @ wa[row_a(e)] + z[e] @ wb[row_b(e)] for two groupings of the same entries that each cover
+    EVERY entry (sender rows and receiver rows of the neighbour graph): the second pass accumulates into the
+    first one's output, and so do the two halves of dz, so neither a zero fill nor an add kernel runs."""
+
+    @staticmethod
+    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+        _require_gpu(z, "rowgemm2")
+        z, wa, wb = _f32c(z), _f32c(wa), _f32c(wb)
+        E, Kd = z.shape
+        Ra, _, L = wa.shape
+        Rb = wb.shape[0]
+        if wa.shape[1:] != wb.shape[1:] or wa.shape[1] != Kd or rowptr_a.numel() != Ra + 1 or rowptr_b.numel() != Rb + 1:
+            raise ValueError("rowgemm2: z[E,Kd], wa[Ra,Kd,L], wb[Rb,Kd,L], rowptr_a[Ra+1], rowptr_b[Rb+1] expected")
+        out = torch.empty((E, L), dtype=torch.float32, device=z.device)
+        L_ = hip.lib()
+        st = _stream(z.device)
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0, st),
+                                "hg_rowgemm_fwd"))
+        timed("k_rowgemm_fwd", 2 * E * Kd * L,
+              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1, st),
+                                "hg_rowgemm_fwd"))
+        ctx.save_for_backward(z, wa, wb)
+        ctx.idx = (rowptr_a, perm_a, rowptr_b, perm_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, wa, wb = ctx.saved_tensors
+        rowptr_a, perm_a, rowptr_b, perm_b = ctx.idx
+        dout = _f32c(dout)
+        Ra, Kd, L = wa.shape
+        Rb = wb.shape[0]
+        need_z = ctx.needs_input_grad[0]
+        dz = torch.empty_like(z) if need_z else None
+        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] else None
+        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] else None
+        L_ = hip.lib()
+        st = _stream(z.device)
+        E = z.shape[0]
+        nf = (2 if need_z else 0) * E * Kd * L
+        timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwa is not None else 0),
+              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz), 0,
+                                                  _ptr(dwa), st), "hg_rowgemm_bwd"))
+        timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwb is not None else 0),
+              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
+                                                  _ptr(dwb), st), "hg_rowgemm_bwd"))
+        return dz, dwa, None, None, dwb, None, None
+
+
+class _RadialWeightLayout(torch.autograd.Function):
+    """nn.Linear(mid, lo * li).weight [(lo, li), mid] -> [li, mid * lo_p] with columns ordered (k, lo) and lo zero-padded to lo_p:
+    w.view(lo, li, mid).permute(1, 2, 0) (+ pad) as one tiled transposition each way (eqh_permute_tiles_f32)."""
+
+    @staticmethod
+    def forward(ctx, w, lo, li, mid, lo_p):
+        _require_gpu(w, "radial_weight_layout")
+        w = _f32c(w)
+        out = torch.empty((li, mid * lo_p), dtype=torch.float32, device=w.device)
+        # b = li, x = k (contiguous in the source), y = lo (contiguous in the destination)
+        hip.check(hip.lib().eqh_permute_tiles_f32(_ptr(w), _ptr(out), mid, lo, lo_p, li, li * mid, mid, lo_p, mid * lo_p,
+                                                  _stream(w.device)), "eqh_permute_tiles_f32")
+        ctx.dims = (lo, li, mid, lo_p, tuple(w.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lo, li, mid, lo_p, shape = ctx.dims
+        dout = _f32c(dout)
+        dw = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        # b = li, x = lo (contiguous in the source), y = k (contiguous in the destination)
+        hip.check(hip.lib().eqh_permute_tiles_f32(_ptr(dout), _ptr(dw), lo, mid, mid, li, lo_p, mid * lo_p, li * mid, mid,
+                                                  _stream(dout.device)), "eqh_permute_tiles_f32")
+        return dw, None, None, None, None
+
+
+def radial_weight_layout(w, lo: int, li: int, mid: int, lo_p: int):
+    """See _RadialWeightLayout; ``w`` is the [lo * li, mid] weight PARAMETER of the radial network's last Linear."""
+    return _RadialWeightLayout.apply(w, lo, li, mid, lo_p)
+
+
+class _AttnPool(torch.autograd.Function):
+    """Softmax over (self + 16 neighbour) slots of LeakyReLU-Linear logits, SiLU values, value Linear and the
+    weighted sum, per node, one launch each way (eqf_attn_pool_fwd / _bwd, csrc/attn_pool.hip)."""
+
+    @staticmethod
+    def forward(ctx, me, edge, maskf, w_logit, wv, v_off, scale, slope, acc_params):
+        _require_gpu(me, "attn_pool")
+        me, edge, maskf = _f32c(me), _f32c(edge), _f32c(maskf)
+        wl, wvv = _f32c(w_logit.detach()).reshape(-1), _f32c(wv.detach())
+        N, D = me.shape
+        K, V = maskf.shape[1], wvv.shape[0]
+        out = torch.empty((N, V), dtype=torch.float32, device=me.device)
+        attn = torch.empty((N, K + 1), dtype=torch.float32, device=me.device)
+        hip.check(hip.lib().eqf_attn_pool_fwd(_ptr(me), _ptr(edge), _ptr(maskf), _ptr(wl), _ptr(wvv), N, K, D, v_off, V,
+                                              float(scale), float(slope), _ptr(out), _ptr(attn), _stream(me.device)),
+                  "eqf_attn_pool_fwd")
+        ctx.save_for_backward(me, edge, maskf, wl, wvv, attn)
+        ctx.meta = (v_off, float(scale), float(slope), w_logit.shape)
+        ctx.acc = acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        me, edge, maskf, wl, wvv, attn = ctx.saved_tensors
+        v_off, scale, slope, wl_shape = ctx.meta
+        dout = _f32c(dout)
+        N, D = me.shape
+        K, V = maskf.shape[1], wvv.shape[0]
+        dev = me.device
+        dme, dedge = torch.empty_like(me), torch.empty_like(edge)
+        L = hip.lib()
+        ws_bytes = L.eqf_attn_pool_bwd_workspace_bytes(N)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(p) for p in ctx.acc]            # (w_logit, wv)
+        in_place = all(t is not None for t in tg)
+        dwl, dwv = tg if in_place else (torch.empty(wl_shape, dtype=torch.float32, device=dev), torch.empty_like(wvv))
+        hip.check(L.eqf_attn_pool_bwd(_ptr(me), _ptr(edge), _ptr(maskf), _ptr(wl), _ptr(wvv), _ptr(attn), _ptr(dout), N, K,
+                                      D, v_off, V, scale, slope, _ptr(dme), _ptr(dedge), _ptr(dwl), _ptr(dwv),
+                                      1 if in_place else 0, _ptr(ws), ws_bytes, _stream(dev)), "eqf_attn_pool_bwd")
+        if in_place:
+            return dme, dedge, None, None, None, None, None, None, None
+        dwl, dwv = _hand_out([dwl, dwv], tg)
+        return dme, dedge, None, dwl, dwv, None, None, None, None
+
+
+def attn_pool_supported(me, edge, maskf, w_logit, wv, v_off) -> bool:
+    return (me.is_cuda and me.dim() == 2 and edge.dim() == 2 and me.dtype == torch.float32 and maskf.dim() == 2
+            and maskf.shape[1] == 16 and edge.shape[0] == me.shape[0] * 16 and edge.shape[1] == me.shape[1]
+            and tuple(wv.shape) == (48, 48) and w_logit.numel() == 4 and me.shape[1] % 4 == 0 and v_off % 4 == 0
+            and v_off >= 4 and v_off + 48 <= me.shape[1])
+
+
+def attn_pool(me, edge, maskf, w_logit, wv, v_off: int, scale: float, slope: float):
+    """out[n] = sum_s softmax_s(scale * w_logit . leaky_relu(x_s[:4])) * (silu(x_s[v_off:v_off+48]) @ wv) over the
+    slots x_0 = me[n], x_1.. = edge[n*16 + s - 1] (valid where maskf[n, s-1] != 0; slot 0 always)."""
+    if torch.is_grad_enabled():
+        for w_ in (w_logit, wv):
+            if w_.requires_grad and w_.is_leaf:
+                LINEAR_PARAMS[id(w_)] = w_
+    return _AttnPool.apply(me, edge, maskf, w_logit, wv, v_off, scale, slope, (w_logit, wv))
+
+
+class _RmsNormRows(torch.autograd.Function):
+    """t / max(||t|| * C^-1/2, eps) * g over dense rows (eqf_rms_norm_fwd / _bwd, csrc/rmsnorm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, g, eps, acc_param):
+        _require_gpu(x, "rms_norm_rows")
+        x, gv = _f32c(x), _f32c(g.detach()).reshape(-1)
+        R, C = x.shape
+        out = torch.empty_like(x)
+        scale = float(torch.tensor(C ** -0.5, dtype=torch.float32))
+        hip.check(hip.lib().eqf_rms_norm_fwd(_ptr(x), _ptr(gv), R, C, scale, float(eps), _ptr(out), _stream(x.device)),
+                  "eqf_rms_norm_fwd")
+        ctx.save_for_backward(x, gv)
+        ctx.eps, ctx.scale, ctx.acc, ctx.gshape = float(eps), scale, acc_param, g.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gv = ctx.saved_tensors
+        dy = _f32c(dy)
+        R, C = x.shape
+        dx = torch.empty_like(x)
+        L = hip.lib()
+        ws_bytes = L.eqf_rms_norm_bwd_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x.device)
+        tg = _acc_target(ctx.acc)
+        dg = tg if tg is not None else torch.empty(ctx.gshape, dtype=torch.float32, device=x.device)
+        hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dg),
+                                     1 if tg is not None else 0, _ptr(ws), ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
+        return dx, (None if tg is not None else dg), None, None
+
+
+def rms_norm_rows(x, g, eps: float):
+    """The degree-0 Norm of the Equiformer (equiformer_layer.py:194-225) for 2-D fp32 rows; ``g`` is the
+    ``transforms.0`` parameter [C, 1]."""
+    if torch.is_grad_enabled() and g.requires_grad and g.is_leaf:
+        (LINEAR_PARAMS if g.dim() == 2 else ACC_PARAMS)[id(g)] = g
+    return _RmsNormRows.apply(x, g, eps, g)
+
+
+class _RadialTrunk(torch.autograd.Function):
+    """Linear(1,64) -> SiLU -> LN -> Linear(64,64) -> SiLU -> LN per edge, one launch each way
+    (eqf_radial_trunk_fwd / _bwd, csrc/radial.hip); the backward recomputes the forward from ``dist``."""
+
+    @staticmethod
+    def forward(ctx, dist, eps, acc_params, w0, b0, g1, be1, w1, b1, g2, be2):
+        _require_gpu(dist, "radial_trunk")
+        dist = _f32c(dist).reshape(-1)
+        ps = [_f32c(t.detach()) for t in (w0, b0, g1, be1, w1, b1, g2, be2)]
+        E, M = dist.shape[0], ps[4].shape[0]
+        out = torch.empty((E, M), dtype=torch.float32, device=dist.device)
+        vp = ctypes.c_void_p * 8
+        hip.check(hip.lib().eqf_radial_trunk_fwd(_ptr(dist), vp(*[t.data_ptr() for t in ps]), E, M, float(eps), _ptr(out),
+                                                 _stream(dist.device)), "eqf_radial_trunk_fwd")
+        ctx.dist, ctx.ps, ctx.eps, ctx.acc = dist, ps, float(eps), acc_params
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        dist, ps = ctx.dist, ctx.ps
+        dh = _f32c(dh)
+        E, M = dist.shape[0], ps[4].shape[0]
+        dev = dist.device
+        L = hip.lib()
+        ws_bytes = L.eqf_radial_trunk_bwd_workspace_bytes(E)
+        ws = _workspace(max(ws_bytes, 16), dev)
+        tg = [_acc_target(p) for p in ctx.acc]          # order: w0, b0, g1, w1, b1, g2
+        in_place = all(t is not None for t in tg)
+        grads = tg if in_place else [torch.empty_like(ps[i]) for i in (0, 1, 2, 4, 5, 6)]
+        vp8, vp6 = ctypes.c_void_p * 8, ctypes.c_void_p * 6
+        hip.check(L.eqf_radial_trunk_bwd(_ptr(dist), vp8(*[t.data_ptr() for t in ps]), _ptr(dh), E, M, ctx.eps,
+                                         vp6(*[g.data_ptr() for g in grads]), 1 if in_place else 0, _ptr(ws), ws_bytes,
+                                         _stream(dev)), "eqf_radial_trunk_bwd")
+        if in_place:
+            return (None,) * 11
+        dw0, db0, dg1, dw1, db1, dg2 = _hand_out(grads, tg)
+        return None, None, None, dw0, db0, dg1, None, dw1, db1, dg2, None
+
+
+def radial_trunk_supported(dist, lin0, ln1, lin1, ln2) -> bool:
+    return (dist.is_cuda and not dist.requires_grad and dist.dtype == torch.float32 and lin0.in_features == 1
+            and lin0.out_features == 64 and lin1.in_features == 64 and lin1.out_features == 64
+            and lin0.bias is not None and lin1.bias is not None)
+
+
+def radial_trunk(dist, lin0, ln1, lin1, ln2, eps: float = 1e-5):
+    """[E] or [E,1] distances -> [E,64]: ``lin0`` Linear(1,64), ``ln1``/``ln2`` modules with ``gamma`` (parameter)
+    and ``beta`` (buffer), ``lin1`` Linear(64,64); SiLU between Linear and LayerNorm (equiformer_layer.py:451-479)."""
+    params = (lin0.weight, lin0.bias, ln1.gamma, lin1.weight, lin1.bias, ln2.gamma)
+    if torch.is_grad_enabled():
+        for w in params:
+            if w.requires_grad and w.is_leaf:
+                (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
+    return _RadialTrunk.apply(dist, eps, params, lin0.weight, lin0.bias, ln1.gamma, ln1.beta, lin1.weight, lin1.bias,
+                              ln2.gamma, ln2.beta)
+
+
+def rowgemm(z, w, rowptr, perm=None):
+    """out[e, :] = z[e, :] @ w[row(e)]; rows given by rowptr (+ perm: entry ids per row)."""
+    return _RowGemm.apply(z, w, rowptr, perm)
+
+
+def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+    """rowgemm(z, wa, rowptr_a, perm_a) + rowgemm(z, wb, rowptr_b, perm_b) when BOTH groupings cover every entry
+    of z (no entry outside all rows): one output buffer, the second pass accumulates."""
+    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
+
+
+def edge_geometry(pos, nbr, dist, radius: float, full_d: bool = False):
+    """eqf_edge_geometry: (rhat [E,3] = D[:, m=0], maskf [N,K], mean_w [N,K], mean_w_rhat [N,K,3]) for the
+    self-excluded neighbour lists of geo_knn(mode 1), plus the whole D[1] [E,3,3] with ``full_d``; see
+    csrc/edge_geom.hip.  No gradient."""
+    _require_gpu(pos, "edge_geometry")
+    pos, dist = _f32c(pos.detach()), _f32c(dist)
+    N, K = nbr.shape
+    if nbr.dtype != torch.int32 or dist.shape != (N, K) or pos.shape != (N, 3) or K > 16:
+        raise ValueError("edge_geometry: pos[N,3] fp32, nbr[N,K] int32, dist[N,K] fp32, K <= 16 expected")
+    dev = pos.device
+    rhat = torch.empty((N * K, 3), dtype=torch.float32, device=dev)
+    maskf = torch.empty((N, K), dtype=torch.float32, device=dev)
+    mean_w = torch.empty((N, K), dtype=torch.float32, device=dev)
+    mean_w_rhat = torch.empty((N, K, 3), dtype=torch.float32, device=dev)
+    dmat = torch.empty((N * K, 3, 3), dtype=torch.float32, device=dev) if full_d else None
+    hip.check(hip.lib().eqf_edge_geometry(_ptr(pos), _ptr(nbr.contiguous()), _ptr(dist), N, K, float(radius), _ptr(rhat),
+                                          _ptr(maskf), _ptr(mean_w), _ptr(mean_w_rhat), _ptr(dmat), _stream(dev)),
+              "eqf_edge_geometry")
+    return (rhat, maskf, mean_w, mean_w_rhat, dmat) if full_d else (rhat, maskf, mean_w, mean_w_rhat)

@@ -4,7 +4,7 @@
  * The reference (HySonLab/EquiHGNN) is pure Python; the only native code its hot path reaches
  * is third-party (torch_scatter, ATen, PyG).  Each entry point below replaces one such operator
  * call site (cited as reference file:line, relative to the reference checkout).  The Python host
- * side (equihgnn_amd/ops.py) binds these with ctypes; INTEGRATION.md shows the stub a
+ * side (equihgnn_amd/hip.py, used by equihgnn_amd/ops/) binds these with ctypes; INTEGRATION.md shows the stub a
  * maintainer of the reference would add.
  *
  * Conventions (every function):

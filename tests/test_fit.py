@@ -254,6 +254,26 @@ def test_bucketed_loader_runs_one_epoch_ahead_and_no_further():
     assert threading.active_count() == before
 
 
+def test_bucketed_loader_lookahead_does_not_refill_buffers_that_are_still_queued():
+    """The epoch started ahead shares the queue of the one being consumed: with a queue of its own it would have
+    refilled ring buffers (prefetch + 3 per shape) whose batches still waited, unconsumed, in the old queue -- the tail
+    of every epoch silently replaced by molecules of the next one."""
+    import time
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    mols = _mols(16 * 9, 3)                                   # 9 equal-shape batches per epoch > 6 ring buffers
+    for i, m in enumerate(mols):
+        m.y = float(i)
+    ld = BucketedLoader(MolStore(mols), 16, True, seed=3, device=None, prefetch=3)
+    for _ in range(3):
+        seen = []
+        for b in ld:
+            time.sleep(0.02)                                  # a slow consumer: the producer runs as far ahead as it may
+            seen.extend(int(v) for v in b.y[:b.num_real_graphs].tolist())
+        assert sorted(seen) == list(range(len(mols)))
+    ld.close()
+
+
 @pytest.mark.gpu
 def test_evaluation_on_reused_loader_buffers_matches_fresh_batches():
     """Fitter._evaluate / test on a BucketedLoader with MORE equal-shape batches than the ring holds,
