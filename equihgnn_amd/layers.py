@@ -7,7 +7,7 @@ The arithmetic is re-derived for the device rather than transcribed:
   MFMA instead of 2·nnz rows); the per-incidence work becomes a row gather-add.
 * The last Linear of a per-incidence MLP commutes with the (linear) mean aggregation, so it runs
   on the aggregated rows: ``mean_r(W·h_p + b) = W·mean_r(h_p) + b·[deg(r) > 0]``.
-* All gathers / scatters go through the CSR kernels of libequihgnn_hip.so (ops/scatter.py).
+* All gathers / scatters go through the CSR kernels of libequihgnn_hip.so (ops/aggregate.py).
 
 Dense Linears are plain library GEMMs (fp32 MFMA through hipBLASLt via torch); they are the
 "dense per-type linear mixes" of the north star, not the hand-written part.

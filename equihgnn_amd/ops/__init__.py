@@ -8,10 +8,10 @@ has a CPU fallback: tensors must live on a HIP device.
 One module per subsystem; everything is re-exported here, so callers keep writing ``ops.linear``:
 
   _base    pointers / streams for the C ABI, in-graph Timeline, accumulator registry, deferred-scratch bookkeeping
-  scatter  CSR builds, gather / segmented reduce (torch_scatter.scatter of conv.py), embedding sums, kNN
-  gemm     x6 GEMM, fp32-MFMA dense batch, dispatch against the library, weight-level small products
+  aggregate CSR builds, gather / segmented reduce (torch_scatter.scatter of conv.py), embedding sums, kNN
+  products x6 GEMM, fp32-MFMA dense batch, dispatch against the library, weight-level small products
   grads    persistent gradient accumulators, deferred weight / bias gradients and slab reductions, gradient fan-in
-  linear   nn.Linear-shaped autograd nodes, merged consecutive Linears, matmul fans
+  linears  nn.Linear-shaped autograd nodes, merged consecutive Linears, matmul fans
   rows     per-incidence hidden layer + reduce, bias/ReLU/LayerNorm rows, BatchNorm / LayerNorm rows, residual mix
   egnn     EGNN edge kernels, feature node, weight packing
   readout  pooled readout head + MSE in one launch
@@ -21,20 +21,20 @@ One module per subsystem; everything is re-exported here, so cal
 Module-level switches (``ops.GEMM_TILE``, ``ops.TIMELINE``, ``ops.KNN_GRID_MIN_POINTS``, ...) are read by the
 submodule that owns them; assigning them on this package forwards the value there (_OpsModule below).
 """
+import importlib as _importlib
 import sys as _sys
 import types as _types
 
-from . import _base, scatter, gemm, grads, linear, rows, egnn, readout, se3, frames  # noqa: F401
 from ._base import (  # noqa: F401
     _c_void_p, _ptr, _stream, _require_gpu, _f32c, Timeline, TIMELINE, timed, _row_view, _as2d, _contiguous_run,
     _stacked_view, _rows_ld, _DEFER, _workspace, _acc_target, _hand_out, _note_acc, LINEAR_PARAMS, ACC_PARAMS,
 )
-from .scatter import (  # noqa: F401
+from .aggregate import (  # noqa: F401
     CSR, csr_build, csr_build_batch, index_aux, segment_reduce_bytes, _segment_reduce, entry_weights,
     _segment_reduce_w, _ReduceGathered, _ReduceEntries, _GatherRows, _EmbedSum, reduce_gathered, reduce_entries,
     gather_rows, embed_sum, KNN_GRID_MIN_POINTS, knn, scatter,
 )
-from .gemm import (  # noqa: F401
+from .products import (  # noqa: F401
     DenseProblem, dense_supported, dense_batch, dense, GemmProblem, GEMM_TILE, gemm_supported, gemm_batch, gemm,
     X6_MIN_OUTPUTS, X6_MAX_K, X6_DEEP_ROWS, X6_WGRAD_ROWS, USE_X6, _x6_ok, mm_nt, mm_nn, small_mm_batch,
 )
@@ -43,7 +43,7 @@ from .grads import (  # noqa: F401
     defer_begin, wgrad_batch, colsum_batch, defer_flush, copy_many, colsum, USE_WGRAD_KERNEL, DEFER_WGRAD,
     _wgrad_shape_ok, _wgrad_ok, _wgrad_deferred, wgrad, _linear_weight_grad, MERGED_SCRATCH, _merged_acc,
 )
-from .linear import (  # noqa: F401
+from .linears import (  # noqa: F401
     _MergedWeight, _MergedWeights, merged_weights, merged_weight, _Linear, _Linear2, _LinearAddC, linear, linear2,
     linear_add, _MatmulFan, matmul_fan, matmul,
 )
@@ -71,21 +71,23 @@ from .frames import (  # noqa: F401
 
 # switches that tests / tools / bench.py set as ``ops.NAME = value``: owner module of each
 _SWITCH_OWNER = {
-    "DEFER_WGRAD": grads,
-    "GEMM_TILE": gemm,
-    "KNN_GRID_MIN_POINTS": scatter,
-    "TIMELINE": _base,
-    "USE_WGRAD_KERNEL": grads,
-    "USE_X6": gemm,
-    "WGRAD_ON_SIDE_STREAM": grads,
-    "X6_DEEP_ROWS": gemm,
-    "X6_MAX_K": gemm,
-    "X6_MIN_OUTPUTS": gemm,
-    "X6_WGRAD_ROWS": gemm,
+    "DEFER_WGRAD": "grads",
+    "GEMM_TILE": "products",
+    "KNN_GRID_MIN_POINTS": "aggregate",
+    "TIMELINE": "_base",
+    "USE_WGRAD_KERNEL": "grads",
+    "USE_X6": "products",
+    "WGRAD_ON_SIDE_STREAM": "grads",
+    "X6_DEEP_ROWS": "products",
+    "X6_MAX_K": "products",
+    "X6_MIN_OUTPUTS": "products",
+    "X6_WGRAD_ROWS": "products",
 }
 
 
-_SUBMODULES = (_base, scatter, gemm, grads, linear, rows, egnn, readout, se3, frames)
+# (module objects by name: the package attributes ``linear`` etc. are the re-exported FUNCTIONS)
+_SUBMODULES = tuple(_importlib.import_module(f"{__name__}.{_n}") for _n in (
+    "_base", "aggregate", "products", "grads", "linears", "rows", "egnn", "readout", "se3", "frames"))
 
 
 class _OpsModule(_types.ModuleType):

@@ -11,8 +11,8 @@ from .. import hip
 from ._base import (
     ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream,
     _workspace, timed)
-from .scatter import (CSR)
-from .gemm import (mm_nn, mm_nt)
+from .aggregate import (CSR)
+from .products import (mm_nn, mm_nt)
 from .grads import (colsum)
 
 

@@ -10,7 +10,7 @@ import torch
 
 from .. import hip
 from ._base import (_acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
-from .scatter import (CSR, _segment_reduce)
+from .aggregate import (CSR, _segment_reduce)
 
 
 def _dropout_seed(device, p):

@@ -11,7 +11,7 @@ import torch
 
 from .. import hip
 from ._base import (_DEFER, _f32c, _ptr, _stream, _workspace)
-from .gemm import (GemmProblem, USE_X6, X6_DEEP_ROWS, X6_WGRAD_ROWS, gemm, gemm_batch, gemm_supported)
+from .products import (GemmProblem, USE_X6, X6_DEEP_ROWS, X6_WGRAD_ROWS, gemm, gemm_batch, gemm_supported)
 
 
 class GradFan:

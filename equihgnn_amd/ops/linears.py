@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from ._base import (LINEAR_PARAMS, _DEFER, _acc_target, _note_acc)
-from .gemm import (mm_nn, mm_nt, small_mm_batch)
+from .products import (mm_nn, mm_nt, small_mm_batch)
 from .grads import (_linear_weight_grad, _merged_acc, _wgrad_deferred, _wgrad_ok, colsum, wgrad)
 
 

@@ -11,8 +11,8 @@ import torch
 from .. import hip
 from ._base import (
     LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
-from .scatter import (CSR, entry_weights, segment_reduce_bytes)
-from .gemm import (mm_nn, mm_nt)
+from .aggregate import (CSR, entry_weights, segment_reduce_bytes)
+from .products import (mm_nn, mm_nt)
 from .grads import (_wgrad_deferred, _wgrad_ok, colsum, wgrad)
 
 
