@@ -154,7 +154,9 @@ def _fan(x, *ws):
 
 def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
     """out[e, lo] = sum_li R_e[lo, li] (xj[j_e, li] + xi[i_e, li]) without forming R_e.
-    xj / xi: [N, li] (degree 0) or [N, li, 3] (degree 1, with ``zscale`` = r_hat [E, 3])."""
+    xj / xi: [N, li] (degree 0) or [N, li, 3] (degree 1, with ``zscale`` [E, 3]: the input vectors are contracted with it
+    per edge -- r_hat for the (1 -> 0) pair).  ``zscale`` may be a LIST of [E, 3] tensors: the node-level products are
+    formed once and one output per entry is returned (the three components of a (1 -> 1) pair)."""
     w, b3, lo_p = radial.node_weights()
     n, lo, mid = geo.N, radial.nc_out, radial.mid
     if zscale is None:
@@ -162,20 +164,21 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
         p, pb = _fan(xj, w, b3t)                                                    # [N, mid*lo_p], [N, lo]
         q, qb = _fan(xi, w, b3t)
         p, q = p.view(n, mid, lo_p), q.view(n, mid, lo_p)
-        ze = z
         bias = ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, lo) + qb[:, None, :]
-        bias = bias.reshape(-1, lo)
-    else:
-        p = (xj.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)                         # [(m,k), lo]
-        q = (xi.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)
-        ze = (zscale[:, :, None] * z[:, None, :]).reshape(-1, 3 * mid)              # [E, (m,k)]
-        pb = (xj.transpose(1, 2) @ b3.t()).reshape(n, 3 * lo)                       # [N, (m,lo)]
-        qb = xi.transpose(1, 2) @ b3.t()                                            # [N, 3, lo]
-        g = ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]
-        bias = (g.reshape(-1, 3, lo) * zscale[:, :, None]).sum(1)
-    # sender rows (transposed neighbour CSR) and receiver rows both list every edge: one buffer, second pass adds
-    out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
-    return out[:, :lo] + bias
+        # sender rows (transposed neighbour CSR) and receiver rows both list every edge: one buffer, second pass adds
+        out = ops.rowgemm2(z, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
+        return out[:, :lo] + bias.reshape(-1, lo)
+    p = (xj.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)                             # [(m,k), lo]
+    q = (xi.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)
+    pb = (xj.transpose(1, 2) @ b3.t()).reshape(n, 3 * lo)                           # [N, (m,lo)]
+    qb = xi.transpose(1, 2) @ b3.t()                                                # [N, 3, lo]
+    g = (ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]).reshape(-1, 3, lo)
+    outs = []
+    for zs in (zscale if isinstance(zscale, (list, tuple)) else (zscale,)):
+        ze = (zs[:, :, None] * z[:, None, :]).reshape(-1, 3 * mid)                  # [E, (m,k)]
+        out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
+        outs.append(out[:, :lo] + (g * zs[:, :, None]).sum(1))
+    return outs if isinstance(zscale, (list, tuple)) else outs[0]
 
 
 class DTPIn(nn.Module):
@@ -287,10 +290,10 @@ class FeedForward(nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 # Degree-1 outputs.  The reference's wrapper builds the layer with depth 1 and reads type 0 only, so
 # everything below is dead there; with depth > 1 block t+1's (1 -> 0) pair consumes block t's degree-1 output and it
-# all becomes live.  No registry name reaches this configuration, so it is written for correctness with torch
-# operations on the device tensors (per-edge radial weights materialised, as the reference does) on top of the same
-# HIP neighbour search / edge geometry / row gathers; tests/test_equiformer_layer.py pins it to the reference's layer
-# at depth 1-3.
+# all becomes live.  No registry name reaches this configuration.  The radial tensor products of the degree-1 outputs
+# run on the same row-GEMM kernels as the degree-0 ones (round 3: no per-edge radial weights are formed); the small
+# per-edge rotations, gates and the degree-1 attention are torch operations on the device tensors.
+# tests/test_equiformer_layer.py pins it to the reference's layer at depth 1-3.
 # ---------------------------------------------------------------------------------------------------------------
 def _mix1(lin: FiberLinear, t):
     """Degree-1 channel mix [..., d, 3] -> [..., e, 3] (equiformer_layer.py:186-189)."""
@@ -303,17 +306,23 @@ def attention_degree1(att: "MLPAttention", f0, f1, me, edge, geo: EdgeGeometry, 
     n, k, dh = geo.N, geo.K, att.dh
     dtp = att.to_attn_and_v
     D = geo.D
-    d = geo.dist.view(n, k, 1)
-    gat = lambda t: ops.gather_rows(t.reshape(n, -1), geo.nbr_flat, geo.csr_t).view(n, k, *t.shape[1:])
-    x0 = gat(f0 @ dtp.to_xj.w(0)) + (f0 @ dtp.to_xi.w(0))[:, None]                              # [N,K,C]
-    x1 = gat(_mix1(dtp.to_xj, f1)) + _mix1(dtp.to_xi, f1)[:, None]                               # [N,K,C,3]
-    x1r = torch.einsum("nkab,nkla->nklb", D, x1)                                                 # rotate in, :364-366
+    # The (0 -> 1) and (1 -> 1) pairs through the SAME re-association as the degree-0 ones: the per-edge
+    # radial weights R_e[lo, li] (262 KB per edge at C = 256) are never formed.  (0 -> 1) is a plain radial contraction of
+    # the degree-0 inputs.  For (1 -> 1), :364-366 rotates the input into the edge frame (x1r = D^T x1), :389-404 combines
+    # its components with the 3 x 3 basis (component m of the result reads x1r[m] and x1r[2 - m]), so output component m
+    # is the radial contraction of the UNROTATED node vectors with the per-edge 3-vector
+    #     T_e[m, a] = (basis[m, 0] + basis[m, 2]) D_e[a, m] + basis[m, 1] D_e[a, 2 - m]
+    # folded into the edge row, exactly as r_hat is for the (1 -> 0) pair: three row-GEMM passes over one pair of
+    # node-level products.
     r01, r11 = dtp.kernel_unary["(0,1)"], dtp.kernel_unary["(1,1)"]
-    R01 = r01.rp(d).view(n, k, r01.nc_out, r01.nc_in)
-    R11 = r11.rp(d).view(n, k, r11.nc_out, r11.nc_in)
-    o01 = F.pad(torch.einsum("nkol,nkl->nko", R01, x0)[..., None], (1, 1))                       # result at m = 1, :407-409
-    xf = torch.stack((x1r, x1r.flip(-1), x1r), -1)                                               # [..., m, f], :389-399
-    o11 = torch.einsum("nkoi,mf,nkimf->nkom", R11, basis11, xf)                                  # :402-404
+    dflat = geo.dist
+    o01 = radial_contract(r01, r01.trunk(dflat), f0 @ dtp.to_xj.w(0), f0 @ dtp.to_xi.w(0), geo)  # [E, lo01]
+    o01 = F.pad(o01.view(n, k, -1)[..., None], (1, 1))                                           # result at m = 1, :407-409
+    Df = D.reshape(n * k, 3, 3)
+    c0, c1 = basis11[:, 0] + basis11[:, 2], basis11[:, 1]
+    T = [c0[m] * Df[:, :, m] + c1[m] * Df[:, :, 2 - m] for m in range(3)]                        # 3 x [E, 3]
+    o11 = radial_contract(r11, r11.trunk(dflat), _mix1(dtp.to_xj, f1), _mix1(dtp.to_xi, f1), geo, zscale=T)
+    o11 = torch.stack(o11, -1).view(n, k, -1, 3)                                                 # [N,K,lo11,3]
     out1 = torch.einsum("nklm,nkam->nkla", torch.cat((o01, o11), 2), D)                          # rotate out, :416-418
     inter1 = torch.cat((_mix1(dtp.self_interact, f1)[:, None], _mix1(dtp.to_out, out1)), 1)      # [N,1+K,48,3]
     inter0 = torch.cat((me[:, None], edge.view(n, k, -1)), 1)                                    # [N,1+K,104]

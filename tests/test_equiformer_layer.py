@@ -88,3 +88,50 @@ def test_hip_layer_matches_reference(name):
     _load(model, case, seed)
     model.to("cuda:0")
     _check(model, case, name, dev="cuda:0", grad_rtol=5e-4)
+
+
+@pytest.mark.gpu
+def test_hip_degree1_at_hidden_256_is_equivariant_and_forms_no_per_edge_weights():
+    """depth 2 at C = 256 (block 1's degree-1 output feeds block 2) on the row-GEMM kernels.  No oracle
+    holds this size, so the size-independent properties: type 0 invariant and type 1 equivariant under a rigid motion,
+    finite gradients, and a peak allocation far below what the per-edge radial weights would take
+    (E x (24 + 24) x 256 floats = 49 KB per edge: 0.6 GB for this batch, per block and direction)."""
+    from equihgnn_amd.equiformer import Equiformer
+    dev = "cuda:0"
+    torch.manual_seed(11)
+    n = 768
+    model = Equiformer(256, depth=2, type1=True).to(dev)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(n, 256, generator=g).to(dev)
+    coors = (torch.randn(n, 3, generator=g) * 2.5).to(dev)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    q = (q * torch.sign(torch.det(q))).to(dev)                     # a proper rotation
+    def peak_of(m, out_loss):
+        with torch.no_grad():
+            m(feats.detach(), coors)                               # (warm-up: library workspaces, index buffers)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        x = feats.detach().requires_grad_(True)
+        out = m(x, coors)
+        out_loss(out).backward()
+        torch.cuda.synchronize()
+        return out, x.grad, torch.cuda.max_memory_allocated(dev) - base
+
+    # reference point: the degree-0-only layer (the registered wrapper's use) at the same size, one block
+    plain = Equiformer(256, depth=1, type1=False).to(dev)
+    _, _, peak0 = peak_of(plain, lambda o: o.square().mean())
+    del plain
+    (a0, a1), gx, peak = peak_of(model, lambda o: o[0].square().mean() + o[1].square().mean())
+    assert torch.isfinite(a0).all() and torch.isfinite(a1).all() and torch.isfinite(gx).all()
+    assert float(a1.detach().abs().max()) > 1e-4                   # the degree-1 path is live
+    one_set = n * 16 * 48 * 256 * 4                                # R01 + R11 of ONE block, forward only: 0.6 GB
+    # two blocks with degree-1 outputs stay within two degree-0 blocks plus one such set; materialised per-edge
+    # weights (saved for the backward, plus their gradients) took four to six sets
+    assert peak < 2 * peak0 + one_set, (peak, peak0, one_set)
+    with torch.no_grad():
+        b0, b1 = model(feats.detach(), coors @ q.T + 0.5)
+    a0, a1 = a0.detach(), a1.detach()
+    s0, s1 = float(a0.abs().max()), float(a1.abs().max())
+    assert float((a0 - b0).abs().max()) < 2e-5 * max(1.0, s0)
+    assert float((a1 @ q.T - b1).abs().max()) < 2e-5 * max(1.0, s1)
