@@ -125,13 +125,19 @@ k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F_rt, int C, const i
     }
 }
 
+// COLSUM: the column sums of dx ride along (the bias gradient of the Linear that produced the forward's input: one
+// more pass over the 2 GB [E * 8, 256] tensor of FAFormer's frame MLP otherwise, 0.6 ms).  The grid stride and the block
+// size are multiples of C / 4, so a thread always works on the same four columns: per-thread partial sums -> the
+// block's slab row [C] (threads sharing columns summed in thread order) -> fixed-order slab reduction.
+template <bool COLSUM>
 __global__ void __launch_bounds__(256)
 k_drop_mean_bwd(const float* __restrict__ dout, int64_t R, int F, int C, const int64_t* __restrict__ seed_ptr,
-                uint32_t threshold, float inv_keep, float* __restrict__ dx) {
+                uint32_t threshold, float inv_keep, float* __restrict__ dx, float* __restrict__ slab) {
     const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int c4 = C >> 2;
     const int64_t total = R * F * c4;
     const float inv_f = 1.0f / (float)F;
+    float4 cs = f4_zero();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / c4;
         const int c = (int)(i - row * c4) * 4;
@@ -143,6 +149,17 @@ k_drop_mean_bwd(const float* __restrict__ dout, int64_t R, int F, int C, const i
             g.z *= keep_scale(seed, e + 2, threshold, inv_keep); g.w *= keep_scale(seed, e + 3, threshold, inv_keep);
         }
         *reinterpret_cast<float4*>(dx + row * C + c) = g;
+        if (COLSUM) f4_add(cs, g);
+    }
+    if (COLSUM) {
+        __shared__ float4 s_cs[256];
+        s_cs[threadIdx.x] = cs;
+        __syncthreads();
+        if ((int)threadIdx.x < c4) {
+            float4 t = s_cs[threadIdx.x];
+            for (int k = threadIdx.x + c4; k < 256; k += c4) f4_add(t, s_cs[k]);
+            *reinterpret_cast<float4*>(slab + (int64_t)blockIdx.x * C + threadIdx.x * 4) = t;
+        }
     }
 }
 
@@ -209,10 +226,39 @@ extern "C" int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int
     if (!dout || !dx || (p > 0.f && !seed)) return EQH_ERR_ARG;
     if (!eqh_aligned16(dout) || !eqh_aligned16(dx)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(k_drop_mean_bwd, dim3(eqh_grid_for(R * F * (C / 4), 256, 8192)), dim3(256), 0, stream, dout, R, (int)F,
-                       (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), dx);
+    hipLaunchKernelGGL(k_drop_mean_bwd<false>, dim3(eqh_grid_for(R * F * (C / 4), 256, 8192)), dim3(256), 0, stream, dout, R,
+                       (int)F, (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
+}
+
+// the column-sum rider needs a thread to stay on its columns: C / 4 divides the block size (C = 4 .. 1024, a power of two)
+static inline bool dm_colsum_ok(int32_t C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0; }
+static inline int dm_colsum_blocks(int64_t R, int32_t F, int32_t C) { return eqh_grid_for(R * F * (C / 4), 256, 4096); }
+
+extern "C" size_t faf_dropout_mean_bwd_colsum_workspace_bytes(int64_t R, int32_t F, int32_t C) {
+    if (R <= 0 || F <= 0 || !dm_colsum_ok(C)) return 0;
+    return (size_t)dm_colsum_blocks(R, F, C) * (size_t)C * sizeof(float);
+}
+
+extern "C" int faf_dropout_mean_bwd_colsum(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed,
+                                           float* dx, float* colsum, int32_t accumulate, void* workspace,
+                                           size_t workspace_bytes, void* stream_) {
+    int rc = ew_check(R, C, p);
+    if (rc || F <= 0) return rc ? rc : EQH_ERR_ARG;
+    if (!dm_colsum_ok(C)) return EQH_ERR_ARG;
+    if (!colsum) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (R == 0) return accumulate ? EQH_OK : eqh_zero_async(colsum, C, stream);
+    if (!dout || !dx || !workspace || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if (!eqh_aligned16(dout) || !eqh_aligned16(dx) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
+    if (workspace_bytes < faf_dropout_mean_bwd_colsum_workspace_bytes(R, F, C)) return EQH_ERR_ARG;
+    const int blocks = dm_colsum_blocks(R, F, C);
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_drop_mean_bwd<true>, dim3(blocks), dim3(256), 0, stream, dout, R, (int)F, (int)C, seed,
+                       ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs_async(slab, blocks, C, colsum, stream, accumulate ? 1 : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -109,10 +109,12 @@ class SwiGLUMLP(nn.Module):
         if pre is not None:
             h = self.hidden(pre)                                           # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
-            out = self._fc2(h)
-            if out.is_cuda and out.dtype == torch.float32 and out.shape[-1] % 4 == 0:
-                return ops.dropout_mean(out, self.p)                       # dropout + frame average, one pass
-            return F.dropout(out, self.p, True).mean(-2)
+            if h.is_cuda and h.dtype == torch.float32 and self.fc2.weight.shape[0] % 4 == 0:
+                # dropout + frame average in one pass; fc2's bias gradient (the column sums of the [E * 8, C] gradient)
+                # rides that pass's backward instead of reading the tensor once more
+                out = ops.linear(h, self.fc2.weight, self.fc2.bias, bias_grad=False)
+                return ops.dropout_mean(out, self.p, bias=self.fc2.bias)
+            return F.dropout(self._fc2(h), self.p, True).mean(-2)
         return self._fc2(h.mean(-2))
 
 

@@ -97,6 +97,9 @@ SIGNATURES = {
     "faf_swiglu_dropout_bwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_fwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_dropout_mean_bwd": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_dropout_mean_bwd_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "faf_dropout_mean_bwd_colsum": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p,
+                                              c_int32, c_void_p, c_size_t, c_void_p]),
     "faf_attn_sum_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "faf_attn_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                    c_void_p]),

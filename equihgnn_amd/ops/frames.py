@@ -11,6 +11,7 @@ import torch
 from .. import hip
 from ._base import (_acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
 from .aggregate import (CSR, _segment_reduce)
+from .grads import colsum
 
 
 def _dropout_seed(device, p):
@@ -48,10 +49,12 @@ class _SwigluDropout(torch.autograd.Function):
 
 
 class _DropoutMean(torch.autograd.Function):
-    """mean over dim -2 of dropout_p(x) in one pass each way (faf_dropout_mean_*)."""
+    """mean over dim -2 of dropout_p(x) in one pass each way (faf_dropout_mean_*).  ``bias``: the bias PARAMETER of the
+    Linear that produced x (called with ``bias_grad=False``): its gradient, the column sums of dx, rides the backward
+    pass instead of costing another pass over dx (faf_dropout_mean_bwd_colsum)."""
 
     @staticmethod
-    def forward(ctx, x, p, seed=None):
+    def forward(ctx, x, p, seed=None, bias=None):
         _require_gpu(x, "dropout_mean")
         F_, C = x.shape[-2], x.shape[-1]
         x2 = _f32c(x).reshape(-1, C)
@@ -61,7 +64,7 @@ class _DropoutMean(torch.autograd.Function):
         timed("k_drop_mean_fwd", 4 * C * R * (F_ + 1),        # one read of [R * F, C], one write of [R, C]
               lambda: hip.check(hip.lib().faf_dropout_mean_fwd(_ptr(x2), R, F_, C, float(p), _ptr(seed), _ptr(out),
                                                                _stream(x.device)), "faf_dropout_mean_fwd"))
-        ctx.seed, ctx.p, ctx.shape = seed, float(p), x.shape
+        ctx.seed, ctx.p, ctx.shape, ctx.bias = seed, float(p), x.shape, bias
         return out.view(*x.shape[:-2], C)
 
     @staticmethod
@@ -70,10 +73,25 @@ class _DropoutMean(torch.autograd.Function):
         dout = _f32c(dout).reshape(-1, C)
         R = dout.shape[0]
         dx = torch.empty((R * F_, C), dtype=torch.float32, device=dout.device)
-        timed("k_drop_mean_bwd", 4 * C * R * (F_ + 1),
-              lambda: hip.check(hip.lib().faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx),
-                                                               _stream(dout.device)), "faf_dropout_mean_bwd"))
-        return dx.view(ctx.shape), None, None
+        L = hip.lib()
+        bias, db = ctx.bias, None
+        ws_bytes = L.faf_dropout_mean_bwd_colsum_workspace_bytes(R, F_, C) if (bias is not None and ctx.needs_input_grad[3]) else 0
+        if ws_bytes:
+            acc = _acc_target(bias)
+            tgt = acc if acc is not None else torch.empty(C, dtype=torch.float32, device=dout.device)
+            ws = _workspace(ws_bytes, dout.device)
+            timed("k_drop_mean_bwd", 4 * C * R * (F_ + 1),
+                  lambda: hip.check(L.faf_dropout_mean_bwd_colsum(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx),
+                                                                  _ptr(tgt), 1 if acc is not None else 0, _ptr(ws), ws_bytes,
+                                                                  _stream(dout.device)), "faf_dropout_mean_bwd_colsum"))
+            db = None if acc is not None else tgt
+        else:
+            timed("k_drop_mean_bwd", 4 * C * R * (F_ + 1),
+                  lambda: hip.check(L.faf_dropout_mean_bwd(_ptr(dout), R, F_, C, ctx.p, _ptr(ctx.seed), _ptr(dx),
+                                                           _stream(dout.device)), "faf_dropout_mean_bwd"))
+            if bias is not None and ctx.needs_input_grad[3]:      # (a width the rider does not take)
+                db = colsum(dx, into=_acc_target(bias))
+        return dx.view(ctx.shape), None, None, db
 
 
 class _FramePre(torch.autograd.Function):
@@ -234,6 +252,16 @@ def edge_hidden(A, B, Cf, nbr, csr_t: CSR, gamma, beta, eps: float = 1e-5, p: fl
     return _EdgeHidden.apply(A, B, Cf, nbr, csr_t, gamma, beta, eps, p, seed, (gamma, beta))
 
 
+def _tall_colsum(t):
+    """t.sum(0) for a tall [R, J <= 4] matrix.  torch reduces it with ONE 64-thread workgroup (600 us for the
+    [248 k, 2] logit gradients of a Molecule3D batch); through a [R / 64, 64 J] view the first pass has 64 J independent
+    columns and runs chip-wide."""
+    R, J = t.shape
+    if R >= 4096 and R % 64 == 0 and t.is_contiguous():
+        return t.view(R // 64, 64 * J).sum(0).view(64, J).sum(0)
+    return t.sum(0)
+
+
 class _RowDot(torch.autograd.Function):
     """y = x @ U.T + bias for a FEW output columns (J <= 4), one pass over x each way (faf_rowdot_*).  With
     ``passthrough`` the node also returns x itself for x's OTHER consumer, and the backward adds that consumer's gradient
@@ -271,7 +299,7 @@ class _RowDot(torch.autograd.Function):
         ws = _workspace(max(ws_bytes, 16), x2.device)
         hip.check(L.faf_rowdot_bwd(_ptr(x2), _ptr(Uc), _ptr(dy2), _ptr(add), R, C, J, _ptr(dx), _ptr(dU), 0, _ptr(ws),
                                    ws_bytes, _stream(x2.device)), "faf_rowdot_bwd")
-        db = dy2.sum(0) if ctx.has_bias else None
+        db = _tall_colsum(dy2) if ctx.has_bias else None
         return dx.view(ctx.shape), dU, db, None
 
 
@@ -396,9 +424,12 @@ def swiglu_dropout(pre, p: float = 0.0, seed=None):
     return _SwigluDropout.apply(pre, p, seed)
 
 
-def dropout_mean(x, p: float = 0.0, seed=None):
-    """dropout_p(x).mean(-2) for fp32 x [..., F, C] (C % 4 == 0)."""
-    return _DropoutMean.apply(x, p, seed)
+def dropout_mean(x, p: float = 0.0, seed=None, bias=None):
+    """dropout_p(x).mean(-2) for fp32 x [..., F, C] (C % 4 == 0).  ``bias``: see _DropoutMean (the producing Linear must
+    have been called with ``bias_grad=False``)."""
+    if bias is not None:
+        _note_acc(bias)
+    return _DropoutMean.apply(x, p, seed, bias)
 
 
 def eigh3(cov):

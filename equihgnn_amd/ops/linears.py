@@ -244,14 +244,14 @@ class _Linear(torch.autograd.Function):
     applied L times) and column-split weights (W·cat(a,b) = Wa·a + Wb·b) cost no extra kernels."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, c0, c1, r0=None, r1=None, relu=False):
+    def forward(ctx, x, weight, bias, c0, c1, r0=None, r1=None, relu=False, bias_grad=True):
         w = weight if c0 is None else weight[:, c0:c1]
         b = bias
         if r0 is not None:
             w = w[r0:r1]
             b = bias[r0:r1] if bias is not None else None
         ctx.cols, ctx.rows = (c0, c1), (r0, r1)
-        ctx.has_bias = bias is not None
+        ctx.has_bias = bias is not None and bool(bias_grad)      # (bias_grad False: another node produces the bias gradient)
         ctx.bias_param = bias
         ctx.relu = bool(relu)
         if relu:    # relu(x W^T + b) with the activation in the GEMM's epilogue (2-D x, bias given: checked by linear())
@@ -292,7 +292,7 @@ class _Linear(torch.autograd.Function):
             else:
                 db = torch.zeros_like(ctx.bias_param)
                 db[r0:r1] = colsum(dy2)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _Linear2(torch.autograd.Function):
@@ -368,10 +368,11 @@ class _LinearAddC(torch.autograd.Function):
         return dx, dw, (dy if ctx.needs_input_grad[2] and ctx.fan is None else None), None, None
 
 
-def linear(x, weight, bias=None, cols=None, rows=None, relu=False):
+def linear(x, weight, bias=None, cols=None, rows=None, relu=False, bias_grad=True):
     """F.linear(x, weight[rows[0]:rows[1], cols[0]:cols[1]], bias[rows[0]:rows[1]]) through _Linear (``weight`` and
     ``bias`` are the PARAMETERS, not slices of them, so that their gradient accumulators can be found).  ``relu``:
-    relu(...) with the activation in the GEMM epilogue (2-D fp32 x on the GPU with a bias; else a separate kernel)."""
+    relu(...) with the activation in the GEMM epilogue (2-D fp32 x on the GPU with a bias; else a separate kernel).
+    ``bias_grad=False``: the bias gradient is produced by the consumer of the output (ops.dropout_mean(..., bias=...))."""
     if relu and not (x.is_cuda and x.dim() == 2 and bias is not None and x.dtype == torch.float32):
         return torch.relu(linear(x, weight, bias, cols, rows))
     if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
@@ -379,7 +380,7 @@ def linear(x, weight, bias=None, cols=None, rows=None, relu=False):
     _note_acc(bias)
     c0, c1 = cols if cols is not None else (None, None)
     r0, r1 = rows if rows is not None else (None, None)
-    return _Linear.apply(x, weight, bias, c0, c1, r0, r1, relu)
+    return _Linear.apply(x, weight, bias, c0, c1, r0, r1, relu, bias_grad)
 
 
 def linear2(x, wa, cols_a, wb, cols_b):

@@ -544,6 +544,14 @@ int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_t C, float 
                          void* stream);
 int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed, float* dx,
                          void* stream);
+/* faf_dropout_mean_bwd with a rider: colsum[c] (+)= sum over the R*F rows of dx[:, c] -- the bias gradient
+ * (grad_output.sum(0)) of the nn.Linear whose output the forward consumed (fa_former_layer.py:61-120: fc2 of the frame
+ * MLP), taken from the values this pass writes instead of by another pass over the [R*F, C] tensor.  C a power of two,
+ * 4 .. 1024; `workspace` of faf_dropout_mean_bwd_colsum_workspace_bytes(R, F, C) bytes holds the per-workgroup partial
+ * sums, reduced in fixed order (deferred with the other accumulating reductions between eqh_defer_begin / flush). */
+size_t faf_dropout_mean_bwd_colsum_workspace_bytes(int64_t R, int32_t F, int32_t C);
+int faf_dropout_mean_bwd_colsum(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed, float* dx,
+                                float* colsum, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* First Linear of the frame-averaged MLP: out[e, f, :] = w3 (y[e] * s_f) + base[e, :] for the 8 sign frames
  * s_f = ((f&4 ? +1 : -1), (f&2 ? +1 : -1), (f&1 ? +1 : -1)) (fa_former_layer.py:70-84 order); y [E,3], w3 [H,3]
  * (= fc1.weight[:, :3], contiguous), base [E,H], out [E,8,H].  bwd reads dpre [E,8,H] once: dy [E,3], dbase [E,H],

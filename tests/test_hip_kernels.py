@@ -1209,6 +1209,34 @@ def test_gate_rows_matches_float64(R, C, p, with_res):
         assert err < 3e-5, (name, err)
 
 
+@pytest.mark.parametrize("R,F_,C,p", [(1, 8, 4, 0.0), (777, 8, 256, 0.1), (5000, 8, 256, 0.1), (301, 3, 64, 0.25), (64, 8, 320, 0.1)])
+def test_dropout_mean_backward_carries_the_bias_gradient_of_the_producing_linear(R, F_, C, p):
+    """faf_dropout_mean_bwd_colsum: linear(h, W, b, bias_grad=False) -> dropout_mean(., p, bias=b) against the same two ops
+    with the bias gradient taken by the Linear (a column sum over [R * F, C]): identical outputs, dh and dW bitwise,
+    db to fp32 rounding of a differently ordered sum; twice: bitwise equal; C = 320 takes the fallback (not a power of two)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    K = 32
+    h = torch.randn(R, F_, K, generator=g).to(DEV)
+    W = (0.2 * torch.randn(C, K, generator=g)).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    wo = torch.randn(R, C, generator=g).to(DEV)
+    seed = torch.tensor([24681357], dtype=torch.int64, device=DEV)
+    runs = []
+    for rider in (False, True, True):
+        hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, b))
+        y = ops.linear(hh, WW, bb, bias_grad=not rider)
+        out = ops.dropout_mean(y, p, seed, bias=bb if rider else None)
+        (out * wo).sum().backward()
+        runs.append((out.detach(), hh.grad, WW.grad, bb.grad))
+    ref, a, a2 = runs
+    for i in range(3):
+        assert torch.equal(ref[i], a[i])
+    assert torch.equal(a[3], a2[3])                                      # fixed-order slab reduction
+    scale = float(ref[3].abs().max()) + 1e-6
+    assert float((ref[3] - a[3]).abs().max()) <= 2e-6 * scale * max(1.0, (R * F_) ** 0.5 / 30), (ref[3] - a[3]).abs().max()
+
+
 @pytest.mark.parametrize("N,p", [(40, 0.0), (700, 0.1)])
 def test_edge_hidden_matches_the_unfused_composition(N, p):
     """faf_edge_hidden_fwd / _bwd against gather_rows + adds + swiglu_dropout + LayerNorm rows (same dropout seed): output and
