@@ -1,0 +1,37 @@
+// Dropout decisions as a hash of (seed, element index): no mask tensor, recomputed by every pass that needs it (forward,
+// backward, and the fused Linear + dropout + frame-mean epilogue of gemm_x6.hip), graph-replay safe (the seed lives in
+// device memory).
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+// Dropout decision of element i: 32-bit avalanche (the murmur3 finaliser) of the element index, keyed by the 64-bit
+// seed.  (Round 1 used the 64-bit splitmix finaliser per ELEMENT: ~25 instructions with its 64-bit multiplies -- on the
+// [E * 8, 256] frame tensors the hash, not the memory pass, bounded drop_mean and the fused hidden-layer kernels; this
+// one is 8.)  The seed enters through a key that is derived ONCE per thread by the full 64-bit mix: an XOR offset of
+// the index AND the first multiplier of the avalanche.  With the seed only XOR-ed in before / after a fixed avalanche
+// (round 2) the masks of two steps, or of two dropout sites, were XOR-translates of one fixed pattern; a seed-dependent
+// odd multiplier makes them different functions of the index at no cost per element.
+struct DropKey {
+    uint32_t x, m, a;   // index offset, odd multiplier, addend of the high index word
+};
+__device__ __forceinline__ DropKey drop_key(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull;            // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint64_t y = z + 0x9E3779B97F4A7C15ull;
+    y = (y ^ (y >> 30)) * 0xBF58476D1CE4E5B9ull;
+    y = (y ^ (y >> 27)) * 0x94D049BB133111EBull;
+    y ^= y >> 31;
+    return DropKey{(uint32_t)z, (uint32_t)(z >> 32) | 1u, (uint32_t)y | 1u};
+}
+// keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
+__device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
+    uint32_t h = ((uint32_t)i ^ key.x) + (uint32_t)(i >> 32) * key.a;
+    h ^= h >> 16; h *= key.m;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h >= threshold ? inv_keep : 0.f;
+}

@@ -35,6 +35,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "drop_hash.h"
 
 namespace {
 
@@ -45,7 +46,7 @@ constexpr int GX_THREADS = 768;      // wavefronts 0-3 multiply (2 x 2), wavefro
 constexpr int GX_BK = 32;
 constexpr int GX_MAXP = 8;
 
-enum : int { GX_TRANS_A = 1, GX_TRANS_B = 2, GX_RELU = 4 };
+enum : int { GX_TRANS_A = 1, GX_TRANS_B = 2, GX_RELU = 4, GX_MEAN8 = 8 };
 
 struct GxProb {
     const float* A;      // !TRANS_A: [M, K] (lda);  TRANS_A: [K, M] (lda)
@@ -61,6 +62,9 @@ struct GxProb {
     int tiles_mn;                       // row tiles x column tiles
     int chunk_steps;                    // K steps (of 32) per split
     float* slab;                        // splits > 1: [splits][M][N] partial products (alpha applied), else null
+    const int64_t* drop_seed;           // frame-mean epilogue: c[m / 8, :] = mean over the 8 rows of dropout_p(alpha a b + bias)
+    uint32_t drop_threshold;            //   p * 2^32 (0: no dropout)
+    float drop_inv_keep;                //   1 / (1 - p)
 };
 
 struct GxBatch {
@@ -412,9 +416,58 @@ k_gemm_x6(const GxBatch batch) {
             }
         }
     };
+    // Frame-mean epilogue (FAFormer's frame MLP, fa_former_layer.py:61-120: fc2 -> dropout -> mean over the 8 sign frames):
+    // rows 8 e .. 8 e + 7 of the product are the frames of row e of the output, so the [M, N] product never reaches
+    // memory -- c[e, :] = 1/8 sum_f keep(8 e + f, :) * (alpha ab + bias)[8 e + f, :], the keep decisions being the hash of
+    // (seed, element of the virtual [M, N] tensor) that faf_dropout_mean_fwd / _bwd use.  A lane takes four consecutive
+    // rows of a frame group and four columns; its partner (lane ^ 8) has the other four rows.
+    auto finish_mean = [&](auto has_bias) {
+        const uint32_t thr = P.drop_threshold;
+        const float inv_keep = P.drop_inv_keep;
+        const DropKey key = drop_key(thr ? (uint64_t)*P.drop_seed : 0);
+        const int grp = lane >> 4, part = (lane >> 3) & 1;            // frame group 0..3 of the 32 rows, its lower / upper half
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                        make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
+                const int col = n0 + (wn * NT + n) * 32 + ec;
+                const int colc = col < N ? col : N - 4;
+                float4 bv = f4_zero();
+                if constexpr (decltype(has_bias)::value) bv = *reinterpret_cast<const float4*>(bias + colc);
+                const int rloc = grp * 8 + part * 4;
+                const int64_t row0 = (int64_t)m0 + (wm * MT + m) * 32 + rloc;
+                float4 sum = f4_zero();
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 a = *reinterpret_cast<const float4*>(ep + (rloc + i) * EP_LD + ec);
+                    float4 o = make_float4(fmaf(alpha, a.x, bv.x), fmaf(alpha, a.y, bv.y), fmaf(alpha, a.z, bv.z), fmaf(alpha, a.w, bv.w));
+                    if (thr) {
+                        const uint64_t e = (uint64_t)((row0 + i) * N + col);
+                        o.x *= keep_scale(key, e, thr, inv_keep); o.y *= keep_scale(key, e + 1, thr, inv_keep);
+                        o.z *= keep_scale(key, e + 2, thr, inv_keep); o.w *= keep_scale(key, e + 3, thr, inv_keep);
+                    }
+                    if (row0 + i < M) f4_add(sum, o);
+                }
+                // rows in the order of the unfused pass (f = 0 .. 7): lower half first, then the partner's upper half
+                float4 other;
+                other.x = __shfl_xor(sum.x, 8); other.y = __shfl_xor(sum.y, 8);
+                other.z = __shfl_xor(sum.z, 8); other.w = __shfl_xor(sum.w, 8);
+                if (part == 0 && row0 < M && col < N) {
+                    f4_add(sum, other);
+                    sum.x *= 0.125f; sum.y *= 0.125f; sum.z *= 0.125f; sum.w *= 0.125f;
+                    *reinterpret_cast<float4*>(P.C + (row0 >> 3) * P.ldc + col) = sum;
+                }
+            }
+        }
+    };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    if (P.slab) {                       // split-K partial: alpha * acc, no addend / bias / activation (the reduction adds them)
+    if (P.flags & GX_MEAN8) { if (bias) finish_mean(T_{}); else finish_mean(F_{}); }
+    else if (P.slab) {                       // split-K partial: alpha * acc, no addend / bias / activation (the reduction adds them)
         float* __restrict__ sl = P.slab + (int64_t)split * M * N;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -486,7 +539,7 @@ extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmPro
         for (int i = 0; i < n_problems; ++i) {
             int sp, ch;
             gx_plan(pr[i].m, pr[i].n, pr[i].k, tms[c], tns[c], &sp, &ch);
-            if (sp > 1 && !pr[i].bias && !pr[i].relu) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
+            if (sp > 1 && !pr[i].bias && !pr[i].relu && !pr[i].mean_rows) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
         }
         if (total > best) best = total;
     }
@@ -507,6 +560,9 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || !q.b || !q.c) return EQH_ERR_ARG;
         if ((q.trans_a != 0) != a_ks || (q.trans_b == 0) != b_ks) return EQH_ERR_ARG;   // one operand layout per launch
         if (q.m >= (1ll << 31) - 256) return EQH_ERR_RANGE;
+        if (q.mean_rows != 0 && (q.mean_rows != 8 || (q.m & 7) || q.d || q.relu || q.trans_a || !(q.drop_p >= 0.f) || !(q.drop_p < 1.f) ||
+                                 (q.drop_p > 0.f && !q.drop_seed)))
+            return EQH_ERR_ARG;
         // float4 / float2 accesses: the contiguous extents and the row strides are multiples of 4 floats
         if ((q.n & 3) || (q.lda & 3) || (q.ldb & 3) || (q.ldc & 3) || (q.d && (q.ldd & 3))) return EQH_ERR_ALIGN;
         if ((!a_ks && (q.k & 3)) || (a_ks && (q.m & 3)) || (!b_ks && (q.k & 3))) return EQH_ERR_ALIGN;
@@ -530,12 +586,15 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldd = q.ldd;
         p.M = (int)q.m; p.N = q.n; p.K = q.k;
         p.alpha = q.alpha; p.beta = q.beta;
-        p.flags = (q.trans_a ? GX_TRANS_A : 0) | (q.trans_b ? GX_TRANS_B : 0) | (q.relu ? GX_RELU : 0);
+        p.flags = (q.trans_a ? GX_TRANS_A : 0) | (q.trans_b ? GX_TRANS_B : 0) | (q.relu ? GX_RELU : 0) | (q.mean_rows ? GX_MEAN8 : 0);
+        p.drop_seed = q.drop_seed;
+        p.drop_threshold = q.drop_p > 0.f ? (uint32_t)((double)q.drop_p * 4294967296.0) : 0u;
+        p.drop_inv_keep = 1.0f / (1.0f - q.drop_p);
         p.tiles_n = (q.n + TN - 1) / TN;
         p.tiles_mn = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
         int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;
         p.slab = nullptr;
-        if (!q.bias && !q.relu) {
+        if (!q.bias && !q.relu && !q.mean_rows) {
             gx_plan(q.m, q.n, q.k, TM, TN, &sp, &ch);
             if (sp > 1) {
                 const size_t need = (size_t)sp * (size_t)q.m * (size_t)q.n * sizeof(float);

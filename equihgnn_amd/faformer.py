@@ -109,6 +109,9 @@ class SwiGLUMLP(nn.Module):
         if pre is not None:
             h = self.hidden(pre)                                           # [..., 8, H/2]
         if self.training and self.p > 0:                                   # dropout after fc2 is per frame
+            if ops.linear_dropout_mean_supported(h, self.fc2.weight):
+                # fc2, the per-frame dropout and the frame average as one GEMM: the [E * 8, C] product is never written
+                return ops.linear_dropout_mean(h, self.fc2.weight, self.fc2.bias, self.p)
             if h.is_cuda and h.dtype == torch.float32 and self.fc2.weight.shape[0] % 4 == 0:
                 # dropout + frame average in one pass; fc2's bias gradient (the column sums of the [E * 8, C] gradient)
                 # rides that pass's backward instead of reading the tensor once more

@@ -34,7 +34,8 @@ class HgGemmProblem(ctypes.Structure):
     """HgGemmProblem of include/equihgnn_hip.h (one problem of hg_gemm_x6_batch)."""
     _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("d", c_void_p), ("ldd", c_int64),
                 ("bias", c_void_p), ("c", c_void_p), ("ldc", c_int64), ("m", c_int64), ("n", c_int32), ("k", c_int32),
-                ("trans_a", c_int32), ("trans_b", c_int32), ("relu", c_int32), ("alpha", c_float), ("beta", c_float)]
+                ("trans_a", c_int32), ("trans_b", c_int32), ("relu", c_int32), ("alpha", c_float), ("beta", c_float),
+                ("drop_seed", c_void_p), ("drop_p", c_float), ("mean_rows", c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one

@@ -66,7 +66,7 @@ from .se3 import (  # noqa: F401
 from .frames import (  # noqa: F401
     _dropout_seed, _SwigluDropout, _DropoutMean, _FramePre, _FrameHidden, _EdgeHidden, edge_hidden, _RowDot,
     rowdot, rowdot_supported, _GateRows, gate_rows, _AttnSum, attn_sum_supported, attn_sum, frame_pre,
-    frame_hidden, swiglu_dropout, dropout_mean, eigh3,
+    frame_hidden, swiglu_dropout, dropout_mean, eigh3, linear_dropout_mean, linear_dropout_mean_supported,
 )
 
 # switches that tests / tools / bench.py set as ``ops.NAME = value``: owner module of each

@@ -11,7 +11,9 @@ import torch
 from .. import hip
 from ._base import (_acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
 from .aggregate import (CSR, _segment_reduce)
-from .grads import colsum
+from ._base import LINEAR_PARAMS
+from .grads import _linear_weight_grad, colsum
+from .products import USE_X6, gemm, mm_nn
 
 
 def _dropout_seed(device, p):
@@ -92,6 +94,69 @@ class _DropoutMean(torch.autograd.Function):
             if bias is not None and ctx.needs_input_grad[3]:      # (a width the rider does not take)
                 db = colsum(dx, into=_acc_target(bias))
         return dx.view(ctx.shape), None, None, db
+
+
+class _LinearDropoutMean(torch.autograd.Function):
+    """mean over the F = 8 frames of dropout_p(h W^T + b) for h [..., 8, K] -- fc2, the per-frame dropout and the frame
+    average of FAFormer's frame MLP (fa_former_layer.py:61-120) -- as ONE x6 GEMM whose epilogue drops and averages: the
+    [E * 8, C] product (2 GB at the Molecule3D batch) is neither written nor read back.  Backward: the gradient of the
+    virtual product is formed by faf_dropout_mean_bwd_colsum (same keep decisions; the bias gradient rides along),
+    then the Linear's two products as in ops.linear (input gradient through mm_nn, weight gradient deferred)."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, p, seed):
+        _require_gpu(h, "linear_dropout_mean")
+        K, C = h.shape[-1], weight.shape[0]
+        h2 = _f32c(h).reshape(-1, K)
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(h.device, p)
+        out = gemm(h2, weight, trans_b=True, bias=bias, mean8=(float(p), seed if p > 0 else None))
+        ctx.save_for_backward(h2, weight)
+        ctx.seed, ctx.p, ctx.shape, ctx.bias = seed, float(p), h.shape, bias
+        return out.view(*h.shape[:-2], C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h2, weight = ctx.saved_tensors
+        C = weight.shape[0]
+        dout = _f32c(dout).reshape(-1, C)
+        R = dout.shape[0]
+        dy = torch.empty((R * 8, C), dtype=torch.float32, device=dout.device)
+        L = hip.lib()
+        bias = ctx.bias
+        want_db = bias is not None and ctx.needs_input_grad[2]
+        acc = _acc_target(bias) if want_db else None
+        db = None
+        ws_bytes = L.faf_dropout_mean_bwd_colsum_workspace_bytes(R, 8, C) if want_db else 0
+        if ws_bytes:
+            tgt = acc if acc is not None else torch.empty(C, dtype=torch.float32, device=dout.device)
+            ws = _workspace(ws_bytes, dout.device)
+            timed("k_drop_mean_bwd", 4 * C * R * 9,
+                  lambda: hip.check(L.faf_dropout_mean_bwd_colsum(_ptr(dout), R, 8, C, ctx.p, _ptr(ctx.seed), _ptr(dy), _ptr(tgt),
+                                                                  1 if acc is not None else 0, _ptr(ws), ws_bytes,
+                                                                  _stream(dout.device)), "faf_dropout_mean_bwd_colsum"))
+            db = None if acc is not None else tgt
+        else:
+            timed("k_drop_mean_bwd", 4 * C * R * 9,
+                  lambda: hip.check(L.faf_dropout_mean_bwd(_ptr(dout), R, 8, C, ctx.p, _ptr(ctx.seed), _ptr(dy),
+                                                           _stream(dout.device)), "faf_dropout_mean_bwd"))
+            if want_db:
+                db = colsum(dy, into=acc)
+        dh = mm_nn(dy, weight).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        dw = _linear_weight_grad(weight, None, None, dy, h2) if ctx.needs_input_grad[1] else None
+        return dh, dw, db, None, None
+
+
+def linear_dropout_mean_supported(h, weight) -> bool:
+    return (h.is_cuda and h.dtype == torch.float32 and h.dim() >= 3 and h.shape[-2] == 8 and USE_X6
+            and weight.shape[0] % 4 == 0 and h.shape[-1] % 4 == 0 and h.numel() // h.shape[-1] >= 8192)
+
+
+def linear_dropout_mean(h, weight, bias, p: float, seed=None):
+    """dropout_p(F.linear(h, weight, bias)).mean(-2) for h [..., 8, K]; see _LinearDropoutMean."""
+    if torch.is_grad_enabled() and weight.requires_grad and weight.is_leaf and not hasattr(weight, "_eqh_transient"):
+        LINEAR_PARAMS[id(weight)] = weight
+    _note_acc(bias)
+    return _LinearDropoutMean.apply(h, weight, bias, p, seed)
 
 
 class _FramePre(torch.autograd.Function):

@@ -118,6 +118,7 @@ class GemmProblem:
     beta: float = 1.0
     relu: bool = False
     out: Optional[torch.Tensor] = None
+    mean8: Optional[tuple] = None     # (p, seed tensor or None): frame-mean epilogue, the output is [M / 8, N]
 
 
 GEMM_TILE = 0          # 0: chosen per launch; 64 / 128 force a block tile (tools/gemm_bench.py)
@@ -148,13 +149,22 @@ def gemm_batch(problems):
         N = b.shape[0] if pr.trans_b else b.shape[1]
         if (b.shape[1] if pr.trans_b else b.shape[0]) != K:
             raise ValueError(f"gemm: op(a) is [{M}, {K}] but b is {tuple(b.shape)} (trans_b={pr.trans_b})")
-        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
-        assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+        rows_out = M // 8 if pr.mean8 is not None else M
+        out = pr.out if pr.out is not None else torch.empty((rows_out, N), dtype=torch.float32, device=dev)
+        assert out.shape == (rows_out, N) and out.stride(1) == 1 and out.dtype == torch.float32
         q = arr[i]
         q.a, q.lda, q.b, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
         q.c, q.ldc, q.m, q.n, q.k = out.data_ptr(), out.stride(0), M, N, K
         q.trans_a, q.trans_b, q.relu = int(bool(pr.trans_a)), int(bool(pr.trans_b)), int(bool(pr.relu))
         q.alpha, q.beta = float(pr.alpha), float(pr.beta)
+        if pr.mean8 is not None:
+            drop_p, seed = pr.mean8
+            assert M % 8 == 0 and pr.d is None and not pr.relu and not pr.trans_a
+            q.mean_rows, q.drop_p = 8, float(drop_p)
+            if seed is not None:
+                assert seed.dtype == torch.int64 and seed.is_cuda
+                keep.append(seed)
+                q.drop_seed = seed.data_ptr()
         if pr.d is not None:
             d = pr.d if pr.d is out else _row_view(pr.d, "gemm: d")
             assert d.shape == (M, N)
@@ -176,9 +186,9 @@ def gemm_batch(problems):
     return outs
 
 
-def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None):
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None, mean8=None):
     """One GEMM through hg_gemm_x6_batch (see GemmProblem)."""
-    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out)])[0]
+    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out, mean8)])[0]
 
 
 # Where the x6 kernel replaces the library GEMM (measured on MI355X against the TunableOp-selected hipBLASLt kernels,

@@ -142,6 +142,13 @@ typedef struct HgGemmProblem {
     int32_t n, k;
     int32_t trans_a, trans_b, relu;
     float alpha, beta;
+    /* mean_rows == 8: the frame-mean epilogue of FAFormer's frame MLP (fa_former_layer.py:61-120: fc2 -> dropout ->
+     * mean over the 8 sign frames).  c is [m / 8, n]:  c[e, :] = 1/8 sum_{f < 8} dropout_p(alpha a b + bias)[8 e + f, :],
+     * with the keep decisions of faf_dropout_mean_fwd / _bwd on the virtual [m, n] tensor (hash of (*drop_seed, element));
+     * the [m, n] product is never written.  Needs m % 8 == 0, trans_a == 0, no d, no relu; 0 = ordinary epilogue. */
+    const int64_t* drop_seed;
+    float drop_p;
+    int32_t mean_rows;
 } HgGemmProblem;
 size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* problems, int32_t tile);
 int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* problems, int32_t tile, void* workspace, size_t workspace_bytes,

@@ -1237,6 +1237,47 @@ def test_dropout_mean_backward_carries_the_bias_gradient_of_the_producing_linear
     assert float((ref[3] - a[3]).abs().max()) <= 2e-6 * scale * max(1.0, (R * F_) ** 0.5 / 30), (ref[3] - a[3]).abs().max()
 
 
+@pytest.mark.parametrize("R,K,C,p", [(1, 4, 4, 0.0), (37, 128, 256, 0.1), (1100, 128, 256, 0.1), (300, 36, 68, 0.25), (2048, 128, 128, 0.0)])
+def test_linear_dropout_mean_matches_the_unfused_ops(R, K, C, p):
+    """hg_gemm_x6_batch with mean_rows = 8 (fc2 + per-frame dropout + frame average in the GEMM epilogue) against
+    ops.linear -> ops.dropout_mean with the same seed: same keep decisions, so outputs and all gradients agree to fp32
+    rounding (the frame sum is ordered differently); ragged tiles in both directions; twice: bitwise equal."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + K + C)
+    h = torch.randn(R, 8, K, generator=g).to(DEV)
+    W = (K ** -0.5 * torch.randn(C, K, generator=g)).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    wo = torch.randn(R, C, generator=g).to(DEV)
+    seed = torch.tensor([135792468], dtype=torch.int64, device=DEV)
+    old_tile = ops.GEMM_TILE
+    runs = []
+    try:
+        for fused in (False, True, True):
+            hh, WW, bb = (t.clone().requires_grad_(True) for t in (h, W, b))
+            if fused:
+                out = ops.linear_dropout_mean(hh, WW, bb, p, seed)
+            else:
+                ops.GEMM_TILE = 64                                           # (the unfused product on the same kernel)
+                y = ops.gemm(hh.reshape(-1, K), WW.detach(), trans_b=True, bias=bb.detach()).view(R, 8, C) if K % 4 == 0 else None
+                ops.GEMM_TILE = old_tile
+                out = ops.dropout_mean(ops.linear(hh, WW, bb), p, seed)
+                if y is not None:                                            # the two forward routes see the same product
+                    np.testing.assert_allclose(ops.dropout_mean(y, p, seed).cpu().numpy(), out.detach().cpu().numpy(), rtol=2e-5, atol=2e-6)
+            (out * wo).sum().backward()
+            runs.append((out.detach(), hh.grad, WW.grad, bb.grad))
+    finally:
+        ops.GEMM_TILE = old_tile
+    ref, a, a2 = runs
+    for name, r, x in zip(("out", "dh", "dW", "db"), ref, a):
+        scale = float(r.abs().max()) + 1e-6
+        assert float((r - x).abs().max()) <= 3e-5 * scale, (name, float((r - x).abs().max()), scale)
+    for x, y2 in zip(a, a2):
+        assert torch.equal(x, y2)
+    if p > 0:                                                               # dropout is live: a tenth of the products is gone
+        full = (h.reshape(-1, K) @ W.t() + b).view(R, 8, C).mean(1)
+        assert float((full - a[0]).abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("N,p", [(40, 0.0), (700, 0.1)])
 def test_edge_hidden_matches_the_unfused_composition(N, p):
     """faf_edge_hidden_fwd / _bwd against gather_rows + adds + swiglu_dropout + LayerNorm rows (same dropout seed): output and
