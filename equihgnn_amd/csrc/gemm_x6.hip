@@ -552,8 +552,9 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     GxBatch b;
     b.n = n_problems;
     const bool a_ks = pr[0].trans_a != 0, b_ks = pr[0].trans_b == 0;
-    int64_t tiles_big = 0;
+    int64_t tiles_big = 0, tiles_huge = 0;
     bool deep = true;                       // every problem: few output tiles, long k (the split-K regime)
+    bool long_k = true;                     // every problem: k >= 1024 (a 128 x 128 tile's lower operand traffic pays)
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
         deep = deep && q.m >= 128 && q.n >= 128 && ((q.m + 127) / 128) * ((q.n + 127) / 128) < 128 && q.k >= 16384 && !q.bias && !q.relu;
@@ -569,12 +570,17 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         if (!eqh_aligned16(q.a) || !eqh_aligned16(q.b) || !eqh_aligned16(q.c) || !eqh_aligned16(q.d) || !eqh_aligned16(q.bias))
             return EQH_ERR_ALIGN;
         tiles_big += ((q.m + 127) / 128) * ((q.n + 63) / 64);
+        tiles_huge += ((q.m + 127) / 128) * ((q.n + 127) / 128);
+        long_k = long_k && q.k >= 1024 && q.n >= 128 && !q.mean_rows;
     }
     // 128 x 128 tiles, one workgroup per CU: long-K products (a weight gradient over ~10^5-10^6 rows is split along k
     // into hundreds of workgroups anyway: the largest tile has the least LDS traffic per MFMA, 142 against 103-124 TFLOP/s)
-    const int huge = tile == 256 || (tile == 0 && deep && workspace != nullptr);
-    // 128 x 64 tiles amortise the operand split better, 64 x 64 tiles fill the chip at this model's ~5 k-row batches
-    const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 1024);
+    // ... and products with k >= 1024 and at least one such tile per CU: [31 k x 2176].[2176 x 256] 204 against 221 us
+    // (128 x 64) and 293 us (64 x 64); 4096^3 198 against 173 TFLOP/s
+    const int huge = tile == 256 || (tile == 0 && deep && workspace != nullptr) || (tile == 0 && long_k && tiles_huge >= 256);
+    // 128 x 64 tiles amortise the operand split better (from one tile per CU: [31 k x 256].[256 x 256] 33.6 against
+    // 39.3 us), 64 x 64 tiles fill the chip at this model's ~5 k-row batches
+    const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 256);
     const int TM = big ? 128 : 64, TN = huge ? 128 : 64;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int64_t first = 0;

@@ -12,7 +12,7 @@ from ._base import (
     ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream,
     _workspace, timed)
 from .aggregate import (CSR)
-from .products import (mm_nn, mm_nt)
+from .products import (USE_X6, X6_WGRAD_ROWS, gemm, gemm_supported, mm_nn, mm_nt)
 from .grads import (colsum)
 
 
@@ -111,7 +111,10 @@ class _EgnnFeats(torch.autograd.Function):
             d_ab = _f32c(d_ab)
             dx = mm_nn(d_ab, w_cat) if dx is None else mm_nn(d_ab, w_cat, d=dx, out=dx)
             if ctx.needs_input_grad[1]:
-                dw = d_ab.t() @ feats
+                if USE_X6 and R >= X6_WGRAD_ROWS and gemm_supported(d_ab, feats, True, False):
+                    dw = gemm(d_ab, feats, trans_a=True, trans_b=False)      # split-K x6: 257 against 321 us at 31 k atoms
+                else:
+                    dw = d_ab.t() @ feats
             if ctx.needs_input_grad[2]:
                 db = colsum(d_ab)
         return dx, dw, db, dgamma, dbeta, None, None

@@ -196,7 +196,7 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1
 # (145-150 against 117-125 TFLOP/s at the Molecule3D / PCQM / Equiformer sizes); below that -- the [4.7 k x 256] x
 # [256 x 256] products of a QM9 batch, one workgroup per CU and eight K steps -- the tuned library is 10-30 % ahead.
 X6_MIN_OUTPUTS = 6_000_000
-X6_MAX_K = 1024
+X6_MAX_K = 8192
 X6_DEEP_ROWS = 32768        # weight gradients dY^T X over at least this many rows: the split-K form of the x6 kernel
 X6_WGRAD_ROWS = 8192        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
 USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
