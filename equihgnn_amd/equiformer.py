@@ -168,10 +168,14 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
         # sender rows (transposed neighbour CSR) and receiver rows both list every edge: one buffer, second pass adds
         out = ops.rowgemm2(z, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
         return out[:, :lo] + bias.reshape(-1, lo)
-    p = (xj.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)                             # [(m,k), lo]
-    q = (xi.transpose(1, 2) @ w).view(n, 3 * mid, lo_p)
-    pb = (xj.transpose(1, 2) @ b3.t()).reshape(n, 3 * lo)                           # [N, (m,lo)]
-    qb = xi.transpose(1, 2) @ b3.t()                                                # [N, 3, lo]
+    # (one autograd node per input, as for degree 0: the products take the x6 / library dispatch of ops.matmul_fan and
+    # their input gradients meet in accumulating GEMMs)
+    li = xj.shape[1]
+    b3t = b3.t()
+    p, pb = _fan(xj.transpose(1, 2).reshape(-1, li), w, b3t)                        # [3N, mid*lo_p], [3N, lo]
+    q, qb = _fan(xi.transpose(1, 2).reshape(-1, li), w, b3t)
+    p, q = p.view(n, 3 * mid, lo_p), q.view(n, 3 * mid, lo_p)                       # [(m,k), lo]
+    pb, qb = pb.view(n, 3 * lo), qb.view(n, 3, lo)                                  # [N, (m,lo)], [N, 3, lo]
     g = (ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]).reshape(-1, 3, lo)
     outs = []
     for zs in (zscale if isinstance(zscale, (list, tuple)) else (zscale,)):

@@ -36,7 +36,7 @@ from .aggregate import (  # noqa: F401
 )
 from .products import (  # noqa: F401
     DenseProblem, dense_supported, dense_batch, dense, GemmProblem, GEMM_TILE, gemm_supported, gemm_batch, gemm,
-    X6_MIN_OUTPUTS, X6_MAX_K, X6_DEEP_ROWS, X6_WGRAD_ROWS, USE_X6, _x6_ok, mm_nt, mm_nn, small_mm_batch,
+    X6_MIN_OUTPUTS, X6_MAX_K, X6_DEEP_ROWS, X6_WGRAD_OUTPUTS, X6_WGRAD_ROWS, USE_X6, _x6_ok, mm_nt, mm_nn, small_mm_batch,
 )
 from .grads import (  # noqa: F401
     GradFan, _FanSource, fanout, WGRAD_ON_SIDE_STREAM, _WGRAD_STREAMS, wgrad_stream, join_wgrad_stream,
@@ -81,6 +81,7 @@ _SWITCH_OWNER = {
     "X6_DEEP_ROWS": "products",
     "X6_MAX_K": "products",
     "X6_MIN_OUTPUTS": "products",
+    "X6_WGRAD_OUTPUTS": "products",
     "X6_WGRAD_ROWS": "products",
 }
 

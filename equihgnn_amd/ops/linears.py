@@ -4,12 +4,11 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
-
 import torch
 import torch.nn.functional as F
 
-from ._base import (LINEAR_PARAMS, _DEFER, _acc_target, _note_acc)
-from .products import (mm_nn, mm_nt, small_mm_batch)
+from ._base import (LINEAR_PARAMS, _DEFER, _acc_target, _f32c, _note_acc)
+from .products import (USE_X6, X6_WGRAD_OUTPUTS, gemm, gemm_supported, mm_nn, mm_nt, small_mm_batch)
 from .grads import (_linear_weight_grad, _merged_acc, _wgrad_deferred, _wgrad_ok, colsum, wgrad)
 
 
@@ -443,6 +442,11 @@ class _MatmulFan(torch.autograd.Function):
                 if not _wgrad_deferred(x2, dy2, 1.0, tgt):      # into [in, out] += x2^T dy2
                     tgt.addmm_(x2.t(), dy2)
                 dWs.append(None)
+            elif (USE_X6 and x2.is_cuda and x2.shape[0] >= 1024 and x2.shape[1] * dy2.shape[1] >= X6_WGRAD_OUTPUTS
+                  and gemm_supported(x2, dy2, True, False)):
+                # a wide transient weight (Equiformer's [256 x 16384] radial node weights): 128 x 128 tiles on the x6 kernel,
+                # 114 against the library's 153 us
+                dWs.append(gemm(_f32c(x2), _f32c(dy2), trans_a=True, trans_b=False))
             else:
                 dWs.append(x2.t() @ dy2)
         return (dx.view(x.shape) if dx is not None else None, *dWs)

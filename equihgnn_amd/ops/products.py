@@ -198,6 +198,7 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1
 X6_MIN_OUTPUTS = 6_000_000
 X6_MAX_K = 8192
 X6_DEEP_ROWS = 32768        # weight gradients dY^T X over at least this many rows: the split-K form of the x6 kernel
+X6_WGRAD_OUTPUTS = 4_000_000   # x^T dy products with at least this many outputs (and >= 1024 rows): 128 x 128 tiles
 X6_WGRAD_ROWS = 8192        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
 USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
 
