@@ -11,7 +11,7 @@ import torch
 
 from .. import hip
 from ._base import (_DEFER, _f32c, _ptr, _stream, _workspace)
-from .products import (GemmProblem, USE_X6, X6_DEEP_ROWS, X6_WGRAD_ROWS, gemm, gemm_batch, gemm_supported)
+from .products import (GemmProblem, USE_X6, X6_DEEP_ROWS, X6_WGRAD_ROWS, gemm, gemm_batch, gemm_out_ok, gemm_supported)
 
 
 class GradFan:
@@ -138,7 +138,7 @@ def defer_flush(device):
             rest = [en for en in group if en[0].shape[0] < X6_DEEP_ROWS]
             with torch.no_grad():
                 for dy2, x2, alpha, into in deep:
-                    if USE_X6 and gemm_supported(dy2, x2, True, False):
+                    if USE_X6 and gemm_supported(dy2, x2, True, False) and gemm_out_ok(into):
                         # split-K on the bf16 matrix cores: 140-150 TFLOP/s against 75 (hg_wgrad_f32) / 60-70 (library)
                         _DEFER["keep"].extend((dy2, x2))
                         gemm(dy2, x2, trans_a=True, trans_b=False, d=into, out=into, alpha=alpha)
@@ -147,7 +147,8 @@ def defer_flush(device):
             # ~10^4-row products (FAFormer's atom-level Linears): whatever their shapes, up to eight of them share one x6
             # launch whose split-K plan fills the chip per product (the library runs a [256 x 15 k].[15 k x 128] product on
             # 8 tiles: 100 us for 1 GFLOP; hg_wgrad_batch_f32 reaches 75 TFLOP/s on the fp32 MFMA)
-            mid = [en for en in rest if USE_X6 and en[0].shape[0] >= X6_WGRAD_ROWS and gemm_supported(en[0], en[1], True, False)]
+            mid = [en for en in rest if USE_X6 and en[0].shape[0] >= X6_WGRAD_ROWS and gemm_supported(en[0], en[1], True, False)
+                   and gemm_out_ok(en[3])]
             if mid:
                 x6_mid.extend(mid)
                 rest = [en for en in rest if not any(en is m for m in mid)]
@@ -279,7 +280,8 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
             pass
         elif side is None and _wgrad_ok(dy2, x2):
             wgrad(dy2, x2, into=tgt)
-        elif side is None and USE_X6 and dy2.is_cuda and dy2.shape[0] >= X6_WGRAD_ROWS and gemm_supported(dy2, x2, True, False):
+        elif (side is None and USE_X6 and dy2.is_cuda and dy2.shape[0] >= X6_WGRAD_ROWS and gemm_supported(dy2, x2, True, False)
+              and gemm_out_ok(tgt)):
             # (shapes the batched kernel does not take, e.g. the 272-wide input of the EGNN node MLP: 93 against 127 us)
             dy2, x2 = _f32c(dy2), _f32c(x2)
             if _DEFER["active"]:

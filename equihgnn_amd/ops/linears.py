@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from ._base import (LINEAR_PARAMS, _DEFER, _acc_target, _f32c, _note_acc)
-from .products import (USE_X6, X6_WGRAD_OUTPUTS, gemm, gemm_supported, mm_nn, mm_nt, small_mm_batch)
+from .products import (USE_X6, X6_WGRAD_OUTPUTS, X6_WGRAD_ROWS, gemm, gemm_out_ok, gemm_supported, mm_nn, mm_nt, small_mm_batch)
 from .grads import (_linear_weight_grad, _merged_acc, _wgrad_deferred, _wgrad_ok, colsum, wgrad)
 
 
@@ -439,7 +439,16 @@ class _MatmulFan(torch.autograd.Function):
                 continue
             tgt = _acc_target(W)
             if tgt is not None:
-                if not _wgrad_deferred(x2, dy2, 1.0, tgt):      # into [in, out] += x2^T dy2
+                if _wgrad_deferred(x2, dy2, 1.0, tgt):          # into [in, out] += x2^T dy2
+                    pass
+                elif (USE_X6 and x2.is_cuda and x2.shape[0] >= X6_WGRAD_ROWS and gemm_supported(x2, dy2, True, False)
+                      and gemm_out_ok(tgt)):
+                    # (widths the batched kernel does not take: the [104 x 104] attention mix over 39 k edge rows, split-K)
+                    xa, da = _f32c(x2), _f32c(dy2)
+                    if _DEFER["active"]:
+                        _DEFER["keep"].extend((xa, da))
+                    gemm(xa, da, trans_a=True, trans_b=False, d=tgt, out=tgt)
+                else:
                     tgt.addmm_(x2.t(), dy2)
                 dWs.append(None)
             elif (USE_X6 and x2.is_cuda and x2.shape[0] >= 1024 and x2.shape[1] * dy2.shape[1] >= X6_WGRAD_OUTPUTS

@@ -135,6 +135,12 @@ def gemm_supported(a, b, trans_a=False, trans_b=True) -> bool:
     return n % 4 == 0 and k > 0 and (m % 4 == 0 if trans_a else k % 4 == 0) and (k % 4 == 0 or not trans_b)
 
 
+def gemm_out_ok(t) -> bool:
+    """A destination / addend view hg_gemm_x6_batch can write: unit inner stride, row stride a multiple of 4 floats, 16-byte
+    aligned (a column block of a wider gradient buffer may be neither)."""
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
 def gemm_batch(problems):
     """Up to 8 GEMMs with the same operand layout in ONE launch; returns the outputs."""
     n = len(problems)

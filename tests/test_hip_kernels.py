@@ -1183,6 +1183,37 @@ def test_rowdot_matches_float64(R, C, J):
             assert err < 3e-5, (name, passthrough, err)
 
 
+def test_colsum_batch_groups_entries_of_very_different_sizes():
+    """hg_colsum_batch_f32 with 30 entries from 3 to 70 000 rows (more than one launch group, more than 24 entries), two
+    of them into the same destination, row-weighted ones among them: every destination = its float64 column sums added
+    to what it held; twice: bitwise equal."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(91)
+    rows = [70000, 3, 15000, 16512, 500, 70000, 15488] + [1000 + 37 * i for i in range(23)]
+    entries, want = [], []
+    dests = {}
+    for i, R in enumerate(rows):
+        C = 256 if i % 3 else 64
+        x = torch.randn(R, C, generator=g).to(DEV)
+        key = "shared" if i in (0, 3) else i
+        if key not in dests:
+            dests[key] = [torch.randn(C, generator=g).to(DEV), None]
+            dests[key][1] = dests[key][0].double().clone()
+        scale = 0.5 if i % 4 == 0 else 1.0
+        entries.append((x, None, 0, dests[key][0], scale))
+        dests[key][1] += scale * x.double().sum(0)
+    saved = {k: v[0].clone() for k, v in dests.items()}
+    ops.colsum_batch(entries)
+    first = {k: v[0].clone() for k, v in dests.items()}
+    for k, (got, ref) in dests.items():
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-3)
+    for k, v in dests.items():
+        v[0].copy_(saved[k])
+    ops.colsum_batch(entries)
+    for k, v in dests.items():
+        assert torch.equal(v[0], first[k])
+
+
 @pytest.mark.parametrize("R,C,p,with_res", [(1, 64, 0.0, False), (1000, 256, 0.1, True), (333, 320, 0.0, True), (50, 1024, 0.2, False)])
 def test_gate_rows_matches_float64(R, C, p, with_res):
     """faf_gate_fwd / _bwd: res + xd * sigmoid(xd . w + b) with xd = dropout_p(x); the dropout decisions are reproduced for

@@ -313,6 +313,61 @@ def test_merged_linears_match_the_layer_by_layer_conv(graphed, monkeypatch):
         assert float((g1[n] - g0[n]).abs().max()) / scale < 2e-4, n
 
 
+@pytest.mark.parametrize("method,batch,flavour", [("faformer_equihnns", 48, "pcqm"), ("egnn_equihnns", 300, "pcqm")])
+def test_large_row_gemm_routes_match_the_library_path(method, batch, flavour):
+    """From ~8 k rows the dense products and weight gradients leave the library for the x6 kernel (ops.mm_nt / mm_nn,
+    batched and split-K weight gradients, odd-width and column-block destinations that must fall back): a graphed step
+    on a batch with > 8 k atom rows / > 20 k edge rows gives the same loss and the same gradient for EVERY parameter as
+    the same step with ops.USE_X6 off.  Then two training-mode steps (FAFormer: dropouts on -- the fused fc2 + dropout +
+    frame-mean GEMM epilogue) run and stay finite."""
+    import copy
+
+    from common import zero_dropouts
+    from equihgnn_amd import ops
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+    args = default_args(method=method)                  # hidden 256: the widths and column blocks of the real configurations
+    m = _models()[method](1, args)
+    fill_state_dict(m, 9)
+    m.to(DEV)
+    b = synth_batch(batch, 4242, flavour).to(DEV)
+    b.num_real_graphs = batch
+    assert b.num_nodes >= (8192 if method == "egnn_equihnns" else 1300)
+
+    def grads(use_x6):
+        saved = ops.USE_X6
+        ops.USE_X6 = use_x6
+        try:
+            model = copy.deepcopy(m)
+            zero_dropouts(model)
+            b._hyper_index = None
+            tr = GraphedTrainStep(model, lr=0.0, keep_grads=True)
+            for _ in range(3):                  # bootstrap (eager), capture, replay
+                loss = float(tr.step(b))
+            out = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            tr.close()
+            return loss, out
+        finally:
+            ops.USE_X6 = saved
+
+    l1, g1 = grads(True)
+    l0, g0 = grads(False)
+    assert abs(l1 - l0) <= 2e-5 * max(1.0, abs(l0)), (l1, l0)
+    assert set(g1) == set(g0)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:        # (two fp32 roundings of the same products: entries next to a ReLU / frame-sign kink move by ~1e-3 of
+        #                      the gradient's scale at hidden 256, the bulk agrees to 1e-5)
+        scale = max(float(g0[n].abs().max()), 1e-3 * gmax) + 1e-12
+        assert float((g1[n] - g0[n]).abs().max()) / scale < 1e-2, n
+        assert float((g1[n] - g0[n]).norm()) <= 5e-3 * float(g0[n].norm()) + 1e-5 * gmax, n
+    model = copy.deepcopy(m).train()
+    tr = GraphedTrainStep(model, lr=1e-4)
+    losses = [float(tr.step(b)) for _ in range(4)]
+    tr.close()
+    assert all(np.isfinite(losses)), losses
+
+
 @pytest.mark.parametrize("method", ["egnn_equihnns", "mhnnm", "egnn_equihnnm", "equiformer_equihnns", "faformer_equihnns",
                                     "mhnns", "mhnn"])
 def test_graphed_train_step_matches_eager(method):
