@@ -19,7 +19,16 @@ elif [ "$1" = 1 ]; then
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python3 bench.py --no-cpu-baseline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_main -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
   # kernel order of one replayed step: a trace of the step alone (no roofline probes after it)
-  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_order -- python3 bench.py --steps 6 --warmup 3 --blocks 1 --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > /dev/null 2>> $O/rocprof.err || exit 1
+  # and per-kernel averages of the training step ALONE (95 replays + 2 set-up steps; the CSV above also holds the
+  # roofline probes, which launch the same scatter kernels at the saturating size)
+  rm -rf /tmp/prof_order
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_step_only_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_step_kernel_stats.csv
+  python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
+elif [ "$1" = 1b ]; then
+  rm -rf /tmp/prof_order
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_step_only_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_step_kernel_stats.csv
   python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
 elif [ "$1" = 2 ]; then
   for spec in "egnn_equihnns 1024 pcqm" "mhnns 256 qm9" "mhnn 256 qm9" "mhnnm 256 qm9" "egnn_equihnn 256 qm9" "egnn_equihnnm 256 qm9"; do
