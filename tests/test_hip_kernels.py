@@ -1650,7 +1650,10 @@ def _gemm_ref64(a, b, ta, tb, bias, d, alpha, beta, relu):
 @pytest.mark.parametrize("M,N,K,ta,tb", [(4736, 256, 256, False, True), (4736, 256, 256, False, False),
                                          (256, 256, 4736, True, False), (300, 64, 272, False, True),
                                          (77, 132, 36, False, False), (1, 4, 4, False, True), (516, 2176, 256, False, True),
-                                         (2176, 256, 1000, True, False), (100, 68, 44, True, True)])
+                                         (2176, 256, 1000, True, False), (100, 68, 44, True, True),
+                                         # more tiles than one resident wave of workgroups: every workgroup walks several
+                                         # tiles through one ring (the persistent loop), with a partial last K step
+                                         (70000, 256, 100, False, True), (66000, 132, 36, False, False)])
 def test_gemm_x6_matches_float64_and_is_no_worse_than_the_fp32_mfma(M, N, K, ta, tb, tile):
     """hg_gemm_x6_batch against float64, for every operand layout the models use (x W^T, dY W, dY^T X) and ragged
     shapes.  VERDICT r2 #7's acceptance rule for a split-bf16 product: its error against float64 must be no larger
@@ -1707,6 +1710,8 @@ def test_gemm_x6_epilogues_batches_and_views():
         a = torch.randn(100 + 37 * i, 32 + 4 * i, generator=g).to(DEV)
         b = torch.randn(16 + 4 * i, 32 + 4 * i, generator=g).to(DEV)
         probs.append(ops.GemmProblem(a, b))
+    probs.append(ops.GemmProblem(torch.randn(40000, 72, generator=g).to(DEV), torch.randn(64, 72, generator=g).to(DEV)))   # 625+ tiles
+    probs = probs[1:]
     outs = ops.gemm_batch(probs)
     outs2 = ops.gemm_batch(probs)
     for pr, o, o2 in zip(probs, outs, outs2):
