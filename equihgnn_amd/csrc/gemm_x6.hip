@@ -42,7 +42,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int GX_THREADS = 768;      // wavefronts 0-3 multiply (2 x 2), wavefronts 4-11 load, split and stage (two groups)
+constexpr int GX_STAGERS = 512;      // eight wavefronts load, split and stage (two groups of four), behind the multiplying wavefronts (2 x 2; 2 x 4 for the 128 x 256 tile)
 constexpr int GX_BK = 32;
 constexpr int GX_MAXP = 8;
 
@@ -233,10 +233,12 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 // MT x NT: 32 x 32 MFMA tiles per multiplying wavefront; the four of them sit 2 x 2: block tile 64 MT x 64 NT
-template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS>
-__global__ void __launch_bounds__(GX_THREADS, MINW)
+// WR x WC: the multiplying wavefronts' grid (2 x 2; 2 x 4 and 4 x 2 for the 128 x 256 / 256 x 128 tiles, one workgroup per CU)
+template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS, int WR = 2, int WC = 2>
+__global__ void __launch_bounds__(64 * WR * WC + GX_STAGERS, MINW)
 k_gemm_x6(const GxBatch batch) {
-    constexpr int BM = 64 * MT, BN = 64 * NT;
+    constexpr int BM = 32 * WR * MT, BN = 32 * WC * NT;
+    constexpr int NMT = 64 * WR * WC;                                              // multiplying threads
     constexpr int SA = 3 * (BM / 32) * 2 * 64, SB = 3 * (BN / 32) * 2 * 64;       // uint4 per stage
     __shared__ uint4 s_mem[S * (SA + SB)];                                         // ring of stages, each [A | B]
 
@@ -266,7 +268,7 @@ k_gemm_x6(const GxBatch batch) {
     // A SIMD hosts one multiplier and two stagers per resident block; the hardware interleaves the stagers' VALU work
     // with the multipliers' MFMAs (the 32 x 32 x 16 MFMA holds the vector issue port for 8 of its 32 cycles).
     GX_STAMP(0);
-    if (threadIdx.x >= 256) {
+    if (threadIdx.x >= NMT) {
         using LA = Loader<BM, A_KS>;
         using LB = Loader<BN, B_KS>;
         LA la;
@@ -275,7 +277,7 @@ k_gemm_x6(const GxBatch batch) {
         lb.init(P.B, P.ldb, n0, N);
         typename LA::Regs ra;
         typename LB::Regs rb;
-        const int grp = (int)(threadIdx.x >> 8) - 1;        // 0 or 1 (wavefront-uniform)
+        const int grp = ((int)threadIdx.x - NMT) >> 8;      // 0 or 1 (wavefront-uniform)
         auto fetch = [&](int w) {                           // w: step within this split
             if (w >= NS) return;
             if (kt0 + w < KT) {
@@ -314,7 +316,7 @@ k_gemm_x6(const GxBatch batch) {
     }
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WC, wn = wave % WC;
     const int fh = lane >> 5, fr = lane & 31;
     const int frag_off0 = fh * 32 + (fr ^ (2 * fh)), frag_off1 = 64 + fh * 32 + (fr ^ (2 * (2 + fh)));   // k halves
 
@@ -492,13 +494,13 @@ k_gemm_x6(const GxBatch batch) {
     GX_STAMP(31);
 }
 
-template <int MT, int NT, int S, int MINW>
+template <int MT, int NT, int S, int MINW, int WR = 2, int WC = 2>
 int launch(const GxBatch& b, bool a_ks, bool b_ks, hipStream_t stream) {
-    const dim3 grid(b.total_tiles), block(GX_THREADS);
-    if (!a_ks && !b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false>), grid, block, 0, stream, b);
-    else if (!a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, true>), grid, block, 0, stream, b);
-    else if (a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, true>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, false>), grid, block, 0, stream, b);
+    const dim3 grid(b.total_tiles), block(64 * WR * WC + GX_STAGERS);
+    if (!a_ks && !b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false, WR, WC>), grid, block, 0, stream, b);
+    else if (!a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, true, WR, WC>), grid, block, 0, stream, b);
+    else if (a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, true, WR, WC>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, false, WR, WC>), grid, block, 0, stream, b);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -532,9 +534,9 @@ static inline void gx_plan(int64_t m, int n, int k, int TM, int TN, int* splits,
 extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* pr, int32_t tile) {
     if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return 0;
     size_t best = 0;
-    const int tms[3] = {64, 128, 128}, tns[3] = {64, 64, 128};
-    for (int c = 0; c < 3; ++c) {           // the launch chooses its tile from the shapes: room for whichever it takes
-        if ((tile == 64 && c != 0) || (tile == 128 && c != 1) || (tile == 256 && c != 2)) continue;
+    const int tms[5] = {64, 128, 128, 128, 256}, tns[5] = {64, 64, 128, 256, 128};
+    for (int c = 0; c < 5; ++c) {           // the launch chooses its tile from the shapes: room for whichever it takes
+        if ((tile == 64 && c != 0) || (tile == 128 && c != 1) || (tile == 256 && c != 2) || (tile == 512 && c != 3) || (tile == 513 && c != 4)) continue;
         size_t total = 0;
         for (int i = 0; i < n_problems; ++i) {
             int sp, ch;
@@ -581,7 +583,24 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     // 128 x 64 tiles amortise the operand split better (from one tile per CU: [31 k x 256].[256 x 256] 33.6 against
     // 39.3 us), 64 x 64 tiles fill the chip at this model's ~5 k-row batches
     const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 256);
-    const int TM = big ? 128 : 64, TN = huge ? 128 : 64;
+    // 128 x 256 / 256 x 128 tiles with EIGHT multiplying wavefronts (two per SIMD, one workgroup per CU): half the operand
+    // traffic per MFMA of the 128 x 64 tile and a second multiplier to fill each SIMD's MFMA pipe -- [246 k x 256].[256 x 256]
+    // 199 against 220 us, [1.97 M x 128].[128 x 256] 943 against 1122 us.  Taken when every product is wide (tall) enough
+    // to fill the tile and there is about a tile per CU; split-K products keep the 128 x 128 tile
+    bool fit_wide = true, fit_tall = true;
+    int64_t tiles_wide = 0, tiles_tall = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const HgGemmProblem& q = pr[i];
+        const int nw = (q.n + 255) / 256 * 256, nt = (q.n + 127) / 128 * 128;
+        fit_wide = fit_wide && q.n >= 224 && (nw - q.n) * 8 <= q.n;
+        fit_tall = fit_tall && q.n >= 96 && (nt - q.n) * 8 <= q.n && q.m >= 256;
+        tiles_wide += ((q.m + 127) / 128) * (nw / 256);
+        tiles_tall += ((q.m + 255) / 256) * (nt / 128);
+    }
+    const bool no_split = !(deep && workspace != nullptr);
+    const int wide = tile == 512 || (tile == 0 && no_split && fit_wide && tiles_wide >= 200);
+    const int tall = !wide && (tile == 513 || (tile == 0 && no_split && fit_tall && tiles_tall >= 200));
+    const int TM = tall ? 256 : ((big || wide) ? 128 : 64), TN = wide ? 256 : ((huge || tall) ? 128 : 64);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int64_t first = 0;
     size_t ws_used = 0;
@@ -623,7 +642,9 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     b.total_tiles = (int)first;
     if (first == 0) return EQH_OK;
     int rc;
-    if (huge) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
+    if (wide) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream);
+    else if (tall) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream);
+    else if (huge) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
     else rc = big ? launch<2, 1, 2, 6>(b, a_ks, b_ks, stream) : launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
     if (rc) return rc;
     // split-K problems: c = beta * d + sum of the slabs, in slab order (bitwise reproducible); beta * d with d == c and
