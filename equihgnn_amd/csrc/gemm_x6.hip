@@ -514,13 +514,31 @@ extern "C" int hg_gemm_x6_debug_stamps(void* buf) {
 }
 #endif
 
+// The five tile configurations and what a workgroup of each costs, from tools/gemm_bench.py on MI355X (microseconds per
+// 32-deep K step and per tile for prologue + epilogue, with every CU holding its `slots / CUs` workgroups):
+//   64 x 64 and 128 x 64 run two workgroups per CU (512 slots), the others one (256 slots)
+struct GxCfg {
+    int id, TM, TN, slots;
+    float t_step, t_fixed;
+};
+static const GxCfg GX_CFGS[5] = {{64, 64, 64, 512, 0.95f, 2.0f},
+                                 {128, 128, 64, 512, 1.55f, 2.3f},
+                                 {256, 128, 128, 256, 1.25f, 5.0f},
+                                 {512, 128, 256, 256, 2.41f, 7.2f},     // eight multiplying wavefronts
+                                 {513, 256, 128, 256, 2.41f, 7.2f}};
+static inline const GxCfg& gx_cfg(int id) {
+    for (const GxCfg& c : GX_CFGS)
+        if (c.id == id) return c;
+    return GX_CFGS[0];
+}
+
 // split-K plan of one problem: splits > 1 when the output tiles alone leave most of the chip idle and K is long
-static inline void gx_plan(int64_t m, int n, int k, int TM, int TN, int* splits, int* chunk_steps) {
-    const int64_t tiles = ((m + TM - 1) / TM) * ((n + TN - 1) / TN);
+static inline void gx_plan(int64_t m, int n, int k, const GxCfg& c, int* splits, int* chunk_steps) {
+    const int64_t tiles = ((m + c.TM - 1) / c.TM) * ((n + c.TN - 1) / c.TN);
     const int steps = (k + GX_BK - 1) / GX_BK;
     int sp = 1;
-    if (tiles < 256 && steps >= 64) {
-        const int64_t want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in all
+    if (tiles < c.slots / 2 && steps >= 64) {
+        const int64_t want = (2 * c.slots + tiles - 1) / tiles;   // two rounds of workgroups in all
         sp = (int)(want < steps / 16 ? want : steps / 16);        // at least 16 steps per split
         if (sp < 1) sp = 1;
         if (sp > 4096) sp = 4096;
@@ -531,21 +549,62 @@ static inline void gx_plan(int64_t m, int n, int k, int TM, int TN, int* splits,
     *chunk_steps = ch;
 }
 
-extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* pr, int32_t tile) {
-    if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return 0;
-    size_t best = 0;
-    const int tms[5] = {64, 128, 128, 128, 256}, tns[5] = {64, 64, 128, 256, 128};
-    for (int c = 0; c < 5; ++c) {           // the launch chooses its tile from the shapes: room for whichever it takes
-        if ((tile == 64 && c != 0) || (tile == 128 && c != 1) || (tile == 256 && c != 2) || (tile == 512 && c != 3) || (tile == 513 && c != 4)) continue;
-        size_t total = 0;
-        for (int i = 0; i < n_problems; ++i) {
-            int sp, ch;
-            gx_plan(pr[i].m, pr[i].n, pr[i].k, tms[c], tns[c], &sp, &ch);
-            if (sp > 1 && !pr[i].bias && !pr[i].relu && !pr[i].mean_rows) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
-        }
-        if (total > best) best = total;
+static inline bool gx_may_split(const HgGemmProblem& q) { return !q.bias && !q.relu && !q.mean_rows; }
+
+// Estimated time of a launch with configuration c (microseconds): the workgroups' times summed over the slots, never
+// less than the longest workgroup; a CU that holds ONE workgroup of a two-per-CU configuration runs it ~1.5 x faster;
+// split-K adds the slab traffic (written, then read by the reduction; mostly cache hits).
+static double gx_cost(int32_t n_problems, const HgGemmProblem* pr, const GxCfg& c, bool has_ws) {
+    double work = 0, longest = 0, extra = 0;
+    int64_t blocks = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        const HgGemmProblem& q = pr[i];
+        int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;
+        if (has_ws && gx_may_split(q)) gx_plan(q.m, q.n, q.k, c, &sp, &ch);
+        const int64_t tiles = ((q.m + c.TM - 1) / c.TM) * ((q.n + c.TN - 1) / c.TN);
+        // (a K-slow operand -- a weight gradient's dY^T, a weight stored [k, n] -- costs the four-multiplier 128 x 128 tile
+        // more than the eight-multiplier ones: [256 x 128] over k = 1.97 M 864 against 793 us)
+        const double ts = (c.id == 256 && (q.trans_a || !q.trans_b)) ? 1.15 * c.t_step : c.t_step;
+        const double bt = ch * ts + c.t_fixed;
+        work += (double)(tiles * sp) * bt;
+        blocks += tiles * sp;
+        if (bt > longest) longest = bt;
+        if (sp > 1) extra += 2.0 * sp * (double)q.m * q.n * 4.0 / 6.0e6 + 4.0;
+    }
+    const int cus = c.slots == 512 ? 256 : c.slots;
+    double t = work / c.slots;
+    if (c.slots == 512 && blocks <= cus) t = 0.65 * longest;          // one workgroup per CU, alone
+    else if (blocks <= c.slots) t = longest;
+    else if (t < longest) t = longest;
+    return t + extra;
+}
+
+// tile id (64, 128, 256, 512, 513) the launch takes for these problems
+static int gx_choose(int32_t n_problems, const HgGemmProblem* pr, bool has_ws) {
+    int best = 64;
+    double best_t = 1e30;
+    for (const GxCfg& c : GX_CFGS) {
+        const double t = gx_cost(n_problems, pr, c, has_ws);
+        if (t < best_t) { best_t = t; best = c.id; }
     }
     return best;
+}
+
+extern "C" int32_t hg_gemm_x6_choose_tile(int32_t n_problems, const HgGemmProblem* pr, int32_t with_workspace) {
+    if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return 0;
+    return gx_choose(n_problems, pr, with_workspace != 0);
+}
+
+extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* pr, int32_t tile) {
+    if (n_problems <= 0 || n_problems > GX_MAXP || !pr) return 0;
+    const GxCfg& c = gx_cfg(tile != 0 ? tile : gx_choose(n_problems, pr, true));
+    size_t total = 0;
+    for (int i = 0; i < n_problems; ++i) {
+        int sp, ch;
+        gx_plan(pr[i].m, pr[i].n, pr[i].k, c, &sp, &ch);
+        if (sp > 1 && gx_may_split(pr[i])) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
+    }
+    return total;
 }
 
 extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int32_t tile, void* workspace, size_t workspace_bytes,
@@ -554,12 +613,8 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     GxBatch b;
     b.n = n_problems;
     const bool a_ks = pr[0].trans_a != 0, b_ks = pr[0].trans_b == 0;
-    int64_t tiles_big = 0, tiles_huge = 0;
-    bool deep = true;                       // every problem: few output tiles, long k (the split-K regime)
-    bool long_k = true;                     // every problem: k >= 1024 (a 128 x 128 tile's lower operand traffic pays)
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
-        deep = deep && q.m >= 128 && q.n >= 128 && ((q.m + 127) / 128) * ((q.n + 127) / 128) < 128 && q.k >= 16384 && !q.bias && !q.relu;
         if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || !q.b || !q.c) return EQH_ERR_ARG;
         if ((q.trans_a != 0) != a_ks || (q.trans_b == 0) != b_ks) return EQH_ERR_ARG;   // one operand layout per launch
         if (q.m >= (1ll << 31) - 256) return EQH_ERR_RANGE;
@@ -571,36 +626,16 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         if ((!a_ks && (q.k & 3)) || (a_ks && (q.m & 3)) || (!b_ks && (q.k & 3))) return EQH_ERR_ALIGN;
         if (!eqh_aligned16(q.a) || !eqh_aligned16(q.b) || !eqh_aligned16(q.c) || !eqh_aligned16(q.d) || !eqh_aligned16(q.bias))
             return EQH_ERR_ALIGN;
-        tiles_big += ((q.m + 127) / 128) * ((q.n + 63) / 64);
-        tiles_huge += ((q.m + 127) / 128) * ((q.n + 127) / 128);
-        long_k = long_k && q.k >= 1024 && q.n >= 128 && !q.mean_rows;
     }
-    // 128 x 128 tiles, one workgroup per CU: long-K products (a weight gradient over ~10^5-10^6 rows is split along k
-    // into hundreds of workgroups anyway: the largest tile has the least LDS traffic per MFMA, 142 against 103-124 TFLOP/s)
-    // ... and products with k >= 1024 and at least one such tile per CU: [31 k x 2176].[2176 x 256] 204 against 221 us
-    // (128 x 64) and 293 us (64 x 64); 4096^3 198 against 173 TFLOP/s
-    const int huge = tile == 256 || (tile == 0 && deep && workspace != nullptr) || (tile == 0 && long_k && tiles_huge >= 256);
-    // 128 x 64 tiles amortise the operand split better (from one tile per CU: [31 k x 256].[256 x 256] 33.6 against
-    // 39.3 us), 64 x 64 tiles fill the chip at this model's ~5 k-row batches
-    const int big = huge || tile == 128 || (tile == 0 && tiles_big >= 256);
-    // 128 x 256 / 256 x 128 tiles with EIGHT multiplying wavefronts (two per SIMD, one workgroup per CU): half the operand
-    // traffic per MFMA of the 128 x 64 tile and a second multiplier to fill each SIMD's MFMA pipe -- [246 k x 256].[256 x 256]
-    // 199 against 220 us, [1.97 M x 128].[128 x 256] 943 against 1122 us.  Taken when every product is wide (tall) enough
-    // to fill the tile and there is about a tile per CU; split-K products keep the 128 x 128 tile
-    bool fit_wide = true, fit_tall = true;
-    int64_t tiles_wide = 0, tiles_tall = 0;
-    for (int i = 0; i < n_problems; ++i) {
-        const HgGemmProblem& q = pr[i];
-        const int nw = (q.n + 255) / 256 * 256, nt = (q.n + 127) / 128 * 128;
-        fit_wide = fit_wide && q.n >= 224 && (nw - q.n) * 8 <= q.n;
-        fit_tall = fit_tall && q.n >= 96 && (nt - q.n) * 8 <= q.n && q.m >= 256;
-        tiles_wide += ((q.m + 127) / 128) * (nw / 256);
-        tiles_tall += ((q.m + 255) / 256) * (nt / 128);
-    }
-    const bool no_split = !(deep && workspace != nullptr);
-    const int wide = tile == 512 || (tile == 0 && no_split && fit_wide && tiles_wide >= 200);
-    const int tall = !wide && (tile == 513 || (tile == 0 && no_split && fit_tall && tiles_tall >= 200));
-    const int TM = tall ? 256 : ((big || wide) ? 128 : 64), TN = wide ? 256 : ((huge || tall) ? 128 : 64);
+    // the tile: 64 x 64 fills the chip at ~5 k-row batches; 128 x 64 amortises the operand split better; 128 x 128 (one
+    // workgroup per CU) has the least operand traffic per MFMA among the four-multiplier tiles and takes the deep split-K
+    // products; 128 x 256 / 256 x 128 run EIGHT multiplying wavefronts (two per SIMD): half the operand traffic of 128 x 64
+    // and a second multiplier to fill each SIMD's MFMA pipe -- [246 k x 256].[256 x 256] 199 against 220 us, [1.97 M x
+    // 128].[128 x 256] 943 against 1122 us, [256 x 128] over k = 1.97 M 793 against 864 us.  gx_cost estimates each.
+    const int id = tile != 0 ? tile : gx_choose(n_problems, pr, workspace != nullptr);
+    if (id != 64 && id != 128 && id != 256 && id != 512 && id != 513) return EQH_ERR_ARG;
+    const GxCfg& cfg = gx_cfg(id);
+    const int TM = cfg.TM, TN = cfg.TN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     int64_t first = 0;
     size_t ws_used = 0;
@@ -619,8 +654,8 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         p.tiles_mn = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
         int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;
         p.slab = nullptr;
-        if (!q.bias && !q.relu && !q.mean_rows) {
-            gx_plan(q.m, q.n, q.k, TM, TN, &sp, &ch);
+        if (gx_may_split(q)) {
+            gx_plan(q.m, q.n, q.k, cfg, &sp, &ch);
             if (sp > 1) {
                 const size_t need = (size_t)sp * (size_t)q.m * (size_t)q.n * sizeof(float);
                 if (!workspace || ws_used + need > workspace_bytes) {   // no room: one pass over the whole K
@@ -642,10 +677,11 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     b.total_tiles = (int)first;
     if (first == 0) return EQH_OK;
     int rc;
-    if (wide) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream);
-    else if (tall) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream);
-    else if (huge) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
-    else rc = big ? launch<2, 1, 2, 6>(b, a_ks, b_ks, stream) : launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
+    if (id == 512) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream);
+    else if (id == 513) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream);
+    else if (id == 256) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
+    else if (id == 128) rc = launch<2, 1, 2, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
+    else rc = launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);
     if (rc) return rc;
     // split-K problems: c = beta * d + sum of the slabs, in slab order (bitwise reproducible); beta * d with d == c and
     // beta == 1 is the accumulating form the weight gradients use

@@ -43,6 +43,7 @@ SIGNATURES = {
     "hg_small_mm_batch": (c_int32, [c_int32, ctypes.POINTER(HgSmallMM), c_void_p]),
     "hg_gemm_x6_workspace_bytes": (c_size_t, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32]),
     "hg_gemm_x6_batch": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32, c_void_p, c_size_t, c_void_p]),
+    "hg_gemm_x6_choose_tile": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32]),
     "eqh_version": (c_int32, []),
     "eqh_error_string": (c_char_p, [c_int32]),
     "hg_csr_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),

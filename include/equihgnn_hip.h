@@ -122,8 +122,8 @@ int hg_dense_batch_f32(int32_t n_problems, const HgDenseProblem* problems, void*
  *   trans_b != 0: b is [n, k] (row stride ldb) -- an nn.Linear weight used as x W^T;   trans_b == 0: b is [k, n]
  *   d: optional addend [m, n] (row stride ldd; may be c itself: accumulate), bias: optional [n], relu != 0: max(., 0).
  * n, the contiguous extents of a and b (k, or m for trans_a) and all row strides are multiples of 4 floats; pointers
- * 16-byte aligned.  Up to 8 problems with the same (trans_a, trans_b) share one launch.  tile: 0 = choose, 64, 128 or 256
- * (block tile 64 x 64, 128 x 64, 128 x 128).  Products with few output tiles and a long k (weight gradients: k = rows of the
+ * 16-byte aligned.  Up to 8 problems with the same (trans_a, trans_b) share one launch.  tile: 0 = choose, 64, 128, 256, 512
+ * or 513 (block tile 64 x 64, 128 x 64, 128 x 128, 128 x 256, 256 x 128).  Products with few output tiles and a long k (weight gradients: k = rows of the
  * batch) are split along k: partial tiles go to `workspace` (hg_gemm_x6_workspace_bytes; caller-owned, may be NULL: no
  * split) and are summed in a fixed order (d must then be NULL or c itself with beta = 1, and no bias / relu).  Bitwise
  * reproducible; capturable.
@@ -151,6 +151,9 @@ typedef struct HgGemmProblem {
     int32_t mean_rows;
 } HgGemmProblem;
 size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* problems, int32_t tile);
+/* the block tile hg_gemm_x6_batch takes for these problems with tile == 0 (64, 128, 256: 64 x 64, 128 x 64, 128 x 128;
+ * 512, 513: 128 x 256, 256 x 128 with eight multiplying wavefronts), from its cost estimate of the five configurations */
+int32_t hg_gemm_x6_choose_tile(int32_t n_problems, const HgGemmProblem* problems, int32_t with_workspace);
 int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* problems, int32_t tile, void* workspace, size_t workspace_bytes,
                      void* stream);
 
