@@ -575,7 +575,12 @@ static double gx_cost(int32_t n_problems, const HgGemmProblem* pr, const GxCfg& 
     double t = work / c.slots;
     if (c.slots == 512 && blocks <= cus) t = 0.65 * longest;          // one workgroup per CU, alone
     else if (blocks <= c.slots) t = longest;
-    else if (t < longest) t = longest;
+    else if (blocks <= 3 * c.slots) {                                 // a few rounds: whole ones ([15 k x 768]: 363 tiles of
+        const int64_t rounds = (blocks + c.slots - 1) / c.slots;      // 128 x 256 are two rounds, 46 against 42 us)
+        const double whole = rounds * (work / blocks);
+        if (whole > t) t = whole;
+    }
+    if (t < longest) t = longest;
     return t + extra;
 }
 
