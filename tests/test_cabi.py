@@ -90,3 +90,34 @@ def test_state_dict_matches_reference_names():
         method = str(case["meta_method"])
         m = models.MODELS[method](1, golden_args(method, int(case["meta_hidden"])))
         assert sorted(n for n, _ in m.named_parameters()) == sorted(str(n) for n in case["grad_names"])
+
+
+def test_gemm_x6_tile_choice_is_a_valid_configuration_and_sizes_its_workspace():
+    """hg_gemm_x6_choose_tile (the cost estimate behind tile = 0) on host only: a valid tile id for any shape, the big
+    configurations for the shapes they were built for, and hg_gemm_x6_workspace_bytes(tile = 0) equal to the chosen
+    configuration's own need (the launch re-derives the same choice)."""
+    import random
+
+    from equihgnn_amd import hip
+    L = hip.lib()
+    rng = random.Random(7)
+
+    def prob(m, n, k, ta=0, tb=1):
+        pr = (hip.HgGemmProblem * 1)()
+        q = pr[0]
+        q.m, q.n, q.k, q.trans_a, q.trans_b = m, n, k, ta, tb
+        return pr
+
+    for _ in range(300):
+        m, n, k = rng.choice([1, 77, 256, 4736, 31232, 250000, 1971840]), 4 * rng.randint(1, 4200), 4 * rng.randint(1, 20000)
+        ta = rng.randint(0, 1)
+        pr = prob(m if not ta else 4 * ((m + 3) // 4), n, k, ta, rng.randint(0, 1))
+        tile = L.hg_gemm_x6_choose_tile(1, pr, 1)
+        assert tile in (64, 128, 256, 512, 513), (m, n, k, tile)
+        assert L.hg_gemm_x6_workspace_bytes(1, pr, 0) == L.hg_gemm_x6_workspace_bytes(1, pr, tile)
+        assert L.hg_gemm_x6_choose_tile(1, pr, 0) in (64, 128, 256, 512, 513)
+    assert L.hg_gemm_x6_choose_tile(1, prob(245760, 256, 256), 1) == 512          # [246 k x 256].[256 x 256]: 128 x 256 tiles
+    assert L.hg_gemm_x6_choose_tile(1, prob(1971840, 128, 256, 0, 0), 1) == 513    # N = 128: 256 x 128
+    assert L.hg_gemm_x6_choose_tile(1, prob(77, 132, 36, 0, 0), 1) == 64
+    assert L.hg_gemm_x6_workspace_bytes(1, prob(256, 256, 245760, 1, 0), 0) > 0     # a deep weight gradient is split along k
+    assert L.hg_gemm_x6_workspace_bytes(1, prob(245760, 256, 256), 0) == 0
