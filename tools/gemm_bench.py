@@ -27,7 +27,10 @@ SHAPES = [("c2 conv fwd x W^T", 4736, 256, 256, 0, 1), ("c2 conv dgrad dY W", 47
           ("c5 frame wgrad", 256, 128, 1971840, 1, 0), ("c3 dgrad K=16384", 2312, 256, 16384, 0, 0),
           ("c3 wgrad N=16384", 256, 16384, 2312, 1, 0),
           ("c5 fc", 245760, 256, 256, 0, 1), ("c5 fc dgrad", 245760, 256, 256, 0, 0), ("c5 wgrad", 256, 256, 245760, 1, 0),
-          ("square 4096", 4096, 4096, 4096, 0, 1)]
+          ("square 4096", 4096, 4096, 4096, 0, 1),
+          ("c4 egnn ab dgrad", 31232, 256, 2176, 0, 0), ("c4 egnn ab wgrad", 2176, 256, 31232, 1, 0),
+          ("c5 node fwd", 15488, 256, 256, 0, 1), ("c5 ffn up", 15488, 1024, 512, 0, 1), ("c5 qkv", 15488, 768, 256, 0, 1),
+          ("c5 mid wgrad", 1024, 512, 15488, 1, 0)]
 
 
 def timeit(fn, reps):
@@ -68,7 +71,7 @@ def main():
         fl = 2.0 * M * N * K
         reps = max(3, min(50, int(2e10 / fl)))
         variants = {"lib": lambda: torch.mm(Al, Bl, out=out)}
-        for tile in (64, 128, 256):
+        for tile in (0, 64, 128, 256, 512, 513):      # 0: the launch's own choice (hg_gemm_x6_choose_tile)
             def f(tile=tile):
                 ops.GEMM_TILE = tile
                 ops.gemm(A, B, trans_a=bool(ta), trans_b=bool(tb), out=out)
