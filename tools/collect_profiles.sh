@@ -16,19 +16,19 @@ elif [ "$1" = 1 ]; then
   # the headline line, then the same command under the kernel trace (stats CSV + the order of one replayed step)
   timeout -k 10 500 python bench.py > $O/${R}_bench.json 2> $O/bench.err || exit 1
   tail -c 600 $O/${R}_bench.json
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python3 bench.py --no-cpu-baseline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2> $O/rocprof.err || exit 1
-  cp "$(find /tmp/prof_main -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python3 bench.py --no-cpu-baseline --no-pipeline --c4-steps 0 > $O/${R}_bench_with_roofline_probes_under_rocprof.json 2> $O/rocprof.err || exit 1
+  cp "$(find /tmp/prof_main -name '*kernel_stats.csv' | head -1)" $O/${R}_kernel_stats_with_roofline_probes.csv
   # kernel order of one replayed step: a trace of the step alone (no roofline probes after it)
   # and per-kernel averages of the training step ALONE (95 replays + 2 set-up steps; the CSV above also holds the
   # roofline probes, which launch the same scatter kernels at the saturating size)
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_step_only_under_rocprof.json 2>> $O/rocprof.err || exit 1
-  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_step_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
   python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
 elif [ "$1" = 1b ]; then
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_step_only_under_rocprof.json 2>> $O/rocprof.err || exit 1
-  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_step_kernel_stats.csv
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
   python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
 elif [ "$1" = 2 ]; then
   for spec in "egnn_equihnns 1024 pcqm" "mhnns 256 qm9" "mhnn 256 qm9" "mhnnm 256 qm9" "egnn_equihnn 256 qm9" "egnn_equihnnm 256 qm9"; do
