@@ -5,15 +5,13 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
-
 import torch
 
 from .. import hip
-from ._base import (_acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
+from ._base import (LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
 from .aggregate import (CSR, _segment_reduce)
-from ._base import LINEAR_PARAMS
-from .grads import _linear_weight_grad, colsum
-from .products import USE_X6, gemm, mm_nn
+from .products import (USE_X6, gemm, mm_nn)
+from .grads import (_linear_weight_grad, colsum)
 
 
 def _dropout_seed(device, p):

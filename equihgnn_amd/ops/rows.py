@@ -5,7 +5,6 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
-
 import torch
 
 from .. import hip
