@@ -256,8 +256,10 @@ class BucketedLoader:
                     self.collated += len(b)
                     if cuda:
                         with torch.cuda.stream(side):
-                            if ent[3] is not None:
-                                side.wait_event(ent[3])      # the trainer has taken the device buffer's previous content
+                            if ent[3] is not None and not ent[3].query():
+                                # the trainer has taken the device buffer's previous content (a host-side query first: the
+                                # ring is prefetch + 3 deep, so the event has almost always fired and no wait enters the stream)
+                                side.wait_event(ent[3])
                             ent[2]._flat.copy_(ent[0]._flat, non_blocking=True)
                             ent[2].num_real_graphs = getattr(ent[0], "num_real_graphs", None)
                             ev = torch.cuda.Event()
@@ -326,7 +328,8 @@ class BucketedLoader:
                 if not cuda:
                     yield ent[0].to(self.device)
                     continue
-                torch.cuda.current_stream(self.device).wait_event(ent[1])
+                if not ent[1].query():        # (its copy was issued `prefetch` batches ago: normally complete -- no stream wait)
+                    torch.cuda.current_stream(self.device).wait_event(ent[1])
                 prev = ent
                 yield fresh(ent[2])
         finally:
