@@ -68,9 +68,11 @@ def parse():
     p.add_argument("--pool", type=int, default=8, help="distinct pre-collated batches per rank")
     p.add_argument("--c4-steps", type=int, default=10,
                    help="timed steps of the strong-scaling BASELINE config 4 leg (PCQM-like, global batch 1024); 0 = skip")
-    p.add_argument("--blocks", type=int, default=3,
+    p.add_argument("--blocks", type=int, default=15,
                    help="timed blocks of --steps steps each (every block bracketed by barrier + synchronize); the line "
-                        "reports the MEDIAN block, so that one outlier in a ~40 ms window does not move the headline")
+                        "reports the MEDIAN block with min / max / spread, so that 1-2 %% steps are resolvable")
+    p.add_argument("--no-collective-probe", action="store_true",
+                   help="skip `collective_probe` (N=1 only: the multi-rank step driven through a one-rank RCCL group)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pipeline", action="store_true", help="skip the loader-fed run (`pipeline` in the JSON line)")
     p.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -89,6 +91,31 @@ def parse():
     p.add_argument("--only-saturation", action="store_true",
                    help="run just the cache-exceeding scatter probe (used for the rocprofv3 --pmc passes)")
     return p.parse_args()
+
+
+class ClockProbe:
+    """Shader clock the chip holds, read right after a timed block (outside the timed region): eqh_clock_probe, a one-
+    wavefront kernel that brackets a 20 us wait with s_memtime / s_memrealtime (MI355X_MICROARCH.md, DVFS give-back 6)."""
+
+    def __init__(self, dev):
+        from equihgnn_amd import hip
+        self.lib = hip.lib()
+        self.dev = dev
+        self.out = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.khz = int(self.lib.eqh_wall_clock_khz())
+
+    def mhz(self):
+        from equihgnn_amd import hip, ops
+        hip.check(self.lib.eqh_clock_probe(ops._ptr(self.out), 20, ops._stream(self.dev)), "eqh_clock_probe")
+        cyc, ticks = (int(v) for v in self.out.tolist())
+        return round(cyc / max(ticks, 1) * self.khz / 1e3, 0)
+
+
+def block_stats(ms):
+    """min / median / max of the timed blocks (ms per step) and their spread (max - min) / median."""
+    v = sorted(ms)
+    med = v[len(v) // 2]
+    return {"min": v[0], "median": med, "max": v[-1], "spread_pct": round((v[-1] - v[0]) / med * 100, 2), "blocks": len(v)}
 
 
 def seg_reduce_bytes(nnz, n_out, C, has_idx, has_ptr, has_w, n_src):
@@ -575,7 +602,9 @@ def main():
         return
     use_graph = (not a.no_graph) and a.method not in _EAGER_METHODS
 
-    def timed_run(method, batch, flavour, steps, warmup, cfg_id):
+    probe = ClockProbe(dev)
+
+    def timed_run(method, batch, flavour, steps, warmup, cfg_id, trainer_kw=None, blocks=None):
         """K timed steps of one workload on this rank (barrier + synchronize on both sides, MAX over ranks)."""
         ns = default_args(method=method, batch_size=batch)
         torch.manual_seed(0)
@@ -594,7 +623,7 @@ def main():
             batches = [pad_batch(b, *tgt).packed().to(dev) for b in host]   # one staging buffer per batch
             for b in batches:
                 b.num_real_graphs = batch
-            trainer = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd)
+            trainer = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd, **(trainer_kw or {}))
             # set-up, not warm-up: the eager bootstrap step (lays out the flat buffers, tunes unseen GEMM shapes)
             # and the capture step, so that the W warm-up and K timed steps below are all graph replays whatever W is
             for i in range(2):
@@ -609,8 +638,8 @@ def main():
             trainer.on_batch = fresh
         for i in range(warmup):
             trainer.step(batches[i % a.pool])
-        els = []
-        for blk in range(max(1, a.blocks)):
+        els, clocks = [], []
+        for blk in range(max(1, blocks or a.blocks)):
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
@@ -627,26 +656,69 @@ def main():
             if world > 1:
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's clock, per block
             els.append(float(t.item()))
+            clocks.append(probe.mhz())        # after the block's clock was read: not part of any timed region
         return {"el": sorted(els)[len(els) // 2], "els": els, "loss": float(loss), "host": host, "batches": batches,
-                "model": model, "trainer": trainer, "args": ns}
+                "model": model, "trainer": trainer, "args": ns, "clocks": clocks}
 
     run = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2)
     el, loss, host_batches, batches, model = run["el"], run["loss"], run["host"], run["batches"], run["model"]
-    block_ms = [round(e / a.steps * 1e3, 3) for e in run["els"]]
+    block_ms = [round(e / a.steps * 1e3, 4) for e in run["els"]]
+    block_clocks = run["clocks"]
     run_args = run["args"]
+    mode = getattr(run["trainer"], "collective_mode", "none")
+    mode_err = getattr(run["trainer"], "capture_error", None)
     observed_world = dist.get_world_size() if world > 1 else 1      # what the (RCCL) process group reports
     assert observed_world == a.gpus, (observed_world, a.gpus)
+
+    # The multi-rank step on this one GPU (N=1 only): a ONE-rank RCCL process group drives GraphedTrainStep's collective
+    # path -- broadcast, flat-gradient all-reduce, 1 / world scale -- once with the all-reduce captured into the step's graph
+    # and once in the split form (graph A -> eager all-reduce -> graph B), same workload and batches as the headline.
+    coll = None
+    if world == 1 and use_graph and not a.no_collective_probe:
+        import socket
+        coll = {"what": "the headline step through a 1-rank 'nccl' (RCCL) group with force_collective: all-reduce inside the "
+                        "step's one hipGraph (in_graph) and eagerly between two hipGraphs (two_graph)",
+                "single_rank_ms_per_step": round(el / a.steps * 1e3, 4)}
+        try:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            try:
+                ref = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2, blocks=min(a.blocks, 7),
+                                trainer_kw=dict(collective=False))
+                coll["single_rank_again_ms_per_step"] = round(ref["el"] / a.steps * 1e3, 4)
+                del ref
+                for label, kw in (("in_graph", dict(force_collective=True)),
+                                  ("two_graph", dict(force_collective=True, graph_collective=False))):
+                    r = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2, trainer_kw=kw, blocks=min(a.blocks, 7))
+                    coll[f"{label}_ms_per_step"] = round(r["el"] / a.steps * 1e3, 4)
+                    coll[f"{label}_mode"] = r["trainer"].collective_mode
+                    if r["trainer"].capture_error:
+                        coll[f"{label}_capture_error"] = r["trainer"].capture_error[:300]
+                    coll[f"{label}_final_loss"] = round(r["loss"], 6)
+                    r["trainer"].close()
+                    del r
+                coll["two_graph_over_single"] = round(coll["two_graph_ms_per_step"] / coll["single_rank_again_ms_per_step"], 4)
+                coll["in_graph_over_single"] = round(coll["in_graph_ms_per_step"] / coll["single_rank_again_ms_per_step"], 4)
+            finally:
+                dist.destroy_process_group()
+        except Exception as exc:     # (an RCCL that cannot initialise on this box must not cost the headline)
+            coll["error"] = f"{type(exc).__name__}: {exc}"[:400]
 
     # BASELINE config 4 as a STRONG-scaling point: PCQM4Mv2-like molecules, global batch 1024 split over the ranks
     # (SURVEY.md §8d), beside the weak-scaling headline above.  Reported inside the same JSON line.
     strong = None
     if a.method == "egnn_equihnns" and a.flavour == "qm9" and a.c4_steps > 0 and 1024 % world == 0:
         del run
-        r4 = timed_run("egnn_equihnns", 1024 // world, "pcqm", a.c4_steps, 2, 4)
+        r4 = timed_run("egnn_equihnns", 1024 // world, "pcqm", a.c4_steps, 2, 4, blocks=min(a.blocks, 5))
         strong = {"workload": "PCQM4Mv2-like synthetic molecules, --method egnn_equihnns, GLOBAL batch 1024 "
                               f"({1024 // world}/rank), hidden 256", "scaling": "strong", "n_gpus": observed_world,
                   "steps": a.c4_steps, "value": round(1024 * a.c4_steps / r4["el"], 1), "unit": "molecules/s",
-                  "ms_per_step": round(r4["el"] / a.c4_steps * 1e3, 3), "final_loss": round(r4["loss"], 6)}
+                  "ms_per_step": round(r4["el"] / a.c4_steps * 1e3, 3), "final_loss": round(r4["loss"], 6),
+                  "timed_blocks": block_stats([round(e / a.c4_steps * 1e3, 4) for e in r4["els"]])}
         del r4
 
     result = None
@@ -661,6 +733,9 @@ def main():
             "n_gpus": observed_world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(el / a.steps * 1e3, 3),
             "timed_blocks_ms_per_step": block_ms,        # every block = --steps steps between barrier + synchronize; value = median
+            "timed_blocks": block_stats(block_ms),
+            "shader_clock_mhz": {"after_each_block": block_clocks, "min": min(block_clocks), "max": max(block_clocks),
+                                 "how": "eqh_clock_probe right after each timed block: d s_memtime / d s_memrealtime x 100 MHz"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{a.flavour}-like synthetic molecules, --method {a.method}, "
@@ -670,12 +745,16 @@ def main():
                        "avg_nodes": round(n_nodes, 1), "avg_incidences": round(nnz, 1),
                        "parallelism": f"dp{world}",
                        "launch": "hipGraph replay (padded static shapes)" if use_graph else "eager",
-                       "collective": (f"one flat-gradient all-reduce per step, backend {dist.get_backend()}"
+                       "collective": (f"one flat-gradient all-reduce per step, backend {dist.get_backend()}, "
+                                      + {"in_graph": "captured as a node of the step's one hipGraph",
+                                         "split": "eager between two hipGraphs" + (f" (in-graph capture failed: {mode_err})" if mode_err else "")}.get(mode, mode)
                                       if world > 1 else "none (single rank)")},
             "final_loss": round(float(loss), 6),
         }
         if strong is not None:
             result["strong_scaling_c4"] = strong
+        if coll is not None:
+            result["collective_probe"] = coll
         if not a.no_roofline and use_graph:
             per, floor = measure_in_graph(a.method, a.batch, a.flavour, dev, a.timeline_replays)
             names = SCATTER_KERNELS + (FRAME_KERNELS if a.method == "faformer_equihnns" else ())

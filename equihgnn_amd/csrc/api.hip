@@ -7,7 +7,7 @@
 
 namespace {
 
-constexpr int MANY = 48;  // descriptors per batched launch (kernel-argument struct of 48 x 72 bytes + group starts: 3.7 KB of the 4 KB limit)
+constexpr int MANY = 48;  // descriptors per batched launch (kernel-argument struct of 48 x 80 bytes + group starts: 4040 of the 4096-byte limit)
 
 // Descriptors that add into the SAME destination form a group (kept in issue order): one block owns a
 // 64-element chunk of the destination and runs the group's reductions one after the other, so the
@@ -17,6 +17,7 @@ struct ReduceBatch {
     int g_start[MANY + 1];  // group g = descriptors [g_start[g], g_start[g+1])
     int n_groups;
 };
+static_assert(sizeof(ReduceBatch) <= 4096, "ReduceBatch is passed by value: it must fit the 4 KB kernel-argument segment");
 
 __global__ void __launch_bounds__(1024) eqh_k_reduce_many(ReduceBatch b) {
     __shared__ float s_part[1024];
@@ -174,6 +175,33 @@ extern "C" int eqh_stamp(void* slot, void* stream_) {
     if (!slot) return EQH_ERR_ARG;
     hipLaunchKernelGGL(eqh_k_stamp, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_),
                        static_cast<unsigned long long*>(slot));
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+// Shader clock the chip holds right now: one wavefront brackets a ~spin_us wait on the constant-rate clock with the
+// shader-cycle counter (s_memtime) and the 100 MHz real-time counter (s_memrealtime); out = {d cycles, d ticks}.
+namespace {
+__global__ void eqh_k_clock_probe(unsigned long long* out, unsigned long long spin_ticks) {
+    if (threadIdx.x != 0) return;
+    unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long r1 = r0;
+    while (r1 - r0 < spin_ticks) r1 = __builtin_amdgcn_s_memrealtime();     // every wave leaves after spin_ticks
+    unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    r1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+}
+}  // namespace
+
+extern "C" int eqh_clock_probe(void* out, int32_t spin_us, void* stream_) {
+    if (!out || spin_us < 1 || spin_us > 10000) return EQH_ERR_ARG;
+    int64_t khz = 100000;
+    int dev = 0, k = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&k, hipDeviceAttributeWallClockRate, dev) == hipSuccess && k > 0)
+        khz = k;
+    hipLaunchKernelGGL(eqh_k_clock_probe, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                       static_cast<unsigned long long*>(out), (unsigned long long)(khz * spin_us / 1000));
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

@@ -537,7 +537,7 @@ static inline void gx_plan(int64_t m, int n, int k, const GxCfg& c, int* splits,
     const int64_t tiles = ((m + c.TM - 1) / c.TM) * ((n + c.TN - 1) / c.TN);
     const int steps = (k + GX_BK - 1) / GX_BK;
     int sp = 1;
-    if (tiles < c.slots / 2 && steps >= 64) {
+    if (tiles > 0 && tiles < c.slots / 2 && steps >= 64) {     // (an empty problem, m == 0, has no tiles: no plan)
         const int64_t want = (2 * c.slots + tiles - 1) / tiles;   // two rounds of workgroups in all
         sp = (int)(want < steps / 16 ? want : steps / 16);        // at least 16 steps per split
         if (sp < 1) sp = 1;
@@ -549,7 +549,11 @@ static inline void gx_plan(int64_t m, int n, int k, const GxCfg& c, int* splits,
     *chunk_steps = ch;
 }
 
-static inline bool gx_may_split(const HgGemmProblem& q) { return !q.bias && !q.relu && !q.mean_rows; }
+// split-K sums slabs into c: only the plain product (d absent) or the accumulating form (d == c, beta == 1) can take it;
+// the plan, the cost model, the workspace query and the launch all ask this one predicate
+static inline bool gx_may_split(const HgGemmProblem& q) {
+    return q.m > 0 && !q.bias && !q.relu && !q.mean_rows && (q.d == nullptr || (q.d == q.c && q.beta == 1.f));
+}
 
 // Estimated time of a launch with configuration c (microseconds): the workgroups' times summed over the slots, never
 // less than the longest workgroup; a CU that holds ONE workgroup of a two-per-CU configuration runs it ~1.5 x faster;
@@ -559,6 +563,7 @@ static double gx_cost(int32_t n_problems, const HgGemmProblem* pr, const GxCfg& 
     int64_t blocks = 0;
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
+        if (q.m <= 0) continue;                                   // an empty problem costs nothing
         int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;
         if (has_ws && gx_may_split(q)) gx_plan(q.m, q.n, q.k, c, &sp, &ch);
         const int64_t tiles = ((q.m + c.TM - 1) / c.TM) * ((q.n + c.TN - 1) / c.TN);
@@ -606,8 +611,9 @@ extern "C" size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmPro
     size_t total = 0;
     for (int i = 0; i < n_problems; ++i) {
         int sp, ch;
+        if (!gx_may_split(pr[i])) continue;
         gx_plan(pr[i].m, pr[i].n, pr[i].k, c, &sp, &ch);
-        if (sp > 1 && gx_may_split(pr[i])) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
+        if (sp > 1) total += (size_t)sp * (size_t)pr[i].m * (size_t)pr[i].n * sizeof(float);
     }
     return total;
 }
@@ -694,8 +700,7 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         const GxProb& p = b.p[i];
         if (!p.slab) continue;
         const int sp = p.n_tiles / p.tiles_mn;
-        const bool acc = p.D == p.C && p.beta == 1.0f;
-        if (p.D && !acc) return EQH_ERR_ARG;                   // (split-K with a separate addend is not needed by the models)
+        const bool acc = p.D == p.C && p.beta == 1.0f;           // (gx_may_split admits no other addend)
         rc = eqh_reduce_slabs2d_async(p.slab, sp, p.M, p.N, p.C, p.ldc, acc ? 1 : 0, stream);
         if (rc) return rc;
     }

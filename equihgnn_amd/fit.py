@@ -203,6 +203,10 @@ class BucketedLoader:
         across the epoch boundary -- with a queue of its own the new epoch would refill ring buffers that still wait,
         unconsumed, in the old one."""
         import time
+        # planning advances the shuffle epoch (and may raise the envelope / fix the ladder): remember the state before it,
+        # so that an epoch that was started AHEAD and is never consumed (close()) does not skip a permutation -- the
+        # sequence of epochs must not depend on lookahead (DistributedSampler.set_epoch semantics)
+        undo = (self.epoch, getattr(self, "_envelope", None), getattr(self, "_rungs", None))
         batches, tgts = self.plan()
         ring = self._ring               # (pinning host memory costs milliseconds per buffer: allocate once per shape)
         if q is None:
@@ -281,7 +285,7 @@ class BucketedLoader:
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
-        return {"q": q, "th": th, "stop": stop, "cuda": cuda, "adopted": adopted}
+        return {"q": q, "th": th, "stop": stop, "cuda": cuda, "adopted": adopted, "undo": undo}
 
     def close(self):
         """Stop a prefetch thread that was started ahead for an epoch that will not be consumed."""
@@ -289,6 +293,13 @@ class BucketedLoader:
         if pend is not None:
             pend["stop"].set()
             pend["th"].join()
+            if not pend["adopted"].is_set():       # planned, never consumed: the next epoch is this one again
+                self.epoch, env, rungs = pend["undo"]
+                for name, val in (("_envelope", env), ("_rungs", rungs)):
+                    if val is None:
+                        self.__dict__.pop(name, None)
+                    else:
+                        setattr(self, name, val)
 
     def __iter__(self):
         pend, self._pending = getattr(self, "_pending", None), None
@@ -337,6 +348,12 @@ class BucketedLoader:
             # producer, which may be blocked on a full queue holding ring entries the next __iter__ shares
             if not done:
                 stop.set()
+                if prev is not None and cuda:
+                    # the consumer left with the last yielded device buffer possibly still being read by kernels it
+                    # enqueued: record that point, so the next producer waits for it before refilling the buffer
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    prev[3] = ev
             th.join()                   # (a finished producer has also started the next epoch by now: see _start_epoch)
             if not done:
                 self.close()            # (an epoch started ahead of an abandoned one is abandoned too)

@@ -155,6 +155,7 @@ SIGNATURES = {
     "hg_dense_batch_f32": (c_int32, [c_int32, ctypes.POINTER(HgDenseProblem), c_void_p]),
     "eqh_stamp": (c_int32, [c_void_p, c_void_p]),
     "eqh_wall_clock_khz": (c_int64, []),
+    "eqh_clock_probe": (c_int32, [c_void_p, c_int32, c_void_p]),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

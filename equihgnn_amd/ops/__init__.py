@@ -41,7 +41,7 @@ from .products import (  # noqa: F401
 from .grads import (  # noqa: F401
     GradFan, _FanSource, fanout, WGRAD_ON_SIDE_STREAM, _WGRAD_STREAMS, wgrad_stream, join_wgrad_stream,
     defer_begin, wgrad_batch, colsum_batch, defer_flush, copy_many, colsum, USE_WGRAD_KERNEL, DEFER_WGRAD,
-    _wgrad_shape_ok, _wgrad_ok, _wgrad_deferred, wgrad, _linear_weight_grad, MERGED_SCRATCH, _merged_acc,
+    _wgrad_shape_ok, _wgrad_ok, _wgrad_deferred, wgrad, _linear_weight_grad, MergedScratch, _merged_acc,
 )
 from .linears import (  # noqa: F401
     _MergedWeight, _MergedWeights, merged_weights, merged_weight, _Linear, _Linear2, _LinearAddC, linear, linear2,

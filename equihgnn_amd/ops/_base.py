@@ -132,7 +132,7 @@ def _rows_ld(t):
     return t, t.shape[-1]
 
 
-_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": [], "merged": [], "zslab": None}
+_DEFER = {"active": False, "keep": [], "wgrad": [], "colsum": [], "merged": [], "zslab": None, "scratch": None}
 
 
 def _workspace(nbytes, device):

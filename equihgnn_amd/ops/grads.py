@@ -61,14 +61,46 @@ def join_wgrad_stream(device):
         torch.cuda.current_stream(device).wait_stream(wgrad_stream(device))
 
 
-def defer_begin(device):
+class MergedScratch:
+    """Persistent accumulators of the merged weights (ops.merged_weight) for ONE owner -- a GraphedTrainStep: carved in
+    call order from one buffer that lives across steps and is cleared by the update kernel (eqh_adam_step's zero_also)
+    instead of a fresh zero-filled slab, i.e. a fill launch, per step.  The buffer's address is baked into the owner's
+    captured graphs, so it may grow only until ``freeze()`` (the owner's first capture); after that running out of room
+    is an error, never a reallocation."""
+
+    def __init__(self):
+        self.buf, self.cur, self.frozen = None, 0, False
+
+    def freeze(self):
+        self.frozen = True
+
+    def take(self, n, device):
+        need = self.cur + (n + 63) // 64 * 64
+        if self.buf is None or self.buf.numel() < need:
+            if self.frozen or torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("merged-weight scratch of a captured trainer cannot grow (it is part of the graph)")
+            old = self.buf
+            self.buf = torch.zeros(max(2 * need, 1 << 18), dtype=torch.float32, device=device)
+            if old is not None:
+                self.buf[:old.numel()].copy_(old)
+        assert self.buf.device == torch.device(device), "one MergedScratch per device"
+        out = self.buf[self.cur:self.cur + n]
+        self.cur = need
+        return out
+
+
+def defer_begin(device, scratch=None):
     """Start recording the accumulating gradient reductions issued on the current stream of ``device``
-    (eqh_defer_begin); they all run in one launch at defer_flush()."""
+    (eqh_defer_begin); they all run in one launch at defer_flush().  ``scratch``: the caller's MergedScratch for the
+    accumulators of merged weights during this window (the caller keeps it clear); without one they come from a fresh
+    zero-filled slab per window."""
     hip.check(hip.lib().eqh_defer_begin(_stream(device)), "eqh_defer_begin")
     _DEFER["active"] = True
     _DEFER["merged"] = []       # (a window that ended in an exception must not leak its records into this one)
     _DEFER["zslab"] = None
-    MERGED_SCRATCH["cur"] = 0
+    _DEFER["scratch"] = scratch
+    if scratch is not None:
+        scratch.cur = 0
 
 
 def wgrad_batch(entries):
@@ -167,6 +199,7 @@ def defer_flush(device):
         colsum_batch(sums)
     finally:
         _DEFER["active"] = False
+        _DEFER["scratch"] = None      # the window is over: a later window of another caller must not carve from this one
         hip.check(hip.lib().eqh_defer_flush(_stream(device)), "eqh_defer_flush")
         _DEFER["keep"].clear()
     # merged weights (ops.merged_weight): their accumulated gradients are complete now; one backward through each
@@ -317,28 +350,14 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
     return dw
 
 
-# Persistent scratch for the merged weights' accumulators: with MERGED_SCRATCH["static"] (set by the graphed trainer) the
-# accumulators are carved from ONE buffer that lives across steps and is cleared by the update kernel (eqh_adam_step's
-# zero_also), instead of a fresh zero-filled slab -- a fill launch -- per step.
-MERGED_SCRATCH = {"buf": None, "cur": 0, "static": False}
-
-
 def _merged_acc(shape, device):
-    """A zeroed accumulator for a merged weight: carved from the persistent scratch (graphed trainer) or from one
-    zero-filled slab per deferral window (one fill kernel for all merged weights of a step)."""
+    """A zeroed accumulator for a merged weight: carved from the window owner's persistent MergedScratch (graphed
+    trainer, defer_begin(scratch=...)) or from one zero-filled slab per deferral window (one fill kernel for all merged
+    weights of a step)."""
     n = shape[0] * shape[1]
-    ms = MERGED_SCRATCH
-    if ms["static"]:
-        need = ms["cur"] + (n + 63) // 64 * 64
-        if ms["buf"] is None or ms["buf"].numel() < need or ms["buf"].device != device:
-            assert not torch.cuda.is_current_stream_capturing(), "merged-weight scratch must exist before graph capture"
-            old = ms["buf"]
-            ms["buf"] = torch.zeros(max(2 * need, 1 << 18), dtype=torch.float32, device=device)
-            if old is not None and old.device == device:
-                ms["buf"][:old.numel()].copy_(old)
-        out = ms["buf"][ms["cur"]:ms["cur"] + n].view(shape)
-        ms["cur"] = need
-        return out
+    ms = _DEFER.get("scratch")
+    if ms is not None:
+        return ms.take(n, device).view(shape)
     slab = _DEFER.get("zslab")
     if slab is None or slab[1] + n > slab[0].numel() or slab[0].device != device:
         slab = [torch.zeros(max(4 * n, 1 << 18), dtype=torch.float32, device=device), 0]

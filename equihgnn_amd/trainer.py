@@ -107,6 +107,7 @@ class FlatAdam(torch.optim.Optimizer):
         super().__init__([param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.grad_scale = 1.0
         self.zero_grad_in_step = False      # clear the flat gradient inside the update kernel (GraphedTrainStep)
+        self.zero_also = None               # callable -> a second buffer the update clears (the owner's MergedScratch)
         self._lr_dev = None
         st = self.state[param]
         st["exp_avg"] = torch.zeros_like(param.data)
@@ -130,7 +131,7 @@ class FlatAdam(torch.optim.Optimizer):
         p = g["params"][0]
         st = self.state[p]
         b1, b2 = g["betas"]
-        zs = ops.MERGED_SCRATCH["buf"] if (self.zero_grad_in_step and ops.MERGED_SCRATCH["static"]) else None
+        zs = self.zero_also() if (self.zero_grad_in_step and self.zero_also is not None) else None
         hip.check(hip.lib().eqh_adam_step(ops._ptr(p.data), ops._ptr(p.grad), ops._ptr(st["exp_avg"]),
                                           ops._ptr(st["exp_avg_sq"]), p.numel(), ops._ptr(st["lr"]), b1, b2, g["eps"],
                                           g["weight_decay"], self.grad_scale, ops._ptr(st["step_block"]),
@@ -143,9 +144,12 @@ class GraphedTrainStep:
     """TrainStep with the launch-bound part captured in hipGraphs.
 
     forward + MSE + backward (≈700 kernel launches for egnn_equihnns, including the per-batch index
-    build) are captured ONCE per static shape bucket and replayed; the gradient all-reduce runs
-    eagerly between the two graphs (RCCL on its own terms), and the fused Adam update is a second
-    graph.  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
+    build), the gradient all-reduce and the fused Adam update are captured ONCE per static shape bucket
+    as ONE hipGraph and replayed: with the "nccl" backend (RCCL) the collective is a node of that graph
+    (``collective_mode == "in_graph"``; RCCL kernels are stream-capturable), so a multi-rank step is one
+    graph launch exactly like the single-rank one.  Where the collective cannot be captured (gloo, or
+    a capture that RCCL refuses) the step falls back to graph A -> eager all-reduce -> graph B
+    (``"split"``).  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
     without batch statistics); the loss is taken over the real molecules only.
 
     Parameters live in ONE flat buffer (``pflat``; every ``nn.Parameter`` is a view into it) and so
@@ -157,14 +161,25 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model: nn.Module, lr: float = 1e-4, weight_decay: float = 0.0,
-                 broadcast_from_rank0: bool = True, collective: bool = True, keep_grads: bool = False):
+                 broadcast_from_rank0: bool = True, collective: bool = True, keep_grads: bool = False,
+                 force_collective: bool = False, graph_collective: bool = True):
         """``collective=False``: a rank-local trainer inside a multi-rank job (no broadcast, no all-reduce) -- what a
         measurement on ONE rank needs while the other ranks wait at a barrier.  ``keep_grads``: leave the gradients of the
         last step readable in ``p.grad`` after ``step()`` (tests); by default the update kernel clears the flat gradient
-        buffer as it consumes it -- optimizer.zero_grad() without the fill launch at the head of every replayed step."""
+        buffer as it consumes it -- optimizer.zero_grad() without the fill launch at the head of every replayed step.
+        ``force_collective``: take the multi-rank code path (broadcasts, all-reduce, 1 / world scaling) even when the
+        process group has ONE rank -- how the path is exercised on a one-GPU box.  ``graph_collective=False``: never
+        capture the collective (always graph A -> eager all-reduce -> graph B)."""
         self.model, self.lr, self.wd = model, lr, weight_decay
         self.collective = collective
         self.keep_grads = keep_grads
+        self.force_collective = bool(force_collective) and collective and dist.is_available() and dist.is_initialized()
+        self.graph_collective = graph_collective
+        self.collective_mode = "none"       # "none" | "in_graph" | "split": what the captured steps do (set by _capture)
+        self.capture_error = None           # why an in-graph capture fell back to "split", if it did
+        from . import ops
+        self.scratch = ops.MergedScratch()  # accumulators of the merged weights: owned here, part of the captured graphs
+        self.bflat = []                     # flat buffers (one per dtype) behind the model's buffers (multi-rank BatchNorm)
         self.live = None
         self.opt = None
         self.slots = {}
@@ -176,17 +191,42 @@ class GraphedTrainStep:
         self.other_slots = []
         self.n_w = 0
         self.fused_head = "head" in inspect.signature(model.forward).parameters
-        self._has_buffers = self._w() > 1 and any(True for _ in model.buffers())
+        self._has_buffers = self._multi() and any(True for _ in model.buffers())
         for mod in model.modules():   # padded (null) incidences would enter the batch statistics of a per-incidence norm
             if type(mod).__name__ == "MLP" and any(isinstance(n, nn.BatchNorm1d) for n in mod.normalizations):
                 raise NotImplementedError("GraphedTrainStep pads batches to static shapes; BatchNorm inside the "
                                           "per-incidence MLPs (--normalization bn) would count the padding -- use TrainStep")
-        if broadcast_from_rank0 and self._w() > 1:
-            for t in list(model.parameters()) + list(model.buffers()):
+        if broadcast_from_rank0 and self._multi():
+            for t in list(model.parameters()):
                 dist.broadcast(t.data, src=0)
+            self._flatten_buffers()
+            self.sync_buffers()
 
     def _w(self) -> int:
         return _world() if self.collective else 1
+
+    def _multi(self) -> bool:
+        """Whether this trainer takes the multi-rank path (collectives, 1 / world gradient scale)."""
+        return self._w() > 1 or self.force_collective
+
+    def _flatten_buffers(self):
+        """Re-seat the model's buffers (BatchNorm running statistics, batch counters) as views into ONE flat tensor per
+        dtype, so that DDP's per-forward buffer broadcast is one collective per dtype instead of one per buffer."""
+        if self.bflat:
+            return
+        groups = {}
+        for b in self.model.buffers():
+            groups.setdefault(b.dtype, []).append(b)
+        for dt, bs in groups.items():
+            pad = lambda k: (k + 3) // 4 * 4
+            flat = torch.zeros(sum(pad(b.numel()) for b in bs), dtype=dt, device=bs[0].device)
+            off = 0
+            for b in bs:
+                k = b.numel()
+                flat[off:off + k].copy_(b.data.reshape(-1))
+                b.data = flat[off:off + k].view_as(b)
+                off += pad(k)
+            self.bflat.append(flat)
 
     def close(self):
         """Detach this trainer from the model: the persistent gradient accumulators the kernels add into
@@ -209,10 +249,11 @@ class GraphedTrainStep:
                 b.copy_(s0)
 
     def sync_buffers(self):
-        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics)."""
-        if self._w() > 1:
-            for b in self.model.buffers():
-                dist.broadcast(b.data, src=0)
+        """DDP's per-forward buffer broadcast from rank 0 (BatchNorm running statistics): one collective per dtype."""
+        if self._multi():
+            self._flatten_buffers()
+            for flat in self.bflat:
+                dist.broadcast(flat, src=0)
 
     @staticmethod
     def _key(b):
@@ -235,9 +276,8 @@ class GraphedTrainStep:
             p.grad = None
         if self.wflat is not None:
             self.wflat.zero_()
-        from . import ops
-        if ops.MERGED_SCRATCH["buf"] is not None:
-            ops.MERGED_SCRATCH["buf"].zero_()
+        if self.scratch.buf is not None:
+            self.scratch.buf.zero_()
         return self._loss_backward(data)
 
     def _loss_backward(self, data):
@@ -247,10 +287,10 @@ class GraphedTrainStep:
         from . import ops
         dev = data.y.device
         defer = self.gflat is not None and dev.type == "cuda"
-        # accumulators of merged weights: a persistent scratch that the update kernel clears (no fill launch per step)
-        ops.MERGED_SCRATCH["static"] = defer and not self.keep_grads
         if defer:
-            ops.defer_begin(dev)
+            # accumulators of merged weights: this trainer's persistent scratch, which its update kernel clears (no fill
+            # launch per step); with keep_grads a fresh zero-filled slab per window
+            ops.defer_begin(dev, scratch=None if self.keep_grads else self.scratch)
         try:
             loss = self._loss(data)
             unit = getattr(self, "_unit", None)         # (loss.backward() would fill a fresh ones_like(loss) every step)
@@ -349,26 +389,21 @@ class GraphedTrainStep:
         # Adam is elementwise: one update over the flat tensor equals the per-parameter updates
         self.opt = FlatAdam(self.pflat, lr=self.lr, weight_decay=self.wd)
         self.opt.zero_grad_in_step = not self.keep_grads
-        if self._w() > 1:
-            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
+        self.opt.zero_also = lambda: self.scratch.buf
+        if self._multi():
+            dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)     # (eager: also creates the communicator before any capture)
             self.opt.grad_scale = 1.0 / self._w()     # the average is folded into the update
         self.opt.step()
         return loss.detach()
 
-    def _capture(self, static):
-        world = self._w()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        snap = self._buffer_snapshot()
-        with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
-            for _ in range(2):
-                self._fwd_bwd(static)
-            self._buffer_restore(snap)
-        torch.cuda.current_stream().wait_stream(side)
+    def _capture_pass(self, static, in_graph: bool):
+        """One capture of the step for the static batch.  ``in_graph``: buffer broadcast, all-reduce and update are nodes of
+        the one graph; else the graph ends after the backward pass and the update is a second graph (g_opt)."""
+        from . import ops
+        multi = self._multi()
         for p in self.model.parameters():
             p.grad = None
         g_bwd = torch.cuda.CUDAGraph()
-        from . import ops
         tl = ops.TIMELINE            # bench.py's in-graph kernel timing: only the captured pass is recorded
         if tl is not None:
             tl.reset()
@@ -377,21 +412,53 @@ class GraphedTrainStep:
             if tl is not None:
                 for _ in range(4):
                     tl.pair("stamp_pair")
+            if in_graph and self._has_buffers:
+                self.sync_buffers()
             if self.wflat is not None and self.keep_grads:
                 self.wflat.zero_()
             loss = self._loss_backward(static)
-            if world == 1:          # nothing happens between backward and update: one graph, one launch
+            if in_graph:
+                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
+            if in_graph or not multi:   # nothing the host must do between backward and update: one graph, one launch
                 self.opt.step()
         g_opt = None
-        if world > 1:
+        if multi and not in_graph:
             g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 self.opt.step()
+        return g_bwd, g_opt, loss
+
+    def _capture(self, static):
+        multi = self._multi()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        snap = self._buffer_snapshot()
+        with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
+            for _ in range(2):
+                self._fwd_bwd(static)
+            self._buffer_restore(snap)
+        torch.cuda.current_stream().wait_stream(side)
+        self.scratch.freeze()          # its address is about to become part of a graph
+        mode = "none"
+        if multi:
+            mode = "in_graph" if (self.graph_collective and dist.get_backend() == "nccl"
+                                  and self.collective_mode != "split") else "split"
+        if mode == "in_graph":
+            try:
+                g_bwd, g_opt, loss = self._capture_pass(static, True)
+            except Exception as exc:    # RCCL refused the capture: the split form is always available
+                self.capture_error = f"{type(exc).__name__}: {exc}"
+                torch.cuda.synchronize()
+                self._buffer_restore(snap)
+                mode = "split"
+        if mode != "in_graph":
+            g_bwd, g_opt, loss = self._capture_pass(static, False)
+        self.collective_mode = mode
         if self.wflat is not None and not self.keep_grads:
             self.wflat.zero_()       # what the captured update leaves behind after every replay: zeros to accumulate into
-            if ops.MERGED_SCRATCH["buf"] is not None:
-                ops.MERGED_SCRATCH["buf"].zero_()
-        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss}
+            if self.scratch.buf is not None:
+                self.scratch.buf.zero_()
+        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss, "mode": mode}
 
     def step(self, data) -> torch.Tensor:
         if self.live is None:
@@ -416,7 +483,7 @@ class GraphedTrainStep:
                 if torch.is_tensor(v):
                     getattr(st, f).copy_(v, non_blocking=True)
         self.opt.sync_lr()
-        if self._has_buffers:
+        if self._has_buffers and slot["mode"] != "in_graph":
             self.sync_buffers()
         slot["bwd"].replay()
         if slot["opt"] is not None:

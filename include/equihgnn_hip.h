@@ -189,6 +189,10 @@ int hg_small_mm_batch(int32_t n_problems, const HgSmallMM* problems, void* strea
  * time it INSIDE a replayed hipGraph; eqh_wall_clock_khz is that clock's rate. */
 int eqh_stamp(void* slot, void* stream);
 int64_t eqh_wall_clock_khz(void);
+/* eqh_clock_probe: one wavefront waits spin_us (1..10000) microseconds on the constant-rate clock and stores
+ * out[0] = shader cycles (s_memtime) and out[1] = constant-rate ticks (s_memrealtime) that passed, two uint64: the shader
+ * clock the chip holds at that moment is out[0] / out[1] x eqh_wall_clock_khz (bench.py prints it beside each timed block). */
+int eqh_clock_probe(void* out, int32_t spin_us, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of

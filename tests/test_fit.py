@@ -297,3 +297,30 @@ def test_evaluation_on_reused_loader_buffers_matches_fresh_batches():
         _, table = fitter.test(ld)
         np.testing.assert_allclose(table[:, 0], want, rtol=1e-5, atol=1e-5)
         assert float(np.abs(want).std()) > 1e-3               # (predictions differ between molecules: the check bites)
+
+
+def test_discarded_lookahead_epoch_does_not_skip_a_permutation():
+    """an epoch that was planned AHEAD and then discarded (close() at the end of fit() / test(), a break) must
+    not advance the shuffle epoch: the sequence of permutations a loader yields is the same with and without lookahead
+    (DistributedSampler.set_epoch semantics)."""
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    mols = _mols(16 * 5, 6)
+    for i, m in enumerate(mols):
+        m.y = float(i)
+
+    def epochs(lookahead, close_between):
+        ld = BucketedLoader(MolStore(mols), 16, True, seed=11, device=None, prefetch=2)
+        ld.lookahead = lookahead
+        out = []
+        for _ in range(3):
+            out.append([int(v) for b in ld for v in b.y[:b.num_real_graphs].tolist()])
+            if close_between:
+                ld.close()                      # what Fitter.fit() / test() do when they are done with a loader
+        ld.close()
+        return out
+
+    want = epochs(False, False)
+    assert want[0] != want[1] != want[2]
+    assert epochs(True, True) == want
+    assert epochs(True, False) == want

@@ -1646,7 +1646,7 @@ def _gemm_ref64(a, b, ta, tb, bias, d, alpha, beta, relu):
     return torch.relu(c) if relu else c
 
 
-@pytest.mark.parametrize("tile", [64, 128, 512, 513])      # 512 / 513: the 128 x 256 / 256 x 128 tiles (eight multiplying wavefronts)
+@pytest.mark.parametrize("tile", [64, 128, 256, 512, 513])  # 256: 128 x 128 (the deep split-K choice); 512 / 513: 128 x 256 / 256 x 128 (eight multiplying wavefronts)
 @pytest.mark.parametrize("M,N,K,ta,tb", [(4736, 256, 256, False, True), (4736, 256, 256, False, False),
                                          (256, 256, 4736, True, False), (300, 64, 272, False, True),
                                          (77, 132, 36, False, False), (1, 4, 4, False, True), (516, 2176, 256, False, True),

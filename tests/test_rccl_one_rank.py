@@ -1,0 +1,81 @@
+"""The multi-rank training step on the ONE GPU a test box has: a 1-rank "nccl" (RCCL) process group drives
+GraphedTrainStep's collective path (parameter / buffer broadcast, flat-gradient all-reduce, 1 / world scaling) --
+reference behaviour: Trainer(strategy="ddp_find_unused_parameters_true"), main.py:271-283.  With one rank every
+collective is the identity, so the parameters after K steps must equal those of the rank-local trainer BIT FOR BIT,
+whether the all-reduce is a node of the step's hipGraph ("in_graph") or runs eagerly between two graphs ("split")."""
+import json
+import os
+import socket
+
+import pytest
+import torch
+
+from golden.common import fill_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, port, out_path):
+    import torch.distributed as dist
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    report = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    raw = [synth_batch(8, 810 + i) for i in range(3)]
+    ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64) for b in raw]
+    tgt = tuple(max(e[i] for e in ext) for i in range(3))
+    batches = [pad_batch(b, *tgt).to(dev) for b in raw]
+    for b in batches:
+        b.num_real_graphs = 8
+    for method in ("egnn_equihnns", "mhnnm"):      # the second has BatchNorm buffers (DDP's per-forward broadcast)
+        finals = {}
+        for label, kw in (("local", dict(collective=False)),
+                          ("in_graph", dict(force_collective=True)),
+                          ("split", dict(force_collective=True, graph_collective=False))):
+            m = MODELS[method](1, default_args(method=method, MLP_hidden=64, output_hidden=32))
+            fill_state_dict(m, 5)
+            m.to(dev).train()
+            tr = GraphedTrainStep(m, lr=1e-3, **kw)
+            losses = [float(tr.step(batches[i % 3])) for i in range(6)]
+            torch.cuda.synchronize()
+            finals[label] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses)
+            report[f"{method}/{label}"] = {"mode": tr.collective_mode, "capture_error": tr.capture_error,
+                                           "graphs": [s["opt"] is not None for s in tr.slots.values()],
+                                           "flat_buffers": len(tr.bflat)}
+            tr.close()
+        for label in ("in_graph", "split"):
+            sd, losses = finals[label]
+            assert losses == finals["local"][1], (method, label, losses, finals["local"][1])
+            for k, v in sd.items():
+                assert torch.equal(v, finals["local"][0][k]), (method, label, k)
+    json.dump(report, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_graphed_step_through_a_one_rank_rccl_group(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "report.json"
+    mp.spawn(_worker, args=(port, str(out)), nprocs=1, join=True)       # RCCL lives and dies in a child process
+    rep = json.load(open(out))
+    print("one-rank RCCL report:", json.dumps(rep))
+    assert rep["backend"] == "nccl" and rep["world"] == 1
+    for method in ("egnn_equihnns", "mhnnm"):
+        assert rep[f"{method}/local"]["mode"] == "none"
+        assert rep[f"{method}/split"]["mode"] == "split" and all(rep[f"{method}/split"]["graphs"])
+        ig = rep[f"{method}/in_graph"]
+        # the collective is captured into the step's one graph; falling back to "split" is legal only with the reason recorded
+        assert ig["mode"] == "in_graph" or (ig["mode"] == "split" and ig["capture_error"]), ig
+        if ig["mode"] == "in_graph":
+            assert not any(ig["graphs"])                       # no second graph
+    assert rep["mhnnm/in_graph"]["flat_buffers"] >= 1          # one broadcast per dtype, not one per buffer
