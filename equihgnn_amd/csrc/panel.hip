@@ -1,0 +1,925 @@
+// Row-panel kernels for the conv-sized dense products of the path, [~5 k rows x C] . [C x C] with C = MLP_hidden <= 256
+// (mlp.py:91-99 inside conv.py:169-182: 36 of them per training step of egnn_equihnns at the BASELINE batch), fused with the
+// row-wise work either side of them.
+//
+// Why its own kernel.  At these sizes a tiled GEMM -- the library's fp32-MFMA kernels or gemm_x6.hip -- is bound by its fixed
+// costs: 296 tiles of 64 x 64 are two rounds on 256 CUs, every tile re-stages (and, for x6, re-splits) its slice of the weight,
+// and the bias / ReLU / LayerNorm that follows is one more launch and one more [rows, C] round trip at ~4.5 us per launch inside
+// a replayed graph.  Here a workgroup owns a PANEL of 32 consecutive rows over the WHOLE width:
+//   * the weight is split into its three bf16 planes ONCE per step, ahead of time, in MFMA operand order (hg_panel_pack;
+//     the conv layer's weights are shared by its L applications and by forward and backward); a wavefront streams the
+//     fragments of its own output columns straight from L2 into registers -- no LDS staging and no VALU split for the weight;
+//   * the panel's rows are produced by a row PROLOGUE in the wave-per-row layout of the aggregation kernels (rowln.h), split
+//     (bf16x3.h) and laid into LDS as the A image; they are 48 KB for all of K = 256, shared by the four wavefronts;
+//   * products are the six bf16 MFMAs of gemm_x6.hip (fp32-grade results, tests compare with float64);
+//   * the accumulators go through an fp32 LDS staging tile back into the wave-per-row layout, where the row EPILOGUE runs
+//     (scale, addend, bias, ReLU, LayerNorm and its backward: the same device functions as the stand-alone row kernels, so
+//     the fused and the unfused forms agree bit for bit given the same GEMM result), stores whole 1 KB rows, and -- in the chained
+//     forms -- lays the next product's A image without leaving the workgroup.
+// A panel needs the whole [C x C] weight (384 KB of planes at C = 256) through its CU's vector memory path: that, equal to the
+// MFMA time of 192 MFMAs per wavefront (2.6 us at 2.4 GHz), is what bounds a panel; with ~150 panels on 256 CUs the launch is one
+// round.  MFMA 32 x 32 x 16 with the operands swapped (the accumulator holds C^T: a lane owns 4 consecutive columns of one row).
+#include <initializer_list>
+
+#include "common.h"
+#include "bf16x3.h"
+#include "rowln.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PN_ROWS = 32;        // rows per panel = one MFMA row tile
+constexpr int PN_THREADS = 256;    // four wavefronts: wavefront w multiplies the column tiles w, w + 4
+constexpr int PN_STG_LD = 260;     // floats per staged row: 256 + 4 keeps the accumulators' 16-byte stores conflict-free
+constexpr int PN_PF = 3;           // K steps (of 16) of weight fragments in flight per wavefront
+
+#ifdef PN_STAMPS   // diagnostic build only (tools/panel_stamps.py): per-wavefront s_memtime stamps of the phases
+__device__ unsigned long long* pn_stamp_buf = nullptr;
+#define PN_STAMP(slot)                                                                                              \
+    do {                                                                                                            \
+        if (pn_stamp_buf && (threadIdx.x & 63) == 0)                                                                 \
+            pn_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PN_STAMP(slot) do { } while (0)
+#endif
+
+// ---- weights in MFMA operand order ------------------------------------------------------------------------------------------
+// image[tile = n / 32][kstep = k / 16][plane 3][lane 64] x 16 bytes: lane (fh = lane >> 5, fr = lane & 31) holds the eight bf16
+// B[16 kstep + 8 fh + 0..7][32 tile + fr] of one plane.  Several weights may be stacked along K in one image (kstep0).
+struct PackItem {
+    const float* w;      // trans: B[k][n] = w[n * ld + k]  (an nn.Linear weight used as x W^T);  else B[k][n] = w[k * ld + n]
+    int64_t ld;
+    uint4* dst;
+    int K, N, trans, kstep0, ksteps_total;
+};
+constexpr int PN_MAXPACK = 32;
+struct PackBatch {
+    PackItem it[PN_MAXPACK];
+    int first[PN_MAXPACK + 1];      // prefix sums of the items' (tile, kstep) units
+    int n;
+};
+static_assert(sizeof(PackBatch) <= 4096, "PackBatch is a by-value kernel argument");
+
+__global__ void __launch_bounds__(256) k_panel_pack(const PackBatch b) {
+    const int unit = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    if (unit >= b.first[b.n]) return;
+    int i = 0;
+    while (i + 1 < b.n && unit >= b.first[i + 1]) ++i;
+    const PackItem it = b.it[i];
+    const int local = unit - b.first[i], ks = it.K >> 4;
+    const int tile = local / ks, kstep = local - tile * ks;
+    const int lane = threadIdx.x & 63, fh = lane >> 5, fr = lane & 31;
+    const int n = tile * 32 + fr, k0 = kstep * 16 + 8 * fh;
+    float v[8];
+    if (it.trans) {
+        const float4 a = *reinterpret_cast<const float4*>(it.w + (int64_t)n * it.ld + k0);
+        const float4 c = *reinterpret_cast<const float4*>(it.w + (int64_t)n * it.ld + k0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = it.w[(int64_t)(k0 + j) * it.ld + n];
+    }
+    uint4 p0, p1, p2;
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    uint4* d = it.dst + ((int64_t)(tile * it.ksteps_total + it.kstep0 + kstep) * 3) * 64 + lane;
+    d[0] = p0;
+    d[64] = p1;
+    d[128] = p2;
+}
+
+// ---- the A image: a panel's rows as bf16 planes in LDS ---------------------------------------------------------------------
+// [plane 3][kstep KS][slot 64] x 16 bytes; the fragment of (plane, kstep) is 1 KB, lane (fh, fr) reads slot
+// fh * 32 + (fr ^ swz), swz = ((kstep & 3) << 1) | fh: the xor keeps the 8-byte row-wise writes below (a 16-lane group of a
+// wave-per-row store covers four K steps x two halves of ONE row) on 32 distinct banks, and a ds_read_b128 of a fragment stays
+// a permutation of its 64 slots inside each hardware lane group.
+template <int KS>
+__device__ __forceinline__ int a_slot(int kstep, int fh, int row) {
+    return kstep * 64 + fh * 32 + (row ^ (((kstep & 3) << 1) | fh));
+}
+
+// lane l of a wave-per-row holder has v = row[4 l .. 4 l + 3] (k = 4 l + kbase): its 8 bytes of each plane
+template <int KS>
+__device__ __forceinline__ void a_put(uint4* __restrict__ img, int row, int k4, const float4& v) {
+    const int kstep = k4 >> 2, fh = (k4 >> 1) & 1, half = k4 & 1;
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split_pair(v.x, v.y, a0, a1, a2);
+    split_pair(v.z, v.w, b0, b1, b2);
+    uint2* d = reinterpret_cast<uint2*>(img) + a_slot<KS>(kstep, fh, row) * 2 + half;
+    d[0] = make_uint2(a0, b0);
+    d[KS * 64 * 2] = make_uint2(a1, b1);
+    d[KS * 64 * 4] = make_uint2(a2, b2);
+}
+
+// ---- the product: acc[g][j] (+)= A image . W image g for the column tiles wave + 4 j ---------------------------------------
+// NG products share the A image (conv.py:172,176: X feeds W1's first Linear and the node half of W2's); the weight stream
+// runs on across them, PN_PF K steps ahead of the MFMAs.
+template <int KS, int NTW, int NG = 1>
+struct WStream {
+    uint4 q[PN_PF][NTW][3];
+    const uint4* base[NG][NTW];
+    __device__ __forceinline__ void init(int g, const uint4* __restrict__ w, int wave, int lane) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) base[g][j] = w + (int64_t)((wave + 4 * j) * KS) * 3 * 64 + lane;
+    }
+    __device__ __forceinline__ void fetch(int slot, int kk) {      // kk = product * KS + kstep (compile-time after unrolling)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) q[slot][j][p] = base[kk / KS][j][((kk % KS) * 3 + p) * 64];
+    }
+    __device__ __forceinline__ void prime() {
+#pragma unroll
+        for (int s = 0; s < PN_PF; ++s)
+            if (s < KS * NG) fetch(s, s);
+    }
+};
+
+template <int KS, int NTW, int NG>
+__device__ __forceinline__ void panel_mma(const uint4* __restrict__ img, WStream<KS, NTW, NG>& ws, f32x16 (&acc)[NG][NTW], int lane) {
+    const int fh = lane >> 5, fr = lane & 31;
+    uint4 af[2][3];            // the A fragments of a K step are requested during the step before
+    auto a_read = [&](int kk) {
+        const uint4* ap = img + a_slot<KS>(kk % KS, fh, fr);
+        af[kk & 1][0] = ap[0];
+        af[kk & 1][1] = ap[KS * 64];
+        af[kk & 1][2] = ap[KS * 128];
+    };
+    a_read(0);
+#pragma unroll
+    for (int kk = 0; kk < KS * NG; ++kk) {
+        const int slot = kk % PN_PF, g = kk / KS;
+        if (kk + 1 < KS * NG) a_read(kk + 1);
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[kk & 1][0]);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[kk & 1][1]);
+        const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[kk & 1][2]);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, ws.q[slot][j][0]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, ws.q[slot][j][1]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, ws.q[slot][j][2]);
+            // smallest terms first, as gemm_x6.hip: a1 b1, a0 b2, a2 b0, a0 b1, a1 b0, a0 b0
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[g][j], 0, 0, 0);
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a0, acc[g][j], 0, 0, 0);
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a2, acc[g][j], 0, 0, 0);
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[g][j], 0, 0, 0);
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[g][j], 0, 0, 0);
+            acc[g][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[g][j], 0, 0, 0);
+        }
+        if (kk + PN_PF < KS * NG) ws.fetch(slot, kk + PN_PF);
+        // (the scheduler otherwise sinks the fetches next to their uses -- registers it thinks it saves -- and the stream
+        // runs one load deep)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// accumulators (C^T layout: lane (fh, fr) holds row fr, columns 8 g + 4 fh .. + 3 of its tiles) -> the fp32 staging tile
+template <int NTW>
+__device__ __forceinline__ void acc_to_staging(float* __restrict__ stg, const f32x16 (&acc)[NTW], int wave, int lane) {
+    const int fh = lane >> 5, fr = lane & 31;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(stg + fr * PN_STG_LD + (wave + 4 * j) * 32 + 8 * g + 4 * fh) =
+                make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+}
+
+template <int NG, int NTW>
+__device__ __forceinline__ void acc_zero(f32x16 (&acc)[NG][NTW]) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[g][j][i] = 0.f;
+}
+
+// ---- plain product: C = act(alpha A W + beta D + bias) ----------------------------------------------------------------------
+struct PanelPlain {
+    const float* A;
+    int64_t lda;
+    int rows;
+    const uint4* W;
+    float alpha, beta;
+    const float* D;
+    int64_t ldd;
+    const float* bias;
+    int relu;
+    float* Cout;
+    int64_t ldc;
+};
+
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_panel_plain(const PanelPlain p) {
+    constexpr int KS = C / 16, NT = C / 32, NTW = (NT + 3) / 4;
+    __shared__ uint4 s_img[3 * KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const bool mul = NT >= 4 || wave < NT;        // (C = 64: two column tiles, wavefronts 2 and 3 only move rows)
+    const int c4 = lane * 4;
+
+    PN_STAMP(0);
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = r0 + wave * 8 + i;
+        row = row < p.rows ? row : p.rows - 1;
+        v[i] = c4 < C ? *reinterpret_cast<const float4*>(p.A + (int64_t)row * p.lda + c4) : f4_zero();
+    }
+    WStream<KS, NTW, 1> ws;
+    ws.init(0, p.W, mul ? wave : 0, lane);
+    ws.prime();          // unconditional: loads inside a branch make every later wait conservative (idle waves re-read tile 0)
+    __builtin_amdgcn_sched_barrier(0);
+    if (c4 < C) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a_put<KS>(s_img, wave * 8 + i, lane, v[i]);
+    }
+    PN_STAMP(1);
+    __syncthreads();
+    PN_STAMP(2);
+    f32x16 acc[1][NTW];
+    acc_zero<1, NTW>(acc);
+    if (mul) {
+        panel_mma<KS, NTW, 1>(s_img, ws, acc, lane);
+        PN_STAMP(3);
+        acc_to_staging<NTW>(s_stg, acc[0], wave, lane);
+    }
+    __syncthreads();
+    PN_STAMP(4);
+    if (c4 < C) {
+        const float4 bv = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4) : f4_zero();
+        float4 a[8], d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {          // all of the wavefront's rows requested before the first is used
+            const int lr = wave * 8 + i, row = r0 + lr;
+            a[i] = *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + c4);
+            d[i] = p.D ? *reinterpret_cast<const float4*>(p.D + (int64_t)(row < p.rows ? row : p.rows - 1) * p.ldd + c4) : f4_zero();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = r0 + wave * 8 + i;
+            float4 o = make_float4(p.alpha * a[i].x, p.alpha * a[i].y, p.alpha * a[i].z, p.alpha * a[i].w);
+            if (p.D) { o.x = fmaf(p.beta, d[i].x, o.x); o.y = fmaf(p.beta, d[i].y, o.y); o.z = fmaf(p.beta, d[i].z, o.z); o.w = fmaf(p.beta, d[i].w, o.w); }
+            o.x += bv.x; o.y += bv.y; o.z += bv.z; o.w += bv.w;
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            if (row < p.rows) *reinterpret_cast<float4*>(p.Cout + (int64_t)row * p.ldc + c4) = o;
+        }
+    }
+    PN_STAMP(5);
+}
+
+// =============================================================================================================================
+// The merged MHNNSConv application (conv.py:169-182 after layers.MHNNSConv._prepare_merged) on panels.
+//   forward  F1: h1 = X W1a^T (stored raw, the LayerNorm backward recomputes from it), h1n = LN1(relu(h1 + b1a)), pa = X W2v^T
+//            F2: hbar[e] = mean_{v in e} h1n[v]  (prologue: gathered mean over the hyperedge's nodes, conv.py:172-173)
+//                qb = hbar w12^T + b12
+//            (s = k_inc_fwd_col(pa, qb): incidence.hip, the HBM-bound aggregation, stays its own launch)
+//            F3: u = scale * (s w23^T) + cw,  x3 = LN3(relu(u + b3a)),  Xn = act(x3 W3b^T + b3b)   [+ F1 of the next application]
+//   backward B3: g = dXn * [Xn > 0],  dx3 = g W3b,  dpre = LN3bwd(u + b3a; dx3),  ds = scale * dpre w23
+//            (dpa, dqb = k_inc_bwd_both(ds));  B2 = the plain product dhbar = dqb w12
+//            B1: dh1[v] = LN1bwd(h1[v] + b1a; sum_{e of v} dhbar[e] / deg e)  (prologue),  dX = [dh1 | dpa] . [W1a ; W2v]
+//                [+ B3 of the previous application]
+// Every row-wise step runs in the wave-per-row layout on rowln.h's functions.  The weight / bias / LayerNorm-vector gradients
+// are formed outside from the stored rows (batched weight-gradient launch, column sums) and from the per-workgroup slabs.
+// =============================================================================================================================
+template <int C>
+__device__ __forceinline__ float4 ld_row(const float* __restrict__ base, int64_t ld, int row, int lane) {
+    return (lane * 4 < C) ? *reinterpret_cast<const float4*>(base + (int64_t)row * ld + lane * 4) : f4_zero();
+}
+template <int C>
+__device__ __forceinline__ void st_row(float* __restrict__ base, int64_t ld, int row, int lane, const float4& v) {
+    if (lane * 4 < C) *reinterpret_cast<float4*>(base + (int64_t)row * ld + lane * 4) = v;
+}
+template <int C>
+__device__ __forceinline__ float4 ld_vec(const float* __restrict__ v, int lane) {
+    return (lane * 4 < C) ? *reinterpret_cast<const float4*>(v + lane * 4) : f4_zero();
+}
+
+// y = gamma * xhat(relu(pre + bias)) + beta: the arithmetic of k_rowln_fwd (incidence.hip)
+template <int C>
+__device__ __forceinline__ float4 ln_fwd_row(const float4& pre, const float4& bias, const float4& g, const float4& b, float eps, int lane) {
+    Row<1> u, w, x;
+    u.v[0] = pre;
+    w.v[0] = bias;
+    unsigned pos;
+    float rstd;
+    norm_pair<1, true>(u, w, C, lane, 1.0f / (float)C, eps, x, pos, &rstd);
+    return make_float4(fmaf(g.x, x.v[0].x, b.x), fmaf(g.y, x.v[0].y, b.y), fmaf(g.z, x.v[0].z, b.z), fmaf(g.w, x.v[0].w, b.w));
+}
+
+// gradient of the pre-activation given dy = d LN output; adds this row's terms of d bias, d gamma, d beta (k_rowln_bwd's arithmetic)
+template <int C>
+__device__ __forceinline__ float4 ln_bwd_row(const float4& pre, const float4& bias, const float4& gam, const float4& dy, float eps,
+                                              int lane, float4& a_db, float4& a_dg, float4& a_dbeta) {
+    Row<1> u, w, x;
+    u.v[0] = pre;
+    w.v[0] = bias;
+    unsigned pos;
+    float rstd;
+    const float inv_c = 1.0f / (float)C;
+    norm_pair<1, true>(u, w, C, lane, inv_c, eps, x, pos, &rstd);
+    const float4 xh = x.v[0];
+    float4 d = dy;
+    f4_add(a_dbeta, d);
+    a_dg.x = fmaf(d.x, xh.x, a_dg.x); a_dg.y = fmaf(d.y, xh.y, a_dg.y); a_dg.z = fmaf(d.z, xh.z, a_dg.z); a_dg.w = fmaf(d.w, xh.w, a_dg.w);
+    d.x *= gam.x; d.y *= gam.y; d.z *= gam.z; d.w *= gam.w;
+    float m1 = (d.x + d.y) + (d.z + d.w);
+    float m2 = (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+    wave_sum2(m1, m2);
+    m1 *= inv_c;
+    m2 *= inv_c;
+    float4 dx;
+    dx.x = (pos & 1u) ? rstd * (d.x - m1 - xh.x * m2) : 0.f;
+    dx.y = (pos & 2u) ? rstd * (d.y - m1 - xh.y * m2) : 0.f;
+    dx.z = (pos & 4u) ? rstd * (d.z - m1 - xh.z * m2) : 0.f;
+    dx.w = (pos & 8u) ? rstd * (d.w - m1 - xh.w * m2) : 0.f;
+    f4_add(a_db, dx);
+    return dx;
+}
+
+// the workgroup's [d bias | d gamma | d beta] partial sums -> its slab, wavefronts combined in a fixed order (all threads call)
+template <int C>
+__device__ __forceinline__ void write_slab(float4* __restrict__ s_red, float* __restrict__ slab, const float4& a_db, const float4& a_dg,
+                                           const float4& a_dbeta, int wave, int lane) {
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        s_red[threadIdx.x] = which == 0 ? a_db : (which == 1 ? a_dg : a_dbeta);
+        __syncthreads();
+        if (wave == 0 && lane * 4 < C) {
+            float4 t = s_red[lane];
+            f4_add(t, s_red[64 + lane]);
+            f4_add(t, s_red[128 + lane]);
+            f4_add(t, s_red[192 + lane]);
+            *reinterpret_cast<float4*>(slab + which * C + lane * 4) = t;
+        }
+        __syncthreads();
+    }
+}
+
+// A wavefront's eight consecutive CSR rows [s_beg, s_end): sum_q w[q] * src[col[q]] per row, rows handed to `sink(i, sum, deg)`.
+// One chain fetches the row ends and up to 64 entries of the range (a lane each); four gathered rows in flight (the walk of
+// k_gather_ln_bwd, incidence.hip).
+template <int C, typename Sink>
+__device__ __forceinline__ void gather_range(const float* __restrict__ src, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                             const float* __restrict__ wq, int s_beg, int s_end, int lane, Sink&& sink) {
+    if (s_beg >= s_end) return;
+    const int p_beg = rowptr[s_beg];
+    const int my_rend = (s_beg + lane < s_end) ? rowptr[s_beg + lane + 1] : 0;   // lane i: end of row s_beg + i
+    const int p_end = rowptr[s_end];
+    int q0 = p_beg;
+    int cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+    int my_c = (lane < cnt) ? col[q0 + lane] : 0;
+    float my_w = (wq && lane < cnt) ? wq[q0 + lane] : 1.0f;
+    int q = p_beg;
+    for (int row = s_beg; row < s_end; ++row) {
+        const int rend = __builtin_amdgcn_readlane(my_rend, row - s_beg);
+        const int rbeg = q;
+        float4 sum = f4_zero();
+        while (q < rend) {
+            if (q - q0 >= 64) {
+                q0 += 64;
+                cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+                my_c = (lane < cnt) ? col[q0 + lane] : 0;
+                my_w = (wq && lane < cnt) ? wq[q0 + lane] : 1.0f;
+            }
+            const int j = q - q0;
+            int lim = rend - q0;
+            if (lim > cnt) lim = cnt;
+            const int n = (lim - j < 4) ? lim - j : 4;
+            const int j1 = (n > 1) ? j + 1 : j, j2 = (n > 2) ? j + 2 : j, j3 = (n > 3) ? j + 3 : j;
+            const float4 d0 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j), lane);
+            const float4 d1 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j1), lane);
+            const float4 d2 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j2), lane);
+            const float4 d3 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j3), lane);
+            const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
+            const float w1 = (n > 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j1)) : 0.f;
+            const float w2 = (n > 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j2)) : 0.f;
+            const float w3 = (n > 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j3)) : 0.f;
+            f4_fma(sum, d0, w0);
+            f4_fma(sum, d1, w1);
+            f4_fma(sum, d2, w2);
+            f4_fma(sum, d3, w3);
+            q += n;
+        }
+        sink(row - s_beg, sum, rend - rbeg);
+    }
+}
+
+struct ConvPanelArgs {
+    int rows;                       // rows of this stage's panels (nodes, or hyperedges for F2)
+    float eps, scale;
+    int relu, acc_first, tail;
+    // operands / products (meaning per stage, see the kernels)
+    const float* in0; const float* in1; const float* in2; const float* in3;
+    int64_t ld0;
+    const int* rowptr; const int* col; const float* wq;
+    const uint4* w0; const uint4* w1; const uint4* w2; const uint4* w3;
+    const float* b0; const float* g0; const float* be0;      // bias / gamma / beta of the first LayerNorm of the stage
+    const float* b1; const float* g1; const float* be1;      // ... of the tail's
+    const float* bias_out;                                    // bias of a plain Linear output
+    float* out0; float* out1; float* out2; float* out3; float* out4; float* out5;
+    float* slab; float* slab2;
+    float* acc_out;
+};
+
+template <int C> struct PnShape {
+    static constexpr int KS = C / 16, NT = C / 32, NTW = (NT + 3) / 4;
+};
+
+// ---- F1: X -> h1 (raw), h1n = LN1(relu(h1 + b1a)), pa -------------------------------------------------------------------------
+// in0 = X (ld0), w0 = W1a image (x W^T), w1 = W2v image, b0/g0/be0 = b1a, gamma1, beta1; out0 = h1, out1 = h1n, out2 = pa
+template <int C>
+__device__ __forceinline__ void stage_f1(const ConvPanelArgs& p, uint4* __restrict__ s_img, float* __restrict__ s_stg,
+                                         float* __restrict__ s_stg2, const uint4* w_a, const uint4* w_b, const float* b1a,
+                                         const float* g1, const float* be1, float* h1, float* h1n, float* pa, int r0, int wave,
+                                         int lane, bool mul) {
+    using S = PnShape<C>;
+    WStream<S::KS, S::NTW, 2> ws;
+    ws.init(0, w_a, mul ? wave : 0, lane);
+    ws.init(1, w_b, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc[2][S::NTW];
+    acc_zero<2, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 2>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+        acc_to_staging<S::NTW>(s_stg2, acc[1], wave, lane);
+    }
+    __syncthreads();
+    const float4 bv = ld_vec<C>(b1a, lane), gv = ld_vec<C>(g1, lane), bev = ld_vec<C>(be1, lane);
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, row = r0 + lr;
+        if (row >= p.rows) break;
+        const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+        const float4 b = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg2 + lr * PN_STG_LD + lane * 4) : f4_zero();
+        st_row<C>(h1, C, row, lane, a);
+        st_row<C>(pa, C, row, lane, b);
+        st_row<C>(h1n, C, row, lane, ln_fwd_row<C>(a, bv, gv, bev, p.eps, lane));
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_f1(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    __shared__ float s_stg2[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = r0 + wave * 8 + i;
+        row = row < p.rows ? row : p.rows - 1;
+        v[i] = ld_row<C>(p.in0, p.ld0, row, lane);
+    }
+    if (lane * 4 < C) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a_put<S::KS>(s_img, wave * 8 + i, lane, v[i]);
+    }
+    __syncthreads();
+    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w0, p.w1, p.b0, p.g0, p.be0, p.out0, p.out1, p.out2, r0, wave, lane, mul);
+}
+
+// ---- F2: hbar[e] = mean over the hyperedge's nodes of h1n, qb = hbar w12^T + b12 ---------------------------------------------
+// in0 = h1n [N, C], rowptr / col = the incidence CSR by hyperedge, w0 = w12 image, bias_out = b12; out0 = hbar, out1 = qb
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_f2(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    WStream<S::KS, S::NTW, 1> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    const int s_beg = min(r0 + wave * 8, p.rows), s_end = min(s_beg + 8, p.rows);
+    gather_range<C>(p.in0, p.rowptr, p.col, nullptr, s_beg, s_end, lane, [&](int i, const float4& sum, int deg) {
+        const float den = deg > 1 ? (float)deg : 1.0f;
+        const float4 m = make_float4(sum.x / den, sum.y / den, sum.z / den, sum.w / den);
+        st_row<C>(p.out0, C, s_beg + i, lane, m);
+        if (lane * 4 < C) a_put<S::KS>(s_img, wave * 8 + i, lane, m);
+    });
+    for (int i = s_end - s_beg; i < 8; ++i)                 // rows past the end of the matrix: zeros for the MFMA
+        if (lane * 4 < C) a_put<S::KS>(s_img, wave * 8 + i, lane, f4_zero());
+    __syncthreads();
+    f32x16 acc[1][S::NTW];
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    __syncthreads();
+    const float4 bv = ld_vec<C>(p.bias_out, lane);
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, row = r0 + lr;
+        if (row >= p.rows) break;
+        float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+        f4_add(a, bv);
+        st_row<C>(p.out1, C, row, lane, a);
+    }
+}
+
+// ---- F3: s -> u = scale * (s w23^T) + cw, x3 = LN3(relu(u + b3a)), Xn = act(x3 W3b^T + b3b)  [tail: F1 on Xn] ----------------
+// in0 = s, in1 = cw, w0 = w23 image, b0/g0/be0 = b3a, gamma3, beta3, w1 = W3b image, bias_out = b3b, relu;
+// out0 = u, out1 = x3, out2 = Xn;  tail: w2 = W1a image, w3 = W2v image, b1/g1/be1 = b1a, gamma1, beta1, out3 = h1, out4 = h1n, out5 = pa
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_f3(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    __shared__ float s_stg2[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    float4 v[8], cwv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = r0 + wave * 8 + i;
+        row = row < p.rows ? row : p.rows - 1;
+        v[i] = ld_row<C>(p.in0, C, row, lane);
+    }
+    WStream<S::KS, S::NTW, 1> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.prime();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = r0 + wave * 8 + i;
+        row = row < p.rows ? row : p.rows - 1;
+        cwv[i] = ld_row<C>(p.in1, C, row, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane * 4 < C) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a_put<S::KS>(s_img, wave * 8 + i, lane, v[i]);
+    }
+    __syncthreads();
+    f32x16 acc[1][S::NTW];
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    // the next product's weight stream starts now: its first fragments arrive while the rows are normalised
+    ws.init(0, p.w1, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    {
+        const float4 bv = ld_vec<C>(p.b0, lane), gv = ld_vec<C>(p.g0, lane), bev = ld_vec<C>(p.be0, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = wave * 8 + i, row = r0 + lr;
+            const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+            const float4 u = make_float4(fmaf(p.scale, a.x, cwv[i].x), fmaf(p.scale, a.y, cwv[i].y), fmaf(p.scale, a.z, cwv[i].z),
+                                         fmaf(p.scale, a.w, cwv[i].w));
+            const float4 x3 = ln_fwd_row<C>(u, bv, gv, bev, p.eps, lane);
+            if (row < p.rows) {
+                st_row<C>(p.out0, C, row, lane, u);
+                st_row<C>(p.out1, C, row, lane, x3);
+            }
+            if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, x3);      // (every wavefront has left the MFMA loop: barrier above)
+        }
+    }
+    __syncthreads();
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    __syncthreads();
+    {
+        const float4 bv = ld_vec<C>(p.bias_out, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = wave * 8 + i, row = r0 + lr;
+            float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+            f4_add(a, bv);
+            if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (row < p.rows) st_row<C>(p.out2, C, row, lane, a);
+            if (p.tail && lane * 4 < C) a_put<S::KS>(s_img, lr, lane, a);
+        }
+    }
+    if (!p.tail) return;
+    __syncthreads();
+    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w2, p.w3, p.b1, p.g1, p.be1, p.out3, p.out4, p.out5, r0, wave, lane, mul);
+}
+
+// ---- B3: dXn -> g = dXn * [Xn > 0], dx3 = g W3b, dpre = LN3bwd(u + b3a; dx3), ds = scale * dpre w23 --------------------------
+// Shared by k_conv_b3 (rows from memory) and the tail of k_conv_b1 (rows = the dX it has just formed, in the staging tile).
+// w_a = W3b image (dy W), w_b = w23 image (dy W); slab = [d b3a | d gamma3 | d beta3] of this workgroup; acc_out += dpre
+template <int C, bool FROM_STAGING>
+__device__ __forceinline__ void stage_b3(const ConvPanelArgs& p, uint4* __restrict__ s_img, float* __restrict__ s_stg,
+                                         float4* __restrict__ s_red, const float* dxn, int64_t ld_dxn, const float* xmask,
+                                         const uint4* w_a, const uint4* w_b, const float* u_pre, const float* b3a, const float* g3,
+                                         float* g_out, float* dpre_out, float* ds_out, float* slab, float* acc_out, int acc_first,
+                                         int r0, int wave, int lane, bool mul) {
+    using S = PnShape<C>;
+    float4 v[8], m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i;
+        int row = r0 + lr;
+        row = row < p.rows ? row : p.rows - 1;
+        if constexpr (FROM_STAGING)
+            v[i] = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+        else
+            v[i] = ld_row<C>(dxn, ld_dxn, row, lane);
+        m[i] = xmask ? ld_row<C>(xmask, C, row, lane) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    WStream<S::KS, S::NTW, 1> ws;
+    ws.init(0, w_a, mul ? wave : 0, lane);
+    ws.prime();
+    float4 upre[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int row = r0 + wave * 8 + i;
+        row = row < p.rows ? row : p.rows - 1;
+        upre[i] = ld_row<C>(u_pre, C, row, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (FROM_STAGING: a wavefront reads its own rows of the staging tile here and the tile is next written after the barrier
+    // below, so no barrier is needed in between)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, row = r0 + lr;
+        float4 g = v[i];
+        g.x = m[i].x > 0.f ? g.x : 0.f; g.y = m[i].y > 0.f ? g.y : 0.f; g.z = m[i].z > 0.f ? g.z : 0.f; g.w = m[i].w > 0.f ? g.w : 0.f;
+        if (g_out && row < p.rows) st_row<C>(g_out, C, row, lane, g);
+        if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, g);
+    }
+    __syncthreads();
+    f32x16 acc[1][S::NTW];
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    ws.init(0, w_b, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    float4 a_db = f4_zero(), a_dg = f4_zero(), a_dbeta = f4_zero();
+    {
+        const float4 bv = ld_vec<C>(b3a, lane), gv = ld_vec<C>(g3, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int lr = wave * 8 + i, row = r0 + lr;
+            const float4 dy = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+            float4 db = f4_zero(), dg = f4_zero(), dbe = f4_zero();
+            const float4 dpre = ln_bwd_row<C>(upre[i], bv, gv, dy, p.eps, lane, db, dg, dbe);
+            if (row < p.rows) {                              // rows past the end repeat the last row: not counted, not stored
+                f4_add(a_db, db); f4_add(a_dg, dg); f4_add(a_dbeta, dbe);
+                st_row<C>(dpre_out, C, row, lane, dpre);
+                if (acc_out) {
+                    float4 t = dpre;
+                    if (!acc_first) f4_add(t, ld_row<C>(acc_out, C, row, lane));
+                    st_row<C>(acc_out, C, row, lane, t);
+                }
+            }
+            if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, dpre);
+        }
+    }
+    __syncthreads();
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, row = r0 + lr;
+        float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+        a.x *= p.scale; a.y *= p.scale; a.z *= p.scale; a.w *= p.scale;
+        if (row < p.rows) st_row<C>(ds_out, C, row, lane, a);
+    }
+    write_slab<C>(s_red, slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, wave, lane);
+}
+
+// in0 = dXn (ld0), in1 = Xn or null, w0 = W3b image, w1 = w23 image, in2 = u, b0/g0 = b3a, gamma3;
+// out0 = g (when in1), out1 = dpre, out2 = ds, slab, acc_out (+= dpre; overwritten when acc_first)
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_b3(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    __shared__ float4 s_red[PN_THREADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    stage_b3<C, false>(p, s_img, s_stg, s_red, p.in0, p.ld0, p.in1, p.w0, p.w1, p.in2, p.b0, p.g0, p.out0, p.out1, p.out2, p.slab,
+                       p.acc_out, p.acc_first, (int)blockIdx.x * PN_ROWS, wave, lane, mul);
+}
+
+// ---- B1: dh1[v] = LN1bwd(h1[v] + b1a; sum_e dhbar[e] / deg e), dX = [dh1 | dpa] . [W1a ; W2v]  [tail: B3 of the application before]
+// in0 = dhbar [M, C], rowptr / col / wq = incidence CSR by node + entry weights, in1 = h1, b0/g0 = b1a, gamma1, in2 = dpa,
+// w0 = stacked image [W1a ; W2v] (dy W, K = 2 C); out0 = dh1, out1 = dX, slab = [d b1a | d gamma1 | d beta1];
+// tail: in3 = X of this application = Xn of the one before (mask), w1 = W3b image, w2 = w23 image, ld0/in.. see stage_b3:
+//       out2 = g, out3 = dpre, out4 = ds, slab2, acc_out; b1/g1 = b3a, gamma3; out5 = u (read only)
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_b1(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    constexpr int KS2 = 2 * S::KS;
+    __shared__ uint4 s_img[3 * KS2 * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    __shared__ float4 s_red[PN_THREADS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    WStream<KS2, S::NTW, 1> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    const int s_beg = min(r0 + wave * 8, p.rows), s_end = min(s_beg + 8, p.rows);
+    float4 a_db = f4_zero(), a_dg = f4_zero(), a_dbeta = f4_zero();
+    {
+        const float4 bv = ld_vec<C>(p.b0, lane), gv = ld_vec<C>(p.g0, lane);
+        // this row's h1 and dpa are requested a row ahead (they arrive while the row's entries are gathered)
+        float4 nh = ld_row<C>(p.in1, C, s_beg < p.rows ? s_beg : p.rows - 1, lane);
+        float4 nd = ld_row<C>(p.in2, C, s_beg < p.rows ? s_beg : p.rows - 1, lane);
+        gather_range<C>(p.in0, p.rowptr, p.col, p.wq, s_beg, s_end, lane, [&](int i, const float4& dsum, int) {
+            const int row = s_beg + i;
+            const float4 h = nh, dpa = nd;
+            const int nxt = row + 1 < s_end ? row + 1 : row;
+            nh = ld_row<C>(p.in1, C, nxt, lane);
+            nd = ld_row<C>(p.in2, C, nxt, lane);
+            const float4 dh = ln_bwd_row<C>(h, bv, gv, dsum, p.eps, lane, a_db, a_dg, a_dbeta);
+            st_row<C>(p.out0, C, row, lane, dh);
+            if (lane * 4 < C) {
+                a_put<KS2>(s_img, wave * 8 + i, lane, dh);
+                a_put<KS2>(s_img, wave * 8 + i, C / 4 + lane, dpa);
+            }
+        });
+    }
+    for (int i = s_end - s_beg; i < 8; ++i)
+        if (lane * 4 < C) {
+            a_put<KS2>(s_img, wave * 8 + i, lane, f4_zero());
+            a_put<KS2>(s_img, wave * 8 + i, C / 4 + lane, f4_zero());
+        }
+    __syncthreads();
+    f32x16 acc[1][S::NTW];
+    acc_zero<1, S::NTW>(acc);
+    if (mul) {
+        panel_mma<KS2, S::NTW, 1>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    __syncthreads();
+    for (int i = 0; i < 8; ++i) {
+        const int lr = wave * 8 + i, row = r0 + lr;
+        if (row >= p.rows) break;
+        const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
+        if (p.out1) st_row<C>(p.out1, C, row, lane, a);     // (with the tail only the masked gradient g is needed afterwards)
+    }
+    write_slab<C>(s_red, p.slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, wave, lane);
+    if (!p.tail) return;
+    stage_b3<C, true>(p, s_img, s_stg, s_red, nullptr, 0, p.in3, p.w1, p.w2, p.out5, p.b1, p.g1, p.out2, p.out3, p.out4, p.slab2,
+                      p.acc_out, p.acc_first, r0, wave, lane, mul);
+}
+
+inline bool pn_width_ok(int C) { return C == 64 || C == 128 || C == 256; }
+
+}  // namespace
+
+extern "C" size_t hg_conv_panel_slab_bytes(int64_t rows, int32_t C) {
+    if (rows < 0 || C <= 0) return 0;
+    return (size_t)((rows + PN_ROWS - 1) / PN_ROWS) * 3 * (size_t)C * sizeof(float);
+}
+
+extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_) {
+    if (!q) return EQH_ERR_ARG;
+    const int C = q->C;
+    if (!pn_width_ok(C) || q->rows < 0) return EQH_ERR_ARG;
+    if (q->rows >= ((int64_t)1 << 31) - 64) return EQH_ERR_RANGE;
+    if (q->rows == 0) return EQH_OK;
+    const void* ptrs[] = {q->in0, q->in1, q->in2, q->in3, q->w0, q->w1, q->w2, q->w3, q->b0, q->g0, q->be0, q->b1, q->g1, q->be1,
+                          q->bias_out, q->out0, q->out1, q->out2, q->out3, q->out4, q->out5, q->slab, q->slab2, q->acc_out, q->wq};
+    for (const void* x : ptrs)
+        if (!eqh_aligned16(x)) return EQH_ERR_ALIGN;
+    ConvPanelArgs a{};
+    a.rows = (int)q->rows; a.eps = q->eps; a.scale = q->scale; a.relu = q->relu; a.acc_first = q->acc_first; a.tail = q->tail;
+    a.in0 = q->in0; a.in1 = q->in1; a.in2 = q->in2; a.in3 = q->in3; a.ld0 = q->ld0 > 0 ? q->ld0 : C;
+    a.rowptr = q->rowptr; a.col = q->col; a.wq = q->wq;
+    a.w0 = static_cast<const uint4*>(q->w0); a.w1 = static_cast<const uint4*>(q->w1);
+    a.w2 = static_cast<const uint4*>(q->w2); a.w3 = static_cast<const uint4*>(q->w3);
+    a.b0 = q->b0; a.g0 = q->g0; a.be0 = q->be0; a.b1 = q->b1; a.g1 = q->g1; a.be1 = q->be1; a.bias_out = q->bias_out;
+    a.out0 = q->out0; a.out1 = q->out1; a.out2 = q->out2; a.out3 = q->out3; a.out4 = q->out4; a.out5 = q->out5;
+    a.slab = q->slab; a.slab2 = q->slab2; a.acc_out = q->acc_out;
+    if (a.ld0 & 3) return EQH_ERR_ALIGN;
+    const int blocks = (int)((q->rows + PN_ROWS - 1) / PN_ROWS);
+    const dim3 grid(blocks), block(PN_THREADS);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    auto need = [](std::initializer_list<const void*> l) { for (const void* x : l) if (!x) return false; return true; };
+    auto f1_ok = [&](const void* wa, const void* wb, const void* b, const void* g, const void* be, const void* o0, const void* o1, const void* o2) {
+        return need({wa, wb, b, g, be, o0, o1, o2});
+    };
+#define PN_LAUNCH(K)                                                                                   \
+    do {                                                                                               \
+        if (C == 256) hipLaunchKernelGGL(K<256>, grid, block, 0, stream, a);                           \
+        else if (C == 128) hipLaunchKernelGGL(K<128>, grid, block, 0, stream, a);                      \
+        else hipLaunchKernelGGL(K<64>, grid, block, 0, stream, a);                                     \
+        EQH_CHECK_LAUNCH();                                                                            \
+    } while (0)
+    switch (stage) {
+        case HG_CONV_F1:
+            if (!q->in0 || !f1_ok(q->w0, q->w1, q->b0, q->g0, q->be0, q->out0, q->out1, q->out2)) return EQH_ERR_ARG;
+            PN_LAUNCH(k_conv_f1);
+            return EQH_OK;
+        case HG_CONV_F2:
+            if (!need({q->in0, q->rowptr, q->col, q->w0, q->bias_out, q->out0, q->out1})) return EQH_ERR_ARG;
+            PN_LAUNCH(k_conv_f2);
+            return EQH_OK;
+        case HG_CONV_F3:
+            if (!need({q->in0, q->in1, q->w0, q->b0, q->g0, q->be0, q->w1, q->bias_out, q->out0, q->out1, q->out2})) return EQH_ERR_ARG;
+            if (q->tail && !f1_ok(q->w2, q->w3, q->b1, q->g1, q->be1, q->out3, q->out4, q->out5)) return EQH_ERR_ARG;
+            PN_LAUNCH(k_conv_f3);
+            return EQH_OK;
+        case HG_CONV_B3: {
+            if (!need({q->in0, q->w0, q->w1, q->in2, q->b0, q->g0, q->out1, q->out2, q->slab, q->dbias, q->dgamma, q->dbeta})) return EQH_ERR_ARG;
+            if (q->in1 && !q->out0) return EQH_ERR_ARG;
+            PN_LAUNCH(k_conv_b3);
+            return eqh_reduce_slabs3_async(q->slab, blocks, 3 * (int64_t)C, q->dbias, q->dgamma, q->dbeta, C, C, q->accumulate, stream);
+        }
+        case HG_CONV_B1: {
+            if (!need({q->in0, q->rowptr, q->col, q->in1, q->in2, q->b0, q->g0, q->w0, q->out0, q->slab, q->dbias, q->dgamma, q->dbeta}))
+                return EQH_ERR_ARG;
+            if (!q->tail && !q->out1) return EQH_ERR_ARG;
+            if (q->tail && !need({q->in3, q->w1, q->w2, q->out5, q->b1, q->g1, q->out2, q->out3, q->out4, q->slab2, q->dbias2,
+                                  q->dgamma2, q->dbeta2}))
+                return EQH_ERR_ARG;
+            PN_LAUNCH(k_conv_b1);
+            int rc = eqh_reduce_slabs3_async(q->slab, blocks, 3 * (int64_t)C, q->dbias, q->dgamma, q->dbeta, C, C, q->accumulate, stream);
+            if (rc || !q->tail) return rc;
+            return eqh_reduce_slabs3_async(q->slab2, blocks, 3 * (int64_t)C, q->dbias2, q->dgamma2, q->dbeta2, C, C, q->accumulate, stream);
+        }
+        default:
+            return EQH_ERR_ARG;
+    }
+#undef PN_LAUNCH
+}
+
+#ifdef PN_STAMPS
+extern "C" int hg_panel_debug_stamps(void* buf) {
+    unsigned long long* q = static_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(pn_stamp_buf), &q, sizeof(q)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
+#endif
+
+extern "C" size_t hg_panel_pack_bytes(int32_t K, int32_t N) {
+    if (K <= 0 || N <= 0 || (K & 15) || (N & 31)) return 0;
+    return (size_t)K * (size_t)N * 6;
+}
+
+extern "C" int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* stream_) {
+    if (n_items <= 0 || !items) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    for (int i0 = 0; i0 < n_items; i0 += PN_MAXPACK) {
+        PackBatch b;
+        b.n = (n_items - i0 < PN_MAXPACK) ? n_items - i0 : PN_MAXPACK;
+        b.first[0] = 0;
+        for (int i = 0; i < b.n; ++i) {
+            const HgPanelPack& q = items[i0 + i];
+            if (!q.w || !q.dst || q.K <= 0 || q.N <= 0 || q.kstep0 < 0) return EQH_ERR_ARG;
+            if ((q.K & 15) || (q.N & 31) || (q.ld & 3) || !eqh_aligned16(q.w) || !eqh_aligned16(q.dst)) return EQH_ERR_ALIGN;
+            const int total = q.ksteps_total > 0 ? q.ksteps_total : q.K / 16;
+            if (q.kstep0 + q.K / 16 > total) return EQH_ERR_ARG;
+            b.it[i] = PackItem{q.w, q.ld, static_cast<uint4*>(q.dst), q.K, q.N, q.trans ? 1 : 0, q.kstep0, total};
+            b.first[i + 1] = b.first[i] + (q.K / 16) * (q.N / 32);
+        }
+        for (int i = b.n; i < PN_MAXPACK; ++i) { b.it[i] = b.it[0]; b.first[i + 1] = b.first[b.n]; }
+        const int units = b.first[b.n];
+        hipLaunchKernelGGL(k_panel_pack, dim3((units + 3) / 4), dim3(256), 0, stream, b);
+        EQH_CHECK_LAUNCH();
+    }
+    return EQH_OK;
+}
+
+extern "C" int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t C, const void* wpack, float alpha,
+                                 const float* d, int64_t ldd, float beta, const float* bias, int32_t relu, float* c, int64_t ldc,
+                                 void* stream_) {
+    if (rows < 0 || !a || !wpack || !c) return EQH_ERR_ARG;
+    if (!pn_width_ok(C)) return EQH_ERR_ARG;
+    if ((lda & 3) || (ldc & 3) || (d && (ldd & 3)) || !eqh_aligned16(a) || !eqh_aligned16(c) || !eqh_aligned16(d) ||
+        !eqh_aligned16(bias) || !eqh_aligned16(wpack))
+        return EQH_ERR_ALIGN;
+    if (rows >= ((int64_t)1 << 31) - 64) return EQH_ERR_RANGE;
+    if (rows == 0) return EQH_OK;
+    PanelPlain p{a, lda, (int)rows, static_cast<const uint4*>(wpack), alpha, beta, d, ldd, bias, relu, c, ldc};
+    const dim3 grid((unsigned)((rows + PN_ROWS - 1) / PN_ROWS)), block(PN_THREADS);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (C == 256) hipLaunchKernelGGL(k_panel_plain<256>, grid, block, 0, stream, p);
+    else if (C == 128) hipLaunchKernelGGL(k_panel_plain<128>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(k_panel_plain<64>, grid, block, 0, stream, p);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}

@@ -38,8 +38,32 @@ class HgGemmProblem(ctypes.Structure):
                 ("drop_seed", c_void_p), ("drop_p", c_float), ("mean_rows", c_int32)]
 
 
+class HgPanelPack(ctypes.Structure):
+    """HgPanelPack of include/equihgnn_hip.h (one weight of hg_panel_pack)."""
+    _fields_ = [("w", c_void_p), ("ld", c_int64), ("dst", c_void_p), ("K", c_int32), ("N", c_int32), ("trans", c_int32),
+                ("kstep0", c_int32), ("ksteps_total", c_int32)]
+
+
+class HgConvPanel(ctypes.Structure):
+    """HgConvPanel of include/equihgnn_hip.h (operands of one hg_conv_panel stage)."""
+    _fields_ = ([("rows", c_int64), ("C", c_int32), ("eps", c_float), ("scale", c_float), ("relu", c_int32),
+                 ("acc_first", c_int32), ("tail", c_int32), ("accumulate", c_int32)]
+                + [(n, c_void_p) for n in ("in0", "in1", "in2", "in3")] + [("ld0", c_int64)]
+                + [(n, c_void_p) for n in ("rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
+                                           "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2",
+                                           "acc_out", "dbias", "dgamma", "dbeta", "dbias2", "dgamma2", "dbeta2")])
+
+
+HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1 = 1, 2, 3, 4, 5
+
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
 SIGNATURES = {
+    "hg_conv_panel_slab_bytes": (c_size_t, [c_int64, c_int32]),
+    "hg_conv_panel": (c_int32, [c_int32, ctypes.POINTER(HgConvPanel), c_void_p]),
+    "hg_panel_pack_bytes": (c_size_t, [c_int32, c_int32]),
+    "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),
+    "hg_panel_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_float, c_void_p, c_int64, c_float,
+                                    c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "hg_small_mm_batch": (c_int32, [c_int32, ctypes.POINTER(HgSmallMM), c_void_p]),
     "hg_gemm_x6_workspace_bytes": (c_size_t, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32]),
     "hg_gemm_x6_batch": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32, c_void_p, c_size_t, c_void_p]),

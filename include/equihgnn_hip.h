@@ -184,6 +184,66 @@ typedef struct HgSmallMM {
 } HgSmallMM;
 int hg_small_mm_batch(int32_t n_problems, const HgSmallMM* problems, void* stream);
 
+/* Row-panel kernels (csrc/panel.hip) for the conv-sized dense products [rows x C] . [C x C], C = MLP_hidden in {64, 128,
+ * 256}: mlp.py:91-99 as used by conv.py:169-182 (torch.nn.functional.linear + its input gradient in the reference).
+ * hg_panel_pack splits weights ONCE into their three bf16 planes in MFMA operand order (fp32-grade products from six
+ * bf16 MFMAs, as hg_gemm_x6_batch): item i lays B[k][n] = w[n * ld + k] (trans != 0: an nn.Linear weight used as x W^T)
+ * or B[k][n] = w[k * ld + n] (trans == 0: the same weight used as dY W), K x N (K % 16 == 0, N % 32 == 0), into the image
+ * at dst, hg_panel_pack_bytes(K_total, N) bytes; kstep0 / ksteps_total (in units of 16 k; 0 = this item alone) stack
+ * several weights along K in one image.  All items in ONE launch (per 32).
+ * hg_panel_gemm_f32: c = act(alpha * a . B + beta * d + bias), a [rows, C] (lda), B the packed C x C image. */
+typedef struct {
+    const float* w;
+    int64_t ld;
+    void* dst;
+    int32_t K, N, trans, kstep0, ksteps_total;
+} HgPanelPack;
+size_t hg_panel_pack_bytes(int32_t K, int32_t N);
+int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* stream);
+int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t C, const void* wpack, float alpha,
+                      const float* d, int64_t ldd, float beta, const float* bias, int32_t relu, float* c, int64_t ldc,
+                      void* stream);
+
+/* One application of the merged MHNNSConv (conv.py:169-182; layers.MHNNSConv._forward_merged) as panel stages: each launch
+ * takes panels of 32 rows through one to four [C x C] products with the row-wise work between them (bias, ReLU, LayerNorm and
+ * its backward, the gathered means of conv.py:172-173 and their backward) in the same workgroup.  Weight images from
+ * hg_panel_pack ("T": trans != 0, x W^T; "N": trans == 0, dy W).  All row tensors contiguous [rows, C] fp32 unless ld0 says
+ * otherwise for in0.  Stages and their operands:
+ *  HG_CONV_F1  in0 = X (ld0); w0 = W1a T, w1 = W2v T; b0 / g0 / be0 = b1a, gamma1, beta1.
+ *              out0 = h1 = X W1a^T, out1 = h1n = LN1(relu(h1 + b1a)), out2 = pa = X W2v^T.
+ *  HG_CONV_F2  rows = hyperedges; in0 = h1n; rowptr / col = incidence CSR by hyperedge; w0 = w12 T; bias_out = b12.
+ *              out0 = hbar = mean over the hyperedge's nodes of h1n, out1 = qb = hbar w12^T + b12.
+ *  HG_CONV_F3  in0 = s, in1 = cw; scale; w0 = w23 T; b0 / g0 / be0 = b3a, gamma3, beta3; w1 = W3b T; bias_out = b3b; relu.
+ *              out0 = u = scale s w23^T + cw, out1 = x3 = LN3(relu(u + b3a)), out2 = Xn = act(x3 W3b^T + b3b).
+ *              tail != 0: F1 of the next application on Xn (w2 = W1a T, w3 = W2v T, b1 / g1 / be1, out3 = h1, out4 = h1n, out5 = pa).
+ *  HG_CONV_B3  in0 = dXn (ld0), in1 = Xn or NULL (ReLU mask); w0 = W3b N, w1 = w23 N; in2 = u; b0 / g0 = b3a, gamma3; scale.
+ *              out0 = g = dXn [Xn > 0] (with in1), out1 = dpre, out2 = ds = scale dpre w23; acc_out (+)= dpre (acc_first: =);
+ *              dbias / dgamma / dbeta (+)= the LayerNorm's vector gradients (slab: hg_conv_panel_slab_bytes, kept until
+ *              eqh_defer_flush when reductions are deferred).
+ *  HG_CONV_B1  in0 = dhbar; rowptr / col / wq = incidence CSR by node and its entries' 1 / deg(hyperedge); in1 = h1;
+ *              b0 / g0 = b1a, gamma1; in2 = dpa; w0 = [W1a ; W2v] N stacked along K.
+ *              out0 = dh1, out1 = dX = dh1 W1a + dpa W2v (may be NULL with tail); dbias / dgamma / dbeta, slab as B3.
+ *              tail != 0: B3 of the application before on dX (in3 = its Xn = this X, out5 = its u (read), w1 = W3b N, w2 = w23 N,
+ *              b1 / g1 = b3a, gamma3, out2 = g, out3 = dpre, out4 = ds, acc_out, slab2, dbias2 / dgamma2 / dbeta2). */
+enum { HG_CONV_F1 = 1, HG_CONV_F2 = 2, HG_CONV_F3 = 3, HG_CONV_B3 = 4, HG_CONV_B1 = 5 };
+typedef struct {
+    int64_t rows;
+    int32_t C;
+    float eps, scale;
+    int32_t relu, acc_first, tail, accumulate;
+    const float *in0, *in1, *in2, *in3;
+    int64_t ld0;
+    const int32_t *rowptr, *col;
+    const float* wq;
+    const void *w0, *w1, *w2, *w3;
+    const float *b0, *g0, *be0, *b1, *g1, *be1, *bias_out;
+    float *out0, *out1, *out2, *out3, *out4, *out5;
+    float *slab, *slab2, *acc_out;
+    float *dbias, *dgamma, *dbeta, *dbias2, *dgamma2, *dbeta2;
+} HgConvPanel;
+size_t hg_conv_panel_slab_bytes(int64_t rows, int32_t C);
+int hg_conv_panel(int32_t stage, const HgConvPanel* args, void* stream);
+
 /* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
  * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch
  * time it INSIDE a replayed hipGraph; eqh_wall_clock_khz is that clock's rate. */

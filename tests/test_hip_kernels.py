@@ -1763,3 +1763,182 @@ def test_small_mm_batch_products_riders_and_accumulation():
     np.testing.assert_allclose(d(gB), d(gB0) + d(blk).t() @ d(dwc), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(d(gbb), d(gbb0) + d(blk).t() @ d(dbc), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(d(gbo), d(gbo0) + d(dbc), rtol=1e-6, atol=1e-6)
+
+
+# ---- row-panel kernels (csrc/panel.hip) ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 1000, 4736])
+def test_panel_gemm_matches_float64(C, rows):
+    """hg_panel_pack + hg_panel_gemm_f32: x @ W.T (trans) and dy @ W (not trans) from packed bf16 planes against float64, and
+    no worse than the fp32 library GEMM; bias / ReLU / scaled addend epilogue; a column block of a wider weight."""
+    from equihgnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(rows * 7 + C)
+    x = torch.randn(rows, C, device=DEV, generator=g)
+    wide = torch.randn(C, 2 * C, device=DEV, generator=g) * C ** -0.5
+    w = wide[:, C:]                                                   # a column block (ld = 2 C), like W2's node half
+    bias = torch.randn(C, device=DEV, generator=g)
+    d = torch.randn(rows, C, device=DEV, generator=g)
+    img_t, img_n = ops.panel_pack([(w, True), (w, False)])
+    for img, ref_w in ((img_t, w.t()), (img_n, w)):
+        want = x.double() @ ref_w.double()
+        got = ops.panel_gemm(x, img, C)
+        lib = x @ ref_w
+        scale = (x.abs().double() @ ref_w.abs().double())
+        err = ((got.double() - want).abs() / scale).max().item()
+        err_lib = ((lib.double() - want).abs() / scale).max().item()
+        assert err < 4e-7 and err <= 2.0 * err_lib + 3e-8, (err, err_lib)
+    got = ops.panel_gemm(x, img_t, C, alpha=0.5, d=d, beta=2.0, bias=bias, relu=True)
+    want = torch.relu(0.5 * (x.double() @ w.t().double()) + 2.0 * d.double() + bias.double())
+    assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_panel_pack_stacks_weights_along_k():
+    """Two weights stacked along K in one image = the product of the concatenated operand (the [dh1 | dpa] . [W1a ; W2v]
+    input gradient of conv.py:172-176)."""
+    from equihgnn_amd import ops
+    C = 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    a, b = torch.randn(C, C, device=DEV, generator=g), torch.randn(C, C, device=DEV, generator=g)
+    x = torch.randn(100, C, device=DEV, generator=g)
+    (one,) = ops.panel_pack([[(a, False)]])
+    (both,) = ops.panel_pack([[(a, False), (b, False)]])
+    assert both.numel() == 2 * one.numel()
+    # the stacked image interleaves per column tile: tile t holds a's K steps, then b's
+    ks = C // 16
+    per = both.view(C // 32, 2 * ks, 3 * 64 * 16)
+    assert torch.equal(per[:, :ks].reshape(-1), one) and not torch.equal(per[:, ks:].reshape(-1), one)
+    assert torch.allclose(ops.panel_gemm(x, one, C), x @ a, rtol=1e-5, atol=1e-5)
+
+
+def _conv_panel_case(C, n_nodes, n_he, seed):
+    """Random operands of one merged-conv application and its float64 reference (conv.py:169-182 after
+    layers.MHNNSConv._prepare_merged), every intermediate included."""
+    from equihgnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, device=DEV, generator=g) * s
+    nnz = int(2.2 * n_nodes)
+    v = torch.randint(0, n_nodes, (nnz,), device=DEV, generator=g)
+    e = torch.randint(0, n_he, (nnz,), device=DEV, generator=g)
+    by_e, by_v = ops.csr_build(e, v, n_he), ops.csr_build(v, e, n_nodes)
+    P = dict(W1a=rn(C, C, s=C ** -0.5), W2v=rn(C, C, s=C ** -0.5), w12=rn(C, C, s=C ** -0.5), w23=rn(C, C, s=C ** -0.5),
+             W3b=rn(C, C, s=C ** -0.5), b1a=rn(C, s=0.3), g1=1 + rn(C, s=0.2), be1=rn(C, s=0.2), b12=rn(C, s=0.3),
+             b3a=rn(C, s=0.3), g3=1 + rn(C, s=0.2), be3=rn(C, s=0.2), b3b=rn(C, s=0.3))
+    X, cw = rn(n_nodes, C), rn(n_nodes, C, s=0.5)
+    return P, X, cw, v, e, by_e, by_v
+
+
+def _ln64(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * g + b
+
+
+@pytest.mark.parametrize("C,n_nodes,n_he", [(256, 1000, 1100), (64, 333, 350), (128, 97, 64)])
+def test_conv_panel_forward_stages_match_float64(C, n_nodes, n_he):
+    """HG_CONV_F1 / F2 / F3 (with and without the chained F1 tail) against a float64 evaluation of the same formulas."""
+    from equihgnn_amd import hip, ops
+    P, X, cw, v, e, by_e, by_v = _conv_panel_case(C, n_nodes, n_he, 11)
+    d = lambda t: t.double()
+    imgs = ops.panel_pack([(P[k], True) for k in ("W1a", "W2v", "w12", "w23", "W3b")])
+    iW1a, iW2v, iw12, iw23, iW3b = imgs
+    new = lambda r: torch.empty(r, C, device=DEV)
+    h1, h1n, pa = new(n_nodes), new(n_nodes), new(n_nodes)
+    ops.conv_panel(hip.HG_CONV_F1, n_nodes, C, DEV, in0=X, w0=iW1a, w1=iW2v, b0=P["b1a"], g0=P["g1"], be0=P["be1"],
+                   out0=h1, out1=h1n, out2=pa)
+    h1_64 = d(X) @ d(P["W1a"]).t()
+    h1n_64 = _ln64(torch.relu(h1_64 + d(P["b1a"])), d(P["g1"]), d(P["be1"]))
+    pa_64 = d(X) @ d(P["W2v"]).t()
+    assert torch.allclose(d(h1), h1_64, rtol=1e-5, atol=1e-5) and torch.allclose(d(pa), pa_64, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(d(h1n), h1n_64, rtol=1e-4, atol=2e-5)
+    hbar, qb = new(n_he), new(n_he)
+    ops.conv_panel(hip.HG_CONV_F2, n_he, C, DEV, in0=h1n, rowptr=by_e.rowptr, col=by_e.col, w0=iw12, bias_out=P["b12"],
+                   out0=hbar, out1=qb)
+    deg = torch.bincount(e, minlength=n_he).clamp(min=1).double()
+    hbar_64 = torch.zeros(n_he, C, device=DEV, dtype=torch.float64).index_add_(0, e, d(h1n)[v]) / deg[:, None]
+    assert torch.allclose(d(hbar), hbar_64, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(d(qb), d(hbar) @ d(P["w12"]).t() + d(P["b12"]), rtol=1e-5, atol=2e-5)
+    s = torch.randn(n_nodes, C, device=DEV)
+    for tail in (False, True):
+        u, x3, xn = new(n_nodes), new(n_nodes), new(n_nodes)
+        h1b, h1nb, pab = new(n_nodes), new(n_nodes), new(n_nodes)
+        ops.conv_panel(hip.HG_CONV_F3, n_nodes, C, DEV, scale=0.5, relu=True, tail=tail, in0=s, in1=cw, w0=iw23, b0=P["b3a"],
+                       g0=P["g3"], be0=P["be3"], w1=iW3b, bias_out=P["b3b"], out0=u, out1=x3, out2=xn, w2=iW1a, w3=iW2v,
+                       b1=P["b1a"], g1=P["g1"], be1=P["be1"], out3=h1b, out4=h1nb, out5=pab)
+        u_64 = 0.5 * (d(s) @ d(P["w23"]).t()) + d(cw)
+        assert torch.allclose(d(u), u_64, rtol=1e-5, atol=1e-5)
+        x3_64 = _ln64(torch.relu(d(u) + d(P["b3a"])), d(P["g3"]), d(P["be3"]))          # (from the kernel's own u: kinks aside)
+        assert torch.allclose(d(x3), x3_64, rtol=1e-4, atol=2e-5)
+        xn_64 = torch.relu(d(x3) @ d(P["W3b"]).t() + d(P["b3b"]))
+        assert torch.allclose(d(xn), xn_64, rtol=1e-5, atol=2e-5)
+        if tail:
+            assert torch.allclose(d(h1b), d(xn) @ d(P["W1a"]).t(), rtol=1e-5, atol=2e-5)
+            assert torch.allclose(d(pab), d(xn) @ d(P["W2v"]).t(), rtol=1e-5, atol=2e-5)
+            assert torch.allclose(d(h1nb), _ln64(torch.relu(d(h1b) + d(P["b1a"])), d(P["g1"]), d(P["be1"])), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("C,n_nodes,n_he", [(256, 1000, 1100), (64, 333, 350)])
+def test_conv_panel_backward_stages_match_autograd_float64(C, n_nodes, n_he):
+    """HG_CONV_B3 / B1 (and B1 with the chained B3 tail) against float64 autograd of the same formulas; the LayerNorm vector
+    gradients arrive through the slabs."""
+    from equihgnn_amd import hip, ops
+    P, X, cw, v, e, by_e, by_v = _conv_panel_case(C, n_nodes, n_he, 12)
+    d = lambda t: t.double()
+    new = lambda r: torch.empty(r, C, device=DEV)
+    iW3b_n, iw23_n = ops.panel_pack([(P["W3b"], False), (P["w23"], False)])
+    (istack,) = ops.panel_pack([[(P["W1a"], False), (P["W2v"], False)]])
+    g_ = torch.Generator(device=DEV).manual_seed(3)
+    # ---- B3 -------------------------------------------------------------------------------------------------------------------
+    s = torch.randn(n_nodes, C, device=DEV, generator=g_)
+    dxn = torch.randn(n_nodes, C, device=DEV, generator=g_)
+    leaves = {k: d(P[k]).requires_grad_() for k in ("b3a", "g3", "be3")}
+    s64, cw64 = d(s).requires_grad_(), d(cw).requires_grad_()
+    u64 = 0.5 * (s64 @ d(P["w23"]).t()) + cw64
+    x3_64 = _ln64(torch.relu(u64 + leaves["b3a"]), leaves["g3"], leaves["be3"])
+    xn64 = torch.relu(x3_64 @ d(P["W3b"]).t() + d(P["b3b"]))
+    xn64.backward(d(dxn))
+    u, xn = u64.detach().float().contiguous(), xn64.detach().float().contiguous()
+    gout, dpre, ds, acc = new(n_nodes), new(n_nodes), new(n_nodes), torch.ones(n_nodes, C, device=DEV)
+    vec = torch.zeros(3, C, device=DEV)
+    slab = ops.conv_panel_slab(n_nodes, C, DEV)
+    ops.conv_panel(hip.HG_CONV_B3, n_nodes, C, DEV, scale=0.5, acc_first=False, in0=dxn, in1=xn, w0=iW3b_n, w1=iw23_n, in2=u,
+                   b0=P["b3a"], g0=P["g3"], out0=gout, out1=dpre, out2=ds, acc_out=acc, slab=slab, dbias=vec[0], dgamma=vec[1],
+                   dbeta=vec[2])
+    tol = dict(rtol=2e-4, atol=2e-4)
+    assert torch.allclose(d(gout), d(dxn) * (xn64.detach() > 0), rtol=0, atol=0)
+    assert torch.allclose(d(ds), s64.grad, **tol)
+    assert torch.allclose(d(dpre), cw64.grad, **tol) and torch.allclose(d(acc), 1 + cw64.grad, **tol)
+    for i, k in enumerate(("b3a", "g3", "be3")):
+        assert torch.allclose(d(vec[i]), leaves[k].grad, rtol=1e-3, atol=1e-3 * float(leaves[k].grad.abs().max())), k
+    # ---- B1 (alone, then with the B3 tail) ------------------------------------------------------------------------------------
+    dhbar = torch.randn(n_he, C, device=DEV, generator=g_)
+    dpa = torch.randn(n_nodes, C, device=DEV, generator=g_)
+    lv = {k: d(P[k]).requires_grad_() for k in ("b1a", "g1", "be1")}
+    X64 = d(X).requires_grad_()
+    h1_64 = X64 @ d(P["W1a"]).t()
+    h1n_64 = _ln64(torch.relu(h1_64 + lv["b1a"]), lv["g1"], lv["be1"])
+    deg = torch.bincount(e, minlength=n_he).clamp(min=1).double()
+    hbar_64 = torch.zeros(n_he, C, device=DEV, dtype=torch.float64).index_add(0, e, h1n_64[v]) / deg[:, None]
+    pa_64 = X64 @ d(P["W2v"]).t()
+    ((hbar_64 * d(dhbar)).sum() + (pa_64 * d(dpa)).sum()).backward()
+    h1 = h1_64.detach().float().contiguous()
+    ew = ops.entry_weights(by_v, by_e)
+    for tail in (False, True):
+        dh1, dX, vec1, vec3 = new(n_nodes), new(n_nodes), torch.zeros(3, C, device=DEV), torch.zeros(3, C, device=DEV)
+        g2, dpre2, ds2 = new(n_nodes), new(n_nodes), new(n_nodes)
+        slab1, slab3 = ops.conv_panel_slab(n_nodes, C, DEV), ops.conv_panel_slab(n_nodes, C, DEV)
+        xprev = torch.randn(n_nodes, C, device=DEV, generator=g_)       # the previous application's (ReLU) output = this X's mask
+        ops.conv_panel(hip.HG_CONV_B1, n_nodes, C, DEV, scale=0.5, tail=tail, acc_first=True, in0=dhbar, rowptr=by_v.rowptr,
+                       col=by_v.col, wq=ew, in1=h1, b0=P["b1a"], g0=P["g1"], in2=dpa, w0=istack, out0=dh1, out1=dX, slab=slab1,
+                       dbias=vec1[0], dgamma=vec1[1], dbeta=vec1[2], in3=xprev, w1=iW3b_n, w2=iw23_n, out5=u, b1=P["b3a"],
+                       g1=P["g3"], out2=g2, out3=dpre2, out4=ds2, acc_out=acc, slab2=slab3, dbias2=vec3[0], dgamma2=vec3[1],
+                       dbeta2=vec3[2])
+        assert torch.allclose(d(dX), X64.grad, **tol)
+        for i, k in enumerate(("b1a", "g1", "be1")):
+            assert torch.allclose(d(vec1[i]), lv[k].grad, rtol=1e-3, atol=1e-3 * float(lv[k].grad.abs().max())), k
+        if tail:   # = HG_CONV_B3 with dXn = this dX and the mask [xprev > 0]
+            gr, dprer, dsr, vr = new(n_nodes), new(n_nodes), new(n_nodes), torch.zeros(3, C, device=DEV)
+            ops.conv_panel(hip.HG_CONV_B3, n_nodes, C, DEV, scale=0.5, acc_first=True, in0=dX, in1=xprev, w0=iW3b_n, w1=iw23_n,
+                           in2=u, b0=P["b3a"], g0=P["g3"], out0=gr, out1=dprer, out2=dsr, acc_out=new(n_nodes),
+                           slab=ops.conv_panel_slab(n_nodes, C, DEV), dbias=vr[0], dgamma=vr[1], dbeta=vr[2])
+            assert torch.equal(g2, gr) and torch.equal(dpre2, dprer) and torch.equal(ds2, dsr) and torch.equal(vec3, vr)
+            assert torch.equal(acc, dpre2)
