@@ -286,86 +286,179 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
 //            (dpa, dqb = k_inc_bwd_both(ds));  B2 = the plain product dhbar = dqb w12
 //            B1: dh1[v] = LN1bwd(h1[v] + b1a; sum_{e of v} dhbar[e] / deg e)  (prologue),  dX = [dh1 | dpa] . [W1a ; W2v]
 //                [+ B3 of the previous application]
-// Every row-wise step runs in the wave-per-row layout on rowln.h's functions.  The weight / bias / LayerNorm-vector gradients
-// are formed outside from the stored rows (batched weight-gradient launch, column sums) and from the per-workgroup slabs.
+// Row-wise work runs on ROW TILES: a wavefront holds its eight rows of the panel at once, eight lanes per row -- lane
+// (r = lane >> 3, c = lane & 7) has the float4 at columns 32 j + 4 c, j < C / 32 -- so a LayerNorm statistic is a sum over a
+// lane's own registers plus three DPP steps, the sqrt / division of a row is computed once for all eight rows, and a
+// wave-instruction still moves whole 128-byte row segments.  (One wavefront per row, as the stand-alone row kernels have it,
+// spends ~150 instructions per row on 64-lane reductions and per-row scalars: 5.5 us of a 16.7 us F3 launch.)  The
+// arithmetic per element is that of rowln.h (two-pass mean / variance, correctly rounded sqrt and division); only the order
+// of the row sums differs.  The weight / bias / LayerNorm-vector gradients are formed outside from the stored rows (batched
+// weight-gradient launch, column sums) and from the per-workgroup slabs.
 // =============================================================================================================================
+template <int C> struct PnShape {
+    static constexpr int KS = C / 16, NT = C / 32, NTW = (NT + 3) / 4, NJ = C / 32;
+};
+
+template <int C> struct RowTile { float4 v[C / 32]; };
+
+// sum over the eight lanes of a row (every lane gets the total): quad butterflies, then the other quad through the half-row mirror
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_move<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);   // row_half_mirror: lane i <- lane 7 - i of its group of eight
+    return v;
+}
+
+template <int C>
+__device__ __forceinline__ void rt_load(RowTile<C>& t, const float* __restrict__ base, int64_t ld, int row, int c4) {
+#pragma unroll
+    for (int j = 0; j < C / 32; ++j) t.v[j] = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + 32 * j + c4);
+}
+template <int C>
+__device__ __forceinline__ void rt_store(const RowTile<C>& t, float* __restrict__ base, int64_t ld, int row, int c4) {
+#pragma unroll
+    for (int j = 0; j < C / 32; ++j) *reinterpret_cast<float4*>(base + (int64_t)row * ld + 32 * j + c4) = t.v[j];
+}
+template <int C>
+__device__ __forceinline__ void rt_load_vec(RowTile<C>& t, const float* __restrict__ vec, int c4) {
+#pragma unroll
+    for (int j = 0; j < C / 32; ++j) t.v[j] = *reinterpret_cast<const float4*>(vec + 32 * j + c4);
+}
+// the tile's rows -> the A image (K offset kb4 = k / 4 of the tile's first column)
+template <int C, int KS>
+__device__ __forceinline__ void rt_a_put(const RowTile<C>& t, uint4* __restrict__ img, int lrow, int c8, int kb4 = 0) {
+#pragma unroll
+    for (int j = 0; j < C / 32; ++j) a_put<KS>(img, lrow, kb4 + 8 * j + c8, t.v[j]);
+}
+
+// y = gamma * xhat(relu(pre + bias)) + beta per row (mlp.py:93-97)
+template <int C>
+__device__ __forceinline__ void rt_ln_fwd(const RowTile<C>& pre, const RowTile<C>& bias, const RowTile<C>& gam, const RowTile<C>& bet,
+                                          float eps, RowTile<C>& y) {
+    constexpr int NJ = C / 32;
+    const float inv_c = 1.0f / (float)C;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 h = make_float4(pre.v[j].x + bias.v[j].x, pre.v[j].y + bias.v[j].y, pre.v[j].z + bias.v[j].z, pre.v[j].w + bias.v[j].w);
+        h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        y.v[j] = h;
+        s += (h.x + h.y) + (h.z + h.w);
+    }
+    const float mu = row8_sum(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 d = y.v[j];
+        d.x -= mu; d.y -= mu; d.z -= mu; d.w -= mu;
+        y.v[j] = d;
+        ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float r = 1.0f / sqrtf(row8_sum(ss) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        y.v[j].x = fmaf(gam.v[j].x, y.v[j].x * r, bet.v[j].x); y.v[j].y = fmaf(gam.v[j].y, y.v[j].y * r, bet.v[j].y);
+        y.v[j].z = fmaf(gam.v[j].z, y.v[j].z * r, bet.v[j].z); y.v[j].w = fmaf(gam.v[j].w, y.v[j].w * r, bet.v[j].w);
+    }
+}
+
+// dpre = gradient of the pre-activation given dy = d LN output (the formulas of k_rowln_bwd); the lane's terms of d bias,
+// d gamma, d beta are ADDED to a_db / a_dg / a_dbeta when `count` (rows past the end of the matrix are not counted)
+template <int C>
+__device__ __forceinline__ void rt_ln_bwd(const RowTile<C>& pre, const RowTile<C>& bias, const RowTile<C>& gam, const RowTile<C>& dy,
+                                          float eps, bool count, RowTile<C>& dpre, RowTile<C>& a_db, RowTile<C>& a_dg, RowTile<C>& a_dbeta) {
+    constexpr int NJ = C / 32;
+    const float inv_c = 1.0f / (float)C;
+    RowTile<C> x;
+    unsigned pos = 0u;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 h = make_float4(pre.v[j].x + bias.v[j].x, pre.v[j].y + bias.v[j].y, pre.v[j].z + bias.v[j].z, pre.v[j].w + bias.v[j].w);
+        pos |= (((h.x > 0.f) ? 1u : 0u) | ((h.y > 0.f) ? 2u : 0u) | ((h.z > 0.f) ? 4u : 0u) | ((h.w > 0.f) ? 8u : 0u)) << (4 * j);
+        h.x = fmaxf(h.x, 0.f); h.y = fmaxf(h.y, 0.f); h.z = fmaxf(h.z, 0.f); h.w = fmaxf(h.w, 0.f);
+        x.v[j] = h;
+        s += (h.x + h.y) + (h.z + h.w);
+    }
+    const float mu = row8_sum(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 d = x.v[j];
+        d.x -= mu; d.y -= mu; d.z -= mu; d.w -= mu;
+        x.v[j] = d;
+        ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    const float rstd = 1.0f / sqrtf(row8_sum(ss) * inv_c + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 xh = x.v[j];
+        xh.x *= rstd; xh.y *= rstd; xh.z *= rstd; xh.w *= rstd;
+        x.v[j] = xh;
+        float4 d = dy.v[j];
+        if (count) {
+            f4_add(a_dbeta.v[j], d);
+            a_dg.v[j].x = fmaf(d.x, xh.x, a_dg.v[j].x); a_dg.v[j].y = fmaf(d.y, xh.y, a_dg.v[j].y);
+            a_dg.v[j].z = fmaf(d.z, xh.z, a_dg.v[j].z); a_dg.v[j].w = fmaf(d.w, xh.w, a_dg.v[j].w);
+        }
+        d.x *= gam.v[j].x; d.y *= gam.v[j].y; d.z *= gam.v[j].z; d.w *= gam.v[j].w;
+        dpre.v[j] = d;
+        m1 += (d.x + d.y) + (d.z + d.w);
+        m2 += (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
+    }
+    m1 = row8_sum(m1) * inv_c;
+    m2 = row8_sum(m2) * inv_c;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const unsigned b = pos >> (4 * j);
+        const float4 d = dpre.v[j], xh = x.v[j];
+        float4 dx;
+        dx.x = (b & 1u) ? rstd * (d.x - m1 - xh.x * m2) : 0.f;
+        dx.y = (b & 2u) ? rstd * (d.y - m1 - xh.y * m2) : 0.f;
+        dx.z = (b & 4u) ? rstd * (d.z - m1 - xh.z * m2) : 0.f;
+        dx.w = (b & 8u) ? rstd * (d.w - m1 - xh.w * m2) : 0.f;
+        dpre.v[j] = dx;
+        if (count) f4_add(a_db.v[j], dx);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void rt_zero(RowTile<C>& t) {
+#pragma unroll
+    for (int j = 0; j < C / 32; ++j) t.v[j] = f4_zero();
+}
+
+// The workgroup's [d bias | d gamma | d beta]: every lane holds its row's terms; the 32 rows meet through the staging tile and
+// are summed per column in row order (fixed order: bitwise reproducible) -> slab[3][C].  All threads call; the staging tile is
+// free again afterwards.
+template <int C>
+__device__ __forceinline__ void write_slab(float* __restrict__ s_stg, float* __restrict__ slab, const RowTile<C>& a_db, const RowTile<C>& a_dg,
+                                           const RowTile<C>& a_dbeta, int lrow, int c4) {
+#pragma unroll
+    for (int which = 0; which < 3; ++which) {
+        const RowTile<C>& t = which == 0 ? a_db : (which == 1 ? a_dg : a_dbeta);
+        __syncthreads();
+        rt_store<C>(t, s_stg, PN_STG_LD, lrow, c4);
+        __syncthreads();
+        if ((int)threadIdx.x < C) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < PN_ROWS; ++r) acc += s_stg[r * PN_STG_LD + threadIdx.x];
+            slab[which * C + threadIdx.x] = acc;
+        }
+    }
+    __syncthreads();
+}
+
+// A wavefront's eight consecutive CSR rows [s_beg, s_end): sum_q w[q] * src[col[q]] per row, in the wave-per-row layout
+// (lane l: columns 4 l .. 4 l + 3; rows of 1 KB are what a gather should move), rows handed to `sink(i, sum, deg)`.  One
+// chain fetches the row ends and up to 64 entries of the range (a lane each); four gathered rows in flight (the walk of
+// k_gather_ln_bwd, incidence.hip).
 template <int C>
 __device__ __forceinline__ float4 ld_row(const float* __restrict__ base, int64_t ld, int row, int lane) {
     return (lane * 4 < C) ? *reinterpret_cast<const float4*>(base + (int64_t)row * ld + lane * 4) : f4_zero();
 }
-template <int C>
-__device__ __forceinline__ void st_row(float* __restrict__ base, int64_t ld, int row, int lane, const float4& v) {
-    if (lane * 4 < C) *reinterpret_cast<float4*>(base + (int64_t)row * ld + lane * 4) = v;
-}
-template <int C>
-__device__ __forceinline__ float4 ld_vec(const float* __restrict__ v, int lane) {
-    return (lane * 4 < C) ? *reinterpret_cast<const float4*>(v + lane * 4) : f4_zero();
-}
-
-// y = gamma * xhat(relu(pre + bias)) + beta: the arithmetic of k_rowln_fwd (incidence.hip)
-template <int C>
-__device__ __forceinline__ float4 ln_fwd_row(const float4& pre, const float4& bias, const float4& g, const float4& b, float eps, int lane) {
-    Row<1> u, w, x;
-    u.v[0] = pre;
-    w.v[0] = bias;
-    unsigned pos;
-    float rstd;
-    norm_pair<1, true>(u, w, C, lane, 1.0f / (float)C, eps, x, pos, &rstd);
-    return make_float4(fmaf(g.x, x.v[0].x, b.x), fmaf(g.y, x.v[0].y, b.y), fmaf(g.z, x.v[0].z, b.z), fmaf(g.w, x.v[0].w, b.w));
-}
-
-// gradient of the pre-activation given dy = d LN output; adds this row's terms of d bias, d gamma, d beta (k_rowln_bwd's arithmetic)
-template <int C>
-__device__ __forceinline__ float4 ln_bwd_row(const float4& pre, const float4& bias, const float4& gam, const float4& dy, float eps,
-                                              int lane, float4& a_db, float4& a_dg, float4& a_dbeta) {
-    Row<1> u, w, x;
-    u.v[0] = pre;
-    w.v[0] = bias;
-    unsigned pos;
-    float rstd;
-    const float inv_c = 1.0f / (float)C;
-    norm_pair<1, true>(u, w, C, lane, inv_c, eps, x, pos, &rstd);
-    const float4 xh = x.v[0];
-    float4 d = dy;
-    f4_add(a_dbeta, d);
-    a_dg.x = fmaf(d.x, xh.x, a_dg.x); a_dg.y = fmaf(d.y, xh.y, a_dg.y); a_dg.z = fmaf(d.z, xh.z, a_dg.z); a_dg.w = fmaf(d.w, xh.w, a_dg.w);
-    d.x *= gam.x; d.y *= gam.y; d.z *= gam.z; d.w *= gam.w;
-    float m1 = (d.x + d.y) + (d.z + d.w);
-    float m2 = (d.x * xh.x + d.y * xh.y) + (d.z * xh.z + d.w * xh.w);
-    wave_sum2(m1, m2);
-    m1 *= inv_c;
-    m2 *= inv_c;
-    float4 dx;
-    dx.x = (pos & 1u) ? rstd * (d.x - m1 - xh.x * m2) : 0.f;
-    dx.y = (pos & 2u) ? rstd * (d.y - m1 - xh.y * m2) : 0.f;
-    dx.z = (pos & 4u) ? rstd * (d.z - m1 - xh.z * m2) : 0.f;
-    dx.w = (pos & 8u) ? rstd * (d.w - m1 - xh.w * m2) : 0.f;
-    f4_add(a_db, dx);
-    return dx;
-}
-
-// the workgroup's [d bias | d gamma | d beta] partial sums -> its slab, wavefronts combined in a fixed order (all threads call)
-template <int C>
-__device__ __forceinline__ void write_slab(float4* __restrict__ s_red, float* __restrict__ slab, const float4& a_db, const float4& a_dg,
-                                           const float4& a_dbeta, int wave, int lane) {
-#pragma unroll
-    for (int which = 0; which < 3; ++which) {
-        s_red[threadIdx.x] = which == 0 ? a_db : (which == 1 ? a_dg : a_dbeta);
-        __syncthreads();
-        if (wave == 0 && lane * 4 < C) {
-            float4 t = s_red[lane];
-            f4_add(t, s_red[64 + lane]);
-            f4_add(t, s_red[128 + lane]);
-            f4_add(t, s_red[192 + lane]);
-            *reinterpret_cast<float4*>(slab + which * C + lane * 4) = t;
-        }
-        __syncthreads();
-    }
-}
-
-// A wavefront's eight consecutive CSR rows [s_beg, s_end): sum_q w[q] * src[col[q]] per row, rows handed to `sink(i, sum, deg)`.
-// One chain fetches the row ends and up to 64 entries of the range (a lane each); four gathered rows in flight (the walk of
-// k_gather_ln_bwd, incidence.hip).
 template <int C, typename Sink>
 __device__ __forceinline__ void gather_range(const float* __restrict__ src, const int* __restrict__ rowptr, const int* __restrict__ col,
                                              const float* __restrict__ wq, int s_beg, int s_end, int lane, Sink&& sink) {
@@ -429,16 +522,26 @@ struct ConvPanelArgs {
     float* acc_out;
 };
 
-template <int C> struct PnShape {
-    static constexpr int KS = C / 16, NT = C / 32, NTW = (NT + 3) / 4;
+// lane -> (its row of the wavefront's eight, its column quad); rows past the end of the matrix are clamped for loads
+struct RtPos {
+    int lrow, c8, c4, row, rowc;
+    bool live;
+    __device__ __forceinline__ RtPos(int r0, int rows, int wave, int lane) {
+        lrow = wave * 8 + (lane >> 3);
+        c8 = lane & 7;
+        c4 = c8 * 4;
+        row = r0 + lrow;
+        live = row < rows;
+        rowc = live ? row : rows - 1;
+    }
 };
 
 // ---- F1: X -> h1 (raw), h1n = LN1(relu(h1 + b1a)), pa -------------------------------------------------------------------------
-// in0 = X (ld0), w0 = W1a image (x W^T), w1 = W2v image, b0/g0/be0 = b1a, gamma1, beta1; out0 = h1, out1 = h1n, out2 = pa
+// the A image holds X's panel; w_a = W1a image (x W^T), w_b = W2v image
 template <int C>
 __device__ __forceinline__ void stage_f1(const ConvPanelArgs& p, uint4* __restrict__ s_img, float* __restrict__ s_stg,
                                          float* __restrict__ s_stg2, const uint4* w_a, const uint4* w_b, const float* b1a,
-                                         const float* g1, const float* be1, float* h1, float* h1n, float* pa, int r0, int wave,
+                                         const float* g1, const float* be1, float* h1, float* h1n, float* pa, const RtPos& P, int wave,
                                          int lane, bool mul) {
     using S = PnShape<C>;
     WStream<S::KS, S::NTW, 2> ws;
@@ -454,16 +557,18 @@ __device__ __forceinline__ void stage_f1(const ConvPanelArgs& p, uint4* __restri
         acc_to_staging<S::NTW>(s_stg2, acc[1], wave, lane);
     }
     __syncthreads();
-    const float4 bv = ld_vec<C>(b1a, lane), gv = ld_vec<C>(g1, lane), bev = ld_vec<C>(be1, lane);
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, row = r0 + lr;
-        if (row >= p.rows) break;
-        const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-        const float4 b = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg2 + lr * PN_STG_LD + lane * 4) : f4_zero();
-        st_row<C>(h1, C, row, lane, a);
-        st_row<C>(pa, C, row, lane, b);
-        st_row<C>(h1n, C, row, lane, ln_fwd_row<C>(a, bv, gv, bev, p.eps, lane));
+    RowTile<C> a, b, bv, gv, bev, y;
+    rt_load<C>(a, s_stg, PN_STG_LD, P.lrow, P.c4);
+    rt_load<C>(b, s_stg2, PN_STG_LD, P.lrow, P.c4);
+    rt_load_vec<C>(bv, b1a, P.c4);
+    rt_load_vec<C>(gv, g1, P.c4);
+    rt_load_vec<C>(bev, be1, P.c4);
+    if (P.live) {
+        rt_store<C>(a, h1, C, P.row, P.c4);
+        rt_store<C>(b, pa, C, P.row, P.c4);
     }
+    rt_ln_fwd<C>(a, bv, gv, bev, p.eps, y);
+    if (P.live) rt_store<C>(y, h1n, C, P.row, P.c4);
 }
 
 template <int C>
@@ -473,21 +578,13 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ float s_stg[PN_ROWS * PN_STG_LD];
     __shared__ float s_stg2[PN_ROWS * PN_STG_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
-    float4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = r0 + wave * 8 + i;
-        row = row < p.rows ? row : p.rows - 1;
-        v[i] = ld_row<C>(p.in0, p.ld0, row, lane);
-    }
-    if (lane * 4 < C) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a_put<S::KS>(s_img, wave * 8 + i, lane, v[i]);
-    }
+    RowTile<C> x;
+    rt_load<C>(x, p.in0, p.ld0, P.rowc, P.c4);
+    rt_a_put<C, S::KS>(x, s_img, P.lrow, P.c8);
     __syncthreads();
-    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w0, p.w1, p.b0, p.g0, p.be0, p.out0, p.out1, p.out2, r0, wave, lane, mul);
+    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w0, p.w1, p.b0, p.g0, p.be0, p.out0, p.out1, p.out2, P, wave, lane, mul);
 }
 
 // ---- F2: hbar[e] = mean over the hyperedge's nodes of h1n, qb = hbar w12^T + b12 ---------------------------------------------
@@ -499,6 +596,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ float s_stg[PN_ROWS * PN_STG_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (int)blockIdx.x * PN_ROWS;
+    const RtPos P(r0, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
     WStream<S::KS, S::NTW, 1> ws;
     ws.init(0, p.w0, mul ? wave : 0, lane);
@@ -508,8 +606,10 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     gather_range<C>(p.in0, p.rowptr, p.col, nullptr, s_beg, s_end, lane, [&](int i, const float4& sum, int deg) {
         const float den = deg > 1 ? (float)deg : 1.0f;
         const float4 m = make_float4(sum.x / den, sum.y / den, sum.z / den, sum.w / den);
-        st_row<C>(p.out0, C, s_beg + i, lane, m);
-        if (lane * 4 < C) a_put<S::KS>(s_img, wave * 8 + i, lane, m);
+        if (lane * 4 < C) {
+            *reinterpret_cast<float4*>(p.out0 + (int64_t)(s_beg + i) * C + lane * 4) = m;
+            a_put<S::KS>(s_img, wave * 8 + i, lane, m);
+        }
     });
     for (int i = s_end - s_beg; i < 8; ++i)                 // rows past the end of the matrix: zeros for the MFMA
         if (lane * 4 < C) a_put<S::KS>(s_img, wave * 8 + i, lane, f4_zero());
@@ -521,14 +621,12 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
     __syncthreads();
-    const float4 bv = ld_vec<C>(p.bias_out, lane);
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, row = r0 + lr;
-        if (row >= p.rows) break;
-        float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-        f4_add(a, bv);
-        st_row<C>(p.out1, C, row, lane, a);
-    }
+    RowTile<C> a, bv;
+    rt_load<C>(a, s_stg, PN_STG_LD, P.lrow, P.c4);
+    rt_load_vec<C>(bv, p.bias_out, P.c4);
+#pragma unroll
+    for (int j = 0; j < S::NJ; ++j) f4_add(a.v[j], bv.v[j]);
+    if (P.live) rt_store<C>(a, p.out1, C, P.row, P.c4);
 }
 
 // ---- F3: s -> u = scale * (s w23^T) + cw, x3 = LN3(relu(u + b3a)), Xn = act(x3 W3b^T + b3b)  [tail: F1 on Xn] ----------------
@@ -541,29 +639,16 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ float s_stg[PN_ROWS * PN_STG_LD];
     __shared__ float s_stg2[PN_ROWS * PN_STG_LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (int)blockIdx.x * PN_ROWS;
+    const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
-    float4 v[8], cwv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = r0 + wave * 8 + i;
-        row = row < p.rows ? row : p.rows - 1;
-        v[i] = ld_row<C>(p.in0, C, row, lane);
-    }
+    RowTile<C> t, cw;
+    rt_load<C>(t, p.in0, C, P.rowc, P.c4);
     WStream<S::KS, S::NTW, 1> ws;
     ws.init(0, p.w0, mul ? wave : 0, lane);
     ws.prime();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = r0 + wave * 8 + i;
-        row = row < p.rows ? row : p.rows - 1;
-        cwv[i] = ld_row<C>(p.in1, C, row, lane);
-    }
+    rt_load<C>(cw, p.in1, C, P.rowc, P.c4);
     __builtin_amdgcn_sched_barrier(0);
-    if (lane * 4 < C) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a_put<S::KS>(s_img, wave * 8 + i, lane, v[i]);
-    }
+    rt_a_put<C, S::KS>(t, s_img, P.lrow, P.c8);
     __syncthreads();
     f32x16 acc[1][S::NTW];
     acc_zero<1, S::NTW>(acc);
@@ -577,20 +662,21 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     {
-        const float4 bv = ld_vec<C>(p.b0, lane), gv = ld_vec<C>(p.g0, lane), bev = ld_vec<C>(p.be0, lane);
+        RowTile<C> bv, gv, bev, x3;
+        rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+        rt_load_vec<C>(bv, p.b0, P.c4);
+        rt_load_vec<C>(gv, p.g0, P.c4);
+        rt_load_vec<C>(bev, p.be0, P.c4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lr = wave * 8 + i, row = r0 + lr;
-            const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-            const float4 u = make_float4(fmaf(p.scale, a.x, cwv[i].x), fmaf(p.scale, a.y, cwv[i].y), fmaf(p.scale, a.z, cwv[i].z),
-                                         fmaf(p.scale, a.w, cwv[i].w));
-            const float4 x3 = ln_fwd_row<C>(u, bv, gv, bev, p.eps, lane);
-            if (row < p.rows) {
-                st_row<C>(p.out0, C, row, lane, u);
-                st_row<C>(p.out1, C, row, lane, x3);
-            }
-            if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, x3);      // (every wavefront has left the MFMA loop: barrier above)
+        for (int j = 0; j < S::NJ; ++j)
+            t.v[j] = make_float4(fmaf(p.scale, t.v[j].x, cw.v[j].x), fmaf(p.scale, t.v[j].y, cw.v[j].y), fmaf(p.scale, t.v[j].z, cw.v[j].z),
+                                 fmaf(p.scale, t.v[j].w, cw.v[j].w));
+        rt_ln_fwd<C>(t, bv, gv, bev, p.eps, x3);
+        if (P.live) {
+            rt_store<C>(t, p.out0, C, P.row, P.c4);
+            rt_store<C>(x3, p.out1, C, P.row, P.c4);
         }
+        rt_a_put<C, S::KS>(x3, s_img, P.lrow, P.c8);       // (every wavefront has left the MFMA loop: barrier above)
     }
     __syncthreads();
     acc_zero<1, S::NTW>(acc);
@@ -600,20 +686,20 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     }
     __syncthreads();
     {
-        const float4 bv = ld_vec<C>(p.bias_out, lane);
+        RowTile<C> bv;
+        rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+        rt_load_vec<C>(bv, p.bias_out, P.c4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lr = wave * 8 + i, row = r0 + lr;
-            float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-            f4_add(a, bv);
-            if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            if (row < p.rows) st_row<C>(p.out2, C, row, lane, a);
-            if (p.tail && lane * 4 < C) a_put<S::KS>(s_img, lr, lane, a);
+        for (int j = 0; j < S::NJ; ++j) {
+            f4_add(t.v[j], bv.v[j]);
+            if (p.relu) { t.v[j].x = fmaxf(t.v[j].x, 0.f); t.v[j].y = fmaxf(t.v[j].y, 0.f); t.v[j].z = fmaxf(t.v[j].z, 0.f); t.v[j].w = fmaxf(t.v[j].w, 0.f); }
         }
+        if (P.live) rt_store<C>(t, p.out2, C, P.row, P.c4);
+        if (p.tail) rt_a_put<C, S::KS>(t, s_img, P.lrow, P.c8);
     }
     if (!p.tail) return;
     __syncthreads();
-    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w2, p.w3, p.b1, p.g1, p.be1, p.out3, p.out4, p.out5, r0, wave, lane, mul);
+    stage_f1<C>(p, s_img, s_stg, s_stg2, p.w2, p.w3, p.b1, p.g1, p.be1, p.out3, p.out4, p.out5, P, wave, lane, mul);
 }
 
 // ---- B3: dXn -> g = dXn * [Xn > 0], dx3 = g W3b, dpre = LN3bwd(u + b3a; dx3), ds = scale * dpre w23 --------------------------
@@ -621,44 +707,32 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
 // w_a = W3b image (dy W), w_b = w23 image (dy W); slab = [d b3a | d gamma3 | d beta3] of this workgroup; acc_out += dpre
 template <int C, bool FROM_STAGING>
 __device__ __forceinline__ void stage_b3(const ConvPanelArgs& p, uint4* __restrict__ s_img, float* __restrict__ s_stg,
-                                         float4* __restrict__ s_red, const float* dxn, int64_t ld_dxn, const float* xmask,
-                                         const uint4* w_a, const uint4* w_b, const float* u_pre, const float* b3a, const float* g3,
-                                         float* g_out, float* dpre_out, float* ds_out, float* slab, float* acc_out, int acc_first,
-                                         int r0, int wave, int lane, bool mul) {
+                                         const float* dxn, int64_t ld_dxn, const float* xmask, const uint4* w_a, const uint4* w_b,
+                                         const float* u_pre, const float* b3a, const float* g3, float* g_out, float* dpre_out,
+                                         float* ds_out, float* slab, float* acc_out, int acc_first, const RtPos& P, int wave, int lane,
+                                         bool mul) {
     using S = PnShape<C>;
-    float4 v[8], m[8];
+    RowTile<C> t, upre;
+    if constexpr (FROM_STAGING) rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+    else rt_load<C>(t, dxn, ld_dxn, P.rowc, P.c4);
+    if (xmask) {
+        RowTile<C> m;
+        rt_load<C>(m, xmask, C, P.rowc, P.c4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i;
-        int row = r0 + lr;
-        row = row < p.rows ? row : p.rows - 1;
-        if constexpr (FROM_STAGING)
-            v[i] = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-        else
-            v[i] = ld_row<C>(dxn, ld_dxn, row, lane);
-        m[i] = xmask ? ld_row<C>(xmask, C, row, lane) : make_float4(1.f, 1.f, 1.f, 1.f);
+        for (int j = 0; j < S::NJ; ++j) {
+            t.v[j].x = m.v[j].x > 0.f ? t.v[j].x : 0.f; t.v[j].y = m.v[j].y > 0.f ? t.v[j].y : 0.f;
+            t.v[j].z = m.v[j].z > 0.f ? t.v[j].z : 0.f; t.v[j].w = m.v[j].w > 0.f ? t.v[j].w : 0.f;
+        }
     }
     WStream<S::KS, S::NTW, 1> ws;
     ws.init(0, w_a, mul ? wave : 0, lane);
     ws.prime();
-    float4 upre[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int row = r0 + wave * 8 + i;
-        row = row < p.rows ? row : p.rows - 1;
-        upre[i] = ld_row<C>(u_pre, C, row, lane);
-    }
+    rt_load<C>(upre, u_pre, C, P.rowc, P.c4);
     __builtin_amdgcn_sched_barrier(0);
-    // (FROM_STAGING: a wavefront reads its own rows of the staging tile here and the tile is next written after the barrier
-    // below, so no barrier is needed in between)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, row = r0 + lr;
-        float4 g = v[i];
-        g.x = m[i].x > 0.f ? g.x : 0.f; g.y = m[i].y > 0.f ? g.y : 0.f; g.z = m[i].z > 0.f ? g.z : 0.f; g.w = m[i].w > 0.f ? g.w : 0.f;
-        if (g_out && row < p.rows) st_row<C>(g_out, C, row, lane, g);
-        if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, g);
-    }
+    if (g_out && P.live) rt_store<C>(t, g_out, C, P.row, P.c4);
+    // (FROM_STAGING: a wavefront reads its own rows of the staging tile above and the tile is next written after the barrier
+    // below; the A image was last read before the barriers of the caller's slab reduction)
+    rt_a_put<C, S::KS>(t, s_img, P.lrow, P.c8);
     __syncthreads();
     f32x16 acc[1][S::NTW];
     acc_zero<1, S::NTW>(acc);
@@ -670,26 +744,29 @@ __device__ __forceinline__ void stage_b3(const ConvPanelArgs& p, uint4* __restri
     ws.prime();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    float4 a_db = f4_zero(), a_dg = f4_zero(), a_dbeta = f4_zero();
+    RowTile<C> a_db, a_dg, a_dbeta;
+    rt_zero<C>(a_db); rt_zero<C>(a_dg); rt_zero<C>(a_dbeta);
     {
-        const float4 bv = ld_vec<C>(b3a, lane), gv = ld_vec<C>(g3, lane);
+        RowTile<C> bv, gv, dpre;
+        rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+        rt_load_vec<C>(bv, b3a, P.c4);
+        rt_load_vec<C>(gv, g3, P.c4);
+        rt_ln_bwd<C>(upre, bv, gv, t, p.eps, P.live, dpre, a_db, a_dg, a_dbeta);
+        if (P.live) {
+            rt_store<C>(dpre, dpre_out, C, P.row, P.c4);
+            if (acc_out) {
+                if (!acc_first) {
+                    RowTile<C> o;
+                    rt_load<C>(o, acc_out, C, P.row, P.c4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int lr = wave * 8 + i, row = r0 + lr;
-            const float4 dy = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-            float4 db = f4_zero(), dg = f4_zero(), dbe = f4_zero();
-            const float4 dpre = ln_bwd_row<C>(upre[i], bv, gv, dy, p.eps, lane, db, dg, dbe);
-            if (row < p.rows) {                              // rows past the end repeat the last row: not counted, not stored
-                f4_add(a_db, db); f4_add(a_dg, dg); f4_add(a_dbeta, dbe);
-                st_row<C>(dpre_out, C, row, lane, dpre);
-                if (acc_out) {
-                    float4 t = dpre;
-                    if (!acc_first) f4_add(t, ld_row<C>(acc_out, C, row, lane));
-                    st_row<C>(acc_out, C, row, lane, t);
+                    for (int j = 0; j < S::NJ; ++j) f4_add(o.v[j], dpre.v[j]);
+                    rt_store<C>(o, acc_out, C, P.row, P.c4);
+                } else {
+                    rt_store<C>(dpre, acc_out, C, P.row, P.c4);
                 }
             }
-            if (lane * 4 < C) a_put<S::KS>(s_img, lr, lane, dpre);
         }
+        rt_a_put<C, S::KS>(dpre, s_img, P.lrow, P.c8);
     }
     __syncthreads();
     acc_zero<1, S::NTW>(acc);
@@ -698,14 +775,11 @@ __device__ __forceinline__ void stage_b3(const ConvPanelArgs& p, uint4* __restri
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
     __syncthreads();
+    rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, row = r0 + lr;
-        float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-        a.x *= p.scale; a.y *= p.scale; a.z *= p.scale; a.w *= p.scale;
-        if (row < p.rows) st_row<C>(ds_out, C, row, lane, a);
-    }
-    write_slab<C>(s_red, slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, wave, lane);
+    for (int j = 0; j < S::NJ; ++j) { t.v[j].x *= p.scale; t.v[j].y *= p.scale; t.v[j].z *= p.scale; t.v[j].w *= p.scale; }
+    if (P.live) rt_store<C>(t, ds_out, C, P.row, P.c4);
+    write_slab<C>(s_stg, slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, P.lrow, P.c4);
 }
 
 // in0 = dXn (ld0), in1 = Xn or null, w0 = W3b image, w1 = w23 image, in2 = u, b0/g0 = b3a, gamma3;
@@ -715,58 +789,54 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     using S = PnShape<C>;
     __shared__ uint4 s_img[3 * S::KS * 64];
     __shared__ float s_stg[PN_ROWS * PN_STG_LD];
-    __shared__ float4 s_red[PN_THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
-    stage_b3<C, false>(p, s_img, s_stg, s_red, p.in0, p.ld0, p.in1, p.w0, p.w1, p.in2, p.b0, p.g0, p.out0, p.out1, p.out2, p.slab,
-                       p.acc_out, p.acc_first, (int)blockIdx.x * PN_ROWS, wave, lane, mul);
+    stage_b3<C, false>(p, s_img, s_stg, p.in0, p.ld0, p.in1, p.w0, p.w1, p.in2, p.b0, p.g0, p.out0, p.out1, p.out2, p.slab,
+                       p.acc_out, p.acc_first, P, wave, lane, mul);
 }
 
 // ---- B1: dh1[v] = LN1bwd(h1[v] + b1a; sum_e dhbar[e] / deg e), dX = [dh1 | dpa] . [W1a ; W2v]  [tail: B3 of the application before]
 // in0 = dhbar [M, C], rowptr / col / wq = incidence CSR by node + entry weights, in1 = h1, b0/g0 = b1a, gamma1, in2 = dpa,
 // w0 = stacked image [W1a ; W2v] (dy W, K = 2 C); out0 = dh1, out1 = dX, slab = [d b1a | d gamma1 | d beta1];
-// tail: in3 = X of this application = Xn of the one before (mask), w1 = W3b image, w2 = w23 image, ld0/in.. see stage_b3:
-//       out2 = g, out3 = dpre, out4 = ds, slab2, acc_out; b1/g1 = b3a, gamma3; out5 = u (read only)
+// tail: in3 = X of this application = Xn of the one before (mask), w1 = W3b image, w2 = w23 image, out5 = its u (read),
+//       b1/g1 = b3a, gamma3; out2 = g, out3 = dpre, out4 = ds, slab2, acc_out
 template <int C>
 __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_conv_b1(const ConvPanelArgs p) {
     using S = PnShape<C>;
     constexpr int KS2 = 2 * S::KS;
     __shared__ uint4 s_img[3 * KS2 * 64];
     __shared__ float s_stg[PN_ROWS * PN_STG_LD];
-    __shared__ float4 s_red[PN_THREADS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (int)blockIdx.x * PN_ROWS;
+    const RtPos P(r0, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
     WStream<KS2, S::NTW, 1> ws;
     ws.init(0, p.w0, mul ? wave : 0, lane);
     ws.prime();
+    RowTile<C> h, dpa;
+    rt_load<C>(h, p.in1, C, P.rowc, P.c4);
+    rt_load<C>(dpa, p.in2, C, P.rowc, P.c4);
     __builtin_amdgcn_sched_barrier(0);
+    // the gathered sums of the wavefront's eight rows go through ITS rows of the staging tile into the row-tile layout
     const int s_beg = min(r0 + wave * 8, p.rows), s_end = min(s_beg + 8, p.rows);
-    float4 a_db = f4_zero(), a_dg = f4_zero(), a_dbeta = f4_zero();
-    {
-        const float4 bv = ld_vec<C>(p.b0, lane), gv = ld_vec<C>(p.g0, lane);
-        // this row's h1 and dpa are requested a row ahead (they arrive while the row's entries are gathered)
-        float4 nh = ld_row<C>(p.in1, C, s_beg < p.rows ? s_beg : p.rows - 1, lane);
-        float4 nd = ld_row<C>(p.in2, C, s_beg < p.rows ? s_beg : p.rows - 1, lane);
-        gather_range<C>(p.in0, p.rowptr, p.col, p.wq, s_beg, s_end, lane, [&](int i, const float4& dsum, int) {
-            const int row = s_beg + i;
-            const float4 h = nh, dpa = nd;
-            const int nxt = row + 1 < s_end ? row + 1 : row;
-            nh = ld_row<C>(p.in1, C, nxt, lane);
-            nd = ld_row<C>(p.in2, C, nxt, lane);
-            const float4 dh = ln_bwd_row<C>(h, bv, gv, dsum, p.eps, lane, a_db, a_dg, a_dbeta);
-            st_row<C>(p.out0, C, row, lane, dh);
-            if (lane * 4 < C) {
-                a_put<KS2>(s_img, wave * 8 + i, lane, dh);
-                a_put<KS2>(s_img, wave * 8 + i, C / 4 + lane, dpa);
-            }
-        });
-    }
+    gather_range<C>(p.in0, p.rowptr, p.col, p.wq, s_beg, s_end, lane, [&](int i, const float4& dsum, int) {
+        if (lane * 4 < C) *reinterpret_cast<float4*>(s_stg + (wave * 8 + i) * PN_STG_LD + lane * 4) = dsum;
+    });
     for (int i = s_end - s_beg; i < 8; ++i)
-        if (lane * 4 < C) {
-            a_put<KS2>(s_img, wave * 8 + i, lane, f4_zero());
-            a_put<KS2>(s_img, wave * 8 + i, C / 4 + lane, f4_zero());
-        }
+        if (lane * 4 < C) *reinterpret_cast<float4*>(s_stg + (wave * 8 + i) * PN_STG_LD + lane * 4) = f4_zero();
+    RowTile<C> a_db, a_dg, a_dbeta;
+    rt_zero<C>(a_db); rt_zero<C>(a_dg); rt_zero<C>(a_dbeta);
+    {
+        RowTile<C> dsum, bv, gv, dh;
+        rt_load<C>(dsum, s_stg, PN_STG_LD, P.lrow, P.c4);      // (the wavefront's own writes: program order, no barrier)
+        rt_load_vec<C>(bv, p.b0, P.c4);
+        rt_load_vec<C>(gv, p.g0, P.c4);
+        rt_ln_bwd<C>(h, bv, gv, dsum, p.eps, P.live, dh, a_db, a_dg, a_dbeta);
+        if (P.live) rt_store<C>(dh, p.out0, C, P.row, P.c4);
+        rt_a_put<C, KS2>(dh, s_img, P.lrow, P.c8, 0);
+        rt_a_put<C, KS2>(dpa, s_img, P.lrow, P.c8, C / 4);
+    }
     __syncthreads();
     f32x16 acc[1][S::NTW];
     acc_zero<1, S::NTW>(acc);
@@ -775,16 +845,15 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
     __syncthreads();
-    for (int i = 0; i < 8; ++i) {
-        const int lr = wave * 8 + i, row = r0 + lr;
-        if (row >= p.rows) break;
-        const float4 a = (lane * 4 < C) ? *reinterpret_cast<const float4*>(s_stg + lr * PN_STG_LD + lane * 4) : f4_zero();
-        if (p.out1) st_row<C>(p.out1, C, row, lane, a);     // (with the tail only the masked gradient g is needed afterwards)
-    }
-    write_slab<C>(s_red, p.slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, wave, lane);
+    RowTile<C> dx;
+    rt_load<C>(dx, s_stg, PN_STG_LD, P.lrow, P.c4);
+    if (p.out1 && P.live) rt_store<C>(dx, p.out1, C, P.row, P.c4);     // (with the tail only the masked gradient g is needed afterwards)
+    write_slab<C>(s_stg, p.slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, P.lrow, P.c4);
     if (!p.tail) return;
-    stage_b3<C, true>(p, s_img, s_stg, s_red, nullptr, 0, p.in3, p.w1, p.w2, p.out5, p.b1, p.g1, p.out2, p.out3, p.out4, p.slab2,
-                      p.acc_out, p.acc_first, r0, wave, lane, mul);
+    // the tail starts from dX, which the slab reduction has overwritten in the staging tile: back from registers
+    rt_store<C>(dx, s_stg, PN_STG_LD, P.lrow, P.c4);
+    stage_b3<C, true>(p, s_img, s_stg, nullptr, 0, p.in3, p.w1, p.w2, p.out5, p.b1, p.g1, p.out2, p.out3, p.out4, p.slab2,
+                      p.acc_out, p.acc_first, P, wave, lane, mul);
 }
 
 inline bool pn_width_ok(int C) { return C == 64 || C == 128 || C == 256; }

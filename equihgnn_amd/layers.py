@@ -323,6 +323,20 @@ class MHNNSConv(nn.Module):
         x = ops.linear_add_relu_ln(s, m["w23"], m["cw"], m["scale"], W3.lins[0].bias, n3.weight, n3.bias, n3.eps, fan=m["fan"])
         return ops.linear(x, W3.lins[1].weight, W3.lins[1].bias, relu=relu_out)
 
+    def stack_supported(self, X, residual) -> bool:
+        """Whether forward_stack applies: the merged path (``residual`` from prepare()) at a width the panel kernels take."""
+        return (isinstance(residual, dict) and not (self.training and self.dropout > 0)
+                and ops.conv_stack_supported(X, self.W1.lins[0].weight.shape[0]))
+
+    def forward_stack(self, X, index: HyperIndex, residual, n_layers: int, relu_out: bool):
+        """``n_layers`` applications of the layer (the wrappers' loop, equihnn_egnn.py:160-165: conv -> activation ->
+        dropout with p = 0) as one autograd node on the row-panel kernels (ops.merged_conv_stack)."""
+        m = residual
+        if X is m["x0"]:
+            X = m["x0_pass"]
+        return ops.merged_conv_stack(X, m["cw"], self.W1, self.W2, self.W3, m["w12"], m["b12"], m["w23"], index, n_layers,
+                                     m["scale"], relu_out)
+
     def forward(self, X, index: HyperIndex, X0, residual=None, relu_out=False):
         """``relu_out``: return relu(output) (the wrappers' activation, fused into the last GEMM); only with the
         dict ``residual`` of the merged path."""

@@ -19,6 +19,22 @@ from .registry import registry
 _ACT = {"Id": nn.Identity, "relu": nn.ReLU, "prelu": nn.PReLU}
 
 
+def _conv_layers(model, x, index, x0, res, fuse_act, taps):
+    """The wrappers' loop over the shared conv layer (equihnn_egnn.py:160-165, mhnn.py:208-212): conv -> activation ->
+    dropout, ``All_num_layers`` times.  With the merged residual, an inactive dropout and the ReLU fused, all applications
+    run as ONE autograd node on the row-panel kernels (MHNNSConv.forward_stack)."""
+    drop_off = not (model.dropout.training and model.dropout.p > 0)
+    if fuse_act and taps is None and drop_off and model.conv.stack_supported(x, res):
+        return model.conv.forward_stack(x, index, res, model.nlayer, relu_out=True)
+    for i in range(model.nlayer):
+        x = model.conv(model.dropout(x), index, x0, res, relu_out=fuse_act)
+        if taps is not None:
+            taps[f"conv{i}"] = x
+        if not fuse_act:
+            x = model.act(x)
+    return x
+
+
 @registry.register_model("egnn_equihnns")
 class EGNNEquiHNNS(nn.Module):
     """equihnn_egnn.py:98-169: AtomEncoder -> EGNN (once) -> shared MHNNSConv x L -> pool -> head."""
@@ -56,12 +72,7 @@ class EGNNEquiHNNS(nn.Module):
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
-        for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
-            if taps is not None:
-                taps[f"conv{i}"] = x
-            if not fuse_act:
-                x = self.act(x)
+        x = _conv_layers(self, x, index, x0, res, fuse_act, taps)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -152,12 +163,7 @@ class EquiformerEquiHNNS(nn.Module):
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
-        for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
-            if taps is not None:
-                taps[f"conv{i}"] = x
-            if not fuse_act:
-                x = self.act(x)
+        x = _conv_layers(self, x, index, x0, res, fuse_act, taps)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -254,12 +260,7 @@ class MHNNS(nn.Module):
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
-        for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
-            if taps is not None:
-                taps[f"conv{i}"] = x
-            if not fuse_act:
-                x = self.act(x)
+        x = _conv_layers(self, x, index, x0, res, fuse_act, taps)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 
@@ -327,12 +328,7 @@ class FAFormerEquiHNNS(nn.Module):
         x0 = x
         res = self.conv.prepare(x0, index)   # layer-independent residual term, built once
         fuse_act = taps is None and isinstance(res, dict) and isinstance(self.act, nn.ReLU)   # ReLU in the GEMM epilogue
-        for i in range(self.nlayer):
-            x = self.conv(self.dropout(x), index, x0, res, relu_out=fuse_act)
-            if taps is not None:
-                taps[f"conv{i}"] = x
-            if not fuse_act:
-                x = self.act(x)
+        x = _conv_layers(self, x, index, x0, res, fuse_act, taps)
         return readout(self.mlp_out, self.dropout(x), index, taps, head)
 
 

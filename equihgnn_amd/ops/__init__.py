@@ -50,6 +50,10 @@ from .linears import (  # noqa: F401
     _MergedWeight, _MergedWeights, merged_weights, merged_weight, _Linear, _Linear2, _LinearAddC, linear, linear2,
     linear_add, _MatmulFan, matmul_fan, matmul,
 )
+from .conv_stack import (  # noqa: F401
+    conv_stack_supported, merged_conv_stack, _MergedConvStack,
+)
+from . import conv_stack  # noqa: F401
 from .rows import (  # noqa: F401
     _IncidenceLnReduce, _BiasReluLn, _LinearAddReluLn, linear_add_relu_ln, _GatherLnReduce, gather_ln_reduce,
     _BatchNormRows, batch_norm_rows, batch_norm_rows_supported, _LayerNormRows, incidence_ln_reduce, bias_relu_ln,
