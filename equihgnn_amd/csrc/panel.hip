@@ -54,6 +54,7 @@ struct PackItem {
     int64_t ld;
     uint4* dst;
     int K, N, trans, kstep0, ksteps_total;
+    int n_valid;         // columns n >= n_valid of B are zero (N padded up to a multiple of 32)
 };
 constexpr int PN_MAXPACK = 32;
 struct PackBatch {
@@ -74,7 +75,10 @@ __global__ void __launch_bounds__(256) k_panel_pack(const PackBatch b) {
     const int lane = threadIdx.x & 63, fh = lane >> 5, fr = lane & 31;
     const int n = tile * 32 + fr, k0 = kstep * 16 + 8 * fh;
     float v[8];
-    if (it.trans) {
+    if (n >= it.n_valid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    } else if (it.trans) {
         const float4 a = *reinterpret_cast<const float4*>(it.w + (int64_t)n * it.ld + k0);
         const float4 c = *reinterpret_cast<const float4*>(it.w + (int64_t)n * it.ld + k0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
@@ -123,9 +127,12 @@ template <int KS, int NTW, int NG = 1>
 struct WStream {
     uint4 q[PN_PF][NTW][3];
     const uint4* base[NG][NTW];
-    __device__ __forceinline__ void init(int g, const uint4* __restrict__ w, int wave, int lane) {
+    __device__ __forceinline__ void init(int g, const uint4* __restrict__ w, int wave, int lane, int n_tiles = 1 << 30) {
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) base[g][j] = w + (int64_t)((wave + 4 * j) * KS) * 3 * 64 + lane;
+        for (int j = 0; j < NTW; ++j) {       // (a tile past the image re-reads tile 0; its product is not staged)
+            const int tile = wave + 4 * j < n_tiles ? wave + 4 * j : 0;
+            base[g][j] = w + (int64_t)(tile * KS) * 3 * 64 + lane;
+        }
     }
     __device__ __forceinline__ void fetch(int slot, int kk) {      // kk = product * KS + kstep (compile-time after unrolling)
 #pragma unroll
@@ -179,15 +186,17 @@ __device__ __forceinline__ void panel_mma(const uint4* __restrict__ img, WStream
 }
 
 // accumulators (C^T layout: lane (fh, fr) holds row fr, columns 8 g + 4 fh .. + 3 of its tiles) -> the fp32 staging tile
-template <int NTW>
-__device__ __forceinline__ void acc_to_staging(float* __restrict__ stg, const f32x16 (&acc)[NTW], int wave, int lane) {
+template <int NTW, int LD = PN_STG_LD>
+__device__ __forceinline__ void acc_to_staging(float* __restrict__ stg, const f32x16 (&acc)[NTW], int wave, int lane, int n_tiles = 1 << 30) {
     const int fh = lane >> 5, fr = lane & 31;
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
+        if (wave + 4 * j < n_tiles) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(stg + fr * PN_STG_LD + (wave + 4 * j) * 32 + 8 * g + 4 * fh) =
-                make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stg + fr * LD + (wave + 4 * j) * 32 + 8 * g + 4 * fh) =
+                    make_float4(acc[j][4 * g + 0], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+        }
 }
 
 template <int NG, int NTW>
@@ -641,6 +650,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
+    PN_STAMP(0);
     RowTile<C> t, cw;
     rt_load<C>(t, p.in0, C, P.rowc, P.c4);
     WStream<S::KS, S::NTW, 1> ws;
@@ -649,11 +659,14 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     rt_load<C>(cw, p.in1, C, P.rowc, P.c4);
     __builtin_amdgcn_sched_barrier(0);
     rt_a_put<C, S::KS>(t, s_img, P.lrow, P.c8);
+    PN_STAMP(1);
     __syncthreads();
+    PN_STAMP(2);
     f32x16 acc[1][S::NTW];
     acc_zero<1, S::NTW>(acc);
     if (mul) {
         panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
+        PN_STAMP(3);
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
     // the next product's weight stream starts now: its first fragments arrive while the rows are normalised
@@ -661,6 +674,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     ws.prime();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    PN_STAMP(4);
     {
         RowTile<C> bv, gv, bev, x3;
         rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
@@ -678,12 +692,15 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         rt_a_put<C, S::KS>(x3, s_img, P.lrow, P.c8);       // (every wavefront has left the MFMA loop: barrier above)
     }
+    PN_STAMP(5);
     __syncthreads();
+    PN_STAMP(6);
     acc_zero<1, S::NTW>(acc);
     if (mul) {
         panel_mma<S::KS, S::NTW, 1>(s_img, ws, acc, lane);
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
+    PN_STAMP(7);
     __syncthreads();
     {
         RowTile<C> bv;
@@ -856,6 +873,161 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
                       p.acc_out, p.acc_first, P, wave, lane, mul);
 }
 
+// =============================================================================================================================
+// The EGNN node update (egnn_layer.py:360-362 with node_mlp = Linear(C + 16, 2 C) -> SiLU -> Linear(2 C, C), :180-187):
+//   forward   node_in = [normed | m_i],  hpre = node_in W0^T + b0,  hid = silu(hpre),  out = hid W3^T + b3 + feats
+//   backward  dhid = dout W3,  dpre = dhid * silu'(hpre),  dnode_in = dpre W0   (= [d normed | d m_i])
+// as two panel launches instead of cat + GEMM + SiLU + GEMM + add (and their five backward launches).  The 2 C-wide hidden row
+// goes through the staging tile in two halves of C columns; the C + 16 columns of dnode_in are nine column tiles (the image is
+// zero-padded to C + 32).
+// =============================================================================================================================
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    const float sg = 1.0f / (1.0f + expf(-x));
+    return sg * (1.0f + x * (1.0f - sg));
+}
+
+// in0 = normed [N, C], in1 = m_i [N, 16], in2 = feats (residual); w0 / w1 = W0 T image, output columns [0, C) / [C, 2 C) (K = C + 16);
+// w2 = W3 T image (K = 2 C); b0 = bias of W0 [2 C], bias_out = bias of W3 [C];
+// out0 = node_in [N, C + 16], out1 = hpre [N, 2 C], out2 = hid [N, 2 C], out3 = out [N, C]
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_node_f(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    constexpr int KS1 = C / 16 + 1, KS2 = C / 8;
+    __shared__ uint4 s_img[3 * KS2 * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    RowTile<C> x, res;
+    rt_load<C>(x, p.in0, C, P.rowc, P.c4);
+    const float4 mi = P.c8 < 4 ? *reinterpret_cast<const float4*>(p.in1 + (int64_t)P.rowc * 16 + P.c4) : f4_zero();
+    WStream<KS1, S::NTW, 2> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.init(1, p.w1, mul ? wave : 0, lane);
+    ws.prime();
+    rt_load<C>(res, p.in2, C, P.rowc, P.c4);
+    __builtin_amdgcn_sched_barrier(0);
+    rt_a_put<C, KS1>(x, s_img, P.lrow, P.c8);
+    if (P.c8 < 4) a_put<KS1>(s_img, P.lrow, C / 4 + P.c8, mi);
+    if (P.live) {
+        rt_store<C>(x, p.out0, C + 16, P.row, P.c4);
+        if (P.c8 < 4) *reinterpret_cast<float4*>(p.out0 + (int64_t)P.row * (C + 16) + C + P.c4) = mi;
+    }
+    __syncthreads();
+    f32x16 acc[2][S::NTW];
+    acc_zero<2, S::NTW>(acc);
+    if (mul) {
+        panel_mma<KS1, S::NTW, 2>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
+    }
+    WStream<KS2, S::NTW, 1> ws2;
+    ws2.init(0, p.w2, mul ? wave : 0, lane);
+    ws2.prime();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                       // (half 0: every wavefront is out of the MFMA loop -- the image may be rewritten)
+        RowTile<C> t, bv;
+        rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+        rt_load_vec<C>(bv, p.b0 + half * C, P.c4);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) f4_add(t.v[j], bv.v[j]);
+        if (P.live) rt_store<C>(t, p.out1 + half * C, 2 * C, P.row, P.c4);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j)
+            t.v[j] = make_float4(silu_f(t.v[j].x), silu_f(t.v[j].y), silu_f(t.v[j].z), silu_f(t.v[j].w));
+        if (P.live) rt_store<C>(t, p.out2 + half * C, 2 * C, P.row, P.c4);
+        rt_a_put<C, KS2>(t, s_img, P.lrow, P.c8, half * (C / 4));
+        if (half == 0) {
+            __syncthreads();                   // the staging tile's rows have been read: second half of the product
+            if (mul) acc_to_staging<S::NTW>(s_stg, acc[1], wave, lane);
+        }
+    }
+    __syncthreads();
+    f32x16 acc2[1][S::NTW];
+    acc_zero<1, S::NTW>(acc2);
+    if (mul) {
+        panel_mma<KS2, S::NTW, 1>(s_img, ws2, acc2, lane);
+        acc_to_staging<S::NTW>(s_stg, acc2[0], wave, lane);
+    }
+    __syncthreads();
+    RowTile<C> t, bv;
+    rt_load<C>(t, s_stg, PN_STG_LD, P.lrow, P.c4);
+    rt_load_vec<C>(bv, p.bias_out, P.c4);
+#pragma unroll
+    for (int j = 0; j < S::NJ; ++j) { f4_add(t.v[j], bv.v[j]); f4_add(t.v[j], res.v[j]); }
+    if (P.live) rt_store<C>(t, p.out3, C, P.row, P.c4);
+}
+
+// in0 = dout [N, C] (ld0), in1 = hpre [N, 2 C]; w0 / w1 = W3 N image, output columns [0, C) / [C, 2 C) (K = C);
+// w2 = W0 N image (K = 2 C, N = C + 16 zero-padded to C + 32); out0 = dpre [N, 2 C], out1 = dnode_in [N, C + 16]
+template <int C>
+__global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) k_node_b(const ConvPanelArgs p) {
+    using S = PnShape<C>;
+    constexpr int KS2 = C / 8, NT2 = C / 32 + 1, NTW2 = (NT2 + 3) / 4, LD2 = C + 32 + 4;
+    __shared__ uint4 s_img[3 * KS2 * 64];
+    __shared__ float s_stg[PN_ROWS * LD2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RtPos P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
+    const bool mul = S::NT >= 4 || wave < S::NT;
+    RowTile<C> d, hp[2];
+    rt_load<C>(d, p.in0, p.ld0, P.rowc, P.c4);
+    WStream<S::KS, S::NTW, 2> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.init(1, p.w1, mul ? wave : 0, lane);
+    ws.prime();
+    rt_load<C>(hp[0], p.in1, 2 * C, P.rowc, P.c4);
+    rt_load<C>(hp[1], p.in1 + C, 2 * C, P.rowc, P.c4);
+    __builtin_amdgcn_sched_barrier(0);
+    rt_a_put<C, S::KS>(d, s_img, P.lrow, P.c8);
+    __syncthreads();
+    f32x16 acc[2][S::NTW];
+    acc_zero<2, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, 2>(s_img, ws, acc, lane);
+        acc_to_staging<S::NTW, LD2>(s_stg, acc[0], wave, lane);
+    }
+    const bool mul2 = NT2 >= 4 || wave < NT2;
+    WStream<KS2, NTW2, 1> ws2;
+    ws2.init(0, p.w2, mul2 ? wave : 0, lane, NT2);
+    ws2.prime();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        RowTile<C> t;
+        rt_load<C>(t, s_stg, LD2, P.lrow, P.c4);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) {
+            const float4 h = hp[half].v[j];
+            t.v[j].x *= silu_grad_f(h.x); t.v[j].y *= silu_grad_f(h.y); t.v[j].z *= silu_grad_f(h.z); t.v[j].w *= silu_grad_f(h.w);
+        }
+        if (P.live) rt_store<C>(t, p.out0 + half * C, 2 * C, P.row, P.c4);
+        rt_a_put<C, KS2>(t, s_img, P.lrow, P.c8, half * (C / 4));
+        if (half == 0) {
+            __syncthreads();
+            if (mul) acc_to_staging<S::NTW, LD2>(s_stg, acc[1], wave, lane);
+        }
+    }
+    __syncthreads();
+    f32x16 acc2[1][NTW2];
+    acc_zero<1, NTW2>(acc2);
+    if (mul2) {
+        panel_mma<KS2, NTW2, 1>(s_img, ws2, acc2, lane);
+        acc_to_staging<NTW2, LD2>(s_stg, acc2[0], wave, lane, NT2);
+    }
+    __syncthreads();
+    RowTile<C> t;
+    rt_load<C>(t, s_stg, LD2, P.lrow, P.c4);
+    if (P.live) {
+        rt_store<C>(t, p.out1, C + 16, P.row, P.c4);
+        if (P.c8 < 4)
+            *reinterpret_cast<float4*>(p.out1 + (int64_t)P.row * (C + 16) + C + P.c4) =
+                *reinterpret_cast<const float4*>(s_stg + P.lrow * LD2 + C + P.c4);
+    }
+}
+
 inline bool pn_width_ok(int C) { return C == 64 || C == 128 || C == 256; }
 
 }  // namespace
@@ -931,6 +1103,14 @@ extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_)
             if (rc || !q->tail) return rc;
             return eqh_reduce_slabs3_async(q->slab2, blocks, 3 * (int64_t)C, q->dbias2, q->dgamma2, q->dbeta2, C, C, q->accumulate, stream);
         }
+        case HG_EGNN_NODE_F:
+            if (!need({q->in0, q->in1, q->in2, q->w0, q->w1, q->w2, q->b0, q->bias_out, q->out0, q->out1, q->out2, q->out3})) return EQH_ERR_ARG;
+            PN_LAUNCH(k_node_f);
+            return EQH_OK;
+        case HG_EGNN_NODE_B:
+            if (!need({q->in0, q->in1, q->w0, q->w1, q->w2, q->out0, q->out1})) return EQH_ERR_ARG;
+            PN_LAUNCH(k_node_b);
+            return EQH_OK;
         default:
             return EQH_ERR_ARG;
     }
@@ -962,7 +1142,8 @@ extern "C" int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* st
             if ((q.K & 15) || (q.N & 31) || (q.ld & 3) || !eqh_aligned16(q.w) || !eqh_aligned16(q.dst)) return EQH_ERR_ALIGN;
             const int total = q.ksteps_total > 0 ? q.ksteps_total : q.K / 16;
             if (q.kstep0 + q.K / 16 > total) return EQH_ERR_ARG;
-            b.it[i] = PackItem{q.w, q.ld, static_cast<uint4*>(q.dst), q.K, q.N, q.trans ? 1 : 0, q.kstep0, total};
+            const int n_valid = (q.n_valid > 0 && q.n_valid < q.N) ? q.n_valid : q.N;
+            b.it[i] = PackItem{q.w, q.ld, static_cast<uint4*>(q.dst), q.K, q.N, q.trans ? 1 : 0, q.kstep0, total, n_valid};
             b.first[i + 1] = b.first[i] + (q.K / 16) * (q.N / 32);
         }
         for (int i = b.n; i < PN_MAXPACK; ++i) { b.it[i] = b.it[0]; b.first[i + 1] = b.first[b.n]; }

@@ -41,7 +41,7 @@ class HgGemmProblem(ctypes.Structure):
 class HgPanelPack(ctypes.Structure):
     """HgPanelPack of include/equihgnn_hip.h (one weight of hg_panel_pack)."""
     _fields_ = [("w", c_void_p), ("ld", c_int64), ("dst", c_void_p), ("K", c_int32), ("N", c_int32), ("trans", c_int32),
-                ("kstep0", c_int32), ("ksteps_total", c_int32)]
+                ("kstep0", c_int32), ("ksteps_total", c_int32), ("n_valid", c_int32)]
 
 
 class HgConvPanel(ctypes.Structure):
@@ -54,7 +54,7 @@ class HgConvPanel(ctypes.Structure):
                                            "acc_out", "dbias", "dgamma", "dbeta", "dbias2", "dgamma2", "dbeta2")])
 
 
-HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1 = 1, 2, 3, 4, 5
+HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1, HG_EGNN_NODE_F, HG_EGNN_NODE_B = 1, 2, 3, 4, 5, 6, 7
 
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
 SIGNATURES = {

@@ -417,8 +417,10 @@ class EGNN(nn.Module):
             ab, normed, res = ops.linear(feats, w_cat, b_cat), nn_(feats), feats
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
-        node_in = torch.cat((normed, m_i), -1)
         n0, n3 = self.node_mlp[0], self.node_mlp[3]
+        if ops.USE_NODE_PANEL and ops.egnn_node_mlp_supported(normed, m_i, n0, n3):
+            return ops.egnn_node_mlp(normed, m_i, res, n0, n3)      # one launch each way (csrc/panel.hip)
+        node_in = torch.cat((normed, m_i), -1)
         hid = F.silu(ops.linear(node_in, n0.weight, n0.bias))
         return ops.linear(hid, n3.weight, n3.bias) + res       # egnn_layer.py:360-362
 

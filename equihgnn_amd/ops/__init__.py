@@ -60,7 +60,8 @@ from .rows import (  # noqa: F401
     _ResidualMix, residual_mix, layer_norm_rows,
 )
 from .egnn import (  # noqa: F401
-    _EgnnEdge, _EgnnFeats, egnn_feats, _EgnnPackWeights, egnn_pack_weights, egnn_edge,
+    _EgnnEdge, _EgnnFeats, egnn_feats, _EgnnPackWeights, egnn_pack_weights, egnn_edge, _EgnnNodeMlp, egnn_node_mlp,
+    egnn_node_mlp_supported,
 )
 from .readout import (  # noqa: F401
     _MseLoss, mse_loss, _READOUT_STATE, _readout_state, _ReadoutMse, readout_mse_supported, readout_mse,
@@ -110,3 +111,7 @@ class _OpsModule(_types.ModuleType):
 
 
 _sys.modules[__name__].__class__ = _OpsModule
+
+import os as _os  # noqa: E402
+
+USE_NODE_PANEL = not _os.environ.get("EQH_NO_NODE_PANEL")     # the EGNN node update on the panel kernels (tests switch it off to compare with the per-operator path)

@@ -7,6 +7,8 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import hip
@@ -15,7 +17,7 @@ from .aggregate import entry_weights
 from .grads import (_linear_weight_grad, _wgrad_deferred, colsum)
 from .panel import (conv_panel, conv_panel_slab, panel_gemm, panel_pack, panel_supported)
 
-USE_CONV_STACK = True     # tests switch it off to compare with the unfused path
+USE_CONV_STACK = not os.environ.get("EQH_NO_CONV_STACK")     # tests switch it off to compare with the unfused path
 
 
 def conv_stack_supported(X, C: int) -> bool:

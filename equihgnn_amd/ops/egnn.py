@@ -178,3 +178,70 @@ def egnn_pack_weights(w1, b1, w2, Hp):
 def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
     _note_acc(b2)
     return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2)
+
+
+class _EgnnNodeMlp(torch.autograd.Function):
+    """out = Linear3(silu(Linear0([normed | m_i]))) + feats (egnn_layer.py:180-187,360-362) as ONE panel launch each way
+    (csrc/panel.hip: HG_EGNN_NODE_F / _B) instead of cat + GEMM + SiLU + GEMM + add and their backward launches.  The weight
+    and bias gradients are formed from the stored rows (node_in, dpre; hid, dout) by the batched / deferred products."""
+
+    @staticmethod
+    def forward(ctx, normed, m_i, res, w0, b0, w3, b3):
+        from .panel import conv_panel, panel_pack
+        _require_gpu(normed, "egnn_node_mlp")
+        normed, m_i, res = _f32c(normed), _f32c(m_i), _f32c(res)
+        N, C = normed.shape
+        dev = normed.device
+        need_grad = any(ctx.needs_input_grad)
+        items = [(w0[:C], True), (w0[C:], True), (w3, True)]
+        if need_grad:
+            items += [(w3[:, :C], False), (w3[:, C:], False), (w0, False, C + 32)]
+        imgs = panel_pack(items)
+        node_in = torch.empty((N, C + 16), dtype=torch.float32, device=dev)
+        hpre = torch.empty((N, 2 * C), dtype=torch.float32, device=dev)
+        hid = torch.empty_like(hpre)
+        out = torch.empty((N, C), dtype=torch.float32, device=dev)
+        timed("k_node_f", 2 * N * ((C + 16) * 2 * C + 2 * C * C), lambda: conv_panel(
+            hip.HG_EGNN_NODE_F, N, C, dev, in0=normed, in1=m_i, in2=res, w0=imgs[0], w1=imgs[1], w2=imgs[2], b0=b0, bias_out=b3,
+            out0=node_in, out1=hpre, out2=hid, out3=out))
+        if need_grad:
+            ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid)
+            ctx.imgs = imgs[3:]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        from .panel import conv_panel
+        from .grads import _linear_weight_grad
+        w0, b0, w3, b3, node_in, hpre, hid = ctx.saved_tensors
+        N, C = hid.shape[0], hid.shape[1] // 2
+        dev = dout.device
+        dout, ld = _rows_ld(dout)
+        dpre = torch.empty_like(hpre)
+        dnode_in = torch.empty_like(node_in)
+        timed("k_node_b", 2 * N * (2 * C * C + 2 * C * (C + 16)), lambda: conv_panel(
+            hip.HG_EGNN_NODE_B, N, C, dev, in0=dout, ld0=ld, in1=hpre, w0=ctx.imgs[0], w1=ctx.imgs[1], w2=ctx.imgs[2], out0=dpre,
+            out1=dnode_in))
+        dout_c = dout if ld == C else dout.contiguous()
+        dw3 = _linear_weight_grad(w3, None, None, dout_c, hid) if ctx.needs_input_grad[5] else None
+        db3 = colsum(dout_c, into=_acc_target(b3)) if ctx.needs_input_grad[6] else None
+        dw0 = _linear_weight_grad(w0, None, None, dpre, node_in) if ctx.needs_input_grad[3] else None
+        db0 = colsum(dpre, into=_acc_target(b0)) if ctx.needs_input_grad[4] else None
+        return dnode_in[:, :C], dnode_in[:, C:], dout, dw0, db0, dw3, db3
+
+
+def egnn_node_mlp_supported(normed, m_i, lin0, lin3) -> bool:
+    from .panel import panel_supported
+    C = normed.shape[-1]
+    return (normed.is_cuda and normed.dim() == 2 and normed.dtype == torch.float32 and panel_supported(C) and m_i.shape[-1] == 16
+            and tuple(lin0.weight.shape) == (2 * C, C + 16) and tuple(lin3.weight.shape) == (C, 2 * C) and normed.shape[0] > 0)
+
+
+def egnn_node_mlp(normed, m_i, res, lin0, lin3):
+    """lin3(silu(lin0(cat(normed, m_i)))) + res; see _EgnnNodeMlp."""
+    if torch.is_grad_enabled():
+        for w in (lin0.weight, lin3.weight):
+            if w.requires_grad and w.is_leaf:
+                LINEAR_PARAMS[id(w)] = w
+    _note_acc(lin0.bias, lin3.bias)
+    return _EgnnNodeMlp.apply(normed, m_i, res, lin0.weight, lin0.bias, lin3.weight, lin3.bias)

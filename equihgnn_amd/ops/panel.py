@@ -20,14 +20,14 @@ def panel_supported(C: int) -> bool:
 def panel_pack(items, out=None):
     """Pack weights for the panel kernels in ONE launch.  ``items`` = [(w, trans)] or [[(w, trans), ...]]: a 2-D fp32 weight
     view ``w`` (unit inner stride) used as B[k][n] = w[n, k] (``trans`` True: x @ w.T) or B[k][n] = w[k, n] (False: dy @ w);
-    an inner list stacks its weights along K in one image.  Returns one uint8 image tensor per item (views of ``out`` if
+    an inner list stacks its weights along K in one image; (w, trans, n_pad): N zero-padded up to n_pad columns.  Returns one uint8 image tensor per item (views of ``out`` if
     given: a uint8 device buffer of at least panel_pack_bytes(items) bytes)."""
     L = hip.lib()
     groups = [it if isinstance(it, list) else [it] for it in items]
     sizes = []
     for g in groups:
-        ks = [(w.shape[1] if tr else w.shape[0]) for w, tr in g]
-        ns = {(w.shape[0] if tr else w.shape[1]) for w, tr in g}
+        ks = [(it[0].shape[1] if it[1] else it[0].shape[0]) for it in g]
+        ns = {(it[2] if len(it) > 2 else (it[0].shape[0] if it[1] else it[0].shape[1])) for it in g}
         if len(ns) != 1:
             raise ValueError("panel_pack: weights stacked along K must share their N")
         sizes.append((sum(ks), ns.pop()))
@@ -44,7 +44,8 @@ def panel_pack(items, out=None):
         img = out[off:off + K * N * 6]
         views.append(img)
         k0 = 0
-        for w, tr in g:
+        for it in g:
+            w, tr = it[0], it[1]
             w = _row_view(w.detach(), "panel_pack: w")
             keep.append(w)
             kk = w.shape[1] if tr else w.shape[0]
@@ -52,6 +53,7 @@ def panel_pack(items, out=None):
                 raise ValueError(f"panel_pack: K = {kk} must be a multiple of 16 and N = {N} of 32")
             arr[i].w, arr[i].ld, arr[i].dst = w.data_ptr(), w.stride(0), img.data_ptr()
             arr[i].K, arr[i].N, arr[i].trans, arr[i].kstep0, arr[i].ksteps_total = kk, N, 1 if tr else 0, k0 // 16, K // 16
+            arr[i].n_valid = w.shape[0] if tr else w.shape[1]
             k0 += kk
             i += 1
         off += K * N * 6
@@ -61,8 +63,8 @@ def panel_pack(items, out=None):
 
 def panel_pack_bytes(items) -> int:
     groups = [it if isinstance(it, list) else [it] for it in items]
-    return sum(sum((w.shape[1] if tr else w.shape[0]) for w, tr in g) * (g[0][0].shape[0] if g[0][1] else g[0][0].shape[1]) * 6
-               for g in groups)
+    return sum(sum((it[0].shape[1] if it[1] else it[0].shape[0]) for it in g)
+               * (g[0][2] if len(g[0]) > 2 else (g[0][0].shape[0] if g[0][1] else g[0][0].shape[1])) * 6 for g in groups)
 
 
 def panel_gemm(a, wpack, C: int, alpha: float = 1.0, d=None, beta: float = 1.0, bias=None, relu: bool = False, out=None):

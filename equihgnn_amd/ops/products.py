@@ -202,11 +202,11 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1
 # ([15 k x 256].[256 x 256] 18.6 against 20.0 us, [15 k x 512].[512 x 1024] 84 against 133 us, 150-215 against 105-135
 # TFLOP/s at the Molecule3D / PCQM / Equiformer sizes); below that -- the [4.7 k x 256] x [256 x 256] products of a QM9
 # batch, one workgroup per CU and eight K steps -- the tuned library is 10-15 % ahead.
-X6_MIN_OUTPUTS = 3_500_000
+X6_MIN_OUTPUTS = int(os.environ.get("EQH_X6_MIN_OUTPUTS", 3_500_000))
 X6_MAX_K = 8192
 X6_DEEP_ROWS = 32768        # weight gradients dY^T X over at least this many rows: the split-K form of the x6 kernel
 X6_WGRAD_OUTPUTS = 4_000_000   # x^T dy products with at least this many outputs (and >= 1024 rows): 128 x 128 tiles
-X6_WGRAD_ROWS = 8192        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
+X6_WGRAD_ROWS = int(os.environ.get("EQH_X6_WGRAD_ROWS", 8192))        # deferred weight gradients from this many rows up go to it in batches of up to 8 products
 USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
 
 

@@ -197,6 +197,7 @@ typedef struct {
     int64_t ld;
     void* dst;
     int32_t K, N, trans, kstep0, ksteps_total;
+    int32_t n_valid;     /* 0 or N: all columns; else columns n >= n_valid of B are zero (N padded to a multiple of 32) */
 } HgPanelPack;
 size_t hg_panel_pack_bytes(int32_t K, int32_t N);
 int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* stream);
@@ -224,8 +225,16 @@ int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t C, cons
  *              b0 / g0 = b1a, gamma1; in2 = dpa; w0 = [W1a ; W2v] N stacked along K.
  *              out0 = dh1, out1 = dX = dh1 W1a + dpa W2v (may be NULL with tail); dbias / dgamma / dbeta, slab as B3.
  *              tail != 0: B3 of the application before on dX (in3 = its Xn = this X, out5 = its u (read), w1 = W3b N, w2 = w23 N,
- *              b1 / g1 = b3a, gamma3, out2 = g, out3 = dpre, out4 = ds, acc_out, slab2, dbias2 / dgamma2 / dbeta2). */
-enum { HG_CONV_F1 = 1, HG_CONV_F2 = 2, HG_CONV_F3 = 3, HG_CONV_B3 = 4, HG_CONV_B1 = 5 };
+ *              b1 / g1 = b3a, gamma3, out2 = g, out3 = dpre, out4 = ds, acc_out, slab2, dbias2 / dgamma2 / dbeta2).
+ *  The EGNN node update (egnn_layer.py:180-187,360-362: node_mlp = Linear(C + 16, 2 C) -> SiLU -> Linear(2 C, C), + feats):
+ *  HG_EGNN_NODE_F  in0 = normed [N, C], in1 = m_i [N, 16], in2 = feats; w0 / w1 = W0 T for output columns [0, C) / [C, 2 C)
+ *              (K = C + 16), w2 = W3 T (K = 2 C); b0 = W0's bias [2 C], bias_out = W3's bias.
+ *              out0 = node_in = [normed | m_i] [N, C + 16], out1 = hpre = node_in W0^T + b0 [N, 2 C], out2 = hid = silu(hpre),
+ *              out3 = hid W3^T + b3 + feats.
+ *  HG_EGNN_NODE_B  in0 = dout (ld0), in1 = hpre; w0 / w1 = W3 N for output columns [0, C) / [C, 2 C) (K = C), w2 = W0 N
+ *              (K = 2 C, N = C + 16 packed with n_valid = C + 16 into C + 32 columns).
+ *              out0 = dpre = (dout W3) silu'(hpre) [N, 2 C], out1 = dnode_in = dpre W0 [N, C + 16]. */
+enum { HG_CONV_F1 = 1, HG_CONV_F2 = 2, HG_CONV_F3 = 3, HG_CONV_B3 = 4, HG_CONV_B1 = 5, HG_EGNN_NODE_F = 6, HG_EGNN_NODE_B = 7 };
 typedef struct {
     int64_t rows;
     int32_t C;

@@ -532,6 +532,7 @@ def test_conv_stack_on_panel_kernels_matches_the_unfused_path(method, hidden):
     res = {}
     for flag in (False, True):
         ops.conv_stack.USE_CONV_STACK = flag
+        ops.USE_NODE_PANEL = flag               # (the EGNN node update's panel launch, too)
         try:
             for p in m.parameters():
                 p.grad = None
@@ -541,6 +542,7 @@ def test_conv_stack_on_panel_kernels_matches_the_unfused_path(method, hidden):
             res[flag] = (out.detach().clone(), {n: (p.grad.clone() if p.grad is not None else None) for n, p in m.named_parameters()})
         finally:
             ops.conv_stack.USE_CONV_STACK = True
+            ops.USE_NODE_PANEL = True
     (o0, g0), (o1, g1) = res[False], res[True]
     assert torch.allclose(o0, o1, rtol=1e-5, atol=1e-5 * float(o0.abs().max()))
     assert {n for n, g in g0.items() if g is not None} == {n for n, g in g1.items() if g is not None}

@@ -23,7 +23,7 @@ def main():
     extra = [f"-D{d}" for d in os.environ.get("PN_DEFS", "").split() if d]
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DPN_STAMPS", *extra,
                            "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "equihgnn_amd", "csrc"),
-                           os.path.join(ROOT, "equihgnn_amd", "csrc", "panel.hip"), "-o", so])
+                           os.path.join(ROOT, "equihgnn_amd", "csrc", "panel.hip"), os.path.join(ROOT, "equihgnn_amd", "csrc", "api.hip"), "-o", so])
     L = ctypes.CDLL(so)
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
