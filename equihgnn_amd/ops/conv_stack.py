@@ -62,7 +62,7 @@ class _MergedConvStack(torch.autograd.Function):
         h1, h1n, pa = new(N), new(N), new(N)
         timed("k_conv_f1", flops(N, 2), lambda: conv_panel(hip.HG_CONV_F1, N, C, dev, eps=eps[0], in0=X, ld0=X.stride(0), w0=iW1a,
                                                            w1=iW2v, b0=b1a, g0=g1, be0=be1, out0=h1, out1=h1n, out2=pa))
-        x_in = X
+        x_in = X.detach()          # (plain aliases on ctx: a tensor that carries a grad_fn there would tie the graph into a cycle)
         for l in range(L):
             hbar, qb, s = new(M), new(M), new(N)
             timed("k_conv_f2", flops(M, 1), lambda: conv_panel(hip.HG_CONV_F2, M, C, dev, in0=h1n, rowptr=ix.by_e.rowptr,
@@ -89,7 +89,10 @@ class _MergedConvStack(torch.autograd.Function):
             ctx.imgs = imgs[5:]
             ctx.meta = (ix, L, float(scale), eps, bool(relu_out))
             ctx.params = (b1a, g1, be1, g2, be2, b12, b3a, g3, be3, b3b)
-        return xn
+        # the OUTPUT object gets this node as its grad_fn; ctx.saved_rows holds xn itself, so hand out an alias -- a reference
+        # cycle (node -> ctx -> xn -> node) would keep every step's graph, and with it AccumulateGrad nodes bound to the stream
+        # of an earlier step, alive until the garbage collector runs (a hipGraph capture then fails: legacy-stream dependency)
+        return xn.view_as(xn)
 
     @staticmethod
     def backward(ctx, dout):

@@ -296,25 +296,56 @@ def d_fixture():
     return {"rel_pos": rel.reshape(-1, 3).numpy(), "D1": D.reshape(-1, 3, 3).numpy()}
 
 
-def run_trajectory(registry, name):
+class _ReluMargin:
+    """While active, every ReLU the reference evaluates (F.relu in mlp.py:93-97, nn.ReLU in the wrappers) reports how close
+    its closest input lies to the kink: min |x| / rms(x).  A training trajectory is reproducible to 1e-4 by another fp32
+    implementation only while no input sits within that implementation's rounding distance (~1e-6 rms) of zero: past such
+    a point the two sides differ by a finite jump of the gradient, not by rounding."""
+
+    def __enter__(self):
+        self.orig = torch.nn.functional.relu
+        self.values = []
+
+        def spy(x, inplace=False):
+            with torch.no_grad():
+                xd = x.detach()
+                self.values.append(float(xd.abs().min() / xd.pow(2).mean().sqrt().clamp_min(1e-30)))
+            return self.orig(x, inplace)
+
+        torch.nn.functional.relu = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.relu = self.orig
+
+    def take(self):
+        v, self.values = (min(self.values) if self.values else float("inf")), []
+        return v
+
+
+def run_trajectory(registry, name, spec=None):
     """`steps` optimiser steps of the reference model as LitModel runs them (main.py:49-63,137-140)."""
-    method, hidden, seed, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    method, hidden, seed, n_mols, steps, lr = spec or TRAJECTORY_TABLE[name]
     torch.manual_seed(0)
     model = registry.get_model_class(method)(1, golden_args(method, hidden))
     fill_state_dict(model, seed)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
-    losses, outs = [], []
-    for data in trajectory_batches(name):
-        opt.zero_grad(set_to_none=True)
-        out = model(data)
-        loss = torch.nn.MSELoss()(out, data.y)
-        loss.backward()
-        opt.step()
-        losses.append(float(loss.detach()))
-        outs.append(out.detach().numpy().copy())
+    losses, outs, margins = [], [], []
+    batches = trajectory_batches(name) if spec is None else [make_batch(seed + t, n_mols) for t in range(steps)]
+    with _ReluMargin() as rm:
+        for data in batches:
+            opt.zero_grad(set_to_none=True)
+            out = model(data)
+            margins.append(rm.take())
+            loss = torch.nn.MSELoss()(out, data.y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            outs.append(out.detach().numpy().copy())
     case = {"meta_method": np.array(method), "meta_hidden": np.array(hidden), "meta_seed": np.array(seed),
             "meta_lr": np.array(lr), "loss": np.array(losses, dtype=np.float64),
+            "relu_margin": np.array(margins, dtype=np.float64),     # per step: the closest ReLU input to its kink, in rms units
             "out": np.stack([np.pad(o, (0, max(len(x) for x in outs) - len(o))) for o in outs]),
             "out_len": np.array([len(o) for o in outs])}
     names, norms = [], []
@@ -434,6 +465,22 @@ def main(only=None, check=False):
     return ok
 
 
+def scan_trajectory_seeds(name, seeds):
+    """Kink margins of the trajectory `name` re-seeded: `python make_golden.py --scan trajectory_egnn_equihnns_c64 81 82 ...`
+    (how the seeds of TRAJECTORY_TABLE were chosen: the closest ReLU input of every step at least 1e-5 rms from zero)."""
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
+    method, hidden, _, n_mols, steps, lr = TRAJECTORY_TABLE[name]
+    registry = import_reference(("mhnn",) if method.startswith("mhnn") else ("equihnn_egnn",))
+    for seed in seeds:
+        case = run_trajectory(registry, name, (method, hidden, seed, n_mols, steps, lr))
+        print(f"seed {seed}: relu margins per step {case['relu_margin']}  losses {case['loss']}")
+
+
 if __name__ == "__main__":
+    if "--scan" in sys.argv:
+        i = sys.argv.index("--scan")
+        scan_trajectory_seeds(sys.argv[i + 1], [int(x) for x in sys.argv[i + 2:]])
+        sys.exit(0)
     argv = [a for a in sys.argv[1:] if a != "--check"]
     sys.exit(0 if main(set(argv) or None, check="--check" in sys.argv) else 1)

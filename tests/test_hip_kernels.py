@@ -1942,3 +1942,35 @@ def test_conv_panel_backward_stages_match_autograd_float64(C, n_nodes, n_he):
                            slab=ops.conv_panel_slab(n_nodes, C, DEV), dbias=vr[0], dgamma=vr[1], dbeta=vr[2])
             assert torch.equal(g2, gr) and torch.equal(dpre2, dprer) and torch.equal(ds2, dsr) and torch.equal(vec3, vr)
             assert torch.equal(acc, dpre2)
+
+
+@pytest.mark.parametrize("C,n_nodes", [(256, 1000), (64, 333), (128, 97)])
+def test_egnn_node_panel_stages_match_float64(C, n_nodes):
+    """HG_EGNN_NODE_F / _B (egnn_layer.py:180-187,360-362: Linear(C + 16, 2 C) -> SiLU -> Linear(2 C, C) + feats) against
+    float64 and float64 autograd."""
+    from equihgnn_amd import hip, ops
+    g = torch.Generator(device=DEV).manual_seed(C + n_nodes)
+    rn = lambda *sh, s=1.0: torch.randn(*sh, device=DEV, generator=g) * s
+    d = lambda t: t.double()
+    normed, m_i, feats = rn(n_nodes, C), rn(n_nodes, 16), rn(n_nodes, C)
+    w0, b0 = rn(2 * C, C + 16, s=(C + 16) ** -0.5), rn(2 * C, s=0.3)
+    w3, b3 = rn(C, 2 * C, s=(2 * C) ** -0.5), rn(C, s=0.3)
+    imgs = ops.panel_pack([(w0[:C], True), (w0[C:], True), (w3, True), (w3[:, :C], False), (w3[:, C:], False), (w0, False, C + 32)])
+    node_in, hpre, hid, out = (torch.empty(n_nodes, k, device=DEV) for k in (C + 16, 2 * C, 2 * C, C))
+    ops.conv_panel(hip.HG_EGNN_NODE_F, n_nodes, C, DEV, in0=normed, in1=m_i, in2=feats, w0=imgs[0], w1=imgs[1], w2=imgs[2], b0=b0,
+                   bias_out=b3, out0=node_in, out1=hpre, out2=hid, out3=out)
+    x64 = torch.cat((d(normed), d(m_i)), -1).requires_grad_()
+    hpre64 = x64 @ d(w0).t() + d(b0)
+    hid64 = torch.nn.functional.silu(hpre64)
+    out64 = hid64 @ d(w3).t() + d(b3) + d(feats)
+    assert torch.equal(node_in, torch.cat((normed, m_i), -1))
+    assert torch.allclose(d(hpre), hpre64, rtol=1e-5, atol=1e-5) and torch.allclose(d(hid), hid64, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(d(out), out64, rtol=1e-5, atol=2e-5)
+    dout = rn(n_nodes, C)
+    dpre, dnode_in = torch.empty(n_nodes, 2 * C, device=DEV), torch.empty(n_nodes, C + 16, device=DEV)
+    ops.conv_panel(hip.HG_EGNN_NODE_B, n_nodes, C, DEV, in0=dout, ld0=C, in1=hpre, w0=imgs[3], w1=imgs[4], w2=imgs[5], out0=dpre,
+                   out1=dnode_in)
+    hpre64.retain_grad()
+    out64.backward(d(dout))
+    assert torch.allclose(d(dpre), hpre64.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(d(dnode_in), x64.grad, rtol=1e-4, atol=2e-5)
