@@ -772,6 +772,24 @@ def main():
                     "peak": round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "frac": round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 4),
                     "note": "six bf16 MFMAs per fp32 product: peak = dense bf16 peak / 6; the fp32-input MFMA peak is "
                             f"{FP32_MFMA_PEAK_TFLOPS} TFLOP/s"}
+            pk = {}
+            for name in ("k_conv_f1", "k_conv_f2", "k_conv_f3", "k_conv_b3", "k_conv_b2", "k_conv_b1", "k_node_f", "k_node_b"):
+                if name in per:     # row-panel kernels (csrc/panel.hip): conv-sized products + the row work between them, x6 arithmetic
+                    tf = per[name]["work"] / per[name]["us"] / 1e6
+                    pk[name] = {"launches_per_step": per[name]["launches_per_step"], "us": round(per[name]["us"], 1),
+                                "fp32_flops": int(per[name]["work"]), "achieved": round(tf, 1),
+                                "frac": round(tf / (BF16_MFMA_PEAK_TFLOPS / 6), 4)}
+            if pk:
+                tot_f = sum(v["fp32_flops"] for v in pk.values())
+                tot_us = sum(v["us"] for v in pk.values())
+                result["roofline"]["panel_kernels"] = {
+                    "bound": "mfma", "unit": "TFLOP/s (2 M N K per second)", "peak": round(BF16_MFMA_PEAK_TFLOPS / 6, 1),
+                    "launches_per_step": sum(v["launches_per_step"] for v in pk.values()), "us": round(tot_us, 1),
+                    "achieved": round(tot_f / tot_us / 1e6, 1), "frac": round(tot_f / tot_us / 1e6 / (BF16_MFMA_PEAK_TFLOPS / 6), 4),
+                    "note": "32-row panels: ~150 workgroups on 256 CUs at the BASELINE batch, each streaming the whole [C x C] weight "
+                            "image (384 KB) through its CU's vector memory path per product -- that and the 192 MFMAs per wavefront "
+                            "(2.6 us) bound a product; LayerNorm / gather / split phases between products do not overlap them",
+                    "kernels": pk}
             mf = {}
             for name in ("k_rowgemm_fwd", "k_rowgemm_bwd"):     # Equiformer's radial tensor product (fp32 MFMA)
                 if name in per:

@@ -58,6 +58,20 @@ ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 
                     ("faformer_equihnns", 512, 5000, "pcqm", 256, "eval-forward")]
 
 
+# (method, batch, mode) -> bound on the largest per-parameter relative L2 gradient error against the fp32 CPU oracle: about 3 x
+# what round 4 measured (in brackets).  Where no ReLU / frame-sign kink separates the two evaluations the error is 1e-6; where
+# one does (hidden 256 at >= 256 molecules always has one within fp32 rounding of zero, train-mode BatchNorm amplifies it) it is
+# 1e-3 -- of one embedding table or one Linear, the others stay at 1e-6.  The tight check is against float64 (next test).
+GRAD_L2_BOUND = {("mhnnm", 32, "train"): 1.2e-2,                    # [3.8e-3]
+                 ("egnn_equihnns", 32, "train"): 1e-4,             # [1.2e-6]
+                 ("egnn_equihnns", 256, "train"): 3e-3,            # [1.0e-3]  BASELINE config 2
+                 ("equiformer_equihnns", 8, "train"): 1e-4,        # [3.2e-6]
+                 ("equiformer_equihnns", 16, "train"): 1e-4,       # [3.9e-6]
+                 ("equiformer_equihnns", 128, "train"): 1e-4,      # [2.9e-6]  BASELINE config 3's batch (hidden 64)
+                 ("egnn_equihnns", 300, "train"): 3e-3,            # [1.0e-3]  config 4's molecules
+                 ("faformer_equihnns", 64, "eval"): 8e-3}          # [2.8e-3]
+
+
 @pytest.mark.parametrize("method,bs,seed,flavour,hidden,mode", ORACLE_WORKLOADS)
 def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed, flavour, hidden, mode):
     from equihgnn_amd.batch import synth_batch
@@ -100,18 +114,27 @@ def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed, flavour, h
     gref = dict(ref.named_parameters())
     # analytically-zero gradients (a bias in front of a train-mode BatchNorm) are pure rounding noise
     floor = 1e-3 * max(float(q.grad.norm()) for q in gref.values() if q.grad is not None)
+    rels = []
     for n, p in mine.named_parameters():
         r = gref[n].grad
         if r is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
         rel = float((p.grad.cpu() - r).norm()) / max(float(r.norm()), floor)
-        assert rel < 5e-2, (n, rel)
+        rels.append((rel, n))
+    print(f"baseline-size {method} B={bs} {flavour} {mode}: largest relative L2 gradient error {max(rels)}")
+    # the measured noise level per workload (round 4, panel path; fp32 CPU oracle against this path, both 1e-4..1e-3 from the
+    # float64 truth where a ReLU / frame-sign kink flipped): bound = ~3 x the measured value
+    bound = GRAD_L2_BOUND.get((method, bs, mode), 5e-2)
+    assert max(rels)[0] < bound, (max(rels), bound)
 
 
 @pytest.mark.parametrize("method,bs,seed,n_seeds,tol", [("mhnnm", 32, 1000, 1, 2e-5), ("egnn_equihnns", 64, 2000, 5, 5e-5),
                                                         ("equiformer_equihnns", 4, 3100, 3, 5e-5),
-                                                        ("faformer_equihnns", 32, 5100, 5, 5e-5)])
+                                                        ("faformer_equihnns", 32, 5100, 5, 5e-5),
+                                                        # BASELINE config 2 at its own size (batch 256, hidden 256: the float64
+                                                        # oracle holds ~0.6 GB per per-edge tensor), three seeds
+                                                        ("egnn_equihnns", 256, 2000, 3, 5e-5)])
 def test_hip_gradients_match_fp64_truth(method, bs, seed, n_seeds, tol):
     """Gradients against the oracle evaluated in float64 (the rounding-free truth).  The fp32 CPU
     oracle itself sits 1e-4 (mhnnm, train-mode BatchNorm) from this truth; the HIP path must be
@@ -161,6 +184,7 @@ def test_hip_gradients_match_fp64_truth(method, bs, seed, n_seeds, tol):
             errs.append((float((p.grad.cpu().double() - r).abs().max()) / gmax, n))
         worst.append(max(errs))
     ranked = sorted(worst)
+    print(f"fp64 truth {method} B={bs}: worst entry error / largest gradient entry per seed: {[f'{w[0]:.2e}' for w in worst]}")
     assert ranked[n_seeds // 2][0] < tol, worst
     assert ranked[-1][0] < 2e-3, worst
 
