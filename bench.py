@@ -246,10 +246,39 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=3, batches_p
             tr.step(b)
     torch.cuda.synchronize(dev)
     res_ms = (time.perf_counter() - t1) / (reps * len(resident)) * 1e3
+    # the evaluation pass of every epoch (main.py:65-87): forward-only hipGraph replay (trainer.GraphedEvalStep) against eager
+    from equihgnn_amd.trainer import GraphedEvalStep
+    model.eval()
+    ev = GraphedEvalStep(model)
+    for b in resident:
+        ev(b)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    for _ in range(reps):
+        for b in resident:
+            ev(b)
+    torch.cuda.synchronize(dev)
+    eval_ms = (time.perf_counter() - t2) / (reps * len(resident)) * 1e3
+    with torch.no_grad():
+        for b in resident:
+            b._hyper_index = None
+            model(b)
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        for b in resident:
+            b._hyper_index = None
+            model(b)
+        torch.cuda.synchronize(dev)
+        eager_eval_ms = (time.perf_counter() - t3) / len(resident) * 1e3
+    model.train()
     loader.close()
     tr.close()
     return {"value": round(n / el, 1), "unit": "molecules/s", "ms_per_step": round(el / (n / batch_size) * 1e3, 3),
             "resident_same_bucket_ms_per_step": round(res_ms, 3),
+            "eval_ms_per_batch": round(eval_ms, 3), "eval_molecules_per_s": round(batch_size / eval_ms * 1e3, 1),
+            "eval_eager_ms_per_batch": round(eager_eval_ms, 3),
+            "eval_what": "forward-only hipGraph replay of the evaluation pass (trainer.GraphedEvalStep) on resident padded "
+                         "batches; eager = the same forward pass launched from Python",
             "fraction_of_resident_same_bucket": round(res_ms / (el / (n / batch_size) * 1e3), 4),
             "bucket": list(resident[0].x.shape[:1]) + [int(resident[0].edge_attr.shape[0]), int(resident[0].edge_index0.shape[0])],
             "what": "training steps fed by MolStore -> BucketedLoader (prefetch thread, pinned packed staging, one H2D "

@@ -409,6 +409,20 @@ class Fitter:
         self.metrics = BootstrapMetrics(50, metric_seed)
         self.patience_lr, self.patience_stop = patience_lr, patience_stop
         self.sched = None
+        self.eval_step = None           # GraphedEvalStep, built at the first evaluation of a graphed fit (see _predict)
+        self.graph_eval = True
+
+    def _predict(self, data):
+        """model(data) for an evaluation pass (eval mode, no_grad): a replayed forward-only hipGraph when the training step is
+        the graphed one and the batch is a padded static-shape batch on the GPU (trainer.GraphedEvalStep), else eager."""
+        from .trainer import GraphedEvalStep, GraphedTrainStep
+        if (self.graph_eval and isinstance(self.step, GraphedTrainStep) and getattr(data, "num_real_graphs", None)
+                and data.y.is_cuda):
+            if self.eval_step is None:
+                self.eval_step = GraphedEvalStep(self.model)
+            return self.eval_step(data)
+        _drop_index(data)
+        return self.model(data)
 
     def _evaluate(self, loader) -> Dict[str, float]:
         self.model.eval()
@@ -416,8 +430,7 @@ class Fitter:
         scale = self.std if self.std else 1.0          # main.py:67-70: `if self.std:`
         with torch.no_grad():
             for data in loader:
-                _drop_index(data)
-                out, y = _real(self.model(data), data)
+                out, y = _real(self._predict(data), data)
                 self.metrics.update(out * scale, y * scale)
         self.model.train()
         return self.metrics.compute()
@@ -469,8 +482,7 @@ class Fitter:
         try:
             with torch.no_grad():
                 for data in test_loader:
-                    _drop_index(data)
-                    out, y = _real(self.model(data), data)
+                    out, y = _real(self._predict(data), data)
                     self.metrics.update(out * scale, y * scale)
                     preds.append(out.detach().float().cpu())
                     truth.append(y.detach().float().cpu())

@@ -490,3 +490,60 @@ class GraphedTrainStep:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
             slot["opt"].replay()
         return slot["loss"].detach()
+
+
+class GraphedEvalStep:
+    """``model(data)`` in eval mode under ``no_grad`` -- the validation / test passes the reference runs every epoch
+    (main.py:65-87,89-132) -- captured ONCE per static shape bucket as a forward-only hipGraph and replayed: an eager forward
+    pass is bound by Python launch issue (4-6 x the replayed time), exactly like the eager training step.  Batches must be
+    padded to bucket extents (``batch.pad_batch`` / ``fit.BucketedLoader``); the returned predictions are a STATIC tensor,
+    valid until the next call (rows past ``num_real_graphs`` are padding).  The graphs read the parameters and buffers in
+    place, so they follow the optimiser and ``load_state_dict`` without re-capture -- but they must be captured after a
+    GraphedTrainStep has moved the parameters into its flat buffer (``Fitter`` builds this lazily at the first evaluation)."""
+
+    def __init__(self, model: nn.Module):
+        self.model = model
+        self.slots = {}
+
+    def close(self):
+        self.slots = {}
+
+    def _capture(self, static):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                static._hyper_index = None
+                self.model(static)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        static._hyper_index = None
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            out = self.model(static)
+        return {"static": static, "graph": g, "out": out}
+
+    @torch.no_grad()
+    def __call__(self, data) -> torch.Tensor:
+        if self.model.training:
+            raise RuntimeError("GraphedEvalStep: put the model in eval mode first (the captured graphs are eval-mode forwards)")
+        key = GraphedTrainStep._key(data)
+        slot = self.slots.get(key)
+        if slot is None:
+            if hasattr(data, "packed"):
+                static = data.packed()
+            else:
+                static = type(data)(**{f: (getattr(data, f).clone() if torch.is_tensor(getattr(data, f))
+                                           else getattr(data, f)) for f in data.__dataclass_fields__})
+            static.num_real_graphs = getattr(data, "num_real_graphs", None)
+            slot = self.slots[key] = self._capture(static)
+        st = slot["static"]
+        lay = getattr(data, "_layout", None)
+        if lay is not None and lay == getattr(st, "_layout", None):
+            st._flat.copy_(data._flat, non_blocking=True)
+        else:
+            for f in data.__dataclass_fields__:
+                v = getattr(data, f)
+                if torch.is_tensor(v):
+                    getattr(st, f).copy_(v, non_blocking=True)
+        slot["graph"].replay()
+        return slot["out"]

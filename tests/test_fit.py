@@ -324,3 +324,39 @@ def test_discarded_lookahead_epoch_does_not_skip_a_permutation():
     assert want[0] != want[1] != want[2]
     assert epochs(True, True) == want
     assert epochs(True, False) == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["egnn_equihnns", "mhnnm"])
+def test_graphed_evaluation_matches_eager_evaluation(method):
+    """Fitter._evaluate / test on padded bucketed batches through trainer.GraphedEvalStep (a forward-only hipGraph per shape
+    bucket, main.py:65-87,89-132) give the predictions of the eager forward pass, before and after further training steps
+    (the graphs read the parameters -- and BatchNorm's running statistics -- in place)."""
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    mols = _mols(16 * 10, 21)
+    args = default_args(method=method, MLP_hidden=64, output_hidden=32)
+    model = MODELS[method](1, args).to("cuda:0")
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.weight, std=m.in_features ** -0.5)
+    fitter = Fitter(model, lr=1e-3, step_factory=GraphedTrainStep)
+    store = MolStore(mols)
+    train = BucketedLoader(store, 16, True, seed=0, device="cuda:0")
+    evald = BucketedLoader(store, 16, False, device="cuda:0")
+    for round_ in range(2):
+        for b in train:                                           # a few optimiser steps move parameters and buffers
+            fitter.step.step(b)
+        fitter.graph_eval = True
+        m_graph, t_graph = fitter.test(evald)
+        assert fitter.eval_step is not None and 1 <= len(fitter.eval_step.slots) <= 2
+        fitter.graph_eval = False
+        m_eager, t_eager = fitter.test(evald)
+        np.testing.assert_allclose(t_graph, t_eager, rtol=1e-5, atol=1e-5)
+        # (the bootstrap metric draws new resamples at every call: compare what it is computed from)
+        assert np.isfinite(m_graph["test_mae_mean"]) and np.isfinite(m_eager["test_mae_mean"])
+        assert float(np.abs(t_eager[:, 0]).std()) > 1e-3
+    train.close()
