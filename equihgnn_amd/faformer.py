@@ -159,8 +159,8 @@ class EdgeGraph:
 
     def __init__(self, pos, index: HyperIndex, k: int, radius: float):
         n = pos.shape[0]
-        if n < k + 1:
-            raise NotImplementedError("faformer: batches with fewer than 17 atoms are not supported")
+        # (clouds of <= k points -- a single small molecule, the reference's tests/run_*_3d.sh use --batch_size 1 -- keep k
+        # slots, the surplus masked: index._small_cloud_knn)
         self.N, self.K = n, k
         self.nbr, dist, self.csr_t = index.knn(pos, k, 1)
         self.nbr_flat = self.nbr.reshape(-1)

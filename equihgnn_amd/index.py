@@ -15,6 +15,23 @@ import torch
 from . import ops
 
 
+def _small_cloud_knn(pos: torch.Tensor, k: int):
+    """Self-excluded neighbour lists of a cloud with fewer than k + 1 points, padded to k slots.  The reference takes
+    min(k, N) (fa_former_layer.py:664,697: N - 1 others and the point itself at distance 1e9) or min(k, N - 1)
+    (equiformer_layer.py:1317-1323) neighbours there and masks by radius; here the list keeps its k slots -- the kernels'
+    fixed shape -- and the slots past the N - 1 real neighbours point at the point itself with key 1e9, which the radius
+    mask (key <= valid_radius) removes exactly like the reference's own self slot.  A handful of points: plain tensor ops."""
+    n = pos.shape[0]
+    p = pos.detach().float()
+    d = (p.unsqueeze(1) - p.unsqueeze(0)).norm(dim=-1)
+    d.fill_diagonal_(float("inf"))
+    val, idx = torch.sort(d, dim=-1, stable=True)                    # (ties: the lower index first, as the kernels)
+    own = torch.arange(n, device=pos.device).unsqueeze(1)
+    nbr = torch.cat((idx[:, :n - 1], own.expand(n, k - (n - 1))), 1)
+    key = torch.cat((val[:, :n - 1], torch.full((n, k - (n - 1)), 1e9, dtype=torch.float32, device=pos.device)), 1)
+    return nbr.to(torch.int32).contiguous(), key.contiguous()
+
+
 class HyperIndex:
     """CSR views of one batch's incidence structure.
 
@@ -82,7 +99,10 @@ class HyperIndex:
         """(nbr int32 [N,k], key fp32 [N,k], CSR of the transposed neighbour graph)."""
         hit = self._knn.get((k, mode))
         if hit is None:
-            nbr, key = ops.knn(pos, k, mode, self.n_box)
+            if mode == 1 and pos.shape[0] - 1 < k:
+                nbr, key = _small_cloud_knn(pos, k)
+            else:
+                nbr, key = ops.knn(pos, k, mode, self.n_box)
             csr_t = ops.csr_build(nbr.reshape(-1), None, self.N)      # int32 keys: no widening copy
             hit = (nbr, key, csr_t)
             self._knn[(k, mode)] = hit

@@ -99,6 +99,10 @@ CASE_TABLE = {
     "equiformer_equihnns_pcqm_c64": ("equiformer_equihnns", 64, 66, 4, True, True, dict(flavour="pcqm", big=41)),
     # FAFormer in TRAINING mode with its dropouts forced to p = 0
     "faformer_equihnns_c64_train_p0": ("faformer_equihnns", 64, 67, 5, True, True, dict(dropout0=True)),
+    # a cloud of <= 16 atoms (one small molecule + the one-atom molecule: 10 atoms): fa_former_layer.py:664,697 takes min(16, N)
+    # neighbours, equiformer_layer.py:1317-1323 min(16, N - 1)
+    "faformer_equihnns_tiny": ("faformer_equihnns", 64, 71, 1, False, True, dict(last_conj=False)),
+    "equiformer_equihnns_tiny": ("equiformer_equihnns", 64, 72, 1, True, True, dict(last_conj=False)),
     # degenerate edge geometry for the Equiformer's D construction
     "equiformer_equihnns_c64_degenerate": ("equiformer_equihnns", 64, 68, 5, True, True, dict(geometry="degenerate")),
 }
