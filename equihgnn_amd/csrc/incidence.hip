@@ -129,6 +129,11 @@ k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const 
 #pragma unroll
         for (int i = 0; i < NV; ++i) acc.v[i] = f4_zero();
         auto add_norm = [&](const Row<NV>& w) {
+#if defined(INC_ABLATE) && INC_ABLATE >= 1      // diagnostic build (tools/inc_ablation.py): the rows are gathered, the LayerNorm is not
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { f4_add(acc.v[i], mine.v[i]); f4_add(acc.v[i], w.v[i]); }
+            return;
+#endif
             Row<NV> x;
             unsigned pos;
             float rstd;
@@ -139,6 +144,10 @@ k_inc_fwd_col(const float* __restrict__ pa, const float* __restrict__ qb, const 
         for (int q0 = beg; q0 < end; q0 += 64) {
             const int cnt = (end - q0 < 64) ? (end - q0) : 64;
             const int my_o = (lane < cnt) ? col[q0 + lane] : 0;
+#if defined(INC_ABLATE) && INC_ABLATE >= 2      // ... and not even gathered: index chain (rowptr -> col) + own row + store only
+            acc.v[0].x += (float)my_o;
+            continue;
+#endif
             for (int j = 0; j < cnt; j += 4) {               // four entries' rows in flight together
                 Row<NV> w0, w1, w2, w3;
                 const int last = cnt - 1;

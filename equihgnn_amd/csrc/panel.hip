@@ -814,8 +814,9 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 // ---- B1: dh1[v] = LN1bwd(h1[v] + b1a; sum_e dhbar[e] / deg e), dX = [dh1 | dpa] . [W1a ; W2v]  [tail: B3 of the application before]
-// in0 = dhbar [M, C], rowptr / col / wq = incidence CSR by node + entry weights, in1 = h1, b0/g0 = b1a, gamma1, in2 = dpa,
-// w0 = stacked image [W1a ; W2v] (dy W, K = 2 C); out0 = dh1, out1 = dX, slab = [d b1a | d gamma1 | d beta1];
+// in0 = dhbar [M, C] (or, with w3 = w12 image (dy W), dqb: B2 folded in), rowptr / col / wq = incidence CSR by node + entry
+// weights, in1 = h1, b0/g0 = b1a, gamma1, in2 = dpa, w0 = stacked image [W1a ; W2v] (dy W, K = 2 C); out0 = dh1, out1 = dX,
+// slab = [d b1a | d gamma1 | d beta1];
 // tail: in3 = X of this application = Xn of the one before (mask), w1 = W3b image, w2 = w23 image, out5 = its u (read),
 //       b1/g1 = b3a, gamma3; out2 = g, out3 = dpre, out4 = ds, slab2, acc_out
 template <int C>
@@ -828,9 +829,13 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     const int r0 = (int)blockIdx.x * PN_ROWS;
     const RtPos P(r0, p.rows, wave, lane);
     const bool mul = S::NT >= 4 || wave < S::NT;
-    WStream<KS2, S::NTW, 1> ws;
-    ws.init(0, p.w0, mul ? wave : 0, lane);
-    ws.prime();
+    // w3 != null: B2 folded in -- in0 is dqb and the gathered sums are multiplied by w12 here (the gathered mean is linear:
+    // sum_e w_e (dqb[e] w12) = (sum_e w_e dqb[e]) w12), so dhbar never exists and its launch is gone
+    WStream<S::KS, S::NTW, 1> ws12;
+    if (p.w3) {
+        ws12.init(0, p.w3, mul ? wave : 0, lane);
+        ws12.prime();
+    }
     RowTile<C> h, dpa;
     rt_load<C>(h, p.in1, C, P.rowc, P.c4);
     rt_load<C>(dpa, p.in2, C, P.rowc, P.c4);
@@ -842,6 +847,23 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     });
     for (int i = s_end - s_beg; i < 8; ++i)
         if (lane * 4 < C) *reinterpret_cast<float4*>(s_stg + (wave * 8 + i) * PN_STG_LD + lane * 4) = f4_zero();
+    if (p.w3) {
+        RowTile<C> dq;
+        rt_load<C>(dq, s_stg, PN_STG_LD, P.lrow, P.c4);
+        rt_a_put<C, S::KS>(dq, s_img, P.lrow, P.c8);
+        __syncthreads();
+        f32x16 acc12[1][S::NTW];
+        acc_zero<1, S::NTW>(acc12);
+        if (mul) {
+            panel_mma<S::KS, S::NTW, 1>(s_img, ws12, acc12, lane);
+            acc_to_staging<S::NTW>(s_stg, acc12[0], wave, lane);
+        }
+        __syncthreads();
+    }
+    WStream<KS2, S::NTW, 1> ws;
+    ws.init(0, p.w0, mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
     RowTile<C> a_db, a_dg, a_dbeta;
     rt_zero<C>(a_db); rt_zero<C>(a_dg); rt_zero<C>(a_dbeta);
     {

@@ -17,6 +17,7 @@ from .aggregate import entry_weights
 from .grads import (_linear_weight_grad, _wgrad_deferred, colsum)
 from .panel import (conv_panel, conv_panel_slab, panel_gemm, panel_pack, panel_supported)
 
+FOLD_B2 = not os.environ.get("EQH_NO_B2_FOLD")     # dhbar = dqb w12 inside B1 (after its gather) instead of a launch of its own
 USE_CONV_STACK = not os.environ.get("EQH_NO_CONV_STACK")     # tests switch it off to compare with the unfused path
 
 
@@ -160,9 +161,11 @@ class _MergedConvStack(torch.autograd.Function):
             if dgamma2 is None:
                 dg2_parts.append(dg2)
             dbe2 = _sum_opt(dbe2, colsum(ds, by_v.rowptr, 1, into=_acc_target(p_be2)))
-            # B2: dhbar = dqb w12;  w12, b12 gradients
-            dhbar = new(M)
-            timed("k_conv_b2", flops(M, 1), lambda: panel_gemm(dqb, iw12_n, C, out=dhbar))
+            # B2 (dhbar = dqb w12) rides inside B1: the gathered mean is linear, so B1 gathers dqb and multiplies the sums by w12
+            b1_in, b1_w3 = dqb, iw12_n
+            if not FOLD_B2:
+                b1_in, b1_w3 = new(M), None
+                timed("k_conv_b2", flops(M, 1), lambda: panel_gemm(dqb, iw12_n, C, out=b1_in))
             dW["w12"] = _sum_opt(dW["w12"], _linear_weight_grad(w12, None, None, dqb, hbar))
             db12 = _sum_opt(db12, colsum(dqb, into=_acc_target(p_b12)))
             # B1 (+ B3 of the application before)
@@ -175,16 +178,16 @@ class _MergedConvStack(torch.autograd.Function):
                 ndx = None if relu_out else new(N)
                 ndpre, nds = new(N), new(N)
                 o3 = vec_out(acc3, t3, sm3)
-                timed("k_conv_b1", flops(N, 4), lambda: conv_panel(
+                timed("k_conv_b1", flops(N, 5), lambda: conv_panel(
                     hip.HG_CONV_B1, N, C, dev, eps=eps[0], scale=scale, tail=True, acc_first=False, accumulate=acc1,
-                    in0=dhbar, rowptr=by_v.rowptr, col=by_v.col, wq=ew, in1=h1, b0=b1a, g0=g1, in2=dpa, w0=istack, out0=dh1,
+                    in0=b1_in, w3=b1_w3, rowptr=by_v.rowptr, col=by_v.col, wq=ew, in1=h1, b0=b1a, g0=g1, in2=dpa, w0=istack, out0=dh1,
                     out1=ndx, slab=conv_panel_slab(N, C, dev), dbias=o1[0], dgamma=o1[1], dbeta=o1[2],
                     in3=pxn if relu_out else None, w1=iW3b_n, w2=iw23_n, out5=pu, b1=b3a, g1=g3, out2=ng, out3=ndpre, out4=nds,
                     acc_out=dcw, slab2=conv_panel_slab(N, C, dev), dbias2=o3[0], dgamma2=o3[1], dbeta2=o3[2]))
             else:
                 dX = new(N)
-                timed("k_conv_b1", flops(N, 2), lambda: conv_panel(
-                    hip.HG_CONV_B1, N, C, dev, eps=eps[0], tail=False, accumulate=acc1, in0=dhbar, rowptr=by_v.rowptr, col=by_v.col,
+                timed("k_conv_b1", flops(N, 3), lambda: conv_panel(
+                    hip.HG_CONV_B1, N, C, dev, eps=eps[0], tail=False, accumulate=acc1, in0=b1_in, w3=b1_w3, rowptr=by_v.rowptr, col=by_v.col,
                     wq=ew, in1=h1, b0=b1a, g0=g1, in2=dpa, w0=istack, out0=dh1, out1=dX, slab=conv_panel_slab(N, C, dev),
                     dbias=o1[0], dgamma=o1[1], dbeta=o1[2]))
             dW["W1a"] = _sum_opt(dW["W1a"], _linear_weight_grad(W1a, None, None, dh1, x_in))

@@ -221,7 +221,8 @@ int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t C, cons
  *              out0 = g = dXn [Xn > 0] (with in1), out1 = dpre, out2 = ds = scale dpre w23; acc_out (+)= dpre (acc_first: =);
  *              dbias / dgamma / dbeta (+)= the LayerNorm's vector gradients (slab: hg_conv_panel_slab_bytes, kept until
  *              eqh_defer_flush when reductions are deferred).
- *  HG_CONV_B1  in0 = dhbar; rowptr / col / wq = incidence CSR by node and its entries' 1 / deg(hyperedge); in1 = h1;
+ *  HG_CONV_B1  in0 = dhbar (or dqb with w3 = w12 N: the product dhbar = dqb w12 is then formed here, after the gather, and
+ *              needs no launch of its own); rowptr / col / wq = incidence CSR by node and its entries' 1 / deg(hyperedge); in1 = h1;
  *              b0 / g0 = b1a, gamma1; in2 = dpa; w0 = [W1a ; W2v] N stacked along K.
  *              out0 = dh1, out1 = dX = dh1 W1a + dpa W2v (may be NULL with tail); dbias / dgamma / dbeta, slab as B3.
  *              tail != 0: B3 of the application before on dX (in3 = its Xn = this X, out5 = its u (read), w1 = W3b N, w2 = w23 N,

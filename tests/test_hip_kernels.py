@@ -1935,6 +1935,18 @@ def test_conv_panel_backward_stages_match_autograd_float64(C, n_nodes, n_he):
         assert torch.allclose(d(dX), X64.grad, **tol)
         for i, k in enumerate(("b1a", "g1", "be1")):
             assert torch.allclose(d(vec1[i]), lv[k].grad, rtol=1e-3, atol=1e-3 * float(lv[k].grad.abs().max())), k
+        if not tail:   # B2 folded in: in0 = dqb, w3 = w12 image  ==  in0 = dqb @ w12
+            (iw12_n,) = ops.panel_pack([(P["w12"], False)])
+            dqb = torch.randn(n_he, C, device=DEV, generator=g_)
+            res = []
+            for kw in (dict(in0=(dqb.double() @ d(P["w12"])).float().contiguous()), dict(in0=dqb, w3=iw12_n)):
+                a, bb, vv = new(n_nodes), new(n_nodes), torch.zeros(3, C, device=DEV)
+                ops.conv_panel(hip.HG_CONV_B1, n_nodes, C, DEV, rowptr=by_v.rowptr, col=by_v.col, wq=ew, in1=h1, b0=P["b1a"],
+                               g0=P["g1"], in2=dpa, w0=istack, out0=a, out1=bb, slab=ops.conv_panel_slab(n_nodes, C, DEV),
+                               dbias=vv[0], dgamma=vv[1], dbeta=vv[2], **kw)
+                res.append((a, bb, vv))
+            for x, y in zip(res[0], res[1]):
+                assert torch.allclose(x, y, rtol=1e-4, atol=1e-4 * float(x.abs().max()))
         if tail:   # = HG_CONV_B3 with dXn = this dX and the mask [xprev > 0]
             gr, dprer, dsr, vr = new(n_nodes), new(n_nodes), new(n_nodes), torch.zeros(3, C, device=DEV)
             ops.conv_panel(hip.HG_CONV_B3, n_nodes, C, DEV, scale=0.5, acc_first=True, in0=dX, in1=xprev, w0=iW3b_n, w1=iw23_n,
