@@ -475,43 +475,41 @@ __device__ __forceinline__ void gather_range(const float* __restrict__ src, cons
     const int p_beg = rowptr[s_beg];
     const int my_rend = (s_beg + lane < s_end) ? rowptr[s_beg + lane + 1] : 0;   // lane i: end of row s_beg + i
     const int p_end = rowptr[s_end];
-    int q0 = p_beg;
-    int cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
-    int my_c = (lane < cnt) ? col[q0 + lane] : 0;
-    float my_w = (wq && lane < cnt) ? wq[q0 + lane] : 1.0f;
-    int q = p_beg;
-    for (int row = s_beg; row < s_end; ++row) {
-        const int rend = __builtin_amdgcn_readlane(my_rend, row - s_beg);
-        const int rbeg = q;
-        float4 sum = f4_zero();
-        while (q < rend) {
-            if (q - q0 >= 64) {
-                q0 += 64;
-                cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
-                my_c = (lane < cnt) ? col[q0 + lane] : 0;
-                my_w = (wq && lane < cnt) ? wq[q0 + lane] : 1.0f;
-            }
-            const int j = q - q0;
-            int lim = rend - q0;
-            if (lim > cnt) lim = cnt;
-            const int n = (lim - j < 4) ? lim - j : 4;
-            const int j1 = (n > 1) ? j + 1 : j, j2 = (n > 2) ? j + 2 : j, j3 = (n > 3) ? j + 3 : j;
-            const float4 d0 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j), lane);
-            const float4 d1 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j1), lane);
-            const float4 d2 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j2), lane);
-            const float4 d3 = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, j3), lane);
-            const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
-            const float w1 = (n > 1) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j1)) : 0.f;
-            const float w2 = (n > 2) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j2)) : 0.f;
-            const float w3 = (n > 3) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j3)) : 0.f;
-            f4_fma(sum, d0, w0);
-            f4_fma(sum, d1, w1);
-            f4_fma(sum, d2, w2);
-            f4_fma(sum, d3, w3);
-            q += n;
-        }
+    // The range's entries are walked in order, EIGHT gathered rows in flight at a time whatever row they belong to (a
+    // hyperedge has 2-3 nodes, a node 2-3 hyperedges: one round trip per CSR row -- eight of them in sequence per wavefront --
+    // was what a panel's prologue waited for); a row is handed to the sink when the walk passes its end.
+    int row = s_beg, rbeg = p_beg;
+    int rend = __builtin_amdgcn_readlane(my_rend, 0);
+    float4 sum = f4_zero();
+    auto flush = [&]() {
         sink(row - s_beg, sum, rend - rbeg);
+        sum = f4_zero();
+        rbeg = rend;
+        ++row;
+        if (row < s_end) rend = __builtin_amdgcn_readlane(my_rend, row - s_beg);
+    };
+    for (int q0 = p_beg; q0 < p_end; q0 += 64) {
+        const int cnt = (p_end - q0 < 64) ? (p_end - q0) : 64;
+        const int my_c = (lane < cnt) ? col[q0 + lane] : 0;
+        const float my_w = (wq && lane < cnt) ? wq[q0 + lane] : 1.0f;
+        for (int j0 = 0; j0 < cnt; j0 += 8) {
+            float4 d[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {       // entries past the chunk re-read its last one and are not added
+                const int jj = (j0 + t < cnt) ? j0 + t : cnt - 1;
+                d[t] = ld_row<C>(src, C, __builtin_amdgcn_readlane(my_c, jj), lane);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (j0 + t < cnt) {
+                    const int q = q0 + j0 + t;
+                    while (q >= rend) flush();          // (rows without entries are handed out empty)
+                    f4_fma(sum, d[t], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j0 + t)));
+                }
+            }
+        }
     }
+    while (row < s_end) flush();
 }
 
 struct ConvPanelArgs {

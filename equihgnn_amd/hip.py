@@ -10,7 +10,9 @@ import os
 from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libequihgnn_hip.so")
+# (EQH_LIB_PATH: another build of the same sources -- how two variants of a kernel are timed on ONE box, whose clocks differ
+# from the next box's by more than most optimisations gain)
+LIB_PATH = os.environ.get("EQH_LIB_PATH") or os.path.join(_PKG, "libequihgnn_hip.so")
 
 class HgDenseProblem(ctypes.Structure):
     """HgDenseProblem of include/equihgnn_hip.h (one dense-layer problem of hg_dense_batch_f32)."""
