@@ -560,6 +560,22 @@ def cpu_baseline(method, args_ns, batch_cpu, seconds):
                       f"{el:.1f} s"}
 
 
+class _StdoutToStderr:
+    """RCCL announces itself on STDOUT when a communicator is created ("RCCL version : ...", five lines); this script's
+    stdout is ONE JSON line.  File-descriptor level: the banner comes from C code."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def launch_ranks(a) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through
     torch.distributed.run, as the reference's Trainer(devices="auto", strategy="ddp...") does (main.py:271-283).
@@ -604,10 +620,14 @@ def main():
         # "nccl" is RCCL on ROCm.  EQH_BACKEND=gloo exists only to rehearse the multi-rank code path
         # on a one-GPU box (several ranks sharing one device cannot form an RCCL communicator).
         backend = os.environ.get("EQH_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
+            t0 = torch.zeros(1, device=dev)
+            dist.all_reduce(t0)                     # (the communicator exists now, whatever the backend's laziness)
+            torch.cuda.synchronize(dev)
 
     if a.only_saturation:
         sat = saturation_probe(dev)
@@ -714,7 +734,11 @@ def main():
             port = sk.getsockname()[1]
             sk.close()
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+                t0 = torch.zeros(1, device=dev)
+                dist.all_reduce(t0)
+                torch.cuda.synchronize(dev)
             try:
                 ref = timed_run(a.method, a.batch, a.flavour, a.steps, a.warmup, 2, blocks=min(a.blocks, 7),
                                 trainer_kw=dict(collective=False))

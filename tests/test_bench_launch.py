@@ -46,6 +46,7 @@ def test_launcher_starts_two_ranks_gloo_on_one_device():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["config"]["parallelism"] == "dp2"
     assert "gloo" in line["config"]["collective"] and line["value"] > 0 and line["scaling"] == "weak"
+    assert len(r.stdout.strip().splitlines()) == 1          # ONE JSON line on stdout (library banners go to stderr)
 
 
 @pytest.mark.gpu
