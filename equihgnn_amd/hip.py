@@ -14,16 +14,6 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # from the next box's by more than most optimisations gain)
 LIB_PATH = os.environ.get("EQH_LIB_PATH") or os.path.join(_PKG, "libequihgnn_hip.so")
 
-class HgDenseProblem(ctypes.Structure):
-    """HgDenseProblem of include/equihgnn_hip.h (one dense-layer problem of hg_dense_batch_f32)."""
-    _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("bias", c_void_p),
-                ("c", c_void_p), ("ldc", c_int64), ("out", c_void_p), ("ldo", c_int64), ("m", c_int64),
-                ("n", c_int32), ("k", c_int32), ("b_is_nk", c_int32), ("alpha", c_float),
-                ("seg_rowptr", c_void_p), ("seg_idx", c_void_p), ("seg_wptr", c_void_p), ("seg_mean", c_int32),
-                ("ln_eps", c_float), ("ln_bias", c_void_p), ("ln_gamma", c_void_p), ("ln_beta", c_void_p),
-                ("a_out", c_void_p), ("ld_aout", c_int64)]
-
-
 class HgSmallMM(ctypes.Structure):
     """HgSmallMM of include/equihgnn_hip.h (one problem of hg_small_mm_batch)."""
     _fields_ = [("a", c_void_p), ("a_rs", c_int64), ("a_cs", c_int64), ("b", c_void_p), ("b_rs", c_int64), ("b_cs", c_int64),
@@ -178,7 +168,6 @@ SIGNATURES = {
     "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
-    "hg_dense_batch_f32": (c_int32, [c_int32, ctypes.POINTER(HgDenseProblem), c_void_p]),
     "eqh_stamp": (c_int32, [c_void_p, c_void_p]),
     "eqh_wall_clock_khz": (c_int64, []),
     "eqh_clock_probe": (c_int32, [c_void_p, c_int32, c_void_p]),

@@ -35,7 +35,7 @@ from .aggregate import (  # noqa: F401
     gather_rows, embed_sum, KNN_GRID_MIN_POINTS, knn, scatter,
 )
 from .products import (  # noqa: F401
-    DenseProblem, dense_supported, dense_batch, dense, GemmProblem, GEMM_TILE, gemm_supported, gemm_batch, gemm,
+    GemmProblem, GEMM_TILE, gemm_supported, gemm_batch, gemm,
     X6_MIN_OUTPUTS, X6_MAX_K, X6_DEEP_ROWS, X6_WGRAD_OUTPUTS, X6_WGRAD_ROWS, USE_X6, _x6_ok, mm_nt, mm_nn, small_mm_batch,
 )
 from .panel import (  # noqa: F401

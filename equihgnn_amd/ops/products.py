@@ -16,90 +16,6 @@ from .. import hip
 from ._base import (_f32c, _ptr, _row_view, _stream, _workspace, timed)
 
 
-# --------------------------------------------------------------------------------------------
-# dense layer (hg_dense_batch_f32, csrc/dense.hip)
-# --------------------------------------------------------------------------------------------
-@dataclass
-class DenseProblem:
-    """One problem of a dense_batch launch: out = alpha * A' @ op(b) (+ bias) (+ c); see include/equihgnn_hip.h.
-    ``a``: [M, K] rows (or, with ``seg``, the SOURCE rows the CSR gathers from); ``b``: weight [N, K] if ``nk`` else
-    [K, N] (any 2-D view with unit inner stride); ``seg`` = (rowptr, idx or None, wptr or None, mean, n_rows);
-    ``ln`` = (bias, gamma, beta, eps); ``a_out``: True to receive the prologue's A'."""
-
-    a: torch.Tensor
-    b: torch.Tensor
-    nk: bool = True
-    bias: Optional[torch.Tensor] = None
-    c: Optional[torch.Tensor] = None
-    alpha: float = 1.0
-    seg: Optional[tuple] = None
-    ln: Optional[tuple] = None
-    a_out: bool = False
-    out: Optional[torch.Tensor] = None
-
-
-def dense_supported(k: int, n: int) -> bool:
-    return k % 4 == 0 and n % 4 == 0 and k > 0 and n > 0
-
-
-def dense_batch(problems):
-    """hg_dense_batch_f32: up to 8 independent dense layers in ONE launch.  Returns [(out, a_out or None)]."""
-    n = len(problems)
-    assert 1 <= n <= 8
-    arr = (hip.HgDenseProblem * n)()
-    keep, res = [], []
-    dev = problems[0].a.device
-    for i, pr in enumerate(problems):
-        a = _row_view(pr.a, "dense: a")
-        b = _row_view(pr.b, "dense: b")
-        K = a.shape[1]
-        N = b.shape[0] if pr.nk else b.shape[1]
-        if (b.shape[1] if pr.nk else b.shape[0]) != K:
-            raise ValueError(f"dense: a is [*, {K}] but b is {tuple(b.shape)} (nk={pr.nk})")
-        M = a.shape[0] if pr.seg is None else int(pr.seg[4])
-        if not dense_supported(K, N):
-            raise ValueError("dense: K and N must be multiples of 4")
-        out = pr.out if pr.out is not None else torch.empty((M, N), dtype=torch.float32, device=dev)
-        q = arr[i]
-        q.a, q.lda, q.b, q.ldb, q.b_is_nk = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), 1 if pr.nk else 0
-        q.out, q.ldo, q.m, q.n, q.k, q.alpha = out.data_ptr(), out.stride(0), M, N, K, float(pr.alpha)
-        if pr.bias is not None:
-            bias = _f32c(pr.bias)
-            keep.append(bias)
-            q.bias = bias.data_ptr()
-        if pr.c is not None:
-            c = _row_view(pr.c, "dense: c")
-            keep.append(c)
-            q.c, q.ldc = c.data_ptr(), c.stride(0)
-        a_out = None
-        if pr.seg is not None:
-            rowptr, idx, wptr, mean = pr.seg[:4]
-            q.seg_rowptr = rowptr.data_ptr()
-            q.seg_idx = idx.data_ptr() if idx is not None else None
-            q.seg_wptr = wptr.data_ptr() if wptr is not None else None
-            q.seg_mean = 1 if mean else 0
-        if pr.ln is not None:
-            lb, lg, lbeta, eps = pr.ln
-            lb, lg, lbeta = _f32c(lb), _f32c(lg), _f32c(lbeta)
-            keep.extend((lb, lg, lbeta))
-            q.ln_bias, q.ln_gamma, q.ln_beta, q.ln_eps = lb.data_ptr(), lg.data_ptr(), lbeta.data_ptr(), float(eps)
-        if pr.a_out:
-            a_out = torch.empty((M, K), dtype=torch.float32, device=dev)
-            q.a_out, q.ld_aout = a_out.data_ptr(), K
-        keep.extend((a, b))
-        res.append((out, a_out))
-    probs = list(problems)
-    timed("k_dense", lambda: sum(2 * r[0].shape[0] * r[0].shape[1] * (pr.a.shape[1]) for r, pr in zip(res, probs)),
-          lambda: hip.check(hip.lib().hg_dense_batch_f32(n, arr, _stream(dev)), "hg_dense_batch_f32"))
-    return res
-
-
-def dense(a, b, nk=True, bias=None, c=None, alpha=1.0, seg=None, ln=None, a_out=False, out=None):
-    """One dense layer through hg_dense_batch_f32; returns out, or (out, a_out) when ``a_out``."""
-    (o, ao), = dense_batch([DenseProblem(a, b, nk, bias, c, alpha, seg, ln, a_out, out)])
-    return (o, ao) if a_out else o
-
-
 # ------------------------------------------------------------------------------------------------------------------
 # fp32 GEMM on the bf16 matrix cores (csrc/gemm_x6.hip): every dense product of the models goes through here
 # ------------------------------------------------------------------------------------------------------------------

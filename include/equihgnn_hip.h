@@ -61,53 +61,6 @@ int eqh_defer_begin(void* stream);
 int eqh_defer_flush(void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Dense layer on the fp32 matrix cores (csrc/dense.hip) -- every nn.Linear / F.linear of the path (mlp.py:91-99,
- * conv.py:169-182, egnn_layer.py:180-208) and its input-gradient product:
- *
- *     out[m, n] = alpha * sum_k A'[m, k] * Bop[k, n]  (+ bias[n])  (+ c[m, n])
- *
- *   b_is_nk != 0 : b is an nn.Linear weight [n, k] (row stride ldb): out = A' b^T           (forward)
- *   b_is_nk == 0 : b is [k, n] (row stride ldb): out = A' b                                  (input gradient)
- * A' is `a` [m, k] (row stride lda), or is produced while the operand tile is staged (at most one prologue):
- *   segment  (seg_rowptr != NULL): A'[r] = s(r) * sum_{q in [seg_rowptr[r], seg_rowptr[r+1])} w(j_q) a[j_q],
- *            j_q = seg_idx[q] (seg_idx NULL: j_q = q; negative: null entry), w(j) = 1 / max(seg_wptr[j+1] -
- *            seg_wptr[j], 1) (seg_wptr NULL: 1), s(r) = 1 / max(row length, 1) if seg_mean else 1 -- the semantics
- *            of hg_segment_reduce_f32, i.e. torch_scatter.scatter of gathered rows (conv.py:172-173) followed by
- *            the Linear, in one launch;
- *   relu_ln  (ln_gamma != NULL):   A'[r] = LayerNorm(relu(a[r] + ln_bias)) * ln_gamma + ln_beta over the k
- *            columns (eps ln_eps): the hidden layer of mlp.py:91-99 followed by the next Linear.
- * a_out (row stride ld_aout), if not NULL, receives A' (the backward pass needs it for the weight gradient).
- * n, k multiples of 4; row strides multiples of 4 floats; pointers 16-byte aligned.  Up to 8 problems per launch
- * (independent Linears of one layer, all with the same kind of prologue); results are bitwise reproducible.
- * ------------------------------------------------------------------------------------------- */
-typedef struct HgDenseProblem {
-    const float* a;
-    int64_t lda;
-    const float* b;
-    int64_t ldb;
-    const float* bias;
-    const float* c;
-    int64_t ldc;
-    float* out;
-    int64_t ldo;
-    int64_t m;
-    int32_t n, k;
-    int32_t b_is_nk;
-    float alpha;
-    const int32_t* seg_rowptr;
-    const int32_t* seg_idx;
-    const int32_t* seg_wptr;
-    int32_t seg_mean;
-    float ln_eps;
-    const float* ln_bias;
-    const float* ln_gamma;
-    const float* ln_beta;
-    float* a_out;
-    int64_t ld_aout;
-} HgDenseProblem;
-int hg_dense_batch_f32(int32_t n_problems, const HgDenseProblem* problems, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
  * fp32 GEMM with fp32-grade results on the bf16 matrix cores (csrc/gemm_x6.hip):
  *
  *     c[m, n] = act( alpha * op(a)[m, k] . op(b)[k, n]  (+ beta * d[m, n])  (+ bias[n]) )

@@ -1546,71 +1546,6 @@ def test_null_entries_read_as_zero_rows():
         np.testing.assert_allclose(H.grad[:40].cpu().numpy(), want.cpu().numpy(), rtol=1e-6)
 
 
-@pytest.mark.parametrize("M,N,K,nk,bias,c,alpha", [(4736, 256, 256, True, False, False, 1.0), (4736, 256, 256, False, False, False, 1.0),
-                                                   (100, 64, 36, True, True, True, 0.5), (33, 68, 272, False, True, False, 1.0),
-                                                   (257, 512, 272, True, True, False, 1.0), (1, 4, 4, True, False, False, 1.0),
-                                                   (300, 2176, 256, True, True, False, 1.0), (300, 256, 2176, False, False, True, 2.0)])
-def test_dense_matches_float64(M, N, K, nk, bias, c, alpha):
-    """hg_dense_batch_f32 (fp32 MFMA dense layer, csrc/dense.hip): both weight layouts, ragged tiles in M / N / K,
-    bias, residual and scale epilogues, against a float64 product."""
-    ops = _ops()
-    g = torch.Generator(device=DEV).manual_seed(M + N + K)
-    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
-    a, b = rnd(M, K), (rnd(N, K) if nk else rnd(K, N))
-    bi, cc = (rnd(N) if bias else None), (rnd(M, N) if c else None)
-    out = ops.dense(a, b, nk, bi, cc, alpha)
-    ref = alpha * (a.double() @ (b.double().t() if nk else b.double()))
-    if bias:
-        ref = ref + bi.double()
-    if c:
-        ref = ref + cc.double()
-    err = float((out.double() - ref).abs().max()) / float(ref.abs().max())
-    assert err < 4e-6 * max(1.0, (K / 256) ** 0.5), err
-    out2 = ops.dense(a, b, nk, bi, cc, alpha)
-    assert torch.equal(out, out2)                     # fixed summation order: bitwise reproducible
-
-
-def test_dense_prologues_and_batching():
-    """The row-op prologues of hg_dense_batch_f32 -- segmented gather-mean (torch_scatter.scatter of gathered rows,
-    conv.py:172-173, forward and mean-weighted backward form) and bias + ReLU + LayerNorm (mlp.py:91-99) -- against
-    the stand-alone kernels they fuse, a column-block weight view (W[:, c0:c1], no copy), and two problems in one
-    launch."""
-    ops = _ops()
-    g = torch.Generator(device=DEV).manual_seed(5)
-    rnd = lambda *s: torch.randn(*s, device=DEV, generator=g)
-    M, S, K, N, nnz = 1203, 1100, 256, 192, 2600
-    key = torch.randint(0, M, (nnz,), device=DEV, generator=g)
-    col = torch.randint(0, S, (nnz,), device=DEV, generator=g)
-    key[:40] = 7                                       # one long row (more entries than the register gather holds)
-    csr = ops.csr_build(key, col, M)
-    csr_t = ops.csr_build(col, key, S)
-    src, w, bias = rnd(S, K), rnd(N, K), rnd(N)
-    out, a_out = ops.dense(src, w, True, bias, seg=(csr.rowptr, csr.col, None, True, M), a_out=True)
-    agg = ops._segment_reduce(src, csr.col, csr.rowptr, None, M, True)
-    np.testing.assert_allclose(a_out.cpu().numpy(), agg.cpu().numpy(), atol=2e-6, rtol=1e-6)
-    ref = agg.double() @ w.double().t() + bias.double()
-    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 4e-6
-    dy, wt = rnd(M, K), rnd(K, N)
-    out2, a2 = ops.dense(dy, wt, False, seg=(csr_t.rowptr, csr_t.col, csr.rowptr, False, S), a_out=True)
-    agg2 = ops._segment_reduce(dy, csr_t.col, csr_t.rowptr, csr.rowptr, S, False)
-    np.testing.assert_allclose(a2.cpu().numpy(), agg2.cpu().numpy(), atol=2e-6, rtol=1e-6)
-    ref2 = agg2.double() @ wt.double()
-    assert float((out2.double() - ref2).abs().max() / ref2.abs().max()) < 4e-6
-    h, pb, ga, be = rnd(M, K), rnd(K), rnd(K), rnd(K)
-    out3, a3 = ops.dense(h, w, True, bias, ln=(pb, ga, be, 1e-5), a_out=True)
-    xn = torch.nn.functional.layer_norm(torch.relu(h.double() + pb.double()), (K,), ga.double(), be.double(), 1e-5)
-    assert float((a3.double() - xn).abs().max()) < 1e-5
-    ref3 = xn @ w.double().t() + bias.double()
-    assert float((out3.double() - ref3).abs().max() / ref3.abs().max()) < 4e-6
-    wide = rnd(N, 2 * K)                               # Linear over cat(a, b): the second half of the weight, in place
-    out4 = ops.dense(h, wide[:, K:], True)
-    ref4 = h.double() @ wide[:, K:].double().t()
-    assert float((out4.double() - ref4).abs().max() / ref4.abs().max()) < 4e-6
-    (o5, _), (o6, _) = ops.dense_batch([ops.DenseProblem(h, w), ops.DenseProblem(dy, wt, nk=False, alpha=0.5)])
-    assert float((o5.double() - h.double() @ w.double().t()).abs().max()) < 2e-4
-    assert float((o6.double() - 0.5 * (dy.double() @ wt.double())).abs().max()) < 2e-4
-    with pytest.raises(Exception):                     # one kind of prologue per launch
-        ops.dense_batch([ops.DenseProblem(h, w), ops.DenseProblem(h, w, ln=(pb, ga, be, 1e-5))])
 
 
 @pytest.mark.parametrize("N,K,H,D", [(1, 16, 2, 128), (517, 16, 2, 128), (33, 16, 2, 32), (40, 7, 1, 64), (9, 16, 4, 16)])
