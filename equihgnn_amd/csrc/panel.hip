@@ -829,6 +829,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     const bool mul = S::NT >= 4 || wave < S::NT;
     // w3 != null: B2 folded in -- in0 is dqb and the gathered sums are multiplied by w12 here (the gathered mean is linear:
     // sum_e w_e (dqb[e] w12) = (sum_e w_e dqb[e]) w12), so dhbar never exists and its launch is gone
+    PN_STAMP(0);
     WStream<S::KS, S::NTW, 1> ws12;
     if (p.w3) {
         ws12.init(0, p.w3, mul ? wave : 0, lane);
@@ -845,6 +846,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
     });
     for (int i = s_end - s_beg; i < 8; ++i)
         if (lane * 4 < C) *reinterpret_cast<float4*>(s_stg + (wave * 8 + i) * PN_STG_LD + lane * 4) = f4_zero();
+    PN_STAMP(1);
     if (p.w3) {
         RowTile<C> dq;
         rt_load<C>(dq, s_stg, PN_STG_LD, P.lrow, P.c4);
@@ -858,6 +860,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         }
         __syncthreads();
     }
+    PN_STAMP(2);
     WStream<KS2, S::NTW, 1> ws;
     ws.init(0, p.w0, mul ? wave : 0, lane);
     ws.prime();
@@ -874,6 +877,7 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         rt_a_put<C, KS2>(dh, s_img, P.lrow, P.c8, 0);
         rt_a_put<C, KS2>(dpa, s_img, P.lrow, P.c8, C / 4);
     }
+    PN_STAMP(3);
     __syncthreads();
     f32x16 acc[1][S::NTW];
     acc_zero<1, S::NTW>(acc);
@@ -881,16 +885,19 @@ __global__ void __launch_bounds__(PN_THREADS) __attribute__((amdgpu_waves_per_eu
         panel_mma<KS2, S::NTW, 1>(s_img, ws, acc, lane);
         acc_to_staging<S::NTW>(s_stg, acc[0], wave, lane);
     }
+    PN_STAMP(4);
     __syncthreads();
     RowTile<C> dx;
     rt_load<C>(dx, s_stg, PN_STG_LD, P.lrow, P.c4);
     if (p.out1 && P.live) rt_store<C>(dx, p.out1, C, P.row, P.c4);     // (with the tail only the masked gradient g is needed afterwards)
     write_slab<C>(s_stg, p.slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, P.lrow, P.c4);
+    PN_STAMP(5);
     if (!p.tail) return;
     // the tail starts from dX, which the slab reduction has overwritten in the staging tile: back from registers
     rt_store<C>(dx, s_stg, PN_STG_LD, P.lrow, P.c4);
     stage_b3<C, true>(p, s_img, s_stg, nullptr, 0, p.in3, p.w1, p.w2, p.out5, p.b1, p.g1, p.out2, p.out3, p.out4, p.slab2,
                       p.acc_out, p.acc_first, P, wave, lane, mul);
+    PN_STAMP(6);
 }
 
 // =============================================================================================================================

@@ -22,12 +22,12 @@ elif [ "$1" = 1 ]; then
   # and per-kernel averages of the training step ALONE (95 replays + 2 set-up steps; the CSV above also holds the
   # roofline probes, which launch the same scatter kernels at the saturating size)
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
   python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
 elif [ "$1" = 1b ]; then
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
   python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
 elif [ "$1" = 2 ]; then
