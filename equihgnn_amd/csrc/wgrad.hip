@@ -37,7 +37,7 @@ struct Stage {
 
 // rows k = k0 + 4 t + q, t < AHEAD; rows at or past k_end contribute zeros (address clamped, value masked)
 __device__ __forceinline__ void load_stage(Stage& st, const float* __restrict__ pa, const float* __restrict__ pb,
-                                           int64_t k0, int64_t k_end, int64_t k_clamp, int O, int I, int q) {
+                                           int64_t k0, int64_t k_end, int64_t k_clamp, int64_t O, int64_t I, int q) {   // O, I: row strides
 #pragma unroll
     for (int t = 0; t < AHEAD; ++t) {
         const int64_t k = k0 + 4 * t + q;
@@ -51,10 +51,11 @@ __device__ __forceinline__ void load_stage(Stage& st, const float* __restrict__ 
 }
 
 // one 64 x 64 output tile over the rows [chunk * k_chunk, (chunk + 1) * k_chunk) of K, by one workgroup
+// (ldy, ldx: row strides of dy and x -- O and I for whole matrices, wider when the operands are column blocks)
 __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const float* __restrict__ x, int64_t K,
                                            int O, int I, float* __restrict__ out, int64_t out_ld, int o0, int i0,
                                            int chunk, int64_t k_chunk, int direct, int accumulate, float alpha,
-                                           float (*s_acc)[64 * 64]) {   // s_acc[2][64 * 64]
+                                           float (*s_acc)[64 * 64], int64_t ldy, int64_t ldx) {   // s_acc[2][64 * 64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
@@ -77,9 +78,9 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const f
         const int64_t k_clamp = K - 1;
         constexpr int64_t STEP = 4 * AHEAD;
         Stage s0, s1, s2, s3;
-        load_stage(s0, pa, pb, k_beg, k_end, k_clamp, O, I, q);
-        load_stage(s1, pa, pb, k_beg + STEP, k_end, k_clamp, O, I, q);
-        load_stage(s2, pa, pb, k_beg + 2 * STEP, k_end, k_clamp, O, I, q);
+        load_stage(s0, pa, pb, k_beg, k_end, k_clamp, ldy, ldx, q);
+        load_stage(s1, pa, pb, k_beg + STEP, k_end, k_clamp, ldy, ldx, q);
+        load_stage(s2, pa, pb, k_beg + 2 * STEP, k_end, k_clamp, ldy, ldx, q);
         auto consume = [&](const Stage& st) {
 #pragma unroll
             for (int t = 0; t < AHEAD; ++t) {
@@ -92,19 +93,19 @@ __device__ __forceinline__ void wgrad_tile(const float* __restrict__ dy, const f
             }
         };
         for (int64_t k0 = k_beg; k0 < k_end; k0 += 4 * STEP) {
-            load_stage(s3, pa, pb, k0 + 3 * STEP, k_end, k_clamp, O, I, q);
+            load_stage(s3, pa, pb, k0 + 3 * STEP, k_end, k_clamp, ldy, ldx, q);
             __builtin_amdgcn_sched_barrier(0);
             consume(s0);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(s0, pa, pb, k0 + 4 * STEP, k_end, k_clamp, O, I, q);
+            load_stage(s0, pa, pb, k0 + 4 * STEP, k_end, k_clamp, ldy, ldx, q);
             __builtin_amdgcn_sched_barrier(0);
             if (k0 + STEP < k_end) consume(s1);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(s1, pa, pb, k0 + 5 * STEP, k_end, k_clamp, O, I, q);
+            load_stage(s1, pa, pb, k0 + 5 * STEP, k_end, k_clamp, ldy, ldx, q);
             __builtin_amdgcn_sched_barrier(0);
             if (k0 + 2 * STEP < k_end) consume(s2);
             __builtin_amdgcn_sched_barrier(0);
-            load_stage(s2, pa, pb, k0 + 6 * STEP, k_end, k_clamp, O, I, q);
+            load_stage(s2, pa, pb, k0 + 6 * STEP, k_end, k_clamp, ldy, ldx, q);
             __builtin_amdgcn_sched_barrier(0);
             if (k0 + 3 * STEP < k_end) consume(s3);
             __builtin_amdgcn_sched_barrier(0);
@@ -178,7 +179,7 @@ k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, in
         chunk = blockIdx.x / tiles;
     }
     wgrad_tile(dy, x, K, O, I, out, out_ld, 64 * (tile / tiles_i), 64 * (tile % tiles_i), chunk, k_chunk, direct,
-               accumulate, alpha, s_acc);
+               accumulate, alpha, s_acc, O, I);
 }
 
 // Many weight gradients of the same [O x I] shape in ONE launch (the backward of a model step defers them to
@@ -189,18 +190,20 @@ k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, in
 // rows through L1 -- same 141 us per 21-product batch; a main loop without clamps / masks / 64-bit multiplies --
 // 157 us.  The memory side alone takes 63 us of the 140, the MFMAs 86: they overlap poorly at two wavefronts
 // per SIMD, which is what the 64 KB LDS epilogue buffer allows.)
-constexpr int WG_MAX_BATCH = 24;
+constexpr int WG_MAX_BATCH = 32;
 struct WgradEntry {
     const float* dy;
     const float* x;
     float* slab;      // [splits][O][I]
     int64_t K;
+    int64_t ldy, ldx; // row strides (column blocks of wider matrices take part as they are)
     float alpha;
     int pad;
 };
 struct WgradBatch {
     WgradEntry e[WG_MAX_BATCH];
 };
+static_assert(sizeof(WgradBatch) <= 4096, "WgradBatch is a by-value kernel argument");
 
 __global__ void __launch_bounds__(THREADS)
 k_wgrad_batch(WgradBatch b, int O, int I, int tiles_i, int tiles, int splits) {
@@ -210,7 +213,7 @@ k_wgrad_batch(WgradBatch b, int O, int I, int tiles_i, int tiles, int splits) {
     int64_t kc = (en.K + splits - 1) / splits;
     kc = (kc + 16 * AHEAD - 1) / (16 * AHEAD) * (16 * AHEAD);
     wgrad_tile(en.dy, en.x, en.K, O, I, en.slab, (int64_t)I, 64 * (tile / tiles_i), 64 * (tile % tiles_i), chunk, kc,
-               0, 0, en.alpha, s_acc);
+               0, 0, en.alpha, s_acc, en.ldy, en.ldx);
 }
 
 // chunks of K: enough workgroups to fill the chip, rows per chunk a whole number of register stages
@@ -271,7 +274,8 @@ extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t 
 
 /* count products of one shape in one launch: dw[i] (+)= alpha[i] * dy[i].T @ x[i].  Entries that share a
  * destination must be adjacent (they are summed in array order by one reduction); the workspace holds
- * count * 3 slabs of O x I floats. */
+ * count * 3 slabs of O x I floats.  ld_dy / ld_x (NULL: O / I): row strides of the operands, so that column blocks of
+ * wider matrices (the two halves of a [rows x 2 C] hidden activation) join a batch of [C x C] products. */
 extern "C" size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I) {
     if (count <= 0 || O <= 0 || I <= 0) return 0;
     return (size_t)count * 3 * (size_t)O * (size_t)I * sizeof(float);
@@ -279,7 +283,8 @@ extern "C" size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32
 
 extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K,
                                   int32_t O, int32_t I, const float* alpha, float* const* dw, const int64_t* ldw,
-                                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
+                                  int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream_,
+                                  const int64_t* ld_dy, const int64_t* ld_x) {
     if (count < 0 || O <= 0 || I <= 0) return EQH_ERR_ARG;
     if (count == 0) return EQH_OK;
     if (!dy || !x || !K || !alpha || !dw || !ldw || !workspace) return EQH_ERR_ARG;
@@ -297,7 +302,9 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
             const int j = i0 + i;
             if (K[j] <= 0 || !dy[j] || !x[j] || !dw[j] || ldw[j] < I || (ldw[j] & 3)) return EQH_ERR_ARG;
             if (!eqh_aligned16(dy[j]) || !eqh_aligned16(x[j]) || !eqh_aligned16(dw[j])) return EQH_ERR_ALIGN;
-            b.e[i] = WgradEntry{dy[j], x[j], ws + (size_t)j * SPLITS * slab_elems, K[j], alpha[j], 0};
+            const int64_t ldy = ld_dy ? ld_dy[j] : O, ldx = ld_x ? ld_x[j] : I;
+            if (ldy < O || ldx < I || (ldy & 3) || (ldx & 3)) return EQH_ERR_ALIGN;
+            b.e[i] = WgradEntry{dy[j], x[j], ws + (size_t)j * SPLITS * slab_elems, K[j], ldy, ldx, alpha[j], 0};
         }
         hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
                            tiles, SPLITS);

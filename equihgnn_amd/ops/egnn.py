@@ -4,6 +4,8 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import hip
@@ -180,6 +182,9 @@ def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
     return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2)
 
 
+NODE_WGRAD_BLOCKS = not os.environ.get("EQH_NO_NODE_WGRAD_BLOCKS")
+
+
 class _EgnnNodeMlp(torch.autograd.Function):
     """out = Linear3(silu(Linear0([normed | m_i]))) + feats (egnn_layer.py:180-187,360-362) as ONE panel launch each way
     (csrc/panel.hip: HG_EGNN_NODE_F / _B) instead of cat + GEMM + SiLU + GEMM + add and their backward launches.  The weight
@@ -223,9 +228,23 @@ class _EgnnNodeMlp(torch.autograd.Function):
             hip.HG_EGNN_NODE_B, N, C, dev, in0=dout, ld0=ld, in1=hpre, w0=ctx.imgs[0], w1=ctx.imgs[1], w2=ctx.imgs[2], out0=dpre,
             out1=dnode_in))
         dout_c = dout if ld == C else dout.contiguous()
-        dw3 = _linear_weight_grad(w3, None, None, dout_c, hid) if ctx.needs_input_grad[5] else None
+        dw3 = dw0 = None
+        blocks = NODE_WGRAD_BLOCKS and _acc_target(w3) is not None and _acc_target(w0) is not None and C % 64 == 0
+        if blocks:
+            # [C x 2 C] and [2 C x (C + 16)] as [C x C] blocks over column blocks of hid / dpre / node_in, read in place: they
+            # join the step's batch of [C x C] weight gradients (hg_wgrad_batch_f32) instead of two lone library products
+            # (26 + 31 us at the BASELINE batch); the 16-wide remainder of W0 is one small product
+            if ctx.needs_input_grad[5]:
+                for c0 in (0, C):
+                    _linear_weight_grad(w3, c0, c0 + C, dout_c, hid[:, c0:c0 + C])
+            if ctx.needs_input_grad[3]:
+                for r0 in (0, C):
+                    _linear_weight_grad(w0, 0, C, dpre[:, r0:r0 + C], node_in[:, :C], r0, r0 + C)
+                _linear_weight_grad(w0, C, C + 16, dpre, node_in[:, C:].contiguous())
+        else:
+            dw3 = _linear_weight_grad(w3, None, None, dout_c, hid) if ctx.needs_input_grad[5] else None
+            dw0 = _linear_weight_grad(w0, None, None, dpre, node_in) if ctx.needs_input_grad[3] else None
         db3 = colsum(dout_c, into=_acc_target(b3)) if ctx.needs_input_grad[6] else None
-        dw0 = _linear_weight_grad(w0, None, None, dpre, node_in) if ctx.needs_input_grad[3] else None
         db0 = colsum(dpre, into=_acc_target(b0)) if ctx.needs_input_grad[4] else None
         return dnode_in[:, :C], dnode_in[:, C:], dout, dw0, db0, dw3, db3
 

@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from .. import hip
-from ._base import (_DEFER, _f32c, _ptr, _stream, _workspace)
+from ._base import (_DEFER, _f32c, _ptr, _rows_ld, _stream, _workspace)
 from .products import (GemmProblem, USE_X6, X6_DEEP_ROWS, X6_WGRAD_ROWS, gemm, gemm_batch, gemm_out_ok, gemm_supported)
 
 
@@ -114,7 +114,9 @@ def wgrad_batch(entries):
         order.setdefault((en[3].data_ptr(), en[3].stride(0)), []).append(en)
     flat = [en for grp in order.values() for en in grp]
     n = len(flat)
-    dys, xs = [_f32c(en[0]) for en in flat], [_f32c(en[1]) for en in flat]
+    # (operands may be column blocks of wider row-major matrices -- the halves of a [rows, 2 C] hidden activation: used in place)
+    dl, xl = [_rows_ld(en[0]) for en in flat], [_rows_ld(en[1]) for en in flat]
+    dys, xs = [t for t, _ in dl], [t for t, _ in xl]
     vp, i64, f32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_float * n
     dev = dys[0].device
     L = hip.lib()
@@ -124,7 +126,8 @@ def wgrad_batch(entries):
     hip.check(L.hg_wgrad_batch_f32(n, vp(*[t.data_ptr() for t in dys]), vp(*[t.data_ptr() for t in xs]),
                                    i64(*[t.shape[0] for t in dys]), O, I, f32(*[float(en[2]) for en in flat]),
                                    vp(*[en[3].data_ptr() for en in flat]), i64(*[en[3].stride(0) for en in flat]), 1,
-                                   _ptr(ws), ws_bytes, _stream(dev)), "hg_wgrad_batch_f32")
+                                   _ptr(ws), ws_bytes, _stream(dev), i64(*[ld for _, ld in dl]), i64(*[ld for _, ld in xl])),
+              "hg_wgrad_batch_f32")
 
 
 def colsum_batch(entries):

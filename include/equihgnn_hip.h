@@ -687,7 +687,8 @@ int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t 
 size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I);
 int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K, int32_t O,
                        int32_t I, const float* alpha, float* const* dw, const int64_t* ldw, int32_t accumulate,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, void* stream,
+                       const int64_t* ld_dy, const int64_t* ld_x);
 size_t hg_colsum_workspace_bytes(int64_t R, int32_t C);
 int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, float scale, int64_t R, int32_t C,
                   int32_t accumulate, float* out, void* workspace, size_t workspace_bytes, void* stream);
