@@ -33,14 +33,17 @@ def _sign_ops(device, dtype):
     return torch.stack(g, -1).reshape(8, 3)                       # fa_former_layer.py:70-84
 
 
-def _layer_norm(mod: nn.LayerNorm, x):
+def _layer_norm(mod: nn.LayerNorm, x, passthrough: bool = False):
     """nn.LayerNorm over the last dim through the row kernels (one launch each way, the backward also yields
     d gamma / d beta): torch's own kernels take 2.3 ms forward and 3.3 ms backward on the [E*8, 128] frame
     tensors of a batch-512 step, 4-5x the time the bytes need."""
     c = x.shape[-1]
     if x.is_cuda and x.dtype == torch.float32 and c % 4 == 0 and c <= 1024 and x.numel() > 0:
+        if passthrough:     # (LayerNorm(x), x): x's other consumer reads the second output, see ops._LayerNormRows
+            y, xp = ops.layer_norm_rows(x.reshape(-1, c), mod.weight, mod.bias, mod.eps, passthrough=True)
+            return y.view(x.shape), xp.view(x.shape)
         return ops.layer_norm_rows(x.reshape(-1, c), mod.weight, mod.bias, mod.eps).view(x.shape)
-    return mod(x)
+    return (mod(x), x) if passthrough else mod(x)
 
 
 FUSE_EDGE_HIDDEN = True     # EdgeModule: gather + adds + SwiGLU + dropout + LayerNorm of the edge MLP's hidden layer in one launch
@@ -183,9 +186,14 @@ class EdgeModule(nn.Module):
 
     def forward(self, tok, geo, g: EdgeGraph, res=None):
         """``res``: the edge features this module's output is added to (:602-604), folded into the gate kernel."""
-        rel = geo.unsqueeze(1) - g.gather(geo_pad(geo))[..., :3]           # x_i - x_j  [N,K,3]
-        d2 = (rel ** 2).sum(-1, keepdim=True)
-        y, _, _ = _frame_axes(rel, g.mask)
+        gj = g.gather(geo_pad(geo))                                        # x_j (padded rows)  [N,K,4]
+        if ops.edge_frame_supported(geo, gj, g.mask):
+            # offsets, squared distances, masked centre / covariance, eigenvectors and the projection: one launch each way
+            y, d2 = ops.edge_frame(geo, gj, g.mask)
+        else:
+            rel = geo.unsqueeze(1) - gj[..., :3]                           # x_i - x_j  [N,K,3]
+            d2 = (rel ** 2).sum(-1, keepdim=True)
+            y, _, _ = _frame_axes(rel, g.mask)
         feats = self.coord_mlp.frame_mean(y, d2)                           # [N,K,C]
         # edge_mlp's first Linear split by input block: token_i / token_j parts at node level
         w, d = self.edge_mlp.fc1.weight, self.d
@@ -213,6 +221,20 @@ class EdgeModule(nn.Module):
         return out if res is None else res + out
 
 
+_HEAD_SELECT = {}
+
+
+def _head_select(h, device):
+    """[4, 3h] 0/1 matrix: row r < 2h picks block r of the (q heads | k heads | v heads) columns of the qkv product."""
+    key = (h, str(device))
+    if key not in _HEAD_SELECT:
+        sel = torch.zeros(4, 3 * h)
+        for r in range(2 * h):
+            sel[r, r] = 1.0
+        _HEAD_SELECT[key] = sel.to(device)
+    return _HEAD_SELECT[key]
+
+
 def geo_pad(geo):
     """[N,3] -> [N,4] (the row-gather kernel moves 16-byte rows)."""
     return F.pad(geo, (0, 1))
@@ -235,11 +257,15 @@ class MLPAttnEdgeAggregation(nn.Module):
         nn.init.constant_(self.W_gate.weight, 0.0)
         nn.init.constant_(self.W_gate.bias, 1.0)
 
-    def forward(self, tok, geo, edge, g: EdgeGraph, row_mask=None):
+    def forward(self, tok, geo, edge, g: EdgeGraph, row_mask=None, edge_passthrough: bool = False):
+        """-> (tokens, coordinates, edge features for the residual of the edge update that follows: ``edge`` itself, or
+        with ``edge_passthrough`` its alias out of the LayerNorm node, whose backward then adds the residual's gradient
+        inside the LayerNorm kernel -- an autograd add over [E, C] otherwise, 130 us at the Molecule3D batch)."""
         n, k, h = g.N, g.K, self.h
         d, de = self.h * self.dh, self.h * self.deh
         qkv_in, qkv_lin = _layer_norm(self.layernorm_qkv[0], tok), self.layernorm_qkv[1]
-        q, kk, v = (ops.linear(qkv_in, qkv_lin.weight, qkv_lin.bias) if tok.is_cuda else qkv_lin(qkv_in)).chunk(3, -1)
+        qkv = ops.linear(qkv_in, qkv_lin.weight, qkv_lin.bias) if tok.is_cuda else qkv_lin(qkv_in)
+        fused = ops.geom_supported(tok) and ops.rowdot_supported(qkv, 4) and h <= 2 and k <= 16
         # The logits are LINEAR in their inputs (:483-489: Linear(dh, 1) of q_i + k_j, plus Linear(deh, 1) of the edge
         # query), so they are evaluated where the inputs live instead of on [N, K, h, dh] edge tensors:
         #   w . (q_i + k_j)      = a_q[i] + a_k[j]                  two dot products per ATOM and head; a_k is gathered
@@ -250,12 +276,24 @@ class MLPAttnEdgeAggregation(nn.Module):
         #                                                           Molecule3D batch) is never formed
         # (as GEMMs with one or two output columns these took 2 ms each in round 1).
         w = self.mlp_attn.weight.view(-1)
-        a_q = (q.reshape(n, h, self.dh) * w).sum(-1)                                          # [N, h]
-        a_k = (kk.reshape(n, h, self.dh) * w).sum(-1)
+        if fused:
+            # a_q and a_k of all heads as ONE row-dot pass over the [N, 3d] product (weight rows: w in the head's
+            # block, zeros elsewhere); its backward writes the q / k columns of the product's gradient and adds v's
+            U = (_head_select(h, tok.device)[:, :, None] * w).reshape(4, 3 * d)
+            qa, qkv = ops.rowdot(qkv, U, None, passthrough=True)                              # [N, 4] = (a_q | a_k)
+            qa_n = g.gather(qa)                                                               # [N, K, 4]
+            v = qkv[:, 2 * d:]
+        else:
+            q, kk, v = qkv.chunk(3, -1)
+            a_q = (q.reshape(n, h, self.dh) * w).sum(-1)                                      # [N, h]
+            a_k = (kk.reshape(n, h, self.dh) * w).sum(-1)
+            ak_n = g.gather(F.pad(a_k, (0, 4 - h)))[..., :h]                                  # [N, K, h] (16-byte rows)
         v_n = g.gather(v)                                                                     # [N, K, d]
-        ak_n = g.gather(F.pad(a_k, (0, 4 - h)))[..., :h]                                      # [N, K, h] (16-byte rows)
         lin_e = self.layernorm_qkv_edge[1]
-        xe = _layer_norm(self.layernorm_qkv_edge[0], edge)                                    # [N, K, de]
+        if edge_passthrough:
+            xe, edge = _layer_norm(self.layernorm_qkv_edge[0], edge, passthrough=True)
+        else:
+            xe = _layer_norm(self.layernorm_qkv_edge[0], edge)                                # [N, K, de]
         w_e = self.edge_attn.weight.view(-1)
         u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)          # [h, de]
         c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                              # [h]
@@ -265,12 +303,18 @@ class MLPAttnEdgeAggregation(nn.Module):
             le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c
         ve = ops.linear(xe, lin_e.weight, lin_e.bias, rows=(de, 2 * de))                      # value half only
         if ops.rowdot_supported(tok, 1):   # Linear(d, 1) on the atom rows: a row-wise dot product, not a one-column GEMM
-            gate = torch.sigmoid(ops.rowdot(tok, self.W_gate.weight, self.W_gate.bias))
+            gate_logit = ops.rowdot(tok, self.W_gate.weight, self.W_gate.bias)
         else:
-            gate = torch.sigmoid(self.W_gate(tok))
-        logits = a_q.unsqueeze(1) + ak_n + le
-        logits = logits.masked_fill(~g.mask.unsqueeze(-1), -1e9)
-        attn = F.dropout(logits.transpose(1, 2).softmax(-1), self.attn_drop, self.training)  # [N,h,K]
+            gate_logit = self.W_gate(tok)
+        if fused and ops.attn_logits_supported(qa, le, g.mask):
+            # the three logit terms, radius mask, softmax over the slots and the dropout: one launch each way
+            attn = ops.attn_logits(qa, qa_n, le, g.mask, self.attn_drop if self.training else 0.0)   # [N,h,K]
+        else:
+            if fused:
+                a_q, ak_n = qa[:, :h], qa_n[..., h:2 * h]
+            logits = a_q.unsqueeze(1) + ak_n + le
+            logits = logits.masked_fill(~g.mask.unsqueeze(-1), -1e9)
+            attn = F.dropout(logits.transpose(1, 2).softmax(-1), self.attn_drop, self.training)  # [N,h,K]
         if ops.attn_sum_supported(attn, ve):   # one pass over the values each (csrc/faformer_ew.hip::k_attn_sum)
             ctx = ops.attn_sum(attn, v_n)
             ectx = ops.attn_sum(attn, ve.reshape(n, k, -1))
@@ -280,6 +324,11 @@ class MLPAttnEdgeAggregation(nn.Module):
         out = self.W_output(torch.cat((ctx, ectx), -1)) + tok
         # geometric context: with the reference's frame-0 gather (module docstring) the signed frame
         # average cancels and what is left is the centroid of the cloud, for every atom
+        if ops.geom_supported(geo):
+            # centroid (float64 partial sums), gate and mix in two launches each way; W_frame_agg gets its zero gradient
+            agg = self.W_frame_agg[0]
+            return out, ops.centre_mix(geo, gate_logit, row_mask, (agg.weight, agg.bias)), edge
+        gate = torch.sigmoid(gate_logit)
         if row_mask is None:
             centre = geo.double().mean(0, keepdim=True).to(geo.dtype)       # (float64 accumulation over the cloud, see _frame_axes)
         else:   # padded batch (hipGraph replay): the centroid of the real atoms
@@ -289,7 +338,7 @@ class MLPAttnEdgeAggregation(nn.Module):
         # keep it in the autograd graph with an exactly-zero contribution so it gets a (zero) gradient
         # like there, instead of None
         centre = centre + 0.0 * (self.W_frame_agg[0].weight.sum() + self.W_frame_agg[0].bias.sum())
-        return out, centre * gate + geo * (1 - gate)
+        return out, centre * gate + geo * (1 - gate), edge
 
 
 class FAFFN(nn.Module):
@@ -302,8 +351,11 @@ class FAFFN(nn.Module):
         self.ln = nn.LayerNorm(d)
 
     def forward(self, tok, geo, row_mask=None):
-        y, _, _ = _frame_axes(geo.unsqueeze(0), None if row_mask is None else row_mask.view(1, -1))
-        gfeat = self.W_frame.frame_mean(y[0])                               # [N,C]
+        if ops.geom_supported(geo):      # centroid, covariance (float64 partial sums), eigenvectors, projection: two launches
+            y = ops.cloud_frame(geo, row_mask)
+        else:
+            y = _frame_axes(geo.unsqueeze(0), None if row_mask is None else row_mask.view(1, -1))[0][0]
+        gfeat = self.W_frame.frame_mean(y)                                  # [N,C]
         return self.ffn(torch.cat((_layer_norm(self.ln, tok), gfeat), -1))
 
 
@@ -315,7 +367,7 @@ class FAFormerEncoderLayer(nn.Module):
         self.edge_module = EdgeModule(d, d_edge, proj_drop)
 
     def forward(self, tok, geo, edge, g, last, row_mask=None):
-        tok, geo = self.self_attn(tok, geo, edge, g, row_mask)
+        tok, geo, edge = self.self_attn(tok, geo, edge, g, row_mask, edge_passthrough=not last)
         if not last:
             edge = self.edge_module(tok, geo, g, res=edge)                  # edge + edge_module(...), :602-604
         return tok + self.ffn(tok, geo, row_mask), geo, edge                # :606
@@ -334,10 +386,12 @@ class FAFormer(nn.Module):
     def forward(self, feats, coords, index: HyperIndex, row_mask=None):
         """``row_mask`` [N,1] float: 1 for the atoms of real molecules of a padded batch (the two cloud-wide
         statistics -- the centroid in the attention and the frame of the FFN -- then skip the padding)."""
-        tok = F.dropout(self.input_transform(feats), self.p, self.training)
-        g = EdgeGraph(coords, index, self.k, self.radius)
-        edge = self.edge_module(tok, coords, g)
-        geo = coords
-        for i, layer in enumerate(self.layers):
-            tok, geo, edge = layer(tok, geo, edge, g, last=(i == len(self.layers) - 1), row_mask=row_mask)
+        # (one generator launch for the seeds of all dropout sites of the pass, ops.dropout_seeds)
+        with ops.dropout_seeds(feats.device, 64, enabled=self.training and feats.is_cuda):
+            tok = F.dropout(self.input_transform(feats), self.p, self.training)
+            g = EdgeGraph(coords, index, self.k, self.radius)
+            edge = self.edge_module(tok, coords, g)
+            geo = coords
+            for i, layer in enumerate(self.layers):
+                tok, geo, edge = layer(tok, geo, edge, g, last=(i == len(self.layers) - 1), row_mask=row_mask)
         return tok

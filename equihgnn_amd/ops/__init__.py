@@ -75,6 +75,8 @@ from .frames import (  # noqa: F401
     _dropout_seed, _SwigluDropout, _DropoutMean, _FramePre, _FrameHidden, _EdgeHidden, edge_hidden, _RowDot,
     rowdot, rowdot_supported, _GateRows, gate_rows, _AttnSum, attn_sum_supported, attn_sum, frame_pre,
     frame_hidden, swiglu_dropout, dropout_mean, eigh3, linear_dropout_mean, linear_dropout_mean_supported,
+    _CentreMix, centre_mix, _CloudFrame, cloud_frame, _EdgeFrame, edge_frame, edge_frame_supported, _AttnLogits,
+    attn_logits, attn_logits_supported, geom_supported, dropout_seeds,
 )
 
 # switches that tests / tools / bench.py set as ``ops.NAME = value``: owner module of each
@@ -83,6 +85,7 @@ _SWITCH_OWNER = {
     "GEMM_TILE": "products",
     "KNN_GRID_MIN_POINTS": "aggregate",
     "TIMELINE": "_base",
+    "USE_GEOM": "frames",
     "USE_WGRAD_KERNEL": "grads",
     "USE_X6": "products",
     "WGRAD_ON_SIDE_STREAM": "grads",

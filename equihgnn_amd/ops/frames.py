@@ -5,6 +5,8 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import hip
@@ -14,10 +16,39 @@ from .products import (USE_X6, gemm, mm_nn)
 from .grads import (_linear_weight_grad, colsum)
 
 
+_SEED_POOL = {"buf": None, "next": 0}
+
+
+class dropout_seeds:
+    """``with dropout_seeds(device, n):`` -- the dropout sites inside take their seeds from ONE tensor of n draws (one
+    generator launch per forward pass instead of one per site: ~20 launches of 4.6 us in a FAFormer step).  The draw
+    happens inside the block, i.e. inside a captured step: every replay sees new seeds."""
+
+    def __init__(self, device, n: int = 64, enabled: bool = True):
+        self.device, self.n, self.enabled, self.mine = device, n, enabled, False
+
+    def __enter__(self):
+        if self.enabled and _SEED_POOL["buf"] is None:
+            _SEED_POOL["buf"] = torch.randint(0, 2 ** 62, (self.n,), dtype=torch.int64, device=self.device)
+            _SEED_POOL["next"] = 0
+            self.mine = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.mine:
+            _SEED_POOL["buf"] = None
+        return False
+
+
 def _dropout_seed(device, p):
     """A fresh int64 seed in device memory (drawn by torch's generator: graph-safe, a new value per replay)."""
     if p <= 0.0:
         return None
+    buf = _SEED_POOL["buf"]
+    if buf is not None and buf.device == torch.device(device) and _SEED_POOL["next"] < buf.numel():
+        i = _SEED_POOL["next"]
+        _SEED_POOL["next"] = i + 1
+        return buf[i:i + 1]
     return torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=device)
 
 
@@ -503,3 +534,181 @@ def eigh3(cov):
     vec = torch.empty_like(cov)
     hip.check(hip.lib().geo_eigh3(_ptr(cov), cov.shape[0], None, _ptr(vec), _stream(cov.device)), "geo_eigh3")
     return vec
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The small geometric steps (csrc/faformer_geom.hip): one launch each way instead of 15-25 elementwise / reduction ones
+# ---------------------------------------------------------------------------------------------------------------
+USE_GEOM = not os.environ.get("EQH_NO_GEOM")   # tests / tools switch the fused geometry off to compare it with the torch expression of the same step
+
+
+def geom_supported(x) -> bool:
+    """centre_mix / cloud_frame take fp32 device tensors."""
+    return bool(USE_GEOM) and x.is_cuda and x.dtype == torch.float32
+
+
+def _moments_ws(n, device):
+    nbytes = hip.lib().faf_moments_workspace_bytes(n)
+    return _workspace(max(nbytes, 16), device), nbytes
+
+
+class _CentreMix(torch.autograd.Function):
+    """c * g + geo * (1 - g), g = sigmoid(logit), c = the (masked) centroid of geo accumulated in float64
+    (faf_centre_mix_*).  ``zero_params`` take part in the reference's expression with a factor that cancels
+    (faformer.MLPAttnEdgeAggregation): they receive an exactly-zero gradient instead of None."""
+
+    @staticmethod
+    def forward(ctx, geo, logit, row_mask, *zero_params):
+        _require_gpu(geo, "centre_mix")
+        g2, lg = _f32c(geo), _f32c(logit).reshape(-1)
+        m = _f32c(row_mask).reshape(-1) if row_mask is not None else None
+        n = g2.shape[0]
+        out = torch.empty_like(g2)
+        aux = torch.empty(4, dtype=torch.float32, device=geo.device)
+        ws, nbytes = _moments_ws(n, geo.device)
+        hip.check(hip.lib().faf_centre_mix_fwd(_ptr(g2), _ptr(lg), _ptr(m), n, _ptr(out), _ptr(aux), _ptr(ws), nbytes,
+                                               _stream(geo.device)), "faf_centre_mix_fwd")
+        ctx.save_for_backward(g2, lg, m, aux)
+        ctx.zero, ctx.lshape = zero_params, logit.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        g2, lg, m, aux = ctx.saved_tensors
+        n = g2.shape[0]
+        dout = _f32c(dout)
+        dgeo, dlogit = torch.empty_like(g2), torch.empty_like(lg)
+        ws, nbytes = _moments_ws(n, g2.device)
+        hip.check(hip.lib().faf_centre_mix_bwd(_ptr(dout), _ptr(g2), _ptr(lg), _ptr(m), _ptr(aux), n, _ptr(dgeo), _ptr(dlogit),
+                                               _ptr(ws), nbytes, _stream(g2.device)), "faf_centre_mix_bwd")
+        zeros = [None if _acc_target(q) is not None else torch.zeros_like(q) for q in ctx.zero]
+        return (dgeo, dlogit.view(ctx.lshape), None, *zeros)
+
+
+def centre_mix(geo, logit, row_mask=None, zero_params=()):
+    """geo [N, 3], logit [N, 1] (the gate BEFORE its sigmoid), row_mask [N, 1] float or None -> [N, 3]; see _CentreMix."""
+    _note_acc(*zero_params)
+    return _CentreMix.apply(geo, logit, row_mask, *zero_params)
+
+
+class _CloudFrame(torch.autograd.Function):
+    """y = (x - c m) V for one point set x [N, 3]: c the masked centroid, V the eigenvectors of the masked covariance
+    (float64 sums, no gradient through V) -- faf_cloud_frame_*."""
+
+    @staticmethod
+    def forward(ctx, x, row_mask):
+        _require_gpu(x, "cloud_frame")
+        x2 = _f32c(x)
+        m = _f32c(row_mask).reshape(-1) if row_mask is not None else None
+        n = x2.shape[0]
+        y = torch.empty_like(x2)
+        aux = torch.empty(13, dtype=torch.float32, device=x.device)
+        ws, nbytes = _moments_ws(n, x.device)
+        hip.check(hip.lib().faf_cloud_frame_fwd(_ptr(x2), _ptr(m), n, _ptr(y), _ptr(aux), _ptr(ws), nbytes, _stream(x.device)),
+                  "faf_cloud_frame_fwd")
+        ctx.save_for_backward(m, aux)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m, aux = ctx.saved_tensors
+        dy = _f32c(dy)
+        n = dy.shape[0]
+        dx = torch.empty_like(dy)
+        ws, nbytes = _moments_ws(n, dy.device)
+        hip.check(hip.lib().faf_cloud_frame_bwd(_ptr(dy), _ptr(m), _ptr(aux), n, _ptr(dx), _ptr(ws), nbytes, _stream(dy.device)),
+                  "faf_cloud_frame_bwd")
+        return dx, None
+
+
+def cloud_frame(x, row_mask=None):
+    """Frame coordinates of the cloud x [N, 3] (fa_former_layer.py:86-113 on one point set); row_mask [N, 1] float or None."""
+    return _CloudFrame.apply(x, row_mask)
+
+
+class _EdgeFrame(torch.autograd.Function):
+    """Per-atom frames over the neighbour offsets: (y [N, K, 3], d2 [N, K, 1]) from geo [N, 3], the neighbours' padded
+    coordinates gj [N, K, 4] and the radius mask [N, K] (bool) -- faf_edge_frame_*."""
+
+    @staticmethod
+    def forward(ctx, geo, gj, mask):
+        _require_gpu(geo, "edge_frame")
+        g2, j2 = _f32c(geo), _f32c(gj)
+        mk = mask.contiguous()
+        n, k = j2.shape[0], j2.shape[1]
+        y = torch.empty((n, k, 3), dtype=torch.float32, device=geo.device)
+        d2 = torch.empty((n, k, 1), dtype=torch.float32, device=geo.device)
+        V = torch.empty((n, 9), dtype=torch.float32, device=geo.device)
+        hip.check(hip.lib().faf_edge_frame_fwd(_ptr(g2), _ptr(j2), _ptr(mk), n, k, _ptr(y), _ptr(d2), _ptr(V),
+                                               _stream(geo.device)), "faf_edge_frame_fwd")
+        ctx.save_for_backward(g2, j2, mk, V)
+        ctx.set_materialize_grads(False)
+        return y, d2
+
+    @staticmethod
+    def backward(ctx, dy, dd2):
+        g2, j2, mk, V = ctx.saved_tensors
+        if dy is None and dd2 is None:
+            return None, None, None
+        n, k = j2.shape[0], j2.shape[1]
+        dy = _f32c(dy) if dy is not None else None
+        dd2 = _f32c(dd2) if dd2 is not None else None
+        dgeo, dgj = torch.empty_like(g2), torch.empty_like(j2)
+        hip.check(hip.lib().faf_edge_frame_bwd(_ptr(g2), _ptr(j2), _ptr(mk), _ptr(V), _ptr(dy), _ptr(dd2), n, k, _ptr(dgeo),
+                                               _ptr(dgj), _stream(g2.device)), "faf_edge_frame_bwd")
+        return dgeo, dgj, None
+
+
+def edge_frame_supported(geo, gj, mask) -> bool:
+    return (USE_GEOM and geo.is_cuda and geo.dtype == torch.float32 and gj.dim() == 3 and gj.shape[-1] == 4
+            and 1 <= gj.shape[1] <= 16 and mask.dtype == torch.bool)
+
+
+def edge_frame(geo, gj, mask):
+    """See _EdgeFrame (fa_former_layer.py:357-372 with create_frame :86-113 per atom)."""
+    return _EdgeFrame.apply(geo, gj, mask)
+
+
+class _AttnLogits(torch.autograd.Function):
+    """dropout_p(softmax_K(masked(a_q[i] + a_k[j] + l_e))) -> [N, H, K] (faf_attn_logits_*); qa [N, 4] holds a_q then a_k
+    of the H <= 2 heads, qan [N, K, 4] is qa gathered by neighbour."""
+
+    @staticmethod
+    def forward(ctx, qa, qan, le, mask, p, seed):
+        _require_gpu(qa, "attn_logits")
+        qa2, qn2, le2 = _f32c(qa), _f32c(qan), _f32c(le)
+        mk = mask.contiguous()
+        n, k, h = le2.shape
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(qa.device, p)
+        attn = torch.empty((n, h, k), dtype=torch.float32, device=qa.device)
+        prob = torch.empty_like(attn) if p > 0 else attn
+        hip.check(hip.lib().faf_attn_logits_fwd(_ptr(qa2), _ptr(qn2), _ptr(le2), _ptr(mk), n, k, h, float(p), _ptr(seed),
+                                                _ptr(prob), _ptr(attn), _stream(qa.device)), "faf_attn_logits_fwd")
+        # (with p = 0 the saved probabilities ARE the output: keep a detached alias, not the output itself, so that the
+        # node does not hold its own result -- see conv_stack._MergedConvStack)
+        ctx.save_for_backward(prob.detach() if p > 0 else attn.detach().view_as(attn), mk)
+        ctx.meta = (float(p), seed, qa.shape, qan.shape, le.shape)
+        return attn
+
+    @staticmethod
+    def backward(ctx, dattn):
+        prob, mk = ctx.saved_tensors
+        p, seed, s_qa, s_qan, s_le = ctx.meta
+        n, h, k = prob.shape
+        dattn = _f32c(dattn)
+        dqa = torch.empty((n, 4), dtype=torch.float32, device=prob.device)
+        dqan = torch.empty((n, k, 4), dtype=torch.float32, device=prob.device)
+        dle = torch.empty((n, k, h), dtype=torch.float32, device=prob.device)
+        hip.check(hip.lib().faf_attn_logits_bwd(_ptr(prob), _ptr(dattn), _ptr(mk), n, k, h, p, _ptr(seed), _ptr(dqa), _ptr(dqan),
+                                                _ptr(dle), _stream(prob.device)), "faf_attn_logits_bwd")
+        return dqa.view(s_qa), dqan.view(s_qan), dle.view(s_le), None, None, None
+
+
+def attn_logits_supported(qa, le, mask) -> bool:
+    return (USE_GEOM and qa.is_cuda and qa.dtype == torch.float32 and qa.shape[-1] == 4 and le.dim() == 3
+            and 1 <= le.shape[1] <= 16 and 1 <= le.shape[2] <= 2 and mask.dtype == torch.bool)
+
+
+def attn_logits(qa, qan, le, mask, p: float = 0.0, seed=None):
+    """See _AttnLogits (fa_former_layer.py:483-496)."""
+    return _AttnLogits.apply(qa, qan, le, mask, p, seed)

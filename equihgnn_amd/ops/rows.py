@@ -293,11 +293,14 @@ def batch_norm_rows_supported(x, bn) -> bool:
 
 
 class _LayerNormRows(torch.autograd.Function):
-    """Plain LayerNorm over dense rows; one launch each way, dgamma/dbeta from the backward pass."""
+    """Plain LayerNorm over dense rows; one launch each way, dgamma/dbeta from the backward pass.  With ``passthrough`` the
+    node also returns x itself for x's OTHER consumer (a residual), whose gradient the backward kernel adds to dx in the
+    same pass instead of an autograd add over the [rows, C] tensor."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, acc_params):
+    def forward(ctx, x, gamma, beta, eps, acc_params, passthrough=False):
         _require_gpu(x, "layer_norm_rows")
+        xin = x
         x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
         R, C = x.shape
         out = torch.empty_like(x)
@@ -306,26 +309,32 @@ class _LayerNormRows(torch.autograd.Function):
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
         ctx.acc = acc_params
+        if passthrough:
+            ctx.set_materialize_grads(False)
+            return out, xin.view_as(xin)
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dpass, None, None, None, None, None
         dy = _f32c(dy)
         R, C = x.shape
+        add = _f32c(dpass).reshape(R, C) if dpass is not None else None
         dx = torch.empty_like(x)
         L = hip.lib()
         ws_bytes = L.hg_layer_norm_bwd_workspace_bytes(R, C)
         ws = _workspace(ws_bytes, x.device)
         tg = [_acc_target(p) for p in ctx.acc]
         if all(t is not None for t in tg):
-            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, None, R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
+            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
                                           _ptr(tg[1]), 1, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, None, R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
+        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
                                       _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
-        return (dx, *_hand_out(list(small), tg), None, None)
+        return (dx, *_hand_out(list(small), tg), None, None, None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -387,7 +396,8 @@ def residual_mix(x0, bias, rowptr, weight_mode: int, alpha: float, passthrough: 
     return _ResidualMix.apply(x0, bias, rowptr, weight_mode, alpha, bias, passthrough)
 
 
-def layer_norm_rows(x, gamma, beta, eps: float = 1e-5):
-    """nn.LayerNorm over the last dim of 2-D ``x`` [rows, C] (C % 4 == 0, C <= 1024)."""
+def layer_norm_rows(x, gamma, beta, eps: float = 1e-5, passthrough: bool = False):
+    """nn.LayerNorm over the last dim of 2-D ``x`` [rows, C] (C % 4 == 0, C <= 1024).  ``passthrough``: returns
+    (LayerNorm(x), x) -- see _LayerNormRows."""
     _note_acc(gamma, beta)
-    return _LayerNormRows.apply(x, gamma, beta, eps, (gamma, beta))
+    return _LayerNormRows.apply(x, gamma, beta, eps, (gamma, beta), passthrough)

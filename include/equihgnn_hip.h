@@ -483,6 +483,43 @@ int faf_attn_sum_bwd(const float* attn, const float* x, const float* dout, int64
                      float* dx, float* dattn, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * FAFormer's small geometric steps, one launch each (+ one partial-sum pass where the step reduces over the whole
+ * cloud; float64 partial sums in a fixed order: bitwise reproducible).  csrc/faformer_geom.hip.
+ * `row_mask` [N] float (> 0: a real atom of a padded batch) or NULL; workspace >= faf_moments_workspace_bytes(N).
+ *
+ * centre mix -- fa_former_layer.py:552-571 as the frame-0 gather leaves it (the geometric context is the centroid):
+ *   out[i] = c g_i + geo[i] (1 - g_i), g = sigmoid(logit), c = sum_valid geo / #valid (float64, rounded once)
+ *   aux [4] = (c, #valid), kept for the backward; bwd: dgeo [N,3], dlogit [N] from dout [N,3]
+ * cloud frame -- create_frame on one point set, fa_former_layer.py:86-113 (called at :310-318):
+ *   y = (x - c m) V, c = masked centroid (count clamped at 1), V = eigenvectors (geo_eigh3's convention) of the
+ *   masked covariance about c; no gradient through V (:98-99).  aux [13] = (V row-major, c, count)
+ * edge frame -- the same per atom over its K <= 16 neighbour offsets, fa_former_layer.py:357-372:
+ *   rel_k = geo[i] - gj[i,k,:3] (gj [N,K,4]: the neighbours' padded coordinates), d2 = |rel|^2, mask [N,K] bytes,
+ *   y [N,K,3], V [N,9]; bwd: dgeo [N,3] (receiver side) and dgj [N,K,4] from dy / dd2 (either may be NULL)
+ * attention logits -- fa_former_layer.py:483-496: logits a_q[i] + a_k[j] + l_e, masked_fill(~mask, -1e9), softmax
+ *   over the K <= 16 slots, dropout (keep decisions of drop_hash.h).  qa [N,4] = (a_q of the H <= 2 heads, a_k of the
+ *   H heads), qan [N,K,4] = qa gathered by neighbour, le [N,K,H]; prob / attn [N,H,K] (prob only written when p > 0);
+ *   bwd: dqa [N,4] (the a_q columns), dqan [N,K,4] (the a_k columns), dle [N,K,H]
+ * ------------------------------------------------------------------------------------------- */
+size_t faf_moments_workspace_bytes(int64_t N);
+int faf_centre_mix_fwd(const float* geo, const float* logit, const float* row_mask, int64_t N, float* out, float* aux,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int faf_centre_mix_bwd(const float* dout, const float* geo, const float* logit, const float* row_mask, const float* aux,
+                       int64_t N, float* dgeo, float* dlogit, void* workspace, size_t workspace_bytes, void* stream);
+int faf_cloud_frame_fwd(const float* x, const float* row_mask, int64_t N, float* y, float* aux, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int faf_cloud_frame_bwd(const float* dy, const float* row_mask, const float* aux, int64_t N, float* dx, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int faf_edge_frame_fwd(const float* geo, const float* gj, const uint8_t* mask, int64_t N, int32_t K, float* y, float* d2,
+                       float* V, void* stream);
+int faf_edge_frame_bwd(const float* geo, const float* gj, const uint8_t* mask, const float* V, const float* dy,
+                       const float* dd2, int64_t N, int32_t K, float* dgeo, float* dgj, void* stream);
+int faf_attn_logits_fwd(const float* qa, const float* qan, const float* le, const uint8_t* mask, int64_t N, int32_t K,
+                        int32_t H, float p, const int64_t* seed, float* prob, float* attn, void* stream);
+int faf_attn_logits_bwd(const float* prob, const float* dattn, const uint8_t* mask, int64_t N, int32_t K, int32_t H, float p,
+                        const int64_t* seed, float* dqa, float* dqan, float* dle, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Per-edge geometry of the Equiformer front-end -- equiformer_layer.py:1250-1252,1317-1346 (rel_pos = x_i - x_j of
  * the selected neighbours, neighbor_mask = dist <= radius), equiformer/basis.py:194-215 with :169-191 and
  * irr_repr.py:105-118,23-32 (D[1] of the rotation taking r_ij onto y, built in float64 with the |x+y|^2 >= 1e-6

@@ -380,11 +380,17 @@ def test_large_row_gemm_routes_match_the_library_path(method, batch, flavour):
     assert abs(l1 - l0) <= 2e-5 * max(1.0, abs(l0)), (l1, l0)
     assert set(g1) == set(g0)
     gmax = max(float(g.abs().max()) for g in g0.values())
-    for n in g0:        # (two fp32 roundings of the same products: entries next to a ReLU / frame-sign kink move by ~1e-3 of
-        #                      the gradient's scale at hidden 256, the bulk agrees to 1e-5)
+    # Two fp32 roundings of the same products: entries next to a ReLU kink move by ~1e-3 of the gradient's scale at hidden
+    # 256, the bulk agrees to 1e-5.  FAFormer adds the frames: an atom whose neighbourhood covariance has two close
+    # eigenvalues swaps two axes under a last-bit change of its coordinates (the reference's eigh does the same), and one
+    # such atom moves a gradient by ~1e-2 -- measured over three batches and both implementations of the frame
+    # (scratch-free: EQH_NO_GEOM=1 selects the torch expression): worst entry 8e-6 ... 2e-2, worst norm 8e-6 ... 1.6e-2.
+    # A wrong route is an O(1) difference.
+    tol_max, tol_norm = (5e-2, 3e-2) if method == "faformer_equihnns" else (1e-2, 5e-3)
+    for n in g0:
         scale = max(float(g0[n].abs().max()), 1e-3 * gmax) + 1e-12
-        assert float((g1[n] - g0[n]).abs().max()) / scale < 1e-2, n
-        assert float((g1[n] - g0[n]).norm()) <= 5e-3 * float(g0[n].norm()) + 1e-5 * gmax, n
+        assert float((g1[n] - g0[n]).abs().max()) / scale < tol_max, n
+        assert float((g1[n] - g0[n]).norm()) <= tol_norm * float(g0[n].norm()) + 1e-5 * gmax, n
     model = copy.deepcopy(m).train()
     tr = GraphedTrainStep(model, lr=1e-4)
     losses = [float(tr.step(b)) for _ in range(4)]
