@@ -707,6 +707,90 @@ k_attn_sum(const float* __restrict__ attn, const float* __restrict__ x, const fl
     }
 }
 
+// The same sum over GATHERED rows: out[n, c] = sum_m attn[n, c / D, m] * x[nbr[n, m], c] for node values x [*, C] (row
+// stride x_ld: x may be a column block of a wider product).  The gathered [N, K, C] tensor (258 MB at the Molecule3D
+// batch) is neither written by a gather kernel nor read back here: the 16 MB table of node rows stays in L2.
+// BWD (receiver side): dattn[n, h, m] = sum over the head's channels of dout[n, c] * x[nbr[n, m], c].
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_attn_gsum(const float* __restrict__ attn, const float* __restrict__ x, int64_t x_ld, const int32_t* __restrict__ nbr,
+            const float* __restrict__ dout, int64_t N, int K, int H, int D, float* __restrict__ out,
+            float* __restrict__ dattn) {
+    const int C = H * D, LPR = C / 4;
+    const int lane = threadIdx.x & 63;
+    const int per_wave = 64 / LPR;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int c = 4 * sl, h = c / D;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n = wave * per_wave + sub;
+    const bool live = n < N;
+    const int64_t nc = live ? n : 0;
+    int64_t row[AS_MAXK];
+#pragma unroll
+    for (int m = 0; m < AS_MAXK; ++m) row[m] = (m < K) ? (int64_t)nbr[nc * K + m] * x_ld + c : 0;
+    if (!BWD) {
+        float a[AS_MAXK];
+#pragma unroll
+        for (int m = 0; m < AS_MAXK; ++m) a[m] = (m < K) ? attn[(nc * H + h) * K + m] : 0.f;
+        float4 acc = f4_zero();
+#pragma unroll 4
+        for (int m = 0; m < K; ++m) f4_fma(acc, *reinterpret_cast<const float4*>(x + row[m]), a[m]);
+        if (live) *reinterpret_cast<float4*>(out + n * C + c) = acc;
+    } else {
+        const float4 g = *reinterpret_cast<const float4*>(dout + nc * C + c);
+        const int hl = D / 4;
+#pragma unroll 4
+        for (int m = 0; m < K; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(x + row[m]);
+            float p = (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
+            for (int o = 1; o < hl; o <<= 1) p += __shfl_xor(p, o, 64);
+            if (live && (sl % hl) == 0) dattn[(n * H + h) * K + m] = p;
+        }
+    }
+}
+
+// BWD (sender side): dx[j, c] = sum over the edges e = (n, m) that read node j of attn[n, h, m] * dout[n, c] -- the rows of
+// the transposed neighbour CSR (rowptr, perm: entry ids n * K + m, ascending: fixed summation order), four entries in
+// flight per step (an entry is a chain of three loads).
+__global__ void __launch_bounds__(256)
+k_attn_gsum_send(const float* __restrict__ attn, const float* __restrict__ dout, const int32_t* __restrict__ rowptr,
+                 const int32_t* __restrict__ perm, int64_t NS, int K, int H, int D, float* __restrict__ dx) {
+    const int C = H * D, LPR = C / 4;
+    const int lane = threadIdx.x & 63;
+    const int per_wave = 64 / LPR;
+    const int sub = lane / LPR, sl = lane % LPR;
+    const int c = 4 * sl, h = c / D;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t j = wave * per_wave + sub;
+    if (j >= NS) return;
+    const int beg = rowptr[j], end = rowptr[j + 1];
+    float4 acc = f4_zero();
+    int p = beg;
+    for (; p + 4 <= end; p += 4) {
+        int e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) e[u] = perm[p + u];
+        float a[4];
+        float4 g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t n = e[u] / K;
+            const int m = e[u] - (int)n * K;
+            a[u] = attn[(n * H + h) * K + m];
+            g[u] = *reinterpret_cast<const float4*>(dout + n * C + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) f4_fma(acc, g[u], a[u]);
+    }
+    for (; p < end; ++p) {
+        const int e = perm[p];
+        const int64_t n = e / K;
+        const int m = e - (int)n * K;
+        f4_fma(acc, *reinterpret_cast<const float4*>(dout + n * C + c), attn[(n * H + h) * K + m]);
+    }
+    *reinterpret_cast<float4*>(dx + j * C + c) = acc;
+}
+
 int attn_sum_check(int64_t N, int K, int H, int D) {
     if (N < 0 || K < 1 || K > AS_MAXK || H < 1 || D < 4) return EQH_ERR_ARG;
     const int C = H * D, lpr = C / 4, hl = D / 4;
@@ -741,6 +825,48 @@ extern "C" int faf_attn_sum_bwd(const float* attn, const float* x, const float* 
     hipLaunchKernelGGL(k_attn_sum<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, x, dout,
                        N, (int)K, (int)H, (int)D, (float*)nullptr, dx, dattn);
     EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+/* the gathered form (see k_attn_gsum): x [NS, H*D] node rows with row stride x_ld floats, nbr [N, K] int32 (< NS);
+   bwd: dattn [N, H, K] and dx [NS, H*D] through the transposed neighbour CSR (rowptr [NS + 1], perm: entry ids) */
+extern "C" int faf_attn_gather_sum_fwd(const float* attn, const float* x, int64_t x_ld, const int32_t* nbr, int64_t N,
+                                       int32_t K, int32_t H, int32_t D, float* out, void* stream) {
+    const int rc = attn_sum_check(N, K, H, D);
+    if (rc) return rc;
+    if (N == 0) return EQH_OK;
+    if (!attn || !x || !nbr || !out || x_ld < (int64_t)H * D || (x_ld & 3) || !eqh_aligned16(x)) return EQH_ERR_ARG;
+    const int per_wave = 64 / (H * D / 4);
+    const int64_t waves = (N + per_wave - 1) / per_wave;
+    hipLaunchKernelGGL(k_attn_gsum<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, x, x_ld,
+                       nbr, (const float*)nullptr, N, (int)K, (int)H, (int)D, out, (float*)nullptr);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int faf_attn_gather_sum_bwd(const float* attn, const float* x, int64_t x_ld, const int32_t* nbr,
+                                       const float* dout, const int32_t* rowptr, const int32_t* perm, int64_t N, int64_t NS,
+                                       int32_t K, int32_t H, int32_t D, float* dattn, float* dx, void* stream) {
+    const int rc = attn_sum_check(N, K, H, D);
+    if (rc) return rc;
+    if (NS < 0) return EQH_ERR_ARG;
+    if (N > 0) {
+        if (!attn || !x || !nbr || !dout || !dattn || x_ld < (int64_t)H * D || (x_ld & 3) || !eqh_aligned16(x))
+            return EQH_ERR_ARG;
+        const int per_wave = 64 / (H * D / 4);
+        const int64_t waves = (N + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL(k_attn_gsum<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, x, x_ld,
+                           nbr, dout, N, (int)K, (int)H, (int)D, (float*)nullptr, dattn);
+        EQH_CHECK_LAUNCH();
+    }
+    if (NS > 0 && dx) {
+        if (!rowptr || !perm || !attn || !dout) return EQH_ERR_ARG;
+        const int per_wave = 64 / (H * D / 4);
+        const int64_t waves = (NS + per_wave - 1) / per_wave;
+        hipLaunchKernelGGL(k_attn_gsum_send, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, attn, dout,
+                           rowptr, perm, NS, (int)K, (int)H, (int)D, dx);
+        EQH_CHECK_LAUNCH();
+    }
     return EQH_OK;
 }
 

@@ -288,7 +288,8 @@ class MLPAttnEdgeAggregation(nn.Module):
             a_q = (q.reshape(n, h, self.dh) * w).sum(-1)                                      # [N, h]
             a_k = (kk.reshape(n, h, self.dh) * w).sum(-1)
             ak_n = g.gather(F.pad(a_k, (0, 4 - h)))[..., :h]                                  # [N, K, h] (16-byte rows)
-        v_n = g.gather(v)                                                                     # [N, K, d]
+        gsum = tok.is_cuda and ops.attn_gather_sum_supported(h, v, g.nbr, g.csr_t)
+        v_n = None if gsum else g.gather(v)                                                   # [N, K, d]
         lin_e = self.layernorm_qkv_edge[1]
         if edge_passthrough:
             xe, edge = _layer_norm(self.layernorm_qkv_edge[0], edge, passthrough=True)
@@ -316,9 +317,11 @@ class MLPAttnEdgeAggregation(nn.Module):
             logits = logits.masked_fill(~g.mask.unsqueeze(-1), -1e9)
             attn = F.dropout(logits.transpose(1, 2).softmax(-1), self.attn_drop, self.training)  # [N,h,K]
         if ops.attn_sum_supported(attn, ve):   # one pass over the values each (csrc/faformer_ew.hip::k_attn_sum)
-            ctx = ops.attn_sum(attn, v_n)
+            # (the neighbours' values are read through the neighbour list: the gathered [N, K, d] tensor is never formed)
+            ctx = ops.attn_gather_sum(attn, v, g.nbr, g.csr_t) if gsum else ops.attn_sum(attn, v_n)
             ectx = ops.attn_sum(attn, ve.reshape(n, k, -1))
         else:
+            v_n = g.gather(v) if v_n is None else v_n
             ctx = torch.einsum("nhm,nmhd->nhd", attn, v_n.reshape(n, k, h, self.dh)).reshape(n, -1)
             ectx = torch.einsum("nhm,nmhd->nhd", attn, ve.reshape(n, k, h, self.deh)).reshape(n, -1)
         out = self.W_output(torch.cat((ctx, ectx), -1)) + tok

@@ -130,6 +130,10 @@ SIGNATURES = {
     "faf_edge_frame_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32] + [c_void_p] * 3),
     "faf_attn_logits_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_float] + [c_void_p] * 4),
     "faf_attn_logits_bwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_int32, c_float] + [c_void_p] * 5),
+    "faf_attn_gather_sum_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p,
+                                          c_void_p]),
+    "faf_attn_gather_sum_bwd": (c_int32, [c_void_p, c_void_p, c_int64] + [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int32,
+                                                                                         c_int32, c_void_p, c_void_p, c_void_p]),
     "faf_frame_pre_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "faf_frame_pre_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "faf_frame_pre_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,

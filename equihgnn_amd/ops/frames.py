@@ -10,7 +10,8 @@ import os
 import torch
 
 from .. import hip
-from ._base import (LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
+from ._base import (LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream, _workspace,
+                    timed)
 from .aggregate import (CSR, _segment_reduce)
 from .products import (USE_X6, gemm, mm_nn)
 from .grads import (_linear_weight_grad, colsum)
@@ -496,6 +497,55 @@ def attn_sum_supported(attn, x) -> bool:
 def attn_sum(attn, x):
     """sum_m attn[n, h, m] * x[n, m, h*D:(h+1)*D] for attn [N, H, K], x [N, K, H*D] -> [N, H*D]."""
     return _AttnSum.apply(attn, x)
+
+
+class _AttnGatherSum(torch.autograd.Function):
+    """out[n, c] = sum_m attn[n, c // D, m] * x[nbr[n, m], c] for node rows x [NS, H*D] (faf_attn_gather_sum_*): the
+    attention-weighted sum over the neighbours' values without the gathered [N, K, H*D] tensor either way."""
+
+    @staticmethod
+    def forward(ctx, attn, x, nbr, csr_t):
+        _require_gpu(x, "attn_gather_sum")
+        attn = _f32c(attn)
+        x2, ld = _rows_ld(x)                     # (a column block of the qkv product is read in place)
+        N, H, K = attn.shape
+        C = x2.shape[1]
+        out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_attn_gather_sum_fwd(_ptr(attn), _ptr(x2), ld, _ptr(nbr), N, K, H, C // H, _ptr(out),
+                                                    _stream(x.device)), "faf_attn_gather_sum_fwd")
+        ctx.save_for_backward(attn, x2, nbr)
+        ctx.csr, ctx.ld = csr_t, ld
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        attn, x2, nbr = ctx.saved_tensors
+        csr = ctx.csr
+        dout = _f32c(dout)
+        N, H, K = attn.shape
+        NS, C = x2.shape
+        dattn = torch.empty_like(attn)
+        dx = torch.empty((NS, C), dtype=torch.float32, device=dout.device) if ctx.needs_input_grad[1] else None
+        hip.check(hip.lib().faf_attn_gather_sum_bwd(_ptr(attn), _ptr(x2), ctx.ld, _ptr(nbr), _ptr(dout), _ptr(csr.rowptr),
+                                                    _ptr(csr.perm), N, NS, K, H, C // H, _ptr(dattn), _ptr(dx),
+                                                    _stream(dout.device)), "faf_attn_gather_sum_bwd")
+        return dattn, dx, None, None
+
+
+def attn_gather_sum_supported(h: int, x, nbr, csr_t) -> bool:
+    """``h`` heads over node rows x [NS, C], neighbour list nbr [N, K] int32, transposed neighbour CSR."""
+    if not (USE_GEOM and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and nbr.dim() == 2 and nbr.dtype == torch.int32):
+        return False
+    k, c = nbr.shape[1], x.shape[-1]
+    lpr, hl = c // 4, (c // h) // 4 if h else 0
+    return (nbr.is_contiguous() and csr_t.n_rows == x.shape[0] and k <= 16 and h >= 1 and c % (4 * h) == 0
+            and 1 <= lpr <= 64 and lpr & (lpr - 1) == 0 and hl >= 1 and hl & (hl - 1) == 0)
+
+
+def attn_gather_sum(attn, x, nbr, csr_t: CSR):
+    """sum_m attn[n, h, m] * x[nbr[n, m], h*D:(h+1)*D] for attn [N, H, K], node rows x [NS, H*D], nbr [N, K] int32 and
+    the CSR of the transposed neighbour graph (for dx); see _AttnGatherSum."""
+    return _AttnGatherSum.apply(attn, x, nbr, csr_t)
 
 
 def frame_pre(y, w3, base):

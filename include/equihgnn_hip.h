@@ -481,6 +481,16 @@ int faf_attn_sum_fwd(const float* attn, const float* x, int64_t N, int32_t K, in
                      void* stream);
 int faf_attn_sum_bwd(const float* attn, const float* x, const float* dout, int64_t N, int32_t K, int32_t H, int32_t D,
                      float* dx, float* dattn, void* stream);
+/* The same sum over rows gathered on the fly -- fa_former_layer.py:497-506 over batched_index_select(values, neighbours):
+ *   out[n, c] = sum_m attn[n, c / D, m] * x[nbr[n, m], c];  x [NS, H*D] node rows with row stride x_ld floats (a column
+ *   block of the qkv product), nbr [N, K] int32.  The [N, K, H*D] gathered tensor is never formed.
+ * bwd: dattn [N, H, K]; dx [NS, H*D] (may be NULL) through the transposed neighbour CSR (rowptr [NS + 1], perm = entry
+ * ids n * K + m ascending inside a row: fixed summation order). */
+int faf_attn_gather_sum_fwd(const float* attn, const float* x, int64_t x_ld, const int32_t* nbr, int64_t N, int32_t K,
+                            int32_t H, int32_t D, float* out, void* stream);
+int faf_attn_gather_sum_bwd(const float* attn, const float* x, int64_t x_ld, const int32_t* nbr, const float* dout,
+                            const int32_t* rowptr, const int32_t* perm, int64_t N, int64_t NS, int32_t K, int32_t H,
+                            int32_t D, float* dattn, float* dx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FAFormer's small geometric steps, one launch each (+ one partial-sum pass where the step reduces over the whole

@@ -204,3 +204,36 @@ def test_faformer_with_fused_geometry_matches_the_unfused_model(masked):
     assert g0.keys() == g1.keys()
     for k in g0:
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * float(g0[k].abs().max()) + 1e-7, k
+
+
+@pytest.mark.parametrize("N,K,H,D,block", [(1, 16, 2, 128, False), (700, 16, 2, 128, True), (15744, 16, 2, 128, True),
+                                           (333, 5, 1, 64, False), (900, 16, 2, 32, True)])
+def test_attn_gather_sum_matches_float64(N, K, H, D, block):
+    """faf_attn_gather_sum_fwd / _bwd against the einsum of fa_former_layer.py:497-506 over explicitly gathered rows in
+    float64: output, dattn and dx (through the transposed neighbour CSR); ``block``: x is a column block of a wider
+    matrix, read in place; two runs are bitwise equal."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + K + D)
+    C = H * D
+    nbr = torch.randint(0, N, (N, K), generator=g).to(torch.int32)
+    attn = torch.randn(N, H, K, generator=g).softmax(-1)
+    wide = torch.randn(N, 3 * C if block else C, generator=g)
+    w = torch.randn(N, C, generator=g)
+    csr_t = ops.csr_build(nbr.reshape(-1).to(DEV), None, N)
+    runs = []
+    for _ in range(2):
+        a, xw = attn.to(DEV).requires_grad_(True), wide.to(DEV).requires_grad_(True)
+        x = xw[:, 2 * C:] if block else xw
+        assert ops.attn_gather_sum_supported(H, x, nbr.to(DEV), csr_t)
+        out = ops.attn_gather_sum(a, x, nbr.to(DEV), csr_t)
+        (out * w.to(DEV)).sum().backward()
+        runs.append((out.detach().clone(), a.grad.clone(), xw.grad.clone()))
+    assert all(torch.equal(p, q) for p, q in zip(runs[0], runs[1]))
+    a64, x64 = attn.double().requires_grad_(True), wide.double().requires_grad_(True)
+    xs = x64[:, 2 * C:] if block else x64
+    ref = torch.einsum("nhm,nmhd->nhd", a64, xs[nbr.long()].view(N, K, H, D)).reshape(N, -1)
+    (ref * w.double()).sum().backward()
+    out, da, dx = runs[0]
+    np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-6)
+    np.testing.assert_allclose(da.cpu().numpy(), a64.grad.numpy(), atol=2e-5, rtol=1e-5)
+    assert _rel(dx, x64.grad) < 5e-6
