@@ -6,6 +6,8 @@
 //   drop_mean:     out[r] = mean over F consecutive rows of dropout(x)                   (one pass each way)
 // The dropout decision of element i is a hash of (seed, i) -- recomputed in the backward pass, so no mask is ever
 // stored -- with the seed in device memory (a fresh draw per launch, also under hipGraph replay).
+#include <cstdlib>
+
 #include "common.h"
 #include "drop_hash.h"
 
@@ -136,6 +138,46 @@ k_drop_mean_bwd(const float* __restrict__ dout, int64_t R, int F, int C, const i
     }
 }
 
+// The same for F = 8 frames of C = 256 channels (FAFormer's frame MLPs): a wavefront owns one row of dout and writes its
+// eight frame rows -- one load per eight 1 KiB stores, no 64-bit divisions (the general kernel above spends two per float4
+// and has one load per store in flight: 3.5 TB/s on the 2 GB gradient, against ~6 TB/s for plain stores).  Bitwise the
+// same dx; the column sums are taken over a different partition of the rows.
+template <bool COLSUM>
+__global__ void __launch_bounds__(256)
+k_drop_mean_bwd_f8c256(const float* __restrict__ dout, int64_t R, const int64_t* __restrict__ seed_ptr, uint32_t threshold,
+                       float inv_keep, float* __restrict__ dx, float* __restrict__ slab) {
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
+    const int lane = threadIdx.x & 63;
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    float4 cs = f4_zero();
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += nw) {
+        float4 g = *reinterpret_cast<const float4*>(dout + r * 256 + lane * 4);
+        g.x *= 0.125f; g.y *= 0.125f; g.z *= 0.125f; g.w *= 0.125f;
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const int64_t row = r * 8 + f;
+            float4 o = g;
+            if (threshold) {
+                const uint64_t e = (uint64_t)(row * 256 + lane * 4);
+                o.x *= keep_scale(seed, e, threshold, inv_keep); o.y *= keep_scale(seed, e + 1, threshold, inv_keep);
+                o.z *= keep_scale(seed, e + 2, threshold, inv_keep); o.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+            }
+            *reinterpret_cast<float4*>(dx + row * 256 + lane * 4) = o;
+            if (COLSUM) f4_add(cs, o);
+        }
+    }
+    if (COLSUM) {
+        __shared__ float4 s_cs[256];
+        s_cs[threadIdx.x] = cs;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float4 t = s_cs[threadIdx.x];
+            for (int k = threadIdx.x + 64; k < 256; k += 64) f4_add(t, s_cs[k]);
+            *reinterpret_cast<float4*>(slab + (int64_t)blockIdx.x * 256 + threadIdx.x * 4) = t;
+        }
+    }
+}
+
 int ew_check(int64_t R, int32_t C, float p) {
     if (R < 0 || C <= 0 || !(p >= 0.f) || !(p < 1.f)) return EQH_ERR_ARG;
     if (C & 3) return EQH_ERR_ALIGN;
@@ -191,6 +233,12 @@ extern "C" int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_
     return EQH_OK;
 }
 
+// (EQH_NO_DM_F8=1: the general kernel also for F = 8, C = 256 -- same-box timing of the two)
+static inline bool dm_f8(int32_t F, int32_t C) {
+    static const bool off = getenv("EQH_NO_DM_F8") != nullptr;
+    return !off && F == 8 && C == 256;
+}
+
 extern "C" int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int32_t C, float p, const int64_t* seed,
                                     float* dx, void* stream_) {
     int rc = ew_check(R, C, p);
@@ -199,8 +247,12 @@ extern "C" int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int
     if (!dout || !dx || (p > 0.f && !seed)) return EQH_ERR_ARG;
     if (!eqh_aligned16(dout) || !eqh_aligned16(dx)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    hipLaunchKernelGGL(k_drop_mean_bwd<false>, dim3(eqh_grid_for(R * F * (C / 4), 256, 8192)), dim3(256), 0, stream, dout, R,
-                       (int)F, (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
+    if (dm_f8(F, C))
+        hipLaunchKernelGGL(k_drop_mean_bwd_f8c256<false>, dim3(eqh_grid_for(R, 4, 8192)), dim3(256), 0, stream, dout, R, seed,
+                           ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
+    else
+        hipLaunchKernelGGL(k_drop_mean_bwd<false>, dim3(eqh_grid_for(R * F * (C / 4), 256, 8192)), dim3(256), 0, stream, dout, R,
+                           (int)F, (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -228,8 +280,12 @@ extern "C" int faf_dropout_mean_bwd_colsum(const float* dout, int64_t R, int32_t
     if (workspace_bytes < faf_dropout_mean_bwd_colsum_workspace_bytes(R, F, C)) return EQH_ERR_ARG;
     const int blocks = dm_colsum_blocks(R, F, C);
     float* slab = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(k_drop_mean_bwd<true>, dim3(blocks), dim3(256), 0, stream, dout, R, (int)F, (int)C, seed,
-                       ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
+    if (dm_f8(F, C))
+        hipLaunchKernelGGL(k_drop_mean_bwd_f8c256<true>, dim3(blocks), dim3(256), 0, stream, dout, R, seed, ew_threshold(p),
+                           1.0f / (1.0f - p), dx, slab);
+    else
+        hipLaunchKernelGGL(k_drop_mean_bwd<true>, dim3(blocks), dim3(256), 0, stream, dout, R, (int)F, (int)C, seed,
+                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(slab, blocks, C, colsum, stream, accumulate ? 1 : 0);
 }
