@@ -362,6 +362,64 @@ k_attn_logits_bwd(const float* __restrict__ prob, const float* __restrict__ datt
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The edge logits' folded weights (fa_former_layer.py:483-489: Linear(deh, 1) of the edge QUERY, itself a Linear of the
+// edge features -- folded at weight level, faformer.MLPAttnEdgeAggregation):
+//   u[h, j] = sum_d w_e[d] W[h * deh + d, j],   c[h] = sum_d w_e[d] b[h * deh + d]          (W: the query rows of the Linear)
+// and their backward.  Twenty elementwise / reduction launches per layer and step as torch expressions.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_elw_fwd(const float* __restrict__ W, int64_t ldw, const float* __restrict__ b, const float* __restrict__ we, int H, int deh,
+          int de, float* __restrict__ u, float* __restrict__ c) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < H * de) {
+        const int hh = t / de, j = t - hh * de;
+        float acc = 0.f;
+        for (int d = 0; d < deh; ++d) acc = fmaf(we[d], W[(int64_t)(hh * deh + d) * ldw + j], acc);
+        u[t] = acc;
+    } else if (t < H * de + H) {
+        const int hh = t - H * de;
+        float acc = 0.f;
+        for (int d = 0; d < deh; ++d) acc = fmaf(we[d], b[hh * deh + d], acc);
+        c[hh] = acc;
+    }
+}
+
+// one workgroup per d: dW[h * deh + d, :] (+)= w_e[d] du[h, :], db[h * deh + d] (+)= w_e[d] dc[h],
+// dwe[d] (+)= sum_h (W[h * deh + d, :] . du[h, :] + b[h * deh + d] dc[h])
+__global__ void __launch_bounds__(256)
+k_elw_bwd(const float* __restrict__ W, int64_t ldw, const float* __restrict__ b, const float* __restrict__ we,
+          const float* __restrict__ du, const float* __restrict__ dc, int H, int deh, int de, float* __restrict__ dW,
+          int64_t lddw, float* __restrict__ db, float* __restrict__ dwe, int acc_w, int acc_b, int acc_e) {
+    __shared__ float s_w[4];
+    const int d = blockIdx.x;
+    const float wd = we[d];
+    float part = 0.f;
+    for (int hh = 0; hh < H; ++hh) {
+        const int64_t r = hh * deh + d;
+        for (int j = threadIdx.x; j < de; j += 256) {
+            const float g = du ? du[hh * de + j] : 0.f;
+            float* o = dW + r * lddw + j;
+            *o = acc_w ? *o + wd * g : wd * g;
+            part = fmaf(W[r * ldw + j], g, part);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        for (int hh = 0; hh < H; ++hh) {
+            const float g = dc ? dc[hh] : 0.f;
+            const int r = hh * deh + d;
+            tot = fmaf(b[r], g, tot);
+            db[r] = acc_b ? db[r] + wd * g : wd * g;
+        }
+        dwe[d] = acc_e ? dwe[d] + tot : tot;
+    }
+}
+
 static inline int moments_grid(int64_t N) { return eqh_grid_for(N, GM_THREADS, GM_MAXP); }
 
 }  // namespace
@@ -476,6 +534,25 @@ extern "C" int faf_attn_logits_bwd(const float* prob, const float* dattn, const 
     if (!prob || !dattn || !mask || !dqa || !dqan || !dle || (p > 0.f && !seed)) return EQH_ERR_ARG;
     hipLaunchKernelGGL(k_attn_logits_bwd, dim3(eqh_grid_for(N * H * 16, GM_THREADS, 1 << 30)), dim3(GM_THREADS), 0,
                        static_cast<hipStream_t>(stream_), prob, dattn, mask, N, K, H, p, seed, dqa, dqan, dle);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int faf_edge_logit_weights_fwd(const float* W, int64_t ldw, const float* b, const float* we, int32_t H, int32_t deh,
+                                          int32_t de, float* u, float* c, void* stream_) {
+    if (H < 1 || deh < 1 || de < 1 || ldw < de || !W || !b || !we || !u || !c) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(k_elw_fwd, dim3(eqh_grid_for((int64_t)H * de + H, 256, 1 << 30)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream_), W, ldw, b, we, (int)H, (int)deh, (int)de, u, c);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int faf_edge_logit_weights_bwd(const float* W, int64_t ldw, const float* b, const float* we, const float* du,
+                                          const float* dc, int32_t H, int32_t deh, int32_t de, float* dW, int64_t lddw,
+                                          float* db, float* dwe, int32_t acc_w, int32_t acc_b, int32_t acc_e, void* stream_) {
+    if (H < 1 || deh < 1 || de < 1 || ldw < de || lddw < de || !W || !b || !we || !dW || !db || !dwe) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(k_elw_bwd, dim3(deh), dim3(256), 0, static_cast<hipStream_t>(stream_), W, ldw, b, we, du, dc, (int)H,
+                       (int)deh, (int)de, dW, lddw, db, dwe, (int)acc_w, (int)acc_b, (int)acc_e);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

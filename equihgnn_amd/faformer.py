@@ -295,9 +295,12 @@ class MLPAttnEdgeAggregation(nn.Module):
             xe, edge = _layer_norm(self.layernorm_qkv_edge[0], edge, passthrough=True)
         else:
             xe = _layer_norm(self.layernorm_qkv_edge[0], edge)                                # [N, K, de]
-        w_e = self.edge_attn.weight.view(-1)
-        u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)          # [h, de]
-        c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                              # [h]
+        if ops.geom_supported(tok) and lin_e.weight.shape == (2 * de, de):
+            u, c = ops.edge_logit_weights(lin_e.weight, lin_e.bias, self.edge_attn.weight, h)  # [h, de], [h]: one launch each way
+        else:
+            w_e = self.edge_attn.weight.view(-1)
+            u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)      # [h, de]
+            c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                          # [h]
         if ops.rowdot_supported(xe, h):   # one pass over xe each way; xe's second gradient (from ve) rides along
             le, xe = ops.rowdot(xe, u, c, passthrough=True)                                   # [N, K, h]
         else:

@@ -762,3 +762,50 @@ def attn_logits_supported(qa, le, mask) -> bool:
 def attn_logits(qa, qan, le, mask, p: float = 0.0, seed=None):
     """See _AttnLogits (fa_former_layer.py:483-496)."""
     return _AttnLogits.apply(qa, qan, le, mask, p, seed)
+
+
+class _EdgeLogitWeights(torch.autograd.Function):
+    """(u [h, de], c [h]) = the Linear(deh, 1) ``we`` folded into the QUERY rows (the first de) of the edge Linear
+    W [2 de, de], b [2 de] (faf_edge_logit_weights_*): one launch each way; the gradients go straight into the
+    parameters' accumulators when they have them (W's value rows are written by ops.linear(..., rows=...))."""
+
+    @staticmethod
+    def forward(ctx, W, b, we, h):
+        _require_gpu(W, "edge_logit_weights")
+        Wc, bc, wc = _f32c(W), _f32c(b), _f32c(we).reshape(-1)
+        de, deh = Wc.shape[1], wc.numel()
+        u = torch.empty((h, de), dtype=torch.float32, device=W.device)
+        c = torch.empty(h, dtype=torch.float32, device=W.device)
+        hip.check(hip.lib().faf_edge_logit_weights_fwd(_ptr(Wc), de, _ptr(bc), _ptr(wc), h, deh, de, _ptr(u), _ptr(c),
+                                                       _stream(W.device)), "faf_edge_logit_weights_fwd")
+        ctx.save_for_backward(Wc, bc, wc)
+        ctx.params, ctx.h, ctx.we_shape = (W, b, we), h, we.shape
+        ctx.set_materialize_grads(False)
+        return u, c
+
+    @staticmethod
+    def backward(ctx, du, dc):
+        Wc, bc, wc = ctx.saved_tensors
+        if du is None and dc is None:
+            return None, None, None, None
+        h, de, deh = ctx.h, Wc.shape[1], wc.numel()
+        du = _f32c(du) if du is not None else None
+        dc = _f32c(dc) if dc is not None else None
+        tg = [_acc_target(q) for q in ctx.params]
+        dW = tg[0] if tg[0] is not None else torch.zeros_like(Wc)
+        db = tg[1] if tg[1] is not None else torch.zeros_like(bc)
+        dwe = tg[2].reshape(-1) if tg[2] is not None else torch.empty_like(wc)
+        hip.check(hip.lib().faf_edge_logit_weights_bwd(_ptr(Wc), de, _ptr(bc), _ptr(wc), _ptr(du), _ptr(dc), h, deh, de,
+                                                       _ptr(dW), de, _ptr(db), _ptr(dwe), int(tg[0] is not None),
+                                                       int(tg[1] is not None), int(tg[2] is not None), _stream(Wc.device)),
+                  "faf_edge_logit_weights_bwd")
+        return (None if tg[0] is not None else dW, None if tg[1] is not None else db,
+                None if tg[2] is not None else dwe.view(ctx.we_shape), None)
+
+
+def edge_logit_weights(W, b, we, h: int):
+    """See _EdgeLogitWeights; W, b, we are the PARAMETERS (layernorm_qkv_edge's Linear, edge_attn's weight)."""
+    if torch.is_grad_enabled() and W.requires_grad and W.is_leaf and not hasattr(W, "_eqh_transient"):
+        LINEAR_PARAMS[id(W)] = W
+    _note_acc(b, we)
+    return _EdgeLogitWeights.apply(W, b, we, h)

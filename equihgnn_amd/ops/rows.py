@@ -9,7 +9,7 @@ import torch
 
 from .. import hip
 from ._base import (
-    LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
+    LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream, _workspace, timed)
 from .aggregate import (CSR, entry_weights, segment_reduce_bytes)
 from .products import (mm_nn, mm_nt)
 from .grads import (_wgrad_deferred, _wgrad_ok, colsum, wgrad)
@@ -319,8 +319,8 @@ class _LayerNormRows(torch.autograd.Function):
         x, gamma = ctx.saved_tensors
         if dy is None:
             return dpass, None, None, None, None, None
-        dy = _f32c(dy)
         R, C = x.shape
+        dy, ld = _rows_ld(dy.reshape(R, C))          # (a column block of a wider gradient -- the backward of a cat -- is read in place)
         add = _f32c(dpass).reshape(R, C) if dpass is not None else None
         dx = torch.empty_like(x)
         L = hip.lib()
@@ -328,11 +328,11 @@ class _LayerNormRows(torch.autograd.Function):
         ws = _workspace(ws_bytes, x.device)
         tg = [_acc_target(p) for p in ctx.acc]
         if all(t is not None for t in tg):
-            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
+            hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), ld, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(tg[0]),
                                           _ptr(tg[1]), 1, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
             return dx, None, None, None, None, None
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), C, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
+        hip.check(L.hg_layer_norm_bwd(_ptr(x), _ptr(gamma), _ptr(dy), ld, _ptr(add), R, C, float(ctx.eps), _ptr(dx), _ptr(small[0]),
                                       _ptr(small[1]), 0, _ptr(ws), ws_bytes, _stream(x.device)), "hg_layer_norm_bwd")
         return (dx, *_hand_out(list(small), tg), None, None, None)
 

@@ -526,6 +526,16 @@ int faf_edge_frame_bwd(const float* geo, const float* gj, const uint8_t* mask, c
                        const float* dd2, int64_t N, int32_t K, float* dgeo, float* dgj, void* stream);
 int faf_attn_logits_fwd(const float* qa, const float* qan, const float* le, const uint8_t* mask, int64_t N, int32_t K,
                         int32_t H, float p, const int64_t* seed, float* prob, float* attn, void* stream);
+/* The edge logits' folded weights -- fa_former_layer.py:483-489, Linear(deh, 1) of the edge query (itself the first de rows
+ * of a Linear(de, 2 de) of the edge features), folded at weight level:
+ *   u[h, j] = sum_d we[d] W[h * deh + d, j],  c[h] = sum_d we[d] b[h * deh + d];   W [H * deh, de] (row stride ldw), we [deh]
+ * bwd: dW [H * deh, de] (row stride lddw), db [H * deh], dwe [deh] from du [H, de] / dc [H] (either may be NULL), each
+ * overwritten or (acc_* != 0) added to. */
+int faf_edge_logit_weights_fwd(const float* W, int64_t ldw, const float* b, const float* we, int32_t H, int32_t deh, int32_t de,
+                               float* u, float* c, void* stream);
+int faf_edge_logit_weights_bwd(const float* W, int64_t ldw, const float* b, const float* we, const float* du, const float* dc,
+                               int32_t H, int32_t deh, int32_t de, float* dW, int64_t lddw, float* db, float* dwe,
+                               int32_t acc_w, int32_t acc_b, int32_t acc_e, void* stream);
 int faf_attn_logits_bwd(const float* prob, const float* dattn, const uint8_t* mask, int64_t N, int32_t K, int32_t H, float p,
                         const int64_t* seed, float* dqa, float* dqan, float* dle, void* stream);
 

@@ -237,3 +237,41 @@ def test_attn_gather_sum_matches_float64(N, K, H, D, block):
     np.testing.assert_allclose(out.cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=1e-6)
     np.testing.assert_allclose(da.cpu().numpy(), a64.grad.numpy(), atol=2e-5, rtol=1e-5)
     assert _rel(dx, x64.grad) < 5e-6
+
+
+@pytest.mark.parametrize("acc", [False, True])
+def test_edge_logit_weights_match_float64(acc):
+    """faf_edge_logit_weights_fwd / _bwd against the torch expression of the fold in float64; with persistent accumulators
+    (the graphed trainer's) the gradients are added in place and autograd gets None."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    h, deh = 2, 128
+    de = h * deh
+    W = torch.nn.Parameter((0.1 * torch.randn(2 * de, de, generator=g)).to(DEV))
+    b = torch.nn.Parameter(torch.randn(2 * de, generator=g).to(DEV))
+    we = torch.nn.Parameter(torch.randn(1, deh, generator=g).to(DEV))
+    wu, wc = torch.randn(h, de, generator=g), torch.randn(h, generator=g)
+    t = [p.detach().cpu().double().requires_grad_(True) for p in (W, b, we)]
+    u64 = (t[0][:de].reshape(h, deh, de) * t[2].view(-1)[None, :, None]).sum(1)
+    c64 = (t[1][:de].reshape(h, deh) * t[2].view(-1)).sum(-1)
+    ((u64 * wu.double()).sum() + (c64 * wc.double()).sum()).backward()
+    base = [torch.randn_like(p) for p in (W, b, we)]
+    if acc:
+        for p, a in zip((W, b, we), base):
+            p._eqh_gbuf = a.clone()
+    try:
+        u, c = ops.edge_logit_weights(W, b, we, h)
+        ((u * wu.to(DEV)).sum() + (c * wc.to(DEV)).sum()).backward()
+        np.testing.assert_allclose(u.detach().cpu().numpy(), u64.detach().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(c.detach().cpu().numpy(), c64.detach().numpy(), rtol=1e-5, atol=1e-5)
+        for p, r, a in zip((W, b, we), t, base):
+            if acc:
+                assert p.grad is None
+                got = p._eqh_gbuf - a
+            else:
+                got = p.grad
+            assert _rel(got, r.grad.view_as(got)) < 1e-5
+    finally:
+        for p in (W, b, we):
+            if hasattr(p, "_eqh_gbuf"):
+                del p._eqh_gbuf
