@@ -291,20 +291,27 @@ class MLPAttnEdgeAggregation(nn.Module):
         gsum = tok.is_cuda and ops.attn_gather_sum_supported(h, v, g.nbr, g.csr_t)
         v_n = None if gsum else g.gather(v)                                                   # [N, K, d]
         lin_e = self.layernorm_qkv_edge[1]
-        if edge_passthrough:
-            xe, edge = _layer_norm(self.layernorm_qkv_edge[0], edge, passthrough=True)
-        else:
-            xe = _layer_norm(self.layernorm_qkv_edge[0], edge)                                # [N, K, de]
-        if ops.geom_supported(tok) and lin_e.weight.shape == (2 * de, de):
+        folded = ops.geom_supported(tok) and lin_e.weight.shape == (2 * de, de)
+        if folded:
             u, c = ops.edge_logit_weights(lin_e.weight, lin_e.bias, self.edge_attn.weight, h)  # [h, de], [h]: one launch each way
         else:
             w_e = self.edge_attn.weight.view(-1)
             u = (lin_e.weight[:de].reshape(h, self.deh, de) * w_e[None, :, None]).sum(1)      # [h, de]
             c = (lin_e.bias[:de].reshape(h, self.deh) * w_e).sum(-1)                          # [h]
-        if ops.rowdot_supported(xe, h):   # one pass over xe each way; xe's second gradient (from ve) rides along
-            le, xe = ops.rowdot(xe, u, c, passthrough=True)                                   # [N, K, h]
+        ln_e = self.layernorm_qkv_edge[0]
+        if folded and ops.ln_rowdot_supported(edge, h):
+            # LayerNorm, the per-head edge logits and (backward) the residual's gradient in one pass over the edge rows
+            xe, le, edge_alias = ops.ln_rowdot(edge, ln_e.weight, ln_e.bias, u, c, ln_e.eps)  # [N,K,de], [N,K,h]
+            edge = edge_alias if edge_passthrough else edge
         else:
-            le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c
+            if edge_passthrough:
+                xe, edge = _layer_norm(ln_e, edge, passthrough=True)
+            else:
+                xe = _layer_norm(ln_e, edge)                                                  # [N, K, de]
+            if ops.rowdot_supported(xe, h):   # one pass over xe each way; xe's second gradient (from ve) rides along
+                le, xe = ops.rowdot(xe, u, c, passthrough=True)                               # [N, K, h]
+            else:
+                le = torch.stack([(xe * u[i]).sum(-1) for i in range(h)], -1) + c
         ve = ops.linear(xe, lin_e.weight, lin_e.bias, rows=(de, 2 * de))                      # value half only
         if ops.rowdot_supported(tok, 1):   # Linear(d, 1) on the atom rows: a row-wise dot product, not a one-column GEMM
             gate_logit = ops.rowdot(tok, self.W_gate.weight, self.W_gate.bias)

@@ -134,6 +134,10 @@ SIGNATURES = {
                                           c_void_p]),
     "faf_attn_gather_sum_bwd": (c_int32, [c_void_p, c_void_p, c_int64] + [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int32,
                                                                                          c_int32, c_void_p, c_void_p, c_void_p]),
+    "faf_ln_rowdot_fwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
+    "faf_ln_rowdot_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "faf_ln_rowdot_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float]
+                          + [c_void_p] * 3 + [c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "faf_edge_logit_weights_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                              c_void_p]),
     "faf_edge_logit_weights_bwd": (c_int32, [c_void_p, c_int64] + [c_void_p] * 4 + [c_int32] * 3 + [c_void_p, c_int64, c_void_p,

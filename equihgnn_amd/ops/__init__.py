@@ -77,7 +77,7 @@ from .frames import (  # noqa: F401
     frame_hidden, swiglu_dropout, dropout_mean, eigh3, linear_dropout_mean, linear_dropout_mean_supported,
     _CentreMix, centre_mix, _CloudFrame, cloud_frame, _EdgeFrame, edge_frame, edge_frame_supported, _AttnLogits,
     attn_logits, attn_logits_supported, geom_supported, dropout_seeds, _AttnGatherSum, attn_gather_sum,
-    attn_gather_sum_supported, _EdgeLogitWeights, edge_logit_weights,
+    attn_gather_sum_supported, _EdgeLogitWeights, edge_logit_weights, _LnRowDot, ln_rowdot, ln_rowdot_supported,
 )
 
 # switches that tests / tools / bench.py set as ``ops.NAME = value``: owner module of each

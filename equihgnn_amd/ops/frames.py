@@ -809,3 +809,63 @@ def edge_logit_weights(W, b, we, h: int):
         LINEAR_PARAMS[id(W)] = W
     _note_acc(b, we)
     return _EdgeLogitWeights.apply(W, b, we, h)
+
+
+class _LnRowDot(torch.autograd.Function):
+    """(xe, le, x) = (LayerNorm(x), LayerNorm(x) @ U.T + cb, x itself) in one pass each way (faf_ln_rowdot_*): the
+    LayerNorm in front of FAFormer's edge Linear with the per-head edge logits riding along.  The third output is x for
+    its OTHER consumer (the residual of the edge update), whose gradient the backward adds in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, U, cb, eps, acc_params):
+        _require_gpu(x, "ln_rowdot")
+        x2 = _f32c(x).reshape(-1, x.shape[-1])
+        g, b, Uc = _f32c(gamma), _f32c(beta), _f32c(U)
+        R, C = x2.shape
+        J = Uc.shape[0]
+        out = torch.empty_like(x2)
+        le = torch.empty((R, J), dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().faf_ln_rowdot_fwd(_ptr(x2), _ptr(g), _ptr(b), _ptr(Uc), _ptr(_f32c(cb) if cb is not None else None),
+                                              R, C, J, float(eps), _ptr(out), _ptr(le), _stream(x.device)), "faf_ln_rowdot_fwd")
+        ctx.save_for_backward(x2, g, b, Uc)
+        ctx.meta = (x.shape, float(eps), cb is not None)
+        ctx.acc = acc_params
+        ctx.set_materialize_grads(False)
+        return out.view(x.shape), le.view(*x.shape[:-1], J), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dxe, dle, dpass):
+        x2, g, b, Uc = ctx.saved_tensors
+        shape, eps, has_cb = ctx.meta
+        R, C = x2.shape
+        J = Uc.shape[0]
+        if dxe is None and dle is None:
+            return dpass, None, None, None, None, None, None
+        dy, ld = _rows_ld(dxe.reshape(R, C)) if dxe is not None else (None, C)
+        dl = _f32c(dle).reshape(R, J) if dle is not None else None
+        add = _f32c(dpass).reshape(R, C) if dpass is not None else None
+        dx = torch.empty_like(x2)
+        dU = torch.empty_like(Uc)
+        L = hip.lib()
+        ws_bytes = L.faf_ln_rowdot_bwd_workspace_bytes(R, C, J)
+        ws = _workspace(max(ws_bytes, 16), x2.device)
+        tg = [_acc_target(q) for q in ctx.acc]
+        acc = all(t is not None for t in tg)
+        small = None if acc else torch.empty((2, C), dtype=torch.float32, device=x2.device)
+        hip.check(L.faf_ln_rowdot_bwd(_ptr(x2), _ptr(g), _ptr(b), _ptr(Uc), _ptr(dy), ld, _ptr(dl), _ptr(add), R, C, J, eps,
+                                      _ptr(dx), _ptr(tg[0] if acc else small[0]), _ptr(tg[1] if acc else small[1]),
+                                      1 if acc else 0, _ptr(dU), _ptr(ws), ws_bytes, _stream(x2.device)), "faf_ln_rowdot_bwd")
+        dgam, dbet = (None, None) if acc else _hand_out(list(small), tg)
+        dcb = _tall_colsum(dl) if (has_cb and dl is not None) else None
+        return dx.view(shape), dgam, dbet, dU, dcb, None, None
+
+
+def ln_rowdot_supported(x, J: int) -> bool:
+    return USE_GEOM and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1024 and 1 <= J <= 2
+
+
+def ln_rowdot(x, gamma, beta, U, cb=None, eps: float = 1e-5):
+    """(LayerNorm(x), LayerNorm(x) @ U.T + cb, x) for x [..., C], U [J <= 2, C]; gamma / beta are the PARAMETERS; see
+    _LnRowDot."""
+    _note_acc(gamma, beta)
+    return _LnRowDot.apply(x, gamma, beta, U, cb, eps, (gamma, beta))

@@ -526,6 +526,17 @@ int faf_edge_frame_bwd(const float* geo, const float* gj, const uint8_t* mask, c
                        const float* dd2, int64_t N, int32_t K, float* dgeo, float* dgj, void* stream);
 int faf_attn_logits_fwd(const float* qa, const float* qan, const float* le, const uint8_t* mask, int64_t N, int32_t K,
                         int32_t H, float p, const int64_t* seed, float* prob, float* attn, void* stream);
+/* LayerNorm over dense rows with J <= 2 row-wise dot products of its output riding along (csrc/ln_rowdot.hip) --
+ * fa_former_layer.py:436-441 (the LayerNorm in front of the edge Linear) with :483-489 (the per-head edge logits, linear
+ * in the normalised edge features):  out = LayerNorm(x) [R, C],  le[r, j] = out[r, :] . U[j, :] + cb[j]  (cb may be NULL).
+ * bwd: dx [R, C] = LNbwd(dy + sum_j dle[r, j] U[j, :]) + add;  dy [R, C] (row stride dy_ld), dle [R, J], add [R, C] may be
+ * NULL;  dU [J, C] overwritten;  dgamma / dbeta [C] overwritten or (accumulate != 0) added to.  C <= 1024, multiple of 4. */
+int faf_ln_rowdot_fwd(const float* x, const float* gamma, const float* beta, const float* U, const float* cb, int64_t R,
+                      int32_t C, int32_t J, float eps, float* out, float* le, void* stream);
+size_t faf_ln_rowdot_bwd_workspace_bytes(int64_t R, int32_t C, int32_t J);
+int faf_ln_rowdot_bwd(const float* x, const float* gamma, const float* beta, const float* U, const float* dy, int64_t dy_ld,
+                      const float* dle, const float* add, int64_t R, int32_t C, int32_t J, float eps, float* dx, float* dgamma,
+                      float* dbeta, int32_t accumulate, float* dU, void* workspace, size_t workspace_bytes, void* stream);
 /* The edge logits' folded weights -- fa_former_layer.py:483-489, Linear(deh, 1) of the edge query (itself the first de rows
  * of a Linear(de, 2 de) of the edge features), folded at weight level:
  *   u[h, j] = sum_d we[d] W[h * deh + d, j],  c[h] = sum_d we[d] b[h * deh + d];   W [H * deh, de] (row stride ldw), we [deh]

@@ -275,3 +275,35 @@ def test_edge_logit_weights_match_float64(acc):
         for p in (W, b, we):
             if hasattr(p, "_eqh_gbuf"):
                 del p._eqh_gbuf
+
+
+@pytest.mark.parametrize("R,C,J,alias", [(1, 256, 2, True), (777, 256, 2, True), (20000, 256, 2, False), (301, 64, 1, True),
+                                         (129, 512, 2, True), (70, 1024, 1, False)])
+def test_ln_rowdot_matches_float64(R, C, J, alias):
+    """faf_ln_rowdot_fwd / _bwd: (LayerNorm(x), its row dots with U, x) against float64 -- every gradient, with the
+    alias's gradient added in the same pass and the upstream gradient of xe a column block of a wider matrix."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C + J)
+    x = torch.randn(R, C, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    U, cb = torch.randn(J, C, generator=g), torch.randn(J, generator=g)
+    wx, wl, wa = torch.randn(R, 2 * C, generator=g), torch.randn(R, J, generator=g), torch.randn(R, C, generator=g)
+    t = [a.double().requires_grad_(True) for a in (x, gamma, beta, U, cb)]
+    xe64 = torch.nn.functional.layer_norm(t[0], (C,), t[1], t[2], 1e-5)
+    le64 = xe64 @ t[3].T + t[4]
+    loss = (torch.cat((xe64, xe64), 1) * wx.double()).sum() + (le64 * wl.double()).sum()
+    if alias:
+        loss = loss + (t[0] * wa.double()).sum()
+    loss.backward()
+    d = [a.to(DEV).requires_grad_(True) for a in (x, gamma, beta, U, cb)]
+    xe, le, xa = ops.ln_rowdot(d[0], d[1], d[2], d[3], d[4], 1e-5)
+    loss = (torch.cat((xe, xe), 1) * wx.to(DEV)).sum() + (le * wl.to(DEV)).sum()
+    if alias:
+        loss = loss + (xa * wa.to(DEV)).sum()
+    loss.backward()
+    np.testing.assert_allclose(xe.detach().cpu().numpy(), xe64.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(le.detach().cpu().numpy(), le64.detach().numpy(), atol=3e-4, rtol=1e-5)
+    for name, a, r in zip(("dx", "dgamma", "dbeta", "dU", "dcb"), d, t):
+        assert _rel(a.grad, r.grad) < 3e-5, (name, _rel(a.grad, r.grad))
+    # the LayerNorm itself is the row kernels' (bitwise)
+    assert torch.equal(xe.detach(), ops.layer_norm_rows(d[0].detach(), d[1].detach(), d[2].detach(), 1e-5))

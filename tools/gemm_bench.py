@@ -30,7 +30,10 @@ SHAPES = [("c2 conv fwd x W^T", 4736, 256, 256, 0, 1), ("c2 conv dgrad dY W", 47
           ("square 4096", 4096, 4096, 4096, 0, 1),
           ("c4 egnn ab dgrad", 31232, 256, 2176, 0, 0), ("c4 egnn ab wgrad", 2176, 256, 31232, 1, 0),
           ("c5 node fwd", 15488, 256, 256, 0, 1), ("c5 ffn up", 15488, 1024, 512, 0, 1), ("c5 qkv", 15488, 768, 256, 0, 1),
-          ("c5 mid wgrad", 1024, 512, 15488, 1, 0)]
+          ("c5 mid wgrad", 1024, 512, 15488, 1, 0),
+          ("c3 attn dgrad K=4096", 2432, 256, 4096, 0, 0), ("c3 attn wgrad N=4096", 256, 4096, 2432, 1, 0),
+          ("c3 attn dgrad 3N rows", 7296, 256, 4096, 0, 0), ("c3 attn wgrad 3N rows", 256, 4096, 7296, 1, 0),
+          ("c3 attn fwd", 2432, 4096, 256, 0, 0), ("c3 attn fwd 3N", 7296, 4096, 256, 0, 0)]
 
 
 def timeit(fn, reps):
@@ -59,11 +62,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--json", default=None)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default=None, help="substring of the shape names to run")
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
     rows = []
     for name, M, N, K, ta, tb in SHAPES:
+        if a.only and a.only not in name:
+            continue
         A = torch.randn((K, M) if ta else (M, K), device=dev, generator=g)
         B = torch.randn((N, K) if tb else (K, N), device=dev, generator=g)
         out = torch.empty(M, N, device=dev)
