@@ -27,6 +27,10 @@ import torch.nn.functional as F
 from . import ops
 from .index import HyperIndex
 
+import os as _os
+
+FUSE_SMALL = not _os.environ.get("EQH_NO_EQF_FUSE")   # degree-1 Norm and masked means on the row kernels (off: the torch expressions, for same-box timing)
+
 
 class FiberLinear(nn.Module):
     """equiformer_layer.py:168-191 — ``weights.{i}`` of shape [d_in, d_out] per shared degree."""
@@ -63,6 +67,10 @@ class FiberNorm(nn.Module):
         return t / rms.clamp(min=self.eps) * self.transforms[0][:, 0]
 
     def norm1(self, t):  # [N, d, 3]
+        if (FUSE_SMALL and t.is_cuda and t.dim() == 3 and t.dtype == torch.float32 and t.shape[-2] * 3 <= 1024
+                and (t.shape[-2] * 3) % 4 == 0):
+            # the same row kernel over the flattened [d, 3] block: one launch each way instead of 6 / 20 elementwise ones
+            return ops.rms_norm_rows(t.flatten(-2), self.transforms[1], self.eps, rep=3).view_as(t)
         rms = t.flatten(-2).norm(dim=-1, keepdim=True)[..., None] * (t.shape[-2] ** -0.5)
         return t / rms.clamp(min=self.eps) * self.transforms[1]
 
@@ -136,7 +144,12 @@ class EdgeGeometry:
     def masked_mean(self, t):
         """equiformer/utils.py:71-82 over the K neighbour slots; t is [E, ...]."""
         shape = t.shape[1:]
-        return torch.bmm(self.mean_w, t.view(self.N, self.K, -1)).view(self.N, *shape)
+        t3 = t.view(self.N, self.K, -1)
+        if FUSE_SMALL and ops.attn_sum_supported(self.mean_w, t3):
+            # one pass over t each way (the attention-sum kernel with one head): the batched [1 x K] . [K x C] products and
+            # the contiguous copy of [N, K, C] in front of their backward took 0.1 ms per call in the library
+            return ops.attn_sum(self.mean_w, t3).view(self.N, *shape)
+        return torch.bmm(self.mean_w, t3).view(self.N, *shape)
 
     def masked_mean_times_rhat(self, t):
         """masked_mean(t[:, :, None] * r_hat[:, None, :]) for t [E, C] -> [N, C, 3] without the [E, C, 3]

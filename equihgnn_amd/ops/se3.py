@@ -191,19 +191,24 @@ def attn_pool(me, edge, maskf, w_logit, wv, v_off: int, scale: float, slope: flo
 
 
 class _RmsNormRows(torch.autograd.Function):
-    """t / max(||t|| * C^-1/2, eps) * g over dense rows (eqf_rms_norm_fwd / _bwd, csrc/rmsnorm.hip)."""
+    """t / max(||t|| * scale, eps) * g over dense rows (eqf_rms_norm_fwd / _bwd, csrc/rmsnorm.hip).  ``rep`` > 1: the rows
+    are [d, rep] blocks flattened (a degree-l feature with its 2l + 1 components, equiformer_layer.py:194-225), the norm runs
+    over the whole row with scale = d^-1/2 and channel c's gain multiplies its rep components."""
 
     @staticmethod
-    def forward(ctx, x, g, eps, acc_param):
+    def forward(ctx, x, g, eps, acc_param, rep=1):
         _require_gpu(x, "rms_norm_rows")
-        x, gv = _f32c(x), _f32c(g.detach()).reshape(-1)
+        x = _f32c(x)
+        gv = _f32c(g.detach()).reshape(-1)
+        if rep > 1:
+            gv = gv[:, None].expand(-1, rep).reshape(-1)
         R, C = x.shape
         out = torch.empty_like(x)
-        scale = float(torch.tensor(C ** -0.5, dtype=torch.float32))
+        scale = float(torch.tensor((C // rep) ** -0.5, dtype=torch.float32))
         hip.check(hip.lib().eqf_rms_norm_fwd(_ptr(x), _ptr(gv), R, C, scale, float(eps), _ptr(out), _stream(x.device)),
                   "eqf_rms_norm_fwd")
         ctx.save_for_backward(x, gv)
-        ctx.eps, ctx.scale, ctx.acc, ctx.gshape = float(eps), scale, acc_param, g.shape
+        ctx.eps, ctx.scale, ctx.acc, ctx.gshape, ctx.rep = float(eps), scale, acc_param, g.shape, rep
         return out
 
     @staticmethod
@@ -216,18 +221,27 @@ class _RmsNormRows(torch.autograd.Function):
         ws_bytes = L.eqf_rms_norm_bwd_workspace_bytes(R, C)
         ws = _workspace(max(ws_bytes, 16), x.device)
         tg = _acc_target(ctx.acc)
+        if ctx.rep > 1:       # the gain's gradient per component, then summed over the components of a channel
+            dgf = torch.empty(C, dtype=torch.float32, device=x.device)
+            hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dgf), 0, _ptr(ws),
+                                         ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
+            dg = dgf.view(-1, ctx.rep).sum(1).view(ctx.gshape)
+            if tg is not None:
+                tg.add_(dg)
+                dg = None
+            return dx, dg, None, None, None
         dg = tg if tg is not None else torch.empty(ctx.gshape, dtype=torch.float32, device=x.device)
         hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dg),
                                      1 if tg is not None else 0, _ptr(ws), ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
-        return dx, (None if tg is not None else dg), None, None
+        return dx, (None if tg is not None else dg), None, None, None
 
 
-def rms_norm_rows(x, g, eps: float):
-    """The degree-0 Norm of the Equiformer (equiformer_layer.py:194-225) for 2-D fp32 rows; ``g`` is the
-    ``transforms.0`` parameter [C, 1]."""
+def rms_norm_rows(x, g, eps: float, rep: int = 1):
+    """The Norm of the Equiformer (equiformer_layer.py:194-225) for 2-D fp32 rows; ``g`` is the ``transforms.l`` parameter
+    [d, 1].  rep = 1: degree 0, rows [*, d].  rep = 2l + 1: degree l, rows [*, d * rep] (the [d, rep] block flattened)."""
     if torch.is_grad_enabled() and g.requires_grad and g.is_leaf:
         (LINEAR_PARAMS if g.dim() == 2 else ACC_PARAMS)[id(g)] = g
-    return _RmsNormRows.apply(x, g, eps, g)
+    return _RmsNormRows.apply(x, g, eps, g, rep)
 
 
 class _RadialTrunk(torch.autograd.Function):

@@ -931,6 +931,34 @@ def test_rms_norm_rows_matches_float64_reference(R, C):
     del gm._eqh_gbuf
 
 
+@pytest.mark.parametrize("R,d", [(1, 64), (500, 256), (300, 340)])
+def test_rms_norm_rows_degree1_matches_float64_reference(R, d):
+    """The degree-1 Norm (equiformer_layer.py:194-225 on [N, d, 3]): t / max(||t|| d^-1/2, eps) * g[c] through the row kernel
+    over the flattened [d, 3] block (rep = 3): forward, dt and dg (summed over the three components) against float64, with
+    and without a persistent accumulator."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + d)
+    t, gam, w = torch.randn(R, d, 3, generator=g), 1 + 0.3 * torch.randn(d, 1, generator=g), torch.randn(R, d, 3, generator=g)
+    eps = 1e-12
+    td, gd = t.double().requires_grad_(True), gam.double().requires_grad_(True)
+    rms = td.flatten(-2).norm(dim=-1, keepdim=True)[..., None] * (d ** -0.5)
+    ref = td / rms.clamp(min=eps) * gd
+    (ref * w.double()).sum().backward()
+    tm, gm = t.to(DEV).requires_grad_(True), gam.to(DEV).requires_grad_(True)
+    out = ops.rms_norm_rows(tm.flatten(-2), gm, eps, rep=3).view_as(tm)
+    (out * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-6, rtol=2e-6)
+    assert float((tm.grad.cpu().double() - td.grad).abs().max() / td.grad.abs().max()) < 2e-5
+    assert float((gm.grad.cpu().double() - gd.grad).abs().max() / gd.grad.abs().max()) < 2e-5
+    gm.grad = None
+    gm._eqh_gbuf = torch.full_like(gm, 0.5)
+    out2 = ops.rms_norm_rows(t.to(DEV).requires_grad_(True).flatten(-2), gm, eps, rep=3)
+    (out2.view_as(tm) * w.to(DEV)).sum().backward()
+    assert gm.grad is None
+    assert float(((gm._eqh_gbuf - 0.5).cpu().double() - gd.grad).abs().max() / gd.grad.abs().max()) < 2e-5
+    del gm._eqh_gbuf
+
+
 def test_shared_input_nodes_match_float64_reference():
     """ops.linear2 (two bias-free Linears of one input) and ops.egnn_feats (GEMM + LayerNorm + residual alias of
     one input): outputs and every gradient against float64 autograd of the separate ops."""

@@ -46,6 +46,11 @@ elif [ "$1" = 3 ]; then
     rm -rf /tmp/prof_$1
     timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python3 bench.py --method $1 --batch $2 --flavour $3 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-pipeline --c4-steps 0 > $O/${R}_bench_$1_$2_under_rocprof.json 2>> $O/rocprof.err || exit 1
     cp "$(find /tmp/prof_$1 -name '*kernel_stats.csv' | head -1)" $O/${R}_kernel_stats_$1_$2.csv
+    # kernel order of one replayed step (launch count, ATen share)
+    rm -rf /tmp/order_$1
+    timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/order_$1 -- python3 bench.py --method $1 --batch $2 --flavour $3 --steps 6 --warmup 3 --blocks 1 --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --c4-steps 0 > /dev/null 2>> $O/rocprof.err || exit 1
+    python3 tools/step_order.py /tmp/order_$1 $O/${R}_step_order_$1_$2.txt
+    tail -1 $O/${R}_step_order_$1_$2.txt
   done
 elif [ "$1" = pmc ]; then
   # HBM traffic of the scatter kernels: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (MI355X_MICROARCH.md), over the
