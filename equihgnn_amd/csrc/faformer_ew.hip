@@ -178,6 +178,26 @@ k_drop_mean_bwd_f8c256(const float* __restrict__ dout, int64_t R, const int64_t*
     }
 }
 
+// out = res + dropout_p(x) (res may be NULL) and its backward dx = dout * keep: the residual connections behind FAFormer's
+// MLPs (fa_former_layer.py:289 with :508, :606) -- torch runs them as a dropout kernel (which also writes a mask tensor)
+// and an add; elements are float4 groups, the keep decision is the hash of the element index
+__global__ void __launch_bounds__(256)
+k_dropout_add(const float* __restrict__ x, const float* __restrict__ res, int64_t n4, const int64_t* __restrict__ seed_ptr,
+              uint32_t threshold, float inv_keep, float* __restrict__ out) {
+    const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v = reinterpret_cast<const float4*>(x)[i];
+        if (threshold) {
+            const uint64_t e = (uint64_t)i * 4;
+            v.x *= keep_scale(seed, e, threshold, inv_keep); v.y *= keep_scale(seed, e + 1, threshold, inv_keep);
+            v.z *= keep_scale(seed, e + 2, threshold, inv_keep); v.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+        }
+        if (res) f4_add(v, reinterpret_cast<const float4*>(res)[i]);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
 int ew_check(int64_t R, int32_t C, float p) {
     if (R < 0 || C <= 0 || !(p >= 0.f) || !(p < 1.f)) return EQH_ERR_ARG;
     if (C & 3) return EQH_ERR_ALIGN;
@@ -229,6 +249,18 @@ extern "C" int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_
     else
         hipLaunchKernelGGL(k_drop_mean_fwd<0>, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
                            (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int faf_dropout_add(const float* x, const float* res, int64_t n, float p, const int64_t* seed, float* out,
+                               void* stream_) {
+    if (n < 0 || (n & 3) || !(p >= 0.f) || !(p < 1.f)) return EQH_ERR_ARG;
+    if (n == 0) return EQH_OK;
+    if (!x || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
+    if (!eqh_aligned16(x) || !eqh_aligned16(res) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
+    hipLaunchKernelGGL(k_dropout_add, dim3(eqh_grid_for(n / 4, 256, 8192)), dim3(256), 0, static_cast<hipStream_t>(stream_), x,
+                       res, n / 4, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -412,14 +444,14 @@ struct FhLane {          // per-lane constants: W3 rows of the four channels, ga
     float wa0[3], wa1[3], wb0[3], wb1[3];
     float g0, g1, be0, be1;
 };
-__device__ __forceinline__ FhLane fh_load(const float* __restrict__ w3, const float* __restrict__ gamma,
+__device__ __forceinline__ FhLane fh_load(const float* __restrict__ w3, int w_ld, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, int lane) {
     FhLane L;
     const int ca = 2 * lane, cb = 128 + 2 * lane;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-        L.wa0[d] = w3[ca * 3 + d]; L.wa1[d] = w3[(ca + 1) * 3 + d];
-        L.wb0[d] = w3[cb * 3 + d]; L.wb1[d] = w3[(cb + 1) * 3 + d];
+        L.wa0[d] = w3[ca * w_ld + d]; L.wa1[d] = w3[(ca + 1) * w_ld + d];
+        L.wb0[d] = w3[cb * w_ld + d]; L.wb1[d] = w3[(cb + 1) * w_ld + d];
     }
     L.g0 = gamma[2 * lane]; L.g1 = gamma[2 * lane + 1];
     L.be0 = beta ? beta[2 * lane] : 0.f; L.be1 = beta ? beta[2 * lane + 1] : 0.f;
@@ -433,14 +465,15 @@ k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, co
                    const float* __restrict__ extra, const float* __restrict__ wx,
                    const float* __restrict__ gamma, const float* __restrict__ beta, int64_t E,
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
-                   float* __restrict__ out) {
+                   float* __restrict__ out, int w_ld) {
     const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const FhLane L = fh_load(w3, gamma, beta, lane);
+    const FhLane L = fh_load(w3, w_ld, gamma, beta, lane);
     float2 wxa = make_float2(0.f, 0.f), wxb = make_float2(0.f, 0.f);
-    if (wx) {
-        wxa = *reinterpret_cast<const float2*>(wx + 2 * lane);
-        wxb = *reinterpret_cast<const float2*>(wx + 128 + 2 * lane);
+    if (wx) {      // (w_ld = 4: w3 and wx are columns 0-2 and 3 of one [256, 4] matrix, wx = w3 + 3)
+        const int ws = w_ld == 4 ? 4 : 1;
+        wxa = make_float2(wx[(2 * lane) * ws], wx[(2 * lane + 1) * ws]);
+        wxb = make_float2(wx[(128 + 2 * lane) * ws], wx[(128 + 2 * lane + 1) * ws]);
     }
     for (int64_t e = (int64_t)blockIdx.x * FP_WAVES + wave; e < E; e += (int64_t)gridDim.x * FP_WAVES) {
         const float y0 = y[e * 3], y1 = y[e * 3 + 1], y2 = y[e * 3 + 2];
@@ -491,17 +524,19 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
                    const float* __restrict__ extra, const float* __restrict__ wx,
                    const float* __restrict__ gamma, const float* __restrict__ dhn, int64_t E,
                    const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float eps,
-                   float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ dextra, float* __restrict__ slab) {
+                   float* __restrict__ dy, float* __restrict__ dbase, float* __restrict__ dextra, float* __restrict__ slab, int w_ld) {
     __shared__ float s_red[FP_WAVES][VEC ? 24 : 16][64];
     const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const FhLane L = fh_load(w3, gamma, nullptr, lane);
+    const FhLane L = fh_load(w3, w_ld, gamma, nullptr, lane);
     float aw[4][3];              // d W3 of channels (a0, a1, b0, b1) x d
     float ag0 = 0.f, ag1 = 0.f, ab0 = 0.f, ab1 = 0.f;   // d gamma, d beta of the two hidden units
     float adb[4] = {0.f, 0.f, 0.f, 0.f}, adx[4] = {0.f, 0.f, 0.f, 0.f};   // VEC: d bias, d wx of the four channels
     float wxv[4] = {0.f, 0.f, 0.f, 0.f};
     if (VEC) {
-        wxv[0] = wx[2 * lane]; wxv[1] = wx[2 * lane + 1]; wxv[2] = wx[128 + 2 * lane]; wxv[3] = wx[128 + 2 * lane + 1];
+        const int ws = w_ld == 4 ? 4 : 1;
+        wxv[0] = wx[(2 * lane) * ws]; wxv[1] = wx[(2 * lane + 1) * ws];
+        wxv[2] = wx[(128 + 2 * lane) * ws]; wxv[3] = wx[(128 + 2 * lane + 1) * ws];
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) aw[c][0] = aw[c][1] = aw[c][2] = 0.f;
@@ -654,20 +689,22 @@ extern "C" int faf_frame_pre_bwd(const float* y, const float* w3, const float* d
 }
 
 /* frame_pre + SwiGLU + dropout + LayerNorm in one launch each way (see k_frame_hidden_fwd): hn [E, 8, 128] from y [E, 3],
-   w3 [256, 3], base ([E, 256] with base_ld = 256, or one row with base_ld = 0), gamma / beta [128].  bwd: dy [E, 3],
-   dbase [E, 256] (per row, also for a broadcast base), dw3 [256, 3], dgamma, dbeta [128] (overwritten or accumulated). */
+   w3 [256, 3] (w_ld = 3) or, with w_ld = 4, columns 0-2 of fc1.weight [256, 4] read in place (wx = w3 + 3 is then its
+   column 3), base ([E, 256] with base_ld = 256, or one row with base_ld = 0), gamma / beta [128].  bwd: dy [E, 3],
+   dbase [E, 256] (per row, also for a broadcast base), dw3 [256, 3] (packed in either case), dgamma, dbeta [128]
+   (overwritten or accumulated). */
 extern "C" int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
                                     const float* wx, const float* gamma, const float* beta, int64_t E, float p,
-                                    const int64_t* seed, float eps, float* out, void* stream_) {
+                                    const int64_t* seed, float eps, float* out, int32_t w_ld, void* stream_) {
     if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256) || (wx && base_ld != 0) || (extra && !wx))
         return EQH_ERR_ARG;
+    if ((w_ld != 3 && w_ld != 4) || (w_ld == 4 && wx && wx != w3 + 3)) return EQH_ERR_ARG;
     if (E == 0) return EQH_OK;
     if (!y || !w3 || !base || !gamma || !beta || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
-    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7) || (reinterpret_cast<uintptr_t>(wx) & 7))
-        return EQH_ERR_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_frame_hidden_fwd, dim3(eqh_grid_for(E, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, y, w3, base,
-                       base_ld, extra, wx, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
+                       base_ld, extra, wx, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out, (int)w_ld);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -682,9 +719,10 @@ extern "C" size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E) {
 extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
                                     const float* wx, const float* gamma, const float* dhn, int64_t E, float p,
                                     const int64_t* seed, float eps, float* dy, float* dbase, float* dwx, float* dextra,
-                                    float* dw3, float* dgamma, float* dbeta, int32_t accumulate, void* workspace,
+                                    float* dw3, float* dgamma, float* dbeta, int32_t accumulate, int32_t w_ld, void* workspace,
                                     size_t workspace_bytes, void* stream_) {
     if (E < 0 || !(p >= 0.f) || !(p < 1.f) || (base_ld != 0 && base_ld != 256) || !dw3 || !dgamma || !dbeta) return EQH_ERR_ARG;
+    if ((w_ld != 3 && w_ld != 4) || (w_ld == 4 && wx && wx != w3 + 3)) return EQH_ERR_ARG;
     if ((wx && (base_ld != 0 || !dwx || !dbase)) || (extra && (!wx || !dextra))) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (E == 0) {
@@ -702,12 +740,12 @@ extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float
     float* slab = static_cast<float*>(workspace);
     if (!wx) {
         hipLaunchKernelGGL(k_frame_hidden_bwd<false>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx,
-                           gamma, dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab);
+                           gamma, dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab, (int)w_ld);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
     }
     hipLaunchKernelGGL(k_frame_hidden_bwd<true>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx, gamma,
-                       dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab);
+                       dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab, (int)w_ld);
     EQH_CHECK_LAUNCH();
     int rc = eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
     if (rc) return rc;

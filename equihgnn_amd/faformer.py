@@ -77,8 +77,14 @@ class SwiGLUMLP(nn.Module):
             return ops.linear(x, self.fc1.weight, self.fc1.bias)
         return self.fc1(x)
 
-    def forward(self, x):
-        return F.dropout(self._fc2(self.hidden(self._fc1(x))), self.p, self.training)
+    def forward(self, x, res=None):
+        """``res``: the tensor the caller adds the result to (a residual connection); folded into the dropout pass."""
+        y = self._fc2(self.hidden(self._fc1(x)))
+        p = self.p if self.training else 0.0
+        if p > 0 and ops.dropout_add_supported(y, res):
+            return ops.dropout_add(y, res, p)
+        y = F.dropout(y, self.p, self.training)
+        return y if res is None else y + res
 
     def frame_mean(self, y, extra=None):
         """mean over the 8 sign frames of MLP(cat(y ⊙ s, extra)); y [..., 3], extra [..., E]."""
@@ -87,8 +93,12 @@ class SwiGLUMLP(nn.Module):
         if fused and (extra is None or extra.shape[-1] == 1):
             # first Linear over the sign frames (the squared distance's K = 1 column included) + SwiGLU + dropout + LayerNorm
             # in one launch each way (csrc/faformer_ew.hip)
-            h = ops.frame_hidden(y, w[:, :3], self.fc1.bias, self.norm.weight, self.norm.bias, self.norm.eps,
-                                 self.p if self.training else 0.0, None, extra, None if extra is None else w[:, 3])
+            if extra is not None and w.shape[1] == 4:      # the whole [256, 4] weight, read in place (column 3 multiplies extra)
+                h = ops.frame_hidden(y, w, self.fc1.bias, self.norm.weight, self.norm.bias, self.norm.eps,
+                                     self.p if self.training else 0.0, None, extra, None)
+            else:
+                h = ops.frame_hidden(y, w[:, :3], self.fc1.bias, self.norm.weight, self.norm.bias, self.norm.eps,
+                                     self.p if self.training else 0.0, None, extra, None if extra is None else w[:, 3])
             pre = base = None
         elif extra is None:
             base = self.fc1.bias
@@ -334,7 +344,7 @@ class MLPAttnEdgeAggregation(nn.Module):
             v_n = g.gather(v) if v_n is None else v_n
             ctx = torch.einsum("nhm,nmhd->nhd", attn, v_n.reshape(n, k, h, self.dh)).reshape(n, -1)
             ectx = torch.einsum("nhm,nmhd->nhd", attn, ve.reshape(n, k, h, self.deh)).reshape(n, -1)
-        out = self.W_output(torch.cat((ctx, ectx), -1)) + tok
+        out = self.W_output(torch.cat((ctx, ectx), -1), res=tok)
         # geometric context: with the reference's frame-0 gather (module docstring) the signed frame
         # average cancels and what is left is the centroid of the cloud, for every atom
         if ops.geom_supported(geo):
@@ -369,7 +379,7 @@ class FAFFN(nn.Module):
         else:
             y = _frame_axes(geo.unsqueeze(0), None if row_mask is None else row_mask.view(1, -1))[0][0]
         gfeat = self.W_frame.frame_mean(y)                                  # [N,C]
-        return self.ffn(torch.cat((_layer_norm(self.ln, tok), gfeat), -1))
+        return self.ffn(torch.cat((_layer_norm(self.ln, tok), gfeat), -1), res=tok)     # tok + ffn(...), :606
 
 
 class FAFormerEncoderLayer(nn.Module):
@@ -383,7 +393,7 @@ class FAFormerEncoderLayer(nn.Module):
         tok, geo, edge = self.self_attn(tok, geo, edge, g, row_mask, edge_passthrough=not last)
         if not last:
             edge = self.edge_module(tok, geo, g, res=edge)                  # edge + edge_module(...), :602-604
-        return tok + self.ffn(tok, geo, row_mask), geo, edge                # :606
+        return self.ffn(tok, geo, row_mask), geo, edge                      # tok + ffn(...) (:606): the residual is added in FAFFN
 
 
 class FAFormer(nn.Module):
@@ -401,7 +411,11 @@ class FAFormer(nn.Module):
         statistics -- the centroid in the attention and the frame of the FFN -- then skip the padding)."""
         # (one generator launch for the seeds of all dropout sites of the pass, ops.dropout_seeds)
         with ops.dropout_seeds(feats.device, 64, enabled=self.training and feats.is_cuda):
-            tok = F.dropout(self.input_transform(feats), self.p, self.training)
+            tok = self.input_transform(feats)
+            if self.training and self.p > 0 and ops.dropout_add_supported(tok, None):
+                tok = ops.dropout_add(tok, None, self.p)
+            else:
+                tok = F.dropout(tok, self.p, self.training)
             g = EdgeGraph(coords, index, self.k, self.radius)
             edge = self.edge_module(tok, coords, g)
             geo = coords

@@ -134,6 +134,7 @@ SIGNATURES = {
                                           c_void_p]),
     "faf_attn_gather_sum_bwd": (c_int32, [c_void_p, c_void_p, c_int64] + [c_void_p] * 4 + [c_int64, c_int64, c_int32, c_int32,
                                                                                          c_int32, c_void_p, c_void_p, c_void_p]),
+    "faf_dropout_add": (c_int32, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_ln_rowdot_fwd": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_ln_rowdot_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "faf_ln_rowdot_bwd": (c_int32, [c_void_p] * 5 + [c_int64, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float]
@@ -148,10 +149,10 @@ SIGNATURES = {
     "faf_frame_pre_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_size_t, c_void_p]),
     "faf_frame_hidden_fwd": (c_int32, [c_void_p] * 3 + [c_int64] + [c_void_p] * 4 + [c_int64, c_float, c_void_p, c_float,
-                                                                                   c_void_p, c_void_p]),
+                                                                                   c_void_p, c_int32, c_void_p]),
     "faf_frame_hidden_bwd_workspace_bytes": (c_size_t, [c_int64]),
     "faf_frame_hidden_bwd": (c_int32, [c_void_p] * 3 + [c_int64] + [c_void_p] * 4 + [c_int64, c_float, c_void_p, c_float]
-                             + [c_void_p] * 7 + [c_int32, c_void_p, c_size_t, c_void_p]),
+                             + [c_void_p] * 7 + [c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "faf_rowdot_fwd": (c_int32, [c_void_p] * 3 + [c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "faf_rowdot_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "faf_rowdot_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_size_t,

@@ -78,6 +78,7 @@ from .frames import (  # noqa: F401
     _CentreMix, centre_mix, _CloudFrame, cloud_frame, _EdgeFrame, edge_frame, edge_frame_supported, _AttnLogits,
     attn_logits, attn_logits_supported, geom_supported, dropout_seeds, _AttnGatherSum, attn_gather_sum,
     attn_gather_sum_supported, _EdgeLogitWeights, edge_logit_weights, _LnRowDot, ln_rowdot, ln_rowdot_supported,
+    _DropoutAdd, dropout_add, dropout_add_supported,
 )
 
 # switches that tests / tools / bench.py set as ``ops.NAME = value``: owner module of each

@@ -231,24 +231,34 @@ class _FrameHidden(torch.autograd.Function):
     """LayerNorm(dropout_p(SiLU(a) * b)) of [a | b] = w3 (y * s_f) + base over the 8 sign frames: frame_pre, swiglu_dropout
     and the row LayerNorm in one launch each way (faf_frame_hidden_*); the [.., 8, 256] pre-activations never exist.
     ``base``: rows [..., 256], or (vector form) fc1's bias [256] with the optional K = 1 Linear extra [..., 1] * wx [256]
-    evaluated inside the kernel."""
+    evaluated inside the kernel.  ``w3`` may be the whole fc1.weight [256, 4] (then ``wx`` must be None: column 3 IS wx):
+    the kernels read it in place and the gradient comes back as one [256, 4] tensor -- no column copies forward, no
+    zero-fill / copy / add of two column gradients backward."""
 
     @staticmethod
     def forward(ctx, y, w3, base, extra, wx, gamma, beta, eps, p, seed, acc_params):
         _require_gpu(y, "frame_hidden")
         lead = y.shape[:-1]
         y2, w3c, gamma, beta = _f32c(y).reshape(-1, 3), _f32c(w3), _f32c(gamma), _f32c(beta)
-        if w3c.shape[0] != 256 or gamma.numel() != 128:
+        if w3c.shape[0] != 256 or gamma.numel() != 128 or w3c.shape[1] not in (3, 4):
             raise ValueError("frame_hidden: fc1 with 256 outputs expected")
+        w_ld = w3c.shape[1]
         E = y2.shape[0]
         vec = base.dim() == 1
         if vec:
             base2, ld = _f32c(base), 0
-            wxc = _f32c(wx) if wx is not None else torch.zeros(256, dtype=torch.float32, device=y.device)
+            if w_ld == 4:
+                if wx is not None:
+                    raise ValueError("frame_hidden: with the whole [256, 4] weight, column 3 is wx")
+                wxc = w3c.view(-1)[3:]                      # (a view of the same storage: w3 + 3)
+            else:
+                wxc = _f32c(wx) if wx is not None else torch.zeros(256, dtype=torch.float32, device=y.device)
             ex = _f32c(extra).reshape(-1) if extra is not None else None
             if ex is not None and ex.shape[0] != E:
                 raise ValueError("frame_hidden: one extra value per point expected")
         else:
+            if w_ld == 4:
+                raise ValueError("frame_hidden: the whole [256, 4] weight goes with the vector form of base")
             base2, ld, wxc, ex = _f32c(base).reshape(-1, 256), 256, None, None
             if base2.shape[0] != E:
                 raise ValueError("frame_hidden: one base row per point expected")
@@ -257,18 +267,18 @@ class _FrameHidden(torch.autograd.Function):
         # algorithmic bytes: 12 B of coordinates (+ a [256] base row when it is per point) in, [8, 128] out
         timed("k_frame_hidden_fwd", E * (12 + (0 if ld == 0 else 1024) + 4096),
               lambda: hip.check(hip.lib().faf_frame_hidden_fwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
-                                                               _ptr(beta), E, float(p), _ptr(seed), float(eps), _ptr(out),
+                                                               _ptr(beta), E, float(p), _ptr(seed), float(eps), _ptr(out), w_ld,
                                                                _stream(y.device)), "faf_frame_hidden_fwd"))
         ctx.save_for_backward(y2, w3c, base2, gamma, ex, wxc)
         ctx.meta = (lead, ld, float(eps), float(p), seed, tuple(base.shape), None if extra is None else tuple(extra.shape),
-                    wx is not None)
+                    wx is not None, w_ld)
         ctx.acc = acc_params
         return out.view(*lead, 8, 128)
 
     @staticmethod
     def backward(ctx, dhn):
         y2, w3c, base2, gamma, ex, wxc = ctx.saved_tensors
-        lead, ld, eps, p, seed, base_shape, extra_shape, has_wx = ctx.meta
+        lead, ld, eps, p, seed, base_shape, extra_shape, has_wx, w_ld = ctx.meta
         E = y2.shape[0]
         dev = y2.device
         vec = wxc is not None
@@ -277,7 +287,7 @@ class _FrameHidden(torch.autograd.Function):
         dbase = torch.empty((256,) if vec else (E, 256), dtype=torch.float32, device=dev)
         dwx = torch.empty(256, dtype=torch.float32, device=dev) if vec else None
         dex = torch.empty(E, dtype=torch.float32, device=dev) if ex is not None else None
-        dw3 = torch.empty_like(w3c)
+        dw3 = torch.empty((256, 3), dtype=torch.float32, device=dev)
         L = hip.lib()
         ws_bytes = L.faf_frame_hidden_bwd_workspace_bytes(E)
         ws = _workspace(max(ws_bytes, 16), dev)
@@ -286,11 +296,13 @@ class _FrameHidden(torch.autograd.Function):
         timed("k_frame_hidden_bwd", E * (12 + (0 if ld == 0 else 2048) + 4096),     # d hidden in, (d base out)
               lambda: hip.check(L.faf_frame_hidden_bwd(_ptr(y2), _ptr(w3c), _ptr(base2), ld, _ptr(ex), _ptr(wxc), _ptr(gamma),
                                                        _ptr(dhn), E, p, _ptr(seed), eps, _ptr(dy), _ptr(dbase), _ptr(dwx),
-                                                       _ptr(dex), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, _ptr(ws),
+                                                       _ptr(dex), _ptr(dw3), _ptr(small[0]), _ptr(small[1]), 0, w_ld, _ptr(ws),
                                                        ws_bytes, _stream(dev)), "faf_frame_hidden_bwd"))
         dgam, dbet = _hand_out(list(small), tg)
         if not vec:
             dbase = dbase.view(base_shape)
+        if w_ld == 4:
+            dw3, dwx = torch.cat((dw3, dwx[:, None]), 1), None
         return (dy.view(*lead, 3), dw3, dbase, None if dex is None else dex.view(extra_shape), dwx if has_wx else None,
                 dgam, dbet, None, None, None, None)
 
@@ -869,3 +881,37 @@ def ln_rowdot(x, gamma, beta, U, cb=None, eps: float = 1e-5):
     _LnRowDot."""
     _note_acc(gamma, beta)
     return _LnRowDot.apply(x, gamma, beta, U, cb, eps, (gamma, beta))
+
+
+class _DropoutAdd(torch.autograd.Function):
+    """res + dropout_p(x) in one pass (faf_dropout_add; no mask tensor: the backward recomputes the keep decisions)."""
+
+    @staticmethod
+    def forward(ctx, x, res, p, seed):
+        _require_gpu(x, "dropout_add")
+        x2 = _f32c(x)
+        r2 = _f32c(res) if res is not None else None
+        seed = seed if (seed is not None and p > 0) else _dropout_seed(x.device, p)
+        out = torch.empty_like(x2)
+        hip.check(hip.lib().faf_dropout_add(_ptr(x2), _ptr(r2), x2.numel(), float(p), _ptr(seed), _ptr(out), _stream(x.device)),
+                  "faf_dropout_add")
+        ctx.p, ctx.seed, ctx.has_res = float(p), seed, res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _f32c(dout)
+        dx = torch.empty_like(dout)
+        hip.check(hip.lib().faf_dropout_add(_ptr(dout), None, dout.numel(), ctx.p, _ptr(ctx.seed), _ptr(dx), _stream(dout.device)),
+                  "faf_dropout_add")
+        return dx, (dout if ctx.has_res else None), None, None
+
+
+def dropout_add_supported(x, res) -> bool:
+    return (USE_GEOM and x.is_cuda and x.dtype == torch.float32 and x.numel() % 4 == 0
+            and (res is None or (res.shape == x.shape and res.dtype == torch.float32)))
+
+
+def dropout_add(x, res=None, p: float = 0.0, seed=None):
+    """res + dropout_p(x) (res optional); fp32, numel % 4 == 0."""
+    return _DropoutAdd.apply(x, res, p, seed)

@@ -526,6 +526,10 @@ int faf_edge_frame_bwd(const float* geo, const float* gj, const uint8_t* mask, c
                        const float* dd2, int64_t N, int32_t K, float* dgeo, float* dgj, void* stream);
 int faf_attn_logits_fwd(const float* qa, const float* qan, const float* le, const uint8_t* mask, int64_t N, int32_t K,
                         int32_t H, float p, const int64_t* seed, float* prob, float* attn, void* stream);
+/* out = res + dropout_p(x) over n floats (n % 4 == 0; res may be NULL): the residual behind FAFormer's MLPs
+ * (fa_former_layer.py:289 with :508 and :606); keep decisions = the hash of (seed, element index) (drop_hash.h).  Its
+ * backward for x is the same call on dout with res = NULL. */
+int faf_dropout_add(const float* x, const float* res, int64_t n, float p, const int64_t* seed, float* out, void* stream);
 /* LayerNorm over dense rows with J <= 2 row-wise dot products of its output riding along (csrc/ln_rowdot.hip) --
  * fa_former_layer.py:436-441 (the LayerNorm in front of the edge Linear) with :483-489 (the per-head edge logits, linear
  * in the normalised edge features):  out = LayerNorm(x) [R, C],  le[r, j] = out[r, :] . U[j, :] + cb[j]  (cb may be NULL).
@@ -670,17 +674,20 @@ int faf_frame_pre_bwd(const float* y, const float* w3, const float* dpre, int64_
  *   hn[e, f, :] = LayerNorm( dropout_p( SiLU(a_f) * b_f ) ),  [a_f | b_f] = w3 (y_e * s_f) + base_e,  256 -> 128 channels
  * = faf_frame_pre_fwd + faf_swiglu_dropout_fwd + hg_layer_norm_fwd without the [E * 8, 256] and [E * 8, 128]
  * intermediates (same dropout hash over the [E * 8, 128] tensor as faf_swiglu_dropout_*).  base: [E, 256] (base_ld 256)
- * or one row broadcast (base_ld 0).  bwd: dy [E, 3], dbase [E, 256], dw3 [256, 3], dgamma / dbeta [128]. */
+ * or one row broadcast (base_ld 0).  w_ld = 3: w3 [256, 3] packed (and wx [256] packed); w_ld = 4: w3 is fc1.weight
+ * [256, 4] read in place (columns 0-2) and wx, when given, must be w3 + 3 (its column 3).  bwd: dy [E, 3], dbase [E, 256],
+ * dw3 [256, 3] and dwx [256] (packed in either case), dgamma / dbeta [128]. */
 int faf_frame_hidden_fwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
                          const float* wx, const float* gamma, const float* beta, int64_t E, float p, const int64_t* seed,
-                         float eps, float* out, void* stream);
+                         float eps, float* out, int32_t w_ld, void* stream);
 size_t faf_frame_hidden_bwd_workspace_bytes(int64_t E);
 /* vector form (wx != NULL; base = fc1's bias vector, base_ld 0; the point's row is bias + extra[e] * wx, extra may be
  * NULL): dbase receives d bias [256], dwx d wx [256], dextra [E] the gradient of extra; row form: dbase [E, 256]. */
 int faf_frame_hidden_bwd(const float* y, const float* w3, const float* base, int64_t base_ld, const float* extra,
                          const float* wx, const float* gamma, const float* dhn, int64_t E, float p, const int64_t* seed,
                          float eps, float* dy, float* dbase, float* dwx, float* dextra, float* dw3, float* dgamma,
-                         float* dbeta, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                         float* dbeta, int32_t accumulate, int32_t w_ld, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* Row-wise dot products -- nn.Linear(C, J) with J <= 4 outputs on edge rows (fa_former_layer.py:340-400 att_mlp,
  * :483-489 the per-head edge logits): y [R, J] = x [R, C] . U [J, C]^T + bias [J] (may be NULL), a wavefront per row.

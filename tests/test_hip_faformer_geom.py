@@ -307,3 +307,31 @@ def test_ln_rowdot_matches_float64(R, C, J, alias):
         assert _rel(a.grad, r.grad) < 3e-5, (name, _rel(a.grad, r.grad))
     # the LayerNorm itself is the row kernels' (bitwise)
     assert torch.equal(xe.detach(), ops.layer_norm_rows(d[0].detach(), d[1].detach(), d[2].detach(), 1e-5))
+
+
+@pytest.mark.parametrize("shape,with_res", [((4,), False), ((777, 256), True), ((15744, 256), True), ((300, 64), False)])
+def test_dropout_add_is_a_consistent_dropout(shape, with_res):
+    """faf_dropout_add: out = res + x * keep with keep in {0, 1 / (1 - p)} from the hash of (seed, element); the backward
+    applies the SAME keep pattern to dout and passes dout through to res; p = 0 is exactly res + x."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.rand(*shape, generator=g) * 2 + 1).to(DEV)         # (in [1, 3]: the keep pattern is read off the output)
+    res = torch.randn(*shape, generator=g).to(DEV) if with_res else None
+    w = torch.randn(*shape, generator=g).to(DEV)
+    seed = torch.tensor([424242], dtype=torch.int64, device=DEV)
+    p = 0.2
+    xa = x.clone().requires_grad_(True)
+    ra = res.clone().requires_grad_(True) if with_res else None
+    assert ops.dropout_add_supported(xa, ra)
+    out = ops.dropout_add(xa, ra, p, seed)
+    (out * w).sum().backward()
+    keep = ((out.detach() - (res if with_res else 0.0)) / x)
+    k0, k1 = keep.abs() < 1e-6, (keep - 1.0 / (1.0 - p)).abs() < 1e-4
+    assert bool((k0 | k1).all())
+    if x.numel() > 10000:
+        assert abs(float(k0.float().mean()) - p) < 0.01
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), (w * torch.where(k0, 0.0, 1.0 / (1.0 - p))).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    if with_res:
+        assert torch.equal(ra.grad, w)
+    assert torch.equal(out.detach(), ops.dropout_add(x, res, p, seed))
+    assert torch.equal(ops.dropout_add(x, res, 0.0), x + res if with_res else x)

@@ -1154,6 +1154,14 @@ def test_frame_hidden_matches_the_three_kernel_composition(E, p, bcast):
         for name, a, b in zip(("dy", "dw3", "dbias", "dgamma", "dbeta", "dextra", "dwx"), d, u):
             err = float((a.grad - b.grad).abs().max() / b.grad.abs().max().clamp(min=1e-9))
             assert err < 5e-5, (name, err)
+        # the whole fc1.weight [256, 4] read in place (column 3 = wx): bitwise the same output, the gradient as one tensor
+        W4 = torch.cat((w3, wx[:, None]), 1).to(DEV).requires_grad_(True)
+        e = [t.to(DEV).requires_grad_(True) for t in (y, base, gamma, beta, extra)]
+        out4 = ops.frame_hidden(e[0], W4, e[1], e[2], e[3], 1e-5, p, seed, e[4], None)
+        (out4 * wgt.to(DEV)).sum().backward()
+        assert torch.equal(out4.detach(), out.detach())
+        assert torch.equal(W4.grad[:, :3], d[1].grad) and torch.equal(W4.grad[:, 3], d[6].grad)
+        assert torch.equal(e[0].grad, d[0].grad) and torch.equal(e[4].grad, d[5].grad)
         return
 
     def run(fused):
