@@ -210,7 +210,7 @@ class _EgnnNodeMlp(torch.autograd.Function):
             hip.HG_EGNN_NODE_F, N, C, dev, in0=normed, in1=m_i, in2=res, w0=imgs[0], w1=imgs[1], w2=imgs[2], b0=b0, bias_out=b3,
             out0=node_in, out1=hpre, out2=hid, out3=out))
         if need_grad:
-            ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid)
+            ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid, m_i)
             ctx.imgs = imgs[3:]
         return out
 
@@ -218,7 +218,7 @@ class _EgnnNodeMlp(torch.autograd.Function):
     def backward(ctx, dout):
         from .panel import conv_panel
         from .grads import _linear_weight_grad
-        w0, b0, w3, b3, node_in, hpre, hid = ctx.saved_tensors
+        w0, b0, w3, b3, node_in, hpre, hid, m_i = ctx.saved_tensors
         N, C = hid.shape[0], hid.shape[1] // 2
         dev = dout.device
         dout, ld = _rows_ld(dout)
@@ -240,7 +240,7 @@ class _EgnnNodeMlp(torch.autograd.Function):
             if ctx.needs_input_grad[3]:
                 for r0 in (0, C):
                     _linear_weight_grad(w0, 0, C, dpre[:, r0:r0 + C], node_in[:, :C], r0, r0 + C)
-                _linear_weight_grad(w0, C, C + 16, dpre, node_in[:, C:].contiguous())
+                _linear_weight_grad(w0, C, C + 16, dpre, m_i)      # (= node_in[:, C:], already contiguous: no copy launch)
         else:
             dw3 = _linear_weight_grad(w3, None, None, dout_c, hid) if ctx.needs_input_grad[5] else None
             dw0 = _linear_weight_grad(w0, None, None, dpre, node_in) if ctx.needs_input_grad[3] else None
