@@ -397,9 +397,10 @@ __global__ void k_index_aux(const int64_t* __restrict__ vertex, const int64_t* _
                             int* __restrict__ v32, int* __restrict__ e32, int* __restrict__ batch32,
                             float* __restrict__ has_v, float* __restrict__ has_e,
                             const int* __restrict__ col_v, const int* __restrict__ col_e, float* __restrict__ ew_v,
-                            float* __restrict__ ew_e) {
+                            float* __restrict__ ew_e, int* __restrict__ zero_buf, int64_t zero_n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t i = t0; i < zero_n; i += stride) zero_buf[i] = 0;     // (the counters a later geo_knn_counted adds into)
     // per-entry mean weights of the two CSRs with respect to each other's rows (the backward of a gathered mean reads
     // w[q] next to col[q] instead of chasing col[q] -> rowptr): entry q of the node CSR lists hyperedge col_v[q]
     if (ew_v) {
@@ -463,10 +464,12 @@ extern "C" size_t hg_csr_build_workspace_bytes(int64_t nnz, int64_t n_rows) {
     return carve(nullptr, nnz, n_rows).bytes;
 }
 
+// ``counted``: [n_rows + 2] ints holding the histogram of the keys (entries n_rows and n_rows + 1 zero) -- the clear and
+// histogram launches are then skipped (the producer of the keys counted them, see geo_knn_counted); the array is consumed
 template <typename KeyT>
 static int csr_build_impl(const KeyT* key, const int64_t* other, int64_t nnz, int64_t n_rows,
                             int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col,
-                            void* workspace, size_t workspace_bytes, void* stream_) {
+                            void* workspace, size_t workspace_bytes, void* stream_, int32_t* counted = nullptr) {
     if (nnz < 0 || n_rows < 0 || !rowptr || !workspace) return EQH_ERR_ARG;
     if (nnz > 0 && (!key || !perm)) return EQH_ERR_ARG;
     if (!other && col && col_div < 1) return EQH_ERR_ARG;
@@ -477,13 +480,18 @@ static int csr_build_impl(const KeyT* key, const int64_t* other, int64_t nnz, in
 
     const int64_t n_items = n_rows + 1;
     const int n_blocks = (int)((n_items + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_clear, dim3(eqh_grid_for(n_items, 256, 1024)), dim3(256), 0, stream, w.cnt, n_items,
-                       w.long_count);
-    EQH_CHECK_LAUNCH();
     const int g_nnz = eqh_grid_for(nnz, 256, 2048);
-    if (nnz > 0) {
-        hipLaunchKernelGGL(k_hist<KeyT>, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
+    if (counted) {
+        w.cnt = counted;
+        w.long_count = counted + n_items;
+    } else {
+        hipLaunchKernelGGL(k_clear, dim3(eqh_grid_for(n_items, 256, 1024)), dim3(256), 0, stream, w.cnt, n_items,
+                           w.long_count);
         EQH_CHECK_LAUNCH();
+        if (nnz > 0) {
+            hipLaunchKernelGGL(k_hist<KeyT>, dim3(g_nnz), dim3(256), 0, stream, key, nnz, n_rows, w.cnt);
+            EQH_CHECK_LAUNCH();
+        }
     }
     if (n_items <= 65536) {
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, stream, w.cnt, (int)n_items, rowptr);
@@ -523,6 +531,17 @@ extern "C" int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_
                                 void* workspace, size_t workspace_bytes, void* stream_) {
     return csr_build_impl<int32_t>(key, other, nnz, n_rows, col_div, rowptr, perm, col, workspace, workspace_bytes,
                                    stream_);
+}
+
+/* hg_csr_build_i32 for keys whose histogram exists already: counts [n_rows + 2] = occurrences of every key, then two
+ * zeros (zeroed before the producer of the keys counted into it: hg_index_aux's zero_buf, geo_knn_counted).  Two launches
+ * fewer; the array is consumed (it becomes the fill cursors). */
+extern "C" int hg_csr_build_i32_counted(const int32_t* key, const int64_t* other, int64_t nnz, int64_t n_rows,
+                                        int32_t col_div, int32_t* rowptr, int32_t* perm, int32_t* col, int32_t* counts,
+                                        void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!counts) return EQH_ERR_ARG;
+    return csr_build_impl<int32_t>(key, other, nnz, n_rows, col_div, rowptr, perm, col, workspace, workspace_bytes,
+                                   stream_, counts);
 }
 
 /* Several CSRs in three launches (see k_csr_front).  Problems whose row counters do not fit LDS, or with
@@ -597,17 +616,19 @@ extern "C" int hg_csr_build_batch(int32_t n, const int64_t* const* key, const in
 extern "C" int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
                             int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
                             int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e,
-                            const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, void* stream_) {
-    if (nnz < 0 || n_nodes < 0 || n_edges < 0) return EQH_ERR_ARG;
+                            const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, int32_t* zero_buf,
+                            int64_t zero_n, void* stream_) {
+    if (nnz < 0 || n_nodes < 0 || n_edges < 0 || zero_n < 0 || (zero_n > 0 && !zero_buf)) return EQH_ERR_ARG;
     if (nnz > 0 && (!vertex || !edges || !v32 || !e32)) return EQH_ERR_ARG;
     if (n_nodes > 0 && (!rowptr_v || !has_v || (batch32 && !batch))) return EQH_ERR_ARG;
     if (n_edges > 0 && (!rowptr_e || !has_e)) return EQH_ERR_ARG;
-    const int64_t most = nnz > n_nodes ? (nnz > n_edges ? nnz : n_edges) : (n_nodes > n_edges ? n_nodes : n_edges);
+    int64_t most = nnz > n_nodes ? (nnz > n_edges ? nnz : n_edges) : (n_nodes > n_edges ? n_nodes : n_edges);
+    if (zero_n > most) most = zero_n;
     if (most == 0) return EQH_OK;
     hipLaunchKernelGGL(k_index_aux, dim3(eqh_grid_for(most, 256, 1024)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                        vertex, edges, nnz, batch, n_nodes, n_edges, rowptr_v, rowptr_e, v32, e32, batch32, has_v, has_e,
                        (ew_v && col_v) ? col_v : nullptr, (ew_e && col_e) ? col_e : nullptr, col_v ? ew_v : nullptr,
-                       col_e ? ew_e : nullptr);
+                       col_e ? ew_e : nullptr, zero_buf, zero_n);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

@@ -30,7 +30,8 @@ namespace {
 // (more wavefronts in flight: 80 vs 127 us at 4.6 k atoms).
 template <int MODE, int QPW>
 __global__ void __launch_bounds__(256)
-k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float* __restrict__ dist) {
+k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float* __restrict__ dist,
+      int* __restrict__ counts) {
     // Candidates reach the wavefronts through LDS: the workgroup's four wavefronts (four query groups) walk the same
     // candidate stream, so each block of 256 candidates is fetched from memory once per workgroup, as one 12-byte
     // strided load per thread, instead of once per wavefront (those strided loads -- 36 cache-line accesses per
@@ -138,6 +139,9 @@ k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float*
                 if (i0 + t < N && lane < k) {
                     nbr[(int64_t)(i0 + t) * k + lane] = li[t];
                     dist[(int64_t)(i0 + t) * k + lane] = ld[t];
+                    // the histogram of the lists' entries = the row lengths of the TRANSPOSED neighbour graph, whose CSR
+                    // the callers build next (integer atomics: order-free)
+                    if (counts && li[t] >= 0) atomicAdd(&counts[li[t]], 1);
                 }
             }
         }
@@ -146,8 +150,8 @@ k_knn(const float* __restrict__ pos, int N, int k, int* __restrict__ nbr, float*
 
 }  // namespace
 
-extern "C" int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr,
-                       float* dist, void* stream_) {
+static int knn_launch(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist, int32_t* counts,
+                      void* stream_) {
     if (N < 0 || k < 1 || k > 64 || (mode != 0 && mode != 1)) return EQH_ERR_ARG;
     if (N == 0) return EQH_OK;
     if (!pos || !nbr || !dist) return EQH_ERR_ARG;
@@ -157,13 +161,26 @@ extern "C" int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int
     const bool big = N > 8192;
     const int grid = eqh_grid_for(big ? (N + 3) / 4 : N, 4, 256 * 8);
     if (mode == 0 && !big)
-        hipLaunchKernelGGL((k_knn<0, 1>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist);
+        hipLaunchKernelGGL((k_knn<0, 1>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist, counts);
     else if (mode == 0)
-        hipLaunchKernelGGL((k_knn<0, 4>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist);
+        hipLaunchKernelGGL((k_knn<0, 4>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist, counts);
     else if (!big)
-        hipLaunchKernelGGL((k_knn<1, 1>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist);
+        hipLaunchKernelGGL((k_knn<1, 1>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist, counts);
     else
-        hipLaunchKernelGGL((k_knn<1, 4>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist);
+        hipLaunchKernelGGL((k_knn<1, 4>), dim3(grid), dim3(256), 0, stream, pos, (int)N, (int)k, nbr, dist, counts);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
+}
+
+extern "C" int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr,
+                       float* dist, void* stream_) {
+    return knn_launch(pos, N, k, mode, nbr, dist, nullptr, stream_);
+}
+
+/* geo_knn that also counts how often every point is listed: counts[j] += 1 per list entry j (counts [N] zeroed by the
+   caller, e.g. by hg_index_aux): the row lengths hg_csr_build_i32_counted starts from. */
+extern "C" int geo_knn_counted(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist,
+                               int32_t* counts, void* stream_) {
+    if (N > 0 && !counts) return EQH_ERR_ARG;
+    return knn_launch(pos, N, k, mode, nbr, dist, counts, stream_);
 }

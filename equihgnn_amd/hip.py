@@ -77,6 +77,9 @@ SIGNATURES = {
     "hg_embed_sum_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_int64, c_void_p, c_int32,
                                    c_void_p, c_size_t, c_void_p]),
     "geo_knn": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "geo_knn_counted": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hg_csr_build_i32_counted": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
     "egnn_edge_fwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "egnn_edge_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "egnn_edge_bwd": (c_int32, [c_void_p] * 7 + [c_int64] + [c_void_p] * 2 + [c_int64, c_int32] + [c_void_p] * 5
@@ -187,7 +190,7 @@ SIGNATURES = {
                                + [c_int32, c_void_p, c_size_t, c_void_p, c_int32, c_void_p]),
     "hg_csr_build_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
     "hg_csr_build_batch": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
-    "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 12),
+    "hg_index_aux": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64] + [c_void_p] * 12 + [c_int64, c_void_p]),
     "eqh_adam_step": (c_int32, [c_void_p] * 4 + [c_int64, c_void_p] + [c_float] * 5 + [c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "eqh_copy_many": (c_int32, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "eqh_mse_fwd_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -32,6 +32,11 @@ def _small_cloud_knn(pos: torch.Tensor, k: int):
     return nbr.to(torch.int32).contiguous(), key.contiguous()
 
 
+import os as _os
+
+COUNTED_KNN = not _os.environ.get("EQH_NO_COUNTED_KNN")   # the kNN counts its lists' entries for the transposed CSR (off: clear + histogram launches)
+
+
 class HyperIndex:
     """CSR views of one batch's incidence structure.
 
@@ -56,9 +61,12 @@ class HyperIndex:
         # int32 gather indices per incidence (null incidences of a padded batch stay -1: the row-gather kernel
         # reads them as zero rows, so they get a zero row forward and a zero gradient backward; the CSRs never
         # list them), int32 `batch`, and the masks of rows a mean leaves at zero -- one launch (hg_index_aux)
+        # (the same launch clears the counters of the neighbour search that usually follows: its lists' histogram is the
+        # row lengths of the transposed neighbour CSR, whose build then needs neither a clear nor a histogram launch)
+        self._knn_counts = torch.empty(self.N + 2, dtype=torch.int32, device=vertex.device) if COUNTED_KNN else None
         self.v32, self.e32, self.batch32, has_v, has_e = ops.index_aux(vertex, edges, batch, self.N, self.M,
                                                                        self.by_v.rowptr, self.by_e.rowptr,
-                                                                       self.by_v, self.by_e)
+                                                                       self.by_v, self.by_e, self._knn_counts)
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
         self._he_pool = None
@@ -99,11 +107,15 @@ class HyperIndex:
         """(nbr int32 [N,k], key fp32 [N,k], CSR of the transposed neighbour graph)."""
         hit = self._knn.get((k, mode))
         if hit is None:
+            counts, counted = self._knn_counts, False
+            self._knn_counts = None                   # (cleared once, by the index's own launch: the first search takes it)
             if mode == 1 and pos.shape[0] - 1 < k:
                 nbr, key = _small_cloud_knn(pos, k)
+            elif counts is not None and pos.shape[0] == self.N:
+                nbr, key, counted = ops.knn(pos, k, mode, self.n_box, counts=counts)
             else:
                 nbr, key = ops.knn(pos, k, mode, self.n_box)
-            csr_t = ops.csr_build(nbr.reshape(-1), None, self.N)      # int32 keys: no widening copy
+            csr_t = ops.csr_build(nbr.reshape(-1), None, self.N, counts=counts if counted else None)   # int32 keys: no widening copy
             hit = (nbr, key, csr_t)
             self._knn[(k, mode)] = hit
         return hit

@@ -35,8 +35,10 @@ class CSR:
     entry_w_of: Optional[torch.Tensor] = None  # the rowptr tensor of the partner CSR `entry_w` was computed against
 
 
-def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1) -> CSR:
-    """hg_csr_build: COO (int64 or int32 keys) -> CSR.  ``other`` int64 or None (then col = perm//col_div)."""
+def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col_div: int = 1, counts=None) -> CSR:
+    """hg_csr_build: COO (int64 or int32 keys) -> CSR.  ``other`` int64 or None (then col = perm//col_div).  ``counts``
+    (int32 keys only): an int32 tensor [n_rows + 2] already holding the keys' histogram (knn(..., counts=...)); it is
+    consumed, and the build skips its clear and histogram launches."""
     _require_gpu(key, "csr_build")
     assert key.dtype in (torch.int64, torch.int32) and key.dim() == 1
     key = key.contiguous()
@@ -51,6 +53,11 @@ def csr_build(key: torch.Tensor, other: Optional[torch.Tensor], n_rows: int, col
     L = hip.lib()
     ws_bytes = L.hg_csr_build_workspace_bytes(nnz, n_rows)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    if counts is not None:
+        assert key.dtype == torch.int32 and counts.dtype == torch.int32 and counts.numel() >= n_rows + 2 and counts.is_contiguous()
+        hip.check(L.hg_csr_build_i32_counted(_ptr(key), _ptr(other), nnz, n_rows, col_div, _ptr(rowptr), _ptr(perm), _ptr(col),
+                                             _ptr(counts), _ptr(ws), ws_bytes, _stream(dev)), "hg_csr_build_i32_counted")
+        return CSR(rowptr, perm[:nnz], col[:nnz], n_rows, nnz)
     build = L.hg_csr_build if key.dtype == torch.int64 else L.hg_csr_build_i32
     hip.check(build(_ptr(key), _ptr(other), nnz, n_rows, col_div, _ptr(rowptr), _ptr(perm),
                     _ptr(col), _ptr(ws), ws_bytes, _stream(dev)), "hg_csr_build")
@@ -93,9 +100,10 @@ def csr_build_batch(problems):
 
 
 def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr_e, by_v: Optional[CSR] = None,
-              by_e: Optional[CSR] = None):
+              by_e: Optional[CSR] = None, zero_buf=None):
     """hg_index_aux: (v32, e32, batch32 or None, has_v [N] float, has_e [M] float).  With the two CSRs it also fills
-    their ``entry_w`` (per-entry mean weights with respect to each other's rows) in the same launch."""
+    their ``entry_w`` (per-entry mean weights with respect to each other's rows) in the same launch.  ``zero_buf``: an
+    int32 tensor cleared by the same launch (the counters of the neighbour search that follows, knn(..., counts=...))."""
     _require_gpu(vertex, "index_aux")
     dev = vertex.device
     vertex, edges = vertex.contiguous(), edges.contiguous()
@@ -114,7 +122,8 @@ def index_aux(vertex, edges, batch, n_nodes: int, n_edges: int, rowptr_v, rowptr
         by_v.entry_w_of, by_e.entry_w_of = by_e.rowptr, by_v.rowptr
     hip.check(hip.lib().hg_index_aux(_ptr(vertex), _ptr(edges), nnz, _ptr(batch.contiguous()) if batch is not None else None,
                                      n_nodes, n_edges, _ptr(rowptr_v), _ptr(rowptr_e), _ptr(v32), _ptr(e32), _ptr(b32),
-                                     _ptr(has_v), _ptr(has_e), _ptr(col_v), _ptr(col_e), _ptr(ew_v), _ptr(ew_e), _stream(dev)),
+                                     _ptr(has_v), _ptr(has_e), _ptr(col_v), _ptr(col_e), _ptr(ew_v), _ptr(ew_e), _ptr(zero_buf),
+                                     zero_buf.numel() if zero_buf is not None else 0, _stream(dev)),
               "hg_index_aux")
     return v32, e32, b32, has_v, has_e
 
@@ -318,12 +327,14 @@ def embed_sum(x, tables, offsets=None):
 KNN_GRID_MIN_POINTS = 10240
 
 
-def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto"):
+def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto", counts=None):
     """(nbr int32 [N,k], key fp32 [N,k]); mode 0 = EGNN (squared distance, self included), 1 = Equiformer /
     FAFormer (true distance, self excluded).  No gradient (the reference feeds ``pos`` as data).
     ``algorithm``: "grid" (geo_knn_grid: cell grid, O(N)), "brute" (geo_knn) or "auto"; the two give identical
     results.  ``n_box``: optional int32 device tensor [1], the number of leading points that define the grid's
-    bounding box (the real atoms of a padded batch)."""
+    bounding box (the real atoms of a padded batch).  ``counts``: a ZEROED int32 tensor [>= N]; the brute-force search adds 1
+    to counts[j] for every list entry j (the histogram csr_build(..., counts=...) starts from) and the call returns
+    (nbr, key, True); the grid search ignores it and returns (nbr, key, False)."""
     _require_gpu(pos, "knn")
     pos = _f32c(pos.detach())
     N = pos.shape[0]
@@ -337,9 +348,14 @@ def knn(pos, k: int, mode: int, n_box=None, algorithm: str = "auto"):
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=pos.device)
         hip.check(L.geo_knn_grid(_ptr(pos), N, k, mode, _ptr(n_box), _ptr(nbr), _ptr(dist), _ptr(ws), ws_bytes,
                                  _stream(pos.device)), "geo_knn_grid")
+    elif counts is not None:
+        assert counts.dtype == torch.int32 and counts.numel() >= N and counts.is_contiguous()
+        hip.check(L.geo_knn_counted(_ptr(pos), N, k, mode, _ptr(nbr), _ptr(dist), _ptr(counts), _stream(pos.device)),
+                  "geo_knn_counted")
+        return nbr, dist, True
     else:
         hip.check(L.geo_knn(_ptr(pos), N, k, mode, _ptr(nbr), _ptr(dist), _stream(pos.device)), "geo_knn")
-    return nbr, dist
+    return (nbr, dist, False) if counts is not None else (nbr, dist)
 
 
 def scatter(src, index, dim: int = -1, out=None, dim_size=None, reduce: str = "sum"):

@@ -238,6 +238,12 @@ int hg_csr_build(const int64_t* key, const int64_t* other, int64_t nnz, int64_t 
 int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int64_t n_rows, int32_t col_div,
                      int32_t* rowptr, int32_t* perm, int32_t* col, void* workspace, size_t workspace_bytes,
                      void* stream);
+/* the same when the histogram of the keys exists already: counts [n_rows + 2] = occurrences of every key followed by two
+ * zeros, i.e. an array that was zeroed (hg_index_aux's zero_buf) before the producer of the keys counted into it
+ * (geo_knn_counted).  The clear and histogram launches are skipped; counts is consumed (it becomes the fill cursors). */
+int hg_csr_build_i32_counted(const int32_t* key, const int64_t* other, int64_t nnz, int64_t n_rows, int32_t col_div,
+                             int32_t* rowptr, int32_t* perm, int32_t* col, int32_t* counts, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* n independent builds at once (arrays of n pointers / sizes, same meaning as above): the three CSRs a
  * model step derives from the batch structure cost 3 launches instead of 18. */
 /* The per-batch index vectors the layers read besides the CSRs, in one launch: int32 copies of the
@@ -246,11 +252,13 @@ int hg_csr_build_i32(const int32_t* key, const int64_t* other, int64_t nnz, int6
  * the float 0/1 masks "row has at least one incidence" of the two CSRs (conv.py's mean leaves such rows
  * at zero, so the bias of the last Linear must not reach them).  Optional (NULL to skip): col_v / col_e, the `col`
  * arrays of the two CSRs, and ew_v / ew_e, which receive the per-entry mean weights of each CSR with respect to the
- * other's rows (ew_v[q] = 1 / max(deg_e(col_v[q]), 1)), as hg_entry_weights would. */
+ * other's rows (ew_v[q] = 1 / max(deg_e(col_v[q]), 1)), as hg_entry_weights would.  zero_buf [zero_n] ints (may be NULL
+ * with zero_n 0) are cleared by the same launch: the counters of the neighbour search that follows (geo_knn_counted). */
 int hg_index_aux(const int64_t* vertex, const int64_t* edges, int64_t nnz, const int64_t* batch,
                  int64_t n_nodes, int64_t n_edges, const int32_t* rowptr_v, const int32_t* rowptr_e,
                  int32_t* v32, int32_t* e32, int32_t* batch32, float* has_v, float* has_e,
-                 const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, void* stream);
+                 const int32_t* col_v, const int32_t* col_e, float* ew_v, float* ew_e, int32_t* zero_buf, int64_t zero_n,
+                 void* stream);
 size_t hg_csr_build_batch_workspace_bytes(int32_t n, const int64_t* nnz, const int64_t* n_rows);
 int hg_csr_build_batch(int32_t n, const int64_t* const* key, const int64_t* const* other, const int64_t* nnz,
                        const int64_t* n_rows, const int32_t* col_div, int32_t* const* rowptr,
@@ -312,6 +320,10 @@ int hg_embed_sum_bwd(const int64_t* x, const float* dout, const int32_t* off_hos
  * ------------------------------------------------------------------------------------------- */
 int geo_knn(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist,
             void* stream);
+/* geo_knn that also counts how often every point is listed: counts[j] += 1 per list entry j (counts [N] zeroed by the
+ * caller): the row lengths of the transposed neighbour graph, which hg_csr_build_i32_counted starts from. */
+int geo_knn_counted(const float* pos, int64_t N, int32_t k, int32_t mode, int32_t* nbr, float* dist, int32_t* counts,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused EGNN edge update for k = 16 neighbours, m_dim = 16 — egnn_layer.py:298-310,357-358

@@ -931,6 +931,33 @@ def test_rms_norm_rows_matches_float64_reference(R, C):
     del gm._eqh_gbuf
 
 
+@pytest.mark.parametrize("N,k,mode", [(17, 16, 0), (18, 16, 1), (4736, 16, 0), (4736, 16, 1), (9000, 16, 1), (300, 5, 0)])
+def test_counted_knn_and_csr_build_match_the_plain_pair(N, k, mode):
+    """geo_knn_counted + hg_csr_build_i32_counted (the lists' histogram taken by the search itself, no clear / histogram
+    launches in the build) against geo_knn + hg_csr_build_i32: identical lists, identical CSR, also on a second use of a
+    re-zeroed counter array (a replayed graph); and through HyperIndex, whose own launch clears the counters."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + k)
+    pos = (torch.randn(N, 3, generator=g) * 2).to(DEV)
+    nbr0, key0 = ops.knn(pos, k, mode, algorithm="brute")
+    csr0 = ops.csr_build(nbr0.reshape(-1), None, N)
+    counts = torch.zeros(N + 2, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        counts.zero_()
+        nbr1, key1, counted = ops.knn(pos, k, mode, algorithm="brute", counts=counts)
+        assert counted and torch.equal(nbr1, nbr0) and torch.equal(key1, key0)
+        assert int(counts[:N].sum()) == N * k and int(counts[N:].abs().sum()) == 0
+        csr1 = ops.csr_build(nbr1.reshape(-1), None, N, counts=counts)
+        assert torch.equal(csr1.rowptr, csr0.rowptr) and torch.equal(csr1.perm, csr0.perm) and torch.equal(csr1.col, csr0.col)
+    from equihgnn_amd.index import HyperIndex
+    one = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ix = HyperIndex(one, one, N, 1)
+    nbr2, key2, csr2 = ix.knn(pos, k, mode)
+    if N < ops.KNN_GRID_MIN_POINTS:
+        assert ix._knn_counts is None
+    assert torch.equal(nbr2, nbr0) and torch.equal(csr2.rowptr, csr0.rowptr) and torch.equal(csr2.perm, csr0.perm)
+
+
 @pytest.mark.parametrize("R,d", [(1, 64), (500, 256), (300, 340)])
 def test_rms_norm_rows_degree1_matches_float64_reference(R, d):
     """The degree-1 Norm (equiformer_layer.py:194-225 on [N, d, 3]): t / max(||t|| d^-1/2, eps) * g[c] through the row kernel
