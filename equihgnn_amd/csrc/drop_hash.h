@@ -27,11 +27,33 @@ __device__ __forceinline__ DropKey drop_key(uint64_t seed) {
     y ^= y >> 31;
     return DropKey{(uint32_t)z, (uint32_t)(z >> 32) | 1u, (uint32_t)y | 1u};
 }
-// keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
-__device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
-    uint32_t h = ((uint32_t)i ^ key.x) + (uint32_t)(i >> 32) * key.a;
+// One avalanche decides TWO elements: the hash of the element pair i >> 1 gives its low 16 bits to the even element and
+// its high 16 bits to the odd one (the keep probability is quantised to 2^-16).  The kernels handle elements in aligned
+// pairs / float4 groups, so the per-element cost of the hash halves (round 4: it was ~10 of the 60 / 106 VALU
+// instructions per hidden unit of the frame hidden layer, forward / backward, and a third of the frame-mean epilogue).
+__device__ __forceinline__ uint32_t drop_hash(const DropKey& key, uint64_t pair) {
+    uint32_t h = ((uint32_t)pair ^ key.x) + (uint32_t)(pair >> 32) * key.a;
     h ^= h >> 16; h *= key.m;
     h ^= h >> 13; h *= 0xC2B2AE35u;
     h ^= h >> 16;
-    return h >= threshold ? inv_keep : 0.f;
+    return h;
+}
+// keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
+__device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
+    const uint32_t h = drop_hash(key, i >> 1);
+    return (((i & 1) ? (h >> 16) : (h & 0xffffu)) >= (threshold >> 16)) ? inv_keep : 0.f;
+}
+// the same for the aligned pair (i, i + 1), i even: one hash
+__device__ __forceinline__ void keep_scale2(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep, float& k0,
+                                            float& k1) {
+    const uint32_t h = drop_hash(key, i >> 1), t16 = threshold >> 16;
+    k0 = (h & 0xffffu) >= t16 ? inv_keep : 0.f;
+    k1 = (h >> 16) >= t16 ? inv_keep : 0.f;
+}
+// ... and for an aligned float4 (i a multiple of 4): v *= keep, two hashes
+__device__ __forceinline__ void keep_scale4(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep, float4& v) {
+    float k0, k1, k2, k3;
+    keep_scale2(key, i, threshold, inv_keep, k0, k1);
+    keep_scale2(key, i + 2, threshold, inv_keep, k2, k3);
+    v.x *= k0; v.y *= k1; v.z *= k2; v.w *= k3;
 }

@@ -31,8 +31,7 @@ k_swiglu_drop_fwd(const float* __restrict__ pre, int64_t R, int H, const int64_t
                                a.z * sigmoid_fast(a.z) * b.z, a.w * sigmoid_fast(a.w) * b.w);
         if (threshold) {
             const uint64_t e = (uint64_t)(r * H + c);
-            o.x *= keep_scale(seed, e, threshold, inv_keep); o.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-            o.z *= keep_scale(seed, e + 2, threshold, inv_keep); o.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+            keep_scale4(seed, e, threshold, inv_keep, o);
         }
         *reinterpret_cast<float4*>(out + r * H + c) = o;
     }
@@ -52,8 +51,7 @@ k_swiglu_drop_bwd(const float* __restrict__ pre, const float* __restrict__ dout,
         float4 g = *reinterpret_cast<const float4*>(dout + r * H + c);
         if (threshold) {
             const uint64_t e = (uint64_t)(r * H + c);
-            g.x *= keep_scale(seed, e, threshold, inv_keep); g.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-            g.z *= keep_scale(seed, e + 2, threshold, inv_keep); g.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+            keep_scale4(seed, e, threshold, inv_keep, g);
         }
         const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w}, gv[4] = {g.x, g.y, g.z, g.w};
         float da[4], db[4];
@@ -90,8 +88,7 @@ k_drop_mean_fwd(const float* __restrict__ x, int64_t R, int F_rt, int C, const i
             float4 v = *reinterpret_cast<const float4*>(x + row * C + c);
             if (threshold) {
                 const uint64_t e = (uint64_t)(row * C + c);
-                v.x *= keep_scale(seed, e, threshold, inv_keep); v.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-                v.z *= keep_scale(seed, e + 2, threshold, inv_keep); v.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+                keep_scale4(seed, e, threshold, inv_keep, v);
             }
             f4_add(acc, v);
         }
@@ -120,8 +117,7 @@ k_drop_mean_bwd(const float* __restrict__ dout, int64_t R, int F, int C, const i
         g.x *= inv_f; g.y *= inv_f; g.z *= inv_f; g.w *= inv_f;
         if (threshold) {
             const uint64_t e = (uint64_t)(row * C + c);
-            g.x *= keep_scale(seed, e, threshold, inv_keep); g.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-            g.z *= keep_scale(seed, e + 2, threshold, inv_keep); g.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+            keep_scale4(seed, e, threshold, inv_keep, g);
         }
         *reinterpret_cast<float4*>(dx + row * C + c) = g;
         if (COLSUM) f4_add(cs, g);
@@ -159,8 +155,7 @@ k_drop_mean_bwd_f8c256(const float* __restrict__ dout, int64_t R, const int64_t*
             float4 o = g;
             if (threshold) {
                 const uint64_t e = (uint64_t)(row * 256 + lane * 4);
-                o.x *= keep_scale(seed, e, threshold, inv_keep); o.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-                o.z *= keep_scale(seed, e + 2, threshold, inv_keep); o.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+                keep_scale4(seed, e, threshold, inv_keep, o);
             }
             *reinterpret_cast<float4*>(dx + row * 256 + lane * 4) = o;
             if (COLSUM) f4_add(cs, o);
@@ -190,8 +185,7 @@ k_dropout_add(const float* __restrict__ x, const float* __restrict__ res, int64_
         float4 v = reinterpret_cast<const float4*>(x)[i];
         if (threshold) {
             const uint64_t e = (uint64_t)i * 4;
-            v.x *= keep_scale(seed, e, threshold, inv_keep); v.y *= keep_scale(seed, e + 1, threshold, inv_keep);
-            v.z *= keep_scale(seed, e + 2, threshold, inv_keep); v.w *= keep_scale(seed, e + 3, threshold, inv_keep);
+            keep_scale4(seed, e, threshold, inv_keep, v);
         }
         if (res) f4_add(v, reinterpret_cast<const float4*>(res)[i]);
         reinterpret_cast<float4*>(out)[i] = v;
@@ -494,8 +488,9 @@ k_frame_hidden_fwd(const float* __restrict__ y, const float* __restrict__ w3, co
             float h0 = a0 * sigmoid_fast(a0) * b0, h1 = a1 * sigmoid_fast(a1) * b1;
             if (threshold) {
                 const uint64_t idx = (uint64_t)((e * 8 + f) * 128 + 2 * lane);
-                h0 *= keep_scale(seed, idx, threshold, inv_keep);
-                h1 *= keep_scale(seed, idx + 1, threshold, inv_keep);
+                float kk0, kk1;
+                keep_scale2(seed, idx, threshold, inv_keep, kk0, kk1);      // (idx is even: one hash for the pair)
+                h0 *= kk0; h1 *= kk1;
             }
             v0[f] = h0; v1[f] = h1;
         }
@@ -568,8 +563,7 @@ k_frame_hidden_bwd(const float* __restrict__ y, const float* __restrict__ w3, co
             float k0 = 1.f, k1 = 1.f;
             if (threshold) {
                 const uint64_t idx = (uint64_t)((e * 8 + f) * 128 + 2 * lane);
-                k0 = keep_scale(seed, idx, threshold, inv_keep);
-                k1 = keep_scale(seed, idx + 1, threshold, inv_keep);
+                keep_scale2(seed, idx, threshold, inv_keep, k0, k1);
             }
             const float h0 = s0 * b0 * k0, h1 = s1 * b1 * k1;
             const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);
@@ -1080,8 +1074,7 @@ __device__ __forceinline__ void rd_dropout(RdRow<NV>& xr, const DropKey& seed, i
     for (int i = 0; i < NV; ++i) {
         const int c = (lane + 64 * i) * 4;
         const uint64_t e = (uint64_t)(r * C + c);
-        xr.v[i].x *= keep_scale(seed, e, threshold, inv_keep); xr.v[i].y *= keep_scale(seed, e + 1, threshold, inv_keep);
-        xr.v[i].z *= keep_scale(seed, e + 2, threshold, inv_keep); xr.v[i].w *= keep_scale(seed, e + 3, threshold, inv_keep);
+        keep_scale4(seed, e, threshold, inv_keep, xr.v[i]);
     }
 }
 
@@ -1338,8 +1331,9 @@ k_edge_hidden_fwd(const float* __restrict__ A, const float* __restrict__ B, cons
             const int64_t r = i * K + k;
             if (threshold) {
                 const uint64_t idx = (uint64_t)(r * 128 + 2 * lane);
-                h0 *= keep_scale(seed, idx, threshold, inv_keep);
-                h1 *= keep_scale(seed, idx + 1, threshold, inv_keep);
+                float kk0, kk1;
+                keep_scale2(seed, idx, threshold, inv_keep, kk0, kk1);      // (idx is even: one hash for the pair)
+                h0 *= kk0; h1 *= kk1;
             }
             const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);
             const float d0 = h0 - mu, d1 = h1 - mu;
@@ -1382,8 +1376,7 @@ k_edge_hidden_bwd(const float* __restrict__ A, const float* __restrict__ B, cons
             float k0 = 1.f, k1 = 1.f;
             if (threshold) {
                 const uint64_t idx = (uint64_t)(r * 128 + 2 * lane);
-                k0 = keep_scale(seed, idx, threshold, inv_keep);
-                k1 = keep_scale(seed, idx + 1, threshold, inv_keep);
+                keep_scale2(seed, idx, threshold, inv_keep, k0, k1);
             }
             const float h0 = s0 * b0 * k0, h1 = s1 * b1 * k1;
             const float mu = fp_wave_sum(h0 + h1) * (1.0f / 128.0f);

@@ -433,8 +433,7 @@ k_gemm_x6(const GxBatch batch) {
                     float4 o = make_float4(fmaf(alpha, a.x, bv.x), fmaf(alpha, a.y, bv.y), fmaf(alpha, a.z, bv.z), fmaf(alpha, a.w, bv.w));
                     if (thr) {
                         const uint64_t e = (uint64_t)((row0 + i) * N + col);
-                        o.x *= keep_scale(key, e, thr, inv_keep); o.y *= keep_scale(key, e + 1, thr, inv_keep);
-                        o.z *= keep_scale(key, e + 2, thr, inv_keep); o.w *= keep_scale(key, e + 3, thr, inv_keep);
+                        keep_scale4(key, e, thr, inv_keep, o);
                     }
                     if (row0 + i < M) f4_add(sum, o);
                 }
