@@ -1108,15 +1108,15 @@ template <int NV>
 __global__ void __launch_bounds__(RD_THREADS)
 k_gate_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ dout,
            int64_t R, int C, const int64_t* __restrict__ seed_ptr, uint32_t threshold, float inv_keep, float* __restrict__ dx,
-           float* __restrict__ slab) {
+           float* __restrict__ slab, float* __restrict__ slab_dx) {
     __shared__ float4 s_red[RD_THREADS];
     __shared__ float s_b[RD_WAVES];
     const DropKey seed = drop_key(threshold ? (uint64_t)*seed_ptr : 0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    RdRow<NV> wr, aw;
+    RdRow<NV> wr, aw, ax;          // ax: column sums of dx (slab_dx given) = the bias gradient of the Linear that produced x
     rd_load<NV>(w, C, lane, wr);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) aw.v[i] = f4_zero();
+    for (int i = 0; i < NV; ++i) aw.v[i] = ax.v[i] = f4_zero();
     float ab = 0.f;
     const float b0 = b[0];
     for (int64_t r = (int64_t)blockIdx.x * RD_WAVES + wave; r < R; r += (int64_t)gridDim.x * RD_WAVES) {
@@ -1139,6 +1139,22 @@ k_gate_bwd(const float* __restrict__ x, const float* __restrict__ w, const float
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (c < C) *reinterpret_cast<float4*>(dx + r * C + c) = dxd.v[i];
+            f4_add(ax.v[i], dxd.v[i]);
+        }
+    }
+    if (slab_dx) {
+        float* __restrict__ sx = slab_dx + (int64_t)blockIdx.x * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            s_red[threadIdx.x] = ax.v[i];
+            __syncthreads();
+            if (wave == 0) {
+                float4 t = s_red[lane];
+                for (int q = 1; q < RD_WAVES; ++q) f4_add(t, s_red[q * 64 + lane]);
+                const int c = (lane + 64 * i) * 4;
+                if (c < C) *reinterpret_cast<float4*>(sx + c) = t;
+            }
+            __syncthreads();
         }
     }
     float* __restrict__ sl = slab + (int64_t)blockIdx.x * (C + 4);
@@ -1254,18 +1270,22 @@ extern "C" int faf_gate_fwd(const float* x, const float* w, const float* b, cons
 
 extern "C" size_t faf_gate_bwd_workspace_bytes(int64_t R, int32_t C) {
     if (R <= 0 || C <= 0) return 0;
-    return ((size_t)rd_blocks(R) * (size_t)(C + 4) + 4) * sizeof(float);   // + a discard row for the slab's padding floats
+    // dw / db slabs + a discard row for their padding floats, then the slabs of the dx column sums
+    return ((size_t)rd_blocks(R) * (size_t)(2 * C + 4) + 4) * sizeof(float);
 }
 
-/* dx [R, C]; dw [C] and db [1] overwritten or accumulated (the gradient of `res` is dout itself) */
+/* dx [R, C]; dw [C] and db [1] overwritten or accumulated (the gradient of `res` is dout itself).  dx_colsum [C] (may be
+   NULL): the column sums of dx, overwritten or (accumulate_colsum != 0) added to -- the bias gradient of the Linear that
+   produced x, which then needs no pass of its own over dx. */
 extern "C" int faf_gate_bwd(const float* x, const float* w, const float* b, const float* dout, int64_t R, int32_t C, float p,
-                            const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, void* workspace,
-                            size_t workspace_bytes, void* stream_) {
+                            const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, float* dx_colsum,
+                            int32_t accumulate_colsum, void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = rd_check(R, C);
     if (rc) return rc;
     if (!(p >= 0.f) || !(p < 1.f) || !dw || !db) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (R == 0) {
+        if (dx_colsum && !accumulate_colsum && eqh_zero_async(dx_colsum, C, stream)) return EQH_ERR_LAUNCH;
         if (accumulate) return EQH_OK;
         if (eqh_zero_async(dw, C, stream)) return EQH_ERR_LAUNCH;
         return eqh_zero_async(db, 1, stream);
@@ -1276,11 +1296,14 @@ extern "C" int faf_gate_bwd(const float* x, const float* w, const float* b, cons
     if (workspace_bytes < faf_gate_bwd_workspace_bytes(R, C)) return EQH_ERR_ARG;
     const int blocks = rd_blocks(R);
     float* slab = static_cast<float*>(workspace);
+    float* slab_dx = dx_colsum ? slab + (size_t)blocks * (C + 4) + 4 : nullptr;
     return rd_dispatch(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_gate_bwd<NV>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, w, b, dout, R, (int)C, seed,
-                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
+                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab, slab_dx);
         EQH_CHECK_LAUNCH();
+        if (slab_dx)
+            if (int e = eqh_reduce_slabs_async(slab_dx, blocks, C, dx_colsum, stream, accumulate_colsum ? 1 : 0)) return e;
         // segments: dw (C), db (1), the slab row's three padding floats (to the discard row)
         return eqh_reduce_slabs3_async(slab, blocks, (int64_t)C + 4, dw, db, slab + (size_t)blocks * (C + 4), C, 1, accumulate,
                                        stream);

@@ -46,6 +46,9 @@ def _layer_norm(mod: nn.LayerNorm, x, passthrough: bool = False):
     return (mod(x), x) if passthrough else mod(x)
 
 
+import os as _os
+
+BIAS_RIDERS = not _os.environ.get("EQH_NO_BIAS_RIDERS")   # bias gradients of edge-level Linears taken by their consumers' backward passes
 FUSE_EDGE_HIDDEN = True     # EdgeModule: gather + adds + SwiGLU + dropout + LayerNorm of the edge MLP's hidden layer in one launch
 FUSE_FRAME_HIDDEN = True    # SwiGLUMLP.frame_mean: one launch for the hidden layer over the 8 sign frames (ops.frame_hidden)
 
@@ -218,14 +221,16 @@ class EdgeModule(nn.Module):
                                   mlp.p if self.training else 0.0)
         else:
             hid = mlp.hidden(a_i.unsqueeze(1) + g.gather(b_j) + c_ij)
-        pair = mlp._fc2(hid)
+        a = self.att_mlp[0]
+        ride = BIAS_RIDERS and ops.geom_supported(tok) and mlp.fc2.weight.shape[0] % 4 == 0 and mlp.fc2.weight.shape[0] <= 1024
+        # (fc2's bias gradient = the column sums of the gate's input gradient: taken by the gate's backward pass, ops.gate_rows)
+        pair = ops.linear(hid, mlp.fc2.weight, mlp.fc2.bias, bias_grad=False) if ride else mlp._fc2(hid)
         # att_mlp = Linear(d, 1) + Sigmoid on ~250 k edge rows: a row-wise dot product -- as a GEMM with ONE output column the
         # library needs 2 ms for it.  The dropout in front of it, the dot product, the gate and the residual add behind it
         # are one pass each way (ops.gate_rows, csrc/faformer_ew.hip)
-        a = self.att_mlp[0]
         p = self.edge_mlp.p if self.training else 0.0
         if pair.is_cuda and pair.dtype == torch.float32 and pair.shape[-1] % 4 == 0 and pair.shape[-1] <= 1024:
-            return ops.gate_rows(pair, a.weight, a.bias, res, p)
+            return ops.gate_rows(pair, a.weight, a.bias, res, p, lin_bias=mlp.fc2.bias if ride else None)
         pair = F.dropout(pair, p, self.training)
         out = pair * torch.sigmoid((pair * a.weight.view(-1)).sum(-1, keepdim=True) + a.bias)
         return out if res is None else res + out

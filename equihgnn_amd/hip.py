@@ -162,8 +162,8 @@ SIGNATURES = {
                                                   c_void_p]),
     "faf_gate_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float, c_void_p, c_void_p, c_void_p]),
     "faf_gate_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "faf_gate_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4 + [c_int32, c_void_p, c_size_t,
-                                                                                               c_void_p]),
+    "faf_gate_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4 + [c_int32, c_void_p, c_int32,
+                                                                                               c_void_p, c_size_t, c_void_p]),
     "faf_edge_hidden_fwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_void_p, c_float, c_void_p, c_void_p]),
     "faf_edge_hidden_bwd_workspace_bytes": (c_size_t, [c_int64]),
     "faf_edge_hidden_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32, c_float, c_void_p, c_float] + [c_void_p] * 4

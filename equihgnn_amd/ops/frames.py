@@ -421,10 +421,11 @@ def rowdot_supported(x, J: int) -> bool:
 
 class _GateRows(torch.autograd.Function):
     """out = res + xd * sigmoid(xd . w + b), xd = dropout_p(x): EdgeModule's gate with the dropout in front of it and the
-    residual behind it, one pass each way (faf_gate_*)."""
+    residual behind it, one pass each way (faf_gate_*).  ``lin_bias``: the bias PARAMETER of the Linear that produced x (called
+    with ``bias_grad=False``): its gradient, the column sums of dx, rides the backward pass instead of reading dx again."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res, p, seed, acc_params):
+    def forward(ctx, x, w, b, res, p, seed, acc_params, lin_bias=None):
         _require_gpu(x, "gate_rows")
         x2 = _f32c(x).reshape(-1, x.shape[-1])
         wc, bc = _f32c(w).reshape(-1), _f32c(b).reshape(-1)
@@ -436,7 +437,7 @@ class _GateRows(torch.autograd.Function):
                                          _stream(x.device)), "faf_gate_fwd")
         ctx.save_for_backward(x2, wc, bc)
         ctx.meta = (x.shape, float(p), seed, res is not None, w.shape, b.shape)
-        ctx.acc = acc_params
+        ctx.acc, ctx.lin_bias = acc_params, lin_bias
         return out.view(x.shape)
 
     @staticmethod
@@ -454,19 +455,28 @@ class _GateRows(torch.autograd.Function):
         small = None if acc else torch.empty(C + 4, dtype=torch.float32, device=x2.device)
         dw_t = tg[0].reshape(-1) if acc else small[:C]
         db_t = tg[1].reshape(-1) if acc else small[C:C + 1]
+        lb, dlb, lb_acc = ctx.lin_bias, None, None
+        if lb is not None:
+            lb_acc = _acc_target(lb)
+            dlb = lb_acc if lb_acc is not None else torch.empty(C, dtype=torch.float32, device=x2.device)
         hip.check(L.faf_gate_bwd(_ptr(x2), _ptr(wc), _ptr(bc), _ptr(dout2), R, C, p, _ptr(seed), _ptr(dx), _ptr(dw_t),
-                                 _ptr(db_t), 1 if acc else 0, _ptr(ws), ws_bytes, _stream(x2.device)), "faf_gate_bwd")
+                                 _ptr(db_t), 1 if acc else 0, _ptr(dlb), 1 if lb_acc is not None else 0, _ptr(ws), ws_bytes,
+                                 _stream(x2.device)), "faf_gate_bwd")
         if acc:
             dw = db = None
         else:
             dw, db = _hand_out([small[:C].view(w_shape), small[C:C + 1].view(b_shape)], tg)
-        return dx.view(shape), dw, db, (dout if has_res else None), None, None, None
+        return (dx.view(shape), dw, db, (dout if has_res else None), None, None, None,
+                None if (lb is None or lb_acc is not None) else dlb)
 
 
-def gate_rows(x, w, b, res=None, p: float = 0.0, seed=None):
-    """res + dropout_p(x) * sigmoid(dropout_p(x) . w + b) over the last dim; w [C] (or [1, C]) and b [1] are the PARAMETERS."""
+def gate_rows(x, w, b, res=None, p: float = 0.0, seed=None, lin_bias=None):
+    """res + dropout_p(x) * sigmoid(dropout_p(x) . w + b) over the last dim; w [C] (or [1, C]) and b [1] are the PARAMETERS;
+    ``lin_bias``: see _GateRows."""
     _note_acc(w, b)
-    return _GateRows.apply(x, w, b, res, p, seed, (w, b))
+    if lin_bias is not None:
+        _note_acc(lin_bias)
+    return _GateRows.apply(x, w, b, res, p, seed, (w, b), lin_bias)
 
 
 class _AttnSum(torch.autograd.Function):

@@ -712,13 +712,15 @@ int faf_rowdot_bwd(const float* x, const float* U, const float* dy, const float*
 
 /* The sigmoid gate of EdgeModule (fa_former_layer.py:340-400: pair * att_mlp(pair)) with the dropout in front of it and the
  * residual behind it:  out = res (may be NULL) + xd * sigmoid(xd . w + b),  xd = dropout_p(x)  (hash of (seed, element)).
- * bwd: dx [R, C], dw [C], db [1] (overwritten or accumulated); the gradient of res is dout itself. */
+ * bwd: dx [R, C], dw [C], db [1] (overwritten or accumulated); the gradient of res is dout itself.  dx_colsum [C] (may be
+ * NULL): the column sums of dx from the same pass (overwritten, or added to with accumulate_colsum != 0) -- the bias
+ * gradient `grad_output.sum(0)` of the Linear that produced x (`edge_mlp.fc2`), which then needs no pass of its own. */
 int faf_gate_fwd(const float* x, const float* w, const float* b, const float* res, int64_t R, int32_t C, float p,
                  const int64_t* seed, float* out, void* stream);
 size_t faf_gate_bwd_workspace_bytes(int64_t R, int32_t C);
 int faf_gate_bwd(const float* x, const float* w, const float* b, const float* dout, int64_t R, int32_t C, float p,
-                 const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, void* workspace,
-                 size_t workspace_bytes, void* stream);
+                 const int64_t* seed, float* dx, float* dw, float* db, int32_t accumulate, float* dx_colsum,
+                 int32_t accumulate_colsum, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Hidden layer of EdgeModule's edge MLP on the kNN edges (fa_former_layer.py:340-400 with :241-289), first Linear split by
  * input block:  hn[i, k, :] = LayerNorm(dropout_p(SiLU(a) * b)),  [a | b] = A[i] + B[nbr[i, k]] + Cf[i, k]  (256 -> 128).

@@ -1301,6 +1301,21 @@ def test_gate_rows_matches_float64(R, C, p, with_res):
     for name, a, r in zip(("dx", "dw", "db", "dres"), d, t):
         err = float((a.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max().clamp(min=1e-9))
         assert err < 3e-5, (name, err)
+    # the producing Linear's bias gradient (column sums of dx) as a rider of the backward pass: fresh, and into an accumulator
+    lb = torch.nn.Parameter(torch.zeros(C, device=DEV))
+    d2 = [a.to(DEV).requires_grad_(True) for a in ((x, w, b) + ((res,) if with_res else ()))]
+    out2 = ops.gate_rows(d2[0], d2[1], d2[2], d2[3] if with_res else None, p, seed, lin_bias=lb)
+    (out2 * wo.to(DEV)).sum().backward()
+    assert torch.equal(out2.detach(), out.detach()) and torch.equal(d2[0].grad, d[0].grad)
+    want = d[0].grad.double().sum(0)
+    assert float((lb.grad.double() - want).abs().max() / want.abs().max().clamp(min=1e-9)) < 2e-5
+    lb.grad = None
+    lb._eqh_gbuf = torch.full_like(lb, 0.25)
+    d3 = [a.to(DEV).requires_grad_(True) for a in ((x, w, b) + ((res,) if with_res else ()))]
+    (ops.gate_rows(d3[0], d3[1], d3[2], d3[3] if with_res else None, p, seed, lin_bias=lb) * wo.to(DEV)).sum().backward()
+    assert lb.grad is None
+    assert float(((lb._eqh_gbuf - 0.25).double() - want).abs().max() / want.abs().max().clamp(min=1e-9)) < 2e-5
+    del lb._eqh_gbuf
 
 
 @pytest.mark.parametrize("R,F_,C,p", [(1, 8, 4, 0.0), (777, 8, 256, 0.1), (5000, 8, 256, 0.1), (301, 3, 64, 0.25), (64, 8, 320, 0.1)])
