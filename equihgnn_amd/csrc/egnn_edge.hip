@@ -676,13 +676,14 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
                              const float* d2, const float* pre2, const float* dm, int64_t dm_ld,
                              const int32_t* t_rowptr, const int32_t* t_perm, int64_t N, int32_t Hp,
                              float* dab, float* dwd, float* dw2, float* dpre2, float* db2,
-                             int32_t db2_accumulate, void* workspace, size_t workspace_bytes, void* stream_) {
+                             int32_t db2_accumulate, int32_t dw_accumulate, void* workspace, size_t workspace_bytes,
+                             void* stream_) {
     int rc = check_common(N, Hp);
     if (rc) return rc;
     if (!dwd || !dw2) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (N == 0) {
-        if (eqh_zero_async(dwd, Hp, stream) || eqh_zero_async(dw2, (int64_t)MDIM * Hp, stream))
+        if (!dw_accumulate && (eqh_zero_async(dwd, Hp, stream) || eqh_zero_async(dw2, (int64_t)MDIM * Hp, stream)))
             return EQH_ERR_LAUNCH;
         if (db2 && !db2_accumulate && eqh_zero_async(db2, MDIM, stream)) return EQH_ERR_LAUNCH;
         return EQH_OK;
@@ -719,6 +720,8 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
     hipLaunchKernelGGL(k_edge_bwd_send, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, dpre2, t_rowptr,
                        rec, dab, (int)N, (int)Hp, tiles, chunk_items);
     EQH_CHECK_LAUNCH();
-    return eqh_reduce_slabs3_async(slab_w2, used, (int64_t)(MDIM + 1) * Hp, dw2, dwd, dwd, (int64_t)MDIM * Hp, Hp, 0,
-                                   stream);
+    // (dw_accumulate: dw2 / dwd are accumulators -- the packed weights' own, ops.egnn_pack_weights -- and the reduction joins
+    // the step's batched one when a deferral window is open)
+    return eqh_reduce_slabs3_async(slab_w2, used, (int64_t)(MDIM + 1) * Hp, dw2, dwd, dwd, (int64_t)MDIM * Hp, Hp,
+                                   dw_accumulate ? 1 : 0, stream);
 }

@@ -10,11 +10,11 @@ import torch
 
 from .. import hip
 from ._base import (
-    ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream,
+    ACC_PARAMS, LINEAR_PARAMS, _DEFER, _acc_target, _f32c, _hand_out, _note_acc, _ptr, _require_gpu, _rows_ld, _stream,
     _workspace, timed)
 from .aggregate import (CSR)
 from .products import (USE_X6, X6_WGRAD_ROWS, gemm, gemm_supported, mm_nn, mm_nt)
-from .grads import (colsum)
+from .grads import (_merged_acc, _wgrad_deferred, colsum)
 
 
 class _EgnnEdge(torch.autograd.Function):
@@ -23,7 +23,7 @@ class _EgnnEdge(torch.autograd.Function):
     pre-activations; the per-edge hidden activations are recomputed in the backward."""
 
     @staticmethod
-    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR, b2_param=None):
+    def forward(ctx, ab, wd, w2, b2, nbr, d2, csr_t: CSR, b2_param=None, w_refs=None):
         _require_gpu(ab, "egnn_edge")
         ab, wd, w2, b2 = _f32c(ab), _f32c(wd), _f32c(w2), _f32c(b2)
         N, Hp = ab.shape[0], ab.shape[1] // 2
@@ -36,7 +36,7 @@ class _EgnnEdge(torch.autograd.Function):
               lambda: hip.check(hip.lib().egnn_edge_fwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(b2), _ptr(nbr), _ptr(d2), N, Hp,
                                                         _ptr(m), _ptr(pre2), _stream(ab.device)), "egnn_edge_fwd"))
         ctx.save_for_backward(ab, wd, w2, pre2)
-        ctx.nbr, ctx.d2, ctx.csr_t, ctx.b2_param = nbr, d2, csr_t, b2_param
+        ctx.nbr, ctx.d2, ctx.csr_t, ctx.b2_param, ctx.w_refs = nbr, d2, csr_t, b2_param, w_refs
         return m
 
     @staticmethod
@@ -46,8 +46,12 @@ class _EgnnEdge(torch.autograd.Function):
         N, Hp = ab.shape[0], ab.shape[1] // 2
         dev = ab.device
         dab = torch.empty_like(ab)
-        dwd = torch.empty_like(wd)
-        dw2 = torch.empty_like(w2)
+        # (wd / w2 with accumulators of their own -- the packed weights of a deferral window, egnn_pack_weights: the slab
+        # reduction adds into them and joins the step's batched one)
+        tw = [_acc_target(q) for q in ctx.w_refs] if ctx.w_refs is not None else [None, None]
+        w_acc = all(t is not None for t in tw)
+        dwd = tw[0] if w_acc else torch.empty_like(wd)
+        dw2 = tw[1] if w_acc else torch.empty_like(w2)
         dpre2 = torch.empty_like(pre2)
         L = hip.lib()
         ws_bytes = L.egnn_edge_bwd_workspace_bytes(N, Hp)
@@ -58,8 +62,9 @@ class _EgnnEdge(torch.autograd.Function):
               lambda: hip.check(L.egnn_edge_bwd(_ptr(ab), _ptr(wd), _ptr(w2), _ptr(ctx.nbr), _ptr(ctx.d2), _ptr(pre2),
                                                 _ptr(dm), dm_ld, _ptr(ctx.csr_t.rowptr), _ptr(ctx.csr_t.perm), N, Hp, _ptr(dab),
                                                 _ptr(dwd), _ptr(dw2), _ptr(dpre2), _ptr(db2), 1 if tg is not None else 0,
-                                                _ptr(ws), ws_bytes, _stream(dev)), "egnn_edge_bwd"))
-        return dab, dwd, dw2, (None if tg is not None else db2), None, None, None, None
+                                                1 if w_acc else 0, _ptr(ws), ws_bytes, _stream(dev)), "egnn_edge_bwd"))
+        return (dab, None if w_acc else dwd, None if w_acc else dw2, (None if tg is not None else db2), None, None, None, None,
+                None)
 
 
 class _EgnnFeats(torch.autograd.Function):
@@ -70,7 +75,7 @@ class _EgnnFeats(torch.autograd.Function):
     GEMM instead of two add kernels."""
 
     @staticmethod
-    def forward(ctx, feats, w_cat, b_cat, gamma, beta, eps, acc_params):
+    def forward(ctx, feats, w_cat, b_cat, gamma, beta, eps, acc_params, w_refs=None):
         _require_gpu(feats, "egnn_feats")
         feats = _f32c(feats)
         g, b = _f32c(gamma), _f32c(beta)
@@ -80,7 +85,7 @@ class _EgnnFeats(torch.autograd.Function):
                                               _stream(feats.device)), "hg_layer_norm_fwd")
         ab = mm_nt(feats, w_cat, bias=b_cat)
         ctx.save_for_backward(feats, w_cat, g)
-        ctx.eps, ctx.acc = float(eps), acc_params
+        ctx.eps, ctx.acc, ctx.w_refs = float(eps), acc_params, w_refs
         ctx.set_materialize_grads(False)
         return ab, normed, feats.view_as(feats)
 
@@ -111,21 +116,29 @@ class _EgnnFeats(torch.autograd.Function):
         if d_ab is not None:
             d_ab = _f32c(d_ab)
             dx = mm_nn(d_ab, w_cat) if dx is None else mm_nn(d_ab, w_cat, d=dx, out=dx)
+            tw = [_acc_target(q) for q in ctx.w_refs] if ctx.w_refs is not None else [None, None]
             if ctx.needs_input_grad[1]:
-                if USE_X6 and R >= X6_WGRAD_ROWS and gemm_supported(d_ab, feats, True, False):
+                if tw[0] is not None:       # w_cat carries an accumulator (egnn_pack_weights inside a deferral window)
+                    if USE_X6 and R >= X6_WGRAD_ROWS and gemm_supported(d_ab, feats, True, False):
+                        gemm(d_ab, feats, trans_a=True, trans_b=False, d=tw[0], out=tw[0])
+                    elif not _wgrad_deferred(d_ab, feats, 1.0, tw[0]):
+                        tw[0].addmm_(d_ab.t(), feats)
+                elif USE_X6 and R >= X6_WGRAD_ROWS and gemm_supported(d_ab, feats, True, False):
                     dw = gemm(d_ab, feats, trans_a=True, trans_b=False)      # split-K x6: 257 against 321 us at 31 k atoms
                 else:
                     dw = d_ab.t() @ feats
             if ctx.needs_input_grad[2]:
-                db = colsum(d_ab)
-        return dx, dw, db, dgamma, dbeta, None, None
+                db = colsum(d_ab, into=tw[1]) if tw[1] is not None else colsum(d_ab)
+                if tw[1] is not None:
+                    db = None
+        return dx, dw, db, dgamma, dbeta, None, None, None
 
 
 def egnn_feats(feats, w_cat, b_cat, norm):
     """(feats @ w_cat.T + b_cat, LayerNorm(feats), feats) for 2-D fp32 ``feats`` [N, C] (C % 4 == 0, C <= 1024);
     ``norm`` the nn.LayerNorm module.  See _EgnnFeats."""
     _note_acc(norm.weight, norm.bias)
-    return _EgnnFeats.apply(feats, w_cat, b_cat, norm.weight, norm.bias, norm.eps, (norm.weight, norm.bias))
+    return _EgnnFeats.apply(feats, w_cat, b_cat, norm.weight, norm.bias, norm.eps, (norm.weight, norm.bias), (w_cat, b_cat))
 
 
 class _EgnnPackWeights(torch.autograd.Function):
@@ -174,15 +187,33 @@ def egnn_pack_weights(w1, b1, w2, Hp):
         for w in (w1, b1, w2):
             if w.requires_grad and w.is_leaf:
                 (LINEAR_PARAMS if w.dim() == 2 else ACC_PARAMS)[id(w)] = w
-    return _EgnnPackWeights.apply(w1, b1, w2, Hp, (w1, b1, w2))
+    res = _EgnnPackWeights.apply(w1, b1, w2, Hp, (w1, b1, w2))
+    if not (DEFER_PACK_BWD and _DEFER["active"] and torch.is_grad_enabled() and any(t.requires_grad for t in res)):
+        return res
+    # Inside a deferral window (graphed trainer) the packed weights are detached leaves with zeroed accumulators of their
+    # own, like the merged weights of ops.merged_weights: the weight / bias gradients of their consumers (egnn_feats' batched
+    # product and column sum, the edge kernels' slab reduction) join the step's batched launches, and defer_flush then runs
+    # this node's backward ONCE on the finished sums -- instead of two slab reductions and a column-sum pass launched
+    # mid-backward only because the un-packing kernel sat there (17 us per c2 step).
+    shapes = [(t.shape[0], t.shape[1]) if t.dim() == 2 else (1, t.shape[0]) for t in res]
+    accs = [_merged_acc(sh, res[0].device).view(t.shape) for sh, t in zip(shapes, res)]
+    leaves = []
+    for t, a in zip(res, accs):
+        leaf = t.detach().requires_grad_()
+        leaf._eqh_transient = True
+        leaf._eqh_gbuf = a
+        leaves.append(leaf)
+    _DEFER["merged"].append((list(res), accs))
+    return tuple(leaves)
 
 
 def egnn_edge(ab, wd, w2, b2, nbr, d2, csr_t: CSR):
     _note_acc(b2)
-    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2)
+    return _EgnnEdge.apply(ab, wd, w2, b2, nbr, d2, csr_t, b2, (wd, w2))
 
 
 NODE_WGRAD_BLOCKS = not os.environ.get("EQH_NO_NODE_WGRAD_BLOCKS")
+DEFER_PACK_BWD = not os.environ.get("EQH_NO_DEFER_PACK")     # the packed EGNN edge weights get accumulators of their own inside a deferral window
 
 
 class _EgnnNodeMlp(torch.autograd.Function):

@@ -338,7 +338,7 @@ int geo_knn_counted(const float* pos, int64_t N, int32_t k, int32_t mode, int32_
  *       (pre-activation of the second SiLU) is saved for the backward.
  * bwd:  given dm [N,16] (row stride dm_ld floats, >= 16 and a multiple of 4): dab [N,2*Hp], dwd [Hp], dw2 [16,Hp], dpre2 [N,16,16], and db2 [16] = the sum
  *       of dpre2 over its first two axes (NULL: not wanted; overwritten, or added to with
- *       db2_accumulate != 0).  t_rowptr / t_perm: CSR of the transposed neighbour graph
+ *       db2_accumulate != 0; dwd / dw2 likewise with dw_accumulate != 0).  t_rowptr / t_perm: CSR of the transposed neighbour graph
  *       (hg_csr_build with key = nbr flattened, n_rows = N; entries are i*16+slot).
  * ------------------------------------------------------------------------------------------- */
 int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, const float* b2,
@@ -348,8 +348,8 @@ size_t egnn_edge_bwd_workspace_bytes(int64_t N, int32_t Hp);
 int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32_t* nbr,
                   const float* d2, const float* pre2, const float* dm, int64_t dm_ld, const int32_t* t_rowptr,
                   const int32_t* t_perm, int64_t N, int32_t Hp, float* dab, float* dwd, float* dw2,
-                  float* dpre2, float* db2, int32_t db2_accumulate, void* workspace, size_t workspace_bytes,
-                  void* stream);
+                  float* dpre2, float* db2, int32_t db2_accumulate, int32_t dw_accumulate, void* workspace,
+                  size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CSR-grouped small GEMMs — the Equiformer's radial tensor product (equiformer_layer.py:376-383:
