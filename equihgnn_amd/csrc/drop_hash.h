@@ -38,19 +38,31 @@ __device__ __forceinline__ uint32_t drop_hash(const DropKey& key, uint64_t pair)
     h ^= h >> 16;
     return h;
 }
-// keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = p * 2^32
+// Host side: the 32-bit threshold handed to the kernels.  Only its high 16 bits are compared (two decisions per hash), so
+// the drop probability IS round(p * 2^16) / 2^16: rounded to nearest (truncation biased every site low by up to 2^-16) and
+// never 0 for p > 0 (a tiny p used to drop nothing and still rescale by 1 / (1 - p)).  The kept elements are scaled by
+// exactly 1 / (1 - p), as torch.nn.functional.dropout does (fa_former_layer.py:20-21 uses nn.Dropout); the expectation is
+// off by at most 2^-17 / (1 - p) relative, below fp32 rounding of the sums it enters.
+__host__ __device__ static inline uint32_t drop_threshold(float p) {
+    if (!(p > 0.f)) return 0u;
+    long t16 = (long)((double)p * 65536.0 + 0.5);
+    t16 = t16 < 1 ? 1 : (t16 > 65535 ? 65535 : t16);
+    return (uint32_t)t16 << 16;
+}
+// keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = drop_threshold(p)
 __device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
     const uint32_t h = drop_hash(key, i >> 1);
     return (((i & 1) ? (h >> 16) : (h & 0xffffu)) >= (threshold >> 16)) ? inv_keep : 0.f;
 }
-// the same for the aligned pair (i, i + 1), i even: one hash
+// the same for the aligned pair (i, i + 1).  CONTRACT: i is EVEN (the pair shares one hash: an odd i would give element i the
+// decision of i - 1's partner); every caller indexes float2 / float4 groups of rows whose length is a multiple of 4.
 __device__ __forceinline__ void keep_scale2(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep, float& k0,
                                             float& k1) {
     const uint32_t h = drop_hash(key, i >> 1), t16 = threshold >> 16;
     k0 = (h & 0xffffu) >= t16 ? inv_keep : 0.f;
     k1 = (h >> 16) >= t16 ? inv_keep : 0.f;
 }
-// ... and for an aligned float4 (i a multiple of 4): v *= keep, two hashes
+// ... and for an aligned float4.  CONTRACT: i is a MULTIPLE OF 4.  v *= keep, two hashes
 __device__ __forceinline__ void keep_scale4(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep, float4& v) {
     float k0, k1, k2, k3;
     keep_scale2(key, i, threshold, inv_keep, k0, k1);

@@ -197,7 +197,7 @@ int ew_check(int64_t R, int32_t C, float p) {
     if (C & 3) return EQH_ERR_ALIGN;
     return EQH_OK;
 }
-inline uint32_t ew_threshold(float p) { return p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u; }
+inline uint32_t ew_threshold(float p) { return drop_threshold(p); }
 
 }  // namespace
 

@@ -315,7 +315,7 @@ k_attn_logits_fwd(const float* __restrict__ qa, const float* __restrict__ qan, c
     float a = pr;
     if (p > 0.f) {
         const DropKey key = drop_key((uint64_t)seed[0]);
-        a = pr * keep_scale(key, (uint64_t)o, (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p));
+        a = pr * keep_scale(key, (uint64_t)o, drop_threshold(p), 1.0f / (1.0f - p));
         prob[o] = pr;
     }
     attn[o] = a;
@@ -339,7 +339,7 @@ k_attn_logits_bwd(const float* __restrict__ prob, const float* __restrict__ datt
         dp = dattn[o];
         if (p > 0.f) {
             const DropKey key = drop_key((uint64_t)seed[0]);
-            dp *= keep_scale(key, (uint64_t)o, (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p));
+            dp *= keep_scale(key, (uint64_t)o, drop_threshold(p), 1.0f / (1.0f - p));
         }
     }
     const float inner = group16_sum(pr * dp);

@@ -43,7 +43,8 @@ class HgConvPanel(ctypes.Structure):
                 + [(n, c_void_p) for n in ("in0", "in1", "in2", "in3")] + [("ld0", c_int64)]
                 + [(n, c_void_p) for n in ("rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
                                            "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2",
-                                           "acc_out", "dbias", "dgamma", "dbeta", "dbias2", "dgamma2", "dbeta2")])
+                                           "acc_out", "dbias", "dgamma", "dbeta", "dbias2", "dgamma2", "dbeta2")]
+                + [("g_inc", c_void_p), ("be_inc", c_void_p), ("eps_inc", c_float), ("out6", c_void_p)])
 
 
 HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1, HG_EGNN_NODE_F, HG_EGNN_NODE_B = 1, 2, 3, 4, 5, 6, 7
@@ -52,6 +53,7 @@ HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1, HG_EGNN_NODE_F, HG_E
 SIGNATURES = {
     "hg_conv_panel_slab_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_conv_panel": (c_int32, [c_int32, ctypes.POINTER(HgConvPanel), c_void_p]),
+    "hg_panel_waves": (c_int32, []),
     "hg_panel_pack_bytes": (c_size_t, [c_int32, c_int32]),
     "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),
     "hg_panel_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_float, c_void_p, c_int64, c_float,

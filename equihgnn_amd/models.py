@@ -24,7 +24,7 @@ def _conv_layers(model, x, index, x0, res, fuse_act, taps):
     dropout, ``All_num_layers`` times.  With the merged residual, an inactive dropout and the ReLU fused, all applications
     run as ONE autograd node on the row-panel kernels (MHNNSConv.forward_stack)."""
     drop_off = not (model.dropout.training and model.dropout.p > 0)
-    if fuse_act and taps is None and drop_off and model.conv.stack_supported(x, res):
+    if model.nlayer >= 1 and fuse_act and taps is None and drop_off and model.conv.stack_supported(x, res):
         return model.conv.forward_stack(x, index, res, model.nlayer, relu_out=True)
     for i in range(model.nlayer):
         x = model.conv(model.dropout(x), index, x0, res, relu_out=fuse_act)

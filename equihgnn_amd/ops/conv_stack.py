@@ -15,9 +15,11 @@ from .. import hip
 from ._base import (LINEAR_PARAMS, _acc_target, _f32c, _note_acc, _ptr, _require_gpu, _stream, _workspace, timed)
 from .aggregate import entry_weights
 from .grads import (_linear_weight_grad, _wgrad_deferred, colsum)
+from .rows import inc_fwd_col_bytes
 from .panel import (conv_panel, conv_panel_slab, panel_gemm, panel_pack, panel_supported)
 
 FOLD_B2 = not os.environ.get("EQH_NO_B2_FOLD")     # dhbar = dqb w12 inside B1 (after its gather) instead of a launch of its own
+FOLD_INC = not os.environ.get("EQH_NO_INC_FOLD")   # the incidence aggregation (k_inc_fwd_col) as the prologue of F3 instead of a launch
 USE_CONV_STACK = not os.environ.get("EQH_NO_CONV_STACK")     # tests switch it off to compare with the unfused path
 
 
@@ -69,17 +71,23 @@ class _MergedConvStack(torch.autograd.Function):
             timed("k_conv_f2", flops(M, 1), lambda: conv_panel(hip.HG_CONV_F2, M, C, dev, in0=h1n, rowptr=ix.by_e.rowptr,
                                                                col=ix.by_e.col, w0=iw12, bias_out=b12, out0=hbar, out1=qb))
             by_v = ix.by_v
-            work = 4 * C * (2 * by_v.nnz + N) + 12 * by_v.nnz + 4 * (N + 1) + 8 * C
-            timed("k_inc_fwd_col", work, lambda: hip.check(L_.hg_incidence_ln_reduce_fwd_col(
-                _ptr(pa), _ptr(qb), _ptr(by_v.rowptr), _ptr(by_v.col), 1, _ptr(g2), _ptr(be2), N, C, 1, float(eps[1]), _ptr(s),
-                _stream(dev)), "hg_incidence_ln_reduce_fwd_col"))
             tail = l + 1 < L
             u, x3, xn = new(N), new(N), new(N)
             nh1, nh1n, npa = (new(N), new(N), new(N)) if tail else (None, None, None)
-            timed("k_conv_f3", flops(N, 4 if tail else 2), lambda: conv_panel(
-                hip.HG_CONV_F3, N, C, dev, eps=eps[2], scale=scale, relu=relu_out, tail=tail, in0=s, in1=cw, w0=iw23, b0=b3a, g0=g3,
-                be0=be3, w1=iW3b, bias_out=b3b, out0=u, out1=x3, out2=xn, w2=iW1a, w3=iW2v, b1=b1a, g1=g1, be1=be1, out3=nh1,
-                out4=nh1n, out5=npa))
+            f3 = dict(eps=eps[2], scale=scale, relu=relu_out, tail=tail, in1=cw, w0=iw23, b0=b3a, g0=g3, be0=be3, w1=iW3b,
+                      bias_out=b3b, out0=u, out1=x3, out2=xn, w2=iW1a, w3=iW2v, b1=b1a, g1=g1, be1=be1, out3=nh1, out4=nh1n,
+                      out5=npa)
+            if FOLD_INC:
+                # the per-incidence hidden layer + hyperedge -> node mean (conv.py:175-177) is F3's prologue: s is written for
+                # the backward pass, never read back
+                timed("k_conv_f3", flops(N, 4 if tail else 2), lambda: conv_panel(
+                    hip.HG_CONV_F3, N, C, dev, in0=pa, in2=qb, rowptr=by_v.rowptr, col=by_v.col, g_inc=g2, be_inc=be2,
+                    eps_inc=eps[1], out6=s, **f3))
+            else:
+                timed("k_inc_fwd_col", inc_fwd_col_bytes(by_v.nnz, N, C), lambda: hip.check(L_.hg_incidence_ln_reduce_fwd_col(
+                    _ptr(pa), _ptr(qb), _ptr(by_v.rowptr), _ptr(by_v.col), 1, _ptr(g2), _ptr(be2), N, C, 1, float(eps[1]), _ptr(s),
+                    _stream(dev)), "hg_incidence_ln_reduce_fwd_col"))
+                timed("k_conv_f3", flops(N, 4 if tail else 2), lambda: conv_panel(hip.HG_CONV_F3, N, C, dev, in0=s, **f3))
             saved.append((x_in, h1, hbar, pa, qb, s, u, x3, xn))
             x_in = xn
             if tail:

@@ -86,14 +86,15 @@ def panel_gemm(a, wpack, C: int, alpha: float = 1.0, d=None, beta: float = 1.0, 
 
 _CP_PTRS = ("in0", "in1", "in2", "in3", "rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
             "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2", "acc_out", "dbias", "dgamma", "dbeta",
-            "dbias2", "dgamma2", "dbeta2")
+            "dbias2", "dgamma2", "dbeta2", "g_inc", "be_inc", "out6")
 
 
 def conv_panel(stage: int, rows: int, C: int, device, eps: float = 1e-5, scale: float = 1.0, relu: bool = False,
-               acc_first: bool = False, tail: bool = False, accumulate: bool = False, ld0: int = 0, **tensors):
+               acc_first: bool = False, tail: bool = False, accumulate: bool = False, ld0: int = 0, eps_inc: float = 1e-5,
+               **tensors):
     """One hg_conv_panel stage (include/equihgnn_hip.h lists the operands of each); ``tensors``: name -> device tensor or None."""
     a = hip.HgConvPanel()
-    a.rows, a.C, a.eps, a.scale = rows, C, float(eps), float(scale)
+    a.rows, a.C, a.eps, a.scale, a.eps_inc = rows, C, float(eps), float(scale), float(eps_inc)
     a.relu, a.acc_first, a.tail, a.accumulate, a.ld0 = int(relu), int(acc_first), int(tail), int(accumulate), int(ld0)
     for k, t in tensors.items():
         if k not in _CP_PTRS:

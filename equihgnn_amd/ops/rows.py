@@ -15,6 +15,19 @@ from .products import (mm_nn, mm_nt)
 from .grads import (_wgrad_deferred, _wgrad_ok, colsum, wgrad)
 
 
+def inc_fwd_bytes(nnz: int, rows: int, C: int) -> int:
+    """Algorithmic bytes of k_inc_fwd (generic form): two gathered rows per incidence + one output row, three index words
+    per incidence, the rowptr, gamma and beta."""
+    return 4 * C * (2 * nnz + rows) + 12 * nnz + 4 * (rows + 1) + 8 * C
+
+
+def inc_fwd_col_bytes(nnz: int, rows: int, C: int) -> int:
+    """Algorithmic bytes of k_inc_fwd_col: the row operand is fetched ONCE per output row
+    (incidence.hip: own row read before the entry loop), one gathered row per incidence, one output row; the col word of
+    every incidence, the rowptr, gamma and beta: 4C (nnz + 2R) + 4 nnz + 4 (R + 1) + 8C."""
+    return 4 * C * (nnz + 2 * rows) + 4 * nnz + 4 * (rows + 1) + 8 * C
+
+
 class _IncidenceLnReduce(torch.autograd.Function):
     """S[r] = reduce_{p in row r} LayerNorm(relu(pa[ia[p]] + qb[ib[p]])) — one launch instead of
     gather, gather, add, ReLU, LayerNorm, segmented reduce (csrc/incidence.hip)."""
@@ -26,16 +39,14 @@ class _IncidenceLnReduce(torch.autograd.Function):
         pa, qb, gamma, beta = _f32c(pa), _f32c(qb), _f32c(gamma), _f32c(beta)
         C = pa.shape[1]
         out = torch.empty((out_csr.n_rows, C), dtype=torch.float32, device=pa.device)
-        # algorithmic bytes: two gathered rows per incidence + one output row, three index words per incidence, rowptr
-        work = 4 * C * (2 * out_csr.nnz + out_csr.n_rows) + 12 * out_csr.nnz + 4 * (out_csr.n_rows + 1) + 8 * C
         if okey32 is ia32 or okey32 is ib32:
             # the output row is one operand's own index: (rowptr, col) of the output CSR says it all
-            timed("k_inc_fwd_col", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(
+            timed("k_inc_fwd_col", inc_fwd_col_bytes(out_csr.nnz, out_csr.n_rows, C), lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(
                 _ptr(pa), _ptr(qb), _ptr(out_csr.rowptr), _ptr(out_csr.col), 1 if okey32 is ia32 else 0, _ptr(gamma),
                 _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
                 "hg_incidence_ln_reduce_fwd_col"))
         else:
-            timed("k_inc_fwd", work, lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
+            timed("k_inc_fwd", inc_fwd_bytes(out_csr.nnz, out_csr.n_rows, C), lambda: hip.check(hip.lib().hg_incidence_ln_reduce_fwd(
                 _ptr(pa), _ptr(qb), _ptr(ia32), _ptr(ib32), _ptr(out_csr.rowptr), _ptr(out_csr.perm), _ptr(gamma),
                 _ptr(beta), out_csr.n_rows, C, 1 if mean else 0, float(eps), _ptr(out), _stream(pa.device)),
                 "hg_incidence_ln_reduce_fwd"))

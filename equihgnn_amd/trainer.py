@@ -498,12 +498,19 @@ class GraphedEvalStep:
     pass is bound by Python launch issue (4-6 x the replayed time), exactly like the eager training step.  Batches must be
     padded to bucket extents (``batch.pad_batch`` / ``fit.BucketedLoader``); the returned predictions are a STATIC tensor,
     valid until the next call (rows past ``num_real_graphs`` are padding).  The graphs read the parameters and buffers in
-    place, so they follow the optimiser and ``load_state_dict`` without re-capture -- but they must be captured after a
-    GraphedTrainStep has moved the parameters into its flat buffer (``Fitter`` builds this lazily at the first evaluation)."""
+    place, so they follow the optimiser and ``load_state_dict`` without re-capture.  A captured graph holds the ADDRESSES of
+    the parameters and buffers: every call compares them with the ones recorded at capture, and when they have moved (a
+    GraphedTrainStep's bootstrap re-seats ``p.data`` into its flat buffer; ``model.to`` / a re-seated BatchNorm buffer) the
+    stale graphs are dropped and the bucket is captured again instead of replaying reads of freed storage."""
 
     def __init__(self, model: nn.Module):
         self.model = model
         self.slots = {}
+        self.addresses = None
+        self.recaptures = 0
+
+    def _addresses(self):
+        return tuple(t.data_ptr() for t in self.model.parameters()) + tuple(t.data_ptr() for t in self.model.buffers())
 
     def close(self):
         self.slots = {}
@@ -527,6 +534,12 @@ class GraphedEvalStep:
         if self.model.training:
             raise RuntimeError("GraphedEvalStep: put the model in eval mode first (the captured graphs are eval-mode forwards)")
         key = GraphedTrainStep._key(data)
+        addr = self._addresses()
+        if addr != self.addresses:
+            if self.slots:
+                self.recaptures += 1
+            self.slots = {}
+            self.addresses = addr
         slot = self.slots.get(key)
         if slot is None:
             if hasattr(data, "packed"):

@@ -203,9 +203,18 @@ typedef struct {
     float *out0, *out1, *out2, *out3, *out4, *out5;
     float *slab, *slab2, *acc_out;
     float *dbias, *dgamma, *dbeta, *dbias2, *dgamma2, *dbeta2;
+    /* HG_CONV_F3 with rowptr != NULL (round 5): the per-incidence hidden layer + hyperedge -> node mean of conv.py:175-177
+     * (hg_incidence_ln_reduce_fwd_col's arithmetic) runs as the stage's prologue: in0 = pa [N, C], in2 = qb [M, C],
+     * rowptr / col = incidence CSR by node, g_inc / be_inc / eps_inc = that LayerNorm; out6 = s [N, C] (written). */
+    const float *g_inc, *be_inc;
+    float eps_inc;
+    float* out6;
 } HgConvPanel;
 size_t hg_conv_panel_slab_bytes(int64_t rows, int32_t C);
 int hg_conv_panel(int32_t stage, const HgConvPanel* args, void* stream);
+/* wavefronts per panel workgroup the library launches (8; 4 with EQH_PANEL_WAVES=4 in the environment: round 4's geometry,
+ * kept for same-box A/B measurements) */
+int32_t hg_panel_waves(void);
 
 /* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
  * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch

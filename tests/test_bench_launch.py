@@ -57,7 +57,7 @@ def test_two_ranks_with_the_roofline_measurement():
     r = _bench(["--gpus", "2"] + args, {"EQH_BACKEND": "gloo"}, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["roofline"]["launches_per_step"] == 6 and 0 < line["roofline"]["frac"] < 1
+    assert line["n_gpus"] == 2 and line["roofline"]["launches_per_step"] == 3 and 0 < line["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu

@@ -360,3 +360,39 @@ def test_graphed_evaluation_matches_eager_evaluation(method):
         assert np.isfinite(m_graph["test_mae_mean"]) and np.isfinite(m_eager["test_mae_mean"])
         assert float(np.abs(t_eager[:, 0]).std()) > 1e-3
     train.close()
+
+
+@pytest.mark.gpu
+def test_graphed_evaluation_before_the_first_training_step_is_recaptured():
+    """An evaluation BEFORE the graphed trainer's bootstrap step (Fitter.test on a loaded checkpoint, an evaluation ahead of
+    training) captures graphs that hold the parameters' pre-flatten addresses; the bootstrap then re-seats every p.data into
+    the flat buffer.  GraphedEvalStep notices the moved addresses, drops the stale graphs and captures again: the next
+    evaluation follows the trained parameters (it used to replay reads of the old storage and return the old predictions)."""
+    from equihgnn_amd.batch import MolStore
+    from equihgnn_amd.fit import BucketedLoader
+    from equihgnn_amd.models import MODELS
+    from equihgnn_amd.trainer import GraphedTrainStep
+    torch.manual_seed(0)
+    mols = _mols(16 * 6, 33)
+    args = default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32)
+    model = MODELS["egnn_equihnns"](1, args).to("cuda:0")
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear):
+            torch.nn.init.normal_(m.weight, std=m.in_features ** -0.5)
+    fitter = Fitter(model, lr=1e-2, step_factory=GraphedTrainStep)
+    store = MolStore(mols)
+    train = BucketedLoader(store, 16, True, seed=0, device="cuda:0")
+    evald = BucketedLoader(store, 16, False, device="cuda:0")
+    assert fitter.step.pflat is None                               # nothing has been flattened yet
+    _, t_before = fitter.test(evald)                              # captured on the pre-flatten parameter addresses
+    assert fitter.eval_step is not None and fitter.eval_step.recaptures == 0
+    for b in train:
+        fitter.step.step(b)                                       # bootstrap (re-seats p.data) + capture + replays
+    assert fitter.step.pflat is not None
+    _, t_graph = fitter.test(evald)
+    assert fitter.eval_step.recaptures == 1
+    fitter.graph_eval = False
+    _, t_eager = fitter.test(evald)
+    np.testing.assert_allclose(t_graph, t_eager, rtol=1e-5, atol=1e-5)
+    assert float(np.abs(t_graph[:, 0] - t_before[:, 0]).max()) > 1e-3          # training at lr 1e-2 did move the predictions
+    train.close()

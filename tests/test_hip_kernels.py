@@ -1889,6 +1889,50 @@ def test_conv_panel_forward_stages_match_float64(C, n_nodes, n_he):
             assert torch.allclose(d(h1nb), _ln64(torch.relu(d(h1b) + d(P["b1a"])), d(P["g1"]), d(P["be1"])), rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("C,n_nodes,n_he", [(256, 1000, 1100), (64, 333, 350), (128, 97, 64)])
+def test_conv_f3_incidence_prologue_matches_float64_and_the_separate_launch(C, n_nodes, n_he):
+    """HG_CONV_F3 with the incidence aggregation as its prologue (conv.py:175-177: s[v] = gamma2 mean_e xhat(relu(pa[v] +
+    qb[e])) + beta2 over the node's hyperedges; nodes without one get 0): s against float64 and against
+    hg_incidence_ln_reduce_fwd_col, the products behind it against the stage fed with that s from memory."""
+    from equihgnn_amd import hip, ops
+    P, X, cw, v, e, by_e, by_v = _conv_panel_case(C, n_nodes, n_he, 13)
+    d = lambda t: t.double()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    pa, qb = torch.randn(n_nodes, C, device=DEV, generator=g), torch.randn(n_he, C, device=DEV, generator=g)
+    g2, be2 = 1 + 0.2 * torch.randn(C, device=DEV, generator=g), 0.2 * torch.randn(C, device=DEV, generator=g)
+    iw23, iW3b = ops.panel_pack([(P["w23"], True), (P["W3b"], True)])
+    new = lambda r: torch.empty(r, C, device=DEV)
+    # float64: xhat per incidence, mean per node, gamma / beta after the mean (beta only where the node has an incidence)
+    h = torch.relu(d(pa)[v] + d(qb)[e])
+    xh = (h - h.mean(-1, keepdim=True)) / torch.sqrt(((h - h.mean(-1, keepdim=True)) ** 2).mean(-1, keepdim=True) + 1e-5)
+    cnt = torch.bincount(v, minlength=n_nodes).double()
+    s64 = torch.zeros(n_nodes, C, device=DEV, dtype=torch.float64).index_add_(0, v, xh) / cnt.clamp(min=1)[:, None]
+    s64 = s64 * d(g2) + d(be2) * (cnt > 0)[:, None]
+    s_sep = new(n_nodes)
+    hip.check(hip.lib().hg_incidence_ln_reduce_fwd_col(ops._ptr(pa), ops._ptr(qb), ops._ptr(by_v.rowptr), ops._ptr(by_v.col), 1,
+                                                       ops._ptr(g2), ops._ptr(be2), n_nodes, C, 1, 1e-5, ops._ptr(s_sep),
+                                                       ops._stream(torch.device(DEV))), "fwd_col")
+    outs = {}
+    for fold in (True, False):
+        s, u, x3, xn = new(n_nodes), new(n_nodes), new(n_nodes), new(n_nodes)
+        kw = dict(scale=0.5, relu=True, tail=False, in1=cw, w0=iw23, b0=P["b3a"], g0=P["g3"], be0=P["be3"], w1=iW3b,
+                  bias_out=P["b3b"], out0=u, out1=x3, out2=xn)
+        if fold:
+            ops.conv_panel(hip.HG_CONV_F3, n_nodes, C, DEV, in0=pa, in2=qb, rowptr=by_v.rowptr, col=by_v.col, g_inc=g2, be_inc=be2,
+                           eps_inc=1e-5, out6=s, **kw)
+        else:
+            ops.conv_panel(hip.HG_CONV_F3, n_nodes, C, DEV, in0=s_sep, **kw)
+            s = s_sep
+        outs[fold] = (s, u, x3, xn)
+    s = outs[True][0]
+    assert bool((cnt == 0).any())                                     # the case has nodes without a hyperedge
+    assert torch.allclose(d(s), s64, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(s, s_sep, rtol=1e-5, atol=2e-6)
+    assert torch.allclose(d(outs[True][1]), 0.5 * (d(s) @ d(P["w23"]).t()) + d(cw), rtol=1e-5, atol=1e-5)
+    for a, b in zip(outs[True][1:], outs[False][1:]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=5e-5)
+
+
 @pytest.mark.parametrize("C,n_nodes,n_he", [(256, 1000, 1100), (64, 333, 350)])
 def test_conv_panel_backward_stages_match_autograd_float64(C, n_nodes, n_he):
     """HG_CONV_B3 / B1 (and B1 with the chained B3 tail) against float64 autograd of the same formulas; the LayerNorm vector

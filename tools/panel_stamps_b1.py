@@ -42,7 +42,7 @@ def main():
     slab1, slab2 = ops.conv_panel_slab(N, C, dev), ops.conv_panel_slab(N, C, dev)
     v1, v3 = torch.zeros(3, C, device=dev), torch.zeros(3, C, device=dev)
     nb = (N + 31) // 32
-    buf = torch.zeros(nb * 4 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nb * 8 * 16, dtype=torch.int64, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     a = hip.HgConvPanel()
     a.rows, a.C, a.eps, a.scale, a.tail, a.acc_first = N, C, 1e-5, 0.5, 1, 0
@@ -59,13 +59,20 @@ def main():
     assert L.hg_panel_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
     assert run() == 0
     torch.cuda.synchronize()
-    st = buf.cpu().numpy().reshape(nb, 4, 8).astype(np.int64)
+    nw = int(L.hg_panel_waves())
+    st = buf.cpu().numpy().reshape(nb, 8, 16).astype(np.int64)[:, :nw, :]
+    print(f"wavefronts per panel: {nw}")
     med = lambda x: float(np.median(x))
     names = ["prime w12, load h / dpa, gather dqb sums", "a_put + product w12 + staging", "prime stacked, LN1 bwd, a_put x 2",
              "barrier + stacked product (K = 512) + staging", "dX tile, slab 1", "tail: B3 (2 products, LN3 bwd, slab 2)"]
     for i, n in enumerate(names):
         print(f"  {n:46s}: {med(st[:, :, i + 1] - st[:, :, i]):8.0f}")
     print(f"  {'total':46s}: {med(st[:, :, 6] - st[:, :, 0]):8.0f}")
+    tail = [(5, 8, "tail: prime W3b, load u / mask, a_put"), (8, 9, "barrier + product W3b + staging"), (9, 10, "prime w23 + barrier"),
+            (10, 11, "LN3 bwd, stores, acc_out, a_put"), (11, 12, "barrier + product w23 + staging"), (12, 13, "barrier + ds store"),
+            (13, 6, "slab 2")]
+    for a_, b_, n in tail:
+        print(f"    {n:44s}: {med(st[:, :, b_] - st[:, :, a_]):8.0f}")
 
 
 if __name__ == "__main__":

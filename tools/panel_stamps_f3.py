@@ -31,7 +31,7 @@ def main():
     i23, i3b = ops.panel_pack([(w23, True), (w3b, True)])
     u, x3, xn = torch.empty_like(s_), torch.empty_like(s_), torch.empty_like(s_)
     nb = (rows + 31) // 32
-    buf = torch.zeros(nb * 4 * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nb * 8 * 16, dtype=torch.int64, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     a = hip.HgConvPanel()
     a.rows, a.C, a.eps, a.scale, a.relu, a.tail = rows, C, 1e-5, 0.5, 1, 0
@@ -45,13 +45,15 @@ def main():
     assert L.hg_panel_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
     assert run() == 0
     torch.cuda.synchronize()
-    st = buf.cpu().numpy().reshape(nb, 4, 8).astype(np.int64)
+    nw = int(L.hg_panel_waves())
+    st = buf.cpu().numpy().reshape(nb, 8, 16).astype(np.int64)[:, :nw, :]
+    print(f"wavefronts per panel: {nw}")
     med = lambda x: float(np.median(x))
     names = ["rows loaded, split, A image", "barrier", "MFMA 1", "staging + prime + barrier", "row phase (LN, stores, split)", "barrier",
-             "MFMA 2 + staging"]
+             "MFMA 2 + staging", "barrier + bias / ReLU + store"]
     for i, n in enumerate(names):
         print(f"  {n:34s}: {med(st[:, :, i + 1] - st[:, :, i]):8.0f}")
-    print(f"  {'stamp 0 -> 7':34s}: {med(st[:, :, 7] - st[:, :, 0]):8.0f}")
+    print(f"  {'stamp 0 -> 8':34s}: {med(st[:, :, 8] - st[:, :, 0]):8.0f}")
 
 
 if __name__ == "__main__":
