@@ -394,6 +394,25 @@ def pmc_traffic(method, batch, flavour, kernel_names):
     return None, None
 
 
+def panel_prologues(method, batch, flavour):
+    """The gather prologues of the panel kernels (k_conv_f2: gathered mean; k_conv_f3: per-incidence hidden layer + mean;
+    k_conv_b1: weighted gather of the backward) are aggregation work that has no launch of its own, so device stamps around
+    launches cannot see it: tools/panel_prologues.py brackets each prologue with s_memtime stamps inside a -DPN_STAMPS build
+    and commits profiles/r*_panel_prologue.json; the newest file whose workload matches THIS run is reported (never a
+    constant in this file)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_panel_prologue.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        wl = d.get("workload", {})
+        if (wl.get("method"), wl.get("batch"), wl.get("flavour")) == (method, batch, flavour):
+            d["source"] = os.path.relpath(path, ROOT) + " (tools/panel_prologues.py: in-kernel s_memtime stamps, offline)"
+            return d
+    return None
+
+
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
@@ -816,6 +835,23 @@ def main():
             result["roofline"]["traffic"] = traffic
             if traffic is not None:
                 result["roofline"]["traffic_source"] = src
+            pp = panel_prologues(a.method, a.batch, a.flavour) if "k_conv_f2" in per else None
+            if pp is not None:
+                # the aggregation work inside the panel launches, next to the stamped launches: bytes / time over both
+                rk = result["roofline"]
+                rk["kernels"]["panel_prologue"] = {"kernels": pp["kernels"], "all": pp["all"], "source": pp["source"],
+                                                   "wavefronts_per_panel": pp.get("wavefronts_per_panel")}
+                b_in = sum(v["alg_bytes_per_launch"] * v["launches_per_step"] for k_, v in rk["kernels"].items() if k_ != "panel_prologue")
+                us_in = sum(v["avg_launch_us"] * v["launches_per_step"] for k_, v in rk["kernels"].items() if k_ != "panel_prologue")
+                b_pp = sum(v["alg_bytes_per_launch"] * v["launches_per_step"] for v in pp["kernels"].values())
+                us_pp = sum(v["prologue_us"] * v["launches_per_step"] for v in pp["kernels"].values())
+                if us_in + us_pp > 0:
+                    gbs = (b_in + b_pp) / (us_in + us_pp) / 1e3
+                    rk["including_panel_prologues"] = {
+                        "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "us_per_step": round(us_in + us_pp, 1), "alg_bytes_per_step": int(b_in + b_pp),
+                        "what": "every node <-> hyperedge aggregation of the step: the stamped launches above (live) + the gather "
+                                "prologues of k_conv_f2 / k_conv_f3 / k_conv_b1 (stamped offline)"}
             if "k_gemm_x6" in per:      # the dense products that run on the bf16 matrix cores (csrc/gemm_x6.hip)
                 gx = per["k_gemm_x6"]
                 tf = gx["work"] / gx["us"] / 1e6
@@ -839,9 +875,10 @@ def main():
                     "bound": "mfma", "unit": "TFLOP/s (2 M N K per second)", "peak": round(BF16_MFMA_PEAK_TFLOPS / 6, 1),
                     "launches_per_step": sum(v["launches_per_step"] for v in pk.values()), "us": round(tot_us, 1),
                     "achieved": round(tot_f / tot_us / 1e6, 1), "frac": round(tot_f / tot_us / 1e6 / (BF16_MFMA_PEAK_TFLOPS / 6), 4),
-                    "note": "32-row panels: ~150 workgroups on 256 CUs at the BASELINE batch, each streaming the whole [C x C] weight "
-                            "image (384 KB) through its CU's vector memory path per product -- that and the 192 MFMAs per wavefront "
-                            "(2.6 us) bound a product; LayerNorm / gather / split phases between products do not overlap them",
+                    "note": "32-row panels, 8 wavefronts each: ~150 workgroups on 256 CUs at the BASELINE batch, each streaming the "
+                            "whole [C x C] weight image (384 KB) through its CU's vector memory path per product -- that and the 192 "
+                            "MFMAs per SIMD (2.6 us) bound a product; the row phases between products (split into bf16 planes, "
+                            "LayerNorm, gathers) are bound by the same 148 CUs' VALU and vector-memory rate (DESIGN.md section 4)",
                     "kernels": pk}
             mf = {}
             for name in ("k_rowgemm_fwd", "k_rowgemm_bwd"):     # Equiformer's radial tensor product (fp32 MFMA)
@@ -864,7 +901,9 @@ def main():
                 edge["bound"] = "mfma"
                 result["roofline"]["edge_kernels"] = edge
             if world == 1:
-                result["roofline"]["back_to_back"] = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
+                b2b = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
+                if b2b["launches"] > 0:      # (methods on the merged conv path launch no plain k_segment_reduce: nothing to report)
+                    result["roofline"]["back_to_back"] = b2b
                 result["roofline"]["saturation"] = saturation_probe(dev)
                 result["roofline"]["saturation"]["fused_kernels"] = fused_saturation(dev)
         if not a.no_pipeline and use_graph and world == 1:

@@ -47,6 +47,15 @@ class HgConvPanel(ctypes.Structure):
                 + [("g_inc", c_void_p), ("be_inc", c_void_p), ("eps_inc", c_float), ("out6", c_void_p)])
 
 
+class HbCollate(ctypes.Structure):
+    """HbCollate of include/equihgnn_hip.h (operands of hb_collate, the host-side batch assembly)."""
+    _fields_ = ([("B", c_int64), ("n_mols", c_int64)]
+                + [(n, c_void_p) for n in ("idx", "node_off", "he_off", "inc_off", "x", "pos", "v", "e", "edge_attr", "e_order", "y")]
+                + [("PN", c_int64), ("PM", c_int64), ("PZ", c_int64), ("padded", c_int32)]
+                + [(n, c_void_p) for n in ("out_x", "out_pos", "out_edge_index0", "out_edge_index1", "out_edge_attr", "out_n_e",
+                                           "out_e_order", "out_batch", "out_y", "out_counts")])
+
+
 HG_CONV_F1, HG_CONV_F2, HG_CONV_F3, HG_CONV_B3, HG_CONV_B1, HG_EGNN_NODE_F, HG_EGNN_NODE_B = 1, 2, 3, 4, 5, 6, 7
 
 # name -> (restype, argtypes); mirrors include/equihgnn_hip.h one to one
@@ -54,6 +63,7 @@ SIGNATURES = {
     "hg_conv_panel_slab_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_conv_panel": (c_int32, [c_int32, ctypes.POINTER(HgConvPanel), c_void_p]),
     "hg_panel_waves": (c_int32, []),
+    "hb_collate": (c_int32, [ctypes.POINTER(HbCollate)]),
     "hg_panel_pack_bytes": (c_size_t, [c_int32, c_int32]),
     "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),
     "hg_panel_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_float, c_void_p, c_int64, c_float,

@@ -216,6 +216,32 @@ int hg_conv_panel(int32_t stage, const HgConvPanel* args, void* stream);
  * kept for same-box A/B measurements) */
 int32_t hg_panel_waves(void);
 
+/* Host-side batch assembly (no device work, no stream): molecules idx[0..B) of a structure-of-arrays dataset -- concatenated
+ * fields plus per-molecule offsets [n_mols + 1], as batch.MolStore and a PyG InMemoryDataset file hold them -- written as one
+ * batch with the HData.__inc__ offsets (data/utils.py:172-178; what main.py:227-229's DataLoader collate produces): node rows
+ * x [., 9] int64 / pos [., 3] f32, incidences v / e (LOCAL node / hyperedge ids, shifted here), hyperedge rows edge_attr [., 1] /
+ * e_order, y per molecule.  padded != 0: outputs have PN / PM / PZ rows and B + 1 molecules; one dummy molecule owns the
+ * padding (atoms 10 A apart on a line 10^4 A away, incidences -1: dropped by hg_csr_build) exactly as batch.pad_batch does;
+ * PN > N, PM > M, PZ >= Z required.  out_counts[3] = N, M, Z of the real molecules.  Replaces the per-molecule Python collate
+ * of torch_geometric's Batch.from_data_list on the loader thread of every rank. */
+typedef struct {
+    int64_t B, n_mols;
+    const int64_t* idx;
+    const int64_t *node_off, *he_off, *inc_off;
+    const int64_t* x;
+    const float* pos;
+    const int64_t *v, *e, *edge_attr, *e_order;
+    const float* y;
+    int64_t PN, PM, PZ;
+    int32_t padded;
+    int64_t* out_x;
+    float* out_pos;
+    int64_t *out_edge_index0, *out_edge_index1, *out_edge_attr, *out_n_e, *out_e_order, *out_batch;
+    float* out_y;
+    int64_t* out_counts;
+} HbCollate;
+int hb_collate(const HbCollate* args);
+
 /* Measurement aid (bench.py, not used by the models): eqh_stamp stores the device's constant-rate wall clock into
  * *slot (uint64, device memory) from a one-thread kernel on `stream` -- capturable, so two stamps around a launch
  * time it INSIDE a replayed hipGraph; eqh_wall_clock_khz is that clock's rate. */

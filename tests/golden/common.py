@@ -114,6 +114,10 @@ CASE_TABLE = {
 TRAJECTORY_TABLE = {
     "trajectory_egnn_equihnns_c64": ("egnn_equihnns", 64, 81, 6, 3, 1e-3),
     "trajectory_mhnnm_c64": ("mhnnm", 64, 85, 6, 3, 1e-3),
+    # round 5: seed 107 keeps every ReLU input of all three steps >= 2.4e-5 rms from its kink on the reference (the widest of
+    # seeds 101-116, `make_golden.py --scan trajectory_egnn_equihnns_c64 101 ... 116`); the DEFAULT (panel) path is held to the
+    # tight bounds on it -- seed 81 above, whose margin is 1e-5, stays as the documented kink case
+    "trajectory_egnn_equihnns_c64_b": ("egnn_equihnns", 64, 107, 6, 3, 1e-3),
 }
 
 
@@ -126,6 +130,41 @@ LAYER_TABLE = {
     "equiformer_layer_depth1_c32": (32, 1, 92, 44),
     "equiformer_layer_depth3_c64": (64, 3, 93, 70),
 }
+
+
+# Gradients pinned to the REFERENCE ITSELF in float64 (round 5): the reference's own model class, `.double()`, on the case's
+# batch with float64 coordinates / targets -- the rounding-free value of the reference's algorithm, so the HIP path is held
+# to 5e-5 of the largest gradient entry against the reference (not against this repo's oracle) and the 1e-2 fp32 tolerance
+# of the hidden-256 / FAFormer cases is retired.  A float32 evaluation reproduces a gradient only while no ReLU input lies
+# within its rounding distance (~1e-6 rms) of zero, so the seeds are the first ones from `seed0` on whose closest ReLU
+# input (measured ON THE REFERENCE in float64, make_golden._ReluMargin) is at least F64_MIN_MARGIN rms away from the kink
+# (`make_golden.py --scan-f64` prints the scan); the chosen seed is part of the row.
+# name: (method, hidden, seed, n_mols, train_mode, options)
+F64_MIN_MARGIN = 1e-5
+F64_TABLE = {
+    "egnn_equihnns_c256_f64": ("egnn_equihnns", 256, 2330, 5, True, dict(last_conj=False)),
+    "mhnnm_c256_train_f64": ("mhnnm", 256, 1309, 4, True, dict(last_conj=False)),
+    "equiformer_equihnns_c256_f64": ("equiformer_equihnns", 256, 3301, 2, True, dict(last_conj=False)),
+    "faformer_equihnns_c256_f64": ("faformer_equihnns", 256, 5304, 2, False, {}),
+    "egnn_equihnns_pcqm_c256_f64": ("egnn_equihnns", 256, 6209, 4, True, dict(flavour="pcqm", big=52)),
+    "faformer_equihnns_pcqm_c256_f64": ("faformer_equihnns", 256, 6417, 3, False, dict(flavour="pcqm", big=41)),
+    "faformer_equihnns_c64_f64": ("faformer_equihnns", 64, 5103, 6, False, {}),
+}
+F64_FULL_LIMIT = 20000      # gradients of at most this many entries are stored whole, larger ones as a sample
+F64_SAMPLE = 4096
+
+
+def f64_spec(name: str) -> dict:
+    method, hidden, seed, n_mols, train, opt = F64_TABLE[name]
+    spec = dict(name=name, method=method, hidden=hidden, seed=seed, n_mols=n_mols, train=train, store_grads=True,
+                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1)
+    spec.update(opt)
+    return spec
+
+
+def f64_sample_indices(numel: int) -> np.ndarray:
+    """Flat indices of the stored sample of a large gradient: F64_SAMPLE entries evenly spread over the tensor."""
+    return np.unique(np.linspace(0, numel - 1, F64_SAMPLE).astype(np.int64))
 
 
 def layer_inputs(name: str):

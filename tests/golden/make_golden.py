@@ -27,8 +27,8 @@ REF = os.environ.get("EQUIHGNN_REFERENCE", "/root/reference")
 sys.path.insert(0, REPO)
 sys.path.insert(0, HERE)
 
-from common import (CASE_TABLE, LAYER_TABLE, TRAJECTORY_TABLE, layer_inputs, case_spec, trajectory_batches, fill_state_dict, golden_args, load_case, make_batch,  # noqa: E402
-                    zero_dropouts)
+from common import (CASE_TABLE, F64_FULL_LIMIT, F64_MIN_MARGIN, F64_TABLE, LAYER_TABLE, TRAJECTORY_TABLE, layer_inputs, case_spec,  # noqa: E402
+                    f64_sample_indices, f64_spec, trajectory_batches, fill_state_dict, golden_args, load_case, make_batch, zero_dropouts)
 
 from equihgnn_amd.batch import ATOM_FEATURE_DIMS  # noqa: E402
 
@@ -279,6 +279,66 @@ def run_case(registry, spec):
     return case
 
 
+def run_case_f64(registry, spec, return_margin_only=False):
+    """The reference's own model in FLOAT64 (`.double()`, float64 coordinates and targets) on a case's batch: output, loss and
+    every parameter gradient (whole up to F64_FULL_LIMIT entries, an evenly spread sample above), plus the distance of the
+    closest ReLU input to its kink (rms units)."""
+    method, hidden, seed, train_mode = spec["method"], spec["hidden"], spec["seed"], spec["train"]
+    torch.manual_seed(0)
+    model = registry.get_model_class(method)(1, golden_args(method, hidden))
+    fill_state_dict(model, seed)               # float32 values, exactly what the float32 side loads
+    model.train(train_mode)
+    if spec["dropout0"]:
+        zero_dropouts(model)
+    model = model.double()
+    data = make_batch(spec)
+    inputs = {k: getattr(data, k).numpy().copy() for k in ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e",
+                                                            "e_order", "batch", "y")}
+    data.pos, data.y = data.pos.double(), data.y.double()
+    with _ReluMargin() as rm:
+        out = model(data)
+        margin = rm.take()
+    if return_margin_only:
+        return margin
+    loss = torch.nn.functional.mse_loss(out, data.y)
+    loss.backward()
+    assert out.dtype == torch.float64
+    case = {"meta_method": np.array(method), "meta_hidden": np.array(hidden), "meta_seed": np.array(seed),
+            "meta_train": np.array(int(train_mode)), "relu_margin": np.array(margin, dtype=np.float64),
+            "out64": out.detach().numpy(), "loss64": loss.detach().numpy()}
+    for k, v in inputs.items():
+        case["in_" + k] = v
+    names, has, absmax = [], [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        has.append(p.grad is not None)
+        if p.grad is None:
+            absmax.append(0.0)
+            continue
+        g = p.grad.detach().numpy()
+        absmax.append(float(np.abs(g).max()))
+        # (stored as float32: the values are the float64 evaluation's, rounded once -- 6e-8 relative against the 5e-5 bound)
+        if g.size <= F64_FULL_LIMIT:
+            case["g64_" + n] = g.astype(np.float32)
+        else:
+            case["g64s_" + n] = g.reshape(-1)[f64_sample_indices(g.size)].astype(np.float32)
+    case["grad_names"], case["grad_present"] = np.array(names), np.array(has)
+    case["grad_absmax"] = np.array(absmax, dtype=np.float64)
+    return case
+
+
+def scan_f64_seeds(registry, name, tries=200):
+    """First seed from the row's seed on whose closest ReLU input is >= F64_MIN_MARGIN rms from zero on the float64
+    reference (`python make_golden.py --scan-f64 [names]`)."""
+    spec = f64_spec(name)
+    for sd in range(spec["seed"], spec["seed"] + tries):
+        m = run_case_f64(registry, dict(spec, seed=sd), return_margin_only=True)
+        print(f"{name}: seed {sd} relu margin {m:.2e}", flush=True)
+        if m >= F64_MIN_MARGIN:
+            return sd
+    return None
+
+
 def d_fixture():
     """Known-answer vectors for the D construction alone (equiformer/basis.py:194-215): crafted rel_pos rows --
     generic directions, the axes, exactly -y, rows inside the |x_hat + y_hat|^2 < 1e-6 clamp on a log scale of
@@ -416,9 +476,10 @@ def main(only=None, check=False):
     torch.set_num_threads(1)
     torch.use_deterministic_algorithms(True)
     names = [n for n in CASE_TABLE if only is None or n in only]
+    f64 = [n for n in F64_TABLE if only is None or n in only]
     traj = [n for n in TRAJECTORY_TABLE if only is None or n in only]
     layers = [n for n in LAYER_TABLE if only is None or n in only]
-    methods = {CASE_TABLE[n][0] for n in names} | {TRAJECTORY_TABLE[n][0] for n in traj}
+    methods = {CASE_TABLE[n][0] for n in names} | {TRAJECTORY_TABLE[n][0] for n in traj} | {F64_TABLE[n][0] for n in f64}
     mods = []
     if methods & {"mhnnm", "mhnn", "mhnns"}:
         mods.append("mhnn")
@@ -440,6 +501,16 @@ def main(only=None, check=False):
         print(f"{name}: N={case['in_x'].shape[0]} M={case['in_edge_attr'].shape[0]} "
               f"nnz={case['in_edge_index0'].shape[0]} out[:3]={case['out'][:3]} "
               f"loss={float(case['loss']):.6f} -> {os.path.getsize(path)/1024:.0f} KiB")
+    for name in f64:
+        case = run_case_f64(registry, f64_spec(name))
+        if check:
+            ok &= compare(case, load_case(name), name)
+            continue
+        assert float(case["relu_margin"]) >= F64_MIN_MARGIN, (name, float(case["relu_margin"]), "re-run --scan-f64 and update the seed")
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **case)
+        print(f"{name}: N={case['in_x'].shape[0]} out64[:3]={case['out64'][:3]} loss64={float(case['loss64']):.9f} "
+              f"relu margin {float(case['relu_margin']):.2e} -> {os.path.getsize(path)/1024:.0f} KiB")
     for name in traj:
         case = run_trajectory(registry, name)
         if check:
@@ -478,6 +549,14 @@ def scan_trajectory_seeds(name, seeds):
 
 
 if __name__ == "__main__":
+    if "--scan-f64" in sys.argv:
+        torch.set_num_threads(1)
+        torch.use_deterministic_algorithms(True)
+        wanted = [a for a in sys.argv[1:] if a in F64_TABLE] or list(F64_TABLE)
+        reg = import_reference(("mhnn", "equihnn_egnn", "equihnn_equiformer", "equihnn_fa_former"))
+        for nm in wanted:
+            print(f"{nm}: first seed with margin >= {F64_MIN_MARGIN:g}: {scan_f64_seeds(reg, nm)}", flush=True)
+        sys.exit(0)
     if "--scan" in sys.argv:
         i = sys.argv.index("--scan")
         scan_trajectory_seeds(sys.argv[i + 1], [int(x) for x in sys.argv[i + 2:]])

@@ -396,3 +396,36 @@ def test_graphed_evaluation_before_the_first_training_step_is_recaptured():
     np.testing.assert_allclose(t_graph, t_eager, rtol=1e-5, atol=1e-5)
     assert float(np.abs(t_graph[:, 0] - t_before[:, 0]).max()) > 1e-3          # training at lr 1e-2 did move the predictions
     train.close()
+
+
+def test_native_collate_equals_the_numpy_restatement_bit_for_bit():
+    """MolStore.collate is the library's host-side hb_collate (csrc/collate.hip); MolStore.collate_numpy the array-operation
+    restatement of rounds 2-4: same batch bit for bit, unpadded, padded, and into caller-owned staging tensors; extents that
+    do not fit raise the same ValueError; a molecule index outside the store is an error, not a read past the arrays."""
+    from equihgnn_amd.batch import HBatch, MolStore, bucket_sizes
+    store = MolStore(_mols(97, 5))
+    rng = np.random.default_rng(0)
+    fields = ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order", "batch", "y")
+    for trial in range(4):
+        idx = rng.permutation(len(store))[: int(rng.integers(1, 40))]
+        a, b = store.collate(idx), store.collate_numpy(idx)
+        for f in fields:
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+        tgt = bucket_sizes(*store.extents(idx), 64)
+        a, b = store.collate(idx, pad_to=tgt), store.collate_numpy(idx, pad_to=tgt)
+        for f in fields:
+            assert torch.equal(getattr(a, f), getattr(b, f)), f
+        assert a.num_real_graphs == b.num_real_graphs == len(idx) and a.num_graphs == len(idx) + 1
+        out = HBatch.empty_packed(tgt[0], tgt[1], tgt[2], len(idx) + 1, pin=False)
+        c = store.collate(idx, pad_to=tgt, out=out)
+        assert c is out
+        for f in fields:
+            assert torch.equal(getattr(c, f), getattr(b, f)), f
+    n, h, z = store.extents(idx)
+    for bad in ((n, h + 1, z), (n + 1, h, z), (n + 1, h + 1, z - 1)):
+        with pytest.raises(ValueError):
+            store.collate(idx, pad_to=bad)
+        with pytest.raises(ValueError):
+            store.collate_numpy(idx, pad_to=bad)
+    with pytest.raises(IndexError):
+        store.collate(np.array([0, len(store)]))

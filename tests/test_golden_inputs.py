@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from common import CASE_TABLE, GOLDEN_DIR, case_spec, load_case, make_batch
+from common import CASE_TABLE, F64_TABLE, GOLDEN_DIR, case_spec, f64_spec, load_case, make_batch
 
 FIELDS = ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order", "batch", "y")
 
@@ -16,12 +16,12 @@ FIELDS = ("x", "pos", "edge_index0", "edge_index1", "edge_attr", "n_e", "e_order
 def test_every_case_has_a_file_and_every_file_a_case():
     files = {f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz")}
     extra = {"equiformer_D"} | {f for f in files if f.startswith(("trajectory_", "equiformer_layer_"))}   # not model cases
-    assert files - extra == set(CASE_TABLE)
+    assert files - extra == set(CASE_TABLE) | set(F64_TABLE)
 
 
-@pytest.mark.parametrize("name", list(CASE_TABLE))
+@pytest.mark.parametrize("name", list(CASE_TABLE) + list(F64_TABLE))
 def test_inputs_rederive_bit_for_bit(name):
-    case, spec = load_case(name), case_spec(name)
+    case, spec = load_case(name), (f64_spec(name) if name in F64_TABLE else case_spec(name))
     b = make_batch(spec)
     for k in FIELDS:
         got = getattr(b, k).numpy()

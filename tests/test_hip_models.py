@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from common import assert_close, batch_from_case, fill_state_dict, golden_args, load_case  # noqa: E402
-from test_oracle_golden import CASES, check_against_case  # noqa: E402
+from test_oracle_golden import CASES, F64_CASES, build_f64, check_against_case, check_grads_against_f64  # noqa: E402
 from test_oracle_golden import build as build_case_model  # noqa: E402
 
 import oracle  # noqa: E402,F401
@@ -41,7 +41,30 @@ def test_hip_model_matches_reference_golden(name):
     # are checked tightly at operator level in test_hip_kernels.py.
     noisy = method in ("mhnnm", "egnn_equihnnm") and bool(int(case["meta_train"]))
     wide = int(case["meta_hidden"]) >= 256 or method == "faformer_equihnns"  # + eigenvector conditioning
+    # Round 5: the hidden-256 and FAFormer gradients are pinned to the reference's own float64 evaluation at 5e-5 in
+    # test_hip_gradients_match_the_reference_in_float64 (fixtures whose ReLU inputs stay clear of the kink); against THESE
+    # float32 captures -- whose seeds were not chosen for that -- the bound stays at the kink noise measured on them.
     check_against_case(model, case, data, grad_rtol=1e-2 if wide else (3e-3 if noisy else 3e-4))
+
+
+@pytest.mark.parametrize("name", F64_CASES)
+def test_hip_gradients_match_the_reference_in_float64(name):
+    """The HIP path (float32) against the REFERENCE's own model evaluated in float64 on the same batch (tests/golden/*_f64.npz,
+    generated from /root/reference by make_golden.run_case_f64): forward within 1e-5, EVERY stored gradient entry within
+    5e-5 of the largest gradient entry -- hidden 256 (BASELINE's width) for every model family and FAFormer at both widths,
+    i.e. exactly the cases whose float32 captures only support 1e-2.  The seeds keep every ReLU input >= 1e-5 rms from zero on
+    the float64 reference, so a float32 evaluation cannot flip one."""
+    case = load_case(name)
+    model = build_f64(case, _models())
+    model.to(DEV)
+    data = batch_from_case(case).to(DEV)
+    out = model(data)
+    assert_close(out.detach().cpu().numpy(), case["out64"], TOL, "out")
+    loss = torch.nn.functional.mse_loss(out, data.y)
+    assert abs(float(loss.detach()) - float(case["loss64"])) <= 2e-5 * max(1.0, float(case["loss64"]))
+    loss.backward()
+    worst = check_grads_against_f64(dict(model.named_parameters()), case, 5e-5)
+    print(f"reference-float64 {name}: worst gradient entry error / largest entry = {worst[0]:.2e} ({worst[1]})")
 
 
 # (method, molecules, seed, flavour, hidden, mode): the BASELINE workloads at sizes the CPU oracle still finishes in

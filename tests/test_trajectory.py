@@ -78,7 +78,10 @@ def test_hip_train_step_reproduces_reference_trajectory(name, graphed, path):
     1e-5 rms from its kink at every step (`relu_margin` in the fixture, measured on the reference), and with BOTH panel paths
     on a handful of units of the seed-81 trajectory cross it at the second update (9 of 4096 entries of conv.W2.lins.1.weight
     end one lr away; either panel path alone stays on the reference's side).  Single-step gradients of the panel path
-    are pinned against float64 by test_hip_gradients_match_fp64_truth."""
+    are pinned against float64 by test_hip_gradients_match_fp64_truth.  ``trajectory_egnn_equihnns_c64_b`` (seed 107: every
+    ReLU input of all three steps >= 2.4e-5 rms from its kink on the reference) holds the panel path to the SAME tight bounds as
+    the per-operator path (measured on sixteen seeds 101-116: losses within 5e-6, parameters within 0.04 lr of the reference's on
+    every one of them, eager and graphed) -- the loosened bound is kept for the seed-81 fixture alone."""
     from equihgnn_amd import ops
     from equihgnn_amd.batch import bucket_sizes, pad_batch
     from equihgnn_amd.models import MODELS
@@ -98,7 +101,8 @@ def test_hip_train_step_reproduces_reference_trajectory(name, graphed, path):
         else:
             dev = [b.to("cuda:0") for b in batches]
             tr = TrainStep(model, lr=lr)
-        _check(name, tr.step, model, dev, lr, kink_limited_from=2 if path == "panel" and method != "mhnnm" else None)
+        # the loosened bound only for the documented kink case (seed 81); seed 107 holds the default path to 1e-4 / 2 % of an Adam step
+        _check(name, tr.step, model, dev, lr, kink_limited_from=2 if path == "panel" and name == "trajectory_egnn_equihnns_c64" else None)
     finally:
         ops.conv_stack.USE_CONV_STACK = ops.USE_NODE_PANEL = True
     if graphed:
