@@ -25,7 +25,10 @@
 // Backward: pass 1 (by receiver i) gives dA, dW2, dwd and stores dpre2; pass 2 (by sender j, over
 // the transposed neighbour CSR) gives dB.  No atomics; per-block partial slabs are reduced by a
 // third kernel in block order, so every result is bitwise reproducible.
+#include <cstdlib>
+
 #include "common.h"
+#include "bf16x3.h"
 
 namespace {
 
@@ -59,6 +62,18 @@ __device__ __forceinline__ float silu_grad(float x, float* ds) {
     *ds = fmaf(s, 1.0f - sig, sig);
     return s;
 }
+
+// blockIdx -> work item such that the items handled by one XCD are CONSECUTIVE: blocks are dealt round-robin over the eight
+// XCDs (b and b + 8 share one: MI355X_MICROARCH.md, speed only -- nothing depends on it), so with the nodes in spatial order an
+// XCD's 4 MB L2 sees a compact region of the cloud and its neighbours.  The grid is rounded up to a multiple of 8; items
+// past the end return -1.
+__device__ __forceinline__ int xcd_item(int b, int grid, int n_items, int remap) {
+    if (!remap) return b < n_items ? b : -1;
+    const int per = grid >> 3;
+    const int item = (b & 7) * per + (b >> 3);
+    return item < n_items ? item : -1;
+}
+static inline int xcd_grid(int n_items, int remap) { return remap ? ((n_items + 7) / 8) * 8 : n_items; }
 
 __host__ __device__ inline int lds_row_stride(int Hp) {  // (stride mod 64) == 24: conflict-free b128
     return Hp + ((24 - (Hp & 63)) + 64) % 64;
@@ -265,6 +280,211 @@ k_edge_fwd(const float* __restrict__ ab, const float* __restrict__ wd, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, round 5: the 16 x Hp -> 16 contraction on the bf16 matrix cores.
+// The fp32 MFMA above shares the VALU's FMA lanes -- a SIMD's time per 16 hidden units is the SUM of the SiLU's VALU cycles and
+// 4 x 32 MFMA cycles (~420).  Here the activations s = silu(h) are split EXACTLY into three bf16 planes (bf16x3.h: s = s0 + s1 +
+// s2, the split of gemm_x6.hip and the panel kernels) and multiplied with W2's three planes by six v_mfma_f32_16x16x32_bf16 per 32
+// hidden units, smallest terms first into one fp32 accumulator: the matrix pipe runs BESIDE the VALU (96 of its cycles per 32
+// units against ~300 VALU cycles for the SiLU and the split), so the step costs what its VALU work costs.  Accuracy is that of
+// the x6 products (dropped terms 2^-24 relative; tests compare with float64 at the same bounds as before).
+// Geometry: 8 wavefronts per workgroup and CU (two per SIMD, 256 registers each), four wavefronts per node, each walking a
+// contiguous quarter of the hidden units in steps of 32; a wavefront's W2 fragments (its k-steps x 3 planes x 16 bytes per lane)
+// are split ONCE at kernel start and stay in registers; B rows / the A row go row-contiguously through a private LDS tile
+// into MFMA operand order, as above (lane (j = lane & 15, kg = lane >> 4) multiplies units 8 kg .. 8 kg + 7 of neighbour j).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int F2_SPLIT = 4;                              // wavefronts per node
+constexpr int F2_LD = 32 + 4;                            // floats per staged row (32 hidden units + pad)
+constexpr int F2_TILE = (KNB + 1) * F2_LD;               // 16 B rows + the A row
+constexpr int F2_MAXSTEPS = 9;                           // k-steps (of 32 units) per wavefront: Hp <= 4 * 9 * 32 = 1152
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& p0, uint4& p1, uint4& p2) {
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+}
+
+template <int NS, int THREADS_, bool W2_LDS>
+__global__ void __launch_bounds__(THREADS_)
+k_edge_fwd_x3(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
+              const float* __restrict__ b2, const int* __restrict__ nbr, const float* __restrict__ d2,
+              float* __restrict__ m, float* __restrict__ pre2, int N, int Hp, int n_items, int remap) {
+    extern __shared__ __attribute__((aligned(16))) float s_mem[];
+    constexpr int NWAVES = THREADS_ / 64, NODES = NWAVES / F2_SPLIT;
+    const int item = xcd_item((int)blockIdx.x, (int)gridDim.x, n_items, remap);
+    if (item < 0) return;
+    const int total = Hp >> 5;                            // k-steps of 32 hidden units
+    float* s_wd = s_mem;                                  // [Hp]
+    float* s_tile = s_wd + Hp;                            // [wavefronts][F2_TILE]
+    uint4* s_w2 = reinterpret_cast<uint4*>(s_tile + NWAVES * F2_TILE);   // W2_LDS: [k-step][plane 3][lane 64] x 16 bytes
+    for (int idx = threadIdx.x * 4; idx < Hp; idx += THREADS_ * 4)
+        *reinterpret_cast<float4*>(s_wd + idx) = *reinterpret_cast<const float4*>(wd + idx);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int slot = wave / F2_SPLIT, part = wave % F2_SPLIT;
+    const int per = (total + F2_SPLIT - 1) / F2_SPLIT;    // <= NS
+    const int s_beg = part * per;
+    const int cnt = (total - s_beg < per) ? (total - s_beg > 0 ? total - s_beg : 0) : per;
+    // W2 fragments: lane (o = r, kg = q) holds W2[o][32 step + 8 q .. + 7], split into planes -- this wavefront's own k-steps in
+    // registers (two wavefronts per SIMD), or every k-step once per workgroup in LDS (four per SIMD: 128 registers each)
+    auto w2_frag = [&](int step, uint4& p0, uint4& p1, uint4& p2) {
+        float v[8];
+        const int k0 = 32 * step + 8 * q;
+        const float4 x0 = *reinterpret_cast<const float4*>(w2 + r * Hp + k0);
+        const float4 x1 = *reinterpret_cast<const float4*>(w2 + r * Hp + k0 + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        split8(v, p0, p1, p2);
+    };
+    uint4 wf[W2_LDS ? 1 : NS][3];
+    if constexpr (W2_LDS) {
+        for (int step = wave; step < total; step += NWAVES) {
+            uint4 p0, p1, p2;
+            w2_frag(step, p0, p1, p2);
+            s_w2[(step * 3 + 0) * 64 + lane] = p0;
+            s_w2[(step * 3 + 1) * 64 + lane] = p1;
+            s_w2[(step * 3 + 2) * 64 + lane] = p2;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s < cnt) w2_frag(s_beg + s, wf[s][0], wf[s][1], wf[s][2]);
+            else wf[s][0] = wf[s][1] = wf[s][2] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    __syncthreads();
+    const float bo = b2[r];
+    float* tile = s_tile + wave * F2_TILE;
+    // staging: two 16-byte pieces per lane and step -- rows (lane >> 3) and 8 + (lane >> 3), piece lane & 7 (a row of 32 units
+    // = 128 bytes = eight lanes); the A row by lanes 0..7
+    const int lrow = lane >> 3, piece = lane & 7;
+    float* t_wr0 = tile + lrow * F2_LD + 4 * piece;
+    float* t_wr1 = t_wr0 + 8 * F2_LD;
+    float* t_wra = tile + KNB * F2_LD + 4 * piece;
+    const float* t_rd = tile + r * F2_LD + 8 * q;         // neighbour r, units 8 q .. 8 q + 7 of the step
+    const float* t_rda = tile + KNB * F2_LD + 8 * q;      // the receiver's own A row (broadcast over r)
+    const int groups = (N + NODES - 1) / NODES;
+    const int gpb = (groups + n_items - 1) / n_items;
+    const int g_beg = item * gpb;
+    const int g_end = (g_beg + gpb < groups) ? g_beg + gpb : groups;
+    if (g_beg >= g_end) return;  // whole workgroup
+    const int col0 = 32 * s_beg + 4 * piece;              // float offset of this lane's piece in step 0 of its range
+    int node_raw = g_beg * NODES + slot;
+    int node = (node_raw < N) ? node_raw : N - 1;  // tail: recompute the last node, not stored
+    float dd = d2[node * KNB + r];
+    const float* __restrict__ arow = ab + (int64_t)node * 2 * Hp;
+    const float* __restrict__ brow0 = ab + (int64_t)nbr[node * KNB + lrow] * 2 * Hp + Hp;
+    const float* __restrict__ brow1 = ab + (int64_t)nbr[node * KNB + 8 + lrow] * 2 * Hp + Hp;
+    float4 nb0 = f4_zero(), nb1 = f4_zero(), na = f4_zero();
+    if (cnt > 0) {
+        nb0 = *reinterpret_cast<const float4*>(brow0 + col0);
+        nb1 = *reinterpret_cast<const float4*>(brow1 + col0);
+        if (lane < 8) na = *reinterpret_cast<const float4*>(arow + col0);
+    }
+    for (int group = g_beg; group < g_end; ++group) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int j0 = 0, j1 = 0, node_raw_n = 0, node_n = 0;
+        float dd_n = 0.f;
+        {   // next group's neighbour list (the last group re-reads its own): in flight behind this group's first steps
+            const int gn = (group + 1 < g_end) ? group + 1 : group;
+            node_raw_n = gn * NODES + slot;
+            node_n = (node_raw_n < N) ? node_raw_n : N - 1;
+            j0 = nbr[node_n * KNB + lrow];
+            j1 = nbr[node_n * KNB + 8 + lrow];
+            dd_n = d2[node_n * KNB + r];
+        }
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            if (st < cnt) {
+                *reinterpret_cast<float4*>(t_wr0) = nb0;
+                *reinterpret_cast<float4*>(t_wr1) = nb1;
+                if (lane < 8) *reinterpret_cast<float4*>(t_wra) = na;
+                const float* __restrict__ p0 = brow0;
+                const float* __restrict__ p1 = brow1;
+                const float* __restrict__ pa = arow;
+                int bc;
+                if (st + 1 < cnt) {                       // next step of this node
+                    bc = col0 + 32 * (st + 1);
+                } else {                                  // first step of the next group's node
+                    asm volatile("" : "+v"(j0), "+v"(j1), "+v"(node_n));   // (keeps the index arithmetic below the branch)
+                    p0 = ab + (int64_t)j0 * 2 * Hp + Hp;
+                    p1 = ab + (int64_t)j1 * 2 * Hp + Hp;
+                    pa = ab + (int64_t)node_n * 2 * Hp;
+                    bc = col0;
+                }
+                nb0 = *reinterpret_cast<const float4*>(p0 + bc);
+                nb1 = *reinterpret_cast<const float4*>(p1 + bc);
+                if (lane < 8) na = *reinterpret_cast<const float4*>(pa + bc);
+                if (st + 1 >= cnt) { brow0 = p0; brow1 = p1; arow = pa; }
+                __builtin_amdgcn_sched_barrier(0);
+                const float* cr = s_wd + 32 * (s_beg + st) + 8 * q;
+                const float4 b0 = *reinterpret_cast<const float4*>(t_rd), b1 = *reinterpret_cast<const float4*>(t_rd + 4);
+                const float4 a0 = *reinterpret_cast<const float4*>(t_rda), a1 = *reinterpret_cast<const float4*>(t_rda + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(cr), c1 = *reinterpret_cast<const float4*>(cr + 4);
+#ifdef EDGE_ABLATE      // diagnostic build: the gather + LDS round trip without the SiLU / split / MFMA work
+                acc[0] += (b0.x + b1.w) + (a0.y + a1.z) + (c0.x + c1.x);
+                __builtin_amdgcn_sched_barrier(0);
+                continue;
+#endif
+                const f32x2 dd2 = {dd, dd};
+                // (the arithmetic of fwd_stage above: h = c * dd + (a + b), silu by v_exp / v_rcp)
+                const f32x2 s01 = silu_fast2(f32x2{c0.x, c0.y} * dd2 + (f32x2{a0.x, a0.y} + f32x2{b0.x, b0.y}));
+                const f32x2 s23 = silu_fast2(f32x2{c0.z, c0.w} * dd2 + (f32x2{a0.z, a0.w} + f32x2{b0.z, b0.w}));
+                const f32x2 s45 = silu_fast2(f32x2{c1.x, c1.y} * dd2 + (f32x2{a1.x, a1.y} + f32x2{b1.x, b1.y}));
+                const f32x2 s67 = silu_fast2(f32x2{c1.z, c1.w} * dd2 + (f32x2{a1.z, a1.w} + f32x2{b1.z, b1.w}));
+                uint4 p0_, p1_, p2_;
+                split_pair(s01.x, s01.y, p0_.x, p1_.x, p2_.x);
+                split_pair(s23.x, s23.y, p0_.y, p1_.y, p2_.y);
+                split_pair(s45.x, s45.y, p0_.z, p1_.z, p2_.z);
+                split_pair(s67.x, s67.y, p0_.w, p1_.w, p2_.w);
+                const bf16x8 x0 = __builtin_bit_cast(bf16x8, p0_), x1 = __builtin_bit_cast(bf16x8, p1_), x2 = __builtin_bit_cast(bf16x8, p2_);
+                uint4 q0, q1, q2;
+                if constexpr (W2_LDS) {
+                    const uint4* wp = s_w2 + (s_beg + st) * 3 * 64 + lane;
+                    q0 = wp[0]; q1 = wp[64]; q2 = wp[128];
+                } else {
+                    q0 = wf[st][0]; q1 = wf[st][1]; q2 = wf[st][2];
+                }
+                const bf16x8 w0 = __builtin_bit_cast(bf16x8, q0), w1 = __builtin_bit_cast(bf16x8, q1), w2p = __builtin_bit_cast(bf16x8, q2);
+                // smallest terms first, as gemm_x6.hip: s1 w1, s0 w2, s2 w0, s0 w1, s1 w0, s0 w0
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w2p, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2, w0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // partial accumulators: wavefronts 1..3 of the node park theirs in their own (now idle) tile
+        if (part > 0) *reinterpret_cast<f32x4*>(tile + lane * 4) = acc;
+        __syncthreads();
+        if (part == 0 && node_raw < N) {
+#pragma unroll
+            for (int pp = 1; pp < F2_SPLIT; ++pp)
+                acc += *reinterpret_cast<const f32x4*>(tile + pp * F2_TILE + lane * 4);
+            // acc[g] = pre2[j = 4q+g][o = r] (before bias)
+            float msum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float pv = acc[g] + bo;
+                pre2[(int64_t)node * (KNB * MDIM) + (4 * q + g) * MDIM + r] = pv;
+                msum += silu_fast(pv);
+            }
+            msum += __shfl_xor(msum, 16, 64);
+            msum += __shfl_xor(msum, 32, 64);
+            if (q == 0) m[(int64_t)node * MDIM + r] = msum;
+        }
+        __syncthreads();  // tiles are overwritten by the next group's first step
+        node_raw = node_raw_n;
+        node = node_n;
+        dd = dd_n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward.  Three kernels, no atomics:
 //   prep : dpre2 = dm * silu'(pre2), stored twice ([n][j][o] and [n][o][j]: the two MFMA operand orders)
 //   recv : by receiver i  -> dA (= dab[:, :Hp]), per-chunk partial slabs of dW2 and dwd
@@ -384,12 +604,14 @@ __global__ void __launch_bounds__(THREADS)
 k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
                 const int* __restrict__ nbr, const float* __restrict__ d2, const float* __restrict__ dpre2,
                 const float* __restrict__ dpre2_t, float* __restrict__ dab, float* __restrict__ slab_w2,
-                float* __restrict__ slab_wd, int N, int Hp, int tiles, int chunk_nodes) {
+                float* __restrict__ slab_wd, int N, int Hp, int tiles, int chunk_nodes, int n_items, int remap) {
     __shared__ __attribute__((aligned(16))) float s_red[WAVES - 1][64 * 20];  // 16 dW2 + 4 dwd floats per lane
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int T = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const int item = xcd_item((int)blockIdx.x, (int)gridDim.x, n_items, remap);
+    if (item < 0) return;
+    const int T = item % tiles, chunk = item / tiles;
     const int base = chunk * chunk_nodes;
     const int cnt = (N - base < chunk_nodes) ? (N - base) : chunk_nodes;
     // lane (r, q) owns the FOUR consecutive hidden units k4 .. k4+3, k4 = 64 T + 4 r (column n = r of MFMA
@@ -419,6 +641,14 @@ k_edge_bwd_recv(const float* __restrict__ ab, const float* __restrict__ wd, cons
             recv_load(nx, ab, d2, dpre2, dpre2_t, clampn(n + WAVES), nb_next, Hp, k4, r, q);
             nb_next = nbr4[(int64_t)clampn(n + 2 * WAVES) * 4 + q];
             __builtin_amdgcn_sched_barrier(0);
+#ifdef EDGE_ABLATE      // diagnostic build: operand traffic of the receiver pass without its MFMA / SiLU work
+            {
+                const float t = (cur.pa.x + cur.pt.y) + (cur.a.x + cur.dd.y) + ((cur.b0.x + cur.b1.y) + (cur.b2.z + cur.b3.w));
+                if (q == 0) *reinterpret_cast<float4*>(dab + (int64_t)node * 2 * Hp + k4) = make_float4(t, t, t, t);
+                ad0 += t;
+                continue;
+            }
+#endif
             // gk_c[g] = sum_o dpre2[j = 4q+g][o] * W2[o][k4 + c]
             f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
             g0 = mfma16(cur.pa.x, w0.x, g0); g1 = mfma16(cur.pa.x, w0.y, g1);
@@ -528,12 +758,14 @@ __device__ __forceinline__ float4 send_row(const float4& wd4, float dd, const fl
 __global__ void __launch_bounds__(THREADS)
 k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd, const float* __restrict__ w2,
                 const float* __restrict__ dpre2, const int* __restrict__ t_rowptr, const int4* __restrict__ rec,
-                float* __restrict__ dab, int N, int Hp, int tiles, int chunk_senders) {
+                float* __restrict__ dab, int N, int Hp, int tiles, int chunk_senders, int n_items, int remap) {
     __shared__ __attribute__((aligned(16))) float s_tile[WAVES][KNB * SEND_LD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int T = blockIdx.x % tiles, chunk = blockIdx.x / tiles;
+    const int item = xcd_item((int)blockIdx.x, (int)gridDim.x, n_items, remap);
+    if (item < 0) return;
+    const int T = item % tiles, chunk = item / tiles;
     const int k4 = 64 * T + 4 * r;
     // this wavefront's senders [s_beg, s_end): an equal share of the chunk
     const int c_beg = chunk * chunk_senders;
@@ -576,6 +808,14 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd, cons
         __builtin_amdgcn_sched_barrier(0);
         const bool live_r = p0 + r < p_end;
         const float4 pa = live_r ? cur_ops.pa : make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef EDGE_ABLATE      // diagnostic build: operand traffic of the sender pass without its MFMA / SiLU work and segmented walk
+        {
+            run += (pa.x + cur_ops.dd0) + ((cur_ops.a0.x + cur_ops.a1.y) + (cur_ops.a2.z + cur_ops.a3.w)) +
+                   ((cur_ops.b0.x + cur_ops.b1.y) + (cur_ops.b2.z + cur_ops.b3.w));
+            if ((p0 & 255) == 0) drow[(int64_t)cur * 2 * Hp] = run;
+            continue;
+        }
+#endif
         f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
         g0 = mfma16(pa.x, w0.x, g0); g1 = mfma16(pa.x, w0.y, g1); g2 = mfma16(pa.x, w0.z, g2); g3 = mfma16(pa.x, w0.w, g3);
         g0 = mfma16(pa.y, w1.x, g0); g1 = mfma16(pa.y, w1.y, g1); g2 = mfma16(pa.y, w1.z, g2); g3 = mfma16(pa.y, w1.w, g3);
@@ -616,6 +856,12 @@ k_edge_bwd_send(const float* __restrict__ ab, const float* __restrict__ wd, cons
     }
 }
 
+// EQH_EDGE_XCD=0 switches the XCD-aware block -> work mapping off (same-box A/B runs)
+inline int edge_xcd_remap() {
+    static const int v = [] { const char* e = std::getenv("EQH_EDGE_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 int check_common(int64_t N, int Hp) {
     if (N < 0 || Hp <= 0) return EQH_ERR_ARG;
     if (Hp & 63) return EQH_ERR_ALIGN;  // the backward walks 64 hidden units per step
@@ -634,12 +880,50 @@ extern "C" int egnn_edge_fwd(const float* ab, const float* wd, const float* w2, 
     if (N == 0) return EQH_OK;
     if (!ab || !wd || !w2 || !b2 || !nbr || !d2 || !m || !pre2) return EQH_ERR_ARG;
     if (!eqh_aligned16(ab) || !eqh_aligned16(wd) || !eqh_aligned16(w2)) return EQH_ERR_ALIGN;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // round 5: the bf16 x 3 kernel (k_edge_fwd_x3) wherever a wavefront's quarter of the hidden units is <= 9 k-steps
+    // (Hp <= 1152: every MLP_hidden <= 256); EQH_EDGE_F32=1 keeps the fp32-MFMA kernel for same-box A/B runs
+    static const bool use_f32 = [] { const char* e = std::getenv("EQH_EDGE_F32"); return e && e[0] == '1'; }();
+    const int per = ((Hp >> 5) + F2_SPLIT - 1) / F2_SPLIT;
+    if (!use_f32 && per <= F2_MAXSTEPS && (size_t)N * 2 * (size_t)Hp < ((size_t)1 << 31)) {
+        // 16 wavefronts (four per SIMD, W2's planes in LDS) by default; EQH_EDGE_W8=1: 8 wavefronts with W2 in registers
+        static const bool w8 = [] { const char* e = std::getenv("EQH_EDGE_W8"); return e && e[0] == '1'; }();
+        const int threads = w8 ? 512 : 1024;
+        const size_t lds2 = ((size_t)Hp + (size_t)(threads / 64) * F2_TILE) * sizeof(float) + (w8 ? 0 : (size_t)(Hp >> 5) * 3 * 64 * 16);
+        const int items2 = eqh_grid_for(N, threads / 64 / F2_SPLIT, 256);  // one workgroup per CU
+        const int remap = edge_xcd_remap();
+        const int grid2 = xcd_grid(items2, remap);
+        static bool attr2 = false;
+#define F2_ATTR(NS_)                                                                                                          \
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd_x3<NS_, 1024, true>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                             160 * 1024) == hipSuccess)
+        if (!attr2) {
+            if (!(F2_ATTR(1) && F2_ATTR(2) && F2_ATTR(3) && F2_ATTR(5) && F2_ATTR(9))) return EQH_ERR_LAUNCH;
+            attr2 = true;
+        }
+#undef F2_ATTR
+        if (lds2 > 160 * 1024) return EQH_ERR_RANGE;
+#define F2_LAUNCH(NS_)                                                                                                         \
+        do {                                                                                                                   \
+            if (w8) hipLaunchKernelGGL((k_edge_fwd_x3<NS_, 512, false>), dim3(grid2), dim3(512), lds2, stream, ab, wd, w2, b2, nbr, d2, m, \
+                                       pre2, (int)N, (int)Hp, items2, remap);                                                  \
+            else hipLaunchKernelGGL((k_edge_fwd_x3<NS_, 1024, true>), dim3(grid2), dim3(1024), lds2, stream, ab, wd, w2, b2, nbr, d2, m, \
+                                    pre2, (int)N, (int)Hp, items2, remap);                                                     \
+        } while (0)
+        if (per <= 1) F2_LAUNCH(1);
+        else if (per <= 2) F2_LAUNCH(2);
+        else if (per <= 3) F2_LAUNCH(3);
+        else if (per <= 5) F2_LAUNCH(5);
+        else F2_LAUNCH(9);
+#undef F2_LAUNCH
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    }
     const size_t lds_rest = ((size_t)Hp + (size_t)(FWD_THREADS / 64) * FWD_TILE) * sizeof(float);
     const size_t lds_w2 = (size_t)MDIM * lds_row_stride(Hp) * sizeof(float);
     const bool w2_lds = lds_rest + lds_w2 <= 160 * 1024;
     const size_t lds = lds_rest + (w2_lds ? lds_w2 : 0);
     if (lds > 160 * 1024) return EQH_ERR_RANGE;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_edge_fwd<true>),
@@ -714,11 +998,12 @@ extern "C" int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, 
         rc = eqh_reduce_slabs_async(slab_b2, pblocks, MDIM, db2, stream, db2_accumulate);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, dpre2,
-                       dpre2_t, dab, slab_w2, slab_wd, (int)N, (int)Hp, tiles, chunk_items);
+    const int remap = edge_xcd_remap();
+    hipLaunchKernelGGL(k_edge_bwd_recv, dim3(xcd_grid(used * tiles, remap)), dim3(THREADS), 0, stream, ab, wd, w2, nbr, d2, dpre2,
+                       dpre2_t, dab, slab_w2, slab_wd, (int)N, (int)Hp, tiles, chunk_items, used * tiles, remap);
     EQH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_edge_bwd_send, dim3(used * tiles), dim3(THREADS), 0, stream, ab, wd, w2, dpre2, t_rowptr,
-                       rec, dab, (int)N, (int)Hp, tiles, chunk_items);
+    hipLaunchKernelGGL(k_edge_bwd_send, dim3(xcd_grid(used * tiles, remap)), dim3(THREADS), 0, stream, ab, wd, w2, dpre2, t_rowptr,
+                       rec, dab, (int)N, (int)Hp, tiles, chunk_items, used * tiles, remap);
     EQH_CHECK_LAUNCH();
     // (dw_accumulate: dw2 / dwd are accumulators -- the packed weights' own, ops.egnn_pack_weights -- and the reduction joins
     // the step's batched one when a deferral window is open)

@@ -17,7 +17,10 @@
 // in chunk order by the common slab reducer -- which can add into the destination (a weight shared by L
 // layer applications) and is deferred to the one batched launch of eqh_defer_flush when active.
 // No atomics: bitwise reproducible.
+#include <cstdlib>
+
 #include "common.h"
+#include "bf16x3.h"
 
 namespace {
 
@@ -216,6 +219,175 @@ k_wgrad_batch(WgradBatch b, int O, int I, int tiles_i, int tiles, int splits) {
                0, 0, en.alpha, s_acc, en.ldy, en.ldx);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the batched weight gradients on the bf16 matrix cores (fp32-grade: the exact three-way split of bf16x3.h and the six
+// products of gemm_x6.hip, smallest first into one fp32 accumulator).  The fp32 MFMA above runs at 1/16 of the bf16 rate; six
+// bf16 MFMAs per product are 2.7x faster, and both operands being K-major is STILL the operand order: for v_mfma_f32_32x32x16_bf16
+// lane (m = lane & 31, kg = lane >> 5) holds the eight values k = 8 kg .. 8 kg + 7 of column m -- eight dword loads, each of which
+// reads two whole 128-byte row segments per wavefront, and split_pair on consecutive rows yields the packed fragment registers
+// directly.  No LDS staging, no transposition.
+// A workgroup of eight wavefronts owns a 128 x 128 output tile of one product over one chunk of K: wavefront (kh, qi, qj) computes
+// the 64 x 64 quadrant (qi, qj) over the kh-th half of the chunk (a quadrant's operand rows are shared with its neighbours through
+// L1, so a product's operands cross L2 -> CU twice instead of four times); the two K-halves meet in LDS, one slab per chunk.
+// ------------------------------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int WX_THREADS = 512;
+
+struct WxStage {
+    float a[2][8], b[2][8];      // [32-column tile][row 8 kg + i of the 16-row step]
+};
+
+// rows 8 kg + i, i < 8, of the two 32-column tiles of each operand: ga / gb are wave-uniform (the operand at row 0 of the
+// step, first column of the quadrant), la / lb the lane's offset (8 kg rows down, column m).  FULL: all sixteen rows exist.
+// (Measured, 21 products of [256 x 4.7 k].[4.7 k x 256] inside the step: fp32-MFMA kernel 131 us; this kernel with one stage
+// of look-ahead 107, with three 91; with the MFMAs compiled out 75 -- the operand side (204 MB of rows written earlier in the
+// step, dword loads, the split) bounds it, the matrix pipe needs 31.  Not kept: dy in 16-byte loads, eight of them feeding FOUR
+// interleaved-column tiles of a 128 x 32 wavefront tile -- half the load instructions per MFMA, a 40-register stage and
+// therefore a ring of three: 98 us.)
+template <bool FULL>
+__device__ __forceinline__ void wx_load(WxStage& st, const float* __restrict__ ga, const float* __restrict__ gb, unsigned la, unsigned lb,
+                                        int64_t ldy, int64_t ldx, int rows_left, int kg) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = FULL || (8 * kg + i < rows_left);
+        const int64_t ri = ok ? i : 0;                    // (a row past the end re-reads the step's first row: in range, masked)
+        const unsigned la_ = ok ? la : (la - (unsigned)(8 * kg * ldy)), lb_ = ok ? lb : (lb - (unsigned)(8 * kg * ldx));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float va = (ga + ri * ldy + 32 * t)[FULL ? la : la_], vb = (gb + ri * ldx + 32 * t)[FULL ? lb : lb_];
+            st.a[t][i] = ok ? va : 0.f;
+            st.b[t][i] = ok ? vb : 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ void wx_split(const float (&v)[8], bf16x8 (&p)[3]) {
+    uint4 p0, p1, p2;
+    split_pair(v[0], v[1], p0.x, p1.x, p2.x);
+    split_pair(v[2], v[3], p0.y, p1.y, p2.y);
+    split_pair(v[4], v[5], p0.z, p1.z, p2.z);
+    split_pair(v[6], v[7], p0.w, p1.w, p2.w);
+    p[0] = __builtin_bit_cast(bf16x8, p0);
+    p[1] = __builtin_bit_cast(bf16x8, p1);
+    p[2] = __builtin_bit_cast(bf16x8, p2);
+}
+
+__global__ void __launch_bounds__(WX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_wgrad_batch_x3(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits) {
+    __shared__ __attribute__((aligned(16))) float s_acc[4][64 * 64];      // the second K-half's quadrants
+    // Work unit = (product, chunk of K, 128 x 128 tile).  The tiles of one (product, chunk) read the same operand rows: they go
+    // to ONE XCD (blocks are dealt round-robin over the eight XCDs: b and b + 8 share one -- speed only, nothing depends on
+    // it), next to each other in its dispatch order, so the rows cross the fabric once and the other tiles hit that XCD's L2.
+    const int groups = n_prod * splits;
+    const int xcd = blockIdx.x & 7, j_ = blockIdx.x >> 3;
+    const int group = xcd + 8 * (j_ / tiles), tile = j_ % tiles;
+    if (group >= groups) return;                                          // whole workgroup
+    const WgradEntry& en = b.e[group / splits];
+    const int chunk = group % splits;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kh = wave >> 2, qd = wave & 3, qi = qd >> 1, qj = qd & 1;
+    const int m = lane & 31, kg = lane >> 5;
+    const int o0 = 128 * (tile / tiles_i) + 64 * qi, i0 = 128 * (tile % tiles_i) + 64 * qj;
+    const bool active = o0 < O && i0 < I;
+    int64_t kc = (en.K + splits - 1) / splits;
+    kc = (kc + 31) / 32 * 32;                                   // two halves of whole 16-row steps
+    const int64_t c_beg = (int64_t)chunk * kc;
+    const int64_t k_beg = c_beg + kh * (kc / 2);
+    int64_t k_end = k_beg + kc / 2;
+    if (k_end > en.K) k_end = en.K;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ta][tb][i] = 0.f;
+    if (active && k_beg < k_end) {
+        const int64_t ldy = en.ldy, ldx = en.ldx;
+        const float* __restrict__ ga = en.dy + k_beg * ldy + o0;       // wave-uniform
+        const float* __restrict__ gb = en.x + k_beg * ldx + i0;
+        const unsigned la = (unsigned)(8 * kg * ldy + m), lb = (unsigned)(8 * kg * ldx + m);
+        auto consume = [&](const WxStage& st) {
+            bf16x8 A[2][3], B[2][3];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                wx_split(st.a[t], A[t]);
+                wx_split(st.b[t], B[t]);
+            }
+#pragma unroll
+            for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    // smallest terms first, as gemm_x6.hip: a1 b1, a0 b2, a2 b0, a0 b1, a1 b0, a0 b0
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][1], B[tb][1], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[tb][2], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][2], B[tb][0], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[tb][1], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][1], B[tb][0], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[tb][0], acc[ta][tb], 0, 0, 0);
+                }
+        };
+        // whole 16-row steps through a ring of four register stages (three in flight behind the one being multiplied), then
+        // the ragged last step with its rows masked
+        const int n_full = (int)((k_end - k_beg) / 16), tail = (int)((k_end - k_beg) % 16);
+        WxStage s0, s1, s2, s3;
+        auto fetch = [&](WxStage& st, int step) {
+            if (step < n_full) wx_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+        };
+        fetch(s0, 0);
+        fetch(s1, 1);
+        fetch(s2, 2);
+        for (int step = 0; step < n_full; step += 4) {
+            fetch(s3, step + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s0, step + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < n_full) consume(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s1, step + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < n_full) consume(s2);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s2, step + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 3 < n_full) consume(s3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tail) {
+            wx_load<false>(s0, ga + (int64_t)n_full * 16 * ldy, gb + (int64_t)n_full * 16 * ldx, la, lb, ldy, ldx, tail, kg);
+            consume(s0);
+        }
+    }
+    // accumulator register e of tile (ta, tb): row 32 ta + (e & 3) + 8 (e >> 2) + 4 kg, column 32 tb + m of the quadrant
+    float* img = s_acc[qd];
+    if (kh == 1) {
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    img[(32 * ta + (e & 3) + 8 * (e >> 2) + 4 * kg) * 64 + 32 * tb + m] = acc[ta][tb][e];
+    }
+    __syncthreads();
+    if (kh == 0 && active) {
+        float* __restrict__ out = en.slab + ((int64_t)chunk * O + o0) * I + i0;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = 32 * ta + (e & 3) + 8 * (e >> 2) + 4 * kg, col = 32 * tb + m;
+                    out[(int64_t)row * I + col] = en.alpha * (acc[ta][tb][e] + img[row * 64 + col]);
+                }
+    }
+}
+
 // chunks of K: enough workgroups to fill the chip, rows per chunk a whole number of register stages
 inline void plan(int64_t K, int O, int I, int* chunks, int64_t* k_chunk) {
     const int tiles = (O / 64) * (I / 64);
@@ -306,8 +478,17 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
             if (ldy < O || ldx < I || (ldy & 3) || (ldx & 3)) return EQH_ERR_ALIGN;
             b.e[i] = WgradEntry{dy[j], x[j], ws + (size_t)j * SPLITS * slab_elems, K[j], ldy, ldx, alpha[j], 0};
         }
-        hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
-                           tiles, SPLITS);
+        // round 5: the bf16 x 3 kernel (128 x 128 workgroup tiles); EQH_WGRAD_F32=1 keeps the fp32-MFMA kernel for same-box A/B runs
+        static const bool use_f32 = [] { const char* e = std::getenv("EQH_WGRAD_F32"); return e && e[0] == '1'; }();
+        if (use_f32) {
+            hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
+                               tiles, SPLITS);
+        } else {
+            const int t_i = (I + 127) / 128, t_all = ((O + 127) / 128) * t_i;
+            const int groups = m * SPLITS;
+            hipLaunchKernelGGL(k_wgrad_batch_x3, dim3(8 * ((groups + 7) / 8) * t_all), dim3(WX_THREADS), 0, stream, b, m, (int)O,
+                               (int)I, t_i, t_all, SPLITS);
+        }
         EQH_CHECK_LAUNCH();
     }
     // one reduction per destination: runs of equal (dw, ldw) are adjacent, their slabs contiguous
