@@ -258,6 +258,19 @@ def run_case(registry, spec):
         case["knn_val"] = rec["val"].reshape(-1, rec["val"].shape[-1]).numpy()
     case["out"] = out.detach().numpy()
     case["loss"] = loss.detach().numpy()
+    if train_mode and any(isinstance(m_, torch.nn.BatchNorm1d) for m_ in model.modules()):
+        # train-mode BatchNorm over ~100 atoms amplifies fp32 rounding: the reference's OWN float32 output sits 3e-6 .. 7e-6 from
+        # its float64 evaluation (and moves by 2e-6 .. 4e-6 with the thread count), so these cases also carry the float64 output --
+        # the rounding-free value of the reference's algorithm -- for the forward bound
+        torch.manual_seed(0)
+        m64 = registry.get_model_class(method)(1, args)
+        fill_state_dict(m64, seed)
+        m64.train(True)
+        m64 = m64.double()
+        d64 = make_batch(spec)
+        d64.pos, d64.y = d64.pos.double(), d64.y.double()
+        with torch.no_grad():
+            case["out_f64"] = m64(d64).numpy()
     names, has_grad, stats = [], [], []
     for n, p in model.named_parameters():
         names.append(n)

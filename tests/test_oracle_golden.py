@@ -38,7 +38,13 @@ def check_against_case(model, case, data, tol=TOL, taps=True, grad_rtol=1e-4):
     tp = {} if taps else None
     out = model(data, taps=tp) if taps else model(data)
     # 1e-5 absolute wherever |out| <= 1 (north_star); entries larger than 1 get the same RELATIVE budget
-    assert_close(out.detach().cpu().numpy(), case["out"], tol, "out")
+    if "out_f64" in case:
+        # train-mode BatchNorm cases: against the reference's float64 evaluation at 1e-5; against its float32 capture -- itself
+        # 3e-6 .. 7e-6 from that float64 value (make_golden.run_case) -- at the sum of both sides' budgets
+        assert_close(out.detach().cpu().numpy(), case["out_f64"], tol, "out (reference in float64)")
+        assert_close(out.detach().cpu().numpy(), case["out"], 2 * tol, "out")
+    else:
+        assert_close(out.detach().cpu().numpy(), case["out"], tol, "out")
     if taps:
         for k, v in tp.items():
             key = "tap_" + k
