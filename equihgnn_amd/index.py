@@ -69,8 +69,23 @@ class HyperIndex:
                                                                        self.by_v, self.by_e, self._knn_counts)
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
+        self._pad = None        # (batch, number of real molecules) of a padded batch, set by from_batch
+        self._masks = None
         self._he_pool = None
         self.n_box = None   # int32 device [1]: number of real atoms of a padded batch (box of the kNN grid)
+
+    def pad_masks(self):
+        """(node, hyperedge, incidence, molecule) [rows, 1] float masks of the REAL rows of a padded static-shape batch
+        (batch.pad_batch: one dummy molecule owns the padded atoms / hyperedges, padded incidences are null), or four Nones
+        for an unpadded batch -- what BatchNorm inside the MLPs needs to keep the padding out of its training statistics."""
+        if self._pad is None:
+            return (None, None, None, None)
+        if self._masks is None:
+            batch, real = self._pad
+            f = torch.float32
+            self._masks = ((batch < real).to(f).unsqueeze(-1), self.has_e.to(f), (self.v32 >= 0).to(f).unsqueeze(-1),
+                           (torch.arange(self.B, device=batch.device) < real).to(f).unsqueeze(-1))
+        return self._masks
 
     def hyperedge_pool(self, n_e: torch.Tensor):
         """CSR of hyperedges per molecule (from ``n_e``; hyperedges are stored molecule by molecule,
@@ -97,6 +112,7 @@ class HyperIndex:
         if real and real < b and idx.pool is not None:
             # padded batch: the atoms of the first `real` molecules come first; their count stays on the device
             idx.n_box = idx.pool.rowptr[real:real + 1]
+            idx._pad = (data.batch, int(real))
         try:
             data._hyper_index = idx
         except Exception:  # a frozen container: just rebuild next time

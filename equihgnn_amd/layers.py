@@ -86,7 +86,19 @@ class MLP(nn.Module):
             if not isinstance(n, nn.Identity):
                 n.reset_parameters()
 
-    def hidden(self, h, start: int):
+    @staticmethod
+    def _norm(norm, h, mask):
+        """A normalisation of mlp.py:17-60 on rows ``h``; ``mask`` ([rows, 1], 1 = real row) keeps the padded rows of a
+        static-shape batch out of BatchNorm's TRAINING statistics (LayerNorm / Identity are row-wise: no mask needed)."""
+        if isinstance(norm, nn.BatchNorm1d) and h.dim() == 2:
+            return batch_norm_rows(norm, h, mask)
+        return norm(h)
+
+    @property
+    def has_batch_norm(self) -> bool:
+        return any(isinstance(n, nn.BatchNorm1d) for n in self.normalizations)
+
+    def hidden(self, h, start: int, mask=None):
         """ReLU -> norm -> dropout after Linear ``start``, then the hidden Linears up to (not
         including) the last one."""
         last = len(self.lins) - 1
@@ -94,7 +106,7 @@ class MLP(nn.Module):
             if i > start:
                 h = ops.linear(h, self.lins[i].weight, self.lins[i].bias) if h.is_cuda else self.lins[i](h)
             h = F.relu(h)
-            h = self.normalizations[i + 1](h)
+            h = self._norm(self.normalizations[i + 1], h, mask)
             h = F.dropout(h, p=self.dropout, training=self.training)
         return h
 
@@ -107,10 +119,10 @@ class MLP(nn.Module):
                 and all(isinstance(n, nn.LayerNorm) for n in self.normalizations[1:])
                 and all(l.out_features % 4 == 0 and l.out_features <= 1024 for l in self.lins[:-1]))
 
-    def forward(self, x, first=None):
+    def forward(self, x, first=None, mask=None):
         """``first``: x @ lins[0].weight.T already computed by the caller (bias-free; only on the fused path,
-        see ``takes_first``)."""
-        x = self.normalizations[0](x)
+        see ``takes_first``).  ``mask``: [rows, 1] real-row mask of a padded batch (BatchNorm statistics, see _norm)."""
+        x = self._norm(self.normalizations[0], x, mask)          # InputNorm (mlp.py:31-58): LayerNorm / BatchNorm of the input
         if len(self.lins) == 1:
             return ops.linear(x, self.lins[0].weight, self.lins[0].bias)
         if self._fusable(x):
@@ -121,7 +133,7 @@ class MLP(nn.Module):
                 h = first if (i == 0 and first is not None) else ops.linear(x, lin.weight)
                 x = ops.bias_relu_ln(h, lin.bias, norm.weight, norm.bias, norm.eps)
             return ops.linear(x, self.lins[-1].weight, self.lins[-1].bias)
-        h = self.hidden(ops.linear(x, self.lins[0].weight, self.lins[0].bias), 0)
+        h = self.hidden(ops.linear(x, self.lins[0].weight, self.lins[0].bias), 0, mask)
         return ops.linear(h, self.lins[-1].weight, self.lins[-1].bias)
 
 
@@ -134,14 +146,19 @@ def _row_weight(out_csr, has_row, aggr, dtype):
 
 
 def _pair_message(mlp: MLP, a, b, idx_a32, idx_b32, csr_a, csr_b, out_csr, out_key32, has_row, aggr,
-                  residual=None, pa=None):
+                  residual=None, pa=None, inc_mask=None):
     """reduce_r( mlp(cat(a[idx_a], b[idx_b])) ) over the rows of ``out_csr`` — the
     per-incidence MLP + scatter of conv.py:90-93,96-97,175-177, restructured (module docstring).
 
     a is indexed by idx_a32 (CSR keyed by that index: csr_a), b by idx_b32 (csr_b)."""
-    if mlp.InputNorm:
-        raise NotImplementedError("InputNorm=True is never set by the reference wrappers "
-                                  "(equihnn_egnn.py:139-149) and is not supported")
+    if mlp.InputNorm or mlp.has_batch_norm:
+        # A normalisation of the CONCATENATED per-incidence input (InputNorm: mlp.py:31-58 over 2C channels), or BatchNorm
+        # statistics over the incidences: the split-weight restructuring does not apply -- the MLP runs on the [nnz, 2C] rows
+        # as conv.py:90,96,176 writes it (null incidences of a padded batch are zero rows, kept out of the statistics by
+        # ``inc_mask`` and out of the reduction by the CSR)
+        h = torch.cat((ops.gather_rows(a, idx_a32, csr_a), ops.gather_rows(b, idx_b32, csr_b)), -1)
+        out = ops.reduce_entries(mlp(h, mask=inc_mask), out_csr, out_key32, aggr)
+        return out if residual is None else residual[0] * out + residual[2]
     lin0 = mlp.lins[0]
     ca = a.shape[-1]
     cin = lin0.weight.shape[1]
@@ -176,27 +193,34 @@ class MHNNConv(nn.Module):
     def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, mlp4_layers=1,
                  aggr="mean", dropout=0.0, normalization="None", input_norm=False):
         super().__init__()
-        if min(mlp1_layers, mlp2_layers, mlp3_layers, mlp4_layers) < 1:
-            raise NotImplementedError("mlpK_layers=0 (conv.py:33-34) is not reachable from the "
-                                      "reference's scripts and is not supported")
-        mk = lambda n: MLP(hid_dim * 2, hid_dim, hid_dim, n, dropout=dropout,
-                           Normalization=normalization, InputNorm=input_norm)
+        # mlpK_layers = 0 (conv.py:33-34,45-46,57-58,69-70): W_k is `lambda X: X[..., hid_dim:]`, the SECOND half of its
+        # concatenated input, and owns no parameters -- kept as None here
+        mk = lambda n: (MLP(hid_dim * 2, hid_dim, hid_dim, n, dropout=dropout, Normalization=normalization, InputNorm=input_norm)
+                        if n > 0 else None)
         self.W1, self.W2, self.W3, self.W4 = mk(mlp1_layers), mk(mlp2_layers), mk(mlp3_layers), mk(mlp4_layers)
         self.aggr = aggr
         self.dropout = dropout
 
     def reset_parameters(self):
         for w in (self.W1, self.W2, self.W3, self.W4):
-            w.reset_parameters()
+            if w is not None:
+                w.reset_parameters()
 
     def forward(self, X, E, index: HyperIndex):
         ix = index
-        m_e = _pair_message(self.W1, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_e, ix.e32,
-                            ix.has_e, self.aggr)                     # conv.py:90-93
-        E = self.W2(torch.cat((E, m_e), -1))                          # conv.py:94
-        m_v = _pair_message(self.W3, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
-                            ix.has_v, self.aggr)                     # conv.py:96-97
-        X = self.W4(torch.cat((X, m_v), -1))                          # conv.py:98
+        mk = ix.pad_masks()                 # (node, hyperedge, incidence) real-row masks of a padded batch, or Nones
+        if self.W1 is None:                 # the message IS the hyperedge's own row: its mean over the incidences is itself
+            m_e = ops.reduce_entries(ops.gather_rows(E, ix.e32, ix.by_e), ix.by_e, ix.e32, self.aggr)
+        else:
+            m_e = _pair_message(self.W1, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_e, ix.e32,
+                                ix.has_e, self.aggr, inc_mask=mk[2])  # conv.py:90-93
+        E = m_e if self.W2 is None else self.W2(torch.cat((E, m_e), -1), mask=mk[1])   # conv.py:94
+        if self.W3 is None:
+            m_v = ops.reduce_gathered(E, ix.by_v, ix.by_e, self.aggr)
+        else:
+            m_v = _pair_message(self.W3, X, E, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32,
+                                ix.has_v, self.aggr, inc_mask=mk[2])  # conv.py:96-97
+        X = m_v if self.W4 is None else self.W4(torch.cat((X, m_v), -1), mask=mk[0])   # conv.py:98
         return X, E
 
 
@@ -239,20 +263,31 @@ class MHNNSConv(nn.Module):
     def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, aggr="mean",
                  alpha=0.5, dropout=0.0, normalization="None", input_norm=False):
         super().__init__()
-        if min(mlp1_layers, mlp2_layers, mlp3_layers) < 1:
-            raise NotImplementedError("mlpK_layers=0 (conv.py:129-130,155-156) is not supported")
-        self.W1 = MLP(hid_dim, hid_dim, hid_dim, mlp1_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
-        self.W2 = MLP(hid_dim * 2, hid_dim, hid_dim, mlp2_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
-        self.W3 = MLP(hid_dim, hid_dim, hid_dim, mlp3_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
+        # mlpK_layers = 0: W1 = Identity (conv.py:128-130), W2 = the second half of its input (:142-143); for W3 the reference
+        # sets ``self.W`` (:155-156), not ``self.W3``, so its forward() fails with AttributeError at :180 -- reproduced
+        mk = lambda cin, n: (MLP(cin, hid_dim, hid_dim, n, dropout=dropout, Normalization=normalization, InputNorm=input_norm)
+                             if n > 0 else None)
+        self.W1, self.W2 = mk(hid_dim, mlp1_layers), mk(hid_dim * 2, mlp2_layers)
+        if mlp3_layers > 0:
+            self.W3 = mk(hid_dim, mlp3_layers)
+        else:
+            self.W = nn.Identity()
         self.aggr = aggr
         self.alpha = alpha
         self.dropout = dropout
 
+    def _mlps(self):
+        return [w for w in (self.W1, self.W2, getattr(self, "W3", None)) if w is not None]
+
+    @property
+    def plain(self) -> bool:
+        """Configurations outside the scripts' (a missing MLP, InputNorm, BatchNorm inside the MLPs): the layer runs as
+        conv.py:169-182 writes it instead of on the restructured / merged / panel paths."""
+        ws = (self.W1, self.W2, getattr(self, "W3", None))
+        return any(w is None for w in ws) or any(w.InputNorm or w.has_batch_norm for w in ws)
+
     def reset_parameters(self):
-        for w in (self.W1, self.W2, self.W3):
+        for w in self._mlps():
             w.reset_parameters()
 
     def residual(self, X0, index: HyperIndex, passthrough: bool = False):
@@ -277,6 +312,8 @@ class MHNNSConv(nn.Module):
 
     def prepare(self, X0, index: HyperIndex):
         """``residual`` for forward() when the fused path applies (call once per model forward)."""
+        if self.plain:
+            return None
         if X0.is_cuda and X0.dim() == 2 and len(self.W2.lins) > 1:
             if self._mergeable(X0):
                 # (X0 is also the first application's input: it reaches that application through the residual's autograd node)
@@ -325,7 +362,7 @@ class MHNNSConv(nn.Module):
 
     def stack_supported(self, X, residual) -> bool:
         """Whether forward_stack applies: the merged path (``residual`` from prepare()) at a width the panel kernels take."""
-        return (isinstance(residual, dict) and not (self.training and self.dropout > 0)
+        return (isinstance(residual, dict) and not self.plain and not (self.training and self.dropout > 0)
                 and ops.conv_stack_supported(X, self.W1.lins[0].weight.shape[0]))
 
     def forward_stack(self, X, index: HyperIndex, residual, n_layers: int, relu_out: bool):
@@ -344,6 +381,16 @@ class MHNNSConv(nn.Module):
         if isinstance(residual, dict):
             return self._forward_merged(X, ix, residual, relu_out)
         assert not relu_out
+        if self.plain:
+            mk = ix.pad_masks()
+            w1x = X if self.W1 is None else self.W1(X, mask=mk[0])
+            x_e = ops.reduce_gathered(w1x, ix.by_e, ix.by_v, self.aggr)              # conv.py:172-173
+            if self.W2 is None:             # the message is the hyperedge half of the concatenation (conv.py:142-143)
+                x_v = ops.reduce_gathered(x_e, ix.by_v, ix.by_e, self.aggr)
+            else:
+                x_v = _pair_message(self.W2, X, x_e, ix.v32, ix.e32, ix.by_v, ix.by_e, ix.by_v, ix.v32, ix.has_v, self.aggr,
+                                    inc_mask=mk[2])
+            return self.W3(torch.lerp(x_v, X0, self.alpha), mask=mk[0])     # (AttributeError without W3: conv.py:155-156,180)
         fused = X.is_cuda and X.dim() == 2 and len(self.W2.lins) > 1
         pa = None
         if fused and self.W1.takes_first(X) and not self.W2.InputNorm:
@@ -453,4 +500,4 @@ def readout(mlp_out, x, index: HyperIndex, taps=None, head=None):
     xp = pool_sum(x, index)
     if taps is not None:
         taps["pool"] = xp
-    return head_loss(mlp_out(xp).view(-1), head)
+    return head_loss(mlp_out(xp, mask=index.pad_masks()[3]).view(-1), head)     # (mask: BatchNorm in the head over real molecules)

@@ -215,7 +215,7 @@ class _PairedBase(nn.Module):
         both = torch.cat((xp, ep), -1)
         if taps is not None:
             taps["pool"] = both
-        return head_loss(self.mlp_out(both).view(-1), head)
+        return head_loss(self.mlp_out(both, mask=index.pad_masks()[3]).view(-1), head)
 
 
 @registry.register_model("mhnn")

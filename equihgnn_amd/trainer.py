@@ -192,10 +192,8 @@ class GraphedTrainStep:
         self.n_w = 0
         self.fused_head = "head" in inspect.signature(model.forward).parameters
         self._has_buffers = self._multi() and any(True for _ in model.buffers())
-        for mod in model.modules():   # padded (null) incidences would enter the batch statistics of a per-incidence norm
-            if type(mod).__name__ == "MLP" and any(isinstance(n, nn.BatchNorm1d) for n in mod.normalizations):
-                raise NotImplementedError("GraphedTrainStep pads batches to static shapes; BatchNorm inside the "
-                                          "per-incidence MLPs (--normalization bn) would count the padding -- use TrainStep")
+        # (--normalization bn: BatchNorm inside the MLPs takes its training statistics over the REAL rows of the padded static
+        # batch -- HyperIndex.pad_masks, layers.MLP._norm -- so those models replay under hipGraph like the others)
         if broadcast_from_rank0 and self._multi():
             for t in list(model.parameters()):
                 dist.broadcast(t.data, src=0)
@@ -430,6 +428,11 @@ class GraphedTrainStep:
 
     def _capture(self, static):
         multi = self._multi()
+        # autograd graphs of earlier eager passes that are only kept alive by reference cycles hold AccumulateGrad nodes bound
+        # to the stream they ran on; a capture that meets one is invalidated (and capture_end of an invalidated capture
+        # segfaults on ROCm 7.2): collect them first (a capture is rare and costs ~0.3 s anyway)
+        import gc
+        gc.collect()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snap = self._buffer_snapshot()

@@ -126,9 +126,10 @@ class MHNNConv(nn.Module):
     def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, mlp4_layers=1,
                  aggr="mean", dropout=0.0, normalization="None", input_norm=False):
         super().__init__()
-        mk = lambda n: MLP(hid_dim * 2, hid_dim, hid_dim, n, dropout=dropout,
-                           Normalization=normalization, InputNorm=input_norm)
-        assert min(mlp1_layers, mlp2_layers, mlp3_layers, mlp4_layers) > 0
+        # conv.py:22-70: mlpK_layers == 0 makes W_k `lambda X: X[..., hid_dim:]` (the second half of its input, no parameters)
+        half = lambda X: X[..., hid_dim:]
+        mk = lambda n: (MLP(hid_dim * 2, hid_dim, hid_dim, n, dropout=dropout, Normalization=normalization, InputNorm=input_norm)
+                        if n > 0 else half)
         self.W1, self.W2, self.W3, self.W4 = mk(mlp1_layers), mk(mlp2_layers), mk(mlp3_layers), mk(mlp4_layers)
         self.aggr = aggr
 
@@ -149,13 +150,15 @@ class MHNNSConv(nn.Module):
     def __init__(self, hid_dim, mlp1_layers=1, mlp2_layers=1, mlp3_layers=1, aggr="mean",
                  alpha=0.5, dropout=0.0, normalization="None", input_norm=False):
         super().__init__()
-        assert min(mlp1_layers, mlp2_layers, mlp3_layers) > 0
-        self.W1 = MLP(hid_dim, hid_dim, hid_dim, mlp1_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
-        self.W2 = MLP(hid_dim * 2, hid_dim, hid_dim, mlp2_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
-        self.W3 = MLP(hid_dim, hid_dim, hid_dim, mlp3_layers, dropout=dropout,
-                      Normalization=normalization, InputNorm=input_norm)
+        # conv.py:118-156: zero layers -> W1 = Identity, W2 = the second half of its input, and for W3 the reference assigns
+        # ``self.W`` instead of ``self.W3`` (:155-156), so forward() raises AttributeError at :180 -- restated as it is
+        mk = lambda cin, n: MLP(cin, hid_dim, hid_dim, n, dropout=dropout, Normalization=normalization, InputNorm=input_norm)
+        self.W1 = mk(hid_dim, mlp1_layers) if mlp1_layers > 0 else nn.Identity()
+        self.W2 = mk(hid_dim * 2, mlp2_layers) if mlp2_layers > 0 else (lambda X: X[..., hid_dim:])
+        if mlp3_layers > 0:
+            self.W3 = mk(hid_dim, mlp3_layers)
+        else:
+            self.W = nn.Identity()
         self.aggr = aggr
         self.alpha = alpha
 

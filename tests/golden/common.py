@@ -105,6 +105,17 @@ CASE_TABLE = {
     "equiformer_equihnns_tiny": ("equiformer_equihnns", 64, 72, 1, True, True, dict(last_conj=False)),
     # degenerate edge geometry for the Equiformer's D construction
     "equiformer_equihnns_c64_degenerate": ("equiformer_equihnns", 64, 68, 5, True, True, dict(geometry="degenerate")),
+    # round 5: configurations the reference accepts but its scripts never set (`args`: overrides of golden_args) -- BatchNorm
+    # inside the MLPs (mlp.py:29-44: --normalization bn), zero-layer MLPs (conv.py:33-34,45-46,57-58,69-70,128-130,142-143:
+    # slices / identity) and one-layer MLPs (a single Linear: mlp.py:30-36)
+    "egnn_equihnns_c64_bn": ("egnn_equihnns", 64, 73, 6, True, True, dict(last_conj=False, args=dict(normalization="bn"))),
+    "mhnnm_c64_bn_train": ("mhnnm", 64, 74, 6, True, True, dict(last_conj=False, args=dict(normalization="bn"))),
+    "egnn_equihnns_c64_mlp0": ("egnn_equihnns", 64, 75, 6, True, True,
+                               dict(last_conj=False, args=dict(MLP1_num_layers=0, MLP2_num_layers=0))),
+    "mhnnm_c64_mlp0_13": ("mhnnm", 64, 76, 6, True, True, dict(last_conj=False, args=dict(MLP1_num_layers=0, MLP3_num_layers=0))),
+    "mhnnm_c64_mlp0_24": ("mhnnm", 64, 77, 6, True, True, dict(last_conj=False, args=dict(MLP2_num_layers=0, MLP4_num_layers=0))),
+    "egnn_equihnns_c64_mlp1": ("egnn_equihnns", 64, 78, 6, True, True,
+                               dict(last_conj=False, args=dict(MLP1_num_layers=1, MLP2_num_layers=1, MLP3_num_layers=1))),
 }
 
 
@@ -157,7 +168,7 @@ F64_SAMPLE = 4096
 def f64_spec(name: str) -> dict:
     method, hidden, seed, n_mols, train, opt = F64_TABLE[name]
     spec = dict(name=name, method=method, hidden=hidden, seed=seed, n_mols=n_mols, train=train, store_grads=True,
-                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1)
+                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1, args={})
     spec.update(opt)
     return spec
 
@@ -190,7 +201,7 @@ def trajectory_batches(name: str):
 def case_spec(name: str) -> dict:
     method, hidden, seed, n_mols, train, store, opt = CASE_TABLE[name]
     spec = dict(name=name, method=method, hidden=hidden, seed=seed, n_mols=n_mols, train=train, store_grads=store,
-                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1)
+                flavour="qm9", last_conj=True, big=None, geometry=None, dropout0=False, depth=1, args={})
     spec.update(opt)
     return spec
 

@@ -188,7 +188,7 @@ def run_case(registry, spec):
     method, hidden, seed, train_mode, store_grads = (spec["method"], spec["hidden"], spec["seed"], spec["train"],
                                                      spec["store_grads"])
     torch.manual_seed(0)
-    args = golden_args(method, hidden)
+    args = golden_args(method, hidden, **spec.get("args", {}))
     model = registry.get_model_class(method)(1, args)
     fill_state_dict(model, seed)
     model.train(train_mode)

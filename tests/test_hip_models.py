@@ -277,6 +277,75 @@ def test_padded_batch_is_exact(method):
             assert float((q.grad - g0[n]).abs().max()) / scale < (2e-3 if bn else 1e-4), n
 
 
+@pytest.mark.parametrize("method,kw", [("egnn_equihnns", dict(normalization="bn")), ("mhnnm", dict(normalization="bn")),
+                                       ("mhnn", dict(normalization="bn")),
+                                       ("egnn_equihnns", dict(MLP1_num_layers=0, MLP2_num_layers=0)),
+                                       ("mhnnm", dict(MLP2_num_layers=0, MLP4_num_layers=0))])
+def test_padded_batch_is_exact_with_batch_norm_inside_the_mlps_and_without_mlps(method, kw):
+    """--normalization bn puts nn.BatchNorm1d inside every MLP (mlp.py:29-44): per-incidence rows (conv.py:90,96,176), node
+    rows, hyperedge rows, and the molecule rows of the output head.  On a padded static-shape batch each of them takes its
+    training statistics and running-buffer updates over the REAL rows only (HyperIndex.pad_masks -> layers.MLP._norm), so
+    outputs, gradients and buffers equal the unpadded batch's -- which is what lets GraphedTrainStep run these models (it
+    refused them until round 5).  Zero-layer MLPs (conv.py:33-34,...: slices / identity) take the same plain path."""
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep
+    args = default_args(method=method, MLP_hidden=64, output_hidden=32, **kw)
+    m = _models()[method](1, args)
+    fill_state_dict(m, 29)
+    m.to(DEV)
+    b = synth_batch(12, 4545)
+    n, mm, z = bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64)
+    p = pad_batch(b, n, mm, z + 64).to(DEV)
+    p.num_real_graphs = 12
+    b = b.to(DEV)
+    buf0 = {k: t.clone() for k, t in m.named_buffers()}
+    out = m(b)
+    torch.nn.functional.mse_loss(out, b.y).backward()
+    g0 = {k: q.grad.clone() for k, q in m.named_parameters() if q.grad is not None}
+    buf1 = {k: t.clone() for k, t in m.named_buffers()}
+    for q in m.parameters():
+        q.grad = None
+    for k, t in m.named_buffers():
+        t.copy_(buf0[k])
+    outp = m(p)
+    for k, t in m.named_buffers():
+        np.testing.assert_allclose(t.cpu().numpy(), buf1[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    torch.nn.functional.mse_loss(outp[:12], p.y[:12]).backward()
+    bn = "normalization" in kw or method == "mhnnm"
+    np.testing.assert_allclose(outp[:12].detach().cpu().numpy(), out.detach().cpu().numpy(), atol=1e-5 if bn else 2e-6,
+                               rtol=1e-5 if bn else 1e-6)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k, q in m.named_parameters():
+        if k in g0:
+            scale = max(float(g0[k].abs().max()), 1e-3 * gmax) + 1e-12
+            assert float((q.grad - g0[k]).abs().max()) / scale < (2e-3 if bn else 1e-4), k
+    # ... and the graphed trainer accepts the model: bootstrap + capture + two replays with a finite, moving loss.  (The eager
+    # passes above ran on the default stream: their autograd graphs -- alive through `out` / `outp` -- hold AccumulateGrad nodes
+    # bound to that stream, which a capture on another stream must not meet: DESIGN.md, "Finding (autograd + capture)".)
+    import gc
+    del out, outp
+    for q in m.parameters():
+        q.grad = None
+    gc.collect()
+    tr = GraphedTrainStep(m, lr=1e-3)
+    losses = [float(tr.step(p)) for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] != losses[0]
+    tr.close()
+
+
+def test_mhnnsconv_without_w3_fails_like_the_reference():
+    """MLP3_num_layers = 0: conv.py:155-156 assigns ``self.W`` instead of ``self.W3``, so the reference's forward raises
+    AttributeError at :180; the drop-in reproduces the error (and the parameter list: no W3)."""
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.registry import default_args
+    m = _models()["egnn_equihnns"](1, default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32, MLP3_num_layers=0))
+    assert not any(k.startswith("conv.W3") for k in m.state_dict())
+    m.to(DEV)
+    with pytest.raises(AttributeError, match="W3"):
+        m(synth_batch(4, 1).to(DEV))
+
+
 @pytest.mark.parametrize("variant", ["mlp3", "no_norm", "mhnn_mlp3"])
 def test_padded_batch_is_exact_on_the_unfused_incidence_path(variant):
     """The per-incidence MLPs leave the fused gather+add+ReLU+LN+reduce kernel when they have three layers or no

@@ -25,11 +25,12 @@ def golden_neighbour_ids(case):
 
 def build(case, models=ref_models.MODELS):
     method = str(case["meta_method"])
-    model = models[method](1, golden_args(method, int(case["meta_hidden"])))
+    name = str(case.get("meta_name", ""))
+    spec = case_spec(name) if name in CASE_TABLE else {"dropout0": False, "args": {}}
+    model = models[method](1, golden_args(method, int(case["meta_hidden"]), **spec["args"]))
     fill_state_dict(model, int(case["meta_seed"]))
     model.train(bool(int(case["meta_train"])))
-    name = str(case.get("meta_name", ""))
-    if name and case_spec(name)["dropout0"]:
+    if spec["dropout0"]:
         zero_dropouts(model)
     return model
 
@@ -39,10 +40,13 @@ def check_against_case(model, case, data, tol=TOL, taps=True, grad_rtol=1e-4):
     out = model(data, taps=tp) if taps else model(data)
     # 1e-5 absolute wherever |out| <= 1 (north_star); entries larger than 1 get the same RELATIVE budget
     if "out_f64" in case:
-        # train-mode BatchNorm cases: against the reference's float64 evaluation at 1e-5; against its float32 capture -- itself
-        # 3e-6 .. 7e-6 from that float64 value (make_golden.run_case) -- at the sum of both sides' budgets
+        # train-mode BatchNorm cases: against the reference's float64 evaluation at 1e-5; against its float32 capture at 1e-5
+        # PLUS that capture's own distance from the float64 value, read off the fixture (3e-6 .. 7e-6 with BatchNorm between
+        # the layers, 2e-5 with --normalization bn, where every MLP -- the head over a handful of molecules included -- has one)
         assert_close(out.detach().cpu().numpy(), case["out_f64"], tol, "out (reference in float64)")
-        assert_close(out.detach().cpu().numpy(), case["out"], 2 * tol, "out")
+        ref32, ref64 = case["out"].astype(np.float64), case["out_f64"]
+        own = float((np.abs(ref32 - ref64) / np.maximum(1.0, np.abs(ref64))).max())
+        assert_close(out.detach().cpu().numpy(), case["out"], tol + own, "out")
     else:
         assert_close(out.detach().cpu().numpy(), case["out"], tol, "out")
     if taps:
