@@ -334,6 +334,44 @@ def test_padded_batch_is_exact_with_batch_norm_inside_the_mlps_and_without_mlps(
     tr.close()
 
 
+@pytest.mark.parametrize("kind,norm", [("s", "ln"), ("s", "bn"), ("m", "ln")])
+def test_conv_layers_with_input_norm_match_the_oracle(kind, norm):
+    """InputNorm=True (mlp.py:31-58: a LayerNorm / BatchNorm of the MLP's INPUT -- for the per-incidence MLPs that is the
+    concatenated [nnz, 2C] row, conv.py:90,96,176).  The reference's wrappers never set it (equihnn_egnn.py:139-149 pass
+    InputNorm=False), the layers accept it: MHNNSConv / MHNNConv against the oracle's layers, outputs and all gradients."""
+    from equihgnn_amd import layers as L
+    from equihgnn_amd.batch import synth_batch
+    from equihgnn_amd.index import HyperIndex
+    C = 64
+    torch.manual_seed(3)
+    data = synth_batch(7, 77)
+    if kind == "s":
+        mine, ref = (cls(C, 2, 2, 2, normalization=norm, input_norm=True) for cls in (L.MHNNSConv, O.MHNNSConv))
+    else:
+        mine, ref = (cls(C, 2, 2, 2, 2, normalization=norm, input_norm=True) for cls in (L.MHNNConv, O.MHNNConv))
+    fill_state_dict(ref, 5)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    mine.to(DEV).train()
+    ref.train()
+    N, M = data.num_nodes, data.num_hyperedges
+    X, X0, E = torch.randn(N, C), torch.randn(N, C), torch.randn(M, C)
+    w = torch.randn(N, C)
+    Xd, X0d, Ed = (t.to(DEV).requires_grad_(True) for t in (X, X0, E))
+    Xr, X0r, Er = (t.clone().requires_grad_(True) for t in (X, X0, E))
+    ix = HyperIndex.from_batch(data.to(DEV))
+    if kind == "s":
+        out, out_ref = mine(Xd, ix, X0d), ref(Xr, data.edge_index0, data.edge_index1, X0r)
+    else:
+        out, out_ref = mine(Xd, Ed, ix)[0], ref(Xr, Er, data.edge_index0, data.edge_index1)[0]
+    (out * w.to(DEV)).sum().backward()
+    (out_ref * w).sum().backward()
+    assert_close(out.detach().cpu().numpy(), out_ref.detach().numpy(), 2e-5 if norm == "bn" else TOL, "out")
+    gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
+    for (n, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert float((p.grad.cpu() - q.grad).abs().max()) <= (2e-3 if norm == "bn" else 2e-4) * gmax, n
+    assert float((Xd.grad.cpu() - Xr.grad).abs().max()) <= 2e-4 * max(1.0, float(Xr.grad.abs().max()))
+
+
 def test_mhnnsconv_without_w3_fails_like_the_reference():
     """MLP3_num_layers = 0: conv.py:155-156 assigns ``self.W`` instead of ``self.W3``, so the reference's forward raises
     AttributeError at :180; the drop-in reproduces the error (and the parameter list: no W3)."""
