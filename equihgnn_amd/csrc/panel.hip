@@ -592,6 +592,66 @@ PN_KERNEL(NW) k_panel_plain(const PanelPlain p) {
     PN_STAMP(5);
 }
 
+// ---- several products of ONE row block: out_g = A W_g + rw_g[row] * bias_g + D_g, g < NG <= 3 --------------------------------
+// (MHNNConv, conv.py:87-101 after the split of every first Linear by input block: X feeds W1's and W3's node halves and W4's own
+// half, E feeds W1's hyperedge half and W2's own half -- one A image, NG weight streams.  rw: per-row weight of the bias, the
+// [row has an incidence] factor that a mean over an empty row leaves on the bias of the Linear behind it.)
+struct PanelMulti {
+    const float* A;
+    int64_t lda;
+    int rows;
+    const uint4* W[3];
+    const float* bias[3];
+    const float* rw[3];
+    const float* D[3];
+    int64_t ldd[3];
+    float* out[3];
+    int64_t ldo[3];
+};
+
+template <int C, int NW, int NG>
+PN_KERNEL(NW) k_panel_multi(const PanelMulti p) {
+    using S = PnShape<C, NW>;
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[NG][PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RtPos<NW> P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
+    const bool mul = wave < S::NT;
+    RowTile<C, NW> x;
+    rt_load<C, NW>(x, p.A, p.lda, P.rowc, P.c4);
+    WStream<S::KS, S::NTW, NG, NW> ws;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ws.init(g, p.W[g], mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    rt_a_put<C, NW, S::KS>(x, s_img, P.lrow, P.c);
+    __syncthreads();
+    f32x16 acc[NG][S::NTW];
+    acc_zero<NG, S::NTW>(acc);
+    if (mul) {
+        panel_mma<S::KS, S::NTW, NG, NW>(s_img, ws, acc, lane);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc_to_staging<S::NTW, NW>(s_stg[g], acc[g], wave, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        RowTile<C, NW> a, bv, d;
+        rt_load<C, NW>(a, s_stg[g], PN_STG_LD, P.lrow, P.c4);
+        if (p.bias[g]) rt_load_vec<C, NW>(bv, p.bias[g], P.c4);
+        else rt_zero<C, NW>(bv);
+        const float w = (p.bias[g] && p.rw[g]) ? p.rw[g][P.rowc] : 1.0f;
+        if (p.D[g]) rt_load<C, NW>(d, p.D[g], p.ldd[g], P.rowc, P.c4);
+        else rt_zero<C, NW>(d);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) {
+            a.v[j].x = fmaf(w, bv.v[j].x, a.v[j].x) + d.v[j].x; a.v[j].y = fmaf(w, bv.v[j].y, a.v[j].y) + d.v[j].y;
+            a.v[j].z = fmaf(w, bv.v[j].z, a.v[j].z) + d.v[j].z; a.v[j].w = fmaf(w, bv.v[j].w, a.v[j].w) + d.v[j].w;
+        }
+        if (P.live) rt_store<C, NW>(a, p.out[g], p.ldo[g], P.row, P.c4);
+    }
+}
+
 // =============================================================================================================================
 // The merged MHNNSConv application (conv.py:169-182 after layers.MHNNSConv._prepare_merged) on panels.
 //   forward  F1: h1 = X W1a^T (stored raw, the LayerNorm backward recomputes from it), h1n = LN1(relu(h1 + b1a)), pa = X W2v^T
@@ -1252,6 +1312,46 @@ extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_)
     }
 #undef PN_LAUNCH
 #undef PN_LAUNCH_W
+}
+
+extern "C" int hg_panel_multi(const HgPanelMulti* q, void* stream_) {
+    if (!q || q->rows < 0 || !q->a || q->n < 1 || q->n > 3) return EQH_ERR_ARG;
+    const int C = q->C;
+    if (!pn_width_ok(C)) return EQH_ERR_ARG;
+    if (q->rows >= ((int64_t)1 << 31) - 64) return EQH_ERR_RANGE;
+    if ((q->lda & 3) || !eqh_aligned16(q->a)) return EQH_ERR_ALIGN;
+    PanelMulti p{};
+    p.A = q->a; p.lda = q->lda; p.rows = (int)q->rows;
+    for (int g = 0; g < q->n; ++g) {
+        if (!q->w[g] || !q->out[g]) return EQH_ERR_ARG;
+        if (!eqh_aligned16(q->w[g]) || !eqh_aligned16(q->out[g]) || !eqh_aligned16(q->bias[g]) || !eqh_aligned16(q->d[g]) ||
+            (q->ldo[g] & 3) || (q->d[g] && (q->ldd[g] & 3)))
+            return EQH_ERR_ALIGN;
+        p.W[g] = static_cast<const uint4*>(q->w[g]); p.bias[g] = q->bias[g]; p.rw[g] = q->rw[g]; p.D[g] = q->d[g];
+        p.ldd[g] = q->ldd[g]; p.out[g] = q->out[g]; p.ldo[g] = q->ldo[g];
+    }
+    if (q->rows == 0) return EQH_OK;
+    const int nw = pn_waves();
+    const dim3 grid((unsigned)((q->rows + PN_ROWS - 1) / PN_ROWS)), block(64 * nw);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define PN_MULTI_C(NW_, NG_)                                                                                   \
+    do {                                                                                                       \
+        if (C == 256) hipLaunchKernelGGL((k_panel_multi<256, NW_, NG_>), grid, block, 0, stream, p);           \
+        else if (C == 128) hipLaunchKernelGGL((k_panel_multi<128, NW_, NG_>), grid, block, 0, stream, p);      \
+        else hipLaunchKernelGGL((k_panel_multi<64, NW_, NG_>), grid, block, 0, stream, p);                     \
+    } while (0)
+#define PN_MULTI(NG_)                                                                                          \
+    do {                                                                                                       \
+        if (nw == 8) PN_MULTI_C(8, NG_);                                                                       \
+        else PN_MULTI_C(4, NG_);                                                                               \
+    } while (0)
+    if (q->n == 1) PN_MULTI(1);
+    else if (q->n == 2) PN_MULTI(2);
+    else PN_MULTI(3);
+#undef PN_MULTI
+#undef PN_MULTI_C
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
 }
 
 extern "C" int32_t hg_panel_waves(void) { return pn_waves(); }

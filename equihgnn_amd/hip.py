@@ -47,6 +47,13 @@ class HgConvPanel(ctypes.Structure):
                 + [("g_inc", c_void_p), ("be_inc", c_void_p), ("eps_inc", c_float), ("out6", c_void_p)])
 
 
+class HgPanelMulti(ctypes.Structure):
+    """HgPanelMulti of include/equihgnn_hip.h (up to three products of one row block)."""
+    _fields_ = [("a", c_void_p), ("lda", c_int64), ("rows", c_int64), ("C", c_int32), ("n", c_int32), ("w", c_void_p * 3),
+                ("bias", c_void_p * 3), ("rw", c_void_p * 3), ("d", c_void_p * 3), ("ldd", c_int64 * 3), ("out", c_void_p * 3),
+                ("ldo", c_int64 * 3)]
+
+
 class HbCollate(ctypes.Structure):
     """HbCollate of include/equihgnn_hip.h (operands of hb_collate, the host-side batch assembly)."""
     _fields_ = ([("B", c_int64), ("n_mols", c_int64)]
@@ -63,6 +70,7 @@ SIGNATURES = {
     "hg_conv_panel_slab_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_conv_panel": (c_int32, [c_int32, ctypes.POINTER(HgConvPanel), c_void_p]),
     "hg_panel_waves": (c_int32, []),
+    "hg_panel_multi": (c_int32, [ctypes.POINTER(HgPanelMulti), c_void_p]),
     "hb_collate": (c_int32, [ctypes.POINTER(HbCollate)]),
     "hg_panel_pack_bytes": (c_size_t, [c_int32, c_int32]),
     "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),

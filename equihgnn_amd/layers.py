@@ -208,6 +208,8 @@ class MHNNConv(nn.Module):
 
     def forward(self, X, E, index: HyperIndex):
         ix = index
+        if ops.mhnn_panel_supported(X, E, self):
+            return ops.mhnn_conv_panel(self, X, E, ix)      # the scripts' configuration: one autograd node on the panel kernels
         mk = ix.pad_masks()                 # (node, hyperedge, incidence) real-row masks of a padded batch, or Nones
         if self.W1 is None:                 # the message IS the hyperedge's own row: its mean over the incidences is itself
             m_e = ops.reduce_entries(ops.gather_rows(E, ix.e32, ix.by_e), ix.by_e, ix.e32, self.aggr)

@@ -54,6 +54,8 @@ from .conv_stack import (  # noqa: F401
     conv_stack_supported, merged_conv_stack, _MergedConvStack,
 )
 from . import conv_stack  # noqa: F401
+from .mhnn_panel import (mhnn_conv_panel, mhnn_panel_supported, panel_multi)  # noqa: F401
+from . import mhnn_panel  # noqa: F401
 from .rows import (  # noqa: F401
     _IncidenceLnReduce, _BiasReluLn, _LinearAddReluLn, linear_add_relu_ln, _GatherLnReduce, gather_ln_reduce,
     _BatchNormRows, batch_norm_rows, batch_norm_rows_supported, _LayerNormRows, incidence_ln_reduce, bias_relu_ln,

@@ -212,6 +212,23 @@ typedef struct {
 } HgConvPanel;
 size_t hg_conv_panel_slab_bytes(int64_t rows, int32_t C);
 int hg_conv_panel(int32_t stage, const HgConvPanel* args, void* stream);
+/* Up to three products of ONE row block in one launch: out[g] = a W_g + rw[g][row] * bias[g] + d[g], g < n <= 3 (bias, rw, d
+ * may be NULL; rw: per-row weight of the bias).  MHNNConv (conv.py:87-101) with every first Linear split by input block: X
+ * feeds the node halves of W1 and W3 and W4's own half, E the hyperedge half of W1 and W2's own half -- the library GEMMs of
+ * `F.linear` on [rows, C] x [C, C] for the `mhnn` / `mhnnm` / `egnn_equihnn(m)` methods. */
+typedef struct {
+    const float* a;
+    int64_t lda, rows;
+    int32_t C, n;
+    const void* w[3];
+    const float* bias[3];
+    const float* rw[3];
+    const float* d[3];
+    int64_t ldd[3];
+    float* out[3];
+    int64_t ldo[3];
+} HgPanelMulti;
+int hg_panel_multi(const HgPanelMulti* args, void* stream);
 /* wavefronts per panel workgroup the library launches (8; 4 with EQH_PANEL_WAVES=4 in the environment: round 4's geometry,
  * kept for same-box A/B measurements) */
 int32_t hg_panel_waves(void);
