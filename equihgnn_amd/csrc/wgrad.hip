@@ -448,9 +448,18 @@ extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t 
  * destination must be adjacent (they are summed in array order by one reduction); the workspace holds
  * count * 3 slabs of O x I floats.  ld_dy / ld_x (NULL: O / I): row strides of the operands, so that column blocks of
  * wider matrices (the two halves of a [rows x 2 C] hidden activation) join a batch of [C x C] products. */
+// chunks of K per product of a batched launch: three where that fills the chip (21 products x four 128 x 128 tiles), more for
+// a few large products (the [2176 x 4.7 k] . [4.7 k x 256] gradient of the EGNN's first edge Linear alone: 34 tiles x 8)
+static inline int wg_batch_splits(int32_t count, int32_t O, int32_t I) {
+    const int64_t tiles = (int64_t)((O + 127) / 128) * ((I + 127) / 128) * count;
+    if (tiles * 3 >= 200) return 3;
+    int64_t s = (256 + tiles - 1) / tiles;
+    return (int)(s < 3 ? 3 : (s > 8 ? 8 : s));
+}
+
 extern "C" size_t hg_wgrad_batch_workspace_bytes(int32_t count, int32_t O, int32_t I) {
     if (count <= 0 || O <= 0 || I <= 0) return 0;
-    return (size_t)count * 3 * (size_t)O * (size_t)I * sizeof(float);
+    return (size_t)count * wg_batch_splits(count, O, I) * (size_t)O * (size_t)I * sizeof(float);
 }
 
 extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const float* const* x, const int64_t* K,
@@ -463,7 +472,7 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
     if ((O & 63) || (I & 63) || !eqh_aligned16(workspace)) return EQH_ERR_ALIGN;
     if (workspace_bytes < hg_wgrad_batch_workspace_bytes(count, O, I)) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    constexpr int SPLITS = 3;  // measured flat between 2 and 6 (2.03-2.06 ms per step); 1 loses 5 %
+    const int SPLITS = wg_batch_splits(count, O, I);  // (three for the conv-sized batches: measured flat between 2 and 6)
     const int tiles_i = I / 64, tiles = (O / 64) * tiles_i;
     const size_t slab_elems = (size_t)O * I;
     float* ws = static_cast<float*>(workspace);

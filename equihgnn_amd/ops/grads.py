@@ -6,6 +6,7 @@ Part of equihgnn_amd.ops (host-side operators over libequihgnn_hip.so; no CPU fa
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -187,7 +188,10 @@ def defer_flush(device):
             if mid:
                 x6_mid.extend(mid)
                 rest = [en for en in rest if not any(en is m for m in mid)]
-            if len(rest) >= 3:
+            big = rest and ((rest[0][3].shape[0] + 127) // 128) * ((rest[0][3].shape[1] + 127) // 128) * len(rest) >= 12
+            if len(rest) >= 3 or (big and BATCH_LONE_WGRAD):
+                # (a lone LARGE product -- the [2176 x 256] gradient of the EGNN's first edge Linear: 34 tiles of 128 x 128 -- fills
+                # the chip in the batched bf16 x 3 kernel with a deeper split of K)
                 wgrad_batch(rest)
             else:   # too few products of this shape to fill the chip together: the library GEMM is faster
                 with torch.no_grad():
@@ -263,6 +267,9 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None, scale: float = 1.0):
 # defer_flush (hg_wgrad_batch_f32): one launch per shape.  Outside deferral the library GEMM is used.
 USE_WGRAD_KERNEL = False      # the single-product kernel (ops.wgrad) for immediate weight gradients
 DEFER_WGRAD = True            # batched weight gradients at defer_flush
+# a lone LARGE product through the batched kernel with a deeper split of K: measured 70 us against the library's 54 for the
+# [2176 x 4.7 k] . [4.7 k x 256] gradient of the EGNN's first edge Linear (eight slabs of 2.2 MB) -- off
+BATCH_LONE_WGRAD = os.environ.get("EQH_LONE_WGRAD", "0") == "1"
 
 
 def _wgrad_shape_ok(dy2, x2):

@@ -126,7 +126,14 @@ X6_WGRAD_ROWS = int(os.environ.get("EQH_X6_WGRAD_ROWS", 8192))        # deferred
 USE_X6 = os.environ.get("EQH_GEMM", "auto") != "library"
 
 
+# judge a product by its work (outputs x K / 256) instead of its outputs: measured on the K = 2176 input gradient of the EGNN's
+# first edge Linear ([4.7 k x 2176] . [2176 x 256]): x6 47.6 us against the library's 49.1 -- not worth a rule of its own; off
+X6_K_WEIGHT = os.environ.get("EQH_X6_KWEIGHT", "0") == "1"
+
+
 def _x6_ok(a, b, trans_b, out_elems, k) -> bool:
+    if X6_K_WEIGHT:
+        out_elems = out_elems * max(k, 256) // 256
     return (USE_X6 and out_elems >= X6_MIN_OUTPUTS and k <= X6_MAX_K and a.is_cuda and a.dtype == torch.float32
             and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2 and gemm_supported(a, b, False, trans_b))
 
