@@ -74,6 +74,10 @@ __device__ __forceinline__ int xcd_item(int b, int grid, int n_items, int remap)
     return item < n_items ? item : -1;
 }
 static inline int xcd_grid(int n_items, int remap) { return remap ? ((n_items + 7) / 8) * 8 : n_items; }
+// (Measured and not kept for the backward kernels: walking an XCD's chunks TILE-MAJOR -- all resident blocks on one 256-byte
+// column block of `ab`, 1.2 MB, L2-sized -- instead of all 17 column blocks at once: recv 96 -> 122 us, send 85 -> 114.  With the
+// nodes in Morton order the chunk-major mapping above is worth 7 % on all three kernels (scratch experiment);
+// in molecule order, where a node's 16 neighbours lie anywhere in the batch, it is worth 1 %.)
 
 __host__ __device__ inline int lds_row_stride(int Hp) {  // (stride mod 64) == 24: conflict-free b128
     return Hp + ((24 - (Hp & 63)) + 64) % 64;

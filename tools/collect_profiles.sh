@@ -3,7 +3,7 @@
 # gpurun_out/final/, named for round $2 (default r03).  Copy what should be judged into profiles/.
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh 1'
 set -u
-R=${2:-r04}
+R=${2:-r05}
 mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
