@@ -350,12 +350,16 @@ extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* row
     if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t lds = row_lds_bytes(Kd, L);
-    if ((Kd == 64 || Kd == 192) && lds <= ROW_LDS_MAX) {   // the widths of the radial contraction (mid, 3 * mid)
-        static bool a4 = false, a12 = false;
+    if ((Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {   // the widths of the radial contraction (mid, 3 * mid; li of the pooled form)
+        static bool a4 = false, a12 = false, a16 = false;
         const int blocks = eqh_grid_for(R, 1, 2048);
         if (Kd == 64) {
             if (row_lds_attr(k_rowgemm_fwd_lds<4>, &a4)) return EQH_ERR_LAUNCH;
             hipLaunchKernelGGL(k_rowgemm_fwd_lds<4>, dim3(blocks), dim3(THREADS), lds, stream, z, w, rowptr, perm, (int)R,
+                               (int)L, out, (int)accumulate);
+        } else if (Kd == 256) {
+            if (row_lds_attr(k_rowgemm_fwd_lds<16>, &a16)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_fwd_lds<16>, dim3(blocks), dim3(THREADS), lds, stream, z, w, rowptr, perm, (int)R,
                                (int)L, out, (int)accumulate);
         } else {
             if (row_lds_attr(k_rowgemm_fwd_lds<12>, &a12)) return EQH_ERR_LAUNCH;
@@ -379,16 +383,20 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
     int rc = check(R, Kd, L);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
-    if (!z || !w || !dout || !rowptr) return EQH_ERR_ARG;
-    if (!eqh_aligned16(dout) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
+    if (!z || !dout || !rowptr || (dz && !w)) return EQH_ERR_ARG;     // (w is read for dz only)
+    if (!eqh_aligned16(dout) || (dz && !eqh_aligned16(w)) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const size_t lds = row_lds_bytes(Kd, L);
-    if (dz && (Kd == 64 || Kd == 192) && lds <= ROW_LDS_MAX) {
-        static bool a4 = false, a12 = false;
+    if (dz && (Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {
+        static bool a4 = false, a12 = false, a16 = false;
         const int blocks = eqh_grid_for(R, 1, 2048);
         if (Kd == 64) {
             if (row_lds_attr(k_rowgemm_bwd_z_lds<4>, &a4)) return EQH_ERR_LAUNCH;
             hipLaunchKernelGGL(k_rowgemm_bwd_z_lds<4>, dim3(blocks), dim3(THREADS), lds, stream, dout, w, rowptr, perm,
+                               (int)R, (int)L, dz, (int)accumulate_dz);
+        } else if (Kd == 256) {
+            if (row_lds_attr(k_rowgemm_bwd_z_lds<16>, &a16)) return EQH_ERR_LAUNCH;
+            hipLaunchKernelGGL(k_rowgemm_bwd_z_lds<16>, dim3(blocks), dim3(THREADS), lds, stream, dout, w, rowptr, perm,
                                (int)R, (int)L, dz, (int)accumulate_dz);
         } else {
             if (row_lds_attr(k_rowgemm_bwd_z_lds<12>, &a12)) return EQH_ERR_LAUNCH;
@@ -403,9 +411,12 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
                            (int)Kd, (int)L, dz, (int)accumulate_dz);
         EQH_CHECK_LAUNCH();
     }
-    if (dw && ((Kd == 64 && (L == 256 || L == 64)) || (Kd == 192 && L == 64))) {
+    if (dw && ((Kd == 64 && (L == 256 || L == 64)) || ((Kd == 192 || Kd == 256) && L == 64))) {
         const int blocks = eqh_grid_for(R, 1, 2048);
-        if (Kd == 64 && L == 256)
+        if (Kd == 256)
+            hipLaunchKernelGGL((k_rowgemm_bwd_w_lds<16, 4>), dim3(blocks), dim3(THREADS), 0, stream, z, dout, rowptr, perm,
+                               (int)R, dw);
+        else if (Kd == 64 && L == 256)
             hipLaunchKernelGGL((k_rowgemm_bwd_w_lds<4, 16>), dim3(blocks), dim3(THREADS), 0, stream, z, dout, rowptr, perm,
                                (int)R, dw);
         else if (Kd == 64)

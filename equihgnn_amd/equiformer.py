@@ -29,6 +29,8 @@ from .index import HyperIndex
 
 import os as _os
 
+# the POOLED (0,0) pair of tp_in through one product per pass instead of two (radial_contract_pooled; off: per-edge outputs, then the mean)
+POOLED = not _os.environ.get("EQH_NO_EQF_POOLED")
 FUSE_SMALL = not _os.environ.get("EQH_NO_EQF_FUSE")   # degree-1 Norm and masked means on the row kernels (off: the torch expressions, for same-box timing)
 
 
@@ -198,6 +200,28 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
     return outs if isinstance(zscale, (list, tuple)) else outs[0]
 
 
+def radial_contract_pooled(radial: Radial, z, xj, xi, geo: EdgeGeometry):
+    """masked_mean over the receiver's neighbour slots of radial_contract(radial, z, xj, xi, geo) -- the pooled output of
+    equiformer_layer.py:383,432-436 -- WITHOUT the per-edge outputs.  The mean is linear, so with w_e its weights
+        p[i, lo] = sum_e w_e sum_li R_e[lo, li] x_e[li]                       x_e = xj[j_e] + xi[i],  R_e = reshape(W3 z_e + b3)
+                 = sum_(li,k) W3[lo, li, k] Y[i, li, k] + sum_li b3[lo, li] xbar[i, li],
+        Y[i] = sum_e x_e^T (x) (w_e z_e)   (a [li x 16] . [16 x mid] product per node, ops.row_outer),   xbar[i] = sum_e w_e x_e:
+    ONE node-level [N x li*mid] . [li*mid x lo] product where the per-edge form needs two ([N x li] . [li x mid*lo] for the
+    senders' and the receivers' node matrices), and two instead of four in the backward pass; W3 is used in the parameter's
+    own layout (no re-laid copy of the weight or of its gradient)."""
+    n, k = geo.N, geo.K
+    xe = (ops.gather_rows(xj, geo.nbr_flat, geo.csr_t).view(n, k, -1) + xi[:, None, :])          # [N, K, li]
+    zw = (z.view(n, k, -1) * geo.mean_w.view(n, k, 1)).reshape(n * k, -1)                        # [E, mid]
+    y = ops.row_outer(xe.reshape(n * k, -1), zw, geo.recv_rowptr)                                 # [N, li, mid]
+    xbar = geo.masked_mean(xe.reshape(n * k, -1))                                                 # [N, li]
+    return ops.pooled_radial(y, xbar, radial.rp[6].weight, radial.rp[6].bias, radial.nc_out)
+
+
+def pooled_supported(radial: Radial, z) -> bool:
+    return (POOLED and z.is_cuda and z.dtype == torch.float32 and radial.mid == 64 and radial.nc_in == 256
+            and radial.nc_out % 4 == 0)
+
+
 class DTPIn(nn.Module):
     """tp_in = DTP((C,), (C, C)), pooled (equiformer_layer.py:260-448, built at :1081-1086)."""
 
@@ -212,9 +236,12 @@ class DTPIn(nn.Module):
     def forward(self, x0, geo: EdgeGeometry):
         xi, xj, si = _fan(x0, self.to_xi.w(0), self.to_xj.w(0), self.self_interact.w(0))
         r00, r01 = self.kernel_unary["(0,0)"], self.kernel_unary["(0,1)"]
-        o0 = radial_contract(r00, r00.trunk(geo.dist), xj, xi, geo)                 # [E, C]
+        z00 = r00.trunk(geo.dist)
+        if pooled_supported(r00, z00):
+            p0 = radial_contract_pooled(r00, z00, xj, xi, geo)                      # [N, C]
+        else:
+            p0 = geo.masked_mean(radial_contract(r00, z00, xj, xi, geo))            # [E, C] -> [N, C]
         o1 = radial_contract(r01, r01.trunk(geo.dist), xj, xi, geo)                 # [E, C]
-        p0 = geo.masked_mean(o0)                                                    # [N, C]
         p1 = geo.masked_mean_times_rhat(o1)                                         # [N, C, 3]
         out0 = _fan(p0, self.to_out.w(0))[0] + si
         out1 = torch.einsum("ndm,de->nem", p1, self.to_out.w(1))

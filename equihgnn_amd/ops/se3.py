@@ -11,7 +11,8 @@ import torch
 
 from .. import hip
 from ._base import (
-    ACC_PARAMS, LINEAR_PARAMS, _acc_target, _f32c, _hand_out, _ptr, _require_gpu, _stream, _workspace, timed)
+    ACC_PARAMS, LINEAR_PARAMS, _DEFER, _acc_target, _f32c, _hand_out, _ptr, _require_gpu, _stream, _workspace, timed)
+from .products import gemm, gemm_out_ok, gemm_supported, mm_nn, mm_nt
 
 
 class _RowGemm(torch.autograd.Function):
@@ -95,6 +96,111 @@ class _RowGemm2(torch.autograd.Function):
               lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
                                                   _ptr(dwb), st), "hg_rowgemm_bwd"))
         return dz, dwa, None, None, dwb, None, None
+
+
+class _RowOuter(torch.autograd.Function):
+    """out[r] = sum_{e in row r} a[e]^T (x) b[e]  ([R, Ka, Lb]; the dw half of hg_rowgemm_bwd), with
+    da[e] = out_grad[row(e)] . b[e] (its dz half) and db[e] = a[e] . out_grad[row(e)] (hg_rowgemm_fwd)."""
+
+    @staticmethod
+    def forward(ctx, a, b, rowptr, perm):
+        _require_gpu(a, "row_outer")
+        a, b = _f32c(a), _f32c(b)
+        E, Ka = a.shape
+        Lb = b.shape[1]
+        R = rowptr.numel() - 1
+        if b.shape[0] != E:
+            raise ValueError("row_outer: a[E,Ka], b[E,Lb], rowptr[R+1] expected")
+        out = torch.empty((R, Ka, Lb), dtype=torch.float32, device=a.device)
+        timed("k_rowgemm_bwd", 2 * E * Ka * Lb,
+              lambda: hip.check(hip.lib().hg_rowgemm_bwd(_ptr(a), None, _ptr(b), _ptr(rowptr), _ptr(perm), R, Ka, Lb, None, 0,
+                                                         _ptr(out), _stream(a.device)), "hg_rowgemm_bwd"))
+        ctx.save_for_backward(a, b)
+        ctx.idx = (rowptr, perm, R)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        rowptr, perm, R = ctx.idx
+        dout = _f32c(dout)
+        E, Ka = a.shape
+        Lb = b.shape[1]
+        L_, st = hip.lib(), _stream(a.device)
+        da = db = None
+        if ctx.needs_input_grad[0]:     # entries outside every row get no gradient
+            da = torch.zeros_like(a) if perm is not None else torch.empty_like(a)
+            hip.check(L_.hg_rowgemm_bwd(_ptr(a), _ptr(dout), _ptr(b), _ptr(rowptr), _ptr(perm), R, Ka, Lb, _ptr(da), 0, None, st),
+                      "hg_rowgemm_bwd")
+        if ctx.needs_input_grad[1]:
+            db = torch.zeros_like(b) if perm is not None else torch.empty_like(b)
+            hip.check(L_.hg_rowgemm_fwd(_ptr(a), _ptr(dout), _ptr(rowptr), _ptr(perm), R, Ka, Lb, _ptr(db), 0, st), "hg_rowgemm_fwd")
+        return da, db, None, None
+
+
+def row_outer(a, b, rowptr, perm=None):
+    """out[r] = sum over the entries e of row r of a[e]^T (x) b[e]  -> [R, Ka, Lb].  With ``perm`` None the rows must cover
+    every entry (rowptr[0] = 0, rowptr[R] = E: the receiver lists of the neighbour graph)."""
+    return _RowOuter.apply(a, b, rowptr, perm)
+
+
+class _PooledRadial(torch.autograd.Function):
+    """p[n, lo] = sum_(li,k) y[n, li, k] W3[lo, li, k] + sum_li xbar[n, li] b3[lo, li] for the radial network's last Linear
+    (weight [(lo, li), mid], bias [(lo, li)]: equiformer_layer.py:451-479) in the PARAMETER's own layout -- the weight viewed
+    [lo, li * mid] is the [out, in] matrix of a plain Linear over y, so neither a re-laid copy of the 16 MB weight nor a
+    transposition of its gradient exists, and the gradient is accumulated straight into the parameter's accumulator."""
+
+    @staticmethod
+    def forward(ctx, y, xbar, weight, bias, lo):
+        n = y.shape[0]
+        wv, b3 = weight.view(lo, -1), bias.view(lo, -1)
+        y2 = y.reshape(n, -1)
+        out = mm_nt(y2, wv)
+        out = mm_nt(xbar, b3, d=out)
+        ctx.save_for_backward(y2, xbar, weight, bias)
+        ctx.lo, ctx.yshape = lo, y.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        y2, xbar, weight, bias = ctx.saved_tensors
+        lo = ctx.lo
+        dp = _f32c(dp)
+        wv, b3 = weight.view(lo, -1), bias.view(lo, -1)
+        dy = mm_nn(dp, wv).view(ctx.yshape) if ctx.needs_input_grad[0] else None
+        dxbar = mm_nn(dp, b3) if ctx.needs_input_grad[1] else None
+        dw = db = None
+        if ctx.needs_input_grad[2]:
+            tgt = _acc_target(weight)
+            if tgt is not None:
+                tv = tgt.view(lo, -1)
+                if gemm_supported(dp, y2, True, False) and gemm_out_ok(tv):
+                    if _DEFER["active"]:
+                        _DEFER["keep"].extend((dp, y2))
+                    gemm(dp, y2, trans_a=True, trans_b=False, d=tv, out=tv)
+                else:
+                    tv.addmm_(dp.t(), y2)
+            elif gemm_supported(dp, y2, True, False):
+                dw = gemm(dp, y2, trans_a=True, trans_b=False).view_as(weight)
+            else:
+                dw = (dp.t() @ y2).view_as(weight)
+        if ctx.needs_input_grad[3]:
+            tgt = _acc_target(bias)
+            if tgt is not None:
+                tgt.view(lo, -1).addmm_(dp.t(), xbar)
+            else:
+                db = (dp.t() @ xbar).view_as(bias)
+        return dy, dxbar, dw, db, None
+
+
+def pooled_radial(y, xbar, weight, bias, lo: int):
+    """See _PooledRadial; ``weight`` / ``bias`` are the PARAMETERS of the radial network's last Linear."""
+    if torch.is_grad_enabled():
+        if weight.requires_grad and weight.is_leaf:
+            LINEAR_PARAMS[id(weight)] = weight
+        if bias.requires_grad and bias.is_leaf:
+            ACC_PARAMS[id(bias)] = bias
+    return _PooledRadial.apply(y, xbar, weight, bias, lo)
 
 
 class _RadialWeightLayout(torch.autograd.Function):

@@ -410,7 +410,8 @@ int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32
  * (node), entries (edges) listed by rowptr / perm (perm NULL = identity: entry q belongs to the
  * row whose range contains q).  Kd and L must be multiples of 16.
  * bwd: dz[e, :] (+)= dout[e, :] . w[row(e)]^T (skipped if dz NULL);
- *      dw[r] = sum_{e in row r} z[e]^T (x) dout[e]  (fully overwritten; skipped if dw NULL).
+ *      dw[r] = sum_{e in row r} z[e]^T (x) dout[e]  (fully overwritten; skipped if dw NULL; w may be NULL when dz is:
+ *      this half alone is the POOLED form of the product, sum_e w_e R_e x_e = reshape(W3)[lo, (li, k)] . sum_e x_e (x) w_e z_e).
  * ------------------------------------------------------------------------------------------- */
 int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm,
                    int64_t R, int32_t Kd, int32_t L, float* out, int32_t accumulate, void* stream);

@@ -608,6 +608,59 @@ def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("R,Ka,Lb,seed", [(40, 256, 64, 0), (70, 64, 256, 1), (25, 64, 64, 2), (33, 192, 64, 3), (9, 32, 48, 4)])
+def test_row_outer_and_pooled_radial_match_float64_reference(R, Ka, Lb, seed):
+    """ops.row_outer: out[r] = sum over the row's entries of a[e]^T (x) b[e] (the pooled form of the radial tensor product,
+    equiformer_layer.py:383,432-436) with both input gradients, for permuted rows (an empty and a long one) and for the
+    receivers' contiguous 16-entry rows; ops.pooled_radial on top of it against the per-edge formulation
+    mean_e (reshape(W3 z_e + b3) x_e) in float64."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(seed)
+    E = R * 16
+    key = torch.randint(0, R, (E,), generator=g)
+    key[key == 1] = 0
+    a, b = torch.randn(E, Ka, generator=g), torch.randn(E, Lb, generator=g)
+    dout = torch.randn(R, Ka, Lb, generator=g)
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.zeros(R, Ka, Lb, dtype=torch.float64).index_add(0, key, a64[:, :, None] * b64[:, None, :])
+    (ref * dout.double()).sum().backward()
+    csr = ops.csr_build(key.to(DEV), None, R)
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.row_outer(ad, bd, csr.rowptr, csr.perm)
+    (out * dout.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-5, rtol=1e-5)
+    assert float(out.detach()[1].abs().max()) == 0.0
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), a64.grad.numpy(), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), b64.grad.numpy(), atol=5e-5, rtol=1e-5)
+    rowptr = torch.arange(0, E + 1, 16, dtype=torch.int32, device=DEV)
+    out2 = ops.row_outer(ad.detach(), bd.detach(), rowptr)
+    ref2 = (a.double()[:, :, None] * b.double()[:, None, :]).view(R, 16, Ka, Lb).sum(1)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), atol=5e-5, rtol=1e-5)
+    if Lb != 64 or Ka % 64:
+        return
+    # pooled radial product: li = Ka, mid = Lb, lo = 52 (a width that is not a multiple of 16)
+    lo, li, mid = 52, Ka, Lb
+    W = (torch.randn(lo * li, mid, generator=g) / mid ** 0.5).double().requires_grad_(True)
+    bias = torch.randn(lo * li, generator=g).double().requires_grad_(True)
+    wts = torch.rand(R, 16, generator=g).double()
+    x64, z64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    Rm = (z64 @ W.t() + bias).view(E, lo, li)
+    per_edge = torch.einsum("eol,el->eo", Rm, x64)
+    pref = (per_edge.view(R, 16, lo) * wts[:, :, None]).sum(1)
+    dp = torch.randn(R, lo, generator=g)
+    (pref * dp.double()).sum().backward()
+    Wd, biasd = W.detach().float().to(DEV).requires_grad_(True), bias.detach().float().to(DEV).requires_grad_(True)
+    xd, zd, wd_ = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True), wts.float().to(DEV)
+    y = ops.row_outer(xd, (zd.view(R, 16, mid) * wd_[:, :, None]).reshape(E, mid), rowptr)
+    xbar = (xd.view(R, 16, li) * wd_[:, :, None]).sum(1)
+    p_ = ops.pooled_radial(y, xbar, Wd, biasd, lo)
+    (p_ * dp.to(DEV)).sum().backward()
+    scale = float(pref.abs().max())
+    np.testing.assert_allclose(p_.detach().cpu().numpy(), pref.detach().numpy(), atol=2e-5 * scale, rtol=0)
+    for got, want in ((xd.grad, x64.grad), (zd.grad, z64.grad), (Wd.grad, W.grad), (biasd.grad, bias.grad)):
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), atol=5e-5 * float(want.abs().max()), rtol=0)
+
+
 @pytest.mark.parametrize("C", [64, 256, 320, 1024])
 @pytest.mark.parametrize("reduce", ["mean", "sum"])
 @pytest.mark.parametrize("path", ["generic", "rows_are_a", "rows_are_b"])
