@@ -104,7 +104,67 @@ k_edge_geom(const float* __restrict__ pos, const int* __restrict__ nbr, const fl
     }
 }
 
+// out[n, m, c] = sum_k w3[n, k, m] t[n, k, c]  (m < 3; component-major rows, so that every later per-channel product sees
+// [3 N, C] rows): the masked mean over the K neighbour slots of t[e, c] r_hat[e, m]
+// (the pooled (0 -> 1) pair, equiformer_layer.py:432-436 with utils.py:71-82) without the [E, C, 3] product and without the
+// batched [C x K] . [K x 3] library products, whose backward handed the next kernel a transposed [E, C] gradient (a 52 us
+// strided copy at the BASELINE batch).  One wavefront per node, lane = four channels; the backward is the same loop turned
+// around: dt[n, k, c] = sum_m w3[n, k, m] dout[n, m, c].
+template <bool BWD>
+__global__ void __launch_bounds__(256)
+k_pool3(const float* __restrict__ src, const float* __restrict__ w3, int64_t N, int K, int C, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* __restrict__ wn = w3 + n * K * 3;
+    for (int c = 4 * lane; c < C; c += 256) {
+        if (!BWD) {
+            float4 a0 = f4_zero(), a1 = f4_zero(), a2 = f4_zero();
+            for (int k = 0; k < K; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (n * K + k) * C + c);
+                const float w0 = wn[3 * k], w1 = wn[3 * k + 1], w2 = wn[3 * k + 2];
+                a0.x = fmaf(w0, t.x, a0.x); a0.y = fmaf(w0, t.y, a0.y); a0.z = fmaf(w0, t.z, a0.z); a0.w = fmaf(w0, t.w, a0.w);
+                a1.x = fmaf(w1, t.x, a1.x); a1.y = fmaf(w1, t.y, a1.y); a1.z = fmaf(w1, t.z, a1.z); a1.w = fmaf(w1, t.w, a1.w);
+                a2.x = fmaf(w2, t.x, a2.x); a2.y = fmaf(w2, t.y, a2.y); a2.z = fmaf(w2, t.z, a2.z); a2.w = fmaf(w2, t.w, a2.w);
+            }
+            float* __restrict__ o = dst + n * 3 * C + c;
+            *reinterpret_cast<float4*>(o) = a0;
+            *reinterpret_cast<float4*>(o + C) = a1;
+            *reinterpret_cast<float4*>(o + 2 * C) = a2;
+        } else {
+            const float* __restrict__ d = src + n * 3 * C + c;
+            const float4 d0 = *reinterpret_cast<const float4*>(d), d1 = *reinterpret_cast<const float4*>(d + C),
+                         d2 = *reinterpret_cast<const float4*>(d + 2 * C);
+            for (int k = 0; k < K; ++k) {
+                const float w0 = wn[3 * k], w1 = wn[3 * k + 1], w2 = wn[3 * k + 2];
+                float4 r;
+                r.x = fmaf(w2, d2.x, fmaf(w1, d1.x, w0 * d0.x));
+                r.y = fmaf(w2, d2.y, fmaf(w1, d1.y, w0 * d0.y));
+                r.z = fmaf(w2, d2.z, fmaf(w1, d1.z, w0 * d0.z));
+                r.w = fmaf(w2, d2.w, fmaf(w1, d1.w, w0 * d0.w));
+                *reinterpret_cast<float4*>(dst + (n * K + k) * C + c) = r;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int eqf_pool3(const float* src, const float* w3, int64_t N, int32_t K, int32_t C, int32_t backward, float* dst,
+                         void* stream) {
+    if (N < 0 || K < 1 || C < 4 || (C & 3)) return EQH_ERR_ARG;
+    if (N == 0) return EQH_OK;
+    if (!src || !w3 || !dst) return EQH_ERR_ARG;
+    if (!eqh_aligned16(src) || !eqh_aligned16(dst)) return EQH_ERR_ALIGN;
+    const int64_t blocks = (N + 3) / 4;
+    if (blocks > 0x7fffffff) return EQH_ERR_RANGE;
+    if (backward)
+        hipLaunchKernelGGL(k_pool3<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, w3, N, (int)K, (int)C, dst);
+    else
+        hipLaunchKernelGGL(k_pool3<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, w3, N, (int)K, (int)C, dst);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
 
 extern "C" int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, int64_t N, int32_t K,
                                  float radius, float* rhat, float* maskf, float* mean_w, float* mean_w_rhat,

@@ -317,6 +317,259 @@ k_rowgemm_bwd_w_lds(const float* __restrict__ z, const float* __restrict__ dout,
     }
 }
 
+// ---- streaming variants (round 5): ONE WAVEFRONT per row, no LDS and no barrier.  The row's [Kd, L] matrix is 48-64 KB that is
+// used once per 16 entries, so these kernels are a stream over 115-160 MB with a few MFMAs riding along; the workgroup-per-row
+// kernels above put a load -> barrier -> multiply -> barrier chain around every matrix and reached 2 TB/s.  Here every
+// wavefront keeps a ring of RING 16-byte loads in flight straight into the registers the MFMA reads:
+//   * B operand by float4: lane (r, q) of a 16x16x4 MFMA supplies B[k = q][n = r]; a float4 at columns 64 u + 4 r .. + 3 of
+//     matrix row k(q) is that lane's value for FOUR column tiles (tile (u, j) holds the columns 64 u + 4 r + j), so one
+//     instruction reads 4 matrix rows x 256 contiguous bytes and feeds 4 MFMAs; the output tiles come back as float4 over j.
+//   * the k index of MFMA step (t, i) is 16 t + 4 q + i, so that the A operand z[e][16 t + 4 q ..] is a float4 as well.
+// L is a multiple of 64 (LU = L / 64), Kd = 16 KT.
+template <int KT, int LU>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
+                     const int* __restrict__ perm, int R, float* __restrict__ out, int accumulate) {
+    // a ROUND is 16 loads = 16 KB of the matrix per wavefront: TB steps of 16 k-values (one for L = 256, four for L = 64);
+    // the loop over rounds is not unrolled, so the loads of round n + 1 are what is in flight while round n multiplies
+    constexpr int Kd = KT * 16, L = LU * 64, TB = LU == 4 ? 1 : 4, PER = TB * 4 * LU, NR = KT / TB;
+    static_assert(KT % TB == 0 && PER == 16, "rounds of 16 loads");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * WAVES + wave;
+    if (row >= R) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float* wr = w + (int64_t)row * Kd * L + (int64_t)(4 * q) * L + 4 * r_;
+    // load n of round rd -> (tt, i, u): matrix row 16 (rd TB + tt) + 4 q + i, columns 64 u + 4 r ..
+    auto wload = [&](int rd, int n) {      // (one base address per round; the 16 loads differ by constants)
+        const int tt = n / (4 * LU), i = (n / LU) & 3, u = n % LU;
+        const float* __restrict__ wb = wr + (int64_t)rd * (16 * TB * L);
+        return *reinterpret_cast<const float4*>(wb + (16 * tt + i) * L + 64 * u);
+    };
+#ifdef ROW_ROTATE
+    const int rot = row % NR;
+#else
+    constexpr int rot = 0;
+#endif
+    auto rnd = [&](int rd) { const int x = rd + rot; return x >= NR ? x - NR : x; };
+    for (int g0 = beg; g0 < end; g0 += 16) {
+        // (the matrix is the same for every group of the row: without this the first round's loads are hoisted out of the
+        // loop and kept -- spilled -- across it)
+        asm volatile("" : "+v"(wr));
+        const int e_r = entry_at(perm, g0 + r_, end);
+        int e_g[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+        const float* __restrict__ zr = z + (int64_t)(e_r >= 0 ? e_r : 0) * Kd + 4 * q;
+        float4 ring[PER], zc[TB];
+#pragma unroll
+        for (int n = 0; n < PER; ++n) ring[n] = wload(rnd(0), n);
+#pragma unroll
+        for (int tt = 0; tt < TB; ++tt) zc[tt] = e_r >= 0 ? *reinterpret_cast<const float4*>(zr + 16 * (rnd(0) * TB + tt)) : f4_zero();
+        f32x4 acc[4 * LU];
+#pragma unroll
+        for (int c = 0; c < 4 * LU; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int rd = 0; rd < NR; ++rd) {
+            const bool more = rd + 1 < NR;
+            float4 zn[TB];
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt)
+                zn[tt] = (more && e_r >= 0) ? *reinterpret_cast<const float4*>(zr + 16 * (rnd(rd + 1) * TB + tt)) : f4_zero();
+            // (the scheduling barriers keep the refill of a half behind its last use: hoisted, the 16 loads of the next round
+            // need 64 registers of their own and the kernel spills)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int n = 8 * h; n < 8 * h + 8; ++n) {
+                    const int tt = n / (4 * LU), i = (n / LU) & 3, u = n % LU;
+                    const float4 b = ring[n];
+                    const float a = i == 0 ? zc[tt].x : i == 1 ? zc[tt].y : i == 2 ? zc[tt].z : zc[tt].w;
+                    acc[4 * u + 0] = mfma16(a, b.x, acc[4 * u + 0]);
+                    acc[4 * u + 1] = mfma16(a, b.y, acc[4 * u + 1]);
+                    acc[4 * u + 2] = mfma16(a, b.z, acc[4 * u + 2]);
+                    acc[4 * u + 3] = mfma16(a, b.w, acc[4 * u + 3]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int n = 8 * h; n < 8 * h + 8; ++n) ring[n] = wload(rnd(rd + 1), n);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < TB; ++tt) zc[tt] = zn[tt];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (e_g[g] < 0) continue;
+            float* __restrict__ o = out + (int64_t)e_g[g] * L + 4 * r_;
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                float4 v = make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+                if (accumulate) {
+                    const float4 p = *reinterpret_cast<const float4*>(o + 64 * u);
+                    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                *reinterpret_cast<float4*>(o + 64 * u) = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (one entry's read-add-write at a time: 16 registers, not 64)
+        }
+    }
+}
+
+// dz[e, k] (+)= sum_l dout[e, l] w[row][k][l]: the contraction runs along the matrix rows, so lane (r, q) reads a float4 of
+// matrix row 16 kt + r at columns 16 t + 4 q .. (64-byte pieces of 16 rows per instruction; consecutive t complete the
+// 128-byte lines while they are still in L1).  A round is TB tile rows (16 loads), stored as soon as it is summed.
+template <int KT, int LU>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__ w, const int* __restrict__ rowptr,
+                       const int* __restrict__ perm, int R, float* __restrict__ dz, int accumulate) {
+    constexpr int Kd = KT * 16, L = LU * 64, LT = 4 * LU, TB = LU == 4 ? 1 : 4, PER = TB * LT, NR = KT / TB;
+    static_assert(KT % TB == 0 && PER == 16, "rounds of 16 loads");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * WAVES + wave;
+    if (row >= R) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float* wr = w + (int64_t)row * Kd * L + (int64_t)r_ * L + 4 * q;
+    auto wload = [&](int rd, int n) {       // n -> (kk, t)
+        const int kk = n / LT, t = n % LT;
+        const float* __restrict__ wb = wr + (int64_t)rd * (16 * TB * L);
+        return *reinterpret_cast<const float4*>(wb + 16 * kk * L + 16 * t);
+    };
+    for (int g0 = beg; g0 < end; g0 += 16) {
+        asm volatile("" : "+v"(wr));        // (as in the forward kernel)
+        const int e_r = entry_at(perm, g0 + r_, end);
+        int e_g[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
+        float4 ring[PER];
+#pragma unroll
+        for (int n = 0; n < PER; ++n) ring[n] = wload(0, n);
+        float4 d4[LT];
+#pragma unroll
+        for (int t = 0; t < LT; ++t)
+            d4[t] = e_r >= 0 ? *reinterpret_cast<const float4*>(dout + (int64_t)e_r * L + 16 * t + 4 * q) : f4_zero();
+#pragma unroll 1
+        for (int rd = 0; rd < NR; ++rd) {
+            const bool more = rd + 1 < NR;
+            // (two accumulators per tile row: a chain of dependent MFMAs waits out the 8 passes of its predecessor)
+            f32x4 acc[TB], acc2[TB];
+#pragma unroll
+            for (int kk = 0; kk < TB; ++kk) acc[kk] = acc2[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int n = 8 * h; n < 8 * h + 8; ++n) {
+                    const int kk = n / LT, t = n % LT;
+                    const float4 b = ring[n];
+                    acc[kk] = mfma16(d4[t].x, b.x, acc[kk]);
+                    acc2[kk] = mfma16(d4[t].y, b.y, acc2[kk]);
+                    acc[kk] = mfma16(d4[t].z, b.z, acc[kk]);
+                    acc2[kk] = mfma16(d4[t].w, b.w, acc2[kk]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+#pragma unroll
+                    for (int n = 8 * h; n < 8 * h + 8; ++n) ring[n] = wload(rd + 1, n);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (e_g[g] < 0) continue;
+                float* __restrict__ o = dz + (int64_t)e_g[g] * Kd + 16 * (rd * TB) + r_;
+#pragma unroll
+                for (int kk = 0; kk < TB; ++kk) {
+                    const float v = acc[kk][g] + acc2[kk][g];
+                    o[16 * kk] = accumulate ? (o[16 * kk] + v) : v;
+                }
+            }
+        }
+    }
+}
+
+// dw[row][k][l] = sum_{e in row} z[e, k] dout[e, l]: the entries are the MFMA's K axis (16 per pass of 4 MFMAs per output tile);
+// the rows of dout are held in registers across the KT tile rows when the row has one group of 16 entries (every receiver row;
+// most sender rows) and re-read from L2 per tile row otherwise.  Rows without entries are written as zeros.
+template <int KT, int LU>
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
+                       const int* __restrict__ perm, int R, float* __restrict__ dw) {
+    constexpr int Kd = KT * 16, L = LU * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r_ = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * WAVES + wave;
+    if (row >= R) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const bool one = end - beg <= 16;
+    float* __restrict__ dwr = dw + (int64_t)row * Kd * L + 4 * r_;
+    float4 b4[4][LU];
+    int ent[4];
+    auto load_group = [&](int g0) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            ent[s] = entry_at(perm, g0 + 4 * s + q, end);
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+                b4[s][u] = ent[s] >= 0 ? *reinterpret_cast<const float4*>(dout + (int64_t)ent[s] * L + 64 * u + 4 * r_) : f4_zero();
+        }
+    };
+    if (one) load_group(beg);
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        f32x4 acc[4 * LU];
+#pragma unroll
+        for (int c = 0; c < 4 * LU; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            if (!one) load_group(g0);
+            float a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = ent[s] >= 0 ? z[(int64_t)ent[s] * Kd + 16 * kt + r_] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    acc[4 * u + 0] = mfma16(a[s], b4[s][u].x, acc[4 * u + 0]);
+                    acc[4 * u + 1] = mfma16(a[s], b4[s][u].y, acc[4 * u + 1]);
+                    acc[4 * u + 2] = mfma16(a[s], b4[s][u].z, acc[4 * u + 2]);
+                    acc[4 * u + 3] = mfma16(a[s], b4[s][u].w, acc[4 * u + 3]);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+                *reinterpret_cast<float4*>(dwr + (int64_t)(16 * kt + 4 * q + g) * L + 64 * u) =
+                    make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+    }
+}
+
+// shapes of the streaming kernels: (Kd, L) = (64, 256) radial pairs into a 256-wide fiber, (64, 64) and (192, 64) the
+// attention's pairs (52 -> 64 columns), (256, 64) the pooled form.  EQH_ROWGEMM_LDS=1 selects the workgroup-per-row kernels.
+inline bool stream_on() {
+    static const bool on = [] { const char* e = getenv("EQH_ROWGEMM_LDS"); return !(e && e[0] == '1'); }();
+    return on;
+}
+inline int stream_shape(int Kd, int L) {
+    if (!stream_on()) return 0;
+    if (Kd == 64 && L == 256) return 1;
+    if (Kd == 64 && L == 64) return 2;
+    if (Kd == 192 && L == 64) return 3;
+    if (Kd == 256 && L == 64) return 4;
+    return 0;
+}
+#define ROW_STREAM_LAUNCH(KERNEL, shape, ...)                                                                                  \
+    do {                                                                                                                       \
+        const dim3 grid_((unsigned)((R + WAVES - 1) / WAVES));                                                                 \
+        if (shape == 1) hipLaunchKernelGGL((KERNEL<4, 4>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                      \
+        else if (shape == 2) hipLaunchKernelGGL((KERNEL<4, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                 \
+        else if (shape == 3) hipLaunchKernelGGL((KERNEL<12, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                \
+        else hipLaunchKernelGGL((KERNEL<16, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                                \
+        EQH_CHECK_LAUNCH();                                                                                                    \
+    } while (0)
+
 constexpr size_t ROW_LDS_MAX = 80 * 1024;   // two workgroups per CU
 
 inline size_t row_lds_bytes(int Kd, int L) { return (size_t)Kd * (size_t)(L + 4) * sizeof(float); }
@@ -349,6 +602,11 @@ extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* row
     if (!z || !w || !rowptr || !out) return EQH_ERR_ARG;
     if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int shape = stream_shape(Kd, L)) {
+        if (!eqh_aligned16(out)) return EQH_ERR_ALIGN;
+        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, out, (int)accumulate);
+        return EQH_OK;
+    }
     const size_t lds = row_lds_bytes(Kd, L);
     if ((Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {   // the widths of the radial contraction (mid, 3 * mid; li of the pooled form)
         static bool a4 = false, a12 = false, a16 = false;
@@ -386,6 +644,14 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
     if (!z || !dout || !rowptr || (dz && !w)) return EQH_ERR_ARG;     // (w is read for dz only)
     if (!eqh_aligned16(dout) || (dz && !eqh_aligned16(w)) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (const int shape = stream_shape(Kd, L)) {
+        if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, dz, (int)accumulate_dz);
+        if (dw) {
+            if (!eqh_aligned16(dw)) return EQH_ERR_ALIGN;
+            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, dw);
+        }
+        return EQH_OK;
+    }
     const size_t lds = row_lds_bytes(Kd, L);
     if (dz && (Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {
         static bool a4 = false, a12 = false, a16 = false;

@@ -34,6 +34,20 @@ POOLED = not _os.environ.get("EQH_NO_EQF_POOLED")
 FUSE_SMALL = not _os.environ.get("EQH_NO_EQF_FUSE")   # degree-1 Norm and masked means on the row kernels (off: the torch expressions, for same-box timing)
 
 
+def _component_major(t) -> bool:
+    """A degree-1 feature [N, d, 3] stored component-major ([N, 3, d] in memory, seen through .transpose(1, 2)): what the
+    pooled (0 -> 1) pair produces (ops.pool3), so that every per-channel product downstream reads [3 N, d] rows in place."""
+    return t.dim() == 3 and t.shape[2] == 3 and t.stride() == (3 * t.shape[1], 1, t.shape[1])
+
+
+def _mix_cm(t, *ws):
+    """(einsum("ndm,de->nem", t, w) for w in ws) for a component-major t, component-major results: one fan of [3 N, d]
+    products, no transposed copies."""
+    n, d, _ = t.shape
+    outs = _fan(t.transpose(1, 2).reshape(3 * n, d), *ws)
+    return tuple(o.view(n, 3, -1).transpose(1, 2) for o in outs)
+
+
 class FiberLinear(nn.Module):
     """equiformer_layer.py:168-191 — ``weights.{i}`` of shape [d_in, d_out] per shared degree."""
 
@@ -69,6 +83,11 @@ class FiberNorm(nn.Module):
         return t / rms.clamp(min=self.eps) * self.transforms[0][:, 0]
 
     def norm1(self, t):  # [N, d, 3]
+        if (FUSE_SMALL and t.is_cuda and t.dtype == torch.float32 and _component_major(t) and t.shape[1] * 3 <= 1024
+                and (t.shape[1] * 3) % 4 == 0):
+            n, d, _ = t.shape
+            out = ops.rms_norm_rows(t.transpose(1, 2).reshape(n, 3 * d), self.transforms[1], self.eps, rep=3, tiled=True)
+            return out.view(n, 3, d).transpose(1, 2)
         if (FUSE_SMALL and t.is_cuda and t.dim() == 3 and t.dtype == torch.float32 and t.shape[-2] * 3 <= 1024
                 and (t.shape[-2] * 3) % 4 == 0):
             # the same row kernel over the flattened [d, 3] block: one launch each way instead of 6 / 20 elementwise ones
@@ -156,7 +175,11 @@ class EdgeGeometry:
     def masked_mean_times_rhat(self, t):
         """masked_mean(t[:, :, None] * r_hat[:, None, :]) for t [E, C] -> [N, C, 3] without the [E, C, 3]
         intermediate: one batched [C x K] . [K x 3] product per node."""
-        return torch.bmm(t.view(self.N, self.K, -1).transpose(1, 2), self.mean_w_rhat)
+        t3 = t.view(self.N, self.K, -1)
+        if FUSE_SMALL and t3.is_cuda and t3.dtype == torch.float32 and t3.shape[-1] % 4 == 0:
+            # one pass each way (component-major result behind a transposed view); the gradient comes back as a contiguous [E, C]
+            return ops.pool3(t3, self.mean_w_rhat).transpose(1, 2)
+        return torch.bmm(t3.transpose(1, 2), self.mean_w_rhat)
 
 
 def _fan(x, *ws):
@@ -244,7 +267,10 @@ class DTPIn(nn.Module):
         o1 = radial_contract(r01, r01.trunk(geo.dist), xj, xi, geo)                 # [E, C]
         p1 = geo.masked_mean_times_rhat(o1)                                         # [N, C, 3]
         out0 = _fan(p0, self.to_out.w(0))[0] + si
-        out1 = torch.einsum("ndm,de->nem", p1, self.to_out.w(1))
+        if p1.is_cuda and _component_major(p1):
+            out1 = _mix_cm(p1, self.to_out.w(1))[0]
+        else:
+            out1 = torch.einsum("ndm,de->nem", p1, self.to_out.w(1))
         return out0, out1
 
 
@@ -266,8 +292,11 @@ class DTPAttn(nn.Module):
         """[N, 1+K, 104] (self-interaction as slot 0), or with ``joined=False`` its two parts: the self rows
         [N, 104] and the edge rows [E, 104]."""
         xi0, xj0, me = _fan(f0, self.to_xi.w(0), self.to_xj.w(0), self.self_interact.w(0))
-        xi1 = torch.einsum("ndm,de->nem", f1, self.to_xi.w(1))
-        xj1 = torch.einsum("ndm,de->nem", f1, self.to_xj.w(1))
+        if f1.is_cuda and _component_major(f1):
+            xi1, xj1 = _mix_cm(f1, self.to_xi.w(1), self.to_xj.w(1))
+        else:
+            xi1 = torch.einsum("ndm,de->nem", f1, self.to_xi.w(1))
+            xj1 = torch.einsum("ndm,de->nem", f1, self.to_xj.w(1))
         r00, r10 = self.kernel_unary["(0,0)"], self.kernel_unary["(1,0)"]
         o00 = radial_contract(r00, r00.trunk(geo.dist), xj0, xi0, geo)
         o10 = radial_contract(r10, r10.trunk(geo.dist), xj1, xi1, geo, zscale=geo.rhat)

@@ -124,6 +124,7 @@ SIGNATURES = {
     "geo_knn_grid_workspace_bytes": (c_size_t, [c_int64]),
     "geo_knn_grid": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                c_void_p]),
+    "eqf_pool3": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "eqf_edge_geometry": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_float] + [c_void_p] * 6),
     "eqf_rms_norm_fwd": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_float, c_void_p, c_void_p]),
     "eqf_rms_norm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),

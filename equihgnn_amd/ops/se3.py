@@ -302,19 +302,19 @@ class _RmsNormRows(torch.autograd.Function):
     over the whole row with scale = d^-1/2 and channel c's gain multiplies its rep components."""
 
     @staticmethod
-    def forward(ctx, x, g, eps, acc_param, rep=1):
+    def forward(ctx, x, g, eps, acc_param, rep=1, tiled=False):
         _require_gpu(x, "rms_norm_rows")
         x = _f32c(x)
         gv = _f32c(g.detach()).reshape(-1)
-        if rep > 1:
-            gv = gv[:, None].expand(-1, rep).reshape(-1)
+        if rep > 1:     # (tiled: the row is [rep, d] -- component-major -- instead of [d, rep])
+            gv = gv.repeat(rep) if tiled else gv[:, None].expand(-1, rep).reshape(-1)
         R, C = x.shape
         out = torch.empty_like(x)
         scale = float(torch.tensor((C // rep) ** -0.5, dtype=torch.float32))
         hip.check(hip.lib().eqf_rms_norm_fwd(_ptr(x), _ptr(gv), R, C, scale, float(eps), _ptr(out), _stream(x.device)),
                   "eqf_rms_norm_fwd")
         ctx.save_for_backward(x, gv)
-        ctx.eps, ctx.scale, ctx.acc, ctx.gshape, ctx.rep = float(eps), scale, acc_param, g.shape, rep
+        ctx.eps, ctx.scale, ctx.acc, ctx.gshape, ctx.rep, ctx.tiled = float(eps), scale, acc_param, g.shape, rep, bool(tiled)
         return out
 
     @staticmethod
@@ -331,23 +331,24 @@ class _RmsNormRows(torch.autograd.Function):
             dgf = torch.empty(C, dtype=torch.float32, device=x.device)
             hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dgf), 0, _ptr(ws),
                                          ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
-            dg = dgf.view(-1, ctx.rep).sum(1).view(ctx.gshape)
+            dg = (dgf.view(ctx.rep, -1).sum(0) if ctx.tiled else dgf.view(-1, ctx.rep).sum(1)).view(ctx.gshape)
             if tg is not None:
                 tg.add_(dg)
                 dg = None
-            return dx, dg, None, None, None
+            return dx, dg, None, None, None, None
         dg = tg if tg is not None else torch.empty(ctx.gshape, dtype=torch.float32, device=x.device)
         hip.check(L.eqf_rms_norm_bwd(_ptr(x), _ptr(gv), _ptr(dy), R, C, ctx.scale, ctx.eps, _ptr(dx), _ptr(dg),
                                      1 if tg is not None else 0, _ptr(ws), ws_bytes, _stream(x.device)), "eqf_rms_norm_bwd")
-        return dx, (None if tg is not None else dg), None, None, None
+        return dx, (None if tg is not None else dg), None, None, None, None
 
 
-def rms_norm_rows(x, g, eps: float, rep: int = 1):
+def rms_norm_rows(x, g, eps: float, rep: int = 1, tiled: bool = False):
     """The Norm of the Equiformer (equiformer_layer.py:194-225) for 2-D fp32 rows; ``g`` is the ``transforms.l`` parameter
-    [d, 1].  rep = 1: degree 0, rows [*, d].  rep = 2l + 1: degree l, rows [*, d * rep] (the [d, rep] block flattened)."""
+    [d, 1].  rep = 1: degree 0, rows [*, d].  rep = 2l + 1: degree l, rows [*, d * rep] (the [d, rep] block flattened; ``tiled``: the
+    [rep, d] block -- component-major features)."""
     if torch.is_grad_enabled() and g.requires_grad and g.is_leaf:
         (LINEAR_PARAMS if g.dim() == 2 else ACC_PARAMS)[id(g)] = g
-    return _RmsNormRows.apply(x, g, eps, g, rep)
+    return _RmsNormRows.apply(x, g, eps, g, rep, tiled)
 
 
 class _RadialTrunk(torch.autograd.Function):
@@ -416,6 +417,37 @@ def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
     """rowgemm(z, wa, rowptr_a, perm_a) + rowgemm(z, wb, rowptr_b, perm_b) when BOTH groupings cover every entry
     of z (no entry outside all rows): one output buffer, the second pass accumulates."""
     return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
+
+
+class _Pool3(torch.autograd.Function):
+    """out[n, m, c] = sum_k w3[n, k, m] t[n, k, c] (eqf_pool3, component-major); w3 carries no gradient (geometry)."""
+
+    @staticmethod
+    def forward(ctx, t, w3):
+        _require_gpu(t, "pool3")
+        t, w3 = _f32c(t), _f32c(w3)
+        N, K, C = t.shape
+        if w3.shape != (N, K, 3) or C % 4:
+            raise ValueError("pool3: t[N,K,C] (C a multiple of 4), w3[N,K,3] expected")
+        out = torch.empty((N, 3, C), dtype=torch.float32, device=t.device)
+        hip.check(hip.lib().eqf_pool3(_ptr(t), _ptr(w3), N, K, C, 0, _ptr(out), _stream(t.device)), "eqf_pool3")
+        ctx.save_for_backward(w3)
+        ctx.dims = (N, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (w3,) = ctx.saved_tensors
+        N, K, C = ctx.dims
+        dout = _f32c(dout)
+        dt = torch.empty((N, K, C), dtype=torch.float32, device=dout.device)
+        hip.check(hip.lib().eqf_pool3(_ptr(dout), _ptr(w3), N, K, C, 1, _ptr(dt), _stream(dout.device)), "eqf_pool3")
+        return dt, None
+
+
+def pool3(t, w3):
+    """masked mean over the K neighbour slots of t[n, k, c] r_hat[n, k, m] -> [N, 3, C], component-major (w3 = mean_w * r_hat)."""
+    return _Pool3.apply(t, w3)
 
 
 def edge_geometry(pos, nbr, dist, radius: float, full_d: bool = False):

@@ -637,6 +637,14 @@ int eqf_edge_geometry(const float* pos, const int32_t* nbr, const float* dist, i
                       float* rhat, float* maskf, float* mean_w, float* mean_w_rhat, float* dmat, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Pooled (0 -> 1) pair: dst[n, m, c] = sum_k w3[n, k, m] src[n, k, c] for m < 3 (component-major) -- masked_mean over the K neighbour slots
+ * (equiformer/utils.py:71-82) of out[e, c] D[e, m] (equiformer_layer.py:432-436), w3 = mean_w_rhat of eqf_edge_geometry.
+ * backward != 0: the same map turned around, dst[n, k, c] = sum_m w3[n, k, m] src[n, m, c] (src = the output's gradient).
+ * C a multiple of 4; src, dst 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+int eqf_pool3(const float* src, const float* w3, int64_t N, int32_t K, int32_t C, int32_t backward, float* dst, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Degree-0 branch of the Equiformer's `Norm` (equiformer_layer.py:194-225): out = t / max(rms, eps) * g with
  * rms = ||t||_2 * scale (scale = C^-1/2 as fp32), g = transforms.0 [C].  bwd: dx and dg (overwritten, or added to
  * with accumulate != 0); the clamp passes the gradient where rms >= eps.  C <= 1024, multiple of 4.

@@ -608,6 +608,38 @@ def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("N,K,C", [(37, 16, 256), (5, 7, 48), (130, 16, 64)])
+def test_pool3_and_component_major_norm_match_float64_reference(N, K, C):
+    """ops.pool3 (the pooled (0 -> 1) pair: masked mean of out[e, c] r_hat[e, m], equiformer_layer.py:432-436) forward and
+    backward against the einsum in float64; the degree-1 Norm (equiformer_layer.py:194-225) on the component-major rows it
+    produces against the [d, 3] formulation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N)
+    t, w3, dout = torch.randn(N, K, C, generator=g), torch.randn(N, K, 3, generator=g), torch.randn(N, 3, C, generator=g)
+    t64 = t.double().requires_grad_(True)
+    ref = torch.einsum("nkc,nkm->nmc", t64, w3.double())
+    (ref * dout.double()).sum().backward()
+    td = t.to(DEV).requires_grad_(True)
+    out = ops.pool3(td, w3.to(DEV))
+    (out * dout.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(td.grad.cpu().numpy(), t64.grad.numpy(), atol=2e-5, rtol=1e-5)
+    # Norm over [N, d, 3] blocks given component-major
+    gain = torch.rand(C, 1, generator=g) + 0.5
+    x64, g64 = ref.detach().transpose(1, 2).clone().requires_grad_(True), gain.double().requires_grad_(True)      # [N, C, 3]
+    rms = x64.flatten(-2).norm(dim=-1, keepdim=True)[..., None] * (C ** -0.5)
+    yref = x64 / rms.clamp(min=1e-12) * g64
+    dy = torch.randn(N, C, 3, generator=g)
+    (yref * dy.double()).sum().backward()
+    xd = out.detach().clone().requires_grad_(True)                                  # [N, 3, C]
+    gd = gain.to(DEV).requires_grad_(True)
+    y = ops.rms_norm_rows(xd.reshape(N, 3 * C), gd, 1e-12, rep=3, tiled=True).view(N, 3, C)
+    (y * dy.transpose(1, 2).to(DEV)).sum().backward()
+    np.testing.assert_allclose(y.detach().transpose(1, 2).cpu().numpy(), yref.detach().numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(xd.grad.transpose(1, 2).cpu().numpy(), x64.grad.numpy(), atol=5e-5, rtol=1e-4)
+    np.testing.assert_allclose(gd.grad.cpu().numpy(), g64.grad.numpy(), atol=5e-5 * float(g64.grad.abs().max()), rtol=1e-4)
+
+
 @pytest.mark.parametrize("R,Ka,Lb,seed", [(40, 256, 64, 0), (70, 64, 256, 1), (25, 64, 64, 2), (33, 192, 64, 3), (9, 32, 48, 4)])
 def test_row_outer_and_pooled_radial_match_float64_reference(R, Ka, Lb, seed):
     """ops.row_outer: out[r] = sum over the row's entries of a[e]^T (x) b[e] (the pooled form of the radial tensor product,

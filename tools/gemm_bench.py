@@ -33,7 +33,10 @@ SHAPES = [("c2 conv fwd x W^T", 4736, 256, 256, 0, 1), ("c2 conv dgrad dY W", 47
           ("c5 mid wgrad", 1024, 512, 15488, 1, 0),
           ("c3 attn dgrad K=4096", 2432, 256, 4096, 0, 0), ("c3 attn wgrad N=4096", 256, 4096, 2432, 1, 0),
           ("c3 attn dgrad 3N rows", 7296, 256, 4096, 0, 0), ("c3 attn wgrad 3N rows", 256, 4096, 7296, 1, 0),
-          ("c3 attn fwd", 2432, 4096, 256, 0, 0), ("c3 attn fwd 3N", 7296, 4096, 256, 0, 0)]
+          ("c3 attn fwd", 2432, 4096, 256, 0, 0), ("c3 attn fwd 3N", 7296, 4096, 256, 0, 0),
+          ("c3 pooled fwd Y W^T", 2432, 256, 16384, 0, 1), ("c3 pooled dgrad dp W", 2432, 16384, 256, 0, 0),
+          ("c3 P/Q stacked 2N rows", 4864, 16384, 256, 0, 0), ("c3 dgrad stacked 2N", 4864, 256, 16384, 0, 1),
+          ("c3 wgrad stacked 2N", 256, 16384, 4864, 1, 0)]
 
 
 def timeit(fn, reps):
