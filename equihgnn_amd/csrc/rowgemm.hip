@@ -329,7 +329,8 @@ k_rowgemm_bwd_w_lds(const float* __restrict__ z, const float* __restrict__ dout,
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
-                     const int* __restrict__ perm, int R, float* __restrict__ out, int accumulate) {
+                     const int* __restrict__ perm, int R, float* __restrict__ out, int accumulate,
+                     const float* __restrict__ rowbias, const float* __restrict__ coef, int MB) {
     // a ROUND is 16 loads = 16 KB of the matrix per wavefront: TB steps of 16 k-values (one for L = 256, four for L = 64);
     // the loop over rounds is not unrolled, so the loads of round n + 1 are what is in flight while round n multiplies
     constexpr int Kd = KT * 16, L = LU * 64, TB = LU == 4 ? 1 : 4, PER = TB * 4 * LU, NR = KT / TB;
@@ -410,6 +411,13 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
                 if (accumulate) {
                     const float4 p = *reinterpret_cast<const float4*>(o + 64 * u);
                     v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+                }
+                if (rowbias) {          // + sum_m coef[e, m] rowbias[row, m, :]  (the row's bias block; L1 hits after the first entry)
+                    for (int m = 0; m < MB; ++m) {
+                        const float cf = coef ? coef[(int64_t)e_g[g] * MB + m] : 1.f;
+                        const float4 rb = *reinterpret_cast<const float4*>(rowbias + ((int64_t)row * MB + m) * L + 64 * u + 4 * r_);
+                        v.x = fmaf(cf, rb.x, v.x); v.y = fmaf(cf, rb.y, v.y); v.z = fmaf(cf, rb.z, v.z); v.w = fmaf(cf, rb.w, v.w);
+                    }
                 }
                 *reinterpret_cast<float4*>(o + 64 * u) = v;
             }
@@ -496,7 +504,8 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
-                       const int* __restrict__ perm, int R, float* __restrict__ dw) {
+                       const int* __restrict__ perm, int R, float* __restrict__ dw, const float* __restrict__ coef, int MB,
+                       float* __restrict__ drowbias) {
     constexpr int Kd = KT * 16, L = LU * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
@@ -543,6 +552,35 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
             for (int u = 0; u < LU; ++u)
                 *reinterpret_cast<float4*>(dwr + (int64_t)(16 * kt + 4 * q + g) * L + 64 * u) =
                     make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+    }
+    if (drowbias) {     // d rowbias[row, m, :] = sum_e coef[e, m] dout[e, :]: one more tile row whose "z" is the coefficient block
+        f32x4 acc[4 * LU];
+#pragma unroll
+        for (int c = 0; c < 4 * LU; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g0 = beg; g0 < end; g0 += 16) {
+            if (!one) load_group(g0);
+            float a[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                a[s] = (ent[s] >= 0 && r_ < MB) ? (coef ? coef[(int64_t)ent[s] * MB + r_] : 1.f) : 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int u = 0; u < LU; ++u) {
+                    acc[4 * u + 0] = mfma16(a[s], b4[s][u].x, acc[4 * u + 0]);
+                    acc[4 * u + 1] = mfma16(a[s], b4[s][u].y, acc[4 * u + 1]);
+                    acc[4 * u + 2] = mfma16(a[s], b4[s][u].z, acc[4 * u + 2]);
+                    acc[4 * u + 3] = mfma16(a[s], b4[s][u].w, acc[4 * u + 3]);
+                }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (4 * q + g >= MB) continue;
+#pragma unroll
+            for (int u = 0; u < LU; ++u)
+                *reinterpret_cast<float4*>(drowbias + ((int64_t)row * MB + 4 * q + g) * L + 64 * u + 4 * r_) =
+                    make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+        }
     }
 }
 
@@ -593,20 +631,23 @@ int check(int64_t R, int Kd, int L) {
 
 }  // namespace
 
-extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr,
-                              const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* out,
-                              int32_t accumulate, void* stream_) {
+extern "C" int hg_rowgemm_fwd_bias(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm, int64_t R,
+                                   int32_t Kd, int32_t L, float* out, int32_t accumulate, const float* rowbias,
+                                   const float* coef, int32_t MB, void* stream_) {
     int rc = check(R, Kd, L);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
     if (!z || !w || !rowptr || !out) return EQH_ERR_ARG;
     if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
+    if (rowbias && (MB < 1 || MB > 16 || !eqh_aligned16(rowbias))) return EQH_ERR_ARG;
+    if (!rowbias && coef) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
         if (!eqh_aligned16(out)) return EQH_ERR_ALIGN;
-        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, out, (int)accumulate);
+        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, out, (int)accumulate, rowbias, coef, (int)MB);
         return EQH_OK;
     }
+    if (rowbias) return EQH_ERR_ARG;          // (the bias block rides the streaming kernels only: see hg_rowgemm_bias_supported)
     const size_t lds = row_lds_bytes(Kd, L);
     if ((Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {   // the widths of the radial contraction (mid, 3 * mid; li of the pooled form)
         static bool a4 = false, a12 = false, a16 = false;
@@ -635,23 +676,32 @@ extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* row
     return EQH_OK;
 }
 
-extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
-                              const int32_t* rowptr, const int32_t* perm, int64_t R, int32_t Kd,
-                              int32_t L, float* dz, int32_t accumulate_dz, float* dw, void* stream_) {
+extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm, int64_t R,
+                              int32_t Kd, int32_t L, float* out, int32_t accumulate, void* stream_) {
+    return hg_rowgemm_fwd_bias(z, w, rowptr, perm, R, Kd, L, out, accumulate, nullptr, nullptr, 0, stream_);
+}
+
+extern "C" int hg_rowgemm_bias_supported(int32_t Kd, int32_t L) { return stream_shape(Kd, L) != 0; }
+
+extern "C" int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* dout, const int32_t* rowptr,
+                                   const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz, int32_t accumulate_dz,
+                                   float* dw, const float* coef, int32_t MB, float* drowbias, void* stream_) {
     int rc = check(R, Kd, L);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
     if (!z || !dout || !rowptr || (dz && !w)) return EQH_ERR_ARG;     // (w is read for dz only)
     if (!eqh_aligned16(dout) || (dz && !eqh_aligned16(w)) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
+    if (drowbias && (!dw || MB < 1 || MB > 16 || !eqh_aligned16(drowbias))) return EQH_ERR_ARG;   // (it rides the dw launch)
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
         if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, dz, (int)accumulate_dz);
         if (dw) {
             if (!eqh_aligned16(dw)) return EQH_ERR_ALIGN;
-            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, dw);
+            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, dw, coef, (int)MB, drowbias);
         }
         return EQH_OK;
     }
+    if (drowbias) return EQH_ERR_ARG;
     const size_t lds = row_lds_bytes(Kd, L);
     if (dz && (Kd == 64 || Kd == 192 || Kd == 256) && lds <= ROW_LDS_MAX) {
         static bool a4 = false, a12 = false, a16 = false;
@@ -700,4 +750,10 @@ extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout,
         EQH_CHECK_LAUNCH();
     }
     return EQH_OK;
+}
+
+extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int32_t* rowptr,
+                              const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz,
+                              int32_t accumulate_dz, float* dw, void* stream_) {
+    return hg_rowgemm_bwd_bias(z, w, dout, rowptr, perm, R, Kd, L, dz, accumulate_dz, dw, nullptr, 0, nullptr, stream_);
 }

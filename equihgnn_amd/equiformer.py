@@ -31,6 +31,8 @@ import os as _os
 
 # the POOLED (0,0) pair of tp_in through one product per pass instead of two (radial_contract_pooled; off: per-edge outputs, then the mean)
 POOLED = not _os.environ.get("EQH_NO_EQF_POOLED")
+# the b3 term of the radial networks inside the row-product launches (off: gathered and added per edge by ATen kernels)
+BIAS_FOLD = not _os.environ.get("EQH_NO_EQF_BIAS_FOLD")
 FUSE_SMALL = not _os.environ.get("EQH_NO_EQF_FUSE")   # degree-1 Norm and masked means on the row kernels (off: the torch expressions, for same-box timing)
 
 
@@ -197,11 +199,19 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
     formed once and one output per entry is returned (the three components of a (1 -> 1) pair)."""
     w, b3, lo_p = radial.node_weights()
     n, lo, mid = geo.N, radial.nc_out, radial.mid
+    kd = mid if zscale is None else 3 * mid
+    fold = BIAS_FOLD and z.is_cuda and z.dtype == torch.float32 and ops.rowgemm_bias_supported(kd, lo_p)
+    b3t = b3.t()
+    if fold and lo_p != lo:
+        b3t = F.pad(b3t, (0, lo_p - lo))                                            # bias blocks as wide as the node matrices
     if zscale is None:
-        b3t = b3.t()
         p, pb = _fan(xj, w, b3t)                                                    # [N, mid*lo_p], [N, lo]
         q, qb = _fan(xi, w, b3t)
         p, q = p.view(n, mid, lo_p), q.view(n, mid, lo_p)
+        if fold:    # out[e] = z_e . (P[j] + Q[i]) + pb[j] + qb[i] in the two row-product launches
+            out = ops.rowgemm2(z, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None, pb.view(n, 1, lo_p),
+                               qb.view(n, 1, lo_p))
+            return out if lo_p == lo else out[:, :lo]
         bias = ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, lo) + qb[:, None, :]
         # sender rows (transposed neighbour CSR) and receiver rows both list every edge: one buffer, second pass adds
         out = ops.rowgemm2(z, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
@@ -209,17 +219,22 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
     # (one autograd node per input, as for degree 0: the products take the x6 / library dispatch of ops.matmul_fan and
     # their input gradients meet in accumulating GEMMs)
     li = xj.shape[1]
-    b3t = b3.t()
     p, pb = _fan(xj.transpose(1, 2).reshape(-1, li), w, b3t)                        # [3N, mid*lo_p], [3N, lo]
     q, qb = _fan(xi.transpose(1, 2).reshape(-1, li), w, b3t)
     p, q = p.view(n, 3 * mid, lo_p), q.view(n, 3 * mid, lo_p)                       # [(m,k), lo]
-    pb, qb = pb.view(n, 3 * lo), qb.view(n, 3, lo)                                  # [N, (m,lo)], [N, 3, lo]
-    g = (ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]).reshape(-1, 3, lo)
+    if not fold:
+        pb, qb = pb.view(n, 3 * lo), qb.view(n, 3, lo)                              # [N, (m,lo)], [N, 3, lo]
+        g = (ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]).reshape(-1, 3, lo)
     outs = []
     for zs in (zscale if isinstance(zscale, (list, tuple)) else (zscale,)):
         ze = (zs[:, :, None] * z[:, None, :]).reshape(-1, 3 * mid)                  # [E, (m,k)]
-        out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
-        outs.append(out[:, :lo] + (g * zs[:, :, None]).sum(1))
+        if fold:    # + sum_m zs[e, m] (pb[j, m] + qb[i, m]) inside the launches
+            out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None, pb.view(n, 3, lo_p),
+                               qb.view(n, 3, lo_p), zs)
+            outs.append(out if lo_p == lo else out[:, :lo])
+        else:
+            out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None)
+            outs.append(out[:, :lo] + (g * zs[:, :, None]).sum(1))
     return outs if isinstance(zscale, (list, tuple)) else outs[0]
 
 

@@ -70,7 +70,7 @@ from .readout import (  # noqa: F401
 )
 from .se3 import (  # noqa: F401
     _RowGemm, _RowGemm2, _RadialWeightLayout, radial_weight_layout, _AttnPool, attn_pool_supported, attn_pool,
-    _RmsNormRows, rms_norm_rows, _RadialTrunk, radial_trunk_supported, radial_trunk, rowgemm, rowgemm2,
+    _RmsNormRows, rms_norm_rows, _RadialTrunk, radial_trunk_supported, radial_trunk, rowgemm, rowgemm2, rowgemm_bias_supported,
     edge_geometry, _RowOuter, row_outer, _PooledRadial, pooled_radial, _Pool3, pool3,
 )
 from .frames import (  # noqa: F401

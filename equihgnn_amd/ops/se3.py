@@ -50,10 +50,13 @@ class _RowGemm(torch.autograd.Function):
 class _RowGemm2(torch.autograd.Function):
     """out[e] = z[e] @ wa[row_a(e)] + z[e] @ wb[row_b(e)] for two groupings of the same entries that each cover
     EVERY entry (sender rows and receiver rows of the neighbour graph): the second pass accumulates into the
-    first one's output, and so do the two halves of dz, so neither a zero fill nor an add kernel runs."""
+    first one's output, and so do the two halves of dz, so neither a zero fill nor an add kernel runs.
+    With bias blocks (ba [Ra, MB, L], bb [Rb, MB, L], coef [E, MB] or None = 1):
+    out[e] += sum_m coef[e, m] (ba[row_a(e), m] + bb[row_b(e), m]) inside the same launches, their gradients beside the
+    node matrices' (hg_rowgemm_fwd_bias / _bwd_bias); coef carries no gradient."""
 
     @staticmethod
-    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, ba=None, bb=None, coef=None):
         _require_gpu(z, "rowgemm2")
         z, wa, wb = _f32c(z), _f32c(wa), _f32c(wb)
         E, Kd = z.shape
@@ -61,41 +64,52 @@ class _RowGemm2(torch.autograd.Function):
         Rb = wb.shape[0]
         if wa.shape[1:] != wb.shape[1:] or wa.shape[1] != Kd or rowptr_a.numel() != Ra + 1 or rowptr_b.numel() != Rb + 1:
             raise ValueError("rowgemm2: z[E,Kd], wa[Ra,Kd,L], wb[Rb,Kd,L], rowptr_a[Ra+1], rowptr_b[Rb+1] expected")
+        MB = 0
+        if ba is not None:
+            ba, bb = _f32c(ba), _f32c(bb)
+            MB = ba.shape[1]
+            coef = _f32c(coef) if coef is not None else None
+            if ba.shape != (Ra, MB, L) or bb.shape != (Rb, MB, L) or (coef is not None and coef.shape != (E, MB)):
+                raise ValueError("rowgemm2: bias blocks [R, MB, L] and coef [E, MB] expected")
         out = torch.empty((E, L), dtype=torch.float32, device=z.device)
         L_ = hip.lib()
         st = _stream(z.device)
         timed("k_rowgemm_fwd", 2 * E * Kd * L,
-              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0, st),
-                                "hg_rowgemm_fwd"))
+              lambda: hip.check(L_.hg_rowgemm_fwd_bias(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0,
+                                                       _ptr(ba), _ptr(coef), MB, st), "hg_rowgemm_fwd_bias"))
         timed("k_rowgemm_fwd", 2 * E * Kd * L,
-              lambda: hip.check(L_.hg_rowgemm_fwd(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1, st),
-                                "hg_rowgemm_fwd"))
-        ctx.save_for_backward(z, wa, wb)
+              lambda: hip.check(L_.hg_rowgemm_fwd_bias(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1,
+                                                       _ptr(bb), _ptr(coef), MB, st), "hg_rowgemm_fwd_bias"))
+        ctx.save_for_backward(z, wa, wb, coef)
         ctx.idx = (rowptr_a, perm_a, rowptr_b, perm_b)
+        ctx.MB = MB
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        z, wa, wb = ctx.saved_tensors
+        z, wa, wb, coef = ctx.saved_tensors
         rowptr_a, perm_a, rowptr_b, perm_b = ctx.idx
         dout = _f32c(dout)
         Ra, Kd, L = wa.shape
         Rb = wb.shape[0]
+        MB = ctx.MB
         need_z = ctx.needs_input_grad[0]
         dz = torch.empty_like(z) if need_z else None
-        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] else None
-        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] else None
+        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] or MB else None
+        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] or MB else None
+        dba = torch.empty((Ra, MB, L), dtype=torch.float32, device=z.device) if MB else None
+        dbb = torch.empty((Rb, MB, L), dtype=torch.float32, device=z.device) if MB else None
         L_ = hip.lib()
         st = _stream(z.device)
         E = z.shape[0]
         nf = (2 if need_z else 0) * E * Kd * L
         timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwa is not None else 0),
-              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz), 0,
-                                                  _ptr(dwa), st), "hg_rowgemm_bwd"))
+              lambda: hip.check(L_.hg_rowgemm_bwd_bias(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz),
+                                                       0, _ptr(dwa), _ptr(coef), MB, _ptr(dba), st), "hg_rowgemm_bwd_bias"))
         timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwb is not None else 0),
-              lambda: hip.check(L_.hg_rowgemm_bwd(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz), 1,
-                                                  _ptr(dwb), st), "hg_rowgemm_bwd"))
-        return dz, dwa, None, None, dwb, None, None
+              lambda: hip.check(L_.hg_rowgemm_bwd_bias(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz),
+                                                       1, _ptr(dwb), _ptr(coef), MB, _ptr(dbb), st), "hg_rowgemm_bwd_bias"))
+        return dz, dwa, None, None, dwb, None, None, dba, dbb, None
 
 
 class _RowOuter(torch.autograd.Function):
@@ -413,10 +427,17 @@ def rowgemm(z, w, rowptr, perm=None):
     return _RowGemm.apply(z, w, rowptr, perm)
 
 
-def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b):
+def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a=None, bias_b=None, coef=None):
     """rowgemm(z, wa, rowptr_a, perm_a) + rowgemm(z, wb, rowptr_b, perm_b) when BOTH groupings cover every entry
-    of z (no entry outside all rows): one output buffer, the second pass accumulates."""
-    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
+    of z (no entry outside all rows): one output buffer, the second pass accumulates.  ``bias_a`` / ``bias_b`` [R, MB, L]
+    (+ ``coef`` [E, MB]): the rows' bias blocks added in the same launches (rowgemm_bias_supported(Kd, L))."""
+    if bias_a is None:
+        return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
+    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a, bias_b, coef)
+
+
+def rowgemm_bias_supported(Kd: int, L: int) -> bool:
+    return bool(hip.lib().hg_rowgemm_bias_supported(int(Kd), int(L)))
 
 
 class _Pool3(torch.autograd.Function):

@@ -608,6 +608,40 @@ def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("R,Kd,L,MB,seed", [(50, 64, 256, 1, 0), (40, 192, 64, 3, 1), (33, 64, 64, 1, 2), (20, 256, 64, 2, 3)])
+def test_rowgemm2_with_bias_blocks_matches_float64_reference(R, Kd, L, MB, seed):
+    """ops.rowgemm2 with the rows' bias blocks in the launches (hg_rowgemm_fwd_bias / _bwd_bias): out[e] = z[e] . (wa[s(e)] +
+    wb[r(e)]) + sum_m coef[e, m] (ba[s(e), m] + bb[r(e), m]) for permuted sender rows (one empty, one longer than 32 entries)
+    and the receivers' contiguous 16-entry rows, with every gradient."""
+    ops = _ops()
+    assert ops.rowgemm_bias_supported(Kd, L)
+    g = torch.Generator().manual_seed(seed)
+    E = R * 16
+    key = torch.randint(0, R, (E,), generator=g)
+    key[key == 1] = 0
+    key[:40] = 2
+    recv = torch.arange(E) // 16
+    z = torch.randn(E, Kd, generator=g)
+    wa, wb = (torch.randn(R, Kd, L, generator=g) / Kd ** 0.5 for _ in range(2))
+    ba, bb = (torch.randn(R, MB, L, generator=g) for _ in range(2))
+    coef = torch.randn(E, MB, generator=g) if MB > 1 else None
+    dout = torch.randn(E, L, generator=g)
+    leaves = [t.double().requires_grad_(True) for t in (z, wa, wb, ba, bb)]
+    z6, wa6, wb6, ba6, bb6 = leaves
+    c6 = coef.double() if coef is not None else torch.ones(E, 1, dtype=torch.float64)
+    ref = (torch.einsum("ek,ekl->el", z6, wa6[key] + wb6[recv]) + torch.einsum("em,eml->el", c6, ba6[key] + bb6[recv]))
+    (ref * dout.double()).sum().backward()
+    csr = ops.csr_build(key.to(DEV), None, R)
+    rowptr = torch.arange(0, E + 1, 16, dtype=torch.int32, device=DEV)
+    dl = [t.to(DEV).requires_grad_(True) for t in (z, wa, wb, ba, bb)]
+    out = ops.rowgemm2(dl[0], dl[1], csr.rowptr, csr.perm, dl[2], rowptr, None, dl[3], dl[4], coef.to(DEV) if coef is not None else None)
+    (out * dout.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), atol=5e-5, rtol=1e-5)
+    for got, want, name in zip(dl, leaves, ("z", "wa", "wb", "ba", "bb")):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), atol=1e-4, rtol=1e-5, err_msg=name)
+    assert float(dl[1].grad[1].abs().max()) == 0.0 and float(dl[3].grad[1].abs().max()) == 0.0      # the empty sender row
+
+
 @pytest.mark.parametrize("N,K,C", [(37, 16, 256), (5, 7, 48), (130, 16, 64)])
 def test_pool3_and_component_major_norm_match_float64_reference(N, K, C):
     """ops.pool3 (the pooled (0 -> 1) pair: masked mean of out[e, c] r_hat[e, m], equiformer_layer.py:432-436) forward and
