@@ -329,14 +329,18 @@ k_rowgemm_bwd_w_lds(const float* __restrict__ z, const float* __restrict__ dout,
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
-                     const int* __restrict__ perm, int R, float* __restrict__ out, int accumulate,
+                     const int* __restrict__ perm, int R, int Lrt, float* __restrict__ out, int accumulate,
                      const float* __restrict__ rowbias, const float* __restrict__ coef, int MB) {
     // a ROUND is 16 loads = 16 KB of the matrix per wavefront: TB steps of 16 k-values (one for L = 256, four for L = 64);
     // the loop over rounds is not unrolled, so the loads of round n + 1 are what is in flight while round n multiplies
-    constexpr int Kd = KT * 16, L = LU * 64, TB = LU == 4 ? 1 : 4, PER = TB * 4 * LU, NR = KT / TB;
+    // L: the matrix' row pitch = its width; 256 for LU = 4, any multiple of 4 up to 64 for LU = 1 (52 columns of the attention's
+    // pairs: lanes whose four columns lie beyond L load zeros and store nothing)
+    constexpr int Kd = KT * 16, TB = LU == 4 ? 1 : 4, PER = TB * 4 * LU, NR = KT / TB;
     static_assert(KT % TB == 0 && PER == 16, "rounds of 16 loads");
+    const int L = LU == 4 ? 256 : Lrt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
+    const bool act = LU == 4 || 4 * r_ < L;
     const int row = blockIdx.x * WAVES + wave;
     if (row >= R) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
@@ -345,7 +349,7 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
     auto wload = [&](int rd, int n) {      // (one base address per round; the 16 loads differ by constants)
         const int tt = n / (4 * LU), i = (n / LU) & 3, u = n % LU;
         const float* __restrict__ wb = wr + (int64_t)rd * (16 * TB * L);
-        return *reinterpret_cast<const float4*>(wb + (16 * tt + i) * L + 64 * u);
+        return act ? *reinterpret_cast<const float4*>(wb + (16 * tt + i) * L + 64 * u) : f4_zero();
     };
 #ifdef ROW_ROTATE
     const int rot = row % NR;
@@ -403,7 +407,7 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (e_g[g] < 0) continue;
+            if (e_g[g] < 0 || !act) continue;
             float* __restrict__ o = out + (int64_t)e_g[g] * L + 4 * r_;
 #pragma unroll
             for (int u = 0; u < LU; ++u) {
@@ -432,9 +436,10 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__ w, const int* __restrict__ rowptr,
-                       const int* __restrict__ perm, int R, float* __restrict__ dz, int accumulate) {
-    constexpr int Kd = KT * 16, L = LU * 64, LT = 4 * LU, TB = LU == 4 ? 1 : 4, PER = TB * LT, NR = KT / TB;
+                       const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dz, int accumulate) {
+    constexpr int Kd = KT * 16, LT = 4 * LU, TB = LU == 4 ? 1 : 4, PER = TB * LT, NR = KT / TB;
     static_assert(KT % TB == 0 && PER == 16, "rounds of 16 loads");
+    const int L = LU == 4 ? 256 : Lrt;        // (as in the forward kernel; here the columns are the contraction index)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * WAVES + wave;
@@ -444,7 +449,7 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
     auto wload = [&](int rd, int n) {       // n -> (kk, t)
         const int kk = n / LT, t = n % LT;
         const float* __restrict__ wb = wr + (int64_t)rd * (16 * TB * L);
-        return *reinterpret_cast<const float4*>(wb + 16 * kk * L + 16 * t);
+        return (LU == 4 || 16 * t + 4 * q < L) ? *reinterpret_cast<const float4*>(wb + 16 * kk * L + 16 * t) : f4_zero();
     };
     for (int g0 = beg; g0 < end; g0 += 16) {
         asm volatile("" : "+v"(wr));        // (as in the forward kernel)
@@ -458,7 +463,8 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
         float4 d4[LT];
 #pragma unroll
         for (int t = 0; t < LT; ++t)
-            d4[t] = e_r >= 0 ? *reinterpret_cast<const float4*>(dout + (int64_t)e_r * L + 16 * t + 4 * q) : f4_zero();
+            d4[t] = (e_r >= 0 && (LU == 4 || 16 * t + 4 * q < L)) ? *reinterpret_cast<const float4*>(dout + (int64_t)e_r * L + 16 * t + 4 * q)
+                                                                  : f4_zero();
 #pragma unroll 1
         for (int rd = 0; rd < NR; ++rd) {
             const bool more = rd + 1 < NR;
@@ -504,11 +510,13 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
-                       const int* __restrict__ perm, int R, float* __restrict__ dw, const float* __restrict__ coef, int MB,
+                       const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dw, const float* __restrict__ coef, int MB,
                        float* __restrict__ drowbias) {
-    constexpr int Kd = KT * 16, L = LU * 64;
+    constexpr int Kd = KT * 16;
+    const int L = LU == 4 ? 256 : Lrt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
+    const bool act = LU == 4 || 4 * r_ < L;
     const int row = blockIdx.x * WAVES + wave;
     if (row >= R) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
@@ -522,7 +530,7 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
             ent[s] = entry_at(perm, g0 + 4 * s + q, end);
 #pragma unroll
             for (int u = 0; u < LU; ++u)
-                b4[s][u] = ent[s] >= 0 ? *reinterpret_cast<const float4*>(dout + (int64_t)ent[s] * L + 64 * u + 4 * r_) : f4_zero();
+                b4[s][u] = (ent[s] >= 0 && act) ? *reinterpret_cast<const float4*>(dout + (int64_t)ent[s] * L + 64 * u + 4 * r_) : f4_zero();
         }
     };
     if (one) load_group(beg);
@@ -546,12 +554,14 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
                     acc[4 * u + 3] = mfma16(a[s], b4[s][u].w, acc[4 * u + 3]);
                 }
         }
+        if (act) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int u = 0; u < LU; ++u)
-                *reinterpret_cast<float4*>(dwr + (int64_t)(16 * kt + 4 * q + g) * L + 64 * u) =
-                    make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+                for (int u = 0; u < LU; ++u)
+                    *reinterpret_cast<float4*>(dwr + (int64_t)(16 * kt + 4 * q + g) * L + 64 * u) =
+                        make_float4(acc[4 * u][g], acc[4 * u + 1][g], acc[4 * u + 2][g], acc[4 * u + 3][g]);
+        }
     }
     if (drowbias) {     // d rowbias[row, m, :] = sum_e coef[e, m] dout[e, :]: one more tile row whose "z" is the coefficient block
         f32x4 acc[4 * LU];
@@ -575,7 +585,7 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (4 * q + g >= MB) continue;
+            if (4 * q + g >= MB || !act) continue;
 #pragma unroll
             for (int u = 0; u < LU; ++u)
                 *reinterpret_cast<float4*>(drowbias + ((int64_t)row * MB + 4 * q + g) * L + 64 * u + 4 * r_) =
@@ -584,8 +594,9 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
     }
 }
 
-// shapes of the streaming kernels: (Kd, L) = (64, 256) radial pairs into a 256-wide fiber, (64, 64) and (192, 64) the
-// attention's pairs (52 -> 64 columns), (256, 64) the pooled form.  EQH_ROWGEMM_LDS=1 selects the workgroup-per-row kernels.
+// shapes of the streaming kernels: (Kd, L) = (64, 256) radial pairs into a 256-wide fiber; (64, L), (192, L) with L <= 64 a
+// multiple of 4 the attention's pairs (52 columns, unpadded); (256, 64) the pooled form.  EQH_ROWGEMM_LDS=1 selects the
+// workgroup-per-row kernels (which want L a multiple of 16).
 inline bool stream_on() {
     static const bool on = [] { const char* e = getenv("EQH_ROWGEMM_LDS"); return !(e && e[0] == '1'); }();
     return on;
@@ -593,9 +604,10 @@ inline bool stream_on() {
 inline int stream_shape(int Kd, int L) {
     if (!stream_on()) return 0;
     if (Kd == 64 && L == 256) return 1;
-    if (Kd == 64 && L == 64) return 2;
-    if (Kd == 192 && L == 64) return 3;
-    if (Kd == 256 && L == 64) return 4;
+    if (L > 64 || L < 4 || (L & 3)) return 0;
+    if (Kd == 64) return 2;
+    if (Kd == 192) return 3;
+    if (Kd == 256) return 4;
     return 0;
 }
 #define ROW_STREAM_LAUNCH(KERNEL, shape, ...)                                                                                  \
@@ -624,7 +636,7 @@ int row_lds_attr(K kernel, bool* done) {
 
 int check(int64_t R, int Kd, int L) {
     if (R < 0 || Kd <= 0 || L <= 0) return EQH_ERR_ARG;
-    if ((Kd & 15) || (L & 15)) return EQH_ERR_ALIGN;
+    if ((Kd & 15) || ((L & 15) && !stream_shape(Kd, L))) return EQH_ERR_ALIGN;
     if (R >= ((int64_t)1 << 31) - 1) return EQH_ERR_RANGE;
     return EQH_OK;
 }
@@ -644,7 +656,7 @@ extern "C" int hg_rowgemm_fwd_bias(const float* z, const float* w, const int32_t
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
         if (!eqh_aligned16(out)) return EQH_ERR_ALIGN;
-        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, out, (int)accumulate, rowbias, coef, (int)MB);
+        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, (int)L, out, (int)accumulate, rowbias, coef, (int)MB);
         return EQH_OK;
     }
     if (rowbias) return EQH_ERR_ARG;          // (the bias block rides the streaming kernels only: see hg_rowgemm_bias_supported)
@@ -694,10 +706,10 @@ extern "C" int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* 
     if (drowbias && (!dw || MB < 1 || MB > 16 || !eqh_aligned16(drowbias))) return EQH_ERR_ARG;   // (it rides the dw launch)
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
-        if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, dz, (int)accumulate_dz);
+        if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, (int)L, dz, (int)accumulate_dz);
         if (dw) {
             if (!eqh_aligned16(dw)) return EQH_ERR_ALIGN;
-            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, dw, coef, (int)MB, drowbias);
+            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, (int)L, dw, coef, (int)MB, drowbias);
         }
         return EQH_OK;
     }

@@ -33,6 +33,7 @@ import os as _os
 POOLED = not _os.environ.get("EQH_NO_EQF_POOLED")
 # the b3 term of the radial networks inside the row-product launches (off: gathered and added per edge by ATen kernels)
 BIAS_FOLD = not _os.environ.get("EQH_NO_EQF_BIAS_FOLD")
+UNPADDED = not _os.environ.get("EQH_NO_EQF_UNPADDED")      # node matrices [mid, lo] at the attention's lo = 52 instead of 64 columns
 FUSE_SMALL = not _os.environ.get("EQH_NO_EQF_FUSE")   # degree-1 Norm and masked means on the row kernels (off: the torch expressions, for same-box timing)
 
 
@@ -131,11 +132,14 @@ class Radial(nn.Module):
         return h
 
     def node_weights(self):
-        """W3 as [li, mid * lo_p] (columns ordered (k, lo), lo zero-padded to a multiple of 16) and
-        b3 as [lo, li]."""
+        """W3 as [li, mid * lo_p] (columns ordered (k, lo), lo zero-padded to a multiple of 16 where the row-product kernels
+        need it) and b3 as [lo, li]."""
         lo, li, mid = self.nc_out, self.nc_in, self.mid
         lo_p = -(-lo // 16) * 16
-        if self.rp[6].weight.is_cuda and self.rp[6].weight.dtype == torch.float32:
+        gpu = self.rp[6].weight.is_cuda and self.rp[6].weight.dtype == torch.float32
+        if UNPADDED and gpu and lo_p != lo and ops.rowgemm_bias_supported(mid, lo):
+            lo_p = lo      # the streaming row products take any width that is a multiple of 4 (the attention's 52): no padded columns
+        if gpu:
             # one tiled transposition each way (16 MB at hidden 256; torch's strided copy moves it at 0.7 TB/s)
             return ops.radial_weight_layout(self.rp[6].weight, lo, li, mid, lo_p), self.rp[6].bias.view(lo, li), lo_p
         w = self.rp[6].weight.view(lo, li, mid).permute(1, 2, 0)

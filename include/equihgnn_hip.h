@@ -408,7 +408,8 @@ int egnn_edge_bwd(const float* ab, const float* wd, const float* w2, const int32
  * R = Radial(d) [lo, li] per edge, out = R x) re-associated so that the per-edge radial weights
  * are never formed:  out[e, :] (+)= z[e, :Kd] . w[row(e)]  with one [Kd, L] matrix per CSR row
  * (node), entries (edges) listed by rowptr / perm (perm NULL = identity: entry q belongs to the
- * row whose range contains q).  Kd and L must be multiples of 16.
+ * row whose range contains q).  Kd a multiple of 16; L a multiple of 16, or -- for Kd of {64, 192, 256} -- any multiple
+ * of 4 up to 64 (hg_rowgemm_bias_supported(Kd, L) reports those shapes).
  * bwd: dz[e, :] (+)= dout[e, :] . w[row(e)]^T (skipped if dz NULL);
  *      dw[r] = sum_{e in row r} z[e]^T (x) dout[e]  (fully overwritten; skipped if dw NULL; w may be NULL when dz is:
  *      this half alone is the POOLED form of the product, sum_e w_e R_e x_e = reshape(W3)[lo, (li, k)] . sum_e x_e (x) w_e z_e).

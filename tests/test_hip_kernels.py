@@ -578,7 +578,8 @@ def test_fused_ops_accumulate_into_parameter_buffers():
         assert torch.equal(p._eqh_gbuf, ref)
 
 
-@pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3), (30, 192, 256, 4)])
+@pytest.mark.parametrize("R,Kd,L,seed", [(5, 16, 16, 0), (60, 64, 64, 1), (200, 64, 256, 2), (90, 192, 64, 3), (30, 192, 256, 4),
+                                         (70, 64, 52, 5), (50, 192, 52, 6)])
 def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     """hg_rowgemm_fwd/bwd: out[e] = z[e] @ w[row(e)] with rows from a CSR (empty rows, rows longer
     than one 16-entry MFMA tile, identity and permuted entry lists)."""
@@ -608,7 +609,8 @@ def test_rowgemm_matches_float64_reference(R, Kd, L, seed):
     np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("R,Kd,L,MB,seed", [(50, 64, 256, 1, 0), (40, 192, 64, 3, 1), (33, 64, 64, 1, 2), (20, 256, 64, 2, 3)])
+@pytest.mark.parametrize("R,Kd,L,MB,seed", [(50, 64, 256, 1, 0), (40, 192, 64, 3, 1), (33, 64, 64, 1, 2), (20, 256, 64, 2, 3),
+                                            (45, 192, 52, 3, 4), (37, 64, 52, 1, 5), (11, 64, 4, 1, 6)])
 def test_rowgemm2_with_bias_blocks_matches_float64_reference(R, Kd, L, MB, seed):
     """ops.rowgemm2 with the rows' bias blocks in the launches (hg_rowgemm_fwd_bias / _bwd_bias): out[e] = z[e] . (wa[s(e)] +
     wb[r(e)]) + sum_m coef[e, m] (ba[s(e), m] + bb[r(e), m]) for permuted sender rows (one empty, one longer than 32 entries)
