@@ -269,9 +269,12 @@ class _BatchNormRows(torch.autograd.Function):
         m = _f32c(mask).reshape(-1) if mask is not None else None
         y = torch.empty_like(x)
         stats = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().hg_batch_norm_rows_fwd(_ptr(x), _ptr(m), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                                   _ptr(n_tracked), float(momentum), float(eps), R, C, _ptr(y), _ptr(stats[0]),
-                                                   _ptr(stats[1]), _stream(x.device)), "hg_batch_norm_rows_fwd")
+        L = hip.lib()
+        ws_bytes = L.hg_batch_norm_rows_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x.device)
+        hip.check(L.hg_batch_norm_rows_fwd(_ptr(x), _ptr(m), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                           _ptr(n_tracked), float(momentum), float(eps), R, C, _ptr(y), _ptr(stats[0]),
+                                           _ptr(stats[1]), _ptr(ws), ws_bytes, _stream(x.device)), "hg_batch_norm_rows_fwd")
         ctx.save_for_backward(x, m, gamma, stats)
         ctx.acc = acc_params
         return y
@@ -283,8 +286,11 @@ class _BatchNormRows(torch.autograd.Function):
         dy = _f32c(dy)
         dx = torch.empty_like(x)
         small = torch.empty((2, C), dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().hg_batch_norm_rows_bwd(_ptr(x), _ptr(dy), _ptr(m), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), R, C,
-                                                   _ptr(dx), _ptr(small[0]), _ptr(small[1]), _stream(x.device)),
+        L = hip.lib()
+        ws_bytes = L.hg_batch_norm_rows_workspace_bytes(R, C)
+        ws = _workspace(max(ws_bytes, 16), x.device)
+        hip.check(L.hg_batch_norm_rows_bwd(_ptr(x), _ptr(dy), _ptr(m), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), R, C,
+                                           _ptr(dx), _ptr(small[0]), _ptr(small[1]), _ptr(ws), ws_bytes, _stream(x.device)),
                   "hg_batch_norm_rows_bwd")
         dgam, dbet = _hand_out(list(small), [_acc_target(p) for p in ctx.acc])
         return dx, None, dgam, dbet, None, None, None, None, None, None

@@ -513,15 +513,19 @@ int hg_gather_ln_reduce_bwd(const float* h, const float* bias, const float* gamm
  * count only the rows with row_mask[i] > 0 (NULL: all rows) -- the real atoms of a padded static-shape batch:
  *   y = (x - mean) * rstd * gamma + beta,  mean / var over the masked rows (biased var for the output, unbiased into
  *   running_var), running buffers updated with `momentum`, *num_batches_tracked += 1 (both optional: NULL).
- * One launch each way (a workgroup owns four columns); save_mean / save_rstd [C] feed the backward, which returns
- * dx [R, C], dgamma, dbeta [C] (overwritten).  C % 4 == 0.
+ * Two launches each way (float64 partial column sums over row chunks, then every workgroup sums the partials of its columns
+ * in chunk order and writes its rows: bitwise reproducible, nothing atomic); save_mean / save_rstd [C] feed the backward,
+ * which returns dx [R, C], dgamma, dbeta [C] (overwritten).  C % 4 == 0; workspace (8-byte aligned) of
+ * hg_batch_norm_rows_workspace_bytes(R, C) for the partials.
  * ------------------------------------------------------------------------------------------- */
+size_t hg_batch_norm_rows_workspace_bytes(int64_t R, int32_t C);
 int hg_batch_norm_rows_fwd(const float* x, const float* row_mask, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
-                           int64_t R, int32_t C, float* y, float* save_mean, float* save_rstd, void* stream);
+                           int64_t R, int32_t C, float* y, float* save_mean, float* save_rstd, void* workspace,
+                           size_t workspace_bytes, void* stream);
 int hg_batch_norm_rows_bwd(const float* x, const float* dy, const float* row_mask, const float* gamma,
                            const float* save_mean, const float* save_rstd, int64_t R, int32_t C, float* dx, float* dgamma,
-                           float* dbeta, void* stream);
+                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Plain LayerNorm over dense rows — nn.LayerNorm(dim) applied to node features at
