@@ -112,15 +112,25 @@ class MHNNM(nn.Module):
         if taps is not None:
             taps["atom_encoder"] = x
         mask = real_row_mask(data, x)   # padded batch: BatchNorm statistics over the real atoms only
-        for i, layer in enumerate(self.layers):
-            x, e = layer(x, e, index)
-            x = batch_norm_rows(self.batch_norms[i], x, mask)
-            if taps is not None:
-                taps[f"bn{i}"] = x
-            if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
-                x, e = self.act(x), self.act(e)
-            x, e = self.dropout(x), self.dropout(e)
+        with _merged_scope(self.layers, x, e):      # the layers' weight-level products in one launch each way
+            for i, layer in enumerate(self.layers):
+                x, e = layer(x, e, index)
+                x = batch_norm_rows(self.batch_norms[i], x, mask)
+                if taps is not None:
+                    taps[f"bn{i}"] = x
+                if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
+                    x, e = self.act(x), self.act(e)
+                x, e = self.dropout(x), self.dropout(e)
         return readout(self.mlp_out, x, index, taps, head)
+
+
+def _merged_scope(convs, x, e):
+    """ops.merged_scope on the GPU (the panel path of MHNNConv); a no-op context elsewhere."""
+    import contextlib
+    if x.is_cuda:
+        from . import ops
+        return ops.merged_scope(convs, x, e)
+    return contextlib.nullcontext()
 
 
 @registry.register_model("equiformer_equihnns")
@@ -203,11 +213,12 @@ class _PairedBase(nn.Module):
             if taps is not None:
                 taps["front_end"] = x
         e = self.bond_encoder(data.edge_attr)
-        for i in range(self.nlayer):
-            x, e = self.conv(x, e, index)
-            if i != self.nlayer - 1:
-                x, e = self.act(x), self.act(e)
-            x, e = self.dropout(x), self.dropout(e)
+        with _merged_scope([self.conv], x, e):      # the shared layer's weight-level products once per step
+            for i in range(self.nlayer):
+                x, e = self.conv(x, e, index)
+                if i != self.nlayer - 1:
+                    x, e = self.act(x), self.act(e)
+                x, e = self.dropout(x), self.dropout(e)
         xp = pool_sum(x, index)
         he_csr, he_key = index.hyperedge_pool(data.n_e)
         keep = (data.e_order > 2).to(e.dtype).unsqueeze(-1)            # mhnn.py:58,72

@@ -212,13 +212,49 @@ class _MHNNConvPanel(torch.autograd.Function):
                 dbe3, dW.get("W4a"), db4a, dg4, dbe4, dW.get("W4b"), db4b, dW.get("w12"), dv12, dW.get("w34"), dv34, None, None)
 
 
+def _merged_items(conv, C):
+    W1, W2, W3, W4 = conv.W1, conv.W2, conv.W3, conv.W4
+    return [(W2.lins[0].weight, W1.lins[1].weight, W1.lins[1].bias, None, (C, 2 * C)),
+            (W4.lins[0].weight, W3.lins[1].weight, W3.lins[1].bias, None, (C, 2 * C))]
+
+
+class merged_scope:
+    """``with merged_scope(convs, X, E):`` around a model's conv applications: the weight-level products of ALL the MHNNConv
+    layers inside (two per layer) are formed by one ops.merged_weights call -- one launch forward, one in the backward pass --
+    instead of one per application; a conv applied several times (mhnn.py's shared layer) gets them once.  The results live on
+    the conv objects only inside the scope (they are functions of the parameters of THIS step)."""
+
+    def __init__(self, convs, X, E):
+        seen, self.convs = set(), []
+        for c in convs:
+            if id(c) not in seen and mhnn_panel_supported(X, E, c):
+                seen.add(id(c))
+                self.convs.append(c)
+        self.C = X.shape[-1]
+
+    def __enter__(self):
+        from .linears import merged_weights
+        if self.convs:
+            items = [it for c in self.convs for it in _merged_items(c, self.C)]
+            res = merged_weights(items)
+            for k, c in enumerate(self.convs):
+                c._eqh_merged = (res[2 * k], res[2 * k + 1])
+        return self
+
+    def __exit__(self, *exc):
+        for c in self.convs:
+            if hasattr(c, "_eqh_merged"):
+                del c._eqh_merged
+        return False
+
+
 def mhnn_conv_panel(conv, X, E, ix):
     """MHNNConv.forward(X, E) on the panel kernels (see the module docstring); returns (X', E')."""
     from .linears import merged_weights
     W1, W2, W3, W4 = conv.W1, conv.W2, conv.W3, conv.W4
     C = X.shape[-1]
-    (w12, v12), (w34, v34) = merged_weights([(W2.lins[0].weight, W1.lins[1].weight, W1.lins[1].bias, None, (C, 2 * C)),
-                                             (W4.lins[0].weight, W3.lins[1].weight, W3.lins[1].bias, None, (C, 2 * C))])
+    pre = getattr(conv, "_eqh_merged", None)
+    (w12, v12), (w34, v34) = pre if pre is not None else merged_weights(_merged_items(conv, C))
     if torch.is_grad_enabled():
         for w in (W1.lins[0].weight, W2.lins[0].weight, W2.lins[1].weight, W3.lins[0].weight, W4.lins[0].weight, W4.lins[1].weight):
             if w.requires_grad and w.is_leaf:
