@@ -414,6 +414,7 @@ def panel_prologues(method, batch, flavour):
 
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+INFINITY_CACHE_GATHER_GBS = 8600.0   # MI355X_MICROARCH.md "Indexed rows: gather": 38 MB table, uniformly random rows, chip-wide
 
 
 def saturation_probe(dev, log2_nodes=20, C=256, reps=10, seed=0):
@@ -892,13 +893,24 @@ def main():
                 result["roofline"]["rowgemm_kernels"] = mf
             edge = {}
             for name in ("egnn_edge_fwd", "egnn_edge_bwd"):
-                if name in per:     # fp32 MFMA flops only (the SiLU / gather VALU work is not counted)
+                if name in per:
+                    # What bounds them (round 5, profiles/r05_ab_runs.txt: with the SiLU / split / MFMA work compiled out the
+                    # forward keeps 46 of its 58 us): the GATHER of the neighbours' rows -- 16 rows of 4 Hp bytes per node, no
+                    # locality (the kNN graph ignores molecule boundaries), served by the Infinity Cache, whose measured ceiling
+                    # for uniformly random rows is 8.6 TB/s (MI355X_MICROARCH.md, "Indexed rows: gather").  Bytes per launch:
+                    # forward N 16 Hp 4 (the senders' B rows) = flops / 8; backward twice that (B rows by receiver, A rows by sender).
                     tf = per[name]["work"] / per[name]["us"] / 1e6
-                    edge[name] = {"us": round(per[name]["us"], 1), "mfma_flops": int(per[name]["work"]), "achieved": round(tf, 1),
-                                  "unit": "TFLOP/s", "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                    gbytes = per[name]["work"] / (8.0 if name == "egnn_edge_fwd" else 12.0)
+                    gbs = gbytes / per[name]["us"] / 1e3
+                    edge[name] = {"us": round(per[name]["us"], 1), "gather_bytes": int(gbytes), "achieved": round(gbs, 1), "unit": "GB/s",
+                                  "peak": INFINITY_CACHE_GATHER_GBS, "frac": round(gbs / INFINITY_CACHE_GATHER_GBS, 4),
+                                  "mfma_flops": int(per[name]["work"]), "mfma_tflops": round(tf, 1),
                                   "where": "inside the replayed step"}
             if edge:
-                edge["bound"] = "mfma"
+                edge["bound"] = "gather"
+                edge["note"] = ("random-row gather from the Infinity Cache (peak: the microarchitecture guide's measured 8.6 TB/s for a 38 MB "
+                                "table); the forward multiplies on the bf16 pipe (3 planes, 6 MFMAs), the backward on the fp32 MFMA; the "
+                                "forward's VALU floor (2 transcendentals + the 3-plane split per hidden unit and edge) is ~37 us at this batch")
                 result["roofline"]["edge_kernels"] = edge
             if world == 1:
                 b2b = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
