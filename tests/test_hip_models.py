@@ -344,7 +344,7 @@ def test_padded_batch_is_exact_with_batch_norm_inside_the_mlps_and_without_mlps(
             assert float((q.grad - g0[k]).abs().max()) / scale < (2e-3 if bn else 1e-4), k
     # ... and the graphed trainer accepts the model: bootstrap + capture + two replays with a finite, moving loss.  (The eager
     # passes above ran on the default stream: their autograd graphs -- alive through `out` / `outp` -- hold AccumulateGrad nodes
-    # bound to that stream, which a capture on another stream must not meet: DESIGN.md section 4.4.)
+    # bound to that stream, which a capture on another stream must not meet: DESIGN.md section 4.5.)
     import gc
     del out, outp
     for q in m.parameters():
