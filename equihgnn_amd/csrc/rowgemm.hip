@@ -330,7 +330,7 @@ template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
                      const int* __restrict__ perm, int R, int Lrt, float* __restrict__ out, int accumulate,
-                     const float* __restrict__ rowbias, const float* __restrict__ coef, int MB) {
+                     const float* __restrict__ rowbias, const float* __restrict__ coef, int MB, int zfac) {
     // a ROUND is 16 loads = 16 KB of the matrix per wavefront: TB steps of 16 k-values (one for L = 256, four for L = 64);
     // the loop over rounds is not unrolled, so the loads of round n + 1 are what is in flight while round n multiplies
     // L: the matrix' row pitch = its width; 256 for LU = 4, any multiple of 4 up to 64 for LU = 1 (52 columns of the attention's
@@ -365,12 +365,25 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
         int e_g[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) e_g[g] = __shfl(e_r, 4 * q + g, 64);
-        const float* __restrict__ zr = z + (int64_t)(e_r >= 0 ? e_r : 0) * Kd + 4 * q;
+        // zfac (LU = 1: a round is 64 k-values): z is [E, 64] and column (m, k) of the A operand is coef[e, m] z[e, k] -- the
+        // (1 -> 0) pair's r_hat (x) z, equiformer_layer.py:376-383, never formed
+        const float* __restrict__ zr = z + (int64_t)(e_r >= 0 ? e_r : 0) * (zfac ? 64 : Kd) + 4 * q;
+        const float* __restrict__ cfr = coef + (int64_t)(e_r >= 0 ? e_r : 0) * MB;
+        auto zload = [&](int rd, int tt) {
+            if (e_r < 0) return f4_zero();
+            if (LU == 1 && zfac) {
+                float4 v = *reinterpret_cast<const float4*>(zr + 16 * tt);
+                const float cf = cfr[rd];
+                v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
+                return v;
+            }
+            return *reinterpret_cast<const float4*>(zr + 16 * (rd * TB + tt));
+        };
         float4 ring[PER], zc[TB];
 #pragma unroll
         for (int n = 0; n < PER; ++n) ring[n] = wload(rnd(0), n);
 #pragma unroll
-        for (int tt = 0; tt < TB; ++tt) zc[tt] = e_r >= 0 ? *reinterpret_cast<const float4*>(zr + 16 * (rnd(0) * TB + tt)) : f4_zero();
+        for (int tt = 0; tt < TB; ++tt) zc[tt] = zload(rnd(0), tt);
         f32x4 acc[4 * LU];
 #pragma unroll
         for (int c = 0; c < 4 * LU; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -380,7 +393,7 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
             float4 zn[TB];
 #pragma unroll
             for (int tt = 0; tt < TB; ++tt)
-                zn[tt] = (more && e_r >= 0) ? *reinterpret_cast<const float4*>(zr + 16 * (rnd(rd + 1) * TB + tt)) : f4_zero();
+                zn[tt] = more ? zload(rnd(rd + 1), tt) : f4_zero();
             // (the scheduling barriers keep the refill of a half behind its last use: hoisted, the 16 loads of the next round
             // need 64 registers of their own and the kernel spills)
 #pragma unroll
@@ -436,7 +449,8 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
 template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__ w, const int* __restrict__ rowptr,
-                       const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dz, int accumulate) {
+                       const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dz, int accumulate,
+                       const float* __restrict__ coef, int MB, int zfac) {
     constexpr int Kd = KT * 16, LT = 4 * LU, TB = LU == 4 ? 1 : 4, PER = TB * LT, NR = KT / TB;
     static_assert(KT % TB == 0 && PER == 16, "rounds of 16 loads");
     const int L = LU == 4 ? 256 : Lrt;        // (as in the forward kernel; here the columns are the contraction index)
@@ -465,6 +479,11 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
         for (int t = 0; t < LT; ++t)
             d4[t] = (e_r >= 0 && (LU == 4 || 16 * t + 4 * q < L)) ? *reinterpret_cast<const float4*>(dout + (int64_t)e_r * L + 16 * t + 4 * q)
                                                                   : f4_zero();
+        float dzf[TB][4];
+#pragma unroll
+        for (int kk = 0; kk < TB; ++kk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dzf[kk][g] = 0.f;
 #pragma unroll 1
         for (int rd = 0; rd < NR; ++rd) {
             const bool more = rd + 1 < NR;
@@ -490,6 +509,15 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (LU == 1 && zfac) {          // dz[e, k] = sum_m coef[e, m] dz'[e, (m, k)]: the round IS m
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float cf = e_g[g] >= 0 ? coef[(int64_t)e_g[g] * MB + rd] : 0.f;
+#pragma unroll
+                    for (int kk = 0; kk < TB; ++kk) dzf[kk][g] = fmaf(cf, acc[kk][g] + acc2[kk][g], dzf[kk][g]);
+                }
+                continue;
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (e_g[g] < 0) continue;
@@ -499,6 +527,15 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
                     const float v = acc[kk][g] + acc2[kk][g];
                     o[16 * kk] = accumulate ? (o[16 * kk] + v) : v;
                 }
+            }
+        }
+        if (LU == 1 && zfac) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (e_g[g] < 0) continue;
+                float* __restrict__ o = dz + (int64_t)e_g[g] * 64 + r_;
+#pragma unroll
+                for (int kk = 0; kk < TB; ++kk) o[16 * kk] = accumulate ? (o[16 * kk] + dzf[kk][g]) : dzf[kk][g];
             }
         }
     }
@@ -511,7 +548,7 @@ template <int KT, int LU>
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
                        const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dw, const float* __restrict__ coef, int MB,
-                       float* __restrict__ drowbias) {
+                       float* __restrict__ drowbias, int zfac) {
     constexpr int Kd = KT * 16;
     const int L = LU == 4 ? 256 : Lrt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -543,7 +580,11 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
             if (!one) load_group(g0);
             float a[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = ent[s] >= 0 ? z[(int64_t)ent[s] * Kd + 16 * kt + r_] : 0.f;
+            for (int s = 0; s < 4; ++s) {
+                if (ent[s] < 0) a[s] = 0.f;
+                else if (zfac) a[s] = coef[(int64_t)ent[s] * MB + (kt >> 2)] * z[(int64_t)ent[s] * 64 + 16 * (kt & 3) + r_];
+                else a[s] = z[(int64_t)ent[s] * Kd + 16 * kt + r_];
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -643,20 +684,29 @@ int check(int64_t R, int Kd, int L) {
 
 }  // namespace
 
+static int zfac_check(int32_t Kd, int32_t L, const float* coef, int32_t MB, int32_t zfac) {
+    if (!zfac) return EQH_OK;
+    // z [E, 64], A column (m, k) = coef[e, m] z[e, k]: the 64-column streaming kernels, a round of 64 k-values per m
+    if (!coef || MB < 1 || Kd != 64 * MB || L > 64 || !stream_shape(Kd, L)) return EQH_ERR_ARG;
+    return EQH_OK;
+}
+
 extern "C" int hg_rowgemm_fwd_bias(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm, int64_t R,
                                    int32_t Kd, int32_t L, float* out, int32_t accumulate, const float* rowbias,
-                                   const float* coef, int32_t MB, void* stream_) {
+                                   const float* coef, int32_t MB, int32_t z_factored, void* stream_) {
     int rc = check(R, Kd, L);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
     if (!z || !w || !rowptr || !out) return EQH_ERR_ARG;
     if (!eqh_aligned16(z) || !eqh_aligned16(w)) return EQH_ERR_ALIGN;
     if (rowbias && (MB < 1 || MB > 16 || !eqh_aligned16(rowbias))) return EQH_ERR_ARG;
-    if (!rowbias && coef) return EQH_ERR_ARG;
+    if (!rowbias && coef && !z_factored) return EQH_ERR_ARG;
+    if (zfac_check(Kd, L, coef, MB, z_factored)) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
         if (!eqh_aligned16(out)) return EQH_ERR_ALIGN;
-        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, (int)L, out, (int)accumulate, rowbias, coef, (int)MB);
+        ROW_STREAM_LAUNCH(k_rowgemm_fwd_stream, shape, z, w, rowptr, perm, (int)R, (int)L, out, (int)accumulate, rowbias, coef, (int)MB,
+                          (int)z_factored);
         return EQH_OK;
     }
     if (rowbias) return EQH_ERR_ARG;          // (the bias block rides the streaming kernels only: see hg_rowgemm_bias_supported)
@@ -690,26 +740,29 @@ extern "C" int hg_rowgemm_fwd_bias(const float* z, const float* w, const int32_t
 
 extern "C" int hg_rowgemm_fwd(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm, int64_t R,
                               int32_t Kd, int32_t L, float* out, int32_t accumulate, void* stream_) {
-    return hg_rowgemm_fwd_bias(z, w, rowptr, perm, R, Kd, L, out, accumulate, nullptr, nullptr, 0, stream_);
+    return hg_rowgemm_fwd_bias(z, w, rowptr, perm, R, Kd, L, out, accumulate, nullptr, nullptr, 0, 0, stream_);
 }
 
 extern "C" int hg_rowgemm_bias_supported(int32_t Kd, int32_t L) { return stream_shape(Kd, L) != 0; }
 
 extern "C" int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* dout, const int32_t* rowptr,
                                    const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz, int32_t accumulate_dz,
-                                   float* dw, const float* coef, int32_t MB, float* drowbias, void* stream_) {
+                                   float* dw, const float* coef, int32_t MB, float* drowbias, int32_t z_factored, void* stream_) {
     int rc = check(R, Kd, L);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
     if (!z || !dout || !rowptr || (dz && !w)) return EQH_ERR_ARG;     // (w is read for dz only)
     if (!eqh_aligned16(dout) || (dz && !eqh_aligned16(w)) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
     if (drowbias && (!dw || MB < 1 || MB > 16 || !eqh_aligned16(drowbias))) return EQH_ERR_ARG;   // (it rides the dw launch)
+    if (zfac_check(Kd, L, coef, MB, z_factored)) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (const int shape = stream_shape(Kd, L)) {
-        if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, (int)L, dz, (int)accumulate_dz);
+        if (dz) ROW_STREAM_LAUNCH(k_rowgemm_bwd_z_stream, shape, dout, w, rowptr, perm, (int)R, (int)L, dz, (int)accumulate_dz, coef,
+                                  (int)MB, (int)z_factored);
         if (dw) {
             if (!eqh_aligned16(dw)) return EQH_ERR_ALIGN;
-            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, (int)L, dw, coef, (int)MB, drowbias);
+            ROW_STREAM_LAUNCH(k_rowgemm_bwd_w_stream, shape, z, dout, rowptr, perm, (int)R, (int)L, dw, coef, (int)MB, drowbias,
+                              (int)z_factored);
         }
         return EQH_OK;
     }
@@ -767,5 +820,5 @@ extern "C" int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* 
 extern "C" int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int32_t* rowptr,
                               const int32_t* perm, int64_t R, int32_t Kd, int32_t L, float* dz,
                               int32_t accumulate_dz, float* dw, void* stream_) {
-    return hg_rowgemm_bwd_bias(z, w, dout, rowptr, perm, R, Kd, L, dz, accumulate_dz, dw, nullptr, 0, nullptr, stream_);
+    return hg_rowgemm_bwd_bias(z, w, dout, rowptr, perm, R, Kd, L, dz, accumulate_dz, dw, nullptr, 0, nullptr, 0, stream_);
 }

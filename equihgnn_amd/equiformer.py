@@ -231,6 +231,12 @@ def radial_contract(radial: Radial, z, xj, xi, geo: EdgeGeometry, zscale=None):
         g = (ops.gather_rows(pb, geo.nbr_flat, geo.csr_t).view(n, geo.K, 3, lo) + qb[:, None]).reshape(-1, 3, lo)
     outs = []
     for zs in (zscale if isinstance(zscale, (list, tuple)) else (zscale,)):
+        if fold and mid == 64 and lo_p <= 64:
+            # + sum_m zs[e, m] (pb[j, m] + qb[i, m]) inside the launches, and the row operand zs (x) z formed in their registers
+            out = ops.rowgemm2(z, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None, pb.view(n, 3, lo_p),
+                               qb.view(n, 3, lo_p), zs, z_factored=True)
+            outs.append(out if lo_p == lo else out[:, :lo])
+            continue
         ze = (zs[:, :, None] * z[:, None, :]).reshape(-1, 3 * mid)                  # [E, (m,k)]
         if fold:    # + sum_m zs[e, m] (pb[j, m] + qb[i, m]) inside the launches
             out = ops.rowgemm2(ze, p, geo.csr_t.rowptr, geo.csr_t.perm, q, geo.recv_rowptr, None, pb.view(n, 3, lo_p),

@@ -106,9 +106,9 @@ SIGNATURES = {
                       + [c_int32, c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_rowgemm_bias_supported": (c_int32, [c_int32, c_int32]),
     "hg_rowgemm_fwd_bias": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
-                                      c_void_p]),
+                                      c_int32, c_void_p]),
     "hg_rowgemm_bwd_bias": (c_int32, [c_void_p] * 5 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int32,
-                                      c_void_p, c_void_p]),
+                                      c_void_p, c_int32, c_void_p]),
     "hg_rowgemm_fwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p]),
     "hg_incidence_ln_reduce_fwd": (c_int32, [c_void_p] * 8 + [c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p]),
     "hg_incidence_ln_reduce_fwd_col": (c_int32, [c_void_p] * 4 + [c_int32, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float,

@@ -56,13 +56,16 @@ class _RowGemm2(torch.autograd.Function):
     node matrices' (hg_rowgemm_fwd_bias / _bwd_bias); coef carries no gradient."""
 
     @staticmethod
-    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, ba=None, bb=None, coef=None):
+    def forward(ctx, z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, ba=None, bb=None, coef=None, z_factored=False):
         _require_gpu(z, "rowgemm2")
         z, wa, wb = _f32c(z), _f32c(wa), _f32c(wb)
-        E, Kd = z.shape
-        Ra, _, L = wa.shape
+        E = z.shape[0]
+        Ra, Kd, L = wa.shape
         Rb = wb.shape[0]
-        if wa.shape[1:] != wb.shape[1:] or wa.shape[1] != Kd or rowptr_a.numel() != Ra + 1 or rowptr_b.numel() != Rb + 1:
+        zf = 1 if z_factored else 0
+        if zf and (coef is None or z.shape[1] * coef.shape[1] != Kd or z.shape[1] != 64):
+            raise ValueError("rowgemm2: z_factored wants z[E,64], coef[E,MB], node matrices [R, 64 * MB, L]")
+        if wa.shape[1:] != wb.shape[1:] or (not zf and z.shape[1] != Kd) or rowptr_a.numel() != Ra + 1 or rowptr_b.numel() != Rb + 1:
             raise ValueError("rowgemm2: z[E,Kd], wa[Ra,Kd,L], wb[Rb,Kd,L], rowptr_a[Ra+1], rowptr_b[Rb+1] expected")
         MB = 0
         if ba is not None:
@@ -71,18 +74,21 @@ class _RowGemm2(torch.autograd.Function):
             coef = _f32c(coef) if coef is not None else None
             if ba.shape != (Ra, MB, L) or bb.shape != (Rb, MB, L) or (coef is not None and coef.shape != (E, MB)):
                 raise ValueError("rowgemm2: bias blocks [R, MB, L] and coef [E, MB] expected")
+        elif zf:
+            coef = _f32c(coef)
+            MB = coef.shape[1]
         out = torch.empty((E, L), dtype=torch.float32, device=z.device)
         L_ = hip.lib()
         st = _stream(z.device)
         timed("k_rowgemm_fwd", 2 * E * Kd * L,
               lambda: hip.check(L_.hg_rowgemm_fwd_bias(_ptr(z), _ptr(wa), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(out), 0,
-                                                       _ptr(ba), _ptr(coef), MB, st), "hg_rowgemm_fwd_bias"))
+                                                       _ptr(ba), _ptr(coef), MB, zf, st), "hg_rowgemm_fwd_bias"))
         timed("k_rowgemm_fwd", 2 * E * Kd * L,
               lambda: hip.check(L_.hg_rowgemm_fwd_bias(_ptr(z), _ptr(wb), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(out), 1,
-                                                       _ptr(bb), _ptr(coef), MB, st), "hg_rowgemm_fwd_bias"))
+                                                       _ptr(bb), _ptr(coef), MB, zf, st), "hg_rowgemm_fwd_bias"))
         ctx.save_for_backward(z, wa, wb, coef)
         ctx.idx = (rowptr_a, perm_a, rowptr_b, perm_b)
-        ctx.MB = MB
+        ctx.MB, ctx.zf, ctx.has_bias = MB, zf, ba is not None
         return out
 
     @staticmethod
@@ -92,24 +98,24 @@ class _RowGemm2(torch.autograd.Function):
         dout = _f32c(dout)
         Ra, Kd, L = wa.shape
         Rb = wb.shape[0]
-        MB = ctx.MB
+        MB, zf, hb = ctx.MB, ctx.zf, ctx.has_bias
         need_z = ctx.needs_input_grad[0]
         dz = torch.empty_like(z) if need_z else None
-        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] or MB else None
-        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] or MB else None
-        dba = torch.empty((Ra, MB, L), dtype=torch.float32, device=z.device) if MB else None
-        dbb = torch.empty((Rb, MB, L), dtype=torch.float32, device=z.device) if MB else None
+        dwa = torch.empty_like(wa) if ctx.needs_input_grad[1] or hb else None
+        dwb = torch.empty_like(wb) if ctx.needs_input_grad[4] or hb else None
+        dba = torch.empty((Ra, MB, L), dtype=torch.float32, device=z.device) if hb else None
+        dbb = torch.empty((Rb, MB, L), dtype=torch.float32, device=z.device) if hb else None
         L_ = hip.lib()
         st = _stream(z.device)
         E = z.shape[0]
         nf = (2 if need_z else 0) * E * Kd * L
         timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwa is not None else 0),
               lambda: hip.check(L_.hg_rowgemm_bwd_bias(_ptr(z), _ptr(wa), _ptr(dout), _ptr(rowptr_a), _ptr(perm_a), Ra, Kd, L, _ptr(dz),
-                                                       0, _ptr(dwa), _ptr(coef), MB, _ptr(dba), st), "hg_rowgemm_bwd_bias"))
+                                                       0, _ptr(dwa), _ptr(coef), MB, _ptr(dba), zf, st), "hg_rowgemm_bwd_bias"))
         timed("k_rowgemm_bwd", nf + (2 * E * Kd * L if dwb is not None else 0),
               lambda: hip.check(L_.hg_rowgemm_bwd_bias(_ptr(z), _ptr(wb), _ptr(dout), _ptr(rowptr_b), _ptr(perm_b), Rb, Kd, L, _ptr(dz),
-                                                       1, _ptr(dwb), _ptr(coef), MB, _ptr(dbb), st), "hg_rowgemm_bwd_bias"))
-        return dz, dwa, None, None, dwb, None, None, dba, dbb, None
+                                                       1, _ptr(dwb), _ptr(coef), MB, _ptr(dbb), zf, st), "hg_rowgemm_bwd_bias"))
+        return dz, dwa, None, None, dwb, None, None, dba, dbb, None, None
 
 
 class _RowOuter(torch.autograd.Function):
@@ -427,13 +433,14 @@ def rowgemm(z, w, rowptr, perm=None):
     return _RowGemm.apply(z, w, rowptr, perm)
 
 
-def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a=None, bias_b=None, coef=None):
+def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a=None, bias_b=None, coef=None, z_factored=False):
     """rowgemm(z, wa, rowptr_a, perm_a) + rowgemm(z, wb, rowptr_b, perm_b) when BOTH groupings cover every entry
     of z (no entry outside all rows): one output buffer, the second pass accumulates.  ``bias_a`` / ``bias_b`` [R, MB, L]
-    (+ ``coef`` [E, MB]): the rows' bias blocks added in the same launches (rowgemm_bias_supported(Kd, L))."""
-    if bias_a is None:
+    (+ ``coef`` [E, MB]): the rows' bias blocks added in the same launches (rowgemm_bias_supported(Kd, L)).  ``z_factored``: z is
+    [E, 64] and the row operand's column (m, k) is coef[e, m] z[e, k] (node matrices [R, 64 MB, L], L <= 64)."""
+    if bias_a is None and not z_factored:
         return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
-    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a, bias_b, coef)
+    return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a, bias_b, coef, bool(z_factored))
 
 
 def rowgemm_bias_supported(Kd: int, L: int) -> bool:

@@ -423,14 +423,16 @@ int hg_rowgemm_bwd(const float* z, const float* w, const float* dout, const int3
  * 451-479: reshape(b3)[lo, li] x[li] per node):  out[e, :] += sum_{m < MB} coef[e, m] rowbias[row(e), m, :]
  * (rowbias [R, MB, L]; coef [E, MB] or NULL = 1; MB <= 16), and in the backward pass
  * drowbias[r, m, :] = sum_{e in row r} coef[e, m] dout[e, :] beside dw (drowbias needs dw).  Only for the shapes
- * hg_rowgemm_bias_supported(Kd, L) reports (L a multiple of 64, Kd of {64, 192, 256}); coef carries no gradient. */
+ * hg_rowgemm_bias_supported(Kd, L) reports (L a multiple of 64, Kd of {64, 192, 256}); coef carries no gradient.
+ * z_factored != 0 (Kd = 64 MB, L <= 64): z is [E, 64] and column (m, k) of the row operand is coef[e, m] z[e, k] -- the
+ * (1 -> 0) pair's D[e, m] z_e[k] (equiformer_layer.py:376-383) without the [E, 3 * 64] product; dz is [E, 64] then. */
 int hg_rowgemm_bias_supported(int32_t Kd, int32_t L);
 int hg_rowgemm_fwd_bias(const float* z, const float* w, const int32_t* rowptr, const int32_t* perm, int64_t R, int32_t Kd,
                         int32_t L, float* out, int32_t accumulate, const float* rowbias, const float* coef, int32_t MB,
-                        void* stream);
+                        int32_t z_factored, void* stream);
 int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* dout, const int32_t* rowptr, const int32_t* perm,
                         int64_t R, int32_t Kd, int32_t L, float* dz, int32_t accumulate_dz, float* dw, const float* coef,
-                        int32_t MB, float* drowbias, void* stream);
+                        int32_t MB, float* drowbias, int32_t z_factored, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused per-incidence hidden layer + aggregation — conv.py:90-93,96-97,175-177 with the MLP of

@@ -642,6 +642,25 @@ def test_rowgemm2_with_bias_blocks_matches_float64_reference(R, Kd, L, MB, seed)
     for got, want, name in zip(dl, leaves, ("z", "wa", "wb", "ba", "bb")):
         np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), atol=1e-4, rtol=1e-5, err_msg=name)
     assert float(dl[1].grad[1].abs().max()) == 0.0 and float(dl[3].grad[1].abs().max()) == 0.0      # the empty sender row
+    if Kd != 192 or L > 64:
+        return
+    # the factored row operand: z [E, 64], column (m, k) = coef[e, m] z[e, k]  (the same product as above with z = coef (x) z64)
+    zs = torch.randn(E, 64, generator=g)
+    zfull = (coef[:, :, None] * zs[:, None, :]).reshape(E, 192)
+    z6 = zs.double().requires_grad_(True)
+    leaves2 = [t.double().requires_grad_(True) for t in (wa, wb, ba, bb)]
+    zf6 = (coef.double()[:, :, None] * z6[:, None, :]).reshape(E, 192)
+    ref2 = (torch.einsum("ek,ekl->el", zf6, leaves2[0][key] + leaves2[1][recv])
+            + torch.einsum("em,eml->el", coef.double(), leaves2[2][key] + leaves2[3][recv]))
+    (ref2 * dout.double()).sum().backward()
+    zd = zs.to(DEV).requires_grad_(True)
+    dl2 = [t.to(DEV).requires_grad_(True) for t in (wa, wb, ba, bb)]
+    out2 = ops.rowgemm2(zd, dl2[0], csr.rowptr, csr.perm, dl2[1], rowptr, None, dl2[2], dl2[3], coef.to(DEV), z_factored=True)
+    (out2 * dout.to(DEV)).sum().backward()
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), ref2.detach().numpy(), atol=5e-5, rtol=1e-5)
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), z6.grad.numpy(), atol=1e-4, rtol=1e-5)
+    for got, want, name in zip(dl2, leaves2, ("wa", "wb", "ba", "bb")):
+        np.testing.assert_allclose(got.grad.cpu().numpy(), want.grad.numpy(), atol=1e-4, rtol=1e-5, err_msg="factored " + name)
 
 
 @pytest.mark.parametrize("N,K,C", [(37, 16, 256), (5, 7, 48), (130, 16, 64)])
