@@ -882,14 +882,19 @@ def main():
                             "LayerNorm, gathers) are bound by the same 148 CUs' VALU and vector-memory rate (DESIGN.md section 4)",
                     "kernels": pk}
             mf = {}
-            for name in ("k_rowgemm_fwd", "k_rowgemm_bwd"):     # Equiformer's radial tensor product (fp32 MFMA)
+            for name in ("k_rowgemm_fwd", "k_rowgemm_bwd"):     # Equiformer's radial tensor product
                 if name in per:
+                    # A node's [Kd, L] matrix is used once per 16 entries: the launches are STREAMS over the node matrices (a few
+                    # fp32 MFMAs ride along: 2 E Kd L flops = 8 flops per matrix byte at 16 entries per node), so they are booked
+                    # against HBM: matrix bytes = flops / 8 (the forward and dz passes read them, the dw pass writes them).
                     tf = per[name]["work"] / per[name]["us"] / 1e6
+                    gbs = per[name]["work"] / 8.0 / per[name]["us"] / 1e3
                     mf[name] = {"launches_per_step": per[name]["launches_per_step"], "us": round(per[name]["us"], 1),
-                                "mfma_flops": int(per[name]["work"]), "achieved": round(tf, 1), "unit": "TFLOP/s",
-                                "peak": FP32_MFMA_PEAK_TFLOPS, "frac": round(tf / FP32_MFMA_PEAK_TFLOPS, 4)}
+                                "matrix_bytes": int(per[name]["work"] / 8.0), "achieved": round(gbs, 1), "unit": "GB/s",
+                                "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                "mfma_flops": int(per[name]["work"]), "mfma_tflops": round(tf, 1)}
             if mf:
-                mf["bound"] = "mfma"
+                mf["bound"] = "hbm"
                 result["roofline"]["rowgemm_kernels"] = mf
             edge = {}
             for name in ("egnn_edge_fwd", "egnn_edge_bwd"):

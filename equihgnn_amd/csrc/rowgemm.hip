@@ -326,8 +326,13 @@ k_rowgemm_bwd_w_lds(const float* __restrict__ z, const float* __restrict__ dout,
 //     instruction reads 4 matrix rows x 256 contiguous bytes and feeds 4 MFMAs; the output tiles come back as float4 over j.
 //   * the k index of MFMA step (t, i) is 16 t + 4 q + i, so that the A operand z[e][16 t + 4 q ..] is a float4 as well.
 // L is a multiple of 64 (LU = L / 64), Kd = 16 KT.
+#ifndef ROW_STREAM_WAVES
+#define ROW_STREAM_WAVES 1      // wavefronts per workgroup of the streaming kernels: ONE, so that the ~10 rows per CU are dealt out
+#endif                          // one by one (four-wavefront workgroups: 3 against 2 of them per CU, the launch as slow as the 3)
+constexpr int SW = ROW_STREAM_WAVES, STHREADS = 64 * SW;
+
 template <int KT, int LU>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, const int* __restrict__ rowptr,
                      const int* __restrict__ perm, int R, int Lrt, float* __restrict__ out, int accumulate,
                      const float* __restrict__ rowbias, const float* __restrict__ coef, int MB, int zfac) {
@@ -341,7 +346,7 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
     const bool act = LU == 4 || 4 * r_ < L;
-    const int row = blockIdx.x * WAVES + wave;
+    const int row = blockIdx.x * SW + wave;
     if (row >= R) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
     const float* wr = w + (int64_t)row * Kd * L + (int64_t)(4 * q) * L + 4 * r_;
@@ -447,7 +452,7 @@ k_rowgemm_fwd_stream(const float* __restrict__ z, const float* __restrict__ w, c
 // matrix row 16 kt + r at columns 16 t + 4 q .. (64-byte pieces of 16 rows per instruction; consecutive t complete the
 // 128-byte lines while they are still in L1).  A round is TB tile rows (16 loads), stored as soon as it is summed.
 template <int KT, int LU>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__ w, const int* __restrict__ rowptr,
                        const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dz, int accumulate,
                        const float* __restrict__ coef, int MB, int zfac) {
@@ -456,7 +461,7 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
     const int L = LU == 4 ? 256 : Lrt;        // (as in the forward kernel; here the columns are the contraction index)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * WAVES + wave;
+    const int row = blockIdx.x * SW + wave;
     if (row >= R) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
     const float* wr = w + (int64_t)row * Kd * L + (int64_t)r_ * L + 4 * q;
@@ -545,7 +550,7 @@ k_rowgemm_bwd_z_stream(const float* __restrict__ dout, const float* __restrict__
 // the rows of dout are held in registers across the KT tile rows when the row has one group of 16 entries (every receiver row;
 // most sender rows) and re-read from L2 per tile row otherwise.  Rows without entries are written as zeros.
 template <int KT, int LU>
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ void __launch_bounds__(STHREADS) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ dout, const int* __restrict__ rowptr,
                        const int* __restrict__ perm, int R, int Lrt, float* __restrict__ dw, const float* __restrict__ coef, int MB,
                        float* __restrict__ drowbias, int zfac) {
@@ -554,7 +559,7 @@ k_rowgemm_bwd_w_stream(const float* __restrict__ z, const float* __restrict__ do
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r_ = lane & 15, q = lane >> 4;
     const bool act = LU == 4 || 4 * r_ < L;
-    const int row = blockIdx.x * WAVES + wave;
+    const int row = blockIdx.x * SW + wave;
     if (row >= R) return;
     const int beg = rowptr[row], end = rowptr[row + 1];
     const bool one = end - beg <= 16;
@@ -653,11 +658,11 @@ inline int stream_shape(int Kd, int L) {
 }
 #define ROW_STREAM_LAUNCH(KERNEL, shape, ...)                                                                                  \
     do {                                                                                                                       \
-        const dim3 grid_((unsigned)((R + WAVES - 1) / WAVES));                                                                 \
-        if (shape == 1) hipLaunchKernelGGL((KERNEL<4, 4>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                      \
-        else if (shape == 2) hipLaunchKernelGGL((KERNEL<4, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                 \
-        else if (shape == 3) hipLaunchKernelGGL((KERNEL<12, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                \
-        else hipLaunchKernelGGL((KERNEL<16, 1>), grid_, dim3(THREADS), 0, stream, __VA_ARGS__);                                \
+        const dim3 grid_((unsigned)((R + SW - 1) / SW));                                                                 \
+        if (shape == 1) hipLaunchKernelGGL((KERNEL<4, 4>), grid_, dim3(STHREADS), 0, stream, __VA_ARGS__);                      \
+        else if (shape == 2) hipLaunchKernelGGL((KERNEL<4, 1>), grid_, dim3(STHREADS), 0, stream, __VA_ARGS__);                 \
+        else if (shape == 3) hipLaunchKernelGGL((KERNEL<12, 1>), grid_, dim3(STHREADS), 0, stream, __VA_ARGS__);                \
+        else hipLaunchKernelGGL((KERNEL<16, 1>), grid_, dim3(STHREADS), 0, stream, __VA_ARGS__);                                \
         EQH_CHECK_LAUNCH();                                                                                                    \
     } while (0)
 

@@ -68,8 +68,8 @@ def test_hip_gradients_match_the_reference_in_float64(name):
 
 
 # (method, molecules, seed, flavour, hidden, mode): the BASELINE workloads at sizes the CPU oracle still finishes in
-# seconds.  c1 mhnnm B=32; c2 egnn_equihnns B=256; c3 equiformer_equihnns B=128 (at the main.py:195 default width 64:
-# at 256 the oracle's per-edge radial weights alone are 9.7 GB per pair type); c4's PCQM-like molecules at B=300, where
+# seconds.  c1 mhnnm B=32; c2 egnn_equihnns B=256; c3 equiformer_equihnns B=128 (at the main.py:195 default width 64 and,
+# since round 5, at its own width 256: 100 s of CPU oracle); c4's PCQM-like molecules at B=300, where
 # the cloud (8.9 k atoms) is past the 8 192-atom switch to the four-queries-per-wavefront neighbour search; c5
 # faformer_equihnns on the Molecule3D-like batch of 512 molecules (15 k atoms) in eval mode, forward only.
 ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 32, 2001, "qm9", 256, "train"),
@@ -79,6 +79,9 @@ ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 
                     # evaluation order drew the same on seed 3004, 3.4e-4 -- see test_hip_gradients_match_fp64_truth)
                     ("equiformer_equihnns", 16, 3003, "qm9", 256, "train"),
                     ("equiformer_equihnns", 128, 3001, "qm9", 64, "train"),
+                    # c3 at its own size (batch 128, hidden 256), forward and gradients: the fp32 oracle's per-edge radial weights are
+                    # 9.7 GB per pair type (45 GB with the autograd tape; the GPU box has 3 TB)
+                    ("equiformer_equihnns", 128, 3008, "qm9", 256, "train"),
                     ("egnn_equihnns", 300, 4000, "pcqm", 256, "train"),
                     ("faformer_equihnns", 64, 5001, "pcqm", 256, "eval"),
                     ("faformer_equihnns", 512, 5000, "pcqm", 256, "eval-forward")]
@@ -94,6 +97,9 @@ GRAD_L2_BOUND = {("mhnnm", 32, "train"): 1.2e-2,                    # [3.8e-3]
                  ("equiformer_equihnns", 8, "train"): 1e-4,        # [3.2e-6]
                  ("equiformer_equihnns", 16, "train"): 1e-4,       # [3.9e-6]
                  ("equiformer_equihnns", 128, "train"): 1e-4,      # [2.9e-6]  BASELINE config 3's batch (hidden 64)
+                 # BASELINE config 3 at its own size (batch 128, hidden 256; round 5: the fp32 oracle holds ~45 GB of per-edge
+                 # radial weights for its backward pass -- the GPU box has the memory; 100 s): [1.6e-3], one gate weight, a kink draw
+                 ("equiformer_equihnns", 128, "train", 256): 5e-3,
                  ("egnn_equihnns", 300, "train"): 3e-3,            # [1.0e-3]  config 4's molecules
                  ("faformer_equihnns", 64, "eval"): 8e-3}          # [2.8e-3]
 
@@ -165,7 +171,7 @@ def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed, flavour, h
     print(f"baseline-size {method} B={bs} {flavour} {mode}: largest relative L2 gradient error {max(rels)}")
     # the measured noise level per workload (round 4, panel path; fp32 CPU oracle against this path, both 1e-4..1e-3 from the
     # float64 truth where a ReLU / frame-sign kink flipped): bound = ~3 x the measured value
-    bound = GRAD_L2_BOUND.get((method, bs, mode), 5e-2)
+    bound = GRAD_L2_BOUND.get((method, bs, mode, hidden), GRAD_L2_BOUND.get((method, bs, mode), 5e-2))
     assert max(rels)[0] < bound, (max(rels), bound)
 
 
