@@ -68,11 +68,12 @@ def test_hip_gradients_match_the_reference_in_float64(name):
 
 
 # (method, molecules, seed, flavour, hidden, mode): the BASELINE workloads at sizes the CPU oracle still finishes in
-# seconds.  c1 mhnnm B=32; c2 egnn_equihnns B=256; c3 equiformer_equihnns B=128 (at the main.py:195 default width 64 and,
+# seconds.  c1 mhnnm B=32 and B=256 (its own size); c2 egnn_equihnns B=256; c3 equiformer_equihnns B=128 (at the main.py:195 default width 64 and,
 # since round 5, at its own width 256: 100 s of CPU oracle); c4's PCQM-like molecules at B=300, where
 # the cloud (8.9 k atoms) is past the 8 192-atom switch to the four-queries-per-wavefront neighbour search; c5
 # faformer_equihnns on the Molecule3D-like batch of 512 molecules (15 k atoms) in eval mode, forward only.
-ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 32, 2001, "qm9", 256, "train"),
+ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("mhnnm", 256, 1010, "qm9", 256, "train"),
+                    ("egnn_equihnns", 32, 2001, "qm9", 256, "train"),
                     ("egnn_equihnns", 256, 2000, "qm9", 256, "train"), ("equiformer_equihnns", 8, 3000, "qm9", 256, "train"),
                     # (seed 3003: on 3002 the pooled (0,0) product of round 5 draws a ReLU input of the conv block within fp32
                     # rounding of zero -- gradients 1.5e-3 from float64 where seeds 3003-3005 sit at 1e-6..3e-6; round 4's
@@ -92,6 +93,7 @@ ORACLE_WORKLOADS = [("mhnnm", 32, 1000, "qm9", 256, "train"), ("egnn_equihnns", 
 # one does (hidden 256 at >= 256 molecules always has one within fp32 rounding of zero, train-mode BatchNorm amplifies it) it is
 # 1e-3 -- of one embedding table or one Linear, the others stay at 1e-6.  The tight check is against float64 (next test).
 GRAD_L2_BOUND = {("mhnnm", 32, "train"): 1.2e-2,                    # [3.8e-3]
+                 ("mhnnm", 256, "train"): 7e-3,                    # [2.1e-3]  BASELINE config 1 at its own size (round 5)
                  ("egnn_equihnns", 32, "train"): 1e-4,             # [1.2e-6]
                  ("egnn_equihnns", 256, "train"): 3e-3,            # [1.0e-3]  BASELINE config 2
                  ("equiformer_equihnns", 8, "train"): 1e-4,        # [3.2e-6]
