@@ -381,8 +381,13 @@ class FeedForward(nn.Module):
         self.project_out.init_zero_()                                               # :514-515
 
     def forward(self, x0):
-        h = _fan(self.prenorm.norm0(x0), self.project_in.w(0))[0]
-        return _fan(F.silu(h[..., self.mult * self.c:]), self.project_out.w(0))[0]
+        # only the SiLU half of project_in reaches the type-0 output (the other 4c columns gate the degree-1 features, :517-529):
+        # the product is formed for those columns alone (their weight gradient comes back zero-padded, as the reference's is)
+        w = self.project_in.w(0)[:, self.mult * self.c:]
+        if x0.is_cuda:
+            w = w.contiguous()
+        h = _fan(self.prenorm.norm0(x0), w)[0]
+        return _fan(F.silu(h), self.project_out.w(0))[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------
