@@ -37,17 +37,19 @@ struct BnPartials {
 template <bool BWD>
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_partial(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mask,
-             const float* __restrict__ save_mean, const float* __restrict__ save_rstd, int64_t R, int C, BnPartials P) {
+             const float* __restrict__ save_mean, const float* __restrict__ save_rstd, int64_t R, int C, BnPartials P,
+             const float* __restrict__ gamma, const float* __restrict__ beta, int relu) {
     __shared__ double s_a[16][BN_COLS], s_b[16][BN_COLS], s_n[16];
     const int l = threadIdx.x & 15, s = threadIdx.x >> 4;
     const int c = blockIdx.y * BN_COLS + 4 * l;
     const bool act = c < C;
     const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0}, n = 0;
-    float4 mu = f4_zero(), rs = f4_zero();
+    float4 mu = f4_zero(), rs = f4_zero(), ga = f4_zero(), be = f4_zero();
     if (BWD && act) {
         mu = *reinterpret_cast<const float4*>(save_mean + c);
         rs = *reinterpret_cast<const float4*>(save_rstd + c);
+        if (relu) { ga = *reinterpret_cast<const float4*>(gamma + c); be = *reinterpret_cast<const float4*>(beta + c); }
     }
 #pragma unroll 4
     for (int k = 0; k < BN_ROWS / 16; ++k) {
@@ -63,10 +65,17 @@ k_bn_partial(const float* __restrict__ x, const float* __restrict__ dy, const fl
             b[0] += m_ * ((double)v.x * v.x); b[1] += m_ * ((double)v.y * v.y);
             b[2] += m_ * ((double)v.z * v.z); b[3] += m_ * ((double)v.w * v.w);
         } else {
-            const float4 g = *reinterpret_cast<const float4*>(dy + i * C + c);
+            float4 g = *reinterpret_cast<const float4*>(dy + i * C + c);
+            const float xh0 = (v.x - mu.x) * rs.x, xh1 = (v.y - mu.y) * rs.y, xh2 = (v.z - mu.z) * rs.z, xh3 = (v.w - mu.w) * rs.w;
+            if (relu) {         // the ReLU behind the normalisation (mhnn.py:208-214): its gate recomputed from x
+                // (the forward's own expression, fmaf(x - mean, rstd * gamma, beta): the same bits decide both ways)
+                if (!(fmaf(v.x - mu.x, rs.x * ga.x, be.x) > 0.f)) g.x = 0.f;
+                if (!(fmaf(v.y - mu.y, rs.y * ga.y, be.y) > 0.f)) g.y = 0.f;
+                if (!(fmaf(v.z - mu.z, rs.z * ga.z, be.z) > 0.f)) g.z = 0.f;
+                if (!(fmaf(v.w - mu.w, rs.w * ga.w, be.w) > 0.f)) g.w = 0.f;
+            }
             a[0] += g.x; a[1] += g.y; a[2] += g.z; a[3] += g.w;
-            b[0] += (double)g.x * ((v.x - mu.x) * rs.x); b[1] += (double)g.y * ((v.y - mu.y) * rs.y);
-            b[2] += (double)g.z * ((v.z - mu.z) * rs.z); b[3] += (double)g.w * ((v.w - mu.w) * rs.w);
+            b[0] += (double)g.x * xh0; b[1] += (double)g.y * xh1; b[2] += (double)g.z * xh2; b[3] += (double)g.w * xh3;
         }
     }
 #pragma unroll
@@ -96,7 +105,7 @@ __global__ void __launch_bounds__(BN_THREADS)
 k_bn_apply_fwd(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                float* __restrict__ run_mean, float* __restrict__ run_var, int64_t* __restrict__ n_tracked, float momentum,
                float eps, int64_t R, int C, BnPartials P, float* __restrict__ y, float* __restrict__ save_mean,
-               float* __restrict__ save_rstd) {
+               float* __restrict__ save_rstd, int relu) {
     __shared__ float s_mean[256], s_scale[256], s_shift[256];
     const int cg = blockIdx.y * 256;
     {
@@ -142,16 +151,19 @@ k_bn_apply_fwd(const float* __restrict__ x, const float* __restrict__ gamma, con
         const int64_t i = r0 + k;
         if (i >= R) break;
         const float4 v = *reinterpret_cast<const float4*>(x + i * C + c);
-        *reinterpret_cast<float4*>(y + i * C + c) = make_float4(fmaf(v.x - mu.x, sc.x, sh.x), fmaf(v.y - mu.y, sc.y, sh.y),
-                                                                 fmaf(v.z - mu.z, sc.z, sh.z), fmaf(v.w - mu.w, sc.w, sh.w));
+        float4 o = make_float4(fmaf(v.x - mu.x, sc.x, sh.x), fmaf(v.y - mu.y, sc.y, sh.y), fmaf(v.z - mu.z, sc.z, sh.z),
+                               fmaf(v.w - mu.w, sc.w, sh.w));
+        if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *reinterpret_cast<float4*>(y + i * C + c) = o;
     }
 }
 
 __global__ void __launch_bounds__(BN_THREADS)
 k_bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ mask,
                const float* __restrict__ gamma, const float* __restrict__ save_mean, const float* __restrict__ save_rstd,
-               int64_t R, int C, BnPartials P, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float s_db[256], s_dg[256], s_mean[256], s_rstd[256], s_scale[256];
+               int64_t R, int C, BnPartials P, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+               const float* __restrict__ beta, int relu) {
+    __shared__ float s_db[256], s_dg[256], s_mean[256], s_rstd[256], s_scale[256], s_beta[256];
     __shared__ float s_inv_n;
     const int cg = blockIdx.y * 256;
     {
@@ -168,6 +180,7 @@ k_bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy, const 
             s_mean[threadIdx.x] = save_mean[c];
             s_rstd[threadIdx.x] = rstd;
             s_scale[threadIdx.x] = rstd * gamma[c];
+            s_beta[threadIdx.x] = relu ? beta[c] : 0.f;
             if (blockIdx.x == 0) { dgamma[c] = dg; dbeta[c] = db; }
         }
         if (threadIdx.x == 0) {
@@ -182,7 +195,7 @@ k_bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy, const 
     if (c >= C) return;
     const float4 mu = *reinterpret_cast<const float4*>(s_mean + 4 * l), rs = *reinterpret_cast<const float4*>(s_rstd + 4 * l),
                  sc = *reinterpret_cast<const float4*>(s_scale + 4 * l), db = *reinterpret_cast<const float4*>(s_db + 4 * l),
-                 dg = *reinterpret_cast<const float4*>(s_dg + 4 * l);
+                 dg = *reinterpret_cast<const float4*>(s_dg + 4 * l), be = *reinterpret_cast<const float4*>(s_beta + 4 * l);
     const float inv_n = s_inv_n;
     const int64_t r0 = (int64_t)blockIdx.x * BN_APPLY_ROWS;
 #pragma unroll 4
@@ -190,7 +203,14 @@ k_bn_apply_bwd(const float* __restrict__ x, const float* __restrict__ dy, const 
         const int64_t i = r0 + k;
         if (i >= R) break;
         const float m = (mask ? mask[i] : 1.0f) * inv_n;
-        const float4 v = *reinterpret_cast<const float4*>(x + i * C + c), g = *reinterpret_cast<const float4*>(dy + i * C + c);
+        const float4 v = *reinterpret_cast<const float4*>(x + i * C + c);
+        float4 g = *reinterpret_cast<const float4*>(dy + i * C + c);
+        if (relu) {
+            if (!(fmaf(v.x - mu.x, sc.x, be.x) > 0.f)) g.x = 0.f;
+            if (!(fmaf(v.y - mu.y, sc.y, be.y) > 0.f)) g.y = 0.f;
+            if (!(fmaf(v.z - mu.z, sc.z, be.z) > 0.f)) g.z = 0.f;
+            if (!(fmaf(v.w - mu.w, sc.w, be.w) > 0.f)) g.w = 0.f;
+        }
         float4 o;
         o.x = sc.x * (g.x - m * db.x - m * ((v.x - mu.x) * rs.x) * dg.x);
         o.y = sc.y * (g.y - m * db.y - m * ((v.y - mu.y) * rs.y) * dg.y);
@@ -227,7 +247,7 @@ extern "C" size_t hg_batch_norm_rows_workspace_bytes(int64_t R, int32_t C) {
 extern "C" int hg_batch_norm_rows_fwd(const float* x, const float* row_mask, const float* gamma, const float* beta,
                                       float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                       float eps, int64_t R, int32_t C, float* y, float* save_mean, float* save_rstd,
-                                      void* workspace, size_t workspace_bytes, void* stream_) {
+                                      int32_t relu, void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = bn_check(R, C);
     if (rc) return rc;
     if (R == 0) return EQH_OK;
@@ -237,18 +257,20 @@ extern "C" int hg_batch_norm_rows_fwd(const float* x, const float* row_mask, con
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const BnPartials P = bn_partials(workspace, R, C);
     hipLaunchKernelGGL(k_bn_partial<false>, dim3(P.chunks, (C + BN_COLS - 1) / BN_COLS), dim3(BN_THREADS), 0, stream, x,
-                       (const float*)nullptr, row_mask, (const float*)nullptr, (const float*)nullptr, R, (int)C, P);
+                       (const float*)nullptr, row_mask, (const float*)nullptr, (const float*)nullptr, R, (int)C, P,
+                       (const float*)nullptr, (const float*)nullptr, 0);
     EQH_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bn_apply_fwd, dim3((unsigned)((R + BN_APPLY_ROWS - 1) / BN_APPLY_ROWS), (C + 255) / 256), dim3(BN_THREADS),
                        0, stream, x, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, R, (int)C, P, y,
-                       save_mean, save_rstd);
+                       save_mean, save_rstd, (int)relu);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
 
 extern "C" int hg_batch_norm_rows_bwd(const float* x, const float* dy, const float* row_mask, const float* gamma,
                                       const float* save_mean, const float* save_rstd, int64_t R, int32_t C, float* dx,
-                                      float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream_) {
+                                      float* dgamma, float* dbeta, const float* beta, int32_t relu, void* workspace,
+                                      size_t workspace_bytes, void* stream_) {
     int rc = bn_check(R, C);
     if (rc) return rc;
     if (!dgamma || !dbeta) return EQH_ERR_ARG;
@@ -257,16 +279,16 @@ extern "C" int hg_batch_norm_rows_bwd(const float* x, const float* dy, const flo
         if (eqh_zero_async(dgamma, C, stream)) return EQH_ERR_LAUNCH;
         return eqh_zero_async(dbeta, C, stream);
     }
-    if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx) return EQH_ERR_ARG;
+    if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || (relu && !beta)) return EQH_ERR_ARG;
     if (!eqh_aligned16(x) || !eqh_aligned16(dy) || !eqh_aligned16(dx) || !eqh_aligned16(save_mean) || !eqh_aligned16(save_rstd))
         return EQH_ERR_ALIGN;
     if (!workspace || workspace_bytes < hg_batch_norm_rows_workspace_bytes(R, C) || ((uintptr_t)workspace & 7)) return EQH_ERR_ARG;
     const BnPartials P = bn_partials(workspace, R, C);
     hipLaunchKernelGGL(k_bn_partial<true>, dim3(P.chunks, (C + BN_COLS - 1) / BN_COLS), dim3(BN_THREADS), 0, stream, x, dy, row_mask,
-                       save_mean, save_rstd, R, (int)C, P);
+                       save_mean, save_rstd, R, (int)C, P, gamma, beta, (int)relu);
     EQH_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_bn_apply_bwd, dim3((unsigned)((R + BN_APPLY_ROWS - 1) / BN_APPLY_ROWS), (C + 255) / 256), dim3(BN_THREADS),
-                       0, stream, x, dy, row_mask, gamma, save_mean, save_rstd, R, (int)C, P, dx, dgamma, dbeta);
+                       0, stream, x, dy, row_mask, gamma, save_mean, save_rstd, R, (int)C, P, dx, dgamma, dbeta, beta, (int)relu);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }

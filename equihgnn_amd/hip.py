@@ -207,8 +207,9 @@ SIGNATURES = {
     "hg_gather_ln_reduce_bwd": (c_int32, [c_void_p] * 7 + [c_int64, c_int32, c_float] + [c_void_p] * 4
                                 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_batch_norm_rows_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "hg_batch_norm_rows_fwd": (c_int32, [c_void_p] * 7 + [c_float, c_float, c_int64, c_int32] + [c_void_p] * 4 + [c_size_t, c_void_p]),
-    "hg_batch_norm_rows_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32] + [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "hg_batch_norm_rows_fwd": (c_int32, [c_void_p] * 7 + [c_float, c_float, c_int64, c_int32] + [c_void_p] * 3 + [c_int32, c_void_p, c_size_t,
+                                                                                                              c_void_p]),
+    "hg_batch_norm_rows_bwd": (c_int32, [c_void_p] * 6 + [c_int64, c_int32] + [c_void_p] * 4 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_bias_relu_ln_bwd_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_bias_relu_ln_bwd": (c_int32, [c_void_p] * 4 + [c_int64, c_int32, c_float] + [c_void_p] * 4
                             + [c_int32, c_void_p, c_size_t, c_void_p]),

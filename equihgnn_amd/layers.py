@@ -235,13 +235,15 @@ def real_row_mask(data, like):
     return (data.batch < nb).to(like.dtype).unsqueeze(-1)
 
 
-def batch_norm_rows(bn: nn.BatchNorm1d, x, mask):
+def batch_norm_rows(bn: nn.BatchNorm1d, x, mask, relu: bool = False):
     """nn.BatchNorm1d over node rows (mhnn.py:182,206) whose TRAINING statistics count the real rows only:
-    with it a padded batch gives the real rows the same outputs, the parameters the same gradients and the
+    (``relu``: the ReLU mhnn.py:208-214 applies behind it, in the same launches) with it a padded batch gives the real rows the same outputs, the parameters the same gradients and the
     running buffers the same updates as the unpadded one, so the BatchNorm models can run under hipGraph
     replay too.  Everything stays on the device (the row count is a device scalar: it changes per batch)."""
-    if ops.batch_norm_rows_supported(x, bn):       # one launch each way (csrc/bn_rows.hip), masked or not
-        return ops.batch_norm_rows(x, mask, bn)
+    if ops.batch_norm_rows_supported(x, bn):       # two launches each way (csrc/bn_rows.hip), masked or not
+        return ops.batch_norm_rows(x, mask, bn, relu=relu)
+    if relu:
+        return torch.relu(batch_norm_rows(bn, x, mask))
     if mask is None or not bn.training or not bn.track_running_stats or bn.momentum is None:
         return bn(x)
     n = mask.sum()

@@ -115,11 +115,13 @@ class MHNNM(nn.Module):
         with _merged_scope(self.layers, x, e):      # the layers' weight-level products in one launch each way
             for i, layer in enumerate(self.layers):
                 x, e = layer(x, e, index)
-                x = batch_norm_rows(self.batch_norms[i], x, mask)
+                # (the ReLU behind the normalisation rides its launches, unless the pre-activation value is tapped)
+                fuse = taps is None and i != self.nlayer - 1 and isinstance(self.act, nn.ReLU)
+                x = batch_norm_rows(self.batch_norms[i], x, mask, relu=fuse)
                 if taps is not None:
                     taps[f"bn{i}"] = x
                 if i != self.nlayer - 1:  # no activation after the last layer, mhnn.py:208-214
-                    x, e = self.act(x), self.act(e)
+                    x, e = (x if fuse else self.act(x)), self.act(e)
                 x, e = self.dropout(x), self.dropout(e)
         return readout(self.mlp_out, x, index, taps, head)
 
@@ -292,11 +294,12 @@ class EGNNEquiHNNM(MHNNM):
         mask = real_row_mask(data, x)   # padded batch: BatchNorm statistics over the real atoms only
         for i, layer in enumerate(self.layers):
             x, e = layer(x, e, index)
-            x = batch_norm_rows(self.batch_norms[i], x, mask)
+            fuse = taps is None and i != self.nlayer - 1 and isinstance(self.act, nn.ReLU)
+            x = batch_norm_rows(self.batch_norms[i], x, mask, relu=fuse)
             if taps is not None:
                 taps[f"bn{i}"] = x
             if i != self.nlayer - 1:
-                x, e = self.act(x), self.act(e)
+                x, e = (x if fuse else self.act(x)), self.act(e)
             x, e = self.dropout(x), self.dropout(e)
         return readout(self.mlp_out, x, index, taps, head)
 

@@ -262,7 +262,7 @@ class _BatchNormRows(torch.autograd.Function):
     buffers updated in the same launch (hg_batch_norm_rows_*; csrc/bn_rows.hip)."""
 
     @staticmethod
-    def forward(ctx, x, mask, gamma, beta, running_mean, running_var, n_tracked, momentum, eps, acc_params):
+    def forward(ctx, x, mask, gamma, beta, running_mean, running_var, n_tracked, momentum, eps, acc_params, relu=False):
         _require_gpu(x, "batch_norm_rows")
         x, gamma, beta = _f32c(x), _f32c(gamma), _f32c(beta)
         R, C = x.shape
@@ -274,14 +274,15 @@ class _BatchNormRows(torch.autograd.Function):
         ws = _workspace(max(ws_bytes, 16), x.device)
         hip.check(L.hg_batch_norm_rows_fwd(_ptr(x), _ptr(m), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                            _ptr(n_tracked), float(momentum), float(eps), R, C, _ptr(y), _ptr(stats[0]),
-                                           _ptr(stats[1]), _ptr(ws), ws_bytes, _stream(x.device)), "hg_batch_norm_rows_fwd")
-        ctx.save_for_backward(x, m, gamma, stats)
-        ctx.acc = acc_params
+                                           _ptr(stats[1]), 1 if relu else 0, _ptr(ws), ws_bytes, _stream(x.device)),
+                  "hg_batch_norm_rows_fwd")
+        ctx.save_for_backward(x, m, gamma, stats, beta)
+        ctx.acc, ctx.relu = acc_params, bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, m, gamma, stats = ctx.saved_tensors
+        x, m, gamma, stats, beta = ctx.saved_tensors
         R, C = x.shape
         dy = _f32c(dy)
         dx = torch.empty_like(x)
@@ -290,18 +291,19 @@ class _BatchNormRows(torch.autograd.Function):
         ws_bytes = L.hg_batch_norm_rows_workspace_bytes(R, C)
         ws = _workspace(max(ws_bytes, 16), x.device)
         hip.check(L.hg_batch_norm_rows_bwd(_ptr(x), _ptr(dy), _ptr(m), _ptr(gamma), _ptr(stats[0]), _ptr(stats[1]), R, C,
-                                           _ptr(dx), _ptr(small[0]), _ptr(small[1]), _ptr(ws), ws_bytes, _stream(x.device)),
-                  "hg_batch_norm_rows_bwd")
+                                           _ptr(dx), _ptr(small[0]), _ptr(small[1]), _ptr(beta), 1 if ctx.relu else 0, _ptr(ws),
+                                           ws_bytes, _stream(x.device)), "hg_batch_norm_rows_bwd")
         dgam, dbet = _hand_out(list(small), [_acc_target(p) for p in ctx.acc])
-        return dx, None, dgam, dbet, None, None, None, None, None, None
+        return dx, None, dgam, dbet, None, None, None, None, None, None, None
 
 
-def batch_norm_rows(x, mask, bn):
+def batch_norm_rows(x, mask, bn, relu: bool = False):
     """Training-mode ``bn`` (nn.BatchNorm1d with running statistics) on 2-D fp32 rows ``x`` with the statistics over the rows
-    where ``mask`` [R, 1] is > 0 (None: all rows); running_mean / running_var / num_batches_tracked are updated in place."""
+    where ``mask`` [R, 1] is > 0 (None: all rows); running_mean / running_var / num_batches_tracked are updated in place.
+    ``relu``: relu(bn(x)) in the same launches."""
     _note_acc(bn.weight, bn.bias)
     return _BatchNormRows.apply(x, mask, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                                bn.momentum, bn.eps, (bn.weight, bn.bias))
+                                bn.momentum, bn.eps, (bn.weight, bn.bias), bool(relu))
 
 
 def batch_norm_rows_supported(x, bn) -> bool:

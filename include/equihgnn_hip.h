@@ -518,16 +518,17 @@ int hg_gather_ln_reduce_bwd(const float* h, const float* bias, const float* gamm
  * Two launches each way (float64 partial column sums over row chunks, then every workgroup sums the partials of its columns
  * in chunk order and writes its rows: bitwise reproducible, nothing atomic); save_mean / save_rstd [C] feed the backward,
  * which returns dx [R, C], dgamma, dbeta [C] (overwritten).  C % 4 == 0; workspace (8-byte aligned) of
- * hg_batch_norm_rows_workspace_bytes(R, C) for the partials.
+ * hg_batch_norm_rows_workspace_bytes(R, C) for the partials.  relu != 0: y = max(0, .) in the same pass (the activation
+ * mhnn.py:208-214 applies behind the normalisation); the backward then takes beta too and gates dy by the sign the forward saw.
  * ------------------------------------------------------------------------------------------- */
 size_t hg_batch_norm_rows_workspace_bytes(int64_t R, int32_t C);
 int hg_batch_norm_rows_fwd(const float* x, const float* row_mask, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
-                           int64_t R, int32_t C, float* y, float* save_mean, float* save_rstd, void* workspace,
+                           int64_t R, int32_t C, float* y, float* save_mean, float* save_rstd, int32_t relu, void* workspace,
                            size_t workspace_bytes, void* stream);
 int hg_batch_norm_rows_bwd(const float* x, const float* dy, const float* row_mask, const float* gamma,
                            const float* save_mean, const float* save_rstd, int64_t R, int32_t C, float* dx, float* dgamma,
-                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+                           float* dbeta, const float* beta, int32_t relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Plain LayerNorm over dense rows — nn.LayerNorm(dim) applied to node features at

@@ -1576,11 +1576,13 @@ def test_radial_weight_layout_is_the_permutation(lo, li, mid):
     assert torch.equal(w.grad, ref_g)
 
 
-@pytest.mark.parametrize("R,C,n_real", [(500, 64, None), (4736, 256, 4600), (37, 128, 20)])
-def test_batch_norm_rows_matches_torch(R, C, n_real):
+@pytest.mark.parametrize("relu", [False, True])
+@pytest.mark.parametrize("R,C,n_real", [(500, 64, None), (4736, 256, 4600), (37, 128, 20), (300, 320, 257)])
+def test_batch_norm_rows_matches_torch(R, C, n_real, relu):
     """hg_batch_norm_rows_fwd / _bwd: training-mode BatchNorm1d with the statistics over the first n_real rows (a padded
     batch) against nn.BatchNorm1d on those rows alone -- outputs of the real rows, running buffers, and the gradients of
-    x (real rows; padded rows get the gradient of an affine map), gamma and beta."""
+    x (real rows; padded rows get the gradient of an affine map), gamma and beta; with ``relu`` the activation behind the
+    normalisation in the same launches (mhnn.py:208-214)."""
     ops = _ops()
     g = torch.Generator().manual_seed(R + C)
     x = torch.randn(R, C, generator=g) * 2 + 0.5
@@ -1598,11 +1600,13 @@ def test_batch_norm_rows_matches_torch(R, C, n_real):
     bn_ref.train()
     xr = x[:nr].double().requires_grad_(True)
     y_ref = bn_ref(xr)                                  # ONE training-mode call: the running buffers move once
+    if relu:
+        y_ref = torch.relu(y_ref)
     (y_ref * w[:nr].double()).sum().backward()
     xd = x.to(DEV).requires_grad_(True)
     mask = None if n_real is None else (torch.arange(R) < nr).float()[:, None].to(DEV)
     assert ops.batch_norm_rows_supported(xd, bn)
-    y = ops.batch_norm_rows(xd, mask, bn)
+    y = ops.batch_norm_rows(xd, mask, bn, relu=relu)
     (y * w.to(DEV)).sum().backward()
     np.testing.assert_allclose(y[:nr].detach().cpu().numpy(), y_ref.detach().numpy(), atol=2e-5, rtol=1e-5)
     for name in ("running_mean", "running_var"):
