@@ -109,6 +109,11 @@ GRAD_L2_BOUND = {("mhnnm", 32, "train"): 1.2e-2,                    # [3.8e-3]
 @pytest.mark.parametrize("method,bs,seed,flavour,hidden,mode", ORACLE_WORKLOADS)
 def test_hip_model_matches_oracle_at_baseline_sizes(method, bs, seed, flavour, hidden, mode):
     from equihgnn_amd.batch import synth_batch
+    if method == "equiformer_equihnns" and bs >= 64 and hidden >= 256:
+        # the fp32 oracle keeps ~45 GB of per-edge radial weights for its backward pass at this size
+        import psutil
+        if psutil.virtual_memory().available < 128 * 2 ** 30:
+            pytest.skip("the CPU oracle of config 3 at its own size needs ~45 GB of host memory")
     from equihgnn_amd.registry import default_args
     torch.manual_seed(0)
     args = default_args(method=method, MLP_hidden=hidden, output_hidden=hidden // 2)
