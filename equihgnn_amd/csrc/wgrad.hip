@@ -193,7 +193,7 @@ k_wgrad(const float* __restrict__ dy, const float* __restrict__ x, int64_t K, in
 // rows through L1 -- same 141 us per 21-product batch; a main loop without clamps / masks / 64-bit multiplies --
 // 157 us.  The memory side alone takes 63 us of the 140, the MFMAs 86: they overlap poorly at two wavefronts
 // per SIMD, which is what the 64 KB LDS epilogue buffer allows.)
-constexpr int WG_MAX_BATCH = 32;
+constexpr int WG_MAX_BATCH = 64;     // (a WgradBatch is a by-value kernel argument of 64 x 56 bytes)
 struct WgradEntry {
     const float* dy;
     const float* x;
@@ -388,6 +388,130 @@ k_wgrad_batch_x3(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles,
     }
 }
 
+// ---- the WIDE form: ONE wavefront per SIMD owning a 64 x 128 tile (2 x 4 MFMA tiles, 128 accumulator registers), four
+// wavefronts = a 128 x 256 workgroup tile.  Six operand fragments are split for eight tile products (0.75 splits per product
+// against 1.0 of the 64 x 64 quadrants above, where the split VALU work equals the MFMA time), an operand row crosses L2 -> CU
+// 1.5 times per 128 x 256 outputs instead of twice per 128 x 128, no K-halves to merge.  The price is one wavefront per SIMD
+// (~380 registers): the four-stage register ring and the wavefront's own MFMAs are what hides the loads.
+struct WxStageW {
+    float a[2][8], b[4][8];
+};
+
+template <bool FULL>
+__device__ __forceinline__ void wxw_load(WxStageW& st, const float* __restrict__ ga, const float* __restrict__ gb, unsigned la,
+                                         unsigned lb, int64_t ldy, int64_t ldx, int rows_left, int kg) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool ok = FULL || (8 * kg + i < rows_left);
+        const int64_t ri = ok ? i : 0;
+        const unsigned la_ = ok ? la : (la - (unsigned)(8 * kg * ldy)), lb_ = ok ? lb : (lb - (unsigned)(8 * kg * ldx));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float va = (ga + ri * ldy + 32 * t)[FULL ? la : la_];
+            st.a[t][i] = ok ? va : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float vb = (gb + ri * ldx + 32 * t)[FULL ? lb : lb_];
+            st.b[t][i] = ok ? vb : 0.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_wgrad_batch_x3w(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits) {
+    const int groups = n_prod * splits;
+    const int xcd = blockIdx.x & 7, j_ = blockIdx.x >> 3;
+    const int group = xcd + 8 * (j_ / tiles), tile = j_ % tiles;
+    if (group >= groups) return;                                          // whole workgroup
+    const WgradEntry& en = b.e[group / splits];
+    const int chunk = group % splits;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int m = lane & 31, kg = lane >> 5;
+    const int o0 = 128 * (tile / tiles_i) + 64 * wi, i0 = 256 * (tile % tiles_i) + 128 * wj;
+    if (o0 >= O || i0 >= I) return;                                       // (whole wavefront; no barrier below)
+    int64_t kc = (en.K + splits - 1) / splits;
+    kc = (kc + 15) / 16 * 16;
+    const int64_t k_beg = (int64_t)chunk * kc;
+    int64_t k_end = k_beg + kc;
+    if (k_end > en.K) k_end = en.K;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ta][tb][i] = 0.f;
+    if (k_beg < k_end) {
+        const int64_t ldy = en.ldy, ldx = en.ldx;
+        const float* __restrict__ ga = en.dy + k_beg * ldy + o0;
+        const float* __restrict__ gb = en.x + k_beg * ldx + i0;
+        const unsigned la = (unsigned)(8 * kg * ldy + m), lb = (unsigned)(8 * kg * ldx + m);
+        auto consume = [&](const WxStageW& st) {
+            bf16x8 A[2][3];
+            wx_split(st.a[0], A[0]);
+            wx_split(st.a[1], A[1]);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+                bf16x8 B[3];
+                wx_split(st.b[tb], B);
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta) {
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][1], B[1], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[2], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][2], B[0], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[1], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][1], B[0], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ta][0], B[0], acc[ta][tb], 0, 0, 0);
+                }
+            }
+        };
+        const int n_full = (int)((k_end - k_beg) / 16), tail = (int)((k_end - k_beg) % 16);
+        WxStageW s0, s1, s2, s3;
+        auto fetch = [&](WxStageW& st, int step) {
+            if (step < n_full) wxw_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+        };
+        fetch(s0, 0);
+        fetch(s1, 1);
+        fetch(s2, 2);
+        for (int step = 0; step < n_full; step += 4) {
+            fetch(s3, step + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s0, step + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 1 < n_full) consume(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s1, step + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 2 < n_full) consume(s2);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(s2, step + 6);
+            __builtin_amdgcn_sched_barrier(0);
+            if (step + 3 < n_full) consume(s3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tail) {
+            wxw_load<false>(s0, ga + (int64_t)n_full * 16 * ldy, gb + (int64_t)n_full * 16 * ldx, la, lb, ldy, ldx, tail, kg);
+            consume(s0);
+        }
+    }
+    // accumulator register e of tile (ta, tb): row 32 ta + (e & 3) + 8 (e >> 2) + 4 kg, column 32 tb + m of the wavefront's tile
+    float* __restrict__ out = en.slab + ((int64_t)chunk * O + o0) * I + i0;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = 32 * ta + (e & 3) + 8 * (e >> 2) + 4 * kg, col = 32 * tb + m;
+                out[(int64_t)row * I + col] = en.alpha * acc[ta][tb][e];
+            }
+}
+
 // chunks of K: enough workgroups to fill the chip, rows per chunk a whole number of register stages
 inline void plan(int64_t K, int O, int I, int* chunks, int64_t* k_chunk) {
     const int tiles = (O / 64) * (I / 64);
@@ -446,12 +570,32 @@ extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t 
 
 /* count products of one shape in one launch: dw[i] (+)= alpha[i] * dy[i].T @ x[i].  Entries that share a
  * destination must be adjacent (they are summed in array order by one reduction); the workspace holds
- * count * 3 slabs of O x I floats.  ld_dy / ld_x (NULL: O / I): row strides of the operands, so that column blocks of
+ * count * (chunks of K) slabs of O x I floats (hg_wgrad_batch_workspace_bytes).  ld_dy / ld_x (NULL: O / I): row strides of the operands, so that column blocks of
  * wider matrices (the two halves of a [rows x 2 C] hidden activation) join a batch of [C x C] products. */
+// A launch takes at most WG_MAX_BATCH products; a longer list is dealt out evenly over the launches it needs.
+static inline int wg_per_launch(int32_t count) {
+    const int n_launch = (count + WG_MAX_BATCH - 1) / WG_MAX_BATCH;
+    return n_launch > 0 ? (count + n_launch - 1) / n_launch : 1;
+}
+// The 128 x 256 workgroup tiles (one wavefront per SIMD) where a launch fills the chip with at most five chunks of K per product
+// (measured: mhnnm's launch 174.6 -> 135.3 us; the 21 products of the BASELINE egnn_equihnns step would need 6 chunks of 49
+// steps each and gain nothing, 100.0 vs 100.8 us: they keep the 128 x 128 tiles).  EQH_WGRAD_WIDE=0 / =1 force either.
+static inline bool wg_wide(int32_t per_launch, int32_t O, int32_t I) {
+    static const int mode = [] { const char* e = std::getenv("EQH_WGRAD_WIDE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (mode == 0 || (O % 128) || (I % 256)) return false;
+    if (mode == 1) return true;
+    return (int64_t)(O / 128) * (I / 256) * per_launch * 5 >= 256;
+}
 // chunks of K per product of a batched launch: three where that fills the chip (21 products x four 128 x 128 tiles), more for
 // a few large products (the [2176 x 4.7 k] . [4.7 k x 256] gradient of the EGNN's first edge Linear alone: 34 tiles x 8)
 static inline int wg_batch_splits(int32_t count, int32_t O, int32_t I) {
-    const int64_t tiles = (int64_t)((O + 127) / 128) * ((I + 127) / 128) * count;
+    const int per = wg_per_launch(count);
+    if (wg_wide(per, O, I)) {        // one workgroup per CU: as many chunks of K as fit 256 workgroups
+        const int64_t t = (int64_t)(O / 128) * (I / 256) * per;
+        int64_t s = 256 / (t > 0 ? t : 1);
+        return (int)(s < 1 ? 1 : (s > 8 ? 8 : s));
+    }
+    const int64_t tiles = (int64_t)((O + 127) / 128) * ((I + 127) / 128) * per;
     if (tiles * 3 >= 200) return 3;
     int64_t s = (256 + tiles - 1) / tiles;
     return (int)(s < 3 ? 3 : (s > 8 ? 8 : s));
@@ -476,9 +620,13 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
     const int tiles_i = I / 64, tiles = (O / 64) * tiles_i;
     const size_t slab_elems = (size_t)O * I;
     float* ws = static_cast<float*>(workspace);
-    for (int i0 = 0; i0 < count; i0 += WG_MAX_BATCH) {
+    const int per = wg_per_launch(count);
+    static const bool debug = std::getenv("EQH_WGRAD_DEBUG") != nullptr;
+    if (debug) fprintf(stderr, "wgrad batch: %d products of %d x %d, %d per launch, %s tiles, %d chunks of K\n", (int)count, (int)O, (int)I,
+                       per, wg_wide(per, O, I) ? "128 x 256" : "128 x 128", SPLITS);
+    for (int i0 = 0; i0 < count; i0 += per) {
         WgradBatch b;
-        const int m = (count - i0 < WG_MAX_BATCH) ? count - i0 : WG_MAX_BATCH;
+        const int m = (count - i0 < per) ? count - i0 : per;
         for (int i = 0; i < m; ++i) {
             const int j = i0 + i;
             if (K[j] <= 0 || !dy[j] || !x[j] || !dw[j] || ldw[j] < I || (ldw[j] & 3)) return EQH_ERR_ARG;
@@ -492,6 +640,11 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
         if (use_f32) {
             hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
                                tiles, SPLITS);
+        } else if (wg_wide(per, O, I)) {
+            const int t_i = I / 256, t_all = (O / 128) * t_i;
+            const int groups = m * SPLITS;
+            hipLaunchKernelGGL(k_wgrad_batch_x3w, dim3(8 * ((groups + 7) / 8) * t_all), dim3(256), 0, stream, b, m, (int)O, (int)I,
+                               t_i, t_all, SPLITS);
         } else {
             const int t_i = (I + 127) / 128, t_all = ((O + 127) / 128) * t_i;
             const int groups = m * SPLITS;
