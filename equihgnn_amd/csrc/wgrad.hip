@@ -274,7 +274,7 @@ __device__ __forceinline__ void wx_split(const float (&v)[8], bf16x8 (&p)[3]) {
 }
 
 __global__ void __launch_bounds__(WX_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_wgrad_batch_x3(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits) {
+k_wgrad_batch_x3(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits, int use_buf) {
     __shared__ __attribute__((aligned(16))) float s_acc[4][64 * 64];      // the second K-half's quadrants
     // Work unit = (product, chunk of K, 128 x 128 tile).  The tiles of one (product, chunk) read the same operand rows: they go
     // to ONE XCD (blocks are dealt round-robin over the eight XCDs: b and b + 8 share one -- speed only, nothing depends on
@@ -333,8 +333,27 @@ k_wgrad_batch_x3(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles,
         // the ragged last step with its rows masked
         const int n_full = (int)((k_end - k_beg) / 16), tail = (int)((k_end - k_beg) % 16);
         WxStage s0, s1, s2, s3;
+        // whole steps through buffer loads (scalar row offsets: see k_wgrad_batch_x3w)
+        const bool buf_ok = use_buf && en.K * ldy < ((int64_t)1 << 29) && en.K * ldx < ((int64_t)1 << 29);
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)en.dy, 0, buf_ok ? (int)(en.K * ldy * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)en.x, 0, buf_ok ? (int)(en.K * ldx * 4) : 0, 0x00020000);
+        const unsigned va = 4u * la, vb = 4u * lb;
+        const unsigned ldyb = (unsigned)(4 * ldy), ldxb = (unsigned)(4 * ldx);
+        const unsigned sa0 = (unsigned)((k_beg * ldy + o0) * 4), sb0 = (unsigned)((k_beg * ldx + i0) * 4);
         auto fetch = [&](WxStage& st, int step) {
-            if (step < n_full) wx_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+            if (step >= n_full) return;
+            if (!buf_ok) {
+                wx_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+                return;
+            }
+            const unsigned sa = sa0 + (unsigned)step * 16u * ldyb, sb = sb0 + (unsigned)step * 16u * ldxb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    st.a[t][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + 128u * t, sa + (unsigned)i * ldyb, 0));
+                    st.b[t][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + 128u * t, sb + (unsigned)i * ldxb, 0));
+                }
         };
         fetch(s0, 0);
         fetch(s1, 1);
@@ -419,7 +438,7 @@ __device__ __forceinline__ void wxw_load(WxStageW& st, const float* __restrict__
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_wgrad_batch_x3w(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits) {
+k_wgrad_batch_x3w(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles, int splits, int use_buf) {
     const int groups = n_prod * splits;
     const int xcd = blockIdx.x & 7, j_ = blockIdx.x >> 3;
     const int group = xcd + 8 * (j_ / tiles), tile = j_ % tiles;
@@ -449,6 +468,7 @@ k_wgrad_batch_x3w(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles
         const float* __restrict__ ga = en.dy + k_beg * ldy + o0;
         const float* __restrict__ gb = en.x + k_beg * ldx + i0;
         const unsigned la = (unsigned)(8 * kg * ldy + m), lb = (unsigned)(8 * kg * ldx + m);
+        const bool buf_ok = use_buf && en.K * ldy < ((int64_t)1 << 29) && en.K * ldx < ((int64_t)1 << 29);   // byte offsets below 2 GB
         auto consume = [&](const WxStageW& st) {
             bf16x8 A[2][3];
             wx_split(st.a[0], A[0]);
@@ -470,8 +490,30 @@ k_wgrad_batch_x3w(WgradBatch b, int n_prod, int O, int I, int tiles_i, int tiles
         };
         const int n_full = (int)((k_end - k_beg) / 16), tail = (int)((k_end - k_beg) % 16);
         WxStageW s0, s1, s2, s3;
+        // Whole steps through BUFFER loads: the row of a load is a scalar offset (an SGPR operand), the lane's part one VGPR for
+        // the whole kernel -- no vector address arithmetic (with 64-bit global addresses it was ~100 of a step's ~400 VALU
+        // instructions, and the VALU issue is what bounds this kernel).  Operands of 4 GB and more keep the global loads.
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)en.dy, 0, buf_ok ? (int)(en.K * ldy * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)en.x, 0, buf_ok ? (int)(en.K * ldx * 4) : 0, 0x00020000);
+        const unsigned va = 4u * la, vb = 4u * lb;
+        const unsigned ldyb = (unsigned)(4 * ldy), ldxb = (unsigned)(4 * ldx);
+        const unsigned sa0 = (unsigned)((k_beg * ldy + o0) * 4), sb0 = (unsigned)((k_beg * ldx + i0) * 4);
         auto fetch = [&](WxStageW& st, int step) {
-            if (step < n_full) wxw_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+            if (step >= n_full) return;
+            if (!buf_ok) {
+                wxw_load<true>(st, ga + (int64_t)step * 16 * ldy, gb + (int64_t)step * 16 * ldx, la, lb, ldy, ldx, 16, kg);
+                return;
+            }
+            const unsigned sa = sa0 + (unsigned)step * 16u * ldyb, sb = sb0 + (unsigned)step * 16u * ldxb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    st.a[t][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ra, va + 128u * t, sa + (unsigned)i * ldyb, 0));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    st.b[t][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, vb + 128u * t, sb + (unsigned)i * ldxb, 0));
+            }
         };
         fetch(s0, 0);
         fetch(s1, 1);
@@ -637,6 +679,8 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
         }
         // round 5: the bf16 x 3 kernel (128 x 128 workgroup tiles); EQH_WGRAD_F32=1 keeps the fp32-MFMA kernel for same-box A/B runs
         static const bool use_f32 = [] { const char* e = std::getenv("EQH_WGRAD_F32"); return e && e[0] == '1'; }();
+        // (EQH_WGRAD_GLOBAL=1: 64-bit global loads instead of buffer loads, for same-box A/B runs)
+        static const int use_buf = [] { const char* e = std::getenv("EQH_WGRAD_GLOBAL"); return (e && e[0] == '1') ? 0 : 1; }();
         if (use_f32) {
             hipLaunchKernelGGL(k_wgrad_batch, dim3(tiles * SPLITS, m), dim3(THREADS), 0, stream, b, (int)O, (int)I, tiles_i,
                                tiles, SPLITS);
@@ -644,12 +688,12 @@ extern "C" int hg_wgrad_batch_f32(int32_t count, const float* const* dy, const f
             const int t_i = I / 256, t_all = (O / 128) * t_i;
             const int groups = m * SPLITS;
             hipLaunchKernelGGL(k_wgrad_batch_x3w, dim3(8 * ((groups + 7) / 8) * t_all), dim3(256), 0, stream, b, m, (int)O, (int)I,
-                               t_i, t_all, SPLITS);
+                               t_i, t_all, SPLITS, use_buf);
         } else {
             const int t_i = (I + 127) / 128, t_all = ((O + 127) / 128) * t_i;
             const int groups = m * SPLITS;
             hipLaunchKernelGGL(k_wgrad_batch_x3, dim3(8 * ((groups + 7) / 8) * t_all), dim3(WX_THREADS), 0, stream, b, m, (int)O,
-                               (int)I, t_i, t_all, SPLITS);
+                               (int)I, t_i, t_all, SPLITS, use_buf);
         }
         EQH_CHECK_LAUNCH();
     }
