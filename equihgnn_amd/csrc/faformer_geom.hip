@@ -374,8 +374,19 @@ k_elw_fwd(const float* __restrict__ W, int64_t ldw, const float* __restrict__ b,
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < H * de) {
         const int hh = t / de, j = t - hh * de;
+        // (514 threads in all: each sums deh rows.  Sixteen loads in flight per thread -- one at a time the 128-deep chain of
+        // L2 round trips took 50 us per call; the products are summed in the same order)
+        const float* __restrict__ wp = W + (int64_t)(hh * deh) * ldw + j;
         float acc = 0.f;
-        for (int d = 0; d < deh; ++d) acc = fmaf(we[d], W[(int64_t)(hh * deh + d) * ldw + j], acc);
+        int d = 0;
+        for (; d + 16 <= deh; d += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = wp[(int64_t)(d + q) * ldw];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc = fmaf(we[d + q], v[q], acc);
+        }
+        for (; d < deh; ++d) acc = fmaf(we[d], wp[(int64_t)d * ldw], acc);
         u[t] = acc;
     } else if (t < H * de + H) {
         const int hh = t - H * de;
