@@ -49,6 +49,37 @@ struct SmBatch {
 __device__ __forceinline__ void sm_load(float (*dst)[SM_LD], const float* __restrict__ src, int64_t rs, int64_t cs, int r0,
                                         int c0, int R, int C) {
     const bool al = ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    // whole tiles (the merged [C x C] weights): all of a thread's eight float4 loads in flight before the first LDS store --
+    // one at a time the loop below is a chain of eight L2 round trips per operand (13 -> 8 us per launch at the BASELINE batch)
+    constexpr int PER = SM_T * (SM_KC / 4) / 256;
+    if (cs == 1 && al && (rs & 3) == 0 && (c0 & 3) == 0 && r0 + SM_T <= R && c0 + SM_KC <= C) {
+        float4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e / (SM_KC / 4), c = (e % (SM_KC / 4)) * 4;
+            v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(r0 + r) * rs + (c0 + c));
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + 256 * u, r = e / (SM_KC / 4), c = (e % (SM_KC / 4)) * 4;
+            dst[r][c] = v[u].x; dst[r][c + 1] = v[u].y; dst[r][c + 2] = v[u].z; dst[r][c + 3] = v[u].w;
+        }
+        return;
+    }
+    if (rs == 1 && al && (cs & 3) == 0 && (r0 & 3) == 0 && r0 + SM_T <= R && c0 + SM_KC <= C) {
+        float4 v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + 256 * u, r = (e % (SM_T / 4)) * 4, c = e / (SM_T / 4);
+            v[u] = *reinterpret_cast<const float4*>(src + (int64_t)(c0 + c) * cs + (r0 + r));
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int e = threadIdx.x + 256 * u, r = (e % (SM_T / 4)) * 4, c = e / (SM_T / 4);
+            dst[r][c] = v[u].x; dst[r + 1][c] = v[u].y; dst[r + 2][c] = v[u].z; dst[r + 3][c] = v[u].w;
+        }
+        return;
+    }
     if (cs == 1 && al && (rs & 3) == 0 && (c0 & 3) == 0) {              // contiguous along k
         for (int e = threadIdx.x; e < SM_T * (SM_KC / 4); e += 256) {
             const int r = e / (SM_KC / 4), c = (e % (SM_KC / 4)) * 4;
