@@ -250,11 +250,8 @@ class MolStore:
                          e_order=t((PM,), torch.int64), batch=t((PN,), torch.int64), y=t((PB,), torch.float32))
         a = hip.HbCollate()
         a.B, a.n_mols, a.idx = B, len(self), idx.ctypes.data
-        for name in ("node_off", "he_off", "inc_off", "x", "pos", "v", "e", "edge_attr", "e_order", "y"):
-            arr = getattr(self, name)
-            if not arr.flags.c_contiguous:
-                raise ValueError(f"MolStore.{name} must be C-contiguous")
-            setattr(a, name, arr.ctypes.data)
+        for name, ptr in self._checked_pointers().items():
+            setattr(a, name, ptr)
         a.PN, a.PM, a.PZ, a.padded = PN, PM, PZ, 0 if pad_to is None else 1
         shapes = dict(x=(PN, 9), pos=(PN, 3), edge_index0=(PZ,), edge_index1=(PZ,), edge_attr=(PM, 1), n_e=(PB,), e_order=(PM,),
                       batch=(PN,), y=(PB,))
@@ -267,13 +264,43 @@ class MolStore:
         counts = np.zeros(3, dtype=np.int64)
         a.out_counts = counts.ctypes.data
         rc = hip.lib().hb_collate(ctypes.byref(a))
-        if rc == -1 and pad_to is not None:       # EQH_ERR_ARG: the extents do not fit
+        if rc == -3 and pad_to is not None:       # EQH_ERR_RANGE: the extents do not fit (indices were checked above)
             raise ValueError("collate: pad_to must exceed the batch (nodes and hyperedges strictly)")
         hip.check(rc, "hb_collate")
         if pad_to is not None:
             out.num_real_graphs = B
         out.num_nodes, out.num_hyperedges, out.num_graphs = PN, PM, PB
         return out
+
+    _ARRAYS = ("node_off", "he_off", "inc_off", "x", "pos", "v", "e", "edge_attr", "e_order", "y")
+
+    def _checked_pointers(self) -> dict:
+        """Addresses of the store's arrays for ``hb_collate``, which memcpy's whole rows by them: a store whose arrays have
+        another dtype, width or length (a processed file with a different feature layout re-seated into a MolStore by hand)
+        must fail HERE, not read the wrong rows or run past the end.  Checked once per set of array objects."""
+        key = tuple(id(getattr(self, n)) for n in self._ARRAYS)
+        cached = getattr(self, "_ptr_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        n_mols = len(self)
+        for name in ("node_off", "he_off", "inc_off"):
+            arr = getattr(self, name)
+            if arr.dtype != np.int64 or arr.shape != (n_mols + 1,) or not arr.flags.c_contiguous:
+                raise ValueError(f"MolStore.{name} must be a C-contiguous int64 array of {n_mols + 1} offsets")
+        N, M, Z = int(self.node_off[-1]), int(self.he_off[-1]), int(self.inc_off[-1])
+        want = dict(x=(np.int64, (N, 9)), pos=(np.float32, (N, 3)), v=(np.int64, (Z,)), e=(np.int64, (Z,)),
+                    edge_attr=(np.int64, (M, 1)), e_order=(np.int64, (M,)), y=(np.float32, (n_mols,)))
+        ptrs = {}
+        for name in self._ARRAYS:
+            arr = getattr(self, name)
+            if name in want:
+                dt, shape = want[name]
+                if arr.dtype != dt or tuple(arr.shape) != shape or not arr.flags.c_contiguous:
+                    raise ValueError(f"MolStore.{name} must be a C-contiguous {np.dtype(dt).name} array of shape {shape}, got "
+                                     f"{arr.dtype} {tuple(arr.shape)}{'' if arr.flags.c_contiguous else ' (strided)'}")
+            ptrs[name] = arr.ctypes.data if arr.size else None
+        self._ptr_cache = (key, ptrs)
+        return ptrs
 
     def collate_numpy(self, idx, pad_to: Optional[tuple] = None, out: Optional["HBatch"] = None) -> "HBatch":
         """``collate`` by numpy gathers driven by cumsum offsets (rounds 2-4's implementation; the restatement
@@ -439,11 +466,13 @@ def shard_indices(n_items: int, rank: int, world_size: int, seed: int, epoch: in
     """DistributedSampler semantics (the Lightning default the reference relies on,
     main.py:271-283): a shared shuffled permutation, padded to a multiple of the world
     size, strided by rank."""
-    if shuffle:
-        g = np.random.default_rng(seed + epoch)
-        perm = g.permutation(n_items).tolist()
-    else:
-        perm = list(range(n_items))
+    return shard_permutation(n_items, world_size, seed, epoch, shuffle)[rank::world_size].tolist()
+
+
+def shard_permutation(n_items: int, world_size: int, seed: int, epoch: int = 0, shuffle: bool = True) -> np.ndarray:
+    """The epoch's shared permutation, padded to a multiple of the world size: rank r's shard is ``[r::world_size]``
+    (every rank can therefore see what every other rank will draw -- ``fit.BucketedLoader.plan``)."""
+    perm = np.random.default_rng(seed + epoch).permutation(n_items) if shuffle else np.arange(n_items)
     total = -(-n_items // world_size) * world_size
-    perm += perm[: total - n_items]
-    return perm[rank:total:world_size]
+    reps = -(-total // max(n_items, 1))
+    return np.concatenate([perm] * reps)[:total] if total > n_items else perm

@@ -9,12 +9,8 @@
 #include "common.h"
 
 extern "C" int hb_collate(const HbCollate* q) {
-    if (!q || q->B < 0 || !q->idx) return EQH_ERR_ARG;
-    const void* need[] = {q->node_off, q->he_off, q->inc_off, q->x, q->pos, q->v, q->e, q->edge_attr, q->e_order, q->y, q->out_x,
-                          q->out_pos, q->out_edge_index0, q->out_edge_index1, q->out_edge_attr, q->out_n_e, q->out_e_order,
-                          q->out_batch, q->out_y, q->out_counts};
-    for (const void* p : need)
-        if (!p) return EQH_ERR_ARG;
+    if (!q || q->B < 0 || (q->B > 0 && !q->idx) || !q->out_counts) return EQH_ERR_ARG;
+    if (q->B > 0 && (!q->node_off || !q->he_off || !q->inc_off)) return EQH_ERR_ARG;
     const int64_t B = q->B;
     int64_t N = 0, M = 0, Z = 0;
     for (int64_t b = 0; b < B; ++b) {
@@ -26,22 +22,37 @@ extern "C" int hb_collate(const HbCollate* q) {
     }
     q->out_counts[0] = N; q->out_counts[1] = M; q->out_counts[2] = Z;
     const int64_t PN = q->padded ? q->PN : N, PM = q->padded ? q->PM : M, PZ = q->padded ? q->PZ : Z;
-    if (q->padded && (PN <= N || PM <= M || PZ < Z)) return EQH_ERR_ARG;   // the padding molecule needs a node and a hyperedge
+    // the padding molecule needs a node and a hyperedge of its own: extents that do not fit are a RANGE error (the Python
+    // wrapper's "pad_to must exceed the batch"), distinct from a missing pointer
+    if (q->padded && (PN <= N || PM <= M || PZ < Z)) return EQH_ERR_RANGE;
+    // an array may be NULL exactly when its extent is zero (a zero-size torch tensor's data_ptr() is 0: an unpadded batch of
+    // molecules without incidences, or of no molecules at all)
+    const int64_t PB = B + (q->padded ? 1 : 0);
+    const struct { const void* p; int64_t extent; } need[] = {
+        {q->x, N}, {q->pos, N}, {q->v, Z}, {q->e, Z}, {q->edge_attr, M}, {q->e_order, M}, {q->y, B},
+        {q->out_x, PN}, {q->out_pos, PN}, {q->out_batch, PN}, {q->out_edge_index0, PZ}, {q->out_edge_index1, PZ},
+        {q->out_edge_attr, PM}, {q->out_e_order, PM}, {q->out_n_e, PB}, {q->out_y, PB}};
+    for (const auto& a : need)
+        if (!a.p && a.extent > 0) return EQH_ERR_ARG;
     int64_t n0 = 0, h0 = 0, z0 = 0;
     for (int64_t b = 0; b < B; ++b) {
         const int64_t m = q->idx[b];
         const int64_t ns = q->node_off[m], n = q->node_off[m + 1] - ns;
         const int64_t hs = q->he_off[m], h = q->he_off[m + 1] - hs;
         const int64_t zs = q->inc_off[m], z = q->inc_off[m + 1] - zs;
-        std::memcpy(q->out_x + n0 * 9, q->x + ns * 9, (size_t)n * 9 * sizeof(int64_t));
-        std::memcpy(q->out_pos + n0 * 3, q->pos + ns * 3, (size_t)n * 3 * sizeof(float));
+        if (n) {
+            std::memcpy(q->out_x + n0 * 9, q->x + ns * 9, (size_t)n * 9 * sizeof(int64_t));
+            std::memcpy(q->out_pos + n0 * 3, q->pos + ns * 3, (size_t)n * 3 * sizeof(float));
+        }
         for (int64_t i = 0; i < n; ++i) q->out_batch[n0 + i] = b;
         for (int64_t i = 0; i < z; ++i) {
             q->out_edge_index0[z0 + i] = q->v[zs + i] + n0;
             q->out_edge_index1[z0 + i] = q->e[zs + i] + h0;
         }
-        std::memcpy(q->out_edge_attr + h0, q->edge_attr + hs, (size_t)h * sizeof(int64_t));
-        std::memcpy(q->out_e_order + h0, q->e_order + hs, (size_t)h * sizeof(int64_t));
+        if (h) {
+            std::memcpy(q->out_edge_attr + h0, q->edge_attr + hs, (size_t)h * sizeof(int64_t));
+            std::memcpy(q->out_e_order + h0, q->e_order + hs, (size_t)h * sizeof(int64_t));
+        }
         q->out_n_e[b] = h;
         q->out_y[b] = q->y[m];
         n0 += n; h0 += h; z0 += z;

@@ -49,6 +49,15 @@ __host__ __device__ static inline uint32_t drop_threshold(float p) {
     t16 = t16 < 1 ? 1 : (t16 > 65535 ? 65535 : t16);
     return (uint32_t)t16 << 16;
 }
+// Host side: the scale of the kept elements.  1 / (1 - p) as torch.nn.functional.dropout -- except at the ends of the range
+// the 16-bit decision cannot represent: p >= 1 drops everything (nn.Dropout(p=1) returns zeros; the 2^-16 of the elements the
+// clamped threshold still keeps are multiplied by 0, not by 1 / 0), and a p whose threshold was clamped to 65535 / 65536
+// rescales by the REALISED keep probability 2^-16, so the expectation stays that of the input.
+__host__ __device__ static inline float drop_inv_keep(float p) {
+    if (!(p > 0.f)) return 1.f;
+    if (p >= 1.f) return 0.f;
+    return ((double)p * 65536.0 + 0.5 >= 65536.0) ? 65536.f : 1.0f / (1.0f - p);
+}
 // keep-scale of element i: 0 (dropped) or 1 / (1 - p); threshold = drop_threshold(p)
 __device__ __forceinline__ float keep_scale(const DropKey& key, uint64_t i, uint32_t threshold, float inv_keep) {
     const uint32_t h = drop_hash(key, i >> 1);

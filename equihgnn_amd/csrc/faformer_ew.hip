@@ -210,7 +210,7 @@ extern "C" int faf_swiglu_dropout_fwd(const float* pre, int64_t R, int32_t H, fl
     if (!eqh_aligned16(pre) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_swiglu_drop_fwd, dim3(eqh_grid_for(R * (H / 4), 256, 8192)), dim3(256), 0, stream, pre, R, (int)H,
-                       seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+                       seed, ew_threshold(p), drop_inv_keep(p), out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -224,7 +224,7 @@ extern "C" int faf_swiglu_dropout_bwd(const float* pre, const float* dout, int64
     if (!eqh_aligned16(pre) || !eqh_aligned16(dout) || !eqh_aligned16(dpre)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_swiglu_drop_bwd, dim3(eqh_grid_for(R * (H / 4), 256, 8192)), dim3(256), 0, stream, pre, dout, R,
-                       (int)H, seed, ew_threshold(p), 1.0f / (1.0f - p), dpre);
+                       (int)H, seed, ew_threshold(p), drop_inv_keep(p), dpre);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -239,10 +239,10 @@ extern "C" int faf_dropout_mean_fwd(const float* x, int64_t R, int32_t F, int32_
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (F == 8)
         hipLaunchKernelGGL(k_drop_mean_fwd<8>, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
-                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+                           (int)C, seed, ew_threshold(p), drop_inv_keep(p), out);
     else
         hipLaunchKernelGGL(k_drop_mean_fwd<0>, dim3(eqh_grid_for(R * (C / 4), 256, 8192)), dim3(256), 0, stream, x, R, (int)F,
-                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+                           (int)C, seed, ew_threshold(p), drop_inv_keep(p), out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -254,7 +254,7 @@ extern "C" int faf_dropout_add(const float* x, const float* res, int64_t n, floa
     if (!x || !out || (p > 0.f && !seed)) return EQH_ERR_ARG;
     if (!eqh_aligned16(x) || !eqh_aligned16(res) || !eqh_aligned16(out)) return EQH_ERR_ALIGN;
     hipLaunchKernelGGL(k_dropout_add, dim3(eqh_grid_for(n / 4, 256, 8192)), dim3(256), 0, static_cast<hipStream_t>(stream_), x,
-                       res, n / 4, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+                       res, n / 4, seed, ew_threshold(p), drop_inv_keep(p), out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -275,10 +275,10 @@ extern "C" int faf_dropout_mean_bwd(const float* dout, int64_t R, int32_t F, int
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     if (dm_f8(F, C))
         hipLaunchKernelGGL(k_drop_mean_bwd_f8c256<false>, dim3(eqh_grid_for(R, 4, 8192)), dim3(256), 0, stream, dout, R, seed,
-                           ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
+                           ew_threshold(p), drop_inv_keep(p), dx, nullptr);
     else
         hipLaunchKernelGGL(k_drop_mean_bwd<false>, dim3(eqh_grid_for(R * F * (C / 4), 256, 8192)), dim3(256), 0, stream, dout, R,
-                           (int)F, (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), dx, nullptr);
+                           (int)F, (int)C, seed, ew_threshold(p), drop_inv_keep(p), dx, nullptr);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -308,10 +308,10 @@ extern "C" int faf_dropout_mean_bwd_colsum(const float* dout, int64_t R, int32_t
     float* slab = static_cast<float*>(workspace);
     if (dm_f8(F, C))
         hipLaunchKernelGGL(k_drop_mean_bwd_f8c256<true>, dim3(blocks), dim3(256), 0, stream, dout, R, seed, ew_threshold(p),
-                           1.0f / (1.0f - p), dx, slab);
+                           drop_inv_keep(p), dx, slab);
     else
         hipLaunchKernelGGL(k_drop_mean_bwd<true>, dim3(blocks), dim3(256), 0, stream, dout, R, (int)F, (int)C, seed,
-                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab);
+                           ew_threshold(p), drop_inv_keep(p), dx, slab);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs_async(slab, blocks, C, colsum, stream, accumulate ? 1 : 0);
 }
@@ -698,7 +698,7 @@ extern "C" int faf_frame_hidden_fwd(const float* y, const float* w3, const float
     if ((reinterpret_cast<uintptr_t>(base) & 7) || (reinterpret_cast<uintptr_t>(out) & 7)) return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_frame_hidden_fwd, dim3(eqh_grid_for(E, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, y, w3, base,
-                       base_ld, extra, wx, gamma, beta, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out, (int)w_ld);
+                       base_ld, extra, wx, gamma, beta, E, seed, ew_threshold(p), drop_inv_keep(p), eps, out, (int)w_ld);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -734,12 +734,12 @@ extern "C" int faf_frame_hidden_bwd(const float* y, const float* w3, const float
     float* slab = static_cast<float*>(workspace);
     if (!wx) {
         hipLaunchKernelGGL(k_frame_hidden_bwd<false>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx,
-                           gamma, dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab, (int)w_ld);
+                           gamma, dhn, E, seed, ew_threshold(p), drop_inv_keep(p), eps, dy, dbase, dextra, slab, (int)w_ld);
         EQH_CHECK_LAUNCH();
         return eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
     }
     hipLaunchKernelGGL(k_frame_hidden_bwd<true>, dim3(blocks), dim3(FP_THREADS), 0, stream, y, w3, base, base_ld, extra, wx, gamma,
-                       dhn, E, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, dy, dbase, dextra, slab, (int)w_ld);
+                       dhn, E, seed, ew_threshold(p), drop_inv_keep(p), eps, dy, dbase, dextra, slab, (int)w_ld);
     EQH_CHECK_LAUNCH();
     int rc = eqh_reduce_slabs3_async(slab, blocks, FH_SLAB, dw3, dgamma, dbeta, 768, 128, accumulate, stream);
     if (rc) return rc;
@@ -1262,7 +1262,7 @@ extern "C" int faf_gate_fwd(const float* x, const float* w, const float* b, cons
     return rd_dispatch(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_gate_fwd<NV>), dim3(eqh_grid_for(R, RD_WAVES, 8192)), dim3(RD_THREADS), 0, stream, x, w, b, res, R,
-                           (int)C, seed, ew_threshold(p), 1.0f / (1.0f - p), out);
+                           (int)C, seed, ew_threshold(p), drop_inv_keep(p), out);
         EQH_CHECK_LAUNCH();
         return EQH_OK;
     });
@@ -1300,7 +1300,7 @@ extern "C" int faf_gate_bwd(const float* x, const float* w, const float* b, cons
     return rd_dispatch(C, [&](auto nv) {
         constexpr int NV = decltype(nv)::value;
         hipLaunchKernelGGL((k_gate_bwd<NV>), dim3(blocks), dim3(RD_THREADS), 0, stream, x, w, b, dout, R, (int)C, seed,
-                           ew_threshold(p), 1.0f / (1.0f - p), dx, slab, slab_dx);
+                           ew_threshold(p), drop_inv_keep(p), dx, slab, slab_dx);
         EQH_CHECK_LAUNCH();
         if (slab_dx)
             if (int e = eqh_reduce_slabs_async(slab_dx, blocks, C, dx_colsum, stream, accumulate_colsum ? 1 : 0)) return e;
@@ -1451,7 +1451,7 @@ extern "C" int faf_edge_hidden_fwd(const float* A, const float* B, const float* 
         return EQH_ERR_ALIGN;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     hipLaunchKernelGGL(k_edge_hidden_fwd, dim3(eqh_grid_for(N, FP_WAVES, 8192)), dim3(FP_THREADS), 0, stream, A, B, Cf, nbr, gamma,
-                       beta, N, (int)K, seed, ew_threshold(p), 1.0f / (1.0f - p), eps, out);
+                       beta, N, (int)K, seed, ew_threshold(p), drop_inv_keep(p), eps, out);
     EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
@@ -1483,7 +1483,7 @@ extern "C" int faf_edge_hidden_bwd(const float* A, const float* B, const float* 
     const int blocks = eh_blocks(N);
     float* slab = static_cast<float*>(workspace);
     hipLaunchKernelGGL(k_edge_hidden_bwd, dim3(blocks), dim3(FP_THREADS), 0, stream, A, B, Cf, nbr, gamma, dhn, N, (int)K, seed,
-                       ew_threshold(p), 1.0f / (1.0f - p), eps, dpre, dA, slab);
+                       ew_threshold(p), drop_inv_keep(p), eps, dpre, dA, slab);
     EQH_CHECK_LAUNCH();
     return eqh_reduce_slabs3_async(slab, blocks, 256, dgamma, dbeta, nullptr, 128, 128, accumulate, stream);
 }

@@ -643,7 +643,7 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         p.flags = (q.trans_a ? GX_TRANS_A : 0) | (q.trans_b ? GX_TRANS_B : 0) | (q.relu ? GX_RELU : 0) | (q.mean_rows ? GX_MEAN8 : 0);
         p.drop_seed = q.drop_seed;
         p.drop_threshold = drop_threshold(q.drop_p);
-        p.drop_inv_keep = 1.0f / (1.0f - q.drop_p);
+        p.drop_inv_keep = drop_inv_keep(q.drop_p);
         p.tiles_n = (q.n + TN - 1) / TN;
         p.tiles_mn = (int)(((q.m + TM - 1) / TM) * p.tiles_n);
         int sp = 1, ch = (q.k + GX_BK - 1) / GX_BK;

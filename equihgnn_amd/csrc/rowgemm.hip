@@ -757,7 +757,7 @@ extern "C" int hg_rowgemm_bwd_bias(const float* z, const float* w, const float* 
     if (rc) return rc;
     if (R == 0) return EQH_OK;
     if (!z || !dout || !rowptr || (dz && !w)) return EQH_ERR_ARG;     // (w is read for dz only)
-    if (!eqh_aligned16(dout) || (dz && !eqh_aligned16(w)) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
+    if (!eqh_aligned16(dout) || (dz && (!eqh_aligned16(w) || !eqh_aligned16(dz))) || !eqh_aligned16(z)) return EQH_ERR_ALIGN;
     if (drowbias && (!dw || MB < 1 || MB > 16 || !eqh_aligned16(drowbias))) return EQH_ERR_ARG;   // (it rides the dw launch)
     if (zfac_check(Kd, L, coef, MB, z_factored)) return EQH_ERR_ARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);

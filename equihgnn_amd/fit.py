@@ -32,7 +32,7 @@ import threading
 import weakref
 import atexit
 
-from .batch import HBatch, HMol, MolStore, bucket_sizes, collate, shard_indices
+from .batch import HBatch, HMol, MolStore, bucket_sizes, collate, shard_indices, shard_permutation
 from .trainer import TrainStep, _world
 
 
@@ -150,14 +150,22 @@ class BucketedLoader:
         the largest batch of the run, and ``levels - 1`` smaller buckets one quantum apart below it take the batches
         that fit -- a batch is padded by half a quantum on average instead of by (largest - mean) atoms, ~5 % of a
         256-molecule QM9 batch, all of it GPU work; each bucket is one captured hipGraph."""
-        idx = np.asarray(shard_indices(len(self.store), self.rank, self.world, self.seed, self.epoch, self.shuffle),
-                         dtype=np.int64)
+        # Every rank holds the whole store and the sampler is a pure function of (seed, epoch, rank): each rank computes the
+        # batch extents of ALL ranks and pads to their maximum, so the ranks agree on the static shape of every step without
+        # a collective in the loader thread -- what bench.py does with an all-reduce(MAX) of the three sizes.  Ranks that
+        # padded to their own maxima would each replay (and, when an epoch raises the envelope, capture) differently shaped
+        # graphs around the one captured all-reduce; the 0.8 ms graph switch would then land on every rank's step whenever
+        # ANY rank switches.
+        perm = shard_permutation(len(self.store), self.world, self.seed, self.epoch, self.shuffle).astype(np.int64)
+        shards = [perm[r::self.world] for r in range(self.world)]
+        idx = shards[self.rank]
         self.epoch += 1
         batches = [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
-        # extents of every batch at once: prefix sums of the permuted per-molecule sizes
-        pre = lambda c: np.concatenate(([0], np.cumsum(c[idx])))
+        # extents of every batch at once: prefix sums of the permuted per-molecule sizes (shards have equal lengths)
         cut = np.minimum(np.arange(0, len(idx) + self.bs, self.bs), len(idx))
-        ext = [np.diff(pre(c)[cut]).max() for c in (self.store.n_nodes, self.store.n_he, self.store.n_inc)]
+        counts = (self.store.n_nodes, self.store.n_he, self.store.n_inc)
+        sizes = [np.max([np.diff(np.concatenate(([0], np.cumsum(c[sh])))[cut]) for sh in shards], axis=0) for c in counts]
+        ext = [sz.max() for sz in sizes]
         # ONE bucket for (almost) the whole run: the largest batch seen so far, a little above the first epoch's own
         # maximum (B x mean + 3.3 sigma sqrt(B) of the per-molecule sizes: the expected maximum of a few hundred batches)
         # so that later epochs -- other permutations, other maxima -- replay the graph captured in the first one; an
@@ -173,7 +181,6 @@ class BucketedLoader:
         top = bucket_sizes(ext[0], ext[1], ext[2], self.quantum)
         q = (self.quantum, self.quantum, 2 * self.quantum)
         ladder = [tuple(t - l * qq for t, qq in zip(top, q)) for l in range(self.levels)]      # ladder[0] = top
-        sizes = [np.diff(pre(c)[cut]) for c in (self.store.n_nodes, self.store.n_he, self.store.n_inc)]
         # the rungs in use are those the FIRST epoch populated (each is then captured in that epoch); later epochs choose
         # among them only, so a rare small or large batch never triggers a capture (seconds, with GEMM tuning) mid-run
         known = getattr(self, "_rungs", None)

@@ -24,6 +24,8 @@ from __future__ import annotations
 import ctypes
 import os
 
+import threading
+
 import torch
 
 from .. import hip
@@ -104,18 +106,20 @@ class _MHNNConvPanel(torch.autograd.Function):
             g_inc=g3, be_inc=be3, eps_inc=eps[2], out6=s_v, in1=cwX, w0=iw34, b0=b4a, g0=g4, be0=be4, w1=iW4b, bias_out=b4b, out0=u_v,
             out1=x3_v, out2=Xn))
         if need_grad:
-            ctx.save_for_backward(X, E, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, g1, g3, b2a, g2, b4a, g4)
-            ctx.rows = (pa1, pa3, qb1, qb3, s_e, u_e, x3_e, s_v, u_v, x3_v, En)
+            # En is an OUTPUT that the backward pass reads (dW3a): saved through save_for_backward, so that an in-place
+            # operation on the returned E' (an inplace activation, dropout_) trips autograd's version check instead of
+            # silently corrupting the weight gradient
+            ctx.save_for_backward(X, E, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, g1, g3, b2a, g2, b4a, g4, En)
+            ctx.rows = (pa1, pa3, qb1, qb3, s_e, u_e, x3_e, s_v, u_v, x3_v)
             ctx.imgs = imgs[10:]
             ctx.meta = (ix, eps)
             ctx.params = (b1a, g1, be1, b2a, g2, be2, b2b, b3a, g3, be3, b4a, g4, be4, b4b, v12, v34)
-        # (aliases: the outputs must not be the tensors kept on ctx -- ops/conv_stack.py, "reference cycle")
-        return Xn.view_as(Xn), En.view_as(En)
+        return Xn, En
 
     @staticmethod
     def backward(ctx, dXn, dEn):
-        X, E, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, g1, g3, b2a, g2, b4a, g4 = ctx.saved_tensors
-        pa1, pa3, qb1, qb3, s_e, u_e, x3_e, s_v, u_v, x3_v, En = ctx.rows
+        X, E, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, g1, g3, b2a, g2, b4a, g4, En = ctx.saved_tensors
+        pa1, pa3, qb1, qb3, s_e, u_e, x3_e, s_v, u_v, x3_v = ctx.rows
         iW4b_n, iw34_n, iW3e_n, iW2b_n, iw12_n, iW2e_n, iW1e_n, iW4x_n, iW3x_n, iW1x_n = ctx.imgs
         ix, eps = ctx.meta
         p_b1a, p_g1, p_be1, p_b2a, p_g2, p_be2, p_b2b, p_b3a, p_g3, p_be3, p_b4a, p_g4, p_be4, p_b4b, p_v12, p_v34 = ctx.params
@@ -221,8 +225,9 @@ def _merged_items(conv, C):
 class merged_scope:
     """``with merged_scope(convs, X, E):`` around a model's conv applications: the weight-level products of ALL the MHNNConv
     layers inside (two per layer) are formed by one ops.merged_weights call -- one launch forward, one in the backward pass --
-    instead of one per application; a conv applied several times (mhnn.py's shared layer) gets them once.  The results live on
-    the conv objects only inside the scope (they are functions of the parameters of THIS step)."""
+    instead of one per application; a conv applied several times (mhnn.py's shared layer) gets them once.  The results are
+    functions of the parameters of THIS step: they live in the scope object (found by ``mhnn_conv_panel`` through a per-thread
+    stack of open scopes), never on the modules, so nested or concurrent scopes over the same conv cannot remove each other's."""
 
     def __init__(self, convs, X, E):
         seen, self.convs = set(), []
@@ -231,21 +236,40 @@ class merged_scope:
                 seen.add(id(c))
                 self.convs.append(c)
         self.C = X.shape[-1]
+        self.merged = {}
 
     def __enter__(self):
         from .linears import merged_weights
         if self.convs:
             items = [it for c in self.convs for it in _merged_items(c, self.C)]
             res = merged_weights(items)
-            for k, c in enumerate(self.convs):
-                c._eqh_merged = (res[2 * k], res[2 * k + 1])
+            self.merged = {id(c): (res[2 * k], res[2 * k + 1]) for k, c in enumerate(self.convs)}
+        _open_scopes().append(self)
         return self
 
     def __exit__(self, *exc):
-        for c in self.convs:
-            if hasattr(c, "_eqh_merged"):
-                del c._eqh_merged
+        stack = _open_scopes()
+        if self in stack:
+            stack.remove(self)
+        self.merged = {}
         return False
+
+
+_SCOPES = threading.local()
+
+
+def _open_scopes() -> list:
+    if not hasattr(_SCOPES, "stack"):
+        _SCOPES.stack = []
+    return _SCOPES.stack
+
+
+def _merged_in_scope(conv):
+    for sc in reversed(_open_scopes()):
+        hit = sc.merged.get(id(conv))
+        if hit is not None:
+            return hit
+    return None
 
 
 def mhnn_conv_panel(conv, X, E, ix):
@@ -253,7 +277,7 @@ def mhnn_conv_panel(conv, X, E, ix):
     from .linears import merged_weights
     W1, W2, W3, W4 = conv.W1, conv.W2, conv.W3, conv.W4
     C = X.shape[-1]
-    pre = getattr(conv, "_eqh_merged", None)
+    pre = _merged_in_scope(conv)
     (w12, v12), (w34, v34) = pre if pre is not None else merged_weights(_merged_items(conv, C))
     if torch.is_grad_enabled():
         for w in (W1.lins[0].weight, W2.lins[0].weight, W2.lins[1].weight, W3.lins[0].weight, W4.lins[0].weight, W4.lins[1].weight):

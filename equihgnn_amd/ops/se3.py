@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes
 
+import os
+
 import torch
 
 from .. import hip
@@ -440,6 +442,13 @@ def rowgemm2(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a=None, bias_b=
     [E, 64] and the row operand's column (m, k) is coef[e, m] z[e, k] (node matrices [R, 64 MB, L], L <= 64)."""
     if bias_a is None and not z_factored:
         return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b)
+    Kd = int(wa.shape[-2])
+    if not rowgemm_bias_supported(Kd, int(wa.shape[-1])):
+        # only the streaming kernels carry the bias blocks / the factored row operand; with EQH_ROWGEMM_LDS=1 (round 4's
+        # workgroup-per-row kernels, kept for A/B runs) or a shape outside theirs the C ABI would answer EQH_ERR_ARG
+        raise ValueError(f"rowgemm2: bias blocks / z_factored need the streaming row-product kernels, which do not take "
+                         f"Kd={Kd}, L={int(wa.shape[-1])}" + (" while EQH_ROWGEMM_LDS=1 selects the LDS kernels"
+                                                               if os.environ.get("EQH_ROWGEMM_LDS") == "1" else ""))
     return _RowGemm2.apply(z, wa, rowptr_a, perm_a, wb, rowptr_b, perm_b, bias_a, bias_b, coef, bool(z_factored))
 
 

@@ -100,10 +100,12 @@ def store_from_slices(fields: Dict[str, torch.Tensor], slices: Dict[str, torch.T
     n_mol = st.n_nodes.shape[0]
     if not (np.array_equal(sl("pos"), st.node_off) and np.array_equal(sl("edge_index1"), st.inc_off)):
         raise ValueError("slices of pos / edge_index1 disagree with x / edge_index0")
-    st.x = npy(fields["x"], np.int64).reshape(-1, fields["x"].shape[-1])
+    if fields["x"].dim() != 2 or fields["x"].shape[-1] != 9:
+        raise ValueError(f"x must hold the 9 ogb atom features per node (data/utils.py:150-178), got shape {tuple(fields['x'].shape)}")
+    st.x = npy(fields["x"], np.int64).reshape(-1, 9)
     st.pos = npy(fields["pos"], np.float32).reshape(-1, 3)
     st.v, st.e = npy(fields["edge_index0"], np.int64).reshape(-1), npy(fields["edge_index1"], np.int64).reshape(-1)
-    st.edge_attr = npy(fields["edge_attr"], np.int64).reshape(st.he_off[-1], -1)[:, :1]
+    st.edge_attr = np.ascontiguousarray(npy(fields["edge_attr"], np.int64).reshape(st.he_off[-1], -1)[:, :1])
     if "n_e" in fields and not np.array_equal(npy(fields["n_e"], np.int64).reshape(-1), st.n_he):
         raise ValueError("n_e disagrees with the number of edge_attr rows per molecule")
     if "e_order" in fields:

@@ -140,6 +140,10 @@ class FlatAdam(torch.optim.Optimizer):
                                           ops._stream(p.device)), "eqh_adam_step")
 
 
+class CollectiveCaptureRefused(RuntimeError):
+    """The process-group backend could not record a collective into a hipGraph (raised by GraphedTrainStep._capture_pass)."""
+
+
 class GraphedTrainStep:
     """TrainStep with the launch-bound part captured in hipGraphs.
 
@@ -149,7 +153,8 @@ class GraphedTrainStep:
     (``collective_mode == "in_graph"``; RCCL kernels are stream-capturable), so a multi-rank step is one
     graph launch exactly like the single-rank one.  Where the collective cannot be captured (gloo, or
     a capture that RCCL refuses) the step falls back to graph A -> eager all-reduce -> graph B
-    (``"split"``).  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
+    (``"split"``) -- on EVERY rank: the ranks settle the form with one eager all-reduce (MIN of a success flag) at their
+    first capture, and only a failing collective call triggers the fallback (kernel / argument errors re-raise).  Batches must be padded to bucket extents with ``batch.pad_batch`` (exact for models
     without batch statistics); the loss is taken over the real molecules only.
 
     Parameters live in ONE flat buffer (``pflat``; every ``nn.Parameter`` is a view into it) and so
@@ -177,6 +182,8 @@ class GraphedTrainStep:
         self.graph_collective = graph_collective
         self.collective_mode = "none"       # "none" | "in_graph" | "split": what the captured steps do (set by _capture)
         self.capture_error = None           # why an in-graph capture fell back to "split", if it did
+        self.in_graph_backends = ("nccl",)  # backends whose collectives are stream-capturable (RCCL)
+        self._mode_agreed = False           # the ranks have settled on one collective_mode (first capture, _agree_on_mode)
         from . import ops
         self.scratch = ops.MergedScratch()  # accumulators of the merged weights: owned here, part of the captured graphs
         self.bflat = []                     # flat buffers (one per dtype) behind the model's buffers (multi-rank BatchNorm)
@@ -394,9 +401,17 @@ class GraphedTrainStep:
         self.opt.step()
         return loss.detach()
 
+    def _captured_all_reduce(self):
+        """The gradient all-reduce as a node of the step graph.  A backend that cannot be stream-captured raises here
+        (RCCL: ``DistBackendError``, a RuntimeError); that -- and nothing else -- is what makes a capture fall back to the
+        split form.  (A method so that the two-rank tests can stand in a backend that refuses on one rank.)"""
+        dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
+
     def _capture_pass(self, static, in_graph: bool):
         """One capture of the step for the static batch.  ``in_graph``: buffer broadcast, all-reduce and update are nodes of
-        the one graph; else the graph ends after the backward pass and the update is a second graph (g_opt)."""
+        the one graph; else the graph ends after the backward pass and the update is a second graph (g_opt).  Raises
+        ``CollectiveCaptureRefused`` when -- and only when -- a captured collective call failed; an error of a kernel launch
+        or of an argument check anywhere else in the pass propagates as itself (the split form would hit it too)."""
         from . import ops
         multi = self._multi()
         for p in self.model.parameters():
@@ -405,26 +420,51 @@ class GraphedTrainStep:
         tl = ops.TIMELINE            # bench.py's in-graph kernel timing: only the captured pass is recorded
         if tl is not None:
             tl.reset()
-        # thread_local: the RCCL watchdog thread may query events while this thread captures
-        with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
-            if tl is not None:
-                for _ in range(4):
-                    tl.pair("stamp_pair")
-            if in_graph and self._has_buffers:
-                self.sync_buffers()
-            if self.wflat is not None and self.keep_grads:
-                self.wflat.zero_()
-            loss = self._loss_backward(static)
-            if in_graph:
-                dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
-            if in_graph or not multi:   # nothing the host must do between backward and update: one graph, one launch
-                self.opt.step()
+        refused = None
+        try:
+            # thread_local: the RCCL watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g_bwd, capture_error_mode="thread_local"):
+                if tl is not None:
+                    for _ in range(4):
+                        tl.pair("stamp_pair")
+                if in_graph and self._has_buffers:
+                    try:
+                        self.sync_buffers()
+                    except RuntimeError as exc:
+                        refused = exc
+                if refused is None:
+                    if self.wflat is not None and self.keep_grads:
+                        self.wflat.zero_()
+                    loss = self._loss_backward(static)
+                    if in_graph:
+                        try:
+                            self._captured_all_reduce()
+                        except RuntimeError as exc:
+                            refused = exc
+                    if refused is None and (in_graph or not multi):
+                        self.opt.step()     # nothing the host must do between backward and update: one graph, one launch
+        except RuntimeError:
+            if refused is None:
+                raise
+            # (the refused collective also invalidated the capture: ending it raised again -- the refusal is the cause)
+        if refused is not None:
+            raise CollectiveCaptureRefused(f"{type(refused).__name__}: {refused}") from refused
         g_opt = None
         if multi and not in_graph:
             g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                 self.opt.step()
         return g_bwd, g_opt, loss
+
+    def _agree_on_mode(self, mode: str) -> str:
+        """All ranks take the SAME form of the step: "in_graph" only if every rank captured the collective.  One eager
+        all-reduce (MIN) of a success flag, at the FIRST capture of the run -- every rank reaches it at its second step,
+        after the eager bootstrap step, whatever its batches look like -- and the outcome then binds every later capture
+        (``_capture`` raises if a later bucket cannot follow it: a rank that changed form alone would leave the others
+        waiting in a collective it never enters)."""
+        flag = torch.tensor([1 if mode == "in_graph" else 0], dtype=torch.int32, device=self.gflat.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return "in_graph" if int(flag.item()) == 1 else "split"
 
     def _capture(self, static):
         multi = self._multi()
@@ -444,18 +484,31 @@ class GraphedTrainStep:
         self.scratch.freeze()          # its address is about to become part of a graph
         mode = "none"
         if multi:
-            mode = "in_graph" if (self.graph_collective and dist.get_backend() == "nccl"
+            mode = "in_graph" if (self.graph_collective and dist.get_backend() in self.in_graph_backends
                                   and self.collective_mode != "split") else "split"
+        first = multi and not self._mode_agreed
+        cap = None
         if mode == "in_graph":
             try:
-                g_bwd, g_opt, loss = self._capture_pass(static, True)
-            except Exception as exc:    # RCCL refused the capture: the split form is always available
-                self.capture_error = f"{type(exc).__name__}: {exc}"
+                cap = self._capture_pass(static, True)
+            except CollectiveCaptureRefused as exc:    # the split form is always available -- if every rank takes it
+                if not first:
+                    raise RuntimeError("GraphedTrainStep: the ranks agreed on the in-graph all-reduce at the first capture "
+                                       f"and this rank can no longer capture it ({exc})") from exc
+                self.capture_error = str(exc)
                 torch.cuda.synchronize()
                 self._buffer_restore(snap)
                 mode = "split"
-        if mode != "in_graph":
-            g_bwd, g_opt, loss = self._capture_pass(static, False)
+        if first:
+            agreed = self._agree_on_mode(mode)
+            self._mode_agreed = True
+            if agreed != mode:         # this rank captured the collective, another one could not: drop the graph, follow
+                self.capture_error = "another rank could not capture the collective"
+                cap, mode = None, agreed
+                self._buffer_restore(snap)
+        if cap is None:
+            cap = self._capture_pass(static, False)
+        g_bwd, g_opt, loss = cap
         self.collective_mode = mode
         if self.wflat is not None and not self.keep_grads:
             self.wflat.zero_()       # what the captured update leaves behind after every replay: zeros to accumulate into

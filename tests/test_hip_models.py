@@ -679,7 +679,7 @@ def test_second_trainer_on_the_same_model_trains_every_parameter():
     assert len(moved) == n_live
 
 
-def _two_rank_worker(rank, world, port, out_dir):
+def _two_rank_worker(rank, world, port, out_dir, refuse_on=None):
     import os
     import torch.distributed as dist
     from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
@@ -700,8 +700,19 @@ def _two_rank_worker(rank, world, port, out_dir):
     for b in batches:
         b.num_real_graphs = 8
     tr = GraphedTrainStep(m, lr=1e-3)
+    if refuse_on is not None:
+        # every rank ATTEMPTS the in-graph form; the stand-in collective records nothing on the ranks where it "works" and
+        # fails on rank `refuse_on`: all ranks must end in the split form (had one kept its graph, it would never enter the
+        # eager all-reduce and the parameters would drift apart -- or the job would hang)
+        tr.in_graph_backends = ("gloo",)
+
+        def stand_in():
+            if rank == refuse_on:
+                raise RuntimeError("stand-in: collective not capturable on this rank")
+        tr._captured_all_reduce = stand_in
     losses = [float(tr.step(batches[i % 3])) for i in range(5)]
-    torch.save({"sd": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses},
+    torch.save({"sd": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses,
+                "mode": tr.collective_mode, "capture_error": tr.capture_error},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -724,6 +735,25 @@ def test_graphed_step_two_ranks_stay_in_sync(tmp_path):
     for k in r0["sd"]:                            # ... identical parameters
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     assert all(np.isfinite(r0["losses"]))
+
+
+def test_a_rank_that_cannot_capture_the_collective_takes_every_rank_to_the_split_form(tmp_path):
+    """main.py:271-283 trains under DDP, where every rank runs the same collective sequence by construction; here the form of
+    the step (all-reduce inside the hipGraph or between two graphs) is decided at capture time, so the ranks must agree on it."""
+    import socket
+
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), 1), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["mode"] == r1["mode"] == "split"
+    assert "another rank" in r0["capture_error"] and "not capturable" in r1["capture_error"]
+    assert r0["losses"] != r1["losses"]
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
 
 
 @pytest.mark.parametrize("method,hidden", [("egnn_equihnns", 256), ("mhnns", 64), ("egnn_equihnns", 128)])

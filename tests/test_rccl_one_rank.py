@@ -37,11 +37,16 @@ def _worker(rank, port, out_path):
         finals = {}
         for label, kw in (("local", dict(collective=False)),
                           ("in_graph", dict(force_collective=True)),
-                          ("split", dict(force_collective=True, graph_collective=False))):
+                          ("split", dict(force_collective=True, graph_collective=False)),
+                          ("refused", dict(force_collective=True))):
             m = MODELS[method](1, default_args(method=method, MLP_hidden=64, output_hidden=32))
             fill_state_dict(m, 5)
             m.to(dev).train()
             tr = GraphedTrainStep(m, lr=1e-3, **kw)
+            if label == "refused":      # a backend that cannot record the collective: only THAT makes the step fall back
+                def refuse():
+                    raise RuntimeError("stand-in: collective not capturable")
+                tr._captured_all_reduce = refuse
             losses = [float(tr.step(batches[i % 3])) for i in range(6)]
             torch.cuda.synchronize()
             finals[label] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses)
@@ -49,11 +54,32 @@ def _worker(rank, port, out_path):
                                            "graphs": [s["opt"] is not None for s in tr.slots.values()],
                                            "flat_buffers": len(tr.bflat)}
             tr.close()
-        for label in ("in_graph", "split"):
+        for label in ("in_graph", "split", "refused"):
             sd, losses = finals[label]
             assert losses == finals["local"][1], (method, label, losses, finals["local"][1])
             for k, v in sd.items():
                 assert torch.equal(v, finals["local"][0][k]), (method, label, k)
+    # an error that is NOT a refused collective (a kernel's argument check, a bug) must surface, not turn into "split"
+    m = MODELS["egnn_equihnns"](1, default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32))
+    fill_state_dict(m, 5)
+    m.to(dev).train()
+    tr = GraphedTrainStep(m, lr=1e-3, force_collective=True)
+    tr.step(batches[0])
+    real, calls = tr._loss_backward, []
+
+    def broken(data):
+        calls.append(torch.cuda.is_current_stream_capturing())
+        if calls[-1]:
+            raise ValueError("stand-in: bad argument inside the captured pass")
+        return real(data)
+    tr._loss_backward = broken
+    try:
+        tr.step(batches[0])
+        report["kernel_error"] = "swallowed"
+    except ValueError as exc:
+        report["kernel_error"] = f"raised: {exc}"
+    torch.cuda.synchronize()
+    tr.close()
     json.dump(report, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
@@ -78,4 +104,7 @@ def test_graphed_step_through_a_one_rank_rccl_group(tmp_path):
         assert ig["mode"] == "in_graph" or (ig["mode"] == "split" and ig["capture_error"]), ig
         if ig["mode"] == "in_graph":
             assert not any(ig["graphs"])                       # no second graph
+        rf = rep[f"{method}/refused"]
+        assert rf["mode"] == "split" and "not capturable" in rf["capture_error"] and all(rf["graphs"]), rf
+    assert rep["kernel_error"].startswith("raised"), rep["kernel_error"]
     assert rep["mhnnm/in_graph"]["flat_buffers"] >= 1          # one broadcast per dtype, not one per buffer

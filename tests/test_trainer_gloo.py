@@ -95,3 +95,61 @@ def test_shard_indices_partition_like_distributed_sampler():
     assert set().union(*map(set, parts)) == set(range(n))
     assert parts != [shard_indices(n, r, world, seed=7, epoch=4) for r in range(world)]
     assert shard_indices(10, 1, 2, seed=0, shuffle=False) == [1, 3, 5, 7, 9]
+
+
+def test_shard_indices_repeat_a_store_smaller_than_the_world():
+    """DistributedSampler pads by repeating the permutation as often as needed: no rank gets an empty shard."""
+    parts = [shard_indices(3, r, 8, seed=1) for r in range(8)]
+    assert all(len(p) == 1 for p in parts) and {p[0] for p in parts} == {0, 1, 2}
+
+
+def _agree_worker(rank, world, port, out_dir):
+    import types
+
+    from equihgnn_amd.trainer import GraphedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    me = types.SimpleNamespace(gflat=torch.zeros(4))
+    got = [GraphedTrainStep._agree_on_mode(me, mode) for mode in
+           ("in_graph", "split", "in_graph" if rank == 0 else "split", "split" if rank == 0 else "in_graph")]
+    torch.save(got, os.path.join(out_dir, f"agree{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_form_of_the_step(tmp_path):
+    """GraphedTrainStep decides at capture time whether the gradient all-reduce is a node of the step's hipGraph; a rank that
+    fell back to the split form alone would leave the others in a collective it never enters (the reference's DDP,
+    main.py:271-283, has one collective sequence by construction).  "in_graph" survives only if EVERY rank reports it."""
+    mp.spawn(_agree_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert torch.load(tmp_path / f"agree{rank}.pt") == ["in_graph", "split", "split", "split"]
+
+
+def test_bucketed_loader_pads_every_rank_to_the_same_extents():
+    """Ranks draw different molecules, hence different natural batch sizes; the loader of the graphed step must still hand
+    every rank the SAME padded extents at every step (one captured graph per rank around the one all-reduce), computed
+    without a collective: each rank evaluates the whole epoch's sampler."""
+    from equihgnn_amd.batch import MolStore, synth_molecule
+    from equihgnn_amd.fit import BucketedLoader
+    rng = np.random.default_rng(11)
+    store = MolStore([synth_molecule(rng) for _ in range(400)])
+    world = 4
+    for levels in (1, 3):
+        plans = []
+        for r in range(world):
+            ld = BucketedLoader(store, 32, shuffle=True, seed=5, rank=r, world=world, levels=levels)
+            ld.lookahead = False
+            plans.append([ld.plan() for _ in range(3)])          # three epochs
+            ld.close()
+        for e in range(3):
+            t0 = plans[0][e][1]
+            for r in range(1, world):
+                assert plans[r][e][1] == t0, (levels, e, r)
+            # ... and the ranks really drew different batches with different natural sizes
+            nat = [[int(store.n_nodes[b].sum()) for b in plans[r][e][0]] for r in range(world)]
+            assert len({tuple(n) for n in nat}) == world
+            # every rank's batches fit the agreed extents
+            for r in range(world):
+                for b, t in zip(plans[r][e][0], plans[r][e][1]):
+                    assert store.n_nodes[b].sum() < t[0] and store.n_he[b].sum() < t[1] and store.n_inc[b].sum() <= t[2]
