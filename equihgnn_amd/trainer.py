@@ -499,6 +499,10 @@ class GraphedTrainStep:
                 torch.cuda.synchronize()
                 self._buffer_restore(snap)
                 mode = "split"
+            if mode == "split":
+                # the abandoned pass's CUDAGraph sits in the exception's traceback (a reference cycle): destroy it NOW --
+                # a hipGraphDestroy issued by the collector in the middle of the next capture aborts the process
+                gc.collect()
         if first:
             agreed = self._agree_on_mode(mode)
             self._mode_agreed = True
@@ -506,6 +510,7 @@ class GraphedTrainStep:
                 self.capture_error = "another rank could not capture the collective"
                 cap, mode = None, agreed
                 self._buffer_restore(snap)
+                gc.collect()
         if cap is None:
             cap = self._capture_pass(static, False)
         g_bwd, g_opt, loss = cap
