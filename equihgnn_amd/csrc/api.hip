@@ -179,6 +179,43 @@ extern "C" int eqh_stamp(void* slot, void* stream_) {
     return EQH_OK;
 }
 
+// Cross-stream trigger INSIDE a replayed graph: eqh_signal_post (a node of the step's hipGraph) bumps a device counter;
+// eqh_signal_wait (launched eagerly on another stream) holds that stream until the counter has reached `target` -- the
+// index build of the next batch starts when the running step has left its chip-filling front-end kernels, not at the step's
+// head (an event cannot be recorded from the middle of a captured graph).  One lane polls with s_sleep between loads and
+// leaves after timeout_us whatever happens, so a wait whose post never comes (a graph that was not launched) drains by
+// itself; the caller enqueues the posting graph BEFORE the wait.
+namespace {
+__global__ void eqh_k_signal_post(int* counter) {
+    __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void eqh_k_signal_wait(const int* counter, int target, unsigned long long timeout_ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 &&
+           __builtin_amdgcn_s_memrealtime() - t0 < timeout_ticks)
+        __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
+extern "C" int eqh_signal_post(int32_t* counter, void* stream_) {
+    if (!counter) return EQH_ERR_ARG;
+    hipLaunchKernelGGL(eqh_k_signal_post, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), counter);
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
+extern "C" int eqh_signal_wait(const int32_t* counter, int32_t target, int32_t timeout_us, void* stream_) {
+    if (!counter || timeout_us < 1 || timeout_us > 1000000) return EQH_ERR_ARG;
+    int64_t khz = 100000;
+    int dev = 0, k = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&k, hipDeviceAttributeWallClockRate, dev) == hipSuccess && k > 0)
+        khz = k;
+    hipLaunchKernelGGL(eqh_k_signal_wait, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream_), counter, (int)target,
+                       (unsigned long long)(khz * timeout_us / 1000));
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
+}
+
 // Shader clock the chip holds right now: one wavefront brackets a ~spin_us wait on the constant-rate clock with the
 // shader-cycle counter (s_memtime) and the 100 MHz real-time counter (s_memrealtime); out = {d cycles, d ticks}.
 namespace {

@@ -33,7 +33,7 @@ import weakref
 import atexit
 
 from .batch import HBatch, HMol, MolStore, bucket_sizes, collate, shard_indices, shard_permutation
-from .trainer import TrainStep, _world
+from .trainer import GraphedTrainStep, TrainStep, _world, with_next
 
 
 # ------------------------------------------------------------------------------------------------
@@ -206,7 +206,7 @@ class BucketedLoader:
     def _start_epoch(self, q=None):
         """Plan the next epoch and start its prefetch thread; returns the epoch's (queue, thread, stop flag).  ``q``: the
         queue of the epoch this one is started AHEAD of.  Both epochs then share it, so the bound on batches in flight
-        (queue depth + the one being staged + the two the consumer holds <= the ring of prefetch + 3 buffers) also holds
+        (queue depth + the one being staged + the three the consumer holds <= the ring of prefetch + 4 buffers) also holds
         across the epoch boundary -- with a queue of its own the new epoch would refill ring buffers that still wait,
         unconsumed, in the old one."""
         import time
@@ -226,9 +226,11 @@ class BucketedLoader:
 
         def stage(tgt, n_mols):
             """a free staging pair (pinned host buffer, device buffer) for a batch of n_mols molecules (ring of
-            prefetch + 3 per shape): [host, h2d_done, device, consumed]"""
+            prefetch + 4 per shape: the queue, the one being staged, and the THREE the consumer may hold -- the batch it steps
+            on, the look-ahead batch behind it (trainer.with_next) and the one whose release is still to be recorded):
+            [host, h2d_done, device, consumed]"""
             slot = ring.setdefault((tgt, n_mols), {"bufs": [], "next": 0})
-            if len(slot["bufs"]) < self.prefetch + 3:
+            if len(slot["bufs"]) < self.prefetch + 4:
                 host = HBatch.empty_packed(tgt[0], tgt[1], tgt[2], n_mols + 1, pin=self.pin)
                 with torch.cuda.stream(side) if cuda else contextlib.nullcontext():
                     devb = host.to(self.device) if cuda else None
@@ -269,7 +271,7 @@ class BucketedLoader:
                         with torch.cuda.stream(side):
                             if ent[3] is not None and not ent[3].query():
                                 # the trainer has taken the device buffer's previous content (a host-side query first: the
-                                # ring is prefetch + 3 deep, so the event has almost always fired and no wait enters the stream)
+                                # ring is prefetch + 4 deep, so the event has almost always fired and no wait enters the stream)
                                 side.wait_event(ent[3])
                             ent[2]._flat.copy_(ent[0]._flat, non_blocking=True)
                             ent[2].num_real_graphs = getattr(ent[0], "num_real_graphs", None)
@@ -321,20 +323,25 @@ class BucketedLoader:
         prev = None
 
         def fresh(b):
-            # The ring hands the SAME HBatch objects out again and again (prefetch + 3 per shape, kept across epochs),
+            # The ring hands the SAME HBatch objects out again and again (prefetch + 4 per shape, kept across epochs),
             # and HyperIndex.from_batch caches the batch's CSRs / kNN lists on the object: a refilled buffer must not
             # carry the index of the molecules it held before.
             b._hyper_index = None
+            b._generation = getattr(b, "_generation", 0) + 1     # (GraphedTrainStep's index prefetch: new contents, same object)
             return b
 
         done = False
+        older = None
         try:
             while True:
                 ent = q.get()
-                if prev is not None and cuda:     # whatever the consumer enqueued for the previous batch reads it before this point
+                # A consumer with one batch of look-ahead (trainer.with_next) asks for batch t+1 BEFORE it enqueues the step
+                # on batch t: what it enqueued by now reads the batch handed out TWO gets ago, not the previous one.
+                if older is not None and cuda:
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(self.device))
-                    prev[3] = ev
+                    older[3] = ev
+                older = prev
                 if ent is None:
                     done = True
                     break
@@ -355,12 +362,14 @@ class BucketedLoader:
             # producer, which may be blocked on a full queue holding ring entries the next __iter__ shares
             if not done:
                 stop.set()
-                if prev is not None and cuda:
-                    # the consumer left with the last yielded device buffer possibly still being read by kernels it
-                    # enqueued: record that point, so the next producer waits for it before refilling the buffer
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(self.device))
-                    prev[3] = ev
+            if cuda:
+                # the consumer left with the last yielded device buffers possibly still being read by kernels it
+                # enqueued: record that point, so the next producer waits for it before refilling them
+                for e_ in (older, prev):
+                    if e_ is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                        e_[3] = ev
             th.join()                   # (a finished producer has also started the next epoch by now: see _start_epoch)
             if not done:
                 self.close()            # (an epoch started ahead of an abandoned one is abandoned too)
@@ -455,9 +464,14 @@ class Fitter:
         bad = 0
         for epoch in range(epochs):
             tot, n = 0.0, 0
-            for data in train_loader:
-                tot += float(self.step.step(data))
-                n += 1
+            if isinstance(self.step, GraphedTrainStep):     # one batch of look-ahead: the next batch's index is built beside this step
+                for data, nxt in with_next(train_loader):
+                    tot += float(self.step.step(data, nxt))
+                    n += 1
+            else:
+                for data in train_loader:
+                    tot += float(self.step.step(data))
+                    n += 1
             if self.sched is None and self.step.opt is not None:  # built lazily with the optimiser
                 self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(
                     self.step.opt, mode="min", factor=0.1, patience=self.patience_lr, min_lr=self.lr * 1e-5)

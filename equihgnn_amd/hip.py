@@ -225,6 +225,8 @@ SIGNATURES = {
     "eqh_stamp": (c_int32, [c_void_p, c_void_p]),
     "eqh_wall_clock_khz": (c_int64, []),
     "eqh_clock_probe": (c_int32, [c_void_p, c_int32, c_void_p]),
+    "eqh_signal_post": (c_int32, [c_void_p, c_void_p]),
+    "eqh_signal_wait": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
@@ -282,3 +284,4 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().eqh_error_string(rc)
         raise HipLibraryError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+

@@ -69,10 +69,55 @@ class HyperIndex:
                                                                        self.by_v, self.by_e, self._knn_counts)
         self.has_v, self.has_e = has_v.unsqueeze(-1), has_e.unsqueeze(-1)
         self._knn = {}
+        self._knn_pos = {}      # (k, mode) -> address of the coordinates the search ran on (GraphedTrainStep's index prefetch)
         self._pad = None        # (batch, number of real molecules) of a padded batch, set by from_batch
         self._masks = None
         self._he_pool = None
         self.n_box = None   # int32 device [1]: number of real atoms of a padded batch (box of the kNN grid)
+
+    def reset_lazy(self):
+        """Forget what the forward pass derives lazily from the index (pad masks, the hyperedge pooling CSR): an index that
+        outlives one pass -- the LIVE index of a GraphedTrainStep with index prefetch -- must derive them again inside every
+        captured pass, or a second capture would read tensors of the first one's memory pool."""
+        self._masks = None
+        self._he_pool = None
+
+    def live_clone(self, batch):
+        """(clone, dsts, srcs): a structural copy of this index whose tensors are fresh allocations -- what the captured
+        training step reads -- and the tensor pairs one batched copy refreshes it with (``ops.copy_many``; every index tensor
+        is int32 or fp32, copied as 4-byte words).  ``batch``: the batch object the clone belongs to (its ``batch`` field backs
+        ``pad_masks``).  Tensor identity is preserved: a tensor referenced twice (``entry_w_of`` is the partner's ``rowptr``)
+        is cloned once."""
+        memo, dsts, srcs = {}, [], []
+
+        def cp(v):
+            if torch.is_tensor(v):
+                hit = memo.get(id(v))
+                if hit is None:
+                    assert v.element_size() == 4, "index tensors are int32 / fp32"
+                    hit = memo[id(v)] = v.detach().clone(memory_format=torch.contiguous_format)
+                    if v.numel():
+                        dsts.append(hit)
+                        srcs.append(v)
+                return hit
+            if isinstance(v, ops.CSR):
+                return ops.CSR(**{k: cp(x) for k, x in v.__dict__.items()})
+            if isinstance(v, tuple):
+                return tuple(cp(x) for x in v)
+            if isinstance(v, list):
+                return [cp(x) for x in v]
+            if isinstance(v, dict):
+                return {k: cp(x) for k, x in v.items()}
+            return v
+
+        out = HyperIndex.__new__(HyperIndex)
+        for name, v in self.__dict__.items():
+            if name in ("_pad", "_masks", "_he_pool", "_knn_counts"):
+                continue
+            setattr(out, name, cp(v))
+        out._masks = out._he_pool = out._knn_counts = None
+        out._pad = None if self._pad is None else (batch.batch, self._pad[1])
+        return out, dsts, srcs
 
     def pad_masks(self):
         """(node, hyperedge, incidence, molecule) [rows, 1] float masks of the REAL rows of a padded static-shape batch
@@ -123,6 +168,7 @@ class HyperIndex:
         """(nbr int32 [N,k], key fp32 [N,k], CSR of the transposed neighbour graph)."""
         hit = self._knn.get((k, mode))
         if hit is None:
+            self._knn_pos[(k, mode)] = (pos.data_ptr(), tuple(pos.shape), pos.dtype)
             counts, counted = self._knn_counts, False
             self._knn_counts = None                   # (cleared once, by the index's own launch: the first search takes it)
             if mode == 1 and pos.shape[0] - 1 < k:

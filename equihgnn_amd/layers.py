@@ -468,6 +468,9 @@ class EGNN(nn.Module):
             ab, normed, res = ops.linear(feats, w_cat, b_cat), nn_(feats), feats
         # egnn_layer.py:298-310,357-358 fused: gather, +, SiLU, 16 x Hp x 16 MFMA, SiLU, sum over j
         m_i = ops.egnn_edge(ab, w_d, w2, lin2.bias, nbr, d2, csr_t)
+        # everything up to here fills the chip; the panel kernels that follow occupy ~150 of 256 CUs: where a graphed
+        # trainer lets the next batch's index build start on its side stream (no-op otherwise)
+        ops.signal_point()
         n0, n3 = self.node_mlp[0], self.node_mlp[3]
         if ops.USE_NODE_PANEL and ops.egnn_node_mlp_supported(normed, m_i, n0, n3):
             return ops.egnn_node_mlp(normed, m_i, res, n0, n3)      # one launch each way (csrc/panel.hip)
@@ -496,6 +499,7 @@ def readout(mlp_out, x, index: HyperIndex, taps=None, head=None):
     when the head has the scripts' shape (three Linears, LayerNorm) pool, MLP, loss and the whole backward
     pass of the head are one launch (ops.readout_mse)."""
     if head is not None and taps is None:
+        ops.signal_point("readout")
         x2 = x.reshape(-1, x.shape[-1])
         if ops.readout_mse_supported(x2, mlp_out) and head[0].is_cuda:
             loss, _ = ops.readout_mse(x2, index.pool.rowptr, mlp_out, head[0], head[1],

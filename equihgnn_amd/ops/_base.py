@@ -88,6 +88,39 @@ def timed(name: str, work, launch):
     return out
 
 
+class StepSignal:
+    """A device counter that a node of the training step's hipGraph bumps (eqh_signal_post) and another stream waits on
+    (eqh_signal_wait): how GraphedTrainStep starts the NEXT batch's index build when the running step has passed its
+    chip-filling front-end -- the place a model marks with ``ops.signal_point()`` -- instead of at the step's head.
+    ``posted``: how many posts the replays so far have enqueued (the host's mirror of the counter's final value)."""
+
+    def __init__(self, device):
+        self.counter = torch.zeros(1, dtype=torch.int32, device=device)
+        self.posted = 0
+        self.armed = False
+
+    def post(self):
+        self.armed = False
+        hip.check(hip.lib().eqh_signal_post(_ptr(self.counter), _stream(self.counter.device)), "eqh_signal_post")
+
+    def wait(self, target: int, timeout_us: int = 20000):
+        """Hold the CURRENT stream until the counter has reached ``target`` (at most timeout_us)."""
+        t = ((int(target) + 2 ** 31) % 2 ** 32) - 2 ** 31          # the device counter wraps as int32
+        hip.check(hip.lib().eqh_signal_wait(_ptr(self.counter), t, int(timeout_us), _stream(self.counter.device)), "eqh_signal_wait")
+
+
+SIGNAL: Optional[StepSignal] = None
+
+
+def signal_point(name: str = "front_end"):
+    """Called where the chip stops being full -- "front_end": behind the EGNN edge kernel; "readout": before the 17-workgroup
+    read-out head; "tail": before the step's closing reductions.  Under an armed StepSignal that listens for ``name`` -- a
+    GraphedTrainStep capturing with index prefetch -- the post lands here; otherwise nothing happens."""
+    sg = SIGNAL
+    if sg is not None and sg.armed and getattr(sg, "at", "front_end") == name:
+        sg.post()
+
+
 def _row_view(t, what):
     """2-D fp32 device tensor usable as a matrix operand in place (unit inner stride, 16-byte aligned rows)."""
     if not (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda):

@@ -203,6 +203,8 @@ def defer_flush(device):
                 for dy2, x2, _, _ in chunk:
                     _DEFER["keep"].extend((dy2, x2))
                 gemm_batch([GemmProblem(dy2, x2, True, False, None, into, alpha, 1.0, False, into) for dy2, x2, alpha, into in chunk])
+        from ._base import signal_point
+        signal_point("tail")
         colsum_batch(sums)
     finally:
         _DEFER["active"] = False

@@ -140,6 +140,20 @@ class FlatAdam(torch.optim.Optimizer):
                                           ops._stream(p.device)), "eqh_adam_step")
 
 
+def with_next(batches):
+    """(batch, next batch or None) pairs of an iterable: the one batch of look-ahead ``GraphedTrainStep.step(data, next_data)``
+    uses to build the next batch's index beside the current step."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 class CollectiveCaptureRefused(RuntimeError):
     """The process-group backend could not record a collective into a hipGraph (raised by GraphedTrainStep._capture_pass)."""
 
@@ -183,6 +197,21 @@ class GraphedTrainStep:
         self.collective_mode = "none"       # "none" | "in_graph" | "split": what the captured steps do (set by _capture)
         self.capture_error = None           # why an in-graph capture fell back to "split", if it did
         self.in_graph_backends = ("nccl",)  # backends whose collectives are stream-capturable (RCCL)
+        # Index prefetch: the per-batch index (three CSR sorts, kNN + its transpose: ~100 us of a 1.1 ms egnn_equihnns step)
+        # depends on the batch only, not on the parameters.  step(data, next_data) builds next_data's index on a side
+        # stream (its own small hipGraph) WHILE the step graph of `data` runs, and the step graph then starts at the
+        # embedding.  EQH_NO_INDEX_PREFETCH=1: the index stays at the head of the step graph (rounds 1-5).
+        import os
+        self.index_prefetch = not os.environ.get("EQH_NO_INDEX_PREFETCH")
+        self.signal_in_model = not os.environ.get("EQH_PREFETCH_AT_HEAD")    # start the next index at the model's ops.signal_point()
+        # which of the marked points releases it.  Measured at the BASELINE batch (same box, ms per step): index at the head
+        # of the step graph 1.137; built ahead and released at the step's head 1.138 (it then competes with the chip-filling
+        # front-end kernels), behind the EGNN edge kernel 1.112, before the read-out head 1.098, before the closing
+        # reductions 1.160 (too late: it spills into the next step)
+        self.signal_at = os.environ.get("EQH_PREFETCH_SIGNAL", "readout")
+        self._signal = None                 # ops.StepSignal: posted by a node of every step graph with index prefetch
+        self.prefetch_hits = 0              # steps whose index had been built ahead
+        self.prefetch_misses = 0            # steps that had to build it first (no next_data was given for them)
         self._mode_agreed = False           # the ranks have settled on one collective_mode (first capture, _agree_on_mode)
         from . import ops
         self.scratch = ops.MergedScratch()  # accumulators of the merged weights: owned here, part of the captured graphs
@@ -266,7 +295,9 @@ class GraphedTrainStep:
 
     def _loss(self, data):
         nb = getattr(data, "num_real_graphs", None) or data.y.shape[0]
-        if hasattr(data, "_hyper_index"):
+        if getattr(data, "_index_is_live", False):
+            data._hyper_index.reset_lazy()      # (built ahead by the index graph and refreshed before this pass: see _capture_index)
+        elif hasattr(data, "_hyper_index"):
             data._hyper_index = None
         from . import ops
         if self.fused_head and data.y.is_cuda:
@@ -435,7 +466,21 @@ class GraphedTrainStep:
                 if refused is None:
                     if self.wflat is not None and self.keep_grads:
                         self.wflat.zero_()
-                    loss = self._loss_backward(static)
+                    sig = self._signal if getattr(static, "_index_is_live", False) else None
+                    if sig is not None:
+                        # the post that releases the NEXT batch's index build: where the model marks it (ops.signal_point:
+                        # behind the EGNN edge kernel, when the chip stops being full), else at the head of the step
+                        sig.armed, sig.at = True, self.signal_at
+                        ops.SIGNAL = sig
+                        if not (self.signal_in_model and self._signal_reached):
+                            sig.post()
+                    try:
+                        loss = self._loss_backward(static)
+                    finally:
+                        if sig is not None:
+                            ops.SIGNAL = None
+                            if sig.armed:       # (cannot happen after the probe; a step without its post would stall the next index build until the wait's timeout)
+                                sig.post()
                     if in_graph:
                         try:
                             self._captured_all_reduce()
@@ -476,12 +521,27 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         snap = self._buffer_snapshot()
+        from . import ops
+
+        class _Probe:       # does this model's step reach the signal point the trainer listens for (ops.signal_point)?
+            armed, reached, at = True, False, self.signal_at
+
+            def post(self):
+                self.armed, self.reached = False, True
+        probe = _Probe()
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
             for _ in range(2):
-                self._fwd_bwd(static)
+                probe.armed = True
+                ops.SIGNAL = probe
+                try:
+                    self._fwd_bwd(static)
+                finally:
+                    ops.SIGNAL = None
             self._buffer_restore(snap)
         torch.cuda.current_stream().wait_stream(side)
+        self._signal_reached = probe.reached
         self.scratch.freeze()          # its address is about to become part of a graph
+        prefetch = self._capture_index(static) if self.index_prefetch else None
         mode = "none"
         if multi:
             mode = "in_graph" if (self.graph_collective and dist.get_backend() in self.in_graph_backends
@@ -519,9 +579,104 @@ class GraphedTrainStep:
             self.wflat.zero_()       # what the captured update leaves behind after every replay: zeros to accumulate into
             if self.scratch.buf is not None:
                 self.scratch.buf.zero_()
-        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss, "mode": mode}
+        return {"static": static, "bwd": g_bwd, "opt": g_opt, "loss": loss, "mode": mode, "prefetch": prefetch}
 
-    def step(self, data) -> torch.Tensor:
+    def _capture_index(self, static):
+        """Set up the index prefetch of one bucket, or return None when the model's index cannot be built ahead (no index
+        on the batch, or a neighbour search on coordinates other than the batch's own ``pos``).
+
+        ``staged``: a second packed copy of the static batch that a step's successor is written into; ``g_index``: a hipGraph
+        that builds the staged batch's HyperIndex (CSR sorts, kNN, transposed kNN CSR) -- replayed on ``stream`` beside the
+        running step; ``live``: a clone of that index, installed on the static batch, which is ALL the step graph reads;
+        ``dsts / srcs``: the tensor pairs (index tensors + the batch's flat buffer) that ONE batched copy at the head of
+        every step moves from staged to live.  One step graph per bucket as before: alternating between two captured step
+        graphs costs ~0.8 ms per switch on ROCm 7.2, a 3 MB copy ~5 us."""
+        from .index import HyperIndex
+        ixw = getattr(static, "_hyper_index", None)
+        flat = getattr(static, "_flat", None)
+        if ixw is None or flat is None or not static.pos.is_cuda:
+            return None
+        want = (static.pos.data_ptr(), tuple(static.pos.shape), static.pos.dtype)
+        keys = list(ixw._knn.keys())
+        if any(ixw._knn_pos.get(k) != want for k in keys) or any(static.pos.shape[0] - 1 < k for k, m in keys if m == 1):
+            return None
+        staged = static.packed()
+        staged.num_real_graphs = getattr(static, "num_real_graphs", None)
+        from . import ops
+        if self._signal is None:
+            self._signal = ops.StepSignal(static.pos.device)
+        stream = getattr(self, "_prefetch_stream", None)
+        if stream is None:
+            stream = self._prefetch_stream = torch.cuda.Stream()
+
+        def build():
+            staged._hyper_index = None
+            ix = HyperIndex.from_batch(staged)
+            for k, m in keys:
+                ix.knn(staged.pos, k, m)
+            return ix
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            build()                                  # (warm-up on the stream the graph will be replayed on)
+        torch.cuda.current_stream().wait_stream(stream)
+        g_index = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_index, capture_error_mode="thread_local"):
+            ix_staged = build()
+        live, dsts, srcs = ix_staged.live_clone(static)
+        static._hyper_index, static._index_is_live = live, True
+        as_words = lambda t: t.view(torch.float32) if t.dtype != torch.float32 else t
+        nf = flat.numel() // 4 * 4
+        dsts = [as_words(t).reshape(-1) for t in dsts] + [flat[:nf].view(torch.float32)]
+        srcs = [as_words(t).reshape(-1) for t in srcs] + [staged._flat[:nf].view(torch.float32)]
+        free = torch.cuda.Event()
+        free.record(torch.cuda.current_stream())
+        return {"staged": staged, "g_index": g_index, "ix_staged": ix_staged, "live": live, "dsts": dsts, "srcs": srcs,
+                "stream": stream, "free": free, "ready": None, "holds": None}
+
+    @staticmethod
+    def _token(data):
+        """Identity of a batch's CONTENTS: loaders hand the same device buffers out again with new molecules (and bump
+        ``_generation``, fit.BucketedLoader)."""
+        return (id(data), getattr(data, "_generation", 0))
+
+    def _stage(self, pf, data, after_signal=None):
+        """Write ``data`` into the bucket's staged batch and build its index there, on the prefetch stream: ordered behind
+        the head copy of the last step that read the staged buffers (``free``), not behind the step itself -- and, with
+        ``after_signal`` (the count the running step's signal node brings the counter to), held back until that step has
+        reached its signal point."""
+        st = pf["staged"]
+        cur = torch.cuda.current_stream()
+        with torch.cuda.stream(pf["stream"]):
+            pf["stream"].wait_event(pf["free"])
+            if after_signal is not None:
+                self._signal.wait(after_signal)
+            lay = getattr(data, "_layout", None)
+            if lay is not None and lay == getattr(st, "_layout", None):
+                st._flat.copy_(data._flat, non_blocking=True)
+            else:
+                for f in data.__dataclass_fields__:
+                    v = getattr(data, f)
+                    if torch.is_tensor(v):
+                        getattr(st, f).copy_(v, non_blocking=True)
+            pf["g_index"].replay()
+            ready = torch.cuda.Event()
+            ready.record(pf["stream"])
+        pf["ready"], pf["holds"] = ready, self._token(data)
+        del cur
+
+    def _refresh(self, pf):
+        """Head of a step: staged -> live (index tensors and the batch itself) in one launch on the step's stream."""
+        from . import ops
+        cur = torch.cuda.current_stream()
+        cur.wait_event(pf["ready"])
+        ops.copy_many(pf["dsts"], pf["srcs"])
+        pf["free"] = torch.cuda.Event()
+        pf["free"].record(cur)
+
+    def step(self, data, next_data=None) -> torch.Tensor:
+        """One training step on ``data``.  ``next_data``: the batch of the NEXT call, if the caller has it (a loader with one
+        batch of look-ahead, ``with_next``): its per-batch index is then built beside this step instead of at the head of
+        the next one.  Numerically the two forms are the same step."""
         if self.live is None:
             return self._bootstrap(data)
         key = self._key(data)
@@ -535,21 +690,39 @@ class GraphedTrainStep:
             static.num_real_graphs = getattr(data, "num_real_graphs", None)
             slot = self.slots[key] = self._capture(static)
         st = slot["static"]
-        lay = getattr(data, "_layout", None)
-        if lay is not None and lay == getattr(st, "_layout", None):
-            st._flat.copy_(data._flat, non_blocking=True)
+        pf = slot.get("prefetch")
+        if pf is not None:
+            if pf["holds"] != self._token(data):
+                self.prefetch_misses += 1
+                pf["stream"].wait_stream(torch.cuda.current_stream())     # (data may have been produced on this stream)
+                self._stage(pf, data)
+            else:
+                self.prefetch_hits += 1
+            self._refresh(pf)
+            pf["holds"] = None
         else:
-            for f in data.__dataclass_fields__:
-                v = getattr(data, f)
-                if torch.is_tensor(v):
-                    getattr(st, f).copy_(v, non_blocking=True)
+            lay = getattr(data, "_layout", None)
+            if lay is not None and lay == getattr(st, "_layout", None):
+                st._flat.copy_(data._flat, non_blocking=True)
+            else:
+                for f in data.__dataclass_fields__:
+                    v = getattr(data, f)
+                    if torch.is_tensor(v):
+                        getattr(st, f).copy_(v, non_blocking=True)
         self.opt.sync_lr()
         if self._has_buffers and slot["mode"] != "in_graph":
             self.sync_buffers()
         slot["bwd"].replay()
+        if pf is not None:
+            self._signal.posted += 1      # (one post per replay of a step graph with a live index)
         if slot["opt"] is not None:
             dist.all_reduce(self.gflat, op=dist.ReduceOp.SUM)
             slot["opt"].replay()
+        if next_data is not None:
+            nslot = self.slots.get(self._key(next_data))
+            npf = nslot.get("prefetch") if nslot is not None else None
+            if npf is not None:
+                self._stage(npf, next_data, after_signal=self._signal.posted if pf is not None else None)
         return slot["loss"].detach()
 
 

@@ -268,6 +268,13 @@ int64_t eqh_wall_clock_khz(void);
  * out[0] = shader cycles (s_memtime) and out[1] = constant-rate ticks (s_memrealtime) that passed, two uint64: the shader
  * clock the chip holds at that moment is out[0] / out[1] x eqh_wall_clock_khz (bench.py prints it beside each timed block). */
 int eqh_clock_probe(void* out, int32_t spin_us, void* stream);
+/* Cross-stream trigger from inside a replayed hipGraph (trainer.GraphedTrainStep's index prefetch; the reference has no
+ * counterpart: it builds every index implicitly inside its scatter / topk calls, conv.py:90-98, egnn_layer.py:253-288).
+ * eqh_signal_post: a one-thread kernel, capturable, that adds 1 to *counter (int32, device memory).  eqh_signal_wait: a
+ * one-thread kernel that returns once *counter - target >= 0 (wrap-around safe) or after timeout_us (1..1000000)
+ * microseconds, whichever comes first -- it never outlives its timeout. */
+int eqh_signal_post(int32_t* counter, void* stream);
+int eqh_signal_wait(const int32_t* counter, int32_t target, int32_t timeout_us, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of

@@ -737,6 +737,62 @@ def test_graphed_step_two_ranks_stay_in_sync(tmp_path):
     assert all(np.isfinite(r0["losses"]))
 
 
+@pytest.mark.parametrize("method", ["egnn_equihnns", "mhnnm", "equiformer_equihnns", "faformer_equihnns"])
+def test_index_built_ahead_on_the_side_stream_gives_the_same_steps(method):
+    """GraphedTrainStep.step(data, next_data) builds next_data's per-batch index (CSR sorts, kNN, transposed kNN CSR:
+    egnn_layer.py:253-288 and the unsorted-COO contract of conv.py's scatters) on a side stream while the step on `data` runs
+    and refreshes the step graph's index by one copy; the index is integer work, so the parameters after K steps must equal
+    those of the trainer that builds the index at the head of its step graph BIT FOR BIT -- whether every step finds its index
+    built ahead, none does (no next_data), or the caller announces one batch and then steps on another."""
+    import copy
+
+    from common import zero_dropouts
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep, with_next
+    args = default_args(method=method, MLP_hidden=64, output_hidden=32)
+    m0 = _models()[method](1, args)
+    fill_state_dict(m0, 4)
+    zero_dropouts(m0)
+    m0.to(DEV)
+    raw = [synth_batch(8, 1300 + i) for i in range(4)]
+    ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64) for b in raw]
+    tgt = tuple(max(e[i] for e in ext) for i in range(3))
+    padded = [pad_batch(b, *tgt).packed().to(DEV) for b in raw]
+    for b in padded:
+        b.num_real_graphs = 8
+    order = [padded[i % 4] for i in range(7)]
+    finals = {}
+    for label in ("in_step", "ahead", "never_ahead", "wrong_guess"):
+        m = copy.deepcopy(m0)
+        tr = GraphedTrainStep(m, lr=1e-3)
+        tr.index_prefetch = label != "in_step"
+        losses = []
+        for i, (b, nxt) in enumerate(with_next(order)):
+            if label == "ahead":
+                losses.append(float(tr.step(b, nxt)))
+            elif label == "wrong_guess":      # announces the batch after next: every announced index is thrown away
+                losses.append(float(tr.step(b, order[(i + 2) % len(order)])))
+            else:
+                losses.append(float(tr.step(b)))
+        torch.cuda.synchronize()
+        slot = next(iter(tr.slots.values()))
+        if label == "in_step":
+            assert slot["prefetch"] is None
+        else:
+            assert slot["prefetch"] is not None, "this model's index can be built ahead"
+            if label == "ahead":
+                assert tr.prefetch_hits == len(order) - 2 and tr.prefetch_misses == 1      # (bootstrap; the capture step builds its own)
+            else:
+                assert tr.prefetch_hits == 0
+        finals[label] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses)
+        tr.close()
+    for label in ("ahead", "never_ahead", "wrong_guess"):
+        assert finals[label][1] == finals["in_step"][1], (label, finals[label][1], finals["in_step"][1])
+        for k, v in finals[label][0].items():
+            assert torch.equal(v, finals["in_step"][0][k]), (label, k)
+
+
 def test_a_rank_that_cannot_capture_the_collective_takes_every_rank_to_the_split_form(tmp_path):
     """main.py:271-283 trains under DDP, where every rank runs the same collective sequence by construction; here the form of
     the step (all-reduce inside the hipGraph or between two graphs) is decided at capture time, so the ranks must agree on it."""
