@@ -592,6 +592,53 @@ PN_KERNEL(NW) k_panel_plain(const PanelPlain p) {
     PN_STAMP(5);
 }
 
+// Measurement aid (EQH_PANEL_PAIR=1, C = 256): the plain product as a COLUMN-SPLIT PAIR -- two workgroups of four
+// wavefronts per 32-row panel, blockIdx.y owning 128 of the 256 output columns: half the weight image (192 KB) and half the
+// MFMAs (96 per SIMD) per workgroup, twice the workgroups.  Each half still needs the panel's whole rows as its A image (K =
+// 256), so the row prologue -- load, split into bf16 planes, LDS image -- is done twice, by half as many wavefronts each.
+template <int C>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) k_panel_plain_pair(const PanelPlain p) {
+    constexpr int NW = 4;
+    using S = PnShape<C, NW>;
+    constexpr int HT = S::NT / 2;          // column tiles per half (4 at C = 256): one per wavefront
+    static_assert(HT == NW, "one column tile per wavefront");
+    __shared__ uint4 s_img[3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * (C / 2 + 4)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = blockIdx.y;
+    const RtPos<NW> P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
+    RowTile<C, NW> x;
+    rt_load<C, NW>(x, p.A, p.lda, P.rowc, P.c4);
+    WStream<S::KS, 1, 1, NW> ws;
+    ws.init(0, p.W + (int64_t)(half * HT * S::KS) * 3 * 64, wave, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    rt_a_put<C, NW, S::KS>(x, s_img, P.lrow, P.c);
+    __syncthreads();
+    f32x16 acc[1][1];
+    acc_zero<1, 1>(acc);
+    panel_mma<S::KS, 1, 1, NW>(s_img, ws, acc, lane);
+    acc_to_staging<1, NW, C / 2 + 4>(s_stg, acc[0], wave, lane);
+    __syncthreads();
+    // epilogue on this half's 32 x 128 block: 8 lanes per row, four float4 each
+    const int row = threadIdx.x >> 3, c = threadIdx.x & 7, grow = (int)blockIdx.x * PN_ROWS + row;
+    if (grow < p.rows) {
+#pragma unroll
+        for (int j = 0; j < C / 64; ++j) {
+            const int col = 4 * (8 * j + c);
+            const float4 a = *reinterpret_cast<const float4*>(s_stg + row * (C / 2 + 4) + col);
+            float4 o = make_float4(p.alpha * a.x, p.alpha * a.y, p.alpha * a.z, p.alpha * a.w);
+            const int gcol = half * (C / 2) + col;
+            if (p.D) {
+                const float4 d = *reinterpret_cast<const float4*>(p.D + (int64_t)grow * p.ldd + gcol);
+                o.x = fmaf(p.beta, d.x, o.x); o.y = fmaf(p.beta, d.y, o.y); o.z = fmaf(p.beta, d.z, o.z); o.w = fmaf(p.beta, d.w, o.w);
+            }
+            if (p.bias) f4_add(o, *reinterpret_cast<const float4*>(p.bias + gcol));
+            if (p.relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+            *reinterpret_cast<float4*>(p.Cout + (int64_t)grow * p.ldc + gcol) = o;
+        }
+    }
+}
+
 // ---- several products of ONE row block: out_g = A W_g + rw_g[row] * bias_g + D_g, g < NG <= 3 --------------------------------
 // (MHNNConv, conv.py:87-101 after the split of every first Linear by input block: X feeds W1's and W3's node halves and W4's own
 // half, E feeds W1's hyperedge half and W2's own half -- one A image, NG weight streams.  rw: per-row weight of the bias, the
@@ -1407,6 +1454,12 @@ extern "C" int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int3
     const int nw = pn_waves();
     const dim3 grid((unsigned)((rows + PN_ROWS - 1) / PN_ROWS)), block(64 * nw);
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    static const bool pair = [] { const char* e = getenv("EQH_PANEL_PAIR"); return e && e[0] == '1'; }();
+    if (pair && C == 256) {      // measurement aid: see k_panel_plain_pair
+        hipLaunchKernelGGL((k_panel_plain_pair<256>), dim3(grid.x, 2), dim3(256), 0, stream, p);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    }
 #define PN_PLAIN(NW_)                                                                                       \
     do {                                                                                                    \
         if (C == 256) hipLaunchKernelGGL((k_panel_plain<256, NW_>), grid, block, 0, stream, p);            \
