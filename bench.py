@@ -80,6 +80,10 @@ def parse():
                    help="molecules in the CPU-baseline sample batch (0: the GPU batch, or a bounded sample for the methods "
                         "whose oracle does not fit a CPU at the full batch)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip `other_configs` (N=1, default workload only: BASELINE configs 0, 2 and 4 -- mhnnm, equiformer_equihnns, "
+                        "faformer_equihnns -- timed for a few graph-replayed steps each after the headline)")
+    p.add_argument("--other-steps", type=int, default=10, help="timed steps per block of each `other_configs` entry")
     p.add_argument("--timeline-replays", type=int, default=30,
                    help="replays of the time-stamped graph that `roofline` averages over")
     p.add_argument("--wgrad-side-stream", action="store_true",
@@ -395,13 +399,22 @@ def pmc_traffic(method, batch, flavour, kernel_names):
     return None, None
 
 
-def panel_prologues(method, batch, flavour):
+def panel_prologues(method, batch, flavour, dev=None):
     """The gather prologues of the panel kernels (k_conv_f2: gathered mean; k_conv_f3: per-incidence hidden layer + mean;
     k_conv_b1: weighted gather of the backward) are aggregation work that has no launch of its own, so device stamps around
-    launches cannot see it: tools/panel_prologues.py brackets each prologue with s_memtime stamps inside a -DPN_STAMPS build
-    and commits profiles/r*_panel_prologue.json; the newest file whose workload matches THIS run is reported (never a
-    constant in this file)."""
+    launches cannot see it.  MEASURED IN THIS RUN: tools/panel_prologues.measure brackets each prologue with s_memtime stamps
+    inside the -DPN_STAMPS build of the panel kernels (equihgnn_amd/libequihgnn_panel_stamps.so, built by
+    __graft_entry__.build() beside the product library) on the index of a batch of this workload.  Only when that library is
+    absent: the newest committed profiles/r*_panel_prologue.json of the same workload, labelled as such."""
     import glob
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import panel_prologues as pp_tool
+        d = pp_tool.measure(method, batch, flavour, dev=dev)
+        d["source"] = "measured in this run (tools/panel_prologues.measure: in-kernel s_memtime stamps, -DPN_STAMPS build loaded beside the product library)"
+        return d
+    except Exception as exc:  # noqa: BLE001 -- the stamped build is a measurement aid: its absence must not cost the headline
+        why = f"{type(exc).__name__}: {exc}"[:200]
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_panel_prologue.json")), reverse=True):
         try:
             d = json.load(open(path))
@@ -409,7 +422,7 @@ def panel_prologues(method, batch, flavour):
             continue
         wl = d.get("workload", {})
         if (wl.get("method"), wl.get("batch"), wl.get("flavour")) == (method, batch, flavour):
-            d["source"] = os.path.relpath(path, ROOT) + " (tools/panel_prologues.py: in-kernel s_memtime stamps, offline)"
+            d["source"] = os.path.relpath(path, ROOT) + f" (offline file: the live measurement failed -- {why})"
             return d
     return None
 
@@ -810,6 +823,29 @@ def main():
                   "timed_blocks": block_stats([round(e / a.c4_steps * 1e3, 4) for e in r4["els"]])}
         del r4
 
+    # BASELINE.json's other configurations on this one GPU (scripts/run_qm9_3d.sh:10-31 hyper-parameters, hidden 256): a few
+    # graph-replayed training steps each, same harness as the headline (no CPU leg, no roofline): driver-visible ms per step.
+    others = None
+    if (world == 1 and use_graph and not a.no_other_configs and a.method == "egnn_equihnns" and a.flavour == "qm9"
+            and a.batch == 256):
+        others = {}
+        for label, (m_, b_, fl_, cfg_, what_) in {
+                "c0_mhnnm_b32": ("mhnnm", 32, "qm9", 10, "BASELINE configs[0]: QM9-like, --method mhnnm, batch 32 (the reference's CPU-runnable case, here on the GPU)"),
+                "c0_mhnnm_b256": ("mhnnm", 256, "qm9", 11, "configs[0]'s method at the headline's batch 256"),
+                "c2_equiformer_equihnns_b128": ("equiformer_equihnns", 128, "qm9", 3, "BASELINE configs[2]: QM9-like, --method equiformer_equihnns, batch 128"),
+                "c4_faformer_equihnns_b512": ("faformer_equihnns", 512, "pcqm", 5, "BASELINE configs[4]: Molecule3D / PCQM-like molecules, --method faformer_equihnns, batch 512 per GPU")}.items():
+            try:
+                r_ = timed_run(m_, b_, fl_, a.other_steps, 3, cfg_, blocks=3)
+                ms_ = r_["el"] / a.other_steps * 1e3
+                others[label] = {"workload": what_, "ms_per_step": round(ms_, 3), "value": round(b_ / ms_ * 1e3, 1), "unit": "molecules/s",
+                                 "steps": a.other_steps, "blocks_ms_per_step": [round(e / a.other_steps * 1e3, 3) for e in r_["els"]],
+                                 "final_loss": round(r_["loss"], 6), "launch": "hipGraph replay (padded static shapes)"}
+                r_["trainer"].close()
+                del r_
+            except Exception as exc:  # noqa: BLE001 -- a side measurement must not cost the headline line
+                others[label] = {"workload": what_, "error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.empty_cache()
+
     result = None
     if rank == 0:
         n_nodes = sum(b.num_nodes for b in host_batches) / a.pool
@@ -842,6 +878,8 @@ def main():
         }
         if index_info is not None:
             result["index_build"] = index_info
+        if others is not None:
+            result["other_configs"] = others
         if strong is not None:
             result["strong_scaling_c4"] = strong
         if coll is not None:
@@ -854,7 +892,7 @@ def main():
             result["roofline"]["traffic"] = traffic
             if traffic is not None:
                 result["roofline"]["traffic_source"] = src
-            pp = panel_prologues(a.method, a.batch, a.flavour) if "k_conv_f2" in per else None
+            pp = panel_prologues(a.method, a.batch, a.flavour, dev) if "k_conv_f2" in per else None
             if pp is not None:
                 # the aggregation work inside the panel launches, next to the stamped launches: bytes / time over both
                 rk = result["roofline"]
@@ -870,7 +908,7 @@ def main():
                         "achieved": round(gbs, 1), "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "us_per_step": round(us_in + us_pp, 1), "alg_bytes_per_step": int(b_in + b_pp),
                         "what": "every node <-> hyperedge aggregation of the step: the stamped launches above (live) + the gather "
-                                "prologues of k_conv_f2 / k_conv_f3 / k_conv_b1 (stamped offline)"}
+                                "prologues of k_conv_f2 / k_conv_f3 / k_conv_b1 (in-kernel stamps of the -DPN_STAMPS build, measured in this run; see panel_prologue.source)"}
             if "k_gemm_x6" in per:      # the dense products that run on the bf16 matrix cores (csrc/gemm_x6.hip)
                 gx = per["k_gemm_x6"]
                 tf = gx["work"] / gx["us"] / 1e6

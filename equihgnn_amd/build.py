@@ -18,6 +18,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(PKG, "libequihgnn_hip.so")
+# measurement build of the panel kernels (-DPN_STAMPS: per-wavefront s_memtime stamps around the phases of a panel's life);
+# bench.py loads it BESIDE the product library to time the aggregation prologues that have no launch of their own
+STAMPS_LIB = os.path.join(PKG, "libequihgnn_panel_stamps.so")
 ARCH = "gfx950"
 
 
@@ -33,9 +36,9 @@ def sources():
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMPS_LIB):
         return True
-    t = os.path.getmtime(LIB)
+    t = min(os.path.getmtime(LIB), os.path.getmtime(STAMPS_LIB))
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(INCLUDE, "*.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -67,6 +70,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    cmd = [hipcc, *common, "-shared", "-DPN_STAMPS", os.path.join(CSRC, "panel.hip"), os.path.join(CSRC, "api.hip"), "-o", STAMPS_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -26,16 +26,20 @@ from equihgnn_amd.index import HyperIndex
 HBM_PEAK_GBS = 8000.0
 
 
-def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else None
-    method, batch, flavour, C = "egnn_equihnns", 256, "qm9", 256
-    so = os.path.join(os.environ.get("TMPDIR", "/tmp"), "libpanel_stamps.so")
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DPN_STAMPS",
-                           "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "equihgnn_amd", "csrc"),
-                           os.path.join(ROOT, "equihgnn_amd", "csrc", "panel.hip"), os.path.join(ROOT, "equihgnn_amd", "csrc", "api.hip"), "-o", so])
+def measure(method="egnn_equihnns", batch=256, flavour="qm9", C=256, dev=None, verbose=False):
+    """The three prologues on the index of one synthetic batch of the workload, through the stamped build of the panel kernels
+    (equihgnn_amd/libequihgnn_panel_stamps.so, built by equihgnn_amd.build next to the product library; compiled here into
+    TMPDIR when it is missing and hipcc is at hand).  Returns the dict bench.py reports."""
+    from equihgnn_amd import build as _build
+    so = _build.STAMPS_LIB
+    if not os.path.exists(so):
+        so = os.path.join(os.environ.get("TMPDIR", "/tmp"), "libpanel_stamps.so")
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DPN_STAMPS",
+                               "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "equihgnn_amd", "csrc"),
+                               os.path.join(ROOT, "equihgnn_amd", "csrc", "panel.hip"), os.path.join(ROOT, "equihgnn_amd", "csrc", "api.hip"), "-o", so])
     L = ctypes.CDLL(so)
     L.hg_conv_panel.argtypes = hip.SIGNATURES["hg_conv_panel"][1]
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda:0") if dev is None else dev
     host = synth_batch(batch, 2000, flavour)
     b = pad_batch(host, *bucket_sizes(host.num_nodes, host.num_hyperedges, host.nnz)).to(dev)
     ix = HyperIndex.from_batch(b)
@@ -92,7 +96,8 @@ def main():
         res[name] = {"prologue_cycles": round(cyc), "shader_clock_mhz": round(clock), "prologue_us": round(us, 2),
                      "alg_bytes_per_launch": int(alg_bytes), "achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "launches_per_step": 3, "what": what}
-        print(f"{name:12s} {cyc:8.0f} cycles = {us:6.2f} us  {alg_bytes / 1e6:7.2f} MB  {gbs:7.1f} GB/s  {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
+        if verbose:
+            print(f"{name:12s} {cyc:8.0f} cycles = {us:6.2f} us  {alg_bytes / 1e6:7.2f} MB  {gbs:7.1f} GB/s  {gbs / HBM_PEAK_GBS:.3f} of 8 TB/s")
 
     # ---- F2: hbar[e] = mean over the hyperedge's nodes of h1n (stamps 0 -> 1: gather, mean, hbar store, A image) -------------
     h1n, hbar, qb = rn(N, C), new(M), new(M)
@@ -133,6 +138,12 @@ def main():
            "kernels": res,
            "all": {"us_per_step": round(tot_us, 2), "achieved": round(tot_b / tot_us / 1e3, 1),
                    "frac": round(tot_b / tot_us / 1e3 / HBM_PEAK_GBS, 4)}}
+    return out
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else None
+    out = measure(verbose=True)
     print(json.dumps(out["all"]))
     if out_path:
         with open(out_path, "w") as f:
