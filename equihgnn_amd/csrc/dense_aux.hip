@@ -62,6 +62,7 @@ struct ColsumEntry {
     const int* rowptr;
     float* part;
     int64_t R;
+    int64_t ld;          // floats between rows of x (>= C: the entry may be the leading C columns of a wider matrix)
     int C;
     int mode;
     float scale;
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) k_colsum_partial_batch(ColsumBatch b) {
 #pragma unroll
     for (int i = 0; i < CS_ROWS / 4; ++i) {
         const int64_t r = r0 + ty + 4 * i;
-        v[i] = (live && r < en.R) ? *reinterpret_cast<const float4*>(en.x + r * en.C + c) : f4_zero();
+        v[i] = (live && r < en.R) ? *reinterpret_cast<const float4*>(en.x + r * en.ld + c) : f4_zero();
         if (en.mode != 0 && r < en.R) {
             const int len = en.rowptr[r + 1] - en.rowptr[r];
             const float w = (en.mode == 1) ? (len > 0 ? 1.f : 0.f) : (float)len;
@@ -212,7 +213,7 @@ extern "C" size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* 
     return total;
 }
 
-extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
+extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const int64_t* ld, const int32_t* const* rowptr,
                                    const int32_t* weight_mode, const float* scale, const int64_t* R,
                                    const int32_t* C, float* const* out, void* workspace, size_t workspace_bytes, void* stream_) {
     if (count < 0) return EQH_ERR_ARG;
@@ -224,6 +225,7 @@ extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const i
         if (R[j] < 0 || C[j] <= 0 || !out[j] || weight_mode[j] < 0 || weight_mode[j] > 2) return EQH_ERR_ARG;
         if (weight_mode[j] != 0 && !rowptr[j]) return EQH_ERR_ARG;
         if ((C[j] & 3) || (R[j] > 0 && (!x[j] || !eqh_aligned16(x[j])))) return EQH_ERR_ALIGN;
+        if (ld && (ld[j] < C[j] || (ld[j] & 3))) return EQH_ERR_ALIGN;
         if ((R[j] + CS_ROWS - 1) / CS_ROWS > 65535) return EQH_ERR_RANGE;
     }
     // workspace slices in entry order (as hg_colsum_batch_workspace_bytes sums them)
@@ -252,7 +254,8 @@ extern "C" int hg_colsum_batch_f32(int32_t count, const float* const* x, const i
         for (int i = 0; i < m; ++i) {
             const int j = order[g0 + i];
             const int chunks = (int)((R[j] + CS_ROWS - 1) / CS_ROWS);
-            b.e[i] = ColsumEntry{x[j], rowptr[j], parts[j], R[j], (int)C[j], (int)weight_mode[j], scale ? scale[j] : 1.f};
+            b.e[i] = ColsumEntry{x[j], rowptr[j], parts[j], R[j], ld ? ld[j] : (int64_t)C[j], (int)C[j], (int)weight_mode[j],
+                                 scale ? scale[j] : 1.f};
             if (R[j] > 0) ++live;
             if (chunks > max_chunks) max_chunks = chunks;
             const int cb = (C[j] / 4 + 63) / 64;

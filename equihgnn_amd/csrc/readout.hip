@@ -13,6 +13,14 @@
 // atoms and one partial slab of every parameter gradient; the slabs are summed by the library's fixed-order
 // reducer (deferred into the step's batched reduction when that is active).  No atomics; bitwise reproducible.
 //
+// Round 6, measured with tools/readout_stamps.py (-DRH_STAMPS: s_memtime stamps of every phase): 26 us of the launch's 34 are
+// the chain of phases itself -- pooling 5.4 us (rowptr -> rows -> LDS: two dependent round trips to memory), the layer products
+// 3.2 + 1.7, the four LayerNorm phases ~0.9 each, the backward products 3.7 + 2.1, the weight-gradient slabs 4.0 -- and none of
+// them shortens with fewer molecules per workgroup: the variant with FOUR molecules per workgroup (65 workgroups for a batch of
+// 256, two wavefronts pooling one molecule) took 36.2 us against 34.1 (same box; the step 1.179 vs 1.172 ms) and left 65
+// gradient slabs instead of 17 for the batched reduction (12.8 vs 9.4 us).  Dropped; in the graphed step the 17-workgroup launch
+// is where the NEXT batch's index build runs on the idle CUs (trainer.GraphedTrainStep, signal point "readout").
+//
 // MFMA operand convention (lane l: r = l & 15, q = l >> 4): A[m = r][k = q], B[k = q][n = r],
 // D[m = 4 q + g][n = r] in accumulator component g.  Four MFMAs share one float4 of K: the j-th of them
 // takes component j on both sides, i.e. k = 16 s + 4 q + j (a permutation of K, which a sum does not see).
@@ -21,6 +29,16 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef RH_STAMPS   // diagnostic build only (tools/readout_stamps.py): s_memtime stamps of the phases, wavefront 0 of every workgroup
+__device__ unsigned long long* rh_stamp_buf = nullptr;
+#define RH_STAMP(slot)                                                                                       \
+    do {                                                                                                     \
+        if (rh_stamp_buf && threadIdx.x == 0) rh_stamp_buf[(size_t)blockIdx.x * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RH_STAMP(slot) do { } while (0)
+#endif
 
 constexpr int RH_THREADS = 512;
 constexpr int RH_WAVES = RH_THREADS / 64;
@@ -235,6 +253,7 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * RH_ROWS;
     const bool train = target != nullptr;
+    RH_STAMP(0);
 
     // ---- requests issued first: the small parameter vectors (to LDS) and this wavefront's tile of W1
     float* sV = s_mem + L::VEC;
@@ -301,7 +320,9 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         if (i < 7 * H) sV[i] = vreg[k];
     }
     if (threadIdx.x == 0) sV[7 * H] = vb3_reg;
+    RH_STAMP(1);
     __syncthreads();
+    RH_STAMP(2);
 
     // ---- forward
     float4 bw2[H / 16];
@@ -310,16 +331,20 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         wt_tile_load<H>(w.w2, wave, lane, bw2);          // in flight during LayerNorm 1
     }
     __syncthreads();
+    RH_STAMP(3);
     relu_ln_rows<H>(sA1, vb1, vg1, vbe1, sXH1, sH1, sR1, LH, eps);
     __syncthreads();
+    RH_STAMP(4);
     float cw2[H / 4];
     if (has_h_tile) {
         wt_tile_mma<H>(sH1, LH, bw2, sA2, LH, wave, lane);
         if (train) w_cols_load<H, H>(w.w2, wave, lane, cw2);   // for d h1, three phases ahead
     }
     __syncthreads();
+    RH_STAMP(5);
     relu_ln_rows<H>(sA2, vb2, vg2, vbe2, sXH2, sH2, sR2, LH, eps);
     __syncthreads();
+    RH_STAMP(6);
     {
         constexpr int CPT = H / 32;
         const int row = threadIdx.x >> 5, l = threadIdx.x & 31;
@@ -341,6 +366,7 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         }
     }
     __syncthreads();
+    RH_STAMP(7);
     if (!train) return;
 
     // ---- backward
@@ -364,6 +390,7 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         }
     }
     __syncthreads();
+    RH_STAMP(8);
     float cw1a[H / 4], cw1b[H / 4];   // W1 columns of this wavefront's (up to) two C tiles, for dx
     const bool has_c0 = wave < C / 16, has_c1 = wave + RH_WAVES < C / 16;
     if (has_h_tile) w_cols_mma<H>(sDZ2, LH, cw2, sDH1, LH, wave, lane);
@@ -371,12 +398,16 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
     if (has_c1) w_cols_load<H, C>(w.w1, wave + RH_WAVES, lane, cw1b);
     ln_param_sums<H>(nullptr, vw3, sDy, sXH2, sDZ2, LH, slab.v2 + wg * 3 * H);
     outer_rows<H, H>(sDZ2, LH, sH1, LH, slab.w2 + wg * H * H, wave, lane);
+    RH_STAMP(9);
     __syncthreads();
+    RH_STAMP(10);
     relu_ln_bwd_rows<H>(sDH1, nullptr, nullptr, sA1, sXH1, vg1, sR1, sDZ1, LH);
     __syncthreads();
+    RH_STAMP(11);
     if (has_c0) w_cols_mma<H>(sDZ1, LH, cw1a, sDX, LX, wave, lane);
     if (has_c1) w_cols_mma<H>(sDZ1, LH, cw1b, sDX, LX, wave + RH_WAVES, lane);
     __syncthreads();
+    RH_STAMP(12);
 
     // ---- dX[n, :] = dx[molecule(n), :] (zero rows for the padding molecules b >= n_real: their dy is 0)
     for (int mi = 2 * wave; mi < 2 * wave + 2; ++mi) {
@@ -387,9 +418,11 @@ k_readout_mse(const float* __restrict__ X, const int* __restrict__ rowptr, int n
         for (int n = beg + sub; n < end; n += AP) *reinterpret_cast<float4*>(dX + (int64_t)n * C + 4 * cl) = g;
     }
 
+    RH_STAMP(13);
     // ---- the two large gradient slabs last: nothing in this kernel waits for them
     ln_param_sums<H>(sDH1, nullptr, nullptr, sXH1, sDZ1, LH, slab.v1 + wg * 3 * H);
     outer_rows<H, C>(sDZ1, LH, sX, LX, slab.w1 + wg * (int64_t)H * C, wave, lane);
+    RH_STAMP(14);
 
     // ---- loss = sum of the workgroups' partials / n_real, by the last workgroup to arrive, in workgroup order
     if (threadIdx.x == H) {   // the thread that stored this workgroup's partial: its store is ordered before its ticket
@@ -447,6 +480,12 @@ int rh_launch(const float* x, const int32_t* rowptr, int n_graphs, int n_real, c
 }
 
 }  // namespace
+
+#ifdef RH_STAMPS
+extern "C" int hg_readout_debug_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(rh_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? EQH_OK : EQH_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int hg_readout_mse_supported(int32_t C, int32_t H) {
     return (C == 64 || C == 128 || C == 256) && (H == 64 || H == 128);

@@ -237,7 +237,7 @@ SIGNATURES = {
                                      c_void_p, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "hg_colsum_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "hg_colsum_batch_workspace_bytes": (c_size_t, [c_int32, c_void_p, c_void_p]),
-    "hg_colsum_batch_f32": (c_int32, [c_int32] + [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "hg_colsum_batch_f32": (c_int32, [c_int32] + [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "hg_colsum_f32": (c_int32, [c_void_p, c_void_p, c_int32, c_float, c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                 c_size_t, c_void_p]),
     "hg_residual_mix_f32": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_float, c_int64, c_int32, c_void_p,

@@ -128,9 +128,14 @@ class _EgnnFeats(torch.autograd.Function):
                 else:
                     dw = d_ab.t() @ feats
             if ctx.needs_input_grad[2]:
-                db = colsum(d_ab, into=tw[1]) if tw[1] is not None else colsum(d_ab)
                 if tw[1] is not None:
+                    # b_cat = [b1 ; 0] (egnn_pack_weights): only its first half is a parameter's image -- the column sums of
+                    # the sender half of d_ab (20 MB at the BASELINE batch) would be thrown away by egnn_pack_weights_bwd
+                    half = d_ab.shape[1] // 2
+                    colsum(d_ab[:, :half], into=tw[1][:half])
                     db = None
+                else:
+                    db = colsum(d_ab)
         return dx, dw, db, dgamma, dbeta, None, None, None
 
 

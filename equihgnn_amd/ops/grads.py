@@ -145,7 +145,7 @@ def colsum_batch(entries):
     ws_bytes = L.hg_colsum_batch_workspace_bytes(n, R, C)
     ws = _workspace(max(ws_bytes, 16), dev)
     _DEFER["keep"].extend(en[0] for en in entries)
-    hip.check(L.hg_colsum_batch_f32(n, vp(*[en[0].data_ptr() for en in entries]),
+    hip.check(L.hg_colsum_batch_f32(n, vp(*[en[0].data_ptr() for en in entries]), i64(*[en[0].stride(0) for en in entries]),
                                     vp(*[(en[1].data_ptr() if en[1] is not None else None) for en in entries]),
                                     i32(*[int(en[2]) for en in entries]),
                                     (ctypes.c_float * n)(*[float(en[4]) for en in entries]), R, C,
@@ -247,11 +247,14 @@ def colsum(x, rowptr=None, weight_mode: int = 0, into=None, scale: float = 1.0):
             return r
         into.add_(r)
         return None
-    x = _f32c(x)
     R, C = x.shape
     if into is not None and _DEFER["active"] and DEFER_WGRAD:
+        # (the leading columns of a wider matrix are summed in place: the batched kernel takes a row stride)
+        if not (x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) >= C and x.data_ptr() % 16 == 0):
+            x = _f32c(x)
         _DEFER["colsum"].append((x, rowptr, weight_mode, into, scale))   # runs with all the others at defer_flush
         return None
+    x = _f32c(x)
     L = hip.lib()
     out = into if into is not None else torch.empty(C, dtype=torch.float32, device=x.device)
     ws_bytes = L.hg_colsum_workspace_bytes(R, C)

@@ -872,9 +872,10 @@ int hg_colsum_f32(const float* x, const int32_t* rowptr, int32_t weight_mode, fl
 int hg_residual_mix_f32(const float* x0, const float* bias, const int32_t* rowptr, int32_t weight_mode,
                         float alpha, int64_t R, int32_t C, float* out, void* stream);
 /* count row-weighted column sums in one launch, each ADDED to its out[i] (the bias gradients of a backward
- * pass, deferred to its end like the weight gradients).  scale may be NULL (all 1). */
+ * pass, deferred to its end like the weight gradients).  scale may be NULL (all 1).  ld[i] (NULL: C[i]): floats between
+ * consecutive rows of x[i], a multiple of 4 and >= C[i] -- an entry may be the leading C columns of a wider matrix. */
 size_t hg_colsum_batch_workspace_bytes(int32_t count, const int64_t* R, const int32_t* C);
-int hg_colsum_batch_f32(int32_t count, const float* const* x, const int32_t* const* rowptr,
+int hg_colsum_batch_f32(int32_t count, const float* const* x, const int64_t* ld, const int32_t* const* rowptr,
                         const int32_t* weight_mode, const float* scale, const int64_t* R, const int32_t* C,
                         float* const* out, void* workspace, size_t workspace_bytes, void* stream);
 int egnn_pack_weights_fwd(const float* w1, const float* b1, const float* w2, int32_t H, int32_t Hp,

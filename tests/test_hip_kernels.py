@@ -862,34 +862,50 @@ def test_layer_norm_rows_matches_float64_reference(R, C):
         assert err < 3e-5, (name, err)
 
 
-@pytest.mark.parametrize("C,H,B,n_real", [(256, 128, 37, 33), (64, 128, 16, 16), (128, 64, 5, 4), (256, 64, 257, 256)])
+@pytest.mark.parametrize("C,H,B,n_real", [(256, 128, 37, 33), (64, 128, 16, 16), (128, 64, 5, 4), (256, 64, 257, 256),
+                                          (256, 128, 600, 577), (128, 128, 11, 10)])
 def test_readout_mse_matches_float64_reference(C, H, B, n_real):
     """pool -> MLP(C,H,H,1; LN after ReLU) -> MSE over the first n_real molecules, fused (one launch for loss, dx and
     the ten parameter gradients) against the same head in float64 autograd; then the accumulate-in-place mode
     the trainer uses, eagerly and with the reductions deferred."""
     ops = _ops()
     from equihgnn_amd.layers import MLP
-    g = torch.Generator().manual_seed(C + H + B)
-    sizes = torch.randint(1, 30, (B,), generator=g)
-    sizes[min(2, B - 1)] = 0                               # a molecule without atoms pools to zero
-    rowptr64 = torch.cat((torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)))
+    # (B = 600: 38 workgroups; B = 11: molecules of up to 150 atoms -- several rounds of the pooling loop)
+    def case(seed):
+        g = torch.Generator().manual_seed(seed)
+        sizes = torch.randint(1, 150 if B == 11 else 30, (B,), generator=g)
+        sizes[min(2, B - 1)] = 0                               # a molecule without atoms pools to zero
+        rowptr64 = torch.cat((torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)))
+        x = torch.randn(int(rowptr64[-1]), C, generator=g)
+        y = torch.randn(B, generator=g)
+        torch.manual_seed(B)
+        mlp = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False)
+        for p in mlp.parameters():
+            p.data.add_(0.1 * torch.randn(p.shape, generator=g))
+        ref = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False).double()
+        ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
+        xd = x.double().requires_grad_(True)
+        batch = torch.repeat_interleave(torch.arange(B), sizes)
+        pooled = torch.zeros(B, C, dtype=torch.double).index_add_(0, batch, xd)
+        h, margin = pooled, float("inf")
+        for i in range(2):
+            pre = ref.lins[i](h)
+            margin = min(margin, float(pre.detach().abs().min()))
+            h = torch.nn.functional.layer_norm(torch.relu(pre), (H,), ref.normalizations[i + 1].weight,
+                                               ref.normalizations[i + 1].bias, 1e-5)
+        out = ref.lins[2](h).view(-1)
+        return margin, (sizes, rowptr64, x, y, mlp, ref, xd, out)
+
+    # a ReLU input within fp32 rounding of zero has a different derivative in float32 and in float64 -- a finite jump of that
+    # molecule's gradient, not an error of the kernel (seen at B = 600: 1.7 % of the largest entry): take the first seed whose
+    # float64 pre-activations all keep 2e-5 from the kink
+    for seed in range(C + H + B, C + H + B + 200):
+        margin, packed = case(seed)
+        if margin >= 2e-5:
+            break
+    assert margin >= 2e-5
+    sizes, rowptr64, x, y, mlp, ref, xd, out = packed
     N = int(rowptr64[-1])
-    x = torch.randn(N, C, generator=g)
-    y = torch.randn(B, generator=g)
-    torch.manual_seed(B)
-    mlp = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False)
-    for p in mlp.parameters():
-        p.data.add_(0.1 * torch.randn(p.shape, generator=g))
-    ref = MLP(C, H, 1, 3, dropout=0.0, Normalization="ln", InputNorm=False).double()
-    ref.load_state_dict({k: v.double() for k, v in mlp.state_dict().items()})
-    xd = x.double().requires_grad_(True)
-    batch = torch.repeat_interleave(torch.arange(B), sizes)
-    pooled = torch.zeros(B, C, dtype=torch.double).index_add_(0, batch, xd)
-    h = pooled
-    for i in range(2):
-        h = torch.nn.functional.layer_norm(torch.relu(ref.lins[i](h)), (H,), ref.normalizations[i + 1].weight,
-                                           ref.normalizations[i + 1].bias, 1e-5)
-    out = ref.lins[2](h).view(-1)
     loss_ref = ((out[:n_real] - y[:n_real].double()) ** 2).mean()
     loss_ref.backward()
 
