@@ -592,6 +592,155 @@ PN_KERNEL(NW) k_panel_plain(const PanelPlain p) {
     PN_STAMP(5);
 }
 
+// ---- the STREAMING product: C = act(alpha A W + beta D + bias) for MANY rows, A [rows, K], W a packed K x N image -------------
+// (round 6; K, N <= 256: FAFormer's frame / edge Linears, [246 k x 256] . [256 x 256] and [1.97 M x 128] . [128 x 256] at the
+// Molecule3D batch, fa_former_layer.py:61-120,241-289 -- 53 % of that step ran in the tiled x6 GEMM at 0.3-0.4 of its peak, its
+// staging wavefronts and its multiplying wavefronts taking turns on the same SIMDs.)  One PERSISTENT workgroup per CU walks its
+// panels; the weight image stays in the XCD's L2 and streams into registers exactly as in the one-panel kernels, and what made
+// those cost 6.3 us per panel against 2.6 us of MFMAs -- the row prologue and epilogue, exposed once per launch -- is hidden:
+// TWO A images, the next panel's rows requested before the MFMA loop and split into the idle image right behind it, so a panel
+// costs its MFMA loop + one image build (~100 VALU instructions per wavefront) + the epilogue's LDS round trip.
+// Two ROLES, as in gemm_x6.hip -- on gfx950 a wavefront's loads AND stores retire in order behind one counter (vmcnt), so a
+// multiplying wavefront that also fetched the next panel's rows or stored the last panel's results would wait for HBM before
+// every weight fragment from L2 (the first version of this kernel did: 8.7 us per panel).  Wavefronts 0-7 only stream weight
+// fragments and multiply; wavefronts 8-15 (the ROW wavefronts) run the previous panel's epilogue out of the staging tile and
+// build the next panel's A image in the meantime, with their rows requested two panels ahead.  Two barriers per panel.
+#ifdef PN_STAMPS
+__device__ int pn_debug_flags = 0;     // diagnostic build only: 1 = no result stores, 2 = every panel re-reads the first panel's rows
+#define PS_FLAG(bit) (pn_debug_flags & (bit))
+#else
+#define PS_FLAG(bit) 0
+#endif
+#ifdef PN_STAMPS
+#define PS_STAMP(slot)                                                                                                  \
+    do {                                                                                                                \
+        if (pn_stamp_buf && (threadIdx.x & 63) == 0 && it == 3)                                                          \
+            pn_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PS_STAMP(slot) do { } while (0)
+#endif
+template <int K, int N>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_panel_stream(const PanelPlain p, int n_panels) {
+    constexpr int NW = 8, KS = K / 16, NT = N / 32, LDS_LD = N + 4;
+    static_assert(NT >= 1 && NT <= NW && K % 64 == 0 && N % 64 == 0, "one column tile per multiplying wavefront; whole row-tile quads");
+    __shared__ uint4 s_img[2][3 * KS * 64];
+    __shared__ float s_stg[PN_ROWS * LDS_LD];
+    const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+    const bool row_role = wave_all >= NW;                 // wavefront-uniform
+    const int wave = wave_all & (NW - 1);
+    const int step = (int)gridDim.x, first = (int)blockIdx.x;
+    if (row_role) {
+        // the row wavefronts' few instructions go in front of the multipliers' MFMA streams at the issue port (priority, then
+        // age: at equal priority a panel's image build took 6.7 k cycles for ~100 VALU instructions per wavefront)
+        __builtin_amdgcn_s_setprio(3);
+        const RtPos<NW> L(0, PN_ROWS, wave, lane);        // lane constants (local row, column quad) of the row-tile layout
+        auto rowc = [&](int pnl) {                        // this lane's (clamped) row of panel pnl; panels past the end re-read the last
+            if (PS_FLAG(2)) pnl = first;
+            const int r = (pnl < n_panels ? pnl : n_panels - 1) * PN_ROWS + L.lrow;
+            return r < p.rows ? r : p.rows - 1;
+        };
+        // the epilogue of one panel out of the staging tile, one float4 column group at a time (the row role shares the
+        // kernel's 128-register budget with the multiplying role: whole row tiles of a, d and the bias spilled)
+        // the epilogue of one panel out of the staging tile.  The bias is loaded ONCE (the same columns for every panel: fetched
+        // per panel and per column group, each load sat in front of its use -- 4 x an L2 round trip per panel); the addend's
+        // rows, when there is one, are requested before the staging tile is read
+        RowTile<N, NW> bv;
+        if (p.bias) rt_load_vec<N, NW>(bv, p.bias, L.c4);
+        else rt_zero<N, NW>(bv);
+        auto epilogue = [&](int pnl, const RtPos<NW>& L) {
+            const int prow = pnl * PN_ROWS + L.lrow;
+            const bool live = prow < p.rows;
+            const int prc = live ? prow : p.rows - 1;
+            RowTile<N, NW> a;
+            if (p.D) {
+                RowTile<N, NW> d;
+                rt_load<N, NW>(d, p.D, p.ldd, prc, L.c4);
+                rt_load<N, NW>(a, s_stg, LDS_LD, L.lrow, L.c4);
+#pragma unroll
+                for (int j = 0; j < PnShape<N, NW>::NJ; ++j) {
+                    a.v[j].x = fmaf(p.beta, d.v[j].x, p.alpha * a.v[j].x); a.v[j].y = fmaf(p.beta, d.v[j].y, p.alpha * a.v[j].y);
+                    a.v[j].z = fmaf(p.beta, d.v[j].z, p.alpha * a.v[j].z); a.v[j].w = fmaf(p.beta, d.v[j].w, p.alpha * a.v[j].w);
+                }
+            } else {
+                rt_load<N, NW>(a, s_stg, LDS_LD, L.lrow, L.c4);
+#pragma unroll
+                for (int j = 0; j < PnShape<N, NW>::NJ; ++j) {
+                    a.v[j].x *= p.alpha; a.v[j].y *= p.alpha; a.v[j].z *= p.alpha; a.v[j].w *= p.alpha;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PnShape<N, NW>::NJ; ++j) {
+                f4_add(a.v[j], bv.v[j]);
+                if (p.relu) { a.v[j].x = fmaxf(a.v[j].x, 0.f); a.v[j].y = fmaxf(a.v[j].y, 0.f); a.v[j].z = fmaxf(a.v[j].z, 0.f); a.v[j].w = fmaxf(a.v[j].w, 0.f); }
+            }
+            if (live && !PS_FLAG(1)) rt_store<N, NW>(a, p.Cout, p.ldc, prow, L.c4);
+        };
+        RowTile<K, NW> xa, xb;                            // rows of the panels at distance 1 and 2
+        rt_load<K, NW>(xa, p.A, p.lda, rowc(first), L.c4);
+        rt_load<K, NW>(xb, p.A, p.lda, rowc(first + step), L.c4);
+        rt_a_put<K, NW, KS>(xa, s_img[0], L.lrow, L.c);
+        xa = xb;
+        rt_load<K, NW>(xb, p.A, p.lda, rowc(first + 2 * step), L.c4);
+        __syncthreads();                                  // (A) image of the first panel is in place
+        int cur = 0, last = first;
+        [[maybe_unused]] int it = -1;
+        for (int pnl = first; pnl < n_panels; pnl += step) {
+            ++it;
+            PS_STAMP(0);
+            // (the lane index is laundered once per panel: the swizzled LDS addresses of a panel's life depend on the lane only,
+            // and hoisted out of this loop -- dozens of them -- they overflowed the 128-register budget into scratch)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const RtPos<NW> L(0, PN_ROWS, wave, ln);
+            // while the multipliers work on panel pnl: the NEXT panel's image, then the PREVIOUS panel's epilogue
+            if (pnl + step < n_panels) rt_a_put<K, NW, KS>(xa, s_img[cur ^ 1], L.lrow, L.c);
+            PS_STAMP(1);
+            xa = xb;
+            rt_load<K, NW>(xb, p.A, p.lda, rowc(pnl + 3 * step), L.c4);
+            if (pnl != first) epilogue(pnl - step, L);
+            PS_STAMP(2);
+            __syncthreads();                              // (B) staging read, next image written | MFMA loop done
+            PS_STAMP(3);
+            __syncthreads();                              // (A) staging of panel pnl written
+            PS_STAMP(4);
+            cur ^= 1;
+            last = pnl;
+        }
+        epilogue(last, L);
+        return;
+    }
+    // ---- multiplying wavefronts
+    const bool mul = wave < NT;
+    WStream<KS, 1, 1, NW> ws;
+    ws.init(0, p.W, mul ? wave : 0, lane);
+    __syncthreads();                                      // (A)
+    int cur = 0;
+    [[maybe_unused]] int it = -1;
+    for (int pnl = first; pnl < n_panels; pnl += step) {
+        ++it;
+        PS_STAMP(0);
+        int ln = lane;                                    // (laundered per panel: see the row role)
+        asm volatile("" : "+v"(ln));
+        // ... and the weight stream's base: the 48 fragment addresses of a panel (1 KB apart: beyond the immediate offset of a
+        // load) are loop-invariant, and hoisted they are 96 registers -- spilled, each reload then sat, with a vmcnt(0), in
+        // front of its fetch: 12.9 us per panel)
+        asm volatile("" : "+v"(ws.base[0][0]));
+        ws.prime();
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[1][1];
+        acc_zero<1, 1>(acc);
+        if (mul) panel_mma<KS, 1, 1, NW>(s_img[cur], ws, acc, ln);
+        PS_STAMP(2);
+        __syncthreads();                                  // (B)
+        PS_STAMP(3);
+        if (mul) acc_to_staging<1, NW, LDS_LD>(s_stg, acc[0], wave, ln);
+        __syncthreads();                                  // (A)
+        PS_STAMP(4);
+        cur ^= 1;
+    }
+}
+
 // Measurement aid (EQH_PANEL_PAIR=1, C = 256): the plain product as a COLUMN-SPLIT PAIR -- two workgroups of four
 // wavefronts per 32-row panel, blockIdx.y owning 128 of the 256 output columns: half the weight image (192 KB) and half the
 // MFMAs (96 per SIMD) per workgroup, twice the workgroups.  Each half still needs the panel's whole rows as its A image (K =
@@ -1408,6 +1557,9 @@ extern "C" int hg_panel_debug_stamps(void* buf) {
     unsigned long long* q = static_cast<unsigned long long*>(buf);
     return hipMemcpyToSymbol(HIP_SYMBOL(pn_stamp_buf), &q, sizeof(q)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
 }
+extern "C" int hg_panel_debug_flags(int flags) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(pn_debug_flags), &flags, sizeof(flags)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
 #endif
 
 extern "C" size_t hg_panel_pack_bytes(int32_t K, int32_t N) {
@@ -1437,6 +1589,37 @@ extern "C" int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* st
         hipLaunchKernelGGL(k_panel_pack, dim3((units + 3) / 4), dim3(256), 0, stream, b);
         EQH_CHECK_LAUNCH();
     }
+    return EQH_OK;
+}
+
+extern "C" int hg_panel_stream_supported(int32_t K, int32_t N) {
+    return (K == 64 || K == 128 || K == 256) && (N == 128 || N == 256);
+}
+
+extern "C" int hg_panel_stream_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t K, int32_t N, const void* wpack, float alpha,
+                                        const float* d, int64_t ldd, float beta, const float* bias, int32_t relu, float* c, int64_t ldc,
+                                        void* stream_) {
+    if (rows < 0 || !a || !wpack || !c) return EQH_ERR_ARG;
+    if (!hg_panel_stream_supported(K, N)) return EQH_ERR_ARG;
+    if ((lda & 3) || (ldc & 3) || (d && (ldd & 3)) || !eqh_aligned16(a) || !eqh_aligned16(c) || !eqh_aligned16(d) ||
+        !eqh_aligned16(bias) || !eqh_aligned16(wpack))
+        return EQH_ERR_ALIGN;
+    if (rows >= ((int64_t)1 << 31) - 64) return EQH_ERR_RANGE;
+    if (rows == 0) return EQH_OK;
+    PanelPlain p{a, lda, (int)rows, static_cast<const uint4*>(wpack), alpha, beta, d, ldd, bias, relu, c, ldc};
+    const int n_panels = (int)((rows + PN_ROWS - 1) / PN_ROWS);
+    static const int n_cu = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        return n;
+    }();
+    const dim3 grid((unsigned)(n_panels < n_cu ? n_panels : n_cu)), block(1024);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define PN_STREAM(K_, N_) if (K == K_ && N == N_) hipLaunchKernelGGL((k_panel_stream<K_, N_>), grid, block, 0, stream, p, n_panels)
+    PN_STREAM(256, 256); else PN_STREAM(128, 256); else PN_STREAM(64, 256);
+    else PN_STREAM(256, 128); else PN_STREAM(128, 128); else PN_STREAM(64, 128);
+#undef PN_STREAM
+    EQH_CHECK_LAUNCH();
     return EQH_OK;
 }
 

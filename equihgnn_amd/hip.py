@@ -76,6 +76,9 @@ SIGNATURES = {
     "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),
     "hg_panel_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_float, c_void_p, c_int64, c_float,
                                     c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
+    "hg_panel_stream_supported": (c_int32, [c_int32, c_int32]),
+    "hg_panel_stream_gemm_f32": (c_int32, [c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p, c_float, c_void_p, c_int64, c_float,
+                                           c_void_p, c_int32, c_void_p, c_int64, c_void_p]),
     "hg_small_mm_batch": (c_int32, [c_int32, ctypes.POINTER(HgSmallMM), c_void_p]),
     "hg_gemm_x6_workspace_bytes": (c_size_t, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32]),
     "hg_gemm_x6_batch": (c_int32, [c_int32, ctypes.POINTER(HgGemmProblem), c_int32, c_void_p, c_size_t, c_void_p]),

@@ -39,7 +39,8 @@ from .products import (  # noqa: F401
     X6_MIN_OUTPUTS, X6_MAX_K, X6_DEEP_ROWS, X6_WGRAD_OUTPUTS, X6_WGRAD_ROWS, USE_X6, _x6_ok, mm_nt, mm_nn, small_mm_batch,
 )
 from .panel import (  # noqa: F401
-    PANEL_WIDTHS, panel_supported, panel_pack, panel_pack_bytes, panel_gemm, conv_panel, conv_panel_slab,
+    PANEL_WIDTHS, panel_supported, panel_pack, panel_pack_bytes, panel_gemm, panel_stream_gemm, panel_stream_supported,
+    conv_panel, conv_panel_slab,
 )
 from .grads import (  # noqa: F401
     GradFan, _FanSource, fanout, WGRAD_ON_SIDE_STREAM, _WGRAD_STREAMS, wgrad_stream, join_wgrad_stream,

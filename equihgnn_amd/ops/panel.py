@@ -84,6 +84,33 @@ def panel_gemm(a, wpack, C: int, alpha: float = 1.0, d=None, beta: float = 1.0, 
     return out
 
 
+def panel_stream_supported(K: int, N: int) -> bool:
+    return bool(hip.lib().hg_panel_stream_supported(int(K), int(N)))
+
+
+def panel_stream_gemm(a, w, trans_b: bool = True, alpha: float = 1.0, d=None, beta: float = 1.0, bias=None, relu: bool = False, out=None):
+    """act(alpha * a @ op(w) + beta * d + bias) for MANY rows a [rows, K] and a small weight (``trans_b``: w [N, K], an
+    nn.Linear weight used as x W^T; else w [K, N], an input gradient dY W), K in {64, 128, 256}, N in {128, 256}: the weight is
+    packed into bf16 planes (one launch) and the persistent row-panel kernel streams the rows (hg_panel_stream_gemm_f32)."""
+    a = _row_view(a, "panel_stream_gemm: a")
+    rows, K = a.shape
+    N = w.shape[0] if trans_b else w.shape[1]
+    if (w.shape[1] if trans_b else w.shape[0]) != K or not panel_stream_supported(K, N):
+        raise ValueError(f"panel_stream_gemm: a [{rows}, {K}] x weight {tuple(w.shape)} (trans_b={trans_b}) is not a supported shape")
+    (img,) = panel_pack([(w, bool(trans_b))])
+    if out is None:
+        out = torch.empty((rows, N), dtype=torch.float32, device=a.device)
+    if d is not None and d is not out:
+        d = _row_view(d, "panel_stream_gemm: d")
+    if bias is not None:
+        bias = bias.detach().contiguous()
+    hip.check(hip.lib().hg_panel_stream_gemm_f32(_ptr(a), a.stride(0), rows, K, N, _ptr(img), float(alpha),
+                                                 _ptr(d) if d is not None else None, d.stride(0) if d is not None else 0, float(beta),
+                                                 _ptr(bias) if bias is not None else None, 1 if relu else 0, _ptr(out), out.stride(0),
+                                                 _stream(a.device)), "hg_panel_stream_gemm_f32")
+    return out
+
+
 _CP_PTRS = ("in0", "in1", "in2", "in3", "rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
             "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2", "acc_out", "dbias", "dgamma", "dbeta",
             "dbias2", "dgamma2", "dbeta2", "g_inc", "be_inc", "out6")

@@ -108,8 +108,39 @@ def gemm_batch(problems):
     return outs
 
 
+# Products of MANY rows with a small weight (K, N <= 256): the persistent row-panel kernel (csrc/panel.hip, k_panel_stream:
+# weights pre-split once per call and streamed from L2, two A images, separate multiplying and row wavefronts) as an alternative
+# to the tiled x6 kernel.  OFF by default (EQH_PANEL_STREAM=1 turns it on): measured in round 6 it is within +-15 % of x6 --
+# [246 k x 256].[256 x 256] 237-258 against 222 us, [1.97 M x 128].[128 x 256] 1121-1168 against 982-1025, [246 k x 64].[64 x 256]
+# dy W 87 against 103 -- because with all 256 CUs streaming the same 384 KB image every panel the XCD's L2 (2 KB/clk) is asked
+# for exactly its peak: the MFMA loop takes 9.5-11.7 k cycles per panel against 6.9 k on the 148 CUs of the one-panel kernels
+# (tools/stream_stamps.py; profiles/r06_ab_runs.txt).
+STREAM_MIN_ROWS = int(os.environ.get("EQH_STREAM_MIN_ROWS", 32768))
+USE_PANEL_STREAM = os.environ.get("EQH_PANEL_STREAM") == "1"
+
+
+def _stream_ok(a, b, trans_a, trans_b, out, d, mean8) -> bool:
+    if not USE_PANEL_STREAM or trans_a or mean8 is not None or a.dim() != 2 or b.dim() != 2 or a.shape[0] < STREAM_MIN_ROWS:
+        return False
+    K = a.shape[1]
+    N = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != K or N != 256 or K not in (64, 128, 256):
+        return False
+    for t in (out, d):
+        if t is not None and not gemm_out_ok(t):
+            return False
+    return a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and b.stride(-1) == 1 and b.stride(0) % 4 == 0
+
+
 def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None, mean8=None):
-    """One GEMM through hg_gemm_x6_batch (see GemmProblem)."""
+    """One GEMM through hg_gemm_x6_batch (see GemmProblem) -- or, many rows against a small weight, through the streaming
+    row-panel kernel (panel_stream_gemm)."""
+    if _stream_ok(a, b, trans_a, trans_b, out, d, mean8):
+        from .panel import panel_stream_gemm
+        M, K = a.shape
+        N = b.shape[0] if trans_b else b.shape[1]
+        return timed("k_panel_stream", 2 * M * N * K,
+                     lambda: panel_stream_gemm(a, b, trans_b, alpha=alpha, d=d, beta=beta, bias=bias, relu=relu, out=out))
     return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out, mean8)])[0]
 
 

@@ -157,6 +157,14 @@ int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* stream);
 int hg_panel_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t C, const void* wpack, float alpha,
                       const float* d, int64_t ldd, float beta, const float* bias, int32_t relu, float* c, int64_t ldc,
                       void* stream);
+/* hg_panel_stream_gemm_f32: the same product for MANY rows and a rectangular weight -- a [rows, K] (lda), B the packed K x N
+ * image (hg_panel_pack), K in {64, 128, 256}, N in {128, 256} (hg_panel_stream_supported): one persistent workgroup per CU walks
+ * 32-row panels with two A images in LDS (the next panel's rows are fetched and split behind the current panel's MFMA loop).
+ * Stands where the reference has F.linear on ~10^5 .. 10^6 rows (fa_former_layer.py:61-120,241-289) and its input gradient. */
+int hg_panel_stream_supported(int32_t K, int32_t N);
+int hg_panel_stream_gemm_f32(const float* a, int64_t lda, int64_t rows, int32_t K, int32_t N, const void* wpack, float alpha,
+                             const float* d, int64_t ldd, float beta, const float* bias, int32_t relu, float* c, int64_t ldc,
+                             void* stream);
 
 /* One application of the merged MHNNSConv (conv.py:169-182; layers.MHNNSConv._forward_merged) as panel stages: each launch
  * takes panels of 32 rows through one to four [C x C] products with the row-wise work between them (bias, ReLU, LayerNorm and

@@ -1939,6 +1939,38 @@ def test_small_mm_batch_products_riders_and_accumulation():
 
 
 # ---- row-panel kernels (csrc/panel.hip) ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,N,rows", [(256, 256, 40000), (128, 256, 33000), (64, 256, 8229), (256, 128, 9999), (256, 256, 31), (128, 128, 70000)])
+def test_panel_stream_gemm_matches_float64(K, N, rows):
+    """hg_panel_stream_gemm_f32 (persistent workgroups, two A images): x @ W.T with bias + ReLU, and dy @ W accumulated onto an
+    addend, against float64 -- F.linear over ~10^5 rows and its input gradient (fa_former_layer.py:61-120); the error of an fp32
+    dot product (the library's fp32-MFMA GEMM is compared on the same operands)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + N + rows)
+    x = torch.randn(rows, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV)          # nn.Linear weight [N, K]
+    wt = (torch.randn(K, N, generator=g) * K ** -0.5).to(DEV)         # used as dy @ W
+    bias = torch.randn(N, generator=g).to(DEV)
+    d = torch.randn(rows, N, generator=g).to(DEV)
+    assert ops.panel_stream_supported(K, N)
+    got = ops.panel_stream_gemm(x, w, True, bias=bias, relu=True)
+    ref = torch.relu(x.double() @ w.double().t() + bias.double())
+    lib = torch.relu(torch.nn.functional.linear(x, w, bias))
+    e_got, e_lib = float((got.double() - ref).abs().max()), float((lib.double() - ref).abs().max())
+    assert e_got <= max(2.0 * e_lib, 2e-6), (e_got, e_lib)
+    got2 = ops.panel_stream_gemm(x, wt, False, alpha=0.5, d=d, beta=2.0, out=d.clone())
+    ref2 = 0.5 * (x.double() @ wt.double()) + 2.0 * d.double()
+    lib2 = torch.addmm(d, x, wt, beta=2.0, alpha=0.5)
+    e_got, e_lib = float((got2.double() - ref2).abs().max()), float((lib2.double() - ref2).abs().max())
+    assert e_got <= max(2.0 * e_lib, 4e-6), (e_got, e_lib)
+    # in place on the addend (the accumulating input gradient), strided output rows
+    wide = torch.zeros(rows, N + 64, device=DEV)
+    acc = wide[:, :N]
+    acc.copy_(d)
+    ops.panel_stream_gemm(x, wt, False, d=acc, out=acc)
+    assert float((acc.double() - (x.double() @ wt.double() + d.double())).abs().max()) <= max(2.0 * e_lib, 4e-6)
+    assert float(wide[:, N:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("C", [64, 128, 256])
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 1000, 4736])
 def test_panel_gemm_matches_float64(C, rows):
