@@ -577,6 +577,89 @@ extern "C" size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I) {
     return chunks > 1 ? (size_t)chunks * (size_t)O * (size_t)I * sizeof(float) : 16;
 }
 
+// ---- skinny weight gradient: dw[O x J] (+)= dy^T [O x K] . x [K x J] with J <= 16 ----------------------------------------------
+// (the m_i block of the EGNN node MLP's first Linear, egnn_layer.py:180-187: [512 x 16] from ~4.7 k rows.  The library ran it
+// as a 1-workgroup split-K product + a post-reduction, 19 us of a 1.1 ms step for 75 MFLOP.)  A workgroup owns 64 columns of dy
+// and a chunk of SK_ROWS rows; a lane owns one column and keeps the J sums in registers; the rows of x are the same for every
+// lane (scalar loads); the four wavefronts' sums meet in LDS in wavefront order, the chunks' partial results in a slab that the
+// step's (deferred) fixed-order reduction adds into dw: no atomics, bitwise reproducible.
+namespace {
+constexpr int SK_ROWS = 256, SK_J = 16;
+__global__ void __launch_bounds__(256) k_wgrad_skinny(const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ x, int64_t ld_x,
+                                                      int64_t K, int O, int J, float alpha, float* __restrict__ slab) {
+    __shared__ float s_part[3][SK_J][64];
+    __shared__ __attribute__((aligned(16))) float s_x[SK_ROWS][SK_J];     // the chunk's rows of x (zero beyond J / K): read as broadcasts
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int o = blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * SK_ROWS;
+    const int64_t r1 = r0 + SK_ROWS < K ? r0 + SK_ROWS : K;
+    const int nr = (int)(r1 - r0);
+    for (int i = threadIdx.x; i < SK_ROWS * SK_J; i += 256) {
+        const int r = i / SK_J, j = i - r * SK_J;
+        s_x[r][j] = (r < nr && j < J) ? x[(r0 + r) * ld_x + j] : 0.f;
+    }
+    float acc[SK_J];
+#pragma unroll
+    for (int j = 0; j < SK_J; ++j) acc[j] = 0.f;
+    constexpr int U = 8;                                   // rows in flight per wavefront
+    float a[U];
+    auto fetch = [&](int rl) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = (rl + u < nr && o < O) ? dy[(r0 + rl + u) * ld_dy + o] : 0.f;
+    };
+    fetch(wave * U);
+    __syncthreads();
+    for (int rl = wave * U; rl < nr; rl += 4 * U) {
+        float c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) c[u] = a[u];
+        fetch(rl + 4 * U);                                 // the next eight rows, behind this round's arithmetic
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rl + u < nr) {                             // wavefront-uniform
+#pragma unroll
+                for (int j4 = 0; j4 < SK_J / 4; ++j4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(&s_x[rl + u][4 * j4]);
+                    acc[4 * j4 + 0] = fmaf(c[u], xv.x, acc[4 * j4 + 0]); acc[4 * j4 + 1] = fmaf(c[u], xv.y, acc[4 * j4 + 1]);
+                    acc[4 * j4 + 2] = fmaf(c[u], xv.z, acc[4 * j4 + 2]); acc[4 * j4 + 3] = fmaf(c[u], xv.w, acc[4 * j4 + 3]);
+                }
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < SK_J; ++j) s_part[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && o < O) {
+        float* out = slab + ((int64_t)blockIdx.y * O + o) * J;
+        for (int j = 0; j < J; ++j)
+            out[j] = alpha * (((acc[j] + s_part[0][j][lane]) + s_part[1][j][lane]) + s_part[2][j][lane]);
+    }
+}
+}  // namespace
+
+extern "C" size_t hg_wgrad_skinny_workspace_bytes(int64_t K, int32_t O, int32_t J) {
+    if (K <= 0 || O <= 0 || J <= 0) return 0;
+    return (size_t)((K + SK_ROWS - 1) / SK_ROWS) * (size_t)O * (size_t)J * sizeof(float);
+}
+
+extern "C" int hg_wgrad_skinny_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t K, int32_t O, int32_t J,
+                                   float alpha, float* dw, int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                   void* stream_) {
+    if (K < 0 || O <= 0 || J <= 0 || J > SK_J || !dw || ldw < J || ld_dy < O || ld_x < J) return EQH_ERR_ARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (K == 0) return EQH_OK;                             // (nothing to add; a non-accumulating caller clears dw itself)
+    if (!dy || !x || !workspace) return EQH_ERR_ARG;
+    if (workspace_bytes < hg_wgrad_skinny_workspace_bytes(K, O, J)) return EQH_ERR_ARG;
+    const int chunks = (int)((K + SK_ROWS - 1) / SK_ROWS);
+    if (chunks > 65535) return EQH_ERR_RANGE;
+    float* slab = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(k_wgrad_skinny, dim3((O + 63) / 64, chunks), dim3(256), 0, stream, dy, ld_dy, x, ld_x, K, (int)O, (int)J, alpha, slab);
+    EQH_CHECK_LAUNCH();
+    return eqh_reduce_slabs2d_async(slab, chunks, O, J, dw, ldw, accumulate, stream);
+}
+
 extern "C" int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t I, float alpha,
                             float* dw, int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes,
                             void* stream_) {

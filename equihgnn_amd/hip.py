@@ -233,6 +233,9 @@ SIGNATURES = {
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "hg_wgrad_skinny_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "hg_wgrad_skinny_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64,
+                                      c_int32, c_void_p, c_size_t, c_void_p]),
     "hg_wgrad_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_float, c_void_p, c_int64, c_int32,
                                c_void_p, c_size_t, c_void_p]),
     "hg_wgrad_batch_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

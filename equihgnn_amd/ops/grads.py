@@ -314,6 +314,28 @@ def wgrad(dy2, x2, alpha: float = 1.0, into=None):
     return None if into is not None else out
 
 
+SKINNY_WGRAD = not os.environ.get("EQH_NO_SKINNY_WGRAD")
+
+
+def _wgrad_skinny(dy2, x2, tgt) -> bool:
+    """tgt [O x J] += dy2.T @ x2 for an input block of at most 16 columns (the m_i block of the EGNN node MLP) through
+    hg_wgrad_skinny_f32: one small launch + the step's deferred slab reduction instead of a split-K library product."""
+    if not (SKINNY_WGRAD and dy2.is_cuda and dy2.dim() == 2 and x2.dim() == 2 and x2.shape[1] <= 16 and dy2.shape[0] == x2.shape[0]
+            and dy2.dtype == torch.float32 and x2.dtype == torch.float32 and dy2.stride(1) == 1 and x2.stride(1) == 1
+            and tgt.stride(1) == 1 and dy2.shape[0] > 0):
+        return False
+    K, O = dy2.shape
+    J = x2.shape[1]
+    L = hip.lib()
+    ws_bytes = L.hg_wgrad_skinny_workspace_bytes(K, O, J)
+    ws = _workspace(max(ws_bytes, 16), dy2.device)
+    if _DEFER["active"]:
+        _DEFER["keep"].extend((dy2, x2))
+    hip.check(L.hg_wgrad_skinny_f32(_ptr(dy2), dy2.stride(0), _ptr(x2), x2.stride(0), K, O, J, 1.0, _ptr(tgt), tgt.stride(0), 1,
+                                    _ptr(ws), ws_bytes, _stream(dy2.device)), "hg_wgrad_skinny_f32")
+    return True
+
+
 def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
     """Weight gradient dy2.T @ x2 of a Linear over the column block [c0, c1) of ``weight``: added to the
     parameter's persistent accumulator (in place, or recorded for the batched launch of defer_flush) when there
@@ -324,7 +346,9 @@ def _linear_weight_grad(weight, c0, c1, dy2, x2, r0=None, r1=None):
         if r0 is not None:
             tgt = tgt[r0:r1]
         side = wgrad_stream(dy2.device) if WGRAD_ON_SIDE_STREAM else None
-        if side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
+        if side is None and _wgrad_skinny(dy2, x2, tgt):
+            pass
+        elif side is None and _wgrad_deferred(dy2, x2, 1.0, tgt):
             pass
         elif side is None and _wgrad_ok(dy2, x2):
             wgrad(dy2, x2, into=tgt)

@@ -1939,6 +1939,30 @@ def test_small_mm_batch_products_riders_and_accumulation():
 
 
 # ---- row-panel kernels (csrc/panel.hip) ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,O,J", [(4736, 512, 16), (300, 128, 16), (1, 64, 4), (70001, 130, 9)])
+def test_skinny_weight_gradient_matches_float64(K, O, J):
+    """hg_wgrad_skinny_f32: the [O x J] block dy^T x (J <= 16; the m_i columns of the EGNN node MLP's first Linear,
+    egnn_layer.py:180-187) added into a column block of a wider accumulator, eagerly and with the reductions deferred."""
+    ops = _ops()
+    from equihgnn_amd.ops import grads
+    g = torch.Generator().manual_seed(K + O + J)
+    dy = torch.randn(K, O + 8, generator=g).to(DEV)[:, :O]          # strided rows
+    x = torch.randn(K, J, generator=g).to(DEV)
+    ref = dy.double().t() @ x.double()
+    for deferred in (False, True):
+        wide = torch.full((O, 280), 0.25, device=DEV)
+        tgt = wide[:, 256:256 + J]
+        if deferred:
+            ops.defer_begin(DEV)
+        assert grads._wgrad_skinny(dy, x, tgt)
+        if deferred:
+            ops.defer_flush(DEV)
+        torch.cuda.synchronize()
+        err = float((tgt.double() - 0.25 - ref).abs().max())
+        assert err <= 3e-6 * max(1.0, float(ref.abs().max())) * max(1.0, (K / 4096) ** 0.5), (deferred, err)
+        assert float((wide[:, :256] - 0.25).abs().max()) == 0.0 and float((wide[:, 256 + J:] - 0.25).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("K,N,rows", [(256, 256, 40000), (128, 256, 33000), (64, 256, 8229), (256, 128, 9999), (256, 256, 31), (128, 128, 70000)])
 def test_panel_stream_gemm_matches_float64(K, N, rows):
     """hg_panel_stream_gemm_f32 (persistent workgroups, two A images): x @ W.T with bias + ReLU, and dy @ W accumulated onto an
