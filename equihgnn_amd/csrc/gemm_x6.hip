@@ -62,6 +62,8 @@ struct GxProb {
     int first_tile, tiles_n, n_tiles;   // n_tiles = row tiles x column tiles x splits
     int tiles_mn;                       // row tiles x column tiles
     int chunk_steps;                    // K steps (of 32) per split
+    const uint4* Bimg;                  // B pre-split into bf16 planes by hg_panel_pack, k_major form (image[k / 32][tile n / 32][k half][plane][lane]), or null
+    int b_ksteps, b_tiles;              //   its K / 16 and N / 32 (N padded up to a multiple of 32)
     float* slab;                        // splits > 1: [splits][M][N] partial products (alpha applied), else null
     const int64_t* drop_seed;           // frame-mean epilogue: c[m / 8, :] = mean over the 8 rows of dropout_p(alpha a b + bias)
     uint32_t drop_threshold;            //   p * 2^32 (0: no dropout)
@@ -205,6 +207,53 @@ struct LoadKS {
     }
 };
 
+// ---- operand ALREADY split into its three bf16 planes, in MFMA operand order (hg_panel_pack: the weight of a Linear, split once
+// per call instead of once per output-row tile -- two thirds of a stager's VALU work at the 128 x 256 tile): in the k_major
+// form of the image a K step of 32 is contiguous over all column tiles ([k / 32][tile][k half][plane][lane] x 16 bytes; with the
+// panel kernels' tile-major order the eight tiles of a step lay 48 KB apart -- one L2 channel group -- and the kernel ran at half
+// speed); the stagers copy it into the ring stage with the slot swizzle of slot_index (lane (h, r) of fragment (tile, k half)
+// -> slot h * 32 + (r ^ 2 q)).
+template <int R>
+struct LoadPre {
+    static constexpr int NB = R / 32, PER = NB * 384 / 256;
+    static_assert((NB * 384) % 256 == 0, "a K step of the image splits evenly over a stager group");
+    const uint4* base;
+    int step_stride;       // uint4 between two K steps of 32 in the image: all its column tiles x (2 k halves x 3 planes x 64 lanes)
+    int off[PER];          // this thread's elements of a K step: offset in the image at k step 0 (uint4) ...
+    int dst[PER];          // ... and slot in the ring stage
+    __device__ __forceinline__ void init(const uint4* img, int ksteps, int tiles, int col0) {
+        const int t = threadIdx.x & 255, tile0 = col0 >> 5;
+        base = img;
+        step_stride = tiles * 384;
+        (void)ksteps;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int id = t + 256 * i;
+            const int tile = id / 384, rem = id - tile * 384;       // rem = (k half * 3 + plane) * 64 + lane
+            const int kh = rem / 192, pl = (rem - kh * 192) >> 6, lane = rem & 63;
+            int gt = tile0 + tile;
+            gt = gt < tiles ? gt : tiles - 1;                        // tiles past N: products the epilogue does not store
+            off[i] = ((gt * 2 + kh) * 3 + pl) * 64 + lane;
+            const int h = lane >> 5, fr = lane & 31, q = 2 * kh + h;
+            dst[i] = ((pl * NB + tile) * 2 + kh) * 64 + h * 32 + (fr ^ (2 * q));
+        }
+    }
+    // (held as float4 like the other loaders' registers: with `uint4 v[PER]` -- or twelve named uint4 -- the compiler kept the
+    // struct in scratch memory, a scratch store behind every load, and the kernel ran at half the speed of the splitting stagers)
+    struct Regs { float4 v[PER]; };
+    __device__ __forceinline__ void fetch(Regs& r, int kt) const {
+        const float4* __restrict__ p = reinterpret_cast<const float4*>(base + (int64_t)kt * step_stride);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) r.v[i] = p[off[i]];
+    }
+    __device__ __forceinline__ void fetch_tail(Regs& r, int kt, int) const { fetch(r, kt); }    // (K % 32 == 0 on this path)
+    __device__ __forceinline__ void store(const Regs& r, uint4* __restrict__ s) const {
+        float4* __restrict__ d = reinterpret_cast<float4*>(s);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) d[dst[i]] = r.v[i];
+    }
+};
+
 template <int R, bool KS> struct Loader;
 template <int R> struct Loader<R, false> : LoadKC<R> {};
 template <int R> struct Loader<R, true> : LoadKS<R> {};
@@ -218,7 +267,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 // MT x NT: 32 x 32 MFMA tiles per multiplying wavefront; the four of them sit 2 x 2: block tile 64 MT x 64 NT
 // WR x WC: the multiplying wavefronts' grid (2 x 2; 2 x 4 and 4 x 2 for the 128 x 256 / 256 x 128 tiles, one workgroup per CU)
-template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS, int WR = 2, int WC = 2>
+template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS, int WR = 2, int WC = 2, bool B_PRE = false>
 __global__ void __launch_bounds__(64 * WR * WC + GX_STAGERS, MINW)
 k_gemm_x6(const GxBatch batch) {
     constexpr int BM = 32 * WR * MT, BN = 32 * WC * NT;
@@ -254,11 +303,12 @@ k_gemm_x6(const GxBatch batch) {
     GX_STAMP(0);
     if (threadIdx.x >= NMT) {
         using LA = Loader<BM, A_KS>;
-        using LB = Loader<BN, B_KS>;
+        using LB = std::conditional_t<B_PRE, LoadPre<BN>, Loader<BN, B_KS>>;
         LA la;
         LB lb;
         la.init(P.A, P.lda, m0, M);
-        lb.init(P.B, P.ldb, n0, N);
+        if constexpr (B_PRE) lb.init(P.Bimg, P.b_ksteps, P.b_tiles, n0);
+        else lb.init(P.B, P.ldb, n0, N);
         typename LA::Regs ra;
         typename LB::Regs rb;
         const int grp = ((int)threadIdx.x - NMT) >> 8;      // 0 or 1 (wavefront-uniform)
@@ -266,7 +316,7 @@ k_gemm_x6(const GxBatch batch) {
             if (w >= NS) return;
             if (kt0 + w < KT) {
                 la.fetch(ra, kt0 + w);
-                lb.fetch(rb, kt0 + w);
+                if constexpr (!B_PRE) lb.fetch(rb, kt0 + w);     // (the pre-split planes are fetched where they are staged: below)
             } else {
                 la.fetch_tail(ra, kt0 + w, rem);
                 lb.fetch_tail(rb, kt0 + w, rem);
@@ -275,8 +325,18 @@ k_gemm_x6(const GxBatch batch) {
         auto stage = [&](int w) {
             if (w >= NS) return;
             uint4* st = s_mem + (w % S) * (SA + SB);
-            LA::store(ra, st);
-            LB::store(rb, st + SA);
+            if constexpr (B_PRE) {
+                // planes from L2 straight through registers into the stage (held across the barrier, as the fp32 operands are, the
+                // twelve registers went to scratch memory -- a scratch store behind every load -- and the kernel ran at half speed);
+                // requested BEFORE the A tile is split, stored behind it
+                typename LB::Regs tb;
+                lb.fetch(tb, kt0 + w);
+                LA::store(ra, st);
+                lb.store(tb, st + SA);
+            } else {
+                LA::store(ra, st);
+                LB::store(rb, st + SA);
+            }
         };
         // tiles 0 .. S-2 before the first barrier (even tiles by group 0, odd ones by group 1), and the request for
         // tile S - 1, which is split during step 0
@@ -478,8 +538,14 @@ k_gemm_x6(const GxBatch batch) {
 }
 
 template <int MT, int NT, int S, int MINW, int WR = 2, int WC = 2>
-int launch(const GxBatch& b, bool a_ks, bool b_ks, hipStream_t stream) {
+int launch(const GxBatch& b, bool a_ks, bool b_ks, hipStream_t stream, bool b_pre = false) {
     const dim3 grid(b.total_tiles), block(64 * WR * WC + GX_STAGERS);
+    if (b_pre) {
+        if (a_ks) return EQH_ERR_ARG;
+        hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false, WR, WC, true>), grid, block, 0, stream, b);
+        EQH_CHECK_LAUNCH();
+        return EQH_OK;
+    }
     if (!a_ks && !b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false, WR, WC>), grid, block, 0, stream, b);
     else if (!a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, true, WR, WC>), grid, block, 0, stream, b);
     else if (a_ks && b_ks) hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, true, true, WR, WC>), grid, block, 0, stream, b);
@@ -607,9 +673,12 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     GxBatch b;
     b.n = n_problems;
     const bool a_ks = pr[0].trans_a != 0, b_ks = pr[0].trans_b == 0;
+    const bool b_pre = pr[0].b_packed != nullptr;
     for (int i = 0; i < n_problems; ++i) {
         const HgGemmProblem& q = pr[i];
-        if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || !q.b || !q.c) return EQH_ERR_ARG;
+        if (q.m < 0 || q.n <= 0 || q.k <= 0 || !q.a || (!q.b && !q.b_packed) || !q.c) return EQH_ERR_ARG;
+        if ((q.b_packed != nullptr) != b_pre) return EQH_ERR_ARG;                       // one B form per launch
+        if (b_pre && ((q.k & 31) || q.trans_a || !eqh_aligned16(q.b_packed))) return EQH_ERR_ARG;   // whole K steps of 32
         if ((q.trans_a != 0) != a_ks || (q.trans_b == 0) != b_ks) return EQH_ERR_ARG;   // one operand layout per launch
         if (q.m >= (1ll << 31) - 256) return EQH_ERR_RANGE;
         if (q.mean_rows != 0 && (q.mean_rows != 8 || (q.m & 7) || q.d || q.relu || q.trans_a || !(q.drop_p >= 0.f) || !(q.drop_p < 1.f) ||
@@ -617,8 +686,8 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
             return EQH_ERR_ARG;
         // float4 / float2 accesses: the contiguous extents and the row strides are multiples of 4 floats
         if ((q.n & 3) || (q.lda & 3) || (q.ldb & 3) || (q.ldc & 3) || (q.d && (q.ldd & 3))) return EQH_ERR_ALIGN;
-        if ((!a_ks && (q.k & 3)) || (a_ks && (q.m & 3)) || (!b_ks && (q.k & 3))) return EQH_ERR_ALIGN;
-        if (!eqh_aligned16(q.a) || !eqh_aligned16(q.b) || !eqh_aligned16(q.c) || !eqh_aligned16(q.d) || !eqh_aligned16(q.bias))
+        if ((!a_ks && (q.k & 3)) || (a_ks && (q.m & 3)) || (!b_pre && !b_ks && (q.k & 3))) return EQH_ERR_ALIGN;
+        if (!eqh_aligned16(q.a) || (!b_pre && !eqh_aligned16(q.b)) || !eqh_aligned16(q.c) || !eqh_aligned16(q.d) || !eqh_aligned16(q.bias))
             return EQH_ERR_ALIGN;
     }
     // the tile: 64 x 64 fills the chip at ~5 k-row batches; 128 x 64 amortises the operand split better; 128 x 128 (one
@@ -637,6 +706,9 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
         const HgGemmProblem& q = pr[i];
         GxProb& p = b.p[i];
         p.A = q.a; p.B = q.b; p.D = q.d; p.bias = q.bias; p.C = q.c;
+        p.Bimg = static_cast<const uint4*>(q.b_packed);
+        p.b_ksteps = q.k / 16;
+        p.b_tiles = (q.n + 31) / 32;
         p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc; p.ldd = q.ldd;
         p.M = (int)q.m; p.N = q.n; p.K = q.k;
         p.alpha = q.alpha; p.beta = q.beta;
@@ -671,11 +743,11 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     b.total_tiles = (int)first;
     if (first == 0) return EQH_OK;
     int rc;
-    if (id == 512) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream);
-    else if (id == 513) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream);
-    else if (id == 256) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream);
-    else if (id == 128) rc = launch<2, 1, 2, 6>(b, a_ks, b_ks, stream);   // 6 waves / SIMD = 2 blocks / CU
-    else rc = launch<1, 1, 3, 6>(b, a_ks, b_ks, stream);
+    if (id == 512) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream, b_pre);
+    else if (id == 513) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream, b_pre);
+    else if (id == 256) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream, b_pre);
+    else if (id == 128) rc = launch<2, 1, 2, 6>(b, a_ks, b_ks, stream, b_pre);   // 6 waves / SIMD = 2 blocks / CU
+    else rc = launch<1, 1, 3, 6>(b, a_ks, b_ks, stream, b_pre);
     if (rc) return rc;
     // split-K problems: c = beta * d + sum of the slabs, in slab order (bitwise reproducible); beta * d with d == c and
     // beta == 1 is the accumulating form the weight gradients use

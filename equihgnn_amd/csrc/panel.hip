@@ -73,6 +73,7 @@ struct PackItem {
     uint4* dst;
     int K, N, trans, kstep0, ksteps_total;
     int n_valid;         // columns n >= n_valid of B are zero (N padded up to a multiple of 32)
+    int k_major;         // image[k / 32][tile][k half][plane][lane] (gemm_x6.hip's pre-split B: a K step of ALL tiles contiguous)
 };
 constexpr int PN_MAXPACK = 32;
 struct PackBatch {
@@ -109,7 +110,9 @@ __global__ void __launch_bounds__(256) k_panel_pack(const PackBatch b) {
     split_pair(v[2], v[3], p0.y, p1.y, p2.y);
     split_pair(v[4], v[5], p0.z, p1.z, p2.z);
     split_pair(v[6], v[7], p0.w, p1.w, p2.w);
-    uint4* d = it.dst + ((int64_t)(tile * it.ksteps_total + it.kstep0 + kstep) * 3) * 64 + lane;
+    const int kg = it.kstep0 + kstep;
+    uint4* d = it.k_major ? it.dst + ((int64_t)(((kg >> 1) * (it.N >> 5) + tile) * 2 + (kg & 1)) * 3) * 64 + lane
+                          : it.dst + ((int64_t)(tile * it.ksteps_total + kg) * 3) * 64 + lane;
     d[0] = p0;
     d[64] = p1;
     d[128] = p2;
@@ -1581,7 +1584,7 @@ extern "C" int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* st
             const int total = q.ksteps_total > 0 ? q.ksteps_total : q.K / 16;
             if (q.kstep0 + q.K / 16 > total) return EQH_ERR_ARG;
             const int n_valid = (q.n_valid > 0 && q.n_valid < q.N) ? q.n_valid : q.N;
-            b.it[i] = PackItem{q.w, q.ld, static_cast<uint4*>(q.dst), q.K, q.N, q.trans ? 1 : 0, q.kstep0, total, n_valid};
+            b.it[i] = PackItem{q.w, q.ld, static_cast<uint4*>(q.dst), q.K, q.N, q.trans ? 1 : 0, q.kstep0, total, n_valid, q.k_major ? 1 : 0};
             b.first[i + 1] = b.first[i] + (q.K / 16) * (q.N / 32);
         }
         for (int i = b.n; i < PN_MAXPACK; ++i) { b.it[i] = b.it[0]; b.first[i + 1] = b.first[b.n]; }

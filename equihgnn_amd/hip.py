@@ -27,13 +27,13 @@ class HgGemmProblem(ctypes.Structure):
     _fields_ = [("a", c_void_p), ("lda", c_int64), ("b", c_void_p), ("ldb", c_int64), ("d", c_void_p), ("ldd", c_int64),
                 ("bias", c_void_p), ("c", c_void_p), ("ldc", c_int64), ("m", c_int64), ("n", c_int32), ("k", c_int32),
                 ("trans_a", c_int32), ("trans_b", c_int32), ("relu", c_int32), ("alpha", c_float), ("beta", c_float),
-                ("drop_seed", c_void_p), ("drop_p", c_float), ("mean_rows", c_int32)]
+                ("drop_seed", c_void_p), ("drop_p", c_float), ("mean_rows", c_int32), ("b_packed", c_void_p)]
 
 
 class HgPanelPack(ctypes.Structure):
     """HgPanelPack of include/equihgnn_hip.h (one weight of hg_panel_pack)."""
     _fields_ = [("w", c_void_p), ("ld", c_int64), ("dst", c_void_p), ("K", c_int32), ("N", c_int32), ("trans", c_int32),
-                ("kstep0", c_int32), ("ksteps_total", c_int32), ("n_valid", c_int32)]
+                ("kstep0", c_int32), ("ksteps_total", c_int32), ("n_valid", c_int32), ("k_major", c_int32)]
 
 
 class HgConvPanel(ctypes.Structure):

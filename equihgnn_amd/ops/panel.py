@@ -17,11 +17,12 @@ def panel_supported(C: int) -> bool:
     return C in PANEL_WIDTHS
 
 
-def panel_pack(items, out=None):
+def panel_pack(items, out=None, k_major: bool = False):
     """Pack weights for the panel kernels in ONE launch.  ``items`` = [(w, trans)] or [[(w, trans), ...]]: a 2-D fp32 weight
     view ``w`` (unit inner stride) used as B[k][n] = w[n, k] (``trans`` True: x @ w.T) or B[k][n] = w[k, n] (False: dy @ w);
     an inner list stacks its weights along K in one image; (w, trans, n_pad): N zero-padded up to n_pad columns.  Returns one uint8 image tensor per item (views of ``out`` if
-    given: a uint8 device buffer of at least panel_pack_bytes(items) bytes)."""
+    given: a uint8 device buffer of at least panel_pack_bytes(items) bytes).  ``k_major``: the image order the x6 GEMM's pre-split
+    B operand takes ([k / 32][tile][k half][plane][lane]) instead of the panel kernels' [tile][k / 16][plane][lane]."""
     L = hip.lib()
     groups = [it if isinstance(it, list) else [it] for it in items]
     sizes = []
@@ -54,6 +55,7 @@ def panel_pack(items, out=None):
             arr[i].w, arr[i].ld, arr[i].dst = w.data_ptr(), w.stride(0), img.data_ptr()
             arr[i].K, arr[i].N, arr[i].trans, arr[i].kstep0, arr[i].ksteps_total = kk, N, 1 if tr else 0, k0 // 16, K // 16
             arr[i].n_valid = w.shape[0] if tr else w.shape[1]
+            arr[i].k_major = 1 if k_major else 0
             k0 += kk
             i += 1
         off += K * N * 6

@@ -35,9 +35,23 @@ class GemmProblem:
     relu: bool = False
     out: Optional[torch.Tensor] = None
     mean8: Optional[tuple] = None     # (p, seed tensor or None): frame-mean epilogue, the output is [M / 8, N]
+    presplit: Optional[bool] = None   # b split into bf16 planes once per call (hg_panel_pack); None: by the rule of _presplit_ok
 
 
 GEMM_TILE = 0          # 0: chosen per launch; 64 / 128 force a block tile (tools/gemm_bench.py)
+# B operand (the weight of a Linear) split into its bf16 planes ONCE per call by hg_panel_pack, the stagers of the x6 kernel then
+# copy planes instead of splitting the weight again for every row tile of the output (two thirds of their VALU work at the
+# 128 x 256 tile) -- VERDICT r5 #2's first lever.  Bit-identical results; measured (round 6, profiles/r06_ab_runs.txt) it is
+# SLOWER: the planes are 1.5 x the weight's bytes through L2 -> registers -> LDS and the split it saves was not what bounded a
+# step ([246 k x 256].[256 x 256] 324 against 239-255 us, [15 k x 256].[256 x 768] 52 against 47-50).  OFF unless
+# EQH_X6_PRESPLIT=1; from this many rows of a (the pack is one ~5 us launch).
+X6_PRESPLIT = os.environ.get("EQH_X6_PRESPLIT") == "1"
+X6_PRESPLIT_MIN_ROWS = int(os.environ.get("EQH_X6_PRESPLIT_MIN_ROWS", 16384))
+
+
+def _presplit_ok(M, N, K, trans_a, b) -> bool:
+    return (X6_PRESPLIT and not trans_a and K % 32 == 0 and M >= X6_PRESPLIT_MIN_ROWS and N * K <= (1 << 23)
+            and b.stride(-1) == 1 and b.stride(0) % 4 == 0)
 
 
 def gemm_supported(a, b, trans_a=False, trans_b=True) -> bool:
@@ -77,6 +91,17 @@ def gemm_batch(problems):
         q = arr[i]
         q.a, q.lda, q.b, q.ldb = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0)
         q.c, q.ldc, q.m, q.n, q.k = out.data_ptr(), out.stride(0), M, N, K
+        pre = pr.presplit if pr.presplit is not None else _presplit_ok(M, N, K, pr.trans_a, b)
+        if i == 0:
+            pre_all = pre
+        if pre_all and pre:      # (one B form per launch: the first problem decides)
+            from .panel import panel_pack
+            n_pad = (N + 31) // 32 * 32
+            (img,) = panel_pack([(b, bool(pr.trans_b), n_pad)], k_major=True)
+            keep.append(img)
+            q.b_packed = img.data_ptr()
+        elif pre_all:
+            raise ValueError("gemm_batch: the problems of one launch must all take the pre-split form of b, or none")
         q.trans_a, q.trans_b, q.relu = int(bool(pr.trans_a)), int(bool(pr.trans_b)), int(bool(pr.relu))
         q.alpha, q.beta = float(pr.alpha), float(pr.beta)
         if pr.mean8 is not None:
@@ -132,7 +157,7 @@ def _stream_ok(a, b, trans_a, trans_b, out, d, mean8) -> bool:
     return a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and b.stride(-1) == 1 and b.stride(0) % 4 == 0
 
 
-def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None, mean8=None):
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1.0, relu=False, out=None, mean8=None, presplit=None):
     """One GEMM through hg_gemm_x6_batch (see GemmProblem) -- or, many rows against a small weight, through the streaming
     row-panel kernel (panel_stream_gemm)."""
     if _stream_ok(a, b, trans_a, trans_b, out, d, mean8):
@@ -141,7 +166,7 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, d=None, alpha=1.0, beta=1
         N = b.shape[0] if trans_b else b.shape[1]
         return timed("k_panel_stream", 2 * M * N * K,
                      lambda: panel_stream_gemm(a, b, trans_b, alpha=alpha, d=d, beta=beta, bias=bias, relu=relu, out=out))
-    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out, mean8)])[0]
+    return gemm_batch([GemmProblem(a, b, trans_a, trans_b, bias, d, alpha, beta, relu, out, mean8, presplit)])[0]
 
 
 # Where the x6 kernel replaces the library GEMM (measured on MI355X against the TunableOp-selected hipBLASLt kernels,

@@ -102,6 +102,10 @@ typedef struct HgGemmProblem {
     const int64_t* drop_seed;
     float drop_p;
     int32_t mean_rows;
+    /* b_packed != NULL: op(b) [k, n] ALREADY split into its bf16 planes by hg_panel_pack (K = k, N = n rounded up to a multiple
+     * of 32; trans as trans_b) -- the weight of a Linear, split once per call instead of once per row tile of the output.  b may
+     * then be NULL; needs k % 32 == 0 and trans_a == 0; every problem of a launch in the same form. */
+    const void* b_packed;
 } HgGemmProblem;
 size_t hg_gemm_x6_workspace_bytes(int32_t n_problems, const HgGemmProblem* problems, int32_t tile);
 /* the block tile hg_gemm_x6_batch takes for these problems with tile == 0 (64, 128, 256: 64 x 64, 128 x 64, 128 x 128;
@@ -151,6 +155,8 @@ typedef struct {
     void* dst;
     int32_t K, N, trans, kstep0, ksteps_total;
     int32_t n_valid;     /* 0 or N: all columns; else columns n >= n_valid of B are zero (N padded to a multiple of 32) */
+    int32_t k_major;     /* != 0: image[k / 32][tile n / 32][k half][plane][lane] -- the form HgGemmProblem.b_packed takes (a K step
+                            of 32 of ALL column tiles contiguous; needs (kstep0 + K / 16) even); 0: image[tile][k / 16][plane][lane] */
 } HgPanelPack;
 size_t hg_panel_pack_bytes(int32_t K, int32_t N);
 int hg_panel_pack(int32_t n_items, const HgPanelPack* items, void* stream);

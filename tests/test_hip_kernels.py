@@ -1858,6 +1858,30 @@ def test_gemm_x6_matches_float64_and_is_no_worse_than_the_fp32_mfma(M, N, K, ta,
     print(f"gemm_x6 [{M}x{N}x{K} ta={ta} tb={tb} tile={tile}]: max {err:.2e} (lib {err_lib:.2e}), rms {rms:.2e} (lib {rms_lib:.2e})")
 
 
+@pytest.mark.parametrize("M,N,K,tb,tile", [(5000, 256, 256, True, 0), (20000, 256, 128, False, 512), (3001, 200, 64, True, 64),
+                                           (4100, 128, 512, False, 128), (9000, 100, 96, True, 256), (7000, 256, 2176, False, 513),
+                                           (700, 1024, 256, True, 512)])
+def test_gemm_x6_with_a_presplit_weight_is_bit_identical(M, N, K, tb, tile):
+    """The B operand split into bf16 planes once per call (hg_panel_pack -> HgGemmProblem.b_packed) instead of once per row
+    tile by the stagers: the same planes, the same MFMAs in the same order -- the results must be the SAME BITS as the ordinary
+    path's, with bias / addend / ReLU epilogues, ragged N (padded tiles) and every tile shape."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(DEV)
+    b = (torch.randn((N, K) if tb else (K, N), generator=g)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    d = torch.randn(M, N, generator=g).to(DEV)
+    old = ops.GEMM_TILE
+    try:
+        ops.GEMM_TILE = tile
+        for kw in (dict(), dict(bias=bias, relu=True), dict(d=d, alpha=0.5, beta=2.0)):
+            ref = ops.gemm(a, b, trans_b=tb, presplit=False, **kw)
+            got = ops.gemm(a, b, trans_b=tb, presplit=True, **kw)
+            assert torch.equal(ref, got), (kw.keys(), float((ref - got).abs().max()))
+    finally:
+        ops.GEMM_TILE = old
+
+
 def test_gemm_x6_epilogues_batches_and_views():
     """alpha / beta * addend (also in place: accumulate) / bias / relu; column-block views of wider matrices (row
     stride > width); eight problems in one launch; bitwise reproducibility."""
