@@ -32,6 +32,7 @@
 // columns of one output row, so the epilogue reads the addend / bias and stores the result as float4.
 //
 // Results are bitwise reproducible (fixed k order, no atomics, no split-K).  Up to 8 problems share a launch.
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -745,7 +746,10 @@ extern "C" int hg_gemm_x6_batch(int32_t n_problems, const HgGemmProblem* pr, int
     int rc;
     if (id == 512) rc = launch<2, 2, 2, 4, 2, 4>(b, a_ks, b_ks, stream, b_pre);
     else if (id == 513) rc = launch<2, 2, 2, 4, 4, 2>(b, a_ks, b_ks, stream, b_pre);
-    else if (id == 256) rc = launch<2, 2, 2, 3>(b, a_ks, b_ks, stream, b_pre);
+    else if (id == 256) {
+        static const bool deep = [] { const char* e = getenv("EQH_X6_DEEP"); return e && e[0] == '1'; }();   // three ring stages (A/B runs)
+        rc = deep ? launch<2, 2, 3, 3>(b, a_ks, b_ks, stream, b_pre) : launch<2, 2, 2, 3>(b, a_ks, b_ks, stream, b_pre);
+    }
     else if (id == 128) rc = launch<2, 1, 2, 6>(b, a_ks, b_ks, stream, b_pre);   // 6 waves / SIMD = 2 blocks / CU
     else rc = launch<1, 1, 3, 6>(b, a_ks, b_ks, stream, b_pre);
     if (rc) return rc;

@@ -3,7 +3,7 @@
 # gpurun_out/final/, named for round $2 (default r03).  Copy what should be judged into profiles/.
 #   /usr/local/graft/bin/gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh 1'
 set -u
-R=${2:-r05}
+R=${2:-r06}
 mkdir -p gpurun_out/final
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/final
@@ -16,30 +16,30 @@ elif [ "$1" = 1 ]; then
   # the headline line, then the same command under the kernel trace (stats CSV + the order of one replayed step)
   timeout -k 10 500 python bench.py > $O/${R}_bench.json 2> $O/bench.err || exit 1
   tail -c 600 $O/${R}_bench.json
-  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python3 bench.py --no-cpu-baseline --no-pipeline --c4-steps 0 > $O/${R}_bench_with_roofline_probes_under_rocprof.json 2> $O/rocprof.err || exit 1
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_main -- python3 bench.py --no-cpu-baseline --no-pipeline --no-other-configs --c4-steps 0 > $O/${R}_bench_with_roofline_probes_under_rocprof.json 2> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_main -name '*kernel_stats.csv' | head -1)" $O/${R}_kernel_stats_with_roofline_probes.csv
   # kernel order of one replayed step: a trace of the step alone (no roofline probes after it)
   # and per-kernel averages of the training step ALONE (95 replays + 2 set-up steps; the CSV above also holds the
   # roofline probes, which launch the same scatter kernels at the saturating size)
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --no-other-configs --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
-  python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
+  python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt --anchor k_embed_fwd
 elif [ "$1" = 1b ]; then
   rm -rf /tmp/prof_order
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_order -- python3 bench.py --no-cpu-baseline --no-roofline --no-pipeline --no-collective-probe --no-other-configs --c4-steps 0 > $O/${R}_bench_under_rocprof.json 2>> $O/rocprof.err || exit 1
   cp "$(find /tmp/prof_order -name '*kernel_stats.csv' | head -1)" $O/${R}_graph_kernel_stats.csv
-  python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt
+  python3 tools/step_order.py /tmp/prof_order $O/${R}_step_order.txt --anchor k_embed_fwd
 elif [ "$1" = 2 ]; then
   for spec in "egnn_equihnns 1024 pcqm" "mhnns 256 qm9" "mhnn 256 qm9" "mhnnm 256 qm9" "egnn_equihnn 256 qm9" "egnn_equihnnm 256 qm9"; do
     set -- $spec
-    timeout -k 10 300 python bench.py --method $1 --batch $2 --flavour $3 --steps 20 --warmup 5 --no-pipeline --c4-steps 0 --cpu-seconds 8 > $O/${R}_bench_$1_$2.json 2>> $O/bench.err || exit 1
+    timeout -k 10 300 python bench.py --method $1 --batch $2 --flavour $3 --steps 20 --warmup 5 --no-pipeline --no-other-configs --c4-steps 0 --cpu-seconds 8 > $O/${R}_bench_$1_$2.json 2>> $O/bench.err || exit 1
     echo "$1 $2: $(cut -c1-160 $O/${R}_bench_$1_$2.json | tail -1)"
   done
 elif [ "$1" = 3 ]; then
-  timeout -k 10 500 python bench.py --method equiformer_equihnns --batch 128 --steps 20 --warmup 5 --no-pipeline --c4-steps 0 --cpu-batch 16 --cpu-seconds 8 > $O/${R}_bench_equiformer_equihnns_128.json 2>> $O/bench.err || exit 1
+  timeout -k 10 500 python bench.py --method equiformer_equihnns --batch 128 --steps 20 --warmup 5 --no-pipeline --no-other-configs --c4-steps 0 --cpu-batch 16 --cpu-seconds 8 > $O/${R}_bench_equiformer_equihnns_128.json 2>> $O/bench.err || exit 1
   cut -c1-200 $O/${R}_bench_equiformer_equihnns_128.json | tail -1
-  timeout -k 10 600 python bench.py --method faformer_equihnns --batch 512 --flavour pcqm --steps 10 --warmup 3 --no-pipeline --c4-steps 0 --cpu-batch 16 --cpu-seconds 8 > $O/${R}_bench_faformer_equihnns_512.json 2>> $O/bench.err || exit 1
+  timeout -k 10 600 python bench.py --method faformer_equihnns --batch 512 --flavour pcqm --steps 10 --warmup 3 --no-pipeline --no-other-configs --c4-steps 0 --cpu-batch 16 --cpu-seconds 8 > $O/${R}_bench_faformer_equihnns_512.json 2>> $O/bench.err || exit 1
   cut -c1-200 $O/${R}_bench_faformer_equihnns_512.json | tail -1
   for spec in "equiformer_equihnns 128 qm9" "faformer_equihnns 512 pcqm"; do
     set -- $spec
