@@ -164,16 +164,21 @@ def measure_in_graph(method, batch_size, flavour, dev, replays=30, seed=2000):
     b = pad_batch(host, *bucket_sizes(host.num_nodes, host.num_hyperedges, host.nnz)).packed().to(dev)
     b.num_real_graphs = batch_size
     tr = GraphedTrainStep(model, lr=ns.lr, weight_decay=ns.wd, collective=False)   # rank-local: the other ranks wait
+    # The measurement graph builds its index at the head of the step (as rounds 1-5 did), NOT on the side stream: the stamps then
+    # bracket each kernel running ALONE, which is what a roofline fraction is about.  In the timed run the next batch's index build
+    # overlaps whatever follows the read-out head (k_conv_b3, the first k_inc_bwd_both ...) and stretches those launches while
+    # shortening the step (index_build in the JSON line).
+    tr.index_prefetch = False
     tr.step(b)                                   # eager bootstrap
     tl = ops.Timeline(dev)
     ops.TIMELINE = tl
     try:
-        tr.step(b, b)                            # capture (stamps included) + first replay
+        tr.step(b)                               # capture (stamps included) + first replay
     finally:
         ops.TIMELINE = None
     acc = {}
     for _ in range(replays):
-        tr.step(b, b)                            # (the next batch's index is built beside the step, as in the timed run)
+        tr.step(b)
         torch.cuda.synchronize(dev)
         for i, (name, work, us) in enumerate(tl.read_us()):
             acc.setdefault(i, [name, work, 0.0])[2] += us / replays
@@ -291,6 +296,37 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=3, batches_p
             "graphs_captured": n_graphs, "graphs_captured_while_timed": n_graphs - seen,
             "host_collate_molecules_per_s": round((loader.collated - c0) / max(loader.collate_seconds - s0, 1e-9), 1),
             "host_collate_threads": 1}
+
+
+def measure_operator_boundary(batch, dev, C=256, reps=30):
+    """The operator-level drop-in of INTEGRATION.md section 3 on its own: ``ops.scatter(src, index, dim=-2, dim_size, reduce)``
+    -- torch_scatter.scatter's signature at the reference's call sites (conv.py:91-93,97,173,177) -- on the incidence list of one
+    batch of this workload: every call builds its CSR from the unsorted int64 index (the models build it once per batch and
+    never take this route), then runs the segmented reduction.  Eager launches, microseconds per call."""
+    from equihgnn_amd import ops
+    v, e = batch.edge_index0, batch.edge_index1
+    keep = v >= 0                                            # (padded batches carry null incidences)
+    v, e = v[keep].contiguous(), e[keep].contiguous()
+    n_nodes, n_he = int(batch.x.shape[0]), int(batch.edge_attr.shape[0])
+    xs = torch.randn(n_nodes, C, device=dev)
+    out = {}
+    for label, src_rows, index, size in (("node_to_hyperedge_mean", xs[v], e, n_he), ("hyperedge_to_node_sum", torch.randn(n_he, C, device=dev)[e], v, n_nodes)):
+        red = "mean" if "mean" in label else "sum"
+        for _ in range(3):
+            ops.scatter(src_rows, index, dim=-2, dim_size=size, reduce=red)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ops.scatter(src_rows, index, dim=-2, dim_size=size, reduce=red)
+        torch.cuda.synchronize(dev)
+        us = (time.perf_counter() - t0) / reps * 1e6
+        nnz = int(index.numel())
+        alg = 4 * C * nnz + 8 * nnz + 4 * C * size
+        out[label] = {"us_per_call": round(us, 1), "incidences": nnz, "rows_out": size, "alg_bytes": alg,
+                      "achieved_gbs": round(alg / us / 1e3, 1)}
+    out["what"] = ("ops.scatter(src, index, dim=-2, dim_size, reduce): torch_scatter.scatter's signature, CSR built per call (4 eager "
+                   "launches) + one segmented reduction; the model classes build the CSR once per batch instead")
+    return out
 
 
 def scatter_roofline(per, floor, names=SCATTER_KERNELS):
@@ -977,6 +1013,7 @@ def main():
                 b2b = measure_scatter_roofline(model, host_batches[0].to(dev), dev)
                 if b2b["launches"] > 0:      # (methods on the merged conv path launch no plain k_segment_reduce: nothing to report)
                     result["roofline"]["back_to_back"] = b2b
+                result["roofline"]["operator_boundary"] = measure_operator_boundary(batches[0], dev)
                 result["roofline"]["saturation"] = saturation_probe(dev)
                 result["roofline"]["saturation"]["fused_kernels"] = fused_saturation(dev)
         if not a.no_pipeline and use_graph and world == 1:
