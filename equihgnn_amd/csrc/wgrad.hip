@@ -584,7 +584,7 @@ extern "C" size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I) {
 // lane (scalar loads); the four wavefronts' sums meet in LDS in wavefront order, the chunks' partial results in a slab that the
 // step's (deferred) fixed-order reduction adds into dw: no atomics, bitwise reproducible.
 namespace {
-constexpr int SK_ROWS = 256, SK_J = 16;
+constexpr int SK_ROWS = 64, SK_J = 16;     // (256-row chunks: 152 workgroups at the BASELINE batch, 16 us; 64: 600 workgroups)
 __global__ void __launch_bounds__(256) k_wgrad_skinny(const float* __restrict__ dy, int64_t ld_dy, const float* __restrict__ x, int64_t ld_x,
                                                       int64_t K, int O, int J, float alpha, float* __restrict__ slab) {
     __shared__ float s_part[3][SK_J][64];

@@ -873,7 +873,7 @@ size_t hg_wgrad_workspace_bytes(int64_t K, int32_t O, int32_t I);
 int hg_wgrad_f32(const float* dy, const float* x, int64_t K, int32_t O, int32_t I, float alpha, float* dw,
                  int64_t ldw, int32_t accumulate, void* workspace, size_t workspace_bytes, void* stream);
 /* hg_wgrad_skinny_f32: dw [O x J] (ldw) (+)= alpha * dy^T x for dy [K, O] (ld_dy), x [K, J] (ld_x), J <= 16 -- the 16-wide m_i
- * block of the EGNN node MLP's first Linear (egnn_layer.py:180-187).  Partial sums per 256-row chunk in `workspace`
+ * block of the EGNN node MLP's first Linear (egnn_layer.py:180-187).  Partial sums per 64-row chunk in `workspace`
  * (hg_wgrad_skinny_workspace_bytes), added by the fixed-order slab reduction (deferred inside eqh_defer_begin / _flush). */
 size_t hg_wgrad_skinny_workspace_bytes(int64_t K, int32_t O, int32_t J);
 int hg_wgrad_skinny_f32(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t K, int32_t O, int32_t J, float alpha,
