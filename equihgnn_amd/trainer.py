@@ -645,7 +645,6 @@ class GraphedTrainStep:
         ``after_signal`` (the count the running step's signal node brings the counter to), held back until that step has
         reached its signal point."""
         st = pf["staged"]
-        cur = torch.cuda.current_stream()
         with torch.cuda.stream(pf["stream"]):
             pf["stream"].wait_event(pf["free"])
             if after_signal is not None:
@@ -662,7 +661,6 @@ class GraphedTrainStep:
             ready = torch.cuda.Event()
             ready.record(pf["stream"])
         pf["ready"], pf["holds"] = ready, self._token(data)
-        del cur
 
     def _refresh(self, pf):
         """Head of a step: staged -> live (index tensors and the batch itself) in one launch on the step's stream."""

@@ -153,3 +153,12 @@ def test_bucketed_loader_pads_every_rank_to_the_same_extents():
             for r in range(world):
                 for b, t in zip(plans[r][e][0], plans[r][e][1]):
                     assert store.n_nodes[b].sum() < t[0] and store.n_he[b].sum() < t[1] and store.n_inc[b].sum() <= t[2]
+
+
+def test_with_next_pairs_every_batch_with_its_successor():
+    """The one batch of look-ahead GraphedTrainStep.step(data, next_data) uses to build the next batch's index beside the
+    current step: every element once, in order, the last one with None; works on one-shot iterators."""
+    from equihgnn_amd.trainer import with_next
+    assert list(with_next([1, 2, 3])) == [(1, 2), (2, 3), (3, None)]
+    assert list(with_next(iter([7]))) == [(7, None)]
+    assert list(with_next([])) == []
