@@ -382,6 +382,58 @@ __device__ __forceinline__ void rt_ln_bwd(const RowTile<C, NW>& pre, const RowTi
     }
 }
 
+// plain LayerNorm of a row (no bias, no ReLU: nn.LayerNorm on node rows, egnn_layer.py:192,360): xhat and 1 / std
+template <int C, int NW>
+__device__ __forceinline__ void rt_xhat_plain(const RowTile<C, NW>& in, float eps, RowTile<C, NW>& x, float& rstd) {
+    constexpr int NJ = PnShape<C, NW>::NJ, LPR = Geo<NW>::LPR;
+    const float inv_c = 1.0f / (float)C;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s += (in.v[j].x + in.v[j].y) + (in.v[j].z + in.v[j].w);
+    const float mu = row_sum<LPR>(s) * inv_c;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        float4 d = in.v[j];
+        d.x -= mu; d.y -= mu; d.z -= mu; d.w -= mu;
+        x.v[j] = d;
+        ss += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+    }
+    rstd = 1.0f / sqrtf(row_sum<LPR>(ss) * inv_c + eps);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { x.v[j].x *= rstd; x.v[j].y *= rstd; x.v[j].z *= rstd; x.v[j].w *= rstd; }
+}
+// ... and its backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; the lane's terms of d gamma / d beta are ADDED
+// to a_dg / a_dbeta when `count`
+template <int C, int NW>
+__device__ __forceinline__ void rt_ln_plain_bwd(const RowTile<C, NW>& xh, float rstd, const RowTile<C, NW>& gam, const RowTile<C, NW>& dy,
+                                                bool count, RowTile<C, NW>& dx, RowTile<C, NW>& a_dg, RowTile<C, NW>& a_dbeta) {
+    constexpr int NJ = PnShape<C, NW>::NJ, LPR = Geo<NW>::LPR;
+    const float inv_c = 1.0f / (float)C;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 x = xh.v[j];
+        float4 d = dy.v[j];
+        if (count) {
+            f4_add(a_dbeta.v[j], d);
+            a_dg.v[j].x = fmaf(d.x, x.x, a_dg.v[j].x); a_dg.v[j].y = fmaf(d.y, x.y, a_dg.v[j].y);
+            a_dg.v[j].z = fmaf(d.z, x.z, a_dg.v[j].z); a_dg.v[j].w = fmaf(d.w, x.w, a_dg.v[j].w);
+        }
+        d.x *= gam.v[j].x; d.y *= gam.v[j].y; d.z *= gam.v[j].z; d.w *= gam.v[j].w;
+        dx.v[j] = d;
+        m1 += (d.x + d.y) + (d.z + d.w);
+        m2 += (d.x * x.x + d.y * x.y) + (d.z * x.z + d.w * x.w);
+    }
+    m1 = row_sum<LPR>(m1) * inv_c;
+    m2 = row_sum<LPR>(m2) * inv_c;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const float4 d = dx.v[j], x = xh.v[j];
+        dx.v[j] = make_float4(rstd * (d.x - m1 - x.x * m2), rstd * (d.y - m1 - x.y * m2), rstd * (d.z - m1 - x.z * m2), rstd * (d.w - m1 - x.w * m2));
+    }
+}
+
 // sum of v over the RPW rows a wavefront holds (lanes with the same c): every lane gets the total.  The rows of a DPP row of
 // sixteen lanes meet by a rotation, the DPP rows by v_permlane16_swap / v_permlane32_swap (gfx950: VALU, no LDS).
 template <int NW>
@@ -1264,7 +1316,9 @@ __device__ __forceinline__ float silu_grad_f(float x) {
 
 // in0 = normed [N, C], in1 = m_i [N, 16], in2 = feats (residual); w0 / w1 = W0 T image, output columns [0, C) / [C, 2 C) (K = C + 16);
 // w2 = W3 T image (K = 2 C); b0 = bias of W0 [2 C], bias_out = bias of W3 [C];
-// out0 = node_in [N, C + 16], out1 = hpre [N, 2 C], out2 = hid [N, 2 C], out3 = out [N, C]
+// out0 = node_in [N, C + 16], out1 = hpre [N, 2 C], out2 = hid [N, 2 C], out3 = out [N, C].
+// g0 != null (round 6): in0 = feats and normed = LayerNorm(feats; g0, be0, eps) is formed HERE (node_norm, egnn_layer.py:192,360:
+// it was a launch of its own each way), the residual is in0 itself (in2 unused)
 template <int C, int NW>
 PN_KERNEL(NW) k_node_f(const ConvPanelArgs p) {
     using S = PnShape<C, NW>;
@@ -1281,7 +1335,21 @@ PN_KERNEL(NW) k_node_f(const ConvPanelArgs p) {
     ws.init(0, p.w0, mul ? wave : 0, lane);
     ws.init(1, p.w1, mul ? wave : 0, lane);
     ws.prime();
-    rt_load<C, NW>(res, p.in2, C, P.rowc, P.c4);
+    if (p.g0) {
+        res = x;
+        RowTile<C, NW> gv, bv, xh;
+        rt_load_vec<C, NW>(gv, p.g0, P.c4);
+        rt_load_vec<C, NW>(bv, p.be0, P.c4);
+        float rstd;
+        rt_xhat_plain<C, NW>(x, p.eps, xh, rstd);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) {
+            x.v[j].x = fmaf(gv.v[j].x, xh.v[j].x, bv.v[j].x); x.v[j].y = fmaf(gv.v[j].y, xh.v[j].y, bv.v[j].y);
+            x.v[j].z = fmaf(gv.v[j].z, xh.v[j].z, bv.v[j].z); x.v[j].w = fmaf(gv.v[j].w, xh.v[j].w, bv.v[j].w);
+        }
+    } else {
+        rt_load<C, NW>(res, p.in2, C, P.rowc, P.c4);
+    }
     __builtin_amdgcn_sched_barrier(0);
     rt_a_put<C, NW, KS1>(x, s_img, P.lrow, P.c);
     if (P.c < 4) a_put<KS1>(s_img, P.lrow, C / 4 + P.c, mi);
@@ -1336,7 +1404,9 @@ PN_KERNEL(NW) k_node_f(const ConvPanelArgs p) {
 }
 
 // in0 = dout [N, C] (ld0), in1 = hpre [N, 2 C]; w0 / w1 = W3 N image, output columns [0, C) / [C, 2 C) (K = C);
-// w2 = W0 N image (K = 2 C, N = C + 16 zero-padded to C + 32); out0 = dpre [N, 2 C], out1 = dnode_in [N, C + 16]
+// w2 = W0 N image (K = 2 C, N = C + 16 zero-padded to C + 32); out0 = dpre [N, 2 C], out1 = dnode_in [N, C + 16].
+// g0 != null (round 6, with k_node_f's LayerNorm): in3 = feats; out1 = d feats [N, C] = LNbwd(d normed) + dout (the residual's
+// gradient rides along), out2 = d m_i [N, 16], slab = [unused | d gamma | d beta] partial sums of this workgroup
 template <int C, int NW>
 PN_KERNEL(NW) k_node_b(const ConvPanelArgs p) {
     using S = PnShape<C, NW>;
@@ -1395,6 +1465,22 @@ PN_KERNEL(NW) k_node_b(const ConvPanelArgs p) {
     __syncthreads();
     RowTile<C, NW> t;
     rt_load<C, NW>(t, s_stg, LD2, P.lrow, P.c4);
+    if (p.g0) {
+        if (P.live && P.c < 4)
+            *reinterpret_cast<float4*>(p.out2 + (int64_t)P.row * 16 + P.c4) = *reinterpret_cast<const float4*>(s_stg + P.lrow * LD2 + C + P.c4);
+        RowTile<C, NW> xr, gv, xh, dx, a_db, a_dg, a_dbeta;
+        rt_load<C, NW>(xr, p.in3, C, P.rowc, P.c4);
+        rt_load_vec<C, NW>(gv, p.g0, P.c4);
+        rt_zero<C, NW>(a_db); rt_zero<C, NW>(a_dg); rt_zero<C, NW>(a_dbeta);
+        float rstd;
+        rt_xhat_plain<C, NW>(xr, p.eps, xh, rstd);
+        rt_ln_plain_bwd<C, NW>(xh, rstd, gv, t, P.live, dx, a_dg, a_dbeta);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) f4_add(dx.v[j], d.v[j]);
+        if (P.live) rt_store<C, NW>(dx, p.out1, C, P.row, P.c4);
+        write_slab<C, NW>(s_stg, p.slab + (int64_t)blockIdx.x * 3 * C, a_db, a_dg, a_dbeta, wave, lane);
+        return;
+    }
     if (P.live) {
         rt_store<C, NW>(t, p.out1, C + 16, P.row, P.c4);
         if (P.c < 4)
@@ -1499,13 +1585,17 @@ extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_)
             return eqh_reduce_slabs3_async(q->slab2, blocks, 3 * (int64_t)C, q->dbias2, q->dgamma2, q->dbeta2, C, C, q->accumulate, stream);
         }
         case HG_EGNN_NODE_F:
-            if (!need({q->in0, q->in1, q->in2, q->w0, q->w1, q->w2, q->b0, q->bias_out, q->out0, q->out1, q->out2, q->out3})) return EQH_ERR_ARG;
+            if (!need({q->in0, q->in1, q->w0, q->w1, q->w2, q->b0, q->bias_out, q->out0, q->out1, q->out2, q->out3})) return EQH_ERR_ARG;
+            if (q->g0 ? !q->be0 : !q->in2) return EQH_ERR_ARG;      // LayerNorm of in0 inside (g0, be0) -- or normed rows + the residual in2
             PN_LAUNCH(k_node_f);
             return EQH_OK;
         case HG_EGNN_NODE_B:
             if (!need({q->in0, q->in1, q->w0, q->w1, q->w2, q->out0, q->out1})) return EQH_ERR_ARG;
+            if (q->g0 && !need({q->in3, q->out2, q->slab, q->dbias, q->dgamma, q->dbeta})) return EQH_ERR_ARG;
             PN_LAUNCH(k_node_b);
-            return EQH_OK;
+            if (!q->g0) return EQH_OK;
+            // (dbias: a [C] scratch row -- a plain LayerNorm has no bias in front of it; the slab's first third is zeros)
+            return eqh_reduce_slabs3_async(q->slab, blocks, 3 * (int64_t)C, q->dbias, q->dgamma, q->dbeta, C, C, q->accumulate, stream);
         default:
             return EQH_ERR_ARG;
     }

@@ -462,7 +462,15 @@ class EGNN(nn.Module):
         # features feed three things (this GEMM, node_norm, the residual): one autograd node, so that their
         # gradients are summed inside the LayerNorm backward kernel and an accumulating GEMM (ops._EgnnFeats)
         nn_ = self.node_norm
-        if feats.dim() == 2 and c % 4 == 0 and c <= 1024:
+        n0, n3 = self.node_mlp[0], self.node_mlp[3]
+        # node_norm inside the node update's panel launches (round 6: its forward and backward were launches of their own)
+        fold = (ops.NODE_LN_FOLD and ops.USE_NODE_PANEL and feats.dim() == 2 and feats.is_cuda and feats.dtype == torch.float32
+                and tuple(nn_.normalized_shape) == (c,) and nn_.elementwise_affine and nn_.bias is not None
+                and ops.panel_supported(c) and tuple(n0.weight.shape) == (2 * c, c + 16) and tuple(n3.weight.shape) == (c, 2 * c)
+                and feats.shape[0] > 0 and self.edge_mlp[3].weight.shape[0] == 16)
+        if fold:
+            ab, normed, res = ops.egnn_feats(feats, w_cat, b_cat, None)
+        elif feats.dim() == 2 and c % 4 == 0 and c <= 1024:
             ab, normed, res = ops.egnn_feats(feats, w_cat, b_cat, nn_)
         else:
             ab, normed, res = ops.linear(feats, w_cat, b_cat), nn_(feats), feats
@@ -471,7 +479,8 @@ class EGNN(nn.Module):
         # everything up to here fills the chip; the panel kernels that follow occupy ~150 of 256 CUs: where a graphed
         # trainer lets the next batch's index build start on its side stream (no-op otherwise)
         ops.signal_point()
-        n0, n3 = self.node_mlp[0], self.node_mlp[3]
+        if fold:
+            return ops.egnn_node_mlp_ln(normed, m_i, n0, n3, nn_)      # (normed is feats here: one launch each way, LayerNorm included)
         if ops.USE_NODE_PANEL and ops.egnn_node_mlp_supported(normed, m_i, n0, n3):
             return ops.egnn_node_mlp(normed, m_i, res, n0, n3)      # one launch each way (csrc/panel.hip)
         node_in = torch.cat((normed, m_i), -1)

@@ -64,7 +64,7 @@ from .rows import (  # noqa: F401
 )
 from .egnn import (  # noqa: F401
     _EgnnEdge, _EgnnFeats, egnn_feats, _EgnnPackWeights, egnn_pack_weights, egnn_edge, _EgnnNodeMlp, egnn_node_mlp,
-    egnn_node_mlp_supported,
+    egnn_node_mlp_supported, egnn_node_mlp_ln, NODE_LN_FOLD,
 )
 from .readout import (  # noqa: F401
     _MseLoss, mse_loss, _READOUT_STATE, _readout_state, _ReadoutMse, readout_mse_supported, readout_mse,
@@ -91,6 +91,7 @@ _SWITCH_OWNER = {
     "KNN_GRID_MIN_POINTS": "aggregate",
     "TIMELINE": "_base",
     "SIGNAL": "_base",
+    "NODE_LN_FOLD": "egnn",
     "USE_GEOM": "frames",
     "USE_WGRAD_KERNEL": "grads",
     "USE_X6": "products",

@@ -78,8 +78,15 @@ class _EgnnFeats(torch.autograd.Function):
     def forward(ctx, feats, w_cat, b_cat, gamma, beta, eps, acc_params, w_refs=None):
         _require_gpu(feats, "egnn_feats")
         feats = _f32c(feats)
-        g, b = _f32c(gamma), _f32c(beta)
         R, C = feats.shape
+        ctx.fold = gamma is None          # the LayerNorm runs inside the node-update panel launches (egnn_node_mlp_ln)
+        if ctx.fold:
+            ab = mm_nt(feats, w_cat, bias=b_cat)
+            ctx.save_for_backward(feats, w_cat)
+            ctx.eps, ctx.acc, ctx.w_refs = 0.0, acc_params, w_refs
+            ctx.set_materialize_grads(False)
+            return ab, feats.view_as(feats), feats.view_as(feats)
+        g, b = _f32c(gamma), _f32c(beta)
         normed = torch.empty_like(feats)
         hip.check(hip.lib().hg_layer_norm_fwd(_ptr(feats), _ptr(g), _ptr(b), R, C, float(eps), _ptr(normed),
                                               _stream(feats.device)), "hg_layer_norm_fwd")
@@ -91,7 +98,18 @@ class _EgnnFeats(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_ab, d_normed, d_res):
-        feats, w_cat, gamma = ctx.saved_tensors
+        if ctx.fold:
+            feats, w_cat = ctx.saved_tensors
+            gamma = None
+            # (d_normed IS the complete gradient of feats from the node update -- LayerNorm backward + residual, formed in
+            # k_node_b; the accumulating GEMM below adds the edge MLP's share onto it in place)
+            if d_normed is not None and d_res is not None:
+                d_res = d_normed + d_res
+            elif d_normed is not None:
+                d_res = d_normed
+            d_normed = None
+        else:
+            feats, w_cat, gamma = ctx.saved_tensors
         R, C = feats.shape
         dev = feats.device
         L = hip.lib()
@@ -110,12 +128,19 @@ class _EgnnFeats(torch.autograd.Function):
                                           _stream(dev)), "hg_layer_norm_bwd")
             if not in_place:
                 dgamma, dbeta = _hand_out(list(small), tg)
+        elif ctx.fold:
+            dx = _f32c(d_res) if d_res is not None else None      # (the node update's gradient tensor: read as the GEMM's addend, not written)
         else:
             dx = _f32c(d_res).clone() if d_res is not None else None
         dw = db = None
         if d_ab is not None:
             d_ab = _f32c(d_ab)
-            dx = mm_nn(d_ab, w_cat) if dx is None else mm_nn(d_ab, w_cat, d=dx, out=dx)
+            if dx is None:
+                dx = mm_nn(d_ab, w_cat)
+            elif ctx.fold:
+                dx = mm_nn(d_ab, w_cat, d=dx)         # out of place: a gradient autograd handed in is not modified
+            else:
+                dx = mm_nn(d_ab, w_cat, d=dx, out=dx)
             tw = [_acc_target(q) for q in ctx.w_refs] if ctx.w_refs is not None else [None, None]
             if ctx.needs_input_grad[1]:
                 if tw[0] is not None:       # w_cat carries an accumulator (egnn_pack_weights inside a deferral window)
@@ -141,7 +166,10 @@ class _EgnnFeats(torch.autograd.Function):
 
 def egnn_feats(feats, w_cat, b_cat, norm):
     """(feats @ w_cat.T + b_cat, LayerNorm(feats), feats) for 2-D fp32 ``feats`` [N, C] (C % 4 == 0, C <= 1024);
-    ``norm`` the nn.LayerNorm module.  See _EgnnFeats."""
+    ``norm`` the nn.LayerNorm module -- or None: the LayerNorm is left to the node update (egnn_node_mlp_ln) and the second
+    result is feats itself.  See _EgnnFeats."""
+    if norm is None:
+        return _EgnnFeats.apply(feats, w_cat, b_cat, None, None, 0.0, (), (w_cat, b_cat))
     _note_acc(norm.weight, norm.bias)
     return _EgnnFeats.apply(feats, w_cat, b_cat, norm.weight, norm.bias, norm.eps, (norm.weight, norm.bias), (w_cat, b_cat))
 
@@ -227,10 +255,14 @@ class _EgnnNodeMlp(torch.autograd.Function):
     and bias gradients are formed from the stored rows (node_in, dpre; hid, dout) by the batched / deferred products."""
 
     @staticmethod
-    def forward(ctx, normed, m_i, res, w0, b0, w3, b3):
+    def forward(ctx, normed, m_i, res, w0, b0, w3, b3, gamma=None, beta=None, eps=0.0):
+        """``gamma`` given (round 6): ``normed`` is the RAW feature rows, LayerNorm(gamma, beta, eps) is formed inside the
+        launch (and its backward inside the backward launch), ``res`` is ignored (the residual is the same rows)."""
         from .panel import conv_panel, panel_pack
         _require_gpu(normed, "egnn_node_mlp")
-        normed, m_i, res = _f32c(normed), _f32c(m_i), _f32c(res)
+        ctx.fold = gamma is not None
+        normed, m_i = _f32c(normed), _f32c(m_i)
+        res = normed if ctx.fold else _f32c(res)
         N, C = normed.shape
         dev = normed.device
         need_grad = any(ctx.needs_input_grad)
@@ -242,27 +274,52 @@ class _EgnnNodeMlp(torch.autograd.Function):
         hpre = torch.empty((N, 2 * C), dtype=torch.float32, device=dev)
         hid = torch.empty_like(hpre)
         out = torch.empty((N, C), dtype=torch.float32, device=dev)
+        ln = dict(g0=_f32c(gamma), be0=_f32c(beta), eps=float(eps)) if ctx.fold else {}
         timed("k_node_f", 2 * N * ((C + 16) * 2 * C + 2 * C * C), lambda: conv_panel(
             hip.HG_EGNN_NODE_F, N, C, dev, in0=normed, in1=m_i, in2=res, w0=imgs[0], w1=imgs[1], w2=imgs[2], b0=b0, bias_out=b3,
-            out0=node_in, out1=hpre, out2=hid, out3=out))
+            out0=node_in, out1=hpre, out2=hid, out3=out, **ln))
         if need_grad:
-            ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid, m_i)
+            if ctx.fold:
+                ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid, m_i, normed, ln["g0"])
+                ctx.ln = (gamma, beta, float(eps))
+            else:
+                ctx.save_for_backward(w0, b0, w3, b3, node_in, hpre, hid, m_i)
             ctx.imgs = imgs[3:]
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        from .panel import conv_panel
+        from .panel import conv_panel, conv_panel_slab
         from .grads import _linear_weight_grad
-        w0, b0, w3, b3, node_in, hpre, hid, m_i = ctx.saved_tensors
+        if ctx.fold:
+            w0, b0, w3, b3, node_in, hpre, hid, m_i, feats, g0 = ctx.saved_tensors
+        else:
+            w0, b0, w3, b3, node_in, hpre, hid, m_i = ctx.saved_tensors
         N, C = hid.shape[0], hid.shape[1] // 2
         dev = dout.device
         dout, ld = _rows_ld(dout)
         dpre = torch.empty_like(hpre)
-        dnode_in = torch.empty_like(node_in)
-        timed("k_node_b", 2 * N * (2 * C * C + 2 * C * (C + 16)), lambda: conv_panel(
-            hip.HG_EGNN_NODE_B, N, C, dev, in0=dout, ld0=ld, in1=hpre, w0=ctx.imgs[0], w1=ctx.imgs[1], w2=ctx.imgs[2], out0=dpre,
-            out1=dnode_in))
+        dgam = dbet = None
+        if ctx.fold:
+            # d feats = LayerNorm backward of d normed + dout (the residual), d m_i, and the LayerNorm's vector gradients (slab sums)
+            dfeats = torch.empty((N, C), dtype=torch.float32, device=dev)
+            dm = torch.empty((N, 16), dtype=torch.float32, device=dev)
+            p_gamma, p_beta, eps = ctx.ln
+            tg = [_acc_target(p_gamma), _acc_target(p_beta)]
+            acc = all(t is not None for t in tg)
+            small = tg if acc else list(torch.empty((2, C), dtype=torch.float32, device=dev))
+            junk = torch.empty(C, dtype=torch.float32, device=dev)          # (the slab's bias third: a plain LayerNorm has none; never read)
+            timed("k_node_b", 2 * N * (2 * C * C + 2 * C * (C + 16)), lambda: conv_panel(
+                hip.HG_EGNN_NODE_B, N, C, dev, eps=eps, accumulate=acc, in0=dout, ld0=ld, in1=hpre, w0=ctx.imgs[0], w1=ctx.imgs[1],
+                w2=ctx.imgs[2], out0=dpre, out1=dfeats, out2=dm, in3=feats, g0=g0, slab=conv_panel_slab(N, C, dev), dbias=junk,
+                dgamma=small[0], dbeta=small[1]))
+            if not acc:
+                dgam, dbet = small[0], small[1]
+        else:
+            dnode_in = torch.empty_like(node_in)
+            timed("k_node_b", 2 * N * (2 * C * C + 2 * C * (C + 16)), lambda: conv_panel(
+                hip.HG_EGNN_NODE_B, N, C, dev, in0=dout, ld0=ld, in1=hpre, w0=ctx.imgs[0], w1=ctx.imgs[1], w2=ctx.imgs[2], out0=dpre,
+                out1=dnode_in))
         dout_c = dout if ld == C else dout.contiguous()
         dw3 = dw0 = None
         blocks = NODE_WGRAD_BLOCKS and _acc_target(w3) is not None and _acc_target(w0) is not None and C % 64 == 0
@@ -282,7 +339,9 @@ class _EgnnNodeMlp(torch.autograd.Function):
             dw0 = _linear_weight_grad(w0, None, None, dpre, node_in) if ctx.needs_input_grad[3] else None
         db3 = colsum(dout_c, into=_acc_target(b3)) if ctx.needs_input_grad[6] else None
         db0 = colsum(dpre, into=_acc_target(b0)) if ctx.needs_input_grad[4] else None
-        return dnode_in[:, :C], dnode_in[:, C:], dout, dw0, db0, dw3, db3
+        if ctx.fold:
+            return dfeats, dm, None, dw0, db0, dw3, db3, dgam, dbet, None
+        return dnode_in[:, :C], dnode_in[:, C:], dout, dw0, db0, dw3, db3, None, None, None
 
 
 def egnn_node_mlp_supported(normed, m_i, lin0, lin3) -> bool:
@@ -300,3 +359,17 @@ def egnn_node_mlp(normed, m_i, res, lin0, lin3):
                 LINEAR_PARAMS[id(w)] = w
     _note_acc(lin0.bias, lin3.bias)
     return _EgnnNodeMlp.apply(normed, m_i, res, lin0.weight, lin0.bias, lin3.weight, lin3.bias)
+
+
+NODE_LN_FOLD = not os.environ.get("EQH_NO_NODE_LN_FOLD")     # node_norm inside the node-update panel launches (A/B runs)
+
+
+def egnn_node_mlp_ln(feats, m_i, lin0, lin3, norm):
+    """lin3(silu(lin0(cat(LayerNorm(feats), m_i)))) + feats (egnn_layer.py:192,360-362) with the LayerNorm -- and its backward,
+    summed with the residual's gradient -- inside the node update's one panel launch each way."""
+    if torch.is_grad_enabled():
+        for w in (lin0.weight, lin3.weight):
+            if w.requires_grad and w.is_leaf:
+                LINEAR_PARAMS[id(w)] = w
+    _note_acc(lin0.bias, lin3.bias, norm.weight, norm.bias)
+    return _EgnnNodeMlp.apply(feats, m_i, None, lin0.weight, lin0.bias, lin3.weight, lin3.bias, norm.weight, norm.bias, norm.eps)
