@@ -513,6 +513,7 @@ def readout(mlp_out, x, index: HyperIndex, taps=None, head=None):
         if ops.readout_mse_supported(x2, mlp_out) and head[0].is_cuda:
             loss, _ = ops.readout_mse(x2, index.pool.rowptr, mlp_out, head[0], head[1],
                                       unit_grad=bool(head[2]) if len(head) > 2 else False)
+            ops.signal_point("after_readout")
             return loss
     xp = pool_sum(x, index)
     if taps is not None:

@@ -113,11 +113,17 @@ SIGNAL: Optional[StepSignal] = None
 
 
 def signal_point(name: str = "front_end"):
-    """Called where the chip stops being full -- "front_end": behind the EGNN edge kernel; "readout": before the 17-workgroup
-    read-out head; "tail": before the step's closing reductions.  Under an armed StepSignal that listens for ``name`` -- a
+    """Called where the chip stops being full -- "front_end": behind the EGNN edge kernel; "conv_<l>" / "conv_last": before the
+    l-th / last application of the conv stack; "readout" / "after_readout": around the 17-workgroup read-out head; "tail": before
+    the step's closing reductions.  Under an armed StepSignal that listens for ``name`` -- a
     GraphedTrainStep capturing with index prefetch -- the post lands here; otherwise nothing happens."""
     sg = SIGNAL
-    if sg is not None and sg.armed and getattr(sg, "at", "front_end") == name:
+    if sg is None:
+        return
+    seen = getattr(sg, "seen", None)        # (a trainer's probe pass: which points does this model's step reach?)
+    if seen is not None:
+        seen.add(name)
+    elif sg.armed and getattr(sg, "at", "front_end") == name:
         sg.post()
 
 

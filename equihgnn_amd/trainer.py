@@ -208,7 +208,9 @@ class GraphedTrainStep:
         # of the step graph 1.137; built ahead and released at the step's head 1.138 (it then competes with the chip-filling
         # front-end kernels), behind the EGNN edge kernel 1.112, before the read-out head 1.098, before the closing
         # reductions 1.160 (too late: it spills into the next step)
-        self.signal_at = os.environ.get("EQH_PREFETCH_SIGNAL", "readout")
+        # (round 6, second scan: before the conv stack's last application 1.075 / 1.076 against 1.079-1.083 before the read-out
+        # head and 1.10 before its first or second application.)  A comma list: the first point the model's step reaches.
+        self.signal_at = os.environ.get("EQH_PREFETCH_SIGNAL", "conv_last,readout")
         self._signal = None                 # ops.StepSignal: posted by a node of every step graph with index prefetch
         self.prefetch_hits = 0              # steps whose index had been built ahead
         self.prefetch_misses = 0            # steps that had to build it first (no next_data was given for them)
@@ -470,7 +472,7 @@ class GraphedTrainStep:
                     if sig is not None:
                         # the post that releases the NEXT batch's index build: where the model marks it (ops.signal_point:
                         # behind the EGNN edge kernel, when the chip stops being full), else at the head of the step
-                        sig.armed, sig.at = True, self.signal_at
+                        sig.armed, sig.at = True, self._signal_name
                         ops.SIGNAL = sig
                         if not (self.signal_in_model and self._signal_reached):
                             sig.post()
@@ -523,15 +525,14 @@ class GraphedTrainStep:
         snap = self._buffer_snapshot()
         from . import ops
 
-        class _Probe:       # does this model's step reach the signal point the trainer listens for (ops.signal_point)?
-            armed, reached, at = True, False, self.signal_at
+        class _Probe:       # which signal points does this model's step reach (ops.signal_point)?
+            armed = False
 
-            def post(self):
-                self.armed, self.reached = False, True
+            def __init__(self):
+                self.seen = set()
         probe = _Probe()
         with torch.cuda.stream(side):  # warm-up on a side stream, as graph capture requires
             for _ in range(2):
-                probe.armed = True
                 ops.SIGNAL = probe
                 try:
                     self._fwd_bwd(static)
@@ -539,7 +540,10 @@ class GraphedTrainStep:
                     ops.SIGNAL = None
             self._buffer_restore(snap)
         torch.cuda.current_stream().wait_stream(side)
-        self._signal_reached = probe.reached
+        # the first of the preferred points this model reaches (conv-stack models: before the last application; models without
+        # the stack: before the read-out head; else the head of the step)
+        self._signal_name = next((n for n in self.signal_at.split(",") if n in probe.seen), None)
+        self._signal_reached = self._signal_name is not None
         self.scratch.freeze()          # its address is about to become part of a graph
         prefetch = self._capture_index(static) if self.index_prefetch else None
         mode = "none"
