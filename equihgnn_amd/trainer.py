@@ -593,8 +593,8 @@ class GraphedTrainStep:
         that builds the staged batch's HyperIndex (CSR sorts, kNN, transposed kNN CSR) -- replayed on ``stream`` beside the
         running step; ``live``: a clone of that index, installed on the static batch, which is ALL the step graph reads;
         ``dsts / srcs``: the tensor pairs (index tensors + the batch's flat buffer) that ONE batched copy at the head of
-        every step moves from staged to live.  One step graph per bucket as before: alternating between two captured step
-        graphs costs ~0.8 ms per switch on ROCm 7.2, a 3 MB copy ~5 us."""
+        every step moves from staged to live (3 MB, ~4.4 us).  One step graph per bucket as before (two step graphs over two
+        sets of live buffers would save the copy and double the captures and the graphs' memory)."""
         from .index import HyperIndex
         ixw = getattr(static, "_hyper_index", None)
         flat = getattr(static, "_flat", None)
