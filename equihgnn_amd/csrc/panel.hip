@@ -934,6 +934,7 @@ struct ConvPanelArgs {
     float* out0; float* out1; float* out2; float* out3; float* out4; float* out5; float* out6;
     float* slab; float* slab2;
     float* acc_out;
+    int* signal;                    // F2: a device counter the first thread of the launch bumps (eqh_signal_post folded in), or null
 };
 
 // ---- F1: X -> h1 (raw), h1n = LN1(relu(h1 + b1a)), pa -------------------------------------------------------------------------
@@ -998,6 +999,9 @@ PN_KERNEL(NW) k_conv_f2(const ConvPanelArgs p) {
     const RtPos<NW> P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
     const bool mul = wave < S::NT;
     PN_STAMP(0);
+    // (round 6) the post that releases the next batch's index build on the trainer's side stream, folded into this launch: one
+    // launch slot (~4.7 us in a replayed graph) less than a one-thread kernel of its own
+    if (p.signal && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(p.signal, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     WStream<S::KS, S::NTW, 1, NW> ws;
     ws.init(0, p.w0, mul ? wave : 0, lane);
     ws.prime();
@@ -1529,6 +1533,7 @@ extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_)
     a.g_inc = q->g_inc; a.be_inc = q->be_inc;
     a.out0 = q->out0; a.out1 = q->out1; a.out2 = q->out2; a.out3 = q->out3; a.out4 = q->out4; a.out5 = q->out5; a.out6 = q->out6;
     a.slab = q->slab; a.slab2 = q->slab2; a.acc_out = q->acc_out;
+    a.signal = stage == HG_CONV_F2 ? q->signal : nullptr;
     if (a.ld0 & 3) return EQH_ERR_ALIGN;
     const int blocks = (int)((q->rows + PN_ROWS - 1) / PN_ROWS);
     const int nw = pn_waves();

@@ -44,7 +44,7 @@ class HgConvPanel(ctypes.Structure):
                 + [(n, c_void_p) for n in ("rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
                                            "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2",
                                            "acc_out", "dbias", "dgamma", "dbeta", "dbias2", "dgamma2", "dbeta2")]
-                + [("g_inc", c_void_p), ("be_inc", c_void_p), ("eps_inc", c_float), ("out6", c_void_p)])
+                + [("g_inc", c_void_p), ("be_inc", c_void_p), ("eps_inc", c_float), ("out6", c_void_p), ("signal", c_void_p)])
 
 
 class HgPanelMulti(ctypes.Structure):

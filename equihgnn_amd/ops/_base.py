@@ -127,6 +127,23 @@ def signal_point(name: str = "front_end"):
         sg.post()
 
 
+def signal_take(name: str):
+    """signal_point(name) for a caller whose NEXT launch can post the signal itself (hg_conv_panel's F2 stage takes a counter):
+    returns the armed signal's device counter -- the caller's launch must then bump it -- or None (nothing to do; under a
+    trainer's probe pass the point is recorded as reached)."""
+    sg = SIGNAL
+    if sg is None:
+        return None
+    seen = getattr(sg, "seen", None)
+    if seen is not None:
+        seen.add(name)
+        return None
+    if sg.armed and getattr(sg, "at", "front_end") == name:
+        sg.armed = False
+        return sg.counter
+    return None
+
+
 def _row_view(t, what):
     """2-D fp32 device tensor usable as a matrix operand in place (unit inner stride, 16-byte aligned rows)."""
     if not (t.dim() == 2 and t.dtype == torch.float32 and t.is_cuda):

@@ -67,13 +67,14 @@ class _MergedConvStack(torch.autograd.Function):
                                                            w1=iW2v, b0=b1a, g0=g1, be0=be1, out0=h1, out1=h1n, out2=pa))
         x_in = X.detach()          # (plain aliases on ctx: a tensor that carries a grad_fn there would tie the graph into a cycle)
         for l in range(L):
-            from ._base import signal_point
-            signal_point(f"conv_{l}")            # (before application l: where a trainer may release the next batch's index build)
-            if l == L - 1:
-                signal_point("conv_last")
+            from ._base import signal_take
+            # (before application l: where a trainer may release the next batch's index build -- posted by the F2 launch itself)
+            sig = signal_take(f"conv_{l}")
+            if sig is None and l == L - 1:
+                sig = signal_take("conv_last")
             hbar, qb, s = new(M), new(M), new(N)
             timed("k_conv_f2", flops(M, 1), lambda: conv_panel(hip.HG_CONV_F2, M, C, dev, in0=h1n, rowptr=ix.by_e.rowptr,
-                                                               col=ix.by_e.col, w0=iw12, bias_out=b12, out0=hbar, out1=qb))
+                                                               col=ix.by_e.col, w0=iw12, bias_out=b12, out0=hbar, out1=qb, signal=sig))
             by_v = ix.by_v
             tail = l + 1 < L
             u, x3, xn = new(N), new(N), new(N)

@@ -115,7 +115,7 @@ def panel_stream_gemm(a, w, trans_b: bool = True, alpha: float = 1.0, d=None, be
 
 _CP_PTRS = ("in0", "in1", "in2", "in3", "rowptr", "col", "wq", "w0", "w1", "w2", "w3", "b0", "g0", "be0", "b1", "g1", "be1",
             "bias_out", "out0", "out1", "out2", "out3", "out4", "out5", "slab", "slab2", "acc_out", "dbias", "dgamma", "dbeta",
-            "dbias2", "dgamma2", "dbeta2", "g_inc", "be_inc", "out6")
+            "dbias2", "dgamma2", "dbeta2", "g_inc", "be_inc", "out6", "signal")
 
 
 def conv_panel(stage: int, rows: int, C: int, device, eps: float = 1e-5, scale: float = 1.0, relu: bool = False,

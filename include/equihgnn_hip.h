@@ -223,6 +223,9 @@ typedef struct {
     const float *g_inc, *be_inc;
     float eps_inc;
     float* out6;
+    /* HG_CONV_F2 (round 6): an int32 device counter that the launch's first thread adds 1 to (eqh_signal_post folded into the
+     * stage: the trainer's index-prefetch stream waits on it with eqh_signal_wait), or NULL. */
+    int32_t* signal;
 } HgConvPanel;
 size_t hg_conv_panel_slab_bytes(int64_t rows, int32_t C);
 int hg_conv_panel(int32_t stage, const HgConvPanel* args, void* stream);
