@@ -103,8 +103,10 @@ class StepSignal:
         self.armed = False
         hip.check(hip.lib().eqh_signal_post(_ptr(self.counter), _stream(self.counter.device)), "eqh_signal_post")
 
-    def wait(self, target: int, timeout_us: int = 20000):
-        """Hold the CURRENT stream until the counter has reached ``target`` (at most timeout_us)."""
+    def wait(self, target: int, timeout_us: int = 200000):
+        """Hold the CURRENT stream until the counter has reached ``target`` (at most timeout_us: a step of the largest workload,
+        faformer_equihnns at batch 512, is 19 ms and the wait spans about one step; an expired wait only starts the index build
+        early -- the staged buffers' reuse is ordered by an event, not by this signal)."""
         t = ((int(target) + 2 ** 31) % 2 ** 32) - 2 ** 31          # the device counter wraps as int32
         hip.check(hip.lib().eqh_signal_wait(_ptr(self.counter), t, int(timeout_us), _stream(self.counter.device)), "eqh_signal_wait")
 
