@@ -759,8 +759,14 @@ def main():
 
             trainer.on_batch = fresh
             step = lambda j: trainer.step(batches[j % a.pool])
+        base = 2
+        # set-up as well: the trainer's choice between building the next index ahead and building it in the step (it times a
+        # window of steps in each form, GraphedTrainStep._calibrate: the same number of steps on every rank)
+        while getattr(trainer, "calibrating", False):
+            step(base)
+            base += 1
         for i in range(warmup):
-            step(2 + i)
+            step(base + i)
         els, clocks = [], []
         for blk in range(max(1, blocks or a.blocks)):
             torch.cuda.synchronize(dev)
@@ -769,7 +775,7 @@ def main():
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             for i in range(steps):
-                loss = step(2 + warmup + blk * steps + i)
+                loss = step(base + warmup + blk * steps + i)
             torch.cuda.synchronize(dev)
             if world > 1:
                 dist.barrier()
@@ -790,6 +796,8 @@ def main():
         on = any(s_.get("prefetch") is not None for s_ in tr0.slots.values())
         index_info = {"mode": "prefetch" if on else "in_step_graph", "steps_with_index_built_ahead": tr0.prefetch_hits,
                       "steps_that_built_it_first": tr0.prefetch_misses,
+                      "index_graph_alone_us": None if tr0.index_build_us is None else round(tr0.index_build_us, 1),
+                      "policy": tr0.prefetch_policy, "calibration": tr0.calibration,
                       "what": ("the per-batch index (three CSR sorts, kNN, transposed kNN CSR) of the NEXT step's batch is built by "
                                "its own small hipGraph on a side stream while this step's graph runs; one build per step, all "
                                "inside the timed region (device-wide synchronize at both ends); the step graph starts with "
@@ -875,7 +883,8 @@ def main():
                 ms_ = r_["el"] / a.other_steps * 1e3
                 others[label] = {"workload": what_, "ms_per_step": round(ms_, 3), "value": round(b_ / ms_ * 1e3, 1), "unit": "molecules/s",
                                  "steps": a.other_steps, "blocks_ms_per_step": [round(e / a.other_steps * 1e3, 3) for e in r_["els"]],
-                                 "final_loss": round(r_["loss"], 6), "launch": "hipGraph replay (padded static shapes)"}
+                                 "final_loss": round(r_["loss"], 6), "launch": "hipGraph replay (padded static shapes)",
+                                 "index_build": getattr(r_["trainer"], "calibration", None)}
                 r_["trainer"].close()
                 del r_
             except Exception as exc:  # noqa: BLE001 -- a side measurement must not cost the headline line

@@ -39,6 +39,10 @@
 #include "bf16x3.h"
 #include "drop_hash.h"
 
+#ifdef GX_ABLATE_SPLIT   // diagnostic build: the stagers store raw bits (no split arithmetic); results are garbage
+#define split_pair(x, y, a, b, c) ((a) = __float_as_uint(x), (b) = __float_as_uint(y), (c) = (a) ^ (b))
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -82,10 +86,16 @@ __device__ unsigned long long* gx_stamp_buf = nullptr;
 #define GX_STAMP(slot)                                                                                  \
     do {                                                                                                \
         if (gx_stamp_buf && (threadIdx.x & 63) == 0 && (slot) < 64)                                      \
-            gx_stamp_buf[((size_t)blockIdx.x * 12 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+            gx_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define GX_STAMP_SIMD()                                                                                 \
+    do {                                                                                                \
+        if (gx_stamp_buf && (threadIdx.x & 63) == 0)                                                     \
+            gx_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + 33] = __builtin_amdgcn_s_getreg(2308) + 1;   /* HW_ID.SIMD_ID + 1 */ \
     } while (0)
 #else
 #define GX_STAMP(slot) do { } while (0)
+#define GX_STAMP_SIMD() do { } while (0)
 #endif
 
 // LDS image of one operand tile (R rows x 32 k): [plane 3][row block R / 32][k half 2][slot 64] x 16 bytes -- the
@@ -266,43 +276,63 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// the tile `bid` of the launch: its problem (a COPY in registers: a reference is re-read from the kernarg segment after every
+// global store -- possible alias -- behind vmcnt(0)), its place in the output and its K steps [kt0, kt0 + NS) (split-K: with more
+// than one split the partial tile goes to a slab that a fixed-order reduction sums afterwards)
+#define GX_TILE(bid)                                                                                               \
+    const int lt = xcd_remap(bid, batch.total_tiles);                                                          \
+    int pi = 0;                                                                                                \
+    _Pragma("unroll")                                                                                          \
+    for (int i = 1; i < GX_MAXP; ++i)                                                                          \
+        if (i < batch.n && lt >= batch.p[i].first_tile) pi = i;                                                \
+    const GxProb P = batch.p[pi];                                                                              \
+    const int local = lt - P.first_tile;                                                                       \
+    const int tile = local % P.tiles_mn, split = local / P.tiles_mn;                                           \
+    const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;                                      \
+    const int M = P.M, N = P.N, K = P.K;                                                                       \
+    const int KT = K / GX_BK, rem = K - KT * GX_BK;                                                            \
+    const int kt0 = split * P.chunk_steps;                                                                     \
+    const int NS = min(KT + (rem > 0 ? 1 : 0) - kt0, P.chunk_steps);
+
 // MT x NT: 32 x 32 MFMA tiles per multiplying wavefront; the four of them sit 2 x 2: block tile 64 MT x 64 NT
 // WR x WC: the multiplying wavefronts' grid (2 x 2; 2 x 4 and 4 x 2 for the 128 x 256 / 256 x 128 tiles, one workgroup per CU)
+//
+// A workgroup walks the tiles blockIdx.x, blockIdx.x + gridDim.x, ...  The one-per-CU configurations (MINW <= 4: their ring
+// leaves no room for a second workgroup) are launched with ONE WORKGROUP PER CU (round 6): nothing else on the CU could cover a
+// tile's prologue -- the stagers' first loads, an HBM latency plus a split, 6-8 k cycles of a 57 k-cycle tile at K = 256 -- so
+// the SAME workgroup covers it: its stagers request and split the next tile's first stages while its multipliers are in the
+// epilogue of this one (whose LDS pieces lie in the ring stage the stagers reach last).  Same box: [246 k x 256].[256 x 256]
+// 204 against 212 us, [1.97 M x 128].[128 x 256] 941 against 1033, the 128 x 128 tile 213 against 238; FAFormer's step 19.0
+// against 19.5-19.6 ms.  (EQH_X6_TILES_PER_WG=n caps a workgroup's tiles for A/B runs: 1 is the old launch; 4 loses to both --
+// 304 workgroups of 4 tiles on 256 CUs are two rounds.)  The two-per-CU configurations keep one tile per workgroup: their CU
+// partner covers the prologue.
 template <int MT, int NT, int S, int MINW, bool A_KS, bool B_KS, int WR = 2, int WC = 2, bool B_PRE = false>
 __global__ void __launch_bounds__(64 * WR * WC + GX_STAGERS, MINW)
 k_gemm_x6(const GxBatch batch) {
     constexpr int BM = 32 * WR * MT, BN = 32 * WC * NT;
     constexpr int NMT = 64 * WR * WC;                                              // multiplying threads
     constexpr int SA = 3 * (BM / 32) * 2 * 64, SB = 3 * (BN / 32) * 2 * 64;       // uint4 per stage
-    __shared__ uint4 s_mem[S * (SA + SB)];                                         // ring of stages, each [A | B]
+    constexpr bool PERSIST = MINW <= 4;
+    constexpr int RING = S * (SA + SB);
+    __shared__ uint4 s_mem[RING];                                                  // ring of stages, each [A | B]
 
-    const int lt = xcd_remap((int)blockIdx.x, batch.total_tiles);
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < GX_MAXP; ++i)
-        if (i < batch.n && lt >= batch.p[i].first_tile) pi = i;
-    const GxProb P = batch.p[pi];                  // a COPY in registers: a reference is re-read from the kernarg
-                                                   // segment after every global store (possible alias), behind vmcnt(0)
-    const int local = lt - P.first_tile;
-    const int tile = local % P.tiles_mn, split = local / P.tiles_mn;
-    const int m0 = (tile / P.tiles_n) * BM, n0 = (tile % P.tiles_n) * BN;
-    const int M = P.M, N = P.N, K = P.K;
-    const int KT = K / GX_BK, rem = K - KT * GX_BK;         // full K steps; the last step may be partial (zero-filled)
-    // split-K: this workgroup multiplies K steps [kt0, kt0 + NS) and, with more than one split, leaves its partial tile
-    // in a slab that a fixed-order reduction sums afterwards (weight gradients: few output tiles, millions of rows)
-    const int kt0 = split * P.chunk_steps;
-    const int NS = min(KT + (rem > 0 ? 1 : 0) - kt0, P.chunk_steps);
-
-    // Two roles, one barrier per K step.  During step k the four MULTIPLIERS (wavefronts 0-3) read the fragments of
-    // tile k from ring stage k % S and issue its MFMAs; the STAGERS (wavefronts 4-11, two groups of four) keep the
-    // ring S - 1 tiles ahead: the group whose turn it is splits tile k + S - 1 -- which it requested from global memory
+    // Two roles, one barrier per K step (and one before a tile's first).  During step k the four MULTIPLIERS (wavefronts 0-3)
+    // read the fragments of tile k from ring stage k % S and issue its MFMAs; the STAGERS (wavefronts 4-11, two groups of four)
+    // keep the ring S - 1 tiles ahead: the group whose turn it is splits tile k + S - 1 -- which it requested from global memory
     // during the PREVIOUS step -- into stage (k + S - 1) % S, the stage the multipliers left at the last barrier, while
     // the other group requests tile k + S.  A stager is plain synchronous code (load, wait, split, store): the two
     // groups alternating hide the memory latency, not a register pipeline, so the compiler's own waits are exact.
     // A SIMD hosts one multiplier and two stagers per resident block; the hardware interleaves the stagers' VALU work
     // with the multipliers' MFMAs (the 32 x 32 x 16 MFMA holds the vector issue port for 8 of its 32 cycles).
-    GX_STAMP(0);
+    GX_STAMP_SIMD();
     if (threadIdx.x >= NMT) {
+#ifdef GX_PRIO_STAGERS
+        __builtin_amdgcn_s_setprio(GX_PRIO_STAGERS);
+#endif
+        int bid = (int)blockIdx.x;
+        do {
+        GX_TILE(bid)
+        GX_STAMP(0);
         using LA = Loader<BM, A_KS>;
         using LB = std::conditional_t<B_PRE, LoadPre<BN>, Loader<BN, B_KS>>;
         LA la;
@@ -315,6 +345,9 @@ k_gemm_x6(const GxBatch batch) {
         const int grp = ((int)threadIdx.x - NMT) >> 8;      // 0 or 1 (wavefront-uniform)
         auto fetch = [&](int w) {                           // w: step within this split
             if (w >= NS) return;
+#ifdef GX_ABLATE_STAGE
+            return;
+#endif
             if (kt0 + w < KT) {
                 la.fetch(ra, kt0 + w);
                 if constexpr (!B_PRE) lb.fetch(rb, kt0 + w);     // (the pre-split planes are fetched where they are staged: below)
@@ -325,6 +358,9 @@ k_gemm_x6(const GxBatch batch) {
         };
         auto stage = [&](int w) {
             if (w >= NS) return;
+#ifdef GX_ABLATE_STAGE
+            return;
+#endif
             uint4* st = s_mem + (w % S) * (SA + SB);
             if constexpr (B_PRE) {
                 // planes from L2 straight through registers into the stage (held across the barrier, as the fp32 operands are, the
@@ -357,10 +393,18 @@ k_gemm_x6(const GxBatch batch) {
             GX_STAMP(k < 14 ? 4 + 2 * k : 63);
         }
         GX_STAMP(31);
+        } while (PERSIST && (bid += (int)gridDim.x) < batch.total_tiles);
         return;
     }
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef GX_PRIO_MULT
+    __builtin_amdgcn_s_setprio(GX_PRIO_MULT);
+#endif
+    int bid = (int)blockIdx.x;
+    do {
+    GX_TILE(bid)
+    GX_STAMP(0);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WC, wn = wave % WC;
     const int fh = lane >> 5, fr = lane & 31;
     const int frag_off0 = fh * 32 + (fr ^ (2 * fh)), frag_off1 = 64 + fh * 32 + (fr ^ (2 * (2 + fh)));   // k halves
@@ -373,44 +417,52 @@ k_gemm_x6(const GxBatch batch) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
+    // one K step from ring stage k % S is two 16-deep halves, each 3 x (MT + NT) fragment reads and 6 x MT x NT MFMAs (smallest
+    // terms first).  (Measured and not kept, round 6: with two multiplying wavefronts per SIMD, the second one running half a step
+    // late -- a step's second-half fragments held in registers across the barrier and multiplied while the first one reads:
+    // [246 k x 256].[256 x 256] 232 against 205 us; the two in step, reading together and multiplying together, are the faster form.)
+    bf16x8 fa[3][MT], fb[3][NT];
+    auto rd = [&](const uint4* __restrict__ sa, const uint4* __restrict__ sb, int off) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                fa[p][m] = __builtin_bit_cast(bf16x8, sa[(p * (BM / 32) + wm * MT + m) * 128 + off]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                fb[p][n] = __builtin_bit_cast(bf16x8, sb[(p * (BN / 32) + wn * NT + n) * 128 + off]);
+        }
+    };
+#define GX_MM(PA, PB)                                                                                              \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                             \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                             \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][n], fa[PA][m], acc[m][n], 0, 0, 0);
+    auto mm = [&]() {
+#ifndef GX_ABLATE_MFMA
+        GX_MM(1, 1) GX_MM(0, 2) GX_MM(2, 0) GX_MM(0, 1) GX_MM(1, 0) GX_MM(0, 0)
+#else
+        _Pragma("unroll") for (int p = 0; p < 3; ++p) {
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) { asm volatile("" :: "v"(fa[p][m])); }
+            _Pragma("unroll") for (int n = 0; n < NT; ++n) { asm volatile("" :: "v"(fb[p][n])); }
+        }
+#endif
+    };
     GX_STAMP(1);
     __syncthreads();
     GX_STAMP(2);
     for (int k = 0; k < NS; ++k) {
-        // one K step from ring stage k % S: 6 x (MT + NT) fragment reads, 12 x MT x NT MFMAs (smallest terms first)
         const uint4* __restrict__ sa = s_mem + (k % S) * (SA + SB);
         const uint4* __restrict__ sb = sa + SA;
-#pragma unroll
-        for (int kh = 0; kh < 2; ++kh) {            // the two 16-deep halves of the step, one after the other (registers)
-            const int off = kh ? frag_off1 : frag_off0;
-            bf16x8 fa[3][MT], fb[3][NT];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    fa[p][m] = __builtin_bit_cast(bf16x8, sa[(p * (BM / 32) + wm * MT + m) * 128 + off]);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    fb[p][n] = __builtin_bit_cast(bf16x8, sb[(p * (BN / 32) + wn * NT + n) * 128 + off]);
-            }
-#define GX_MM(PA, PB)                                                                                              \
-            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                             \
-            _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                             \
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[PB][n], fa[PA][m], acc[m][n], 0, 0, 0);
-#ifndef GX_ABLATE_MFMA
-            GX_MM(1, 1) GX_MM(0, 2) GX_MM(2, 0) GX_MM(0, 1) GX_MM(1, 0) GX_MM(0, 0)
-#else
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) {
-                _Pragma("unroll") for (int m = 0; m < MT; ++m) { asm volatile("" :: "v"(fa[p][m])); }
-                _Pragma("unroll") for (int n = 0; n < NT; ++n) { asm volatile("" :: "v"(fb[p][n])); }
-            }
-#endif
-#undef GX_MM
-        }
+        rd(sa, sb, frag_off0);
+        mm();
+        rd(sa, sb, frag_off1);
+        mm();
         GX_STAMP(k < 14 ? 3 + 2 * k : 63);
         __syncthreads();
         GX_STAMP(k < 14 ? 4 + 2 * k : 63);
     }
+#undef GX_MM
+    GX_STAMP(32);
 
     // epilogue.  The MFMA ran with the operands swapped (D' = C^T tile): lane (fr, fh) holds row fr of the 32 x 32 tile
     // and, in register group g, the four consecutive columns 8 g + 4 fh .. + 3.  Stored like that a wavefront-store would
@@ -421,9 +473,16 @@ k_gemm_x6(const GxBatch batch) {
     const bool relu = (P.flags & GX_RELU) != 0;
     const float* __restrict__ D = P.D;
     const float* __restrict__ bias = P.bias;
+    // The pieces lie in ring stage S - 1: the stagers, who after a tile's last barrier go on to the next tile of the workgroup, write
+    // its first S - 1 stages (0 .. S - 2) before the barrier that the multipliers reach only after this epilogue.
     constexpr int EP_LD = 36;                                  // floats per staged row (32 + 4: conflict-free b128 writes)
-    float* ep = reinterpret_cast<float*>(s_mem) + wave * (32 * EP_LD);
-    const int er = lane >> 3, ec = (lane & 7) * 4;            // read-back: row er + 8 i, columns ec .. ec + 3
+    static_assert((NMT / 64) * 32 * EP_LD * 4 <= (SA + SB) * 16, "the epilogue pieces fit one ring stage");
+    float* ep = reinterpret_cast<float*>(s_mem + (S - 1) * (SA + SB)) + wave * (32 * EP_LD);
+    int le = lane;
+    if constexpr (PERSIST) asm volatile("" : "+v"(le));       // (the epilogue's lane arithmetic stays in the epilogue: hoisted out of the
+                                                               // tile loop it cost 34 spilled registers, reloaded from scratch memory here)
+    const int er = le >> 3, ec = (le & 7) * 4;                 // read-back: row er + 8 i, columns ec .. ec + 3
+    const int pr = le & 31, ph = le >> 5;                      // (fr, fh again)
     // (the addend / bias loads are unconditional, from clamped addresses, in their own instantiation: loads inside
     // branches make the compiler wait vmcnt(0) -- i.e. for every earlier STORE too -- before each use)
     auto finish = [&](auto has_d, auto has_bias) {
@@ -433,7 +492,7 @@ k_gemm_x6(const GxBatch batch) {
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                    *reinterpret_cast<float4*>(ep + pr * EP_LD + 8 * g + 4 * ph) =
                         make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
                 const int col = n0 + (wn * NT + n) * 32 + ec;
                 const int colc = col < N ? col : N - 4;
@@ -472,14 +531,14 @@ k_gemm_x6(const GxBatch batch) {
         const uint32_t thr = P.drop_threshold;
         const float inv_keep = P.drop_inv_keep;
         const DropKey key = drop_key(thr ? (uint64_t)*P.drop_seed : 0);
-        const int grp = lane >> 4, part = (lane >> 3) & 1;            // frame group 0..3 of the 32 rows, its lower / upper half
+        const int grp = le >> 4, part = (le >> 3) & 1;              // frame group 0..3 of the 32 rows, its lower / upper half
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                    *reinterpret_cast<float4*>(ep + pr * EP_LD + 8 * g + 4 * ph) =
                         make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
                 const int col = n0 + (wn * NT + n) * 32 + ec;
                 const int colc = col < N ? col : N - 4;
@@ -521,7 +580,7 @@ k_gemm_x6(const GxBatch batch) {
             for (int n = 0; n < NT; ++n) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<float4*>(ep + fr * EP_LD + 8 * g + 4 * fh) =
+                    *reinterpret_cast<float4*>(ep + pr * EP_LD + 8 * g + 4 * ph) =
                         make_float4(acc[m][n][4 * g + 0], acc[m][n][4 * g + 1], acc[m][n][4 * g + 2], acc[m][n][4 * g + 3]);
                 const int col = n0 + (wn * NT + n) * 32 + ec;
 #pragma unroll
@@ -536,11 +595,25 @@ k_gemm_x6(const GxBatch batch) {
     } else if (D) { if (bias) finish(T_{}, T_{}); else finish(T_{}, F_{}); }
     else   { if (bias) finish(F_{}, T_{}); else finish(F_{}, F_{}); }
     GX_STAMP(31);
+    } while (PERSIST && (bid += (int)gridDim.x) < batch.total_tiles);   // the tiles of this workgroup
 }
 
 template <int MT, int NT, int S, int MINW, int WR = 2, int WC = 2>
 int launch(const GxBatch& b, bool a_ks, bool b_ks, hipStream_t stream, bool b_pre = false) {
-    const dim3 grid(b.total_tiles), block(64 * WR * WC + GX_STAGERS);
+    // the one-per-CU configurations: one workgroup per CU walks its share of the tiles (a multiple of 8 workgroups: a workgroup's
+    // tiles stay on its XCD's L2)
+    static const int per_wg = [] { const char* e = getenv("EQH_X6_TILES_PER_WG"); const int v = e ? atoi(e) : 0; return v > 0 ? v : (1 << 20); }();
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return n & ~7;
+    }();
+    int n_wg = b.total_tiles;
+    if (MINW <= 4 && per_wg > 1 && b.total_tiles > cus) {       // (never fewer workgroups than CUs)
+        n_wg = (((b.total_tiles + per_wg - 1) / per_wg) + 7) & ~7;
+        if (n_wg < cus) n_wg = cus;
+    }
+    const dim3 grid(n_wg), block(64 * WR * WC + GX_STAGERS);
     if (b_pre) {
         if (a_ks) return EQH_ERR_ARG;
         hipLaunchKernelGGL((k_gemm_x6<MT, NT, S, MINW, false, false, WR, WC, true>), grid, block, 0, stream, b);

@@ -201,8 +201,23 @@ class GraphedTrainStep:
         # depends on the batch only, not on the parameters.  step(data, next_data) builds next_data's index on a side
         # stream (its own small hipGraph) WHILE the step graph of `data` runs, and the step graph then starts at the
         # embedding.  EQH_NO_INDEX_PREFETCH=1: the index stays at the head of the step graph (rounds 1-5).
+        #
+        # Whether that pays depends on the model (round 6, same box, ms per step with / without): egnn_equihnns 1.122 / 1.181 at
+        # batch 256 and 5.24 / 5.54 on PCQM batches of 1024, faformer_equihnns 18.9 / 19.0 -- but equiformer_equihnns 5.20 / 4.95,
+        # mhnnm 0.872 / 0.810 at batch 32, egnn_equihnn 1.85 / 1.79: the staged -> live copy, the signal and the rendezvous of the
+        # two streams cost a step more than a short index build saves, and neither the index graph's own time (93 us for both
+        # EGNN models) nor the step's length predicts the sign.  So the trainer MEASURES (``prefetch_policy == "auto"``): the
+        # first captured steps run in the built-ahead form, a window of them is timed, the same number in the in-step form, and
+        # the faster form stays (``calibrating``, ``calibration``; the two forms are numerically the same step).
+        # EQH_NO_INDEX_PREFETCH=1 / EQH_INDEX_PREFETCH=1 (or assigning ``index_prefetch``) pin a form.
         import os
-        self.index_prefetch = not os.environ.get("EQH_NO_INDEX_PREFETCH")
+        self.prefetch_policy = ("off" if os.environ.get("EQH_NO_INDEX_PREFETCH") else
+                                "on" if os.environ.get("EQH_INDEX_PREFETCH") else "auto")
+        self._prefetch_on = self.prefetch_policy != "off"
+        self._cal = None                    # calibration state (auto policy): see _calibrate
+        self._alt_slots = None              # the captured steps of the form that is not running, while calibrating
+        self.calibration = None             # {"built_ahead_ms": .., "in_step_ms": .., "chosen": ..} once decided
+        self.index_build_us = None          # the index graph alone, timed at the first capture (_capture_index)
         self.signal_in_model = not os.environ.get("EQH_PREFETCH_AT_HEAD")    # start the next index at the model's ops.signal_point()
         # which of the marked points releases it.  Measured at the BASELINE batch (same box, ms per step): index at the head
         # of the step graph 1.137; built ahead and released at the step's head 1.138 (it then competes with the chip-filling
@@ -272,6 +287,7 @@ class GraphedTrainStep:
             if hasattr(p, "_eqh_gbuf"):
                 del p._eqh_gbuf
         self.gb_params, self.slots, self.live = [], {}, None
+        self._alt_slots, self._cal = None, None
 
     def _buffer_snapshot(self):
         return [b.detach().clone() for b in self.model.buffers()]
@@ -545,7 +561,7 @@ class GraphedTrainStep:
         self._signal_name = next((n for n in self.signal_at.split(",") if n in probe.seen), None)
         self._signal_reached = self._signal_name is not None
         self.scratch.freeze()          # its address is about to become part of a graph
-        prefetch = self._capture_index(static) if self.index_prefetch else None
+        prefetch = self._capture_index(static) if self._prefetch_on else None
         mode = "none"
         if multi:
             mode = "in_graph" if (self.graph_collective and dist.get_backend() in self.in_graph_backends
@@ -626,6 +642,16 @@ class GraphedTrainStep:
         g_index = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_index, capture_error_mode="thread_local"):
             ix_staged = build()
+        # the index graph alone (reported by bench.py; a pure function of the staged batch)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            g_index.replay()
+            e0.record(stream)
+            for _ in range(3):
+                g_index.replay()
+            e1.record(stream)
+        e1.synchronize()
+        self.index_build_us = e0.elapsed_time(e1) * 1e3 / 3
         live, dsts, srcs = ix_staged.live_clone(static)
         static._hyper_index, static._index_is_live = live, True
         as_words = lambda t: t.view(torch.float32) if t.dtype != torch.float32 else t
@@ -636,6 +662,74 @@ class GraphedTrainStep:
         free.record(torch.cuda.current_stream())
         return {"staged": staged, "g_index": g_index, "ix_staged": ix_staged, "live": live, "dsts": dsts, "srcs": srcs,
                 "stream": stream, "free": free, "ready": None, "holds": None}
+
+    @property
+    def index_prefetch(self) -> bool:
+        """Whether newly captured steps take the built-ahead form.  Assigning it pins the form (no calibration)."""
+        return self._prefetch_on
+
+    @index_prefetch.setter
+    def index_prefetch(self, on: bool):
+        self._prefetch_on = bool(on)
+        self.prefetch_policy = "on" if on else "off"
+        self._cal = None
+        if self._alt_slots is not None:
+            self._alt_slots = None
+            import gc
+            gc.collect()
+
+    @property
+    def calibrating(self) -> bool:
+        """True until the auto policy has timed both forms of the step and kept one (callers that time steps themselves --
+        bench.py -- run steps until this clears before their own warm-up)."""
+        return self.prefetch_policy == "auto" and self.calibration is None
+
+    CAL_WARM, CAL_STEPS = 3, 12          # replays before a timed window, steps in it
+
+    def _calibrate(self, key):
+        """Auto policy, called at the head of every graphed step until the decision: per form, one capture step, CAL_WARM
+        replays, then CAL_STEPS steps between two device synchronisations (wall clock: the two streams overlap, so no single
+        stream's events see a step).  A step of another bucket restarts the window."""
+        import gc
+        import time
+        c = self._cal
+        if c is None:
+            c = self._cal = {"form": "built_ahead", "key": key, "n": 0, "t": {}, "restarts": 0}
+        if key != c["key"]:
+            c["key"], c["n"] = key, 0
+            c["restarts"] += 1
+            if c["restarts"] > 16:          # buckets alternate too fast to time a window: keep the form that is running
+                self._decide(None)
+            return
+        c["n"] += 1
+        first_timed = 1 + self.CAL_WARM + 1
+        if c["n"] == first_timed:
+            torch.cuda.synchronize()
+            c["t0"] = time.perf_counter()
+        elif c["n"] == first_timed + self.CAL_STEPS:
+            torch.cuda.synchronize()
+            c["t"][c["form"]] = (time.perf_counter() - c["t0"]) / self.CAL_STEPS * 1e3
+            if c["form"] == "built_ahead":  # now the other form: every bucket is captured again, the graphs so far are kept aside
+                self._alt_slots, self.slots = self.slots, {}
+                self._prefetch_on = False
+                c["form"], c["n"] = "in_step", 1
+            else:
+                self._decide(c["t"])
+
+    def _decide(self, t):
+        import gc
+        ahead = t is not None and t["built_ahead"] < 0.99 * t["in_step"]
+        if t is None:
+            ahead = self._prefetch_on
+        elif ahead:                          # back to the graphs of the first window
+            self.slots, self._alt_slots = self._alt_slots, None
+            self._prefetch_on = True
+        self._alt_slots = None
+        gc.collect()                         # (dropped graphs are destroyed now, not inside a later capture)
+        self.calibration = {"built_ahead_ms": None if t is None else round(t["built_ahead"], 4),
+                            "in_step_ms": None if t is None else round(t["in_step"], 4),
+                            "steps_per_window": self.CAL_STEPS, "chosen": "built_ahead" if ahead else "in_step"}
+        self._cal = None
 
     @staticmethod
     def _token(data):
@@ -682,6 +776,8 @@ class GraphedTrainStep:
         if self.live is None:
             return self._bootstrap(data)
         key = self._key(data)
+        if self.prefetch_policy == "auto" and self.calibration is None:
+            self._calibrate(key)
         slot = self.slots.get(key)
         if slot is None:
             if hasattr(data, "packed"):

@@ -793,6 +793,53 @@ def test_index_built_ahead_on_the_side_stream_gives_the_same_steps(method):
             assert torch.equal(v, finals["in_step"][0][k]), (label, k)
 
 
+@pytest.mark.gpu
+def test_the_trainer_times_both_forms_of_the_index_build_and_keeps_one_without_changing_the_steps():
+    """Auto policy (GraphedTrainStep._calibrate): a window of steps with the next index built ahead, a window with it built in
+    the step, the faster form stays -- and the sequence of steps is the one a trainer pinned to either form takes."""
+    method = "egnn_equihnns"
+    import copy
+    from common import zero_dropouts
+    from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
+    from equihgnn_amd.registry import default_args
+    from equihgnn_amd.trainer import GraphedTrainStep, with_next
+    args = default_args(method=method, MLP_hidden=64, output_hidden=32)
+    m0 = _models()[method](1, args)
+    fill_state_dict(m0, 4)
+    zero_dropouts(m0)
+    m0.to(DEV)
+    raw = [synth_batch(8, 1700 + i) for i in range(3)]
+    ext = [bucket_sizes(b.num_nodes, b.num_hyperedges, b.nnz, 64) for b in raw]
+    tgt = tuple(max(e[i] for e in ext) for i in range(3))
+    padded = [pad_batch(b, *tgt).packed().to(DEV) for b in raw]
+    for b in padded:
+        b.num_real_graphs = 8
+    n_steps = 2 * (2 + GraphedTrainStep.CAL_WARM + GraphedTrainStep.CAL_STEPS) + 6
+    order = [padded[i % 3] for i in range(n_steps)]
+    finals = {}
+    for label in ("auto", "in_step"):
+        m = copy.deepcopy(m0)
+        tr = GraphedTrainStep(m, lr=1e-3)
+        if label == "in_step":
+            tr.index_prefetch = False
+            assert not tr.calibrating
+        else:
+            assert tr.prefetch_policy == "auto" and tr.calibrating
+        losses = [float(tr.step(b, nxt)) for b, nxt in with_next(order)]
+        torch.cuda.synchronize()
+        if label == "auto":
+            assert not tr.calibrating and tr.calibration["chosen"] in ("built_ahead", "in_step")
+            assert tr.calibration["built_ahead_ms"] > 0 and tr.calibration["in_step_ms"] > 0
+            assert tr._alt_slots is None
+            slot = next(iter(tr.slots.values()))
+            assert (slot["prefetch"] is not None) == (tr.calibration["chosen"] == "built_ahead") == tr.index_prefetch
+        finals[label] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses)
+        tr.close()
+    assert finals["auto"][1] == finals["in_step"][1]
+    for k, v in finals["auto"][0].items():
+        assert torch.equal(v, finals["in_step"][0][k]), k
+
+
 def test_a_rank_that_cannot_capture_the_collective_takes_every_rank_to_the_split_form(tmp_path):
     """main.py:271-283 trains under DDP, where every rank runs the same collective sequence by construction; here the form of
     the step (all-reduce inside the hipGraph or between two graphs) is decided at capture time, so the ranks must agree on it."""

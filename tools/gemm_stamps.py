@@ -24,7 +24,7 @@ def main():
     extra = [f"-D{d}" for d in os.environ.get("GX_DEFS", "").split() if d]
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-DGX_STAMPS", *extra,
                            "-ffp-contract=off", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "equihgnn_amd", "csrc"),
-                           os.path.join(ROOT, "equihgnn_amd", "csrc", "gemm_x6.hip"), "-o", so])
+                           os.path.join(ROOT, "equihgnn_amd", "csrc", "gemm_x6.hip"), os.path.join(ROOT, "equihgnn_amd", "csrc", "api.hip"), "-o", so])
     L = ctypes.CDLL(so)
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -33,7 +33,7 @@ def main():
     C = torch.empty(M, N, device=dev)
     tm = 128 if tile == 128 else 64
     n_blocks = ((M + tm - 1) // tm) * ((N + 63) // 64)
-    buf = torch.zeros(n_blocks * 12 * 64, dtype=torch.int64, device=dev)
+    buf = torch.zeros(n_blocks * 16 * 64, dtype=torch.int64, device=dev)
     pr = (hip.HgGemmProblem * 1)()
     q = pr[0]
     q.a, q.lda, q.b, q.ldb, q.c, q.ldc = A.data_ptr(), A.stride(0), B.data_ptr(), B.stride(0), C.data_ptr(), C.stride(0)
@@ -45,16 +45,28 @@ def main():
         assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
     torch.cuda.synchronize()
     assert L.hg_gemm_x6_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
-    assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
+    e1.record()
     torch.cuda.synchronize()
+    wall_us = e0.elapsed_time(e1) * 1e3 / 20
     ref = (A.t() if ta else A) @ (B.t() if tb else B)
     print("max |err|", float((C - ref).abs().max()))
-    st = buf.cpu().numpy().reshape(n_blocks, 12, 64).astype(np.int64)
+    st = buf.cpu().numpy().reshape(n_blocks, 16, 64).astype(np.int64)
+    nm = 8 if tile in (512, 513) else 4
+    tn = {64: 64, 128: 64, 256: 128, 512: 256, 513: 128}[tile]
+    tmm = {64: 64, 128: 128, 256: 128, 512: 128, 513: 256}[tile]
+    real = ((M + tmm - 1) // tmm) * ((N + tn - 1) // tn)
+    st = st[:real, :nm + 8]
+    n_blocks = real
     t0 = st[:, :, 0].min()
-    print(f"blocks {n_blocks}; kernel span {int(st[:, :, 31].max() - t0)} cycles")
+    print(f"blocks {n_blocks}; kernel span {int(st[:, :, 31].max() - t0)} cycles; {wall_us:.1f} us per launch -> {float(st[:, :, 31].max() - t0) / wall_us:.0f} MHz if the span is the launch; "
+          f"{2.0 * M * N * K / wall_us / 1e6:.1f} TFLOP/s")
     steps = min((K + 31) // 32, 13)                 # (the stamp record holds 32 slots per wavefront)
     lo, hi = n_blocks // 3, 2 * n_blocks // 3 + 1
-    for role, waves in (("multiplier", range(0, 4)), ("stager g0", range(4, 8)), ("stager g1", range(8, 12))):
+    for role, waves in (("multiplier", range(0, nm)), ("stager g0", range(nm, nm + 4)), ("stager g1", range(nm + 4, nm + 8))):
         s = st[lo:hi][:, list(waves), :]
         med = lambda x: float(np.median(x))
         print(f"--- {role} (median over blocks {lo}..{hi})")
@@ -71,6 +83,7 @@ def main():
             print(f"  last barrier -> end            : {med(s[:, :, 31] - s[:, :, 2 + 2 * steps]):9.0f}")
         print(f"  lifetime                       : {med(s[:, :, 31] - s[:, :, 0]):9.0f}")
     # launch cadence: start times of consecutive blocks on the same slot are unknown; print the distribution of starts
+    print("SIMD of wavefronts 0 .. (first blocks):", [[int(x) - 1 for x in st[b, :, 33]] for b in range(0, min(n_blocks, 3))])
     starts = np.sort(st[:, 0, 0] - t0)
     print("block start percentiles (cycles):", [int(np.percentile(starts, p)) for p in (0, 10, 25, 50, 75, 90, 100)])
 
