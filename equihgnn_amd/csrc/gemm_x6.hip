@@ -88,6 +88,14 @@ __device__ unsigned long long* gx_stamp_buf = nullptr;
         if (gx_stamp_buf && (threadIdx.x & 63) == 0 && (slot) < 64)                                      \
             gx_stamp_buf[((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (slot)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
+#define GX_STAMP_CLOCK(slot)                                                                            \
+    do {                                                                                                \
+        if (gx_stamp_buf && (threadIdx.x & 63) == 0) {                                                   \
+            unsigned long long* q_ = gx_stamp_buf + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 64 + (slot);            \
+            q_[0] = __builtin_amdgcn_s_memtime();                                                        \
+            q_[1] = __builtin_amdgcn_s_memrealtime();     /* 100 MHz */                                  \
+        }                                                                                               \
+    } while (0)
 #define GX_STAMP_SIMD()                                                                                 \
     do {                                                                                                \
         if (gx_stamp_buf && (threadIdx.x & 63) == 0)                                                     \
@@ -96,6 +104,7 @@ __device__ unsigned long long* gx_stamp_buf = nullptr;
 #else
 #define GX_STAMP(slot) do { } while (0)
 #define GX_STAMP_SIMD() do { } while (0)
+#define GX_STAMP_CLOCK(slot) do { } while (0)
 #endif
 
 // LDS image of one operand tile (R rows x 32 k): [plane 3][row block R / 32][k half 2][slot 64] x 16 bytes -- the
@@ -400,6 +409,7 @@ k_gemm_x6(const GxBatch batch) {
 #ifdef GX_PRIO_MULT
     __builtin_amdgcn_s_setprio(GX_PRIO_MULT);
 #endif
+    GX_STAMP_CLOCK(34);
     int bid = (int)blockIdx.x;
     do {
     GX_TILE(bid)
@@ -450,6 +460,8 @@ k_gemm_x6(const GxBatch batch) {
     GX_STAMP(1);
     __syncthreads();
     GX_STAMP(2);
+    // (Measured and not kept, round 6: on the three-stage 128 x 128 tile -- stage k + 1 is complete one barrier early there -- the
+    // fragments a step multiplies first read during the previous step: 230-238 against 209-212 us for the two-stage tile.)
     for (int k = 0; k < NS; ++k) {
         const uint4* __restrict__ sa = s_mem + (k % S) * (SA + SB);
         const uint4* __restrict__ sb = sa + SA;
@@ -596,6 +608,7 @@ k_gemm_x6(const GxBatch batch) {
     else   { if (bias) finish(F_{}, T_{}); else finish(F_{}, F_{}); }
     GX_STAMP(31);
     } while (PERSIST && (bid += (int)gridDim.x) < batch.total_tiles);   // the tiles of this workgroup
+    GX_STAMP_CLOCK(36);
 }
 
 template <int MT, int NT, int S, int MINW, int WR = 2, int WC = 2>

@@ -41,9 +41,8 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     L.hg_gemm_x6_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(hip.HgGemmProblem), ctypes.c_int32, ctypes.c_void_p,
                                    ctypes.c_size_t, ctypes.c_void_p]
-    for _ in range(3):
+    for _ in range(int(os.environ.get('GX_WARM', '2000'))):      # ~0.5 s of back-to-back launches: the clock the chip HOLDS under this load
         assert L.hg_gemm_x6_batch(1, pr, tile, None, 0, stream) == 0
-    torch.cuda.synchronize()
     assert L.hg_gemm_x6_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -59,6 +58,8 @@ def main():
     tn = {64: 64, 128: 64, 256: 128, 512: 256, 513: 128}[tile]
     tmm = {64: 64, 128: 128, 256: 128, 512: 128, 513: 256}[tile]
     real = ((M + tmm - 1) // tmm) * ((N + tn - 1) // tn)
+    if tile in (256, 512, 513) and real > 256:
+        real = 256          # one workgroup per CU walks the tiles: the stamps are those of a workgroup's LAST tile
     st = st[:real, :nm + 8]
     n_blocks = real
     t0 = st[:, :, 0].min()
@@ -83,6 +84,11 @@ def main():
             print(f"  last barrier -> end            : {med(s[:, :, 31] - s[:, :, 2 + 2 * steps]):9.0f}")
         print(f"  lifetime                       : {med(s[:, :, 31] - s[:, :, 0]):9.0f}")
     # launch cadence: start times of consecutive blocks on the same slot are unknown; print the distribution of starts
+    dt, dr = (st[:, 0, 36] - st[:, 0, 34]).astype(np.float64), (st[:, 0, 37] - st[:, 0, 35]).astype(np.float64)
+    ok = dr > 0
+    if ok.any():
+        print(f"shader clock over a workgroup's life (s_memtime / s_memrealtime x 100 MHz), median over workgroups: "
+              f"{float(np.median(dt[ok] / dr[ok]) * 100):.0f} MHz; life {float(np.median(dr[ok]) / 100):.1f} us, {float(np.median(dt[ok])):.0f} cycles")
     print("SIMD of wavefronts 0 .. (first blocks):", [[int(x) - 1 for x in st[b, :, 33]] for b in range(0, min(n_blocks, 3))])
     starts = np.sort(st[:, 0, 0] - t0)
     print("block start percentiles (cycles):", [int(np.percentile(starts, p)) for p in (0, 10, 25, 50, 75, 90, 100)])
