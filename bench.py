@@ -220,10 +220,10 @@ def measure_pipeline(method, batch_size, flavour, dev, rank, epochs=3, batches_p
     # untimed: eager bootstrap, then epochs until every bucket of the loader's ladder has been captured (a capture costs
     # ~0.3 s; a training run pays it once per bucket in its first epoch or two)
     seen = -1
-    for _ in range(6):
+    for _ in range(12):
         for b, nxt in with_next(loader):
             tr.step(b, nxt)
-        if len(tr.slots) == seen:
+        if len(tr.slots) == seen and not tr.calibrating:     # (and the trainer has chosen its form of the index build)
             break
         seen = len(tr.slots)
     torch.cuda.synchronize(dev)
