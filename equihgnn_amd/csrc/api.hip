@@ -239,6 +239,29 @@ __global__ void eqh_k_clock_probe(unsigned long long* out, unsigned long long sp
 }
 }  // namespace
 
+// Events for ordering two streams of ONE device (the trainer's index-prefetch stream and the step's): no timing and no
+// system-scope fence -- a default event's release writes the L2 back and invalidates it when it is recorded, at the head of
+// every training step in this use.
+extern "C" int eqh_event_create(void** event) {
+    if (!event) return EQH_ERR_ARG;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return EQH_ERR_ARG;
+    *event = e;
+    return EQH_OK;
+}
+extern "C" int eqh_event_record(void* event, void* stream_) {
+    if (!event) return EQH_ERR_ARG;
+    return hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream_)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
+extern "C" int eqh_event_wait(void* event, void* stream_) {
+    if (!event) return EQH_ERR_ARG;
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream_), static_cast<hipEvent_t>(event), 0) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
+extern "C" int eqh_event_destroy(void* event) {
+    if (!event) return EQH_OK;
+    return hipEventDestroy(static_cast<hipEvent_t>(event)) == hipSuccess ? EQH_OK : EQH_ERR_ARG;
+}
+
 extern "C" int eqh_clock_probe(void* out, int32_t spin_us, void* stream_) {
     if (!out || spin_us < 1 || spin_us > 10000) return EQH_ERR_ARG;
     int64_t khz = 100000;

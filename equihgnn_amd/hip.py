@@ -230,6 +230,10 @@ SIGNATURES = {
     "eqh_clock_probe": (c_int32, [c_void_p, c_int32, c_void_p]),
     "eqh_signal_post": (c_int32, [c_void_p, c_void_p]),
     "eqh_signal_wait": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "eqh_event_create": (c_int32, [ctypes.POINTER(c_void_p)]),
+    "eqh_event_record": (c_int32, [c_void_p, c_void_p]),
+    "eqh_event_wait": (c_int32, [c_void_p, c_void_p]),
+    "eqh_event_destroy": (c_int32, [c_void_p]),
     "eqh_defer_begin": (c_int32, [c_void_p]),
     "eqh_defer_flush": (c_int32, [c_void_p]),
     "hg_wgrad_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),

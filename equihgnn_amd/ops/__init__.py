@@ -26,7 +26,7 @@ import sys as _sys
 import types as _types
 
 from ._base import (  # noqa: F401
-    _c_void_p, _ptr, _stream, _require_gpu, _f32c, Timeline, TIMELINE, timed, StepSignal, SIGNAL, signal_point, _row_view, _as2d, _contiguous_run,
+    _c_void_p, _ptr, _stream, _require_gpu, _f32c, Timeline, TIMELINE, timed, StepSignal, StreamEvent, SIGNAL, signal_point, _row_view, _as2d, _contiguous_run,
     _stacked_view, _rows_ld, _DEFER, _workspace, _acc_target, _hand_out, _note_acc, LINEAR_PARAMS, ACC_PARAMS,
 )
 from .aggregate import (  # noqa: F401

@@ -658,10 +658,15 @@ class GraphedTrainStep:
         nf = flat.numel() // 4 * 4
         dsts = [as_words(t).reshape(-1) for t in dsts] + [flat[:nf].view(torch.float32)]
         srcs = [as_words(t).reshape(-1) for t in srcs] + [staged._flat[:nf].view(torch.float32)]
-        free = torch.cuda.Event()
+        # (ops.StreamEvent: no system-scope fence -- a torch.cuda.Event recorded at the head of every step writes the L2 back and
+        # invalidates it; EQH_TORCH_EVENTS=1 restores those for A/B runs)
+        import os
+        light = not os.environ.get("EQH_TORCH_EVENTS")
+        free = ops.StreamEvent() if light else torch.cuda.Event()
         free.record(torch.cuda.current_stream())
+        ready = ops.StreamEvent() if light else None
         return {"staged": staged, "g_index": g_index, "ix_staged": ix_staged, "live": live, "dsts": dsts, "srcs": srcs,
-                "stream": stream, "free": free, "ready": None, "holds": None}
+                "stream": stream, "free": free, "ready": None, "ready_ev": ready, "holds": None, "light": light}
 
     @property
     def index_prefetch(self) -> bool:
@@ -744,7 +749,10 @@ class GraphedTrainStep:
         reached its signal point."""
         st = pf["staged"]
         with torch.cuda.stream(pf["stream"]):
-            pf["stream"].wait_event(pf["free"])
+            if pf["light"]:
+                pf["free"].wait(pf["stream"])
+            else:
+                pf["stream"].wait_event(pf["free"])
             if after_signal is not None:
                 self._signal.wait(after_signal)
             lay = getattr(data, "_layout", None)
@@ -756,18 +764,27 @@ class GraphedTrainStep:
                     if torch.is_tensor(v):
                         getattr(st, f).copy_(v, non_blocking=True)
             pf["g_index"].replay()
-            ready = torch.cuda.Event()
-            ready.record(pf["stream"])
+            if pf["light"]:
+                ready = pf["ready_ev"]
+                ready.record(pf["stream"])
+            else:
+                ready = torch.cuda.Event()
+                ready.record(pf["stream"])
         pf["ready"], pf["holds"] = ready, self._token(data)
 
     def _refresh(self, pf):
         """Head of a step: staged -> live (index tensors and the batch itself) in one launch on the step's stream."""
         from . import ops
         cur = torch.cuda.current_stream()
-        cur.wait_event(pf["ready"])
-        ops.copy_many(pf["dsts"], pf["srcs"])
-        pf["free"] = torch.cuda.Event()
-        pf["free"].record(cur)
+        if pf["light"]:
+            pf["ready"].wait(cur)
+            ops.copy_many(pf["dsts"], pf["srcs"])
+            pf["free"].record(cur)
+        else:
+            cur.wait_event(pf["ready"])
+            ops.copy_many(pf["dsts"], pf["srcs"])
+            pf["free"] = torch.cuda.Event()
+            pf["free"].record(cur)
 
     def step(self, data, next_data=None) -> torch.Tensor:
         """One training step on ``data``.  ``next_data``: the batch of the NEXT call, if the caller has it (a loader with one

@@ -292,6 +292,13 @@ int eqh_clock_probe(void* out, int32_t spin_us, void* stream);
  * microseconds, whichever comes first -- it never outlives its timeout. */
 int eqh_signal_post(int32_t* counter, void* stream);
 int eqh_signal_wait(const int32_t* counter, int32_t target, int32_t timeout_us, void* stream);
+/* Events that order two streams of one device and nothing else (hipEventDisableTiming | hipEventDisableSystemFence: recording
+ * one does not write back / invalidate the L2, which a default event does -- at the head of every training step in the trainer's
+ * index prefetch).  eqh_event_wait makes `stream` wait for the event's latest record.  Not for host synchronisation. */
+int eqh_event_create(void** event);
+int eqh_event_record(void* event, void* stream);
+int eqh_event_wait(void* event, void* stream);
+int eqh_event_destroy(void* event);
 
 /* ---------------------------------------------------------------------------------------------
  * Incidence CSR.  Replaces the implicit "unsorted int64 index" contract of
