@@ -679,7 +679,7 @@ def test_second_trainer_on_the_same_model_trains_every_parameter():
     assert len(moved) == n_live
 
 
-def _two_rank_worker(rank, world, port, out_dir, refuse_on=None):
+def _two_rank_worker(rank, world, port, out_dir, refuse_on=None, n_steps=5):
     import os
     import torch.distributed as dist
     from equihgnn_amd.batch import bucket_sizes, pad_batch, synth_batch
@@ -710,9 +710,9 @@ def _two_rank_worker(rank, world, port, out_dir, refuse_on=None):
             if rank == refuse_on:
                 raise RuntimeError("stand-in: collective not capturable on this rank")
         tr._captured_all_reduce = stand_in
-    losses = [float(tr.step(batches[i % 3])) for i in range(5)]
+    losses = [float(tr.step(batches[i % 3], batches[(i + 1) % 3])) for i in range(n_steps)]
     torch.save({"sd": {k: v.cpu() for k, v in m.state_dict().items()}, "losses": losses,
-                "mode": tr.collective_mode, "capture_error": tr.capture_error},
+                "mode": tr.collective_mode, "capture_error": tr.capture_error, "calibration": tr.calibration},
                os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -735,6 +735,27 @@ def test_graphed_step_two_ranks_stay_in_sync(tmp_path):
     for k in r0["sd"]:                            # ... identical parameters
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     assert all(np.isfinite(r0["losses"]))
+
+
+def test_two_ranks_stay_in_sync_through_the_calibration_of_the_index_form(tmp_path):
+    """The trainer's two timed windows (GraphedTrainStep._calibrate) re-capture the step in the middle of training; with two
+    ranks (gloo, split form: an eager all-reduce between two graphs) every rank does so at the same step, may keep a different
+    form, and the parameters stay identical."""
+    import socket
+
+    import torch.multiprocessing as mp
+    from equihgnn_amd.trainer import GraphedTrainStep
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    n = 2 * (2 + GraphedTrainStep.CAL_WARM + GraphedTrainStep.CAL_STEPS) + 4
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), None, n), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert r0["calibration"] is not None and r1["calibration"] is not None
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    assert all(np.isfinite(r0["losses"])) and len(r0["losses"]) == n
 
 
 @pytest.mark.parametrize("method", ["egnn_equihnns", "mhnnm", "equiformer_equihnns", "faformer_equihnns"])

@@ -59,6 +59,26 @@ def _worker(rank, port, out_path):
             assert losses == finals["local"][1], (method, label, losses, finals["local"][1])
             for k, v in sd.items():
                 assert torch.equal(v, finals["local"][0][k]), (method, label, k)
+    # the trainer's calibration of the index form (two captures of the step, the second one in the middle of training) with the
+    # collective INSIDE the graphs: the same steps as the rank-local trainer pinned to the in-step form
+    n_long = 2 * (2 + GraphedTrainStep.CAL_WARM + GraphedTrainStep.CAL_STEPS) + 5
+    finals = {}
+    for label, kw in (("local", dict(collective=False)), ("in_graph", dict(force_collective=True))):
+        m = MODELS["egnn_equihnns"](1, default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32))
+        fill_state_dict(m, 5)
+        m.to(dev).train()
+        tr = GraphedTrainStep(m, lr=1e-3, **kw)
+        if label == "local":
+            tr.index_prefetch = False
+        losses = [float(tr.step(batches[i % 3], batches[(i + 1) % 3])) for i in range(n_long)]
+        torch.cuda.synchronize()
+        finals[label] = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, losses)
+        if label == "in_graph":
+            report["calibration"] = {"mode": tr.collective_mode, "calibration": tr.calibration, "calibrating": tr.calibrating}
+        tr.close()
+    assert finals["in_graph"][1] == finals["local"][1]
+    for k, v in finals["in_graph"][0].items():
+        assert torch.equal(v, finals["local"][0][k]), ("calibration", k)
     # an error that is NOT a refused collective (a kernel's argument check, a bug) must surface, not turn into "split"
     m = MODELS["egnn_equihnns"](1, default_args(method="egnn_equihnns", MLP_hidden=64, output_hidden=32))
     fill_state_dict(m, 5)
@@ -107,4 +127,6 @@ def test_graphed_step_through_a_one_rank_rccl_group(tmp_path):
         rf = rep[f"{method}/refused"]
         assert rf["mode"] == "split" and "not capturable" in rf["capture_error"] and all(rf["graphs"]), rf
     assert rep["kernel_error"].startswith("raised"), rep["kernel_error"]
+    cal = rep["calibration"]
+    assert not cal["calibrating"] and cal["calibration"]["chosen"] in ("built_ahead", "in_step"), cal
     assert rep["mhnnm/in_graph"]["flat_buffers"] >= 1          # one broadcast per dtype, not one per buffer
