@@ -207,6 +207,43 @@ __device__ __forceinline__ void panel_mma(const uint4* __restrict__ img, WStream
 }
 
 // accumulators (C^T layout: lane (fh, fr) holds row fr, columns 8 g + 4 fh .. + 3 of its tiles) -> the fp32 staging tile
+// Product G of a SUM of products over different A images (k_panel_sum): K steps [G KS, (G + 1) KS) of the weight stream, which
+// runs on across the products as in panel_mma, against the image of product G; every product adds into the same accumulators.
+template <int KS, int NTW, int NG, int NW, int G>
+__device__ __forceinline__ void panel_mma_part(const uint4* __restrict__ img, WStream<KS, NTW, NG, NW>& ws, f32x16 (&acc)[1][NTW], int lane) {
+    const int fh = lane >> 5, fr = lane & 31;
+    uint4 af[2][3];
+    auto a_read = [&](int ks) {
+        const uint4* ap = img + a_slot<KS>(ks, fh, fr);
+        af[ks & 1][0] = ap[0];
+        af[ks & 1][1] = ap[KS * 64];
+        af[ks & 1][2] = ap[KS * 128];
+    };
+    a_read(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kk = G * KS + ks, slot = kk % PN_PF;
+        if (ks + 1 < KS) a_read(ks + 1);
+        const bf16x8 a0 = __builtin_bit_cast(bf16x8, af[ks & 1][0]);
+        const bf16x8 a1 = __builtin_bit_cast(bf16x8, af[ks & 1][1]);
+        const bf16x8 a2 = __builtin_bit_cast(bf16x8, af[ks & 1][2]);
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const bf16x8 b0 = __builtin_bit_cast(bf16x8, ws.q[slot][j][0]);
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, ws.q[slot][j][1]);
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, ws.q[slot][j][2]);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a0, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a2, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][j], 0, 0, 0);
+        }
+        if (kk + PN_PF < KS * NG) ws.fetch(slot, kk + PN_PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int NTW, int NW, int LD = PN_STG_LD>
 __device__ __forceinline__ void acc_to_staging(float* __restrict__ stg, const f32x16 (&acc)[NTW], int wave, int lane, int n_tiles = 1 << 30) {
     const int fh = lane >> 5, fr = lane & 31;
@@ -1606,6 +1643,105 @@ extern "C" int hg_conv_panel(int32_t stage, const HgConvPanel* q, void* stream_)
     }
 #undef PN_LAUNCH
 #undef PN_LAUNCH_W
+}
+
+// ---- a SUM of products over different row blocks of the same rows: out = sum_g A_g W_g + D, g < NG <= 3 -------------------------
+// (MHNNConv's input gradients, autograd of conv.py:87-101 with every first Linear split by input block: dX = dpre_v W4a_X +
+// dpa3 W3a_x + dpa1 W1a_x, dE = dpre_e W2a_E + dqb1 W1a_e -- three / two single-product launches chained through their addend
+// until round 6; at 19-148 panels a launch is its ~7 us slot, not its work.)  Two A images take turns: image g + 1 is built while
+// product g runs; the weight stream runs on across the products.
+struct PanelSum {
+    const float* A[3];
+    int64_t lda[3];
+    int rows;
+    const uint4* W[3];
+    const float* D;
+    int64_t ldd;
+    float* out;
+    int64_t ldo;
+};
+
+template <int C, int NW, int NG>
+PN_KERNEL(NW) k_panel_sum(const PanelSum p) {
+    using S = PnShape<C, NW>;
+    __shared__ uint4 s_img[2][3 * S::KS * 64];
+    __shared__ float s_stg[PN_ROWS * PN_STG_LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RtPos<NW> P((int)blockIdx.x * PN_ROWS, p.rows, wave, lane);
+    const bool mul = wave < S::NT;
+    RowTile<C, NW> x;
+    rt_load<C, NW>(x, p.A[0], p.lda[0], P.rowc, P.c4);
+    WStream<S::KS, S::NTW, NG, NW> ws;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) ws.init(g, p.W[g], mul ? wave : 0, lane);
+    ws.prime();
+    __builtin_amdgcn_sched_barrier(0);
+    rt_a_put<C, NW, S::KS>(x, s_img[0], P.lrow, P.c);
+    if (NG > 1) rt_load<C, NW>(x, p.A[1], p.lda[1], P.rowc, P.c4);        // (in flight during product 0)
+    __syncthreads();
+    f32x16 acc[1][S::NTW];
+    acc_zero<1, S::NTW>(acc);
+    if (mul) panel_mma_part<S::KS, S::NTW, NG, NW, 0>(s_img[0], ws, acc, lane);
+    if (NG > 1) {
+        rt_a_put<C, NW, S::KS>(x, s_img[1], P.lrow, P.c);                  // (nobody reads image 1 yet)
+        if (NG > 2) rt_load<C, NW>(x, p.A[2], p.lda[2], P.rowc, P.c4);
+        __syncthreads();                                                   // image 1 complete; image 0 free
+        if (mul) panel_mma_part<S::KS, S::NTW, NG, NW, (NG > 1 ? 1 : 0)>(s_img[1], ws, acc, lane);
+    }
+    if (NG > 2) {
+        rt_a_put<C, NW, S::KS>(x, s_img[0], P.lrow, P.c);
+        __syncthreads();
+        if (mul) panel_mma_part<S::KS, S::NTW, NG, NW, (NG > 2 ? 2 : 0)>(s_img[0], ws, acc, lane);
+    }
+    if (mul) acc_to_staging<S::NTW, NW>(s_stg, acc[0], wave, lane);
+    __syncthreads();
+    RowTile<C, NW> a, d;
+    rt_load<C, NW>(a, s_stg, PN_STG_LD, P.lrow, P.c4);
+    if (p.D) {
+        rt_load<C, NW>(d, p.D, p.ldd, P.rowc, P.c4);
+#pragma unroll
+        for (int j = 0; j < S::NJ; ++j) {
+            a.v[j].x += d.v[j].x; a.v[j].y += d.v[j].y; a.v[j].z += d.v[j].z; a.v[j].w += d.v[j].w;
+        }
+    }
+    if (P.live) rt_store<C, NW>(a, p.out, p.ldo, P.row, P.c4);
+}
+
+extern "C" int hg_panel_sum(const HgPanelSum* q, void* stream_) {
+    if (!q || q->rows < 0 || q->n < 1 || q->n > 3 || !q->out) return EQH_ERR_ARG;
+    const int C = q->C;
+    if (!pn_width_ok(C)) return EQH_ERR_ARG;
+    if (q->rows >= ((int64_t)1 << 31) - 64) return EQH_ERR_RANGE;
+    if (!eqh_aligned16(q->out) || (q->ldo & 3) || !eqh_aligned16(q->d) || (q->d && (q->ldd & 3))) return EQH_ERR_ALIGN;
+    PanelSum p{};
+    p.rows = (int)q->rows; p.D = q->d; p.ldd = q->ldd; p.out = q->out; p.ldo = q->ldo;
+    for (int g = 0; g < q->n; ++g) {
+        if (!q->a[g] || !q->w[g]) return EQH_ERR_ARG;
+        if (!eqh_aligned16(q->a[g]) || (q->lda[g] & 3) || !eqh_aligned16(q->w[g])) return EQH_ERR_ALIGN;
+        p.A[g] = q->a[g]; p.lda[g] = q->lda[g]; p.W[g] = static_cast<const uint4*>(q->w[g]);
+    }
+    if (q->rows == 0) return EQH_OK;
+    const int nw = pn_waves();
+    const dim3 grid((unsigned)((q->rows + PN_ROWS - 1) / PN_ROWS)), block(64 * nw);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+#define PN_SUM_C(NW_, NG_)                                                                                     \
+    do {                                                                                                       \
+        if (C == 256) hipLaunchKernelGGL((k_panel_sum<256, NW_, NG_>), grid, block, 0, stream, p);             \
+        else if (C == 128) hipLaunchKernelGGL((k_panel_sum<128, NW_, NG_>), grid, block, 0, stream, p);        \
+        else hipLaunchKernelGGL((k_panel_sum<64, NW_, NG_>), grid, block, 0, stream, p);                       \
+    } while (0)
+#define PN_SUM(NG_)                                                                                            \
+    do {                                                                                                       \
+        if (nw == 8) PN_SUM_C(8, NG_);                                                                         \
+        else PN_SUM_C(4, NG_);                                                                                 \
+    } while (0)
+    if (q->n == 1) PN_SUM(1);
+    else if (q->n == 2) PN_SUM(2);
+    else PN_SUM(3);
+#undef PN_SUM
+#undef PN_SUM_C
+    EQH_CHECK_LAUNCH();
+    return EQH_OK;
 }
 
 extern "C" int hg_panel_multi(const HgPanelMulti* q, void* stream_) {

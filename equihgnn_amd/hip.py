@@ -54,6 +54,12 @@ class HgPanelMulti(ctypes.Structure):
                 ("ldo", c_int64 * 3)]
 
 
+class HgPanelSum(ctypes.Structure):
+    """HgPanelSum of include/equihgnn_hip.h (a sum of up to three products over different row blocks)."""
+    _fields_ = [("a", c_void_p * 3), ("lda", c_int64 * 3), ("rows", c_int64), ("C", c_int32), ("n", c_int32), ("w", c_void_p * 3),
+                ("d", c_void_p), ("ldd", c_int64), ("out", c_void_p), ("ldo", c_int64)]
+
+
 class HbCollate(ctypes.Structure):
     """HbCollate of include/equihgnn_hip.h (operands of hb_collate, the host-side batch assembly)."""
     _fields_ = ([("B", c_int64), ("n_mols", c_int64)]
@@ -71,6 +77,7 @@ SIGNATURES = {
     "hg_conv_panel": (c_int32, [c_int32, ctypes.POINTER(HgConvPanel), c_void_p]),
     "hg_panel_waves": (c_int32, []),
     "hg_panel_multi": (c_int32, [ctypes.POINTER(HgPanelMulti), c_void_p]),
+    "hg_panel_sum": (c_int32, [ctypes.POINTER(HgPanelSum), c_void_p]),
     "hb_collate": (c_int32, [ctypes.POINTER(HbCollate)]),
     "hg_panel_pack_bytes": (c_size_t, [c_int32, c_int32]),
     "hg_panel_pack": (c_int32, [c_int32, ctypes.POINTER(HgPanelPack), c_void_p]),

@@ -55,7 +55,7 @@ from .conv_stack import (  # noqa: F401
     conv_stack_supported, merged_conv_stack, _MergedConvStack,
 )
 from . import conv_stack  # noqa: F401
-from .mhnn_panel import (mhnn_conv_panel, mhnn_panel_supported, panel_multi, merged_scope)  # noqa: F401
+from .mhnn_panel import (mhnn_conv_panel, mhnn_panel_supported, panel_multi, panel_sum, merged_scope)  # noqa: F401
 from . import mhnn_panel  # noqa: F401
 from .rows import (  # noqa: F401
     _IncidenceLnReduce, _BiasReluLn, _LinearAddReluLn, linear_add_relu_ln, _GatherLnReduce, gather_ln_reduce,

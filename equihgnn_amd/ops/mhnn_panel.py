@@ -53,6 +53,25 @@ def panel_multi(a, C, items, rows=None):
     hip.check(hip.lib().hg_panel_multi(ctypes.byref(q), _stream(a.device)), "hg_panel_multi")
 
 
+PANEL_SUM = not os.environ.get("EQH_NO_PANEL_SUM")      # (off: the chained single-product launches of rounds 4-5, for A/B runs)
+
+
+def panel_sum(items, C, out, d=None, rows=None):
+    """out = sum_g a_g @ B_g + d for up to three (a_g [rows, C], packed [C x C] image) pairs over the same rows, one launch
+    (hg_panel_sum)."""
+    q = hip.HgPanelSum()
+    keep = []
+    for g, (a, img) in enumerate(items):
+        a = _f32c(a)
+        keep.append(a)
+        q.a[g], q.lda[g], q.w[g] = a.data_ptr(), a.stride(0), img.data_ptr()
+    q.rows, q.C, q.n = (keep[0].shape[0] if rows is None else rows), C, len(items)
+    q.d, q.ldd = (d.data_ptr(), d.stride(0)) if d is not None else (None, 0)
+    q.out, q.ldo = out.data_ptr(), out.stride(0)
+    hip.check(hip.lib().hg_panel_sum(ctypes.byref(q), _stream(out.device)), "hg_panel_sum")
+    return out
+
+
 def mhnn_panel_supported(X, E, conv) -> bool:
     ws = (conv.W1, conv.W2, conv.W3, conv.W4)
     if not USE_MHNN_PANEL or any(w is None for w in ws):
@@ -201,12 +220,18 @@ class _MHNNConvPanel(torch.autograd.Function):
         # ---- input gradients: dE = dpre_e W2a_E + dqb1 W1a_e;  dX = dpre_v W4a_X + dpa3 W3a_x + dpa1 W1a_x ---------------------------
         need = ctx.needs_input_grad
         dE = dX = None
-        if need[1]:
+        if need[1] and PANEL_SUM:        # one launch per sum (round 6): at these row counts a launch is its slot, not its work
+            dE = new(M)
+            timed("k_panel_sum", flops(M, 2), lambda: panel_sum([(dpre_e, iW2e_n), (dqb1, iW1e_n)], C, dE))
+        elif need[1]:
             t = new(M)
             dE = new(M)
             timed("k_panel_multi", flops(M, 1), lambda: panel_multi(dpre_e, C, [(iW2e_n, None, None, None, t)]))
             timed("k_panel_multi", flops(M, 1), lambda: panel_multi(dqb1, C, [(iW1e_n, None, None, t, dE)]))
-        if need[0]:
+        if need[0] and PANEL_SUM:
+            dX = new(N)
+            timed("k_panel_sum", flops(N, 3), lambda: panel_sum([(dpre_v, iW4x_n), (dpa3, iW3x_n), (dpa1, iW1x_n)], C, dX))
+        elif need[0]:
             t1, t2 = new(N), new(N)
             dX = new(N)
             timed("k_panel_multi", flops(N, 1), lambda: panel_multi(dpre_v, C, [(iW4x_n, None, None, None, t1)]))

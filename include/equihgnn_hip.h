@@ -246,6 +246,22 @@ typedef struct {
     int64_t ldo[3];
 } HgPanelMulti;
 int hg_panel_multi(const HgPanelMulti* args, void* stream);
+/* A SUM of up to three products over different row blocks of the same rows, one launch: out = sum_g a[g] W_g + d (d may be
+ * NULL; out may alias d).  MHNNConv's input gradients (autograd of conv.py:87-101): dX = dpre_v W4a_X + dpa3 W3a_x + dpa1 W1a_x
+ * and dE = dpre_e W2a_E + dqb1 W1a_e -- the dY W products of `F.linear`'s backward summed by autograd's AccumulateGrad in the
+ * reference.  w[g]: images of hg_panel_pack. */
+typedef struct {
+    const float* a[3];
+    int64_t lda[3];
+    int64_t rows;
+    int32_t C, n;
+    const void* w[3];
+    const float* d;
+    int64_t ldd;
+    float* out;
+    int64_t ldo;
+} HgPanelSum;
+int hg_panel_sum(const HgPanelSum* args, void* stream);
 /* wavefronts per panel workgroup the library launches (8; 4 with EQH_PANEL_WAVES=4 in the environment: round 4's geometry,
  * kept for same-box A/B measurements) */
 int32_t hg_panel_waves(void);

@@ -2045,6 +2045,34 @@ def test_panel_gemm_matches_float64(C, rows):
     assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("rows,n", [(1, 2), (33, 3), (600, 3), (4736, 2), (4800, 3), (97, 1)])
+def test_panel_sum_matches_float64(C, rows, n):
+    """hg_panel_sum: out = sum_g a_g W_g (+ d) over different row blocks of the same rows in ONE launch (MHNNConv's input
+    gradients, autograd of conv.py:87-101) against float64; strided operands (column blocks of wider tensors); out aliasing d."""
+    from equihgnn_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(rows * 11 + C + n)
+    wide = torch.randn(rows, n * C + 4, device=DEV, generator=g)
+    a = [wide[:, i * C:(i + 1) * C] for i in range(n)]                       # row stride n C + 4
+    w = [torch.randn(C, C, device=DEV, generator=g) * C ** -0.5 for _ in range(n)]
+    imgs = ops.panel_pack([(wi, False) for wi in w])                          # dY W: not transposed
+    d = torch.randn(rows, C, device=DEV, generator=g)
+    want = sum(ai.double() @ wi.double() for ai, wi in zip(a, w))
+    scale = sum(ai.abs().double() @ wi.abs().double() for ai, wi in zip(a, w))
+    lib = sum(ai @ wi for ai, wi in zip(a, w))
+    out = torch.empty(rows, C, device=DEV)
+    ops.panel_sum(list(zip(a, imgs)), C, out)
+    err = ((out.double() - want).abs() / scale).max().item()
+    rms = ((out.double() - want) / scale).pow(2).mean().sqrt().item()
+    rms_lib = ((lib.double() - want) / scale).pow(2).mean().sqrt().item()
+    # (the acceptance rule of the x6 family, as for hg_gemm_x6_batch: root-mean-square error no worse than the fp32 library
+    # products', the largest one within a few fp32 roundings of the sum of |a||w|)
+    assert err < 4e-7 and rms <= max(1.05 * rms_lib, 6e-8), (err, rms, rms_lib)
+    acc = d.clone()
+    ops.panel_sum(list(zip(a, imgs)), C, acc, d=acc)                          # in place on the addend
+    assert torch.allclose(acc.double(), want + d.double(), rtol=1e-5, atol=1e-5)
+
+
 def test_panel_pack_stacks_weights_along_k():
     """Two weights stacked along K in one image = the product of the concatenated operand (the [dh1 | dpa] . [W1a ; W2v]
     input gradient of conv.py:172-176)."""
