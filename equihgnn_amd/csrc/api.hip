@@ -239,6 +239,15 @@ __global__ void eqh_k_clock_probe(unsigned long long* out, unsigned long long sp
 }
 }  // namespace
 
+// dst[0 .. n) += src[0 .. n): a gradient computed into a fresh tensor handed to the parameter's persistent accumulator.  Inside a
+// deferral window (eqh_defer_begin .. eqh_defer_flush on this stream) it rides the step's one batched reduction launch
+// (a slab reduction over ONE slab); outside it is its own launch.  src must stay alive until the flush.
+extern "C" int eqh_accumulate(const float* src, float* dst, int64_t n, void* stream_) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return EQH_ERR_ARG;
+    if (n == 0) return EQH_OK;
+    return eqh_reduce_slabs_async(src, 1, n, dst, static_cast<hipStream_t>(stream_), 1);
+}
+
 // Events for ordering two streams of ONE device (the trainer's index-prefetch stream and the step's): no timing and no
 // system-scope fence -- a default event's release writes the L2 back and invalidates it when it is recorded, at the head of
 // every training step in this use.

@@ -237,6 +237,7 @@ SIGNATURES = {
     "eqh_clock_probe": (c_int32, [c_void_p, c_int32, c_void_p]),
     "eqh_signal_post": (c_int32, [c_void_p, c_void_p]),
     "eqh_signal_wait": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "eqh_accumulate": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "eqh_event_create": (c_int32, [ctypes.POINTER(c_void_p)]),
     "eqh_event_record": (c_int32, [c_void_p, c_void_p]),
     "eqh_event_wait": (c_int32, [c_void_p, c_void_p]),

@@ -308,6 +308,10 @@ int eqh_clock_probe(void* out, int32_t spin_us, void* stream);
  * microseconds, whichever comes first -- it never outlives its timeout. */
 int eqh_signal_post(int32_t* counter, void* stream);
 int eqh_signal_wait(const int32_t* counter, int32_t target, int32_t timeout_us, void* stream);
+/* dst[0 .. n) += src[0 .. n) (fp32).  Between eqh_defer_begin and eqh_defer_flush on `stream` the addition is recorded and runs
+ * in the flush's one batched launch (src must stay alive until then), otherwise at once.  The reference's counterpart is
+ * autograd's AccumulateGrad (`p.grad += g`) for the 1-D parameters of its normalisation layers. */
+int eqh_accumulate(const float* src, float* dst, int64_t n, void* stream);
 /* Events that order two streams of one device and nothing else (hipEventDisableTiming | hipEventDisableSystemFence: recording
  * one does not write back / invalidate the L2, which a default event does -- at the head of every training step in the trainer's
  * index prefetch).  eqh_event_wait makes `stream` wait for the event's latest record.  Not for host synchronisation. */
