@@ -162,3 +162,91 @@ def test_with_next_pairs_every_batch_with_its_successor():
     assert list(with_next([1, 2, 3])) == [(1, 2), (2, 3), (3, None)]
     assert list(with_next(iter([7]))) == [(7, None)]
     assert list(with_next([])) == []
+
+
+class _FakeClock:
+    """Stands in for the device and the wall clock while GraphedTrainStep._calibrate is driven on the CPU: every step of the
+    form that is 'running' costs a fixed number of milliseconds."""
+
+    def __init__(self, cost):
+        self.cost, self.now, self.form = cost, 0.0, "built_ahead"
+
+    def step(self):
+        self.now += self.cost[self.form] * 1e-3
+
+
+def _calibration_stub(monkeypatch, cost):
+    import time
+    import types
+
+    from equihgnn_amd.trainer import GraphedTrainStep
+    clock = _FakeClock(cost)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(time, "perf_counter", lambda: clock.now)
+    tr = GraphedTrainStep.__new__(GraphedTrainStep)
+    tr.prefetch_policy, tr._prefetch_on, tr._cal, tr._alt_slots, tr.calibration = "auto", True, None, None, None
+    tr.slots = {}
+
+    def step(self, key="bucket"):
+        """What GraphedTrainStep.step does around the calibration: the hook, a capture when the bucket has no graph, one step."""
+        if self.prefetch_policy == "auto" and self.calibration is None:
+            self._calibrate(key)
+        if key not in self.slots:
+            self.slots[key] = {"form": "built_ahead" if self._prefetch_on else "in_step"}
+        clock.form = self.slots[key]["form"]
+        clock.step()
+    tr.step = types.MethodType(step, tr)
+    return tr, clock
+
+
+@pytest.mark.parametrize("cost,chosen", [({"built_ahead": 1.00, "in_step": 1.10}, "built_ahead"),
+                                         ({"built_ahead": 1.10, "in_step": 1.00}, "in_step"),
+                                         ({"built_ahead": 1.000, "in_step": 1.005}, "in_step")])      # inside the 1 % margin
+def test_calibration_times_a_window_of_each_form_and_keeps_the_faster(monkeypatch, cost, chosen):
+    """GraphedTrainStep._calibrate (host logic, no GPU): capture + CAL_WARM replays + CAL_STEPS timed steps built ahead, the same
+    in the step graph (the first form's graphs kept aside), then the decision -- the built-ahead form has to win by 1 %."""
+    from equihgnn_amd.trainer import GraphedTrainStep
+    tr, clock = _calibration_stub(monkeypatch, cost)
+    per_form = 1 + GraphedTrainStep.CAL_WARM + GraphedTrainStep.CAL_STEPS
+    forms = []
+    for i in range(2 * per_form + 3):
+        tr.step()
+        forms.append(clock.form)
+        assert tr.calibrating == (i < 2 * per_form)
+    assert forms[:per_form] == ["built_ahead"] * per_form and forms[per_form:2 * per_form] == ["in_step"] * per_form
+    assert forms[2 * per_form:] == [chosen] * 3
+    cal = tr.calibration
+    assert cal["chosen"] == chosen and tr.index_prefetch == (chosen == "built_ahead") and tr._alt_slots is None
+    assert cal["built_ahead_ms"] == pytest.approx(cost["built_ahead"], rel=1e-6) and cal["in_step_ms"] == pytest.approx(cost["in_step"], rel=1e-6)
+    assert tr.slots["bucket"]["form"] == chosen
+
+
+def test_calibration_restarts_its_window_when_the_bucket_changes_and_gives_up_when_buckets_keep_alternating(monkeypatch):
+    from equihgnn_amd.trainer import GraphedTrainStep
+    tr, clock = _calibration_stub(monkeypatch, {"built_ahead": 1.0, "in_step": 1.2})
+    for _ in range(5):
+        tr.step("a")
+    tr.step("b")                                   # another bucket: the window starts again on it
+    assert tr._cal["key"] == "b" and tr._cal["n"] == 0 and tr.calibrating
+    per_form = 1 + GraphedTrainStep.CAL_WARM + GraphedTrainStep.CAL_STEPS
+    for _ in range(2 * per_form + 1):
+        tr.step("b")
+    assert not tr.calibrating and tr.calibration["chosen"] == "built_ahead"
+    # buckets that alternate faster than a window: after 16 restarts the running form stays, undecided windows are dropped
+    tr2, _ = _calibration_stub(monkeypatch, {"built_ahead": 1.0, "in_step": 1.2})
+    for i in range(60):
+        tr2.step("ab"[i % 2])
+        if not tr2.calibrating:
+            break
+    assert not tr2.calibrating and tr2.calibration["built_ahead_ms"] is None and tr2.calibration["chosen"] == "built_ahead"
+
+
+def test_assigning_index_prefetch_pins_the_form():
+    from equihgnn_amd.trainer import GraphedTrainStep
+    tr = GraphedTrainStep.__new__(GraphedTrainStep)
+    tr.prefetch_policy, tr._prefetch_on, tr._cal, tr._alt_slots, tr.calibration = "auto", True, {"form": "built_ahead"}, None, None
+    assert tr.calibrating
+    tr.index_prefetch = False
+    assert not tr.calibrating and tr.prefetch_policy == "off" and tr._cal is None and not tr.index_prefetch
+    tr.index_prefetch = True
+    assert tr.prefetch_policy == "on" and tr.index_prefetch and not tr.calibrating
