@@ -2311,3 +2311,55 @@ def test_egnn_node_panel_stages_match_float64(C, n_nodes):
     out64.backward(d(dout))
     assert torch.allclose(d(dpre), hpre64.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(d(dnode_in), x64.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_accumulate_adds_at_once_or_inside_the_deferred_batch():
+    """eqh_accumulate: dst += src, either as its own launch or -- between eqh_defer_begin and eqh_defer_flush -- as a one-slab
+    entry of the flush's batched reduction (what ops._hand_out gives a parameter's persistent accumulator: the reference's
+    AccumulateGrad for the 1-D parameters of its normalisation layers)."""
+    from equihgnn_amd import hip, ops
+    from equihgnn_amd.ops._base import _hand_out
+    g = torch.Generator(device=DEV).manual_seed(3)
+    for n in (1, 7, 256, 1000):
+        src = torch.randn(n, device=DEV, generator=g)
+        dst = torch.randn(n, device=DEV, generator=g)
+        want = dst + src
+        hip.check(hip.lib().eqh_accumulate(ops._ptr(src), ops._ptr(dst), n, ops._stream(DEV)), "eqh_accumulate")
+        assert torch.equal(dst, want)
+    # inside a deferral window nothing happens before the flush; two contributions to one accumulator add up in issue order
+    acc = torch.zeros(256, device=DEV)
+    g1, g2 = torch.randn(256, device=DEV, generator=g), torch.randn(256, device=DEV, generator=g)
+    other = torch.randn(2, 256, device=DEV, generator=g)
+    ops.defer_begin(DEV)
+    try:
+        assert _hand_out([g1, other[0]], [acc, None])[0] is None          # owned: accumulated; not owned: handed to autograd
+        assert _hand_out([g2], [acc]) == [None]
+        torch.cuda.synchronize()
+        assert float(acc.abs().max()) == 0.0
+    finally:
+        ops.defer_flush(DEV)
+    torch.cuda.synchronize()
+    assert torch.equal(acc, (torch.zeros(256, device=DEV) + g1) + g2)
+
+
+def test_stream_events_order_two_streams():
+    """eqh_event_* (ops.StreamEvent): a stream that waits for the event sees what the recording stream wrote before it; the
+    event can be recorded again and again."""
+    from equihgnn_amd import ops
+    side = torch.cuda.Stream()
+    ev = ops.StreamEvent()
+    x = torch.zeros(1 << 20, device=DEV)
+    y = torch.empty_like(x)
+    cur = torch.cuda.current_stream()
+    for rep in range(1, 4):
+        ev.record(cur)
+        ev.wait(side)                       # (side may not touch x before the previous copy into y has read it)
+        with torch.cuda.stream(side):
+            for _ in range(20):             # a chain long enough to still be running when the wait is enqueued
+                x.add_(1.0)
+        ev.record(side)
+        ev.wait(cur)
+        y.copy_(x)
+        torch.cuda.synchronize()
+        assert float(y.min()) == float(y.max()) == 20.0 * rep
+    del ev
