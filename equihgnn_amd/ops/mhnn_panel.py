@@ -86,22 +86,32 @@ def mhnn_panel_supported(X, E, conv) -> bool:
     return bool(ok)
 
 
+def _pack_items(C, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, need_grad):
+    """The images of one MHNNConv application, forward ones first (hg_panel_pack items)."""
+    blk = lambda w, half: w[:, :C] if half == 0 else w[:, C:]
+    fwd = [(blk(W1a, 0), True), (blk(W3a, 0), True), (blk(W4a, 0), True), (blk(W1a, 1), True), (blk(W2a, 0), True), (w12, True),
+           (W2b, True), (blk(W3a, 1), True), (w34, True), (W4b, True)]
+    bwd = [(W4b, False), (w34, False), (blk(W3a, 1), False), (W2b, False), (w12, False), (blk(W2a, 0), False),
+           (blk(W1a, 1), False), (blk(W4a, 0), False), (blk(W3a, 0), False), (blk(W1a, 0), False)] if need_grad else []
+    return fwd + bwd
+
+
 class _MHNNConvPanel(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, E, W1a, b1a, g1, be1, W2a, b2a, g2, be2, W2b, b2b, W3a, b3a, g3, be3, W4a, b4a, g4, be4, W4b, b4b,
-                w12, v12, w34, v34, ix, eps):
+                w12, v12, w34, v34, ix, eps, packed=None):
         _require_gpu(X, "mhnn_conv_panel")
         X, E = _f32c(X), _f32c(E)
         N, C = X.shape
         M = E.shape[0]
         dev = X.device
         need_grad = any(ctx.needs_input_grad)
-        blk = lambda w, half: w[:, :C] if half == 0 else w[:, C:]
-        fwd = [(blk(W1a, 0), True), (blk(W3a, 0), True), (blk(W4a, 0), True), (blk(W1a, 1), True), (blk(W2a, 0), True), (w12, True),
-               (W2b, True), (blk(W3a, 1), True), (w34, True), (W4b, True)]
-        bwd = [(W4b, False), (w34, False), (blk(W3a, 1), False), (W2b, False), (w12, False), (blk(W2a, 0), False),
-               (blk(W1a, 1), False), (blk(W4a, 0), False), (blk(W3a, 0), False), (blk(W1a, 0), False)] if need_grad else []
-        imgs = panel_pack(fwd + bwd)
+        # (`packed`: the images of this application, packed with those of the model's other layers in ONE launch by the
+        # merged_scope around them -- with or without the backward ones, as the scope saw fit)
+        if packed is not None and len(packed) >= (20 if need_grad else 10):
+            imgs = packed
+        else:
+            imgs = panel_pack(_pack_items(C, W1a, W2a, W2b, W3a, W4a, W4b, w12, w34, need_grad))
         iW1x, iW3x, iW4x, iW1e, iW2e, iw12, iW2b, iW3e, iw34, iW4b = imgs[:10]
         new = lambda r: torch.empty((r, C), dtype=torch.float32, device=dev)
         flops = lambda rows, n: 2 * rows * C * C * n
@@ -238,7 +248,7 @@ class _MHNNConvPanel(torch.autograd.Function):
             timed("k_panel_multi", flops(N, 1), lambda: panel_multi(dpa3, C, [(iW3x_n, None, None, t1, t2)]))
             timed("k_panel_multi", flops(N, 1), lambda: panel_multi(dpa1, C, [(iW1x_n, None, None, t2, dX)]))
         return (dX, dE, dW.get("W1a"), db1a, dg1, dbe1, dW.get("W2a"), db2a, dg2, dbe2, dW.get("W2b"), db2b, dW.get("W3a"), db3a, dg3,
-                dbe3, dW.get("W4a"), db4a, dg4, dbe4, dW.get("W4b"), db4b, dW.get("w12"), dv12, dW.get("w34"), dv34, None, None)
+                dbe3, dW.get("W4a"), db4a, dg4, dbe4, dW.get("W4b"), db4b, dW.get("w12"), dv12, dW.get("w34"), dv34, None, None, None)
 
 
 def _merged_items(conv, C):
@@ -255,13 +265,15 @@ class merged_scope:
     stack of open scopes), never on the modules, so nested or concurrent scopes over the same conv cannot remove each other's."""
 
     def __init__(self, convs, X, E):
-        seen, self.convs = set(), []
+        seen, self.convs, self.uses = set(), [], {}
         for c in convs:
+            self.uses[id(c)] = self.uses.get(id(c), 0) + 1
             if id(c) not in seen and mhnn_panel_supported(X, E, c):
                 seen.add(id(c))
                 self.convs.append(c)
         self.C = X.shape[-1]
         self.merged = {}
+        self.packed = {}
 
     def __enter__(self):
         from .linears import merged_weights
@@ -269,6 +281,26 @@ class merged_scope:
             items = [it for c in self.convs for it in _merged_items(c, self.C)]
             res = merged_weights(items)
             self.merged = {id(c): (res[2 * k], res[2 * k + 1]) for k, c in enumerate(self.convs)}
+            # ... and the operand images of a conv that is applied SEVERAL times (mhnn.py's shared layer) once per step instead of
+            # once per application: mhnn 1.137 -> 1.105 ms.  Unshared layers keep their own pack launch right in front of their
+            # kernels: packed up front (60 images, 23 MB) the later layers' images have left the L2 by the time they are streamed --
+            # mhnnm 1.150 against 1.122 ms.  (EQH_NO_SCOPE_PACK=1: per application for every conv.)
+            need_grad = torch.is_grad_enabled()
+            lists = []
+            if os.environ.get("EQH_NO_SCOPE_PACK"):
+                self.convs_packed = []
+            else:
+                shared = len(self.convs) == 1          # one conv in the scope: every application inside it uses these images
+                self.convs_packed = [c for c in self.convs if shared or self.uses.get(id(c), 0) > 1]
+            for c in self.convs_packed:
+                (w12, _), (w34, _) = self.merged[id(c)]
+                lists.append(_pack_items(self.C, c.W1.lins[0].weight, c.W2.lins[0].weight, c.W2.lins[1].weight, c.W3.lins[0].weight,
+                                         c.W4.lins[0].weight, c.W4.lins[1].weight, w12, w34, need_grad))
+            imgs = panel_pack([it for lst in lists for it in lst]) if lists else []
+            off = 0
+            for c, lst in zip(self.convs_packed, lists):
+                self.packed[id(c)] = imgs[off:off + len(lst)]
+                off += len(lst)
         _open_scopes().append(self)
         return self
 
@@ -277,6 +309,7 @@ class merged_scope:
         if self in stack:
             stack.remove(self)
         self.merged = {}
+        self.packed = {}
         return False
 
 
@@ -294,6 +327,13 @@ def _merged_in_scope(conv):
         hit = sc.merged.get(id(conv))
         if hit is not None:
             return hit
+    return None
+
+
+def _packed_in_scope(conv):
+    for sc in reversed(_open_scopes()):
+        if id(conv) in sc.merged:
+            return sc.packed.get(id(conv))
     return None
 
 
@@ -315,4 +355,5 @@ def mhnn_conv_panel(conv, X, E, ix):
     return _MHNNConvPanel.apply(X, E, W1.lins[0].weight, W1.lins[0].bias, n1.weight, n1.bias, W2.lins[0].weight, W2.lins[0].bias,
                                 n2.weight, n2.bias, W2.lins[1].weight, W2.lins[1].bias, W3.lins[0].weight, W3.lins[0].bias, n3.weight,
                                 n3.bias, W4.lins[0].weight, W4.lins[0].bias, n4.weight, n4.bias, W4.lins[1].weight, W4.lins[1].bias,
-                                w12, v12, w34, v34, ix, (float(n1.eps), float(n2.eps), float(n3.eps), float(n4.eps)))
+                                w12, v12, w34, v34, ix, (float(n1.eps), float(n2.eps), float(n3.eps), float(n4.eps)),
+                                _packed_in_scope(conv) if pre is not None else None)
